@@ -1,0 +1,204 @@
+/* mathfn.c -- CPU ORACLE (test infrastructure): elementary functions of the arithmetic contract.
+ *
+ * The reference calls tf.tanh / tf.sigmoid / tf.exp / tf.log (wavenet/model.py:86,
+ * wavenet/mixture.py:103-111) and np.log / np.exp / np.logaddexp (generate.py:219-222); their
+ * implementations live in TensorFlow/Eigen/numpy, absent from /root/reference and unpinned.  The
+ * contract (DESIGN.md "AC-2") fixes them as the single-precision rational / Cephes-polynomial forms
+ * Eigen 3.3 ships for CPU [recalled, parity unpinned], evaluated with fused multiply-adds and one
+ * IEEE division, so the same bits come out of gcc here and of the gfx950 kernels.
+ *
+ * Build with -ffp-contract=off: every fusion below is an explicit fmaf().
+ */
+#include <math.h>
+#include <string.h>
+#include "twv_oracle.h"
+
+static inline float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* tanh: odd 13th-degree / even 6th-degree rational, input clamped to [-9, 9] */
+float twvo_tanh(float x)
+{
+    const float a1 = 4.89352455891786e-03f, a3 = 6.37261928875436e-04f, a5 = 1.48572235717979e-05f,
+                a7 = 5.12229709037114e-08f, a9 = -8.60467152213735e-11f, a11 = 2.00018790482477e-13f,
+                a13 = -2.76076847742355e-16f;
+    const float b0 = 4.89352518554385e-03f, b2 = 2.26843463243900e-03f, b4 = 1.18534705686654e-04f,
+                b6 = 1.19825839466702e-06f;
+    x = clampf(x, -9.0f, 9.0f);
+    const float x2 = x * x;
+    float p = fmaf(x2, a13, a11);
+    p = fmaf(x2, p, a9);
+    p = fmaf(x2, p, a7);
+    p = fmaf(x2, p, a5);
+    p = fmaf(x2, p, a3);
+    p = fmaf(x2, p, a1);
+    p = x * p;
+    float q = fmaf(x2, b6, b4);
+    q = fmaf(x2, q, b2);
+    q = fmaf(x2, q, b0);
+    return p / q;
+}
+
+/* logistic: odd 9th-degree / even 10th-degree rational + 0.5, input clamped to [-18, 18] */
+float twvo_sigmoid(float x)
+{
+    const float a1 = 2.48287947061529e-01f, a3 = 8.51377133304701e-03f, a5 = 6.08574864600143e-05f,
+                a7 = 1.15627324459942e-07f, a9 = 4.37031012579801e-11f;
+    const float b0 = 9.93151921023180e-01f, b2 = 1.16817656904453e-01f, b4 = 1.70198817374094e-03f,
+                b6 = 6.29106785017040e-06f, b8 = 5.76102136993427e-09f, b10 = 6.10247389755681e-13f;
+    x = clampf(x, -18.0f, 18.0f);
+    const float x2 = x * x;
+    float p = fmaf(x2, a9, a7);
+    p = fmaf(x2, p, a5);
+    p = fmaf(x2, p, a3);
+    p = fmaf(x2, p, a1);
+    p = x * p;
+    float q = fmaf(x2, b10, b8);
+    q = fmaf(x2, q, b6);
+    q = fmaf(x2, q, b4);
+    q = fmaf(x2, q, b2);
+    q = fmaf(x2, q, b0);
+    return p / q + 0.5f;
+}
+
+static inline float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* exp: Cephes expf as vectorised in Eigen 3.3 (range reduction by ln2 split C1+C2, degree-5 polynomial) */
+float twvo_exp(float x0)
+{
+    const float exp_hi = 88.3762626647950f, exp_lo = -88.3762626647949f, LOG2EF = 1.44269504088896341f;
+    const float C1 = 0.693359375f, C2 = -2.12194440e-4f;
+    const float p0 = 1.9875691500E-4f, p1 = 1.3981999507E-3f, p2 = 8.3334519073E-3f, p3 = 4.1665795894E-2f,
+                p4 = 1.6666665459E-1f, p5 = 5.0000001201E-1f;
+    float x = x0 < exp_hi ? x0 : exp_hi;
+    x = x > exp_lo ? x : exp_lo;
+    float fx = floorf(fmaf(x, LOG2EF, 0.5f));
+    const float tmp = fx * C1, z0 = fx * C2;
+    x = x - tmp;
+    x = x - z0;
+    const float z = x * x;
+    float y = p0;
+    y = fmaf(y, x, p1);
+    y = fmaf(y, x, p2);
+    y = fmaf(y, x, p3);
+    y = fmaf(y, x, p4);
+    y = fmaf(y, x, p5);
+    y = fmaf(y, z, x);
+    y = y + 1.0f;
+    const int32_t n = (int32_t)fx;
+    const float pow2n = bits2f((uint32_t)(n + 0x7f) << 23);
+    return y * pow2n;
+}
+
+/* log: Cephes logf as vectorised in Eigen 3.3.  x <= 0 is outside the path's domain (returns -inf / NaN like libm). */
+float twvo_log(float x)
+{
+    const float SQRTHF = 0.707106781186547524f;
+    const float p0 = 7.0376836292E-2f, p1 = -1.1514610310E-1f, p2 = 1.1676998740E-1f, p3 = -1.2420140846E-1f,
+                p4 = +1.4249322787E-1f, p5 = -1.6668057665E-1f, p6 = +2.0000714765E-1f, p7 = -2.4999993993E-1f,
+                p8 = +3.3333331174E-1f;
+    const float q1 = -2.12194440e-4f, q2 = 0.693359375f;
+    if (x != x || x < 0.0f) return NAN;
+    if (x == 0.0f) return -INFINITY;
+    const float min_norm = bits2f(0x00800000u);
+    if (x < min_norm) x = min_norm; /* denormals are cut off */
+    uint32_t ix = f2bits(x);
+    int32_t emm0 = (int32_t)(ix >> 23) - 0x7f;
+    x = bits2f((ix & ~0x7f800000u) | 0x3f000000u); /* mantissa in [0.5, 1) */
+    float e = (float)emm0 + 1.0f;
+    if (x < SQRTHF) { e = e - 1.0f; x = (x - 1.0f) + x; } else { x = x - 1.0f; }
+    const float x2 = x * x, x3 = x2 * x;
+    float y = fmaf(p0, x, p1), y1 = fmaf(p3, x, p4), y2 = fmaf(p6, x, p7);
+    y = fmaf(y, x, p2);
+    y1 = fmaf(y1, x, p5);
+    y2 = fmaf(y2, x, p8);
+    y = fmaf(y, x3, y1);
+    y = fmaf(y, x3, y2);
+    y = y * x3;
+    y1 = e * q1;
+    const float tmp = x2 * 0.5f;
+    y = y + y1;
+    x = x - tmp;
+    y2 = e * q2;
+    x = x + y;
+    x = x + y2;
+    return x;
+}
+
+/* log1p for the float32 np.logaddexp of generate.py:221: argument is exp(-|a-b|) in [0, 1]. */
+float twvo_log1p(float x)
+{
+    /* log1p(x) = log(u) * x / (u - 1) with u = 1 + x (classic correction), all in f32 */
+    const float u = 1.0f + x;
+    if (u == 1.0f) return x;
+    return twvo_log(u) * (x / (u - 1.0f));
+}
+
+/* ---- float64: model.py:243 casts the logits to float64 before tf.nn.softmax; np.random.choice works in float64 ---- */
+static inline double bits2d(uint64_t u) { double f; memcpy(&f, &u, 8); return f; }
+static inline uint64_t d2bits(double f) { uint64_t u; memcpy(&u, &f, 8); return u; }
+
+/* exp: fdlibm e_exp.c algorithm (argument reduction by ln2 hi/lo, degree-5 Remez in r^2), fma-free */
+double twvo_exp64(double x)
+{
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 709.782712893383973096) return INFINITY;
+    if (x < -745.13321910194110842) return 0.0;
+    const double kf = floor(x * invln2 + 0.5);
+    const int k = (int)kf;
+    const double hi = x - kf * ln2HI, lo = kf * ln2LO;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    /* scale by 2^k in two steps so that subnormal results round once */
+    if (k >= -1021 && k <= 1023) return y * bits2d((uint64_t)(k + 1023) << 52);
+    if (k > 1023) return y * bits2d((uint64_t)(k - 1 + 1023) << 52) * 2.0;
+    return y * bits2d((uint64_t)(k + 1000 + 1023) << 52) * bits2d((uint64_t)(-1000 + 1023) << 52);
+}
+
+/* log: fdlibm e_log.c algorithm */
+double twvo_log64(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    if (x != x || x < 0.0) return NAN;
+    if (x == 0.0) return -INFINITY;
+    if (x == INFINITY) return x;
+    int k = 0;
+    uint64_t ix = d2bits(x);
+    if ((ix >> 52) == 0) { x *= 18014398509481984.0; ix = d2bits(x); k -= 54; } /* subnormal */
+    k += (int)(ix >> 52) - 1023;
+    ix = (ix & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL; /* m in [1,2) */
+    double m = bits2d(ix);
+    if (m > 1.4142135623730951) { m *= 0.5; k += 1; }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+/* chunked dot product of the arithmetic contract (DESIGN.md "AC-1"):
+ * consecutive chunks of 32 terms, each an fma chain from +0 in increasing k; chunk sums added in order. */
+float twvo_cdot(const float* w, int wstride, const float* x, int K)
+{
+    float r = 0.0f;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        const int k1 = k0 + 32 < K ? k0 + 32 : K;
+        float a = 0.0f;
+        for (int k = k0; k < k1; ++k) a = fmaf(w[(size_t)k * wstride], x[k], a);
+        r = (k0 == 0) ? a : r + a;
+    }
+    return r;
+}

@@ -1,0 +1,278 @@
+"""ctypes front-end of the CPU ORACLE (test infrastructure, NOT product code).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module,
+and only as the checker (see oracle/README.md).  PARITY UNPINNED: the reference (Python on
+TensorFlow 1.x) cannot be imported here and ships no golden vectors; this restates its source.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libtwv_oracle.so")
+MAX_LAYERS = 64
+
+
+class Dims(C.Structure):
+    _fields_ = [("n_layers", C.c_int), ("dilations", C.c_int * MAX_LAYERS), ("R", C.c_int), ("D", C.c_int),
+                ("S", C.c_int), ("Q", C.c_int), ("O", C.c_int), ("scalar_input", C.c_int), ("ifw", C.c_int),
+                ("use_bias", C.c_int), ("G", C.c_int), ("gc_card", C.c_int), ("L", C.c_int), ("n_up", C.c_int),
+                ("up", C.c_int * 4)]
+
+
+def make_dims(dilations, R=32, D=32, S=512, Q=256, out_channels=30, scalar_input=True, ifw=32, use_bias=True,
+              G=32, gc_card=2, L=80, up=(5, 5, 12)):
+    d = Dims()
+    d.n_layers = len(dilations)
+    for i, v in enumerate(dilations):
+        d.dilations[i] = int(v)
+    d.R, d.D, d.S, d.Q = R, D, S, Q
+    d.scalar_input = 1 if scalar_input else 0
+    d.O = out_channels if scalar_input else Q
+    d.ifw = ifw if scalar_input else 2
+    d.use_bias = 1 if use_bias else 0
+    d.G = G or 0
+    d.gc_card = gc_card if G else 0
+    d.L = L or 0
+    d.n_up = len(up) if L else 0
+    for i, v in enumerate(up if L else ()):
+        d.up[i] = int(v)
+    return d
+
+
+def build(force=False):
+    """compile oracle/*.c -> oracle/_build/libtwv_oracle.so (gcc)."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))] + [os.path.join(_HERE, "Makefile")]
+    if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        L = _lib
+        fp, ip, dp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        P = C.POINTER(Dims)
+        L.twvo_blob_floats.restype = C.c_size_t; L.twvo_blob_floats.argtypes = [P]
+        L.twvo_receptive_field.restype = C.c_int; L.twvo_receptive_field.argtypes = [P]
+        L.twvo_hop.restype = C.c_int; L.twvo_hop.argtypes = [P]
+        for n in ("twvo_tanh", "twvo_sigmoid", "twvo_exp", "twvo_log", "twvo_log1p"):
+            getattr(L, n).restype = C.c_float; getattr(L, n).argtypes = [C.c_float]
+        for n in ("twvo_exp64", "twvo_log64"):
+            getattr(L, n).restype = C.c_double; getattr(L, n).argtypes = [C.c_double]
+        L.twvo_cdot.restype = C.c_float; L.twvo_cdot.argtypes = [fp, C.c_int, fp, C.c_int]
+        L.twvo_mu_law_encode.argtypes = [fp, C.c_int, C.c_int, ip]
+        L.twvo_mu_law_decode.argtypes = [ip, C.c_int, C.c_int, fp]
+        L.twvo_mu_law_expand.argtypes = [fp, C.c_int, C.c_int, fp]
+        L.twvo_upsample.argtypes = [P, fp, fp, C.c_int, C.c_int, fp]
+        L.twvo_state_new.restype = C.c_void_p; L.twvo_state_new.argtypes = [P, C.c_int]
+        L.twvo_state_reset.argtypes = [C.c_void_p]
+        L.twvo_state_free.argtypes = [C.c_void_p]
+        L.twvo_step.argtypes = [P, fp, C.c_void_p, fp, ip, fp, ip, fp, fp, fp]
+        L.twvo_sample_mol.restype = C.c_float; L.twvo_sample_mol.argtypes = [fp, C.c_int, fp]
+        L.twvo_generate_mol.argtypes = [P, fp, C.c_void_p, fp, ip, fp, fp, C.c_int, C.c_int, fp]
+        L.twvo_sample_categorical.restype = C.c_int
+        L.twvo_sample_categorical.argtypes = [fp, C.c_int, C.c_double, C.c_double, fp]
+        L.twvo_generate_mulaw.argtypes = [P, fp, C.c_void_p, fp, ip, ip, dp, C.c_double, C.c_int, C.c_int, ip]
+        L.twvo_forward_full.argtypes = [P, fp, C.c_int, C.c_int, fp, ip, fp, C.c_int, ip, fp]
+    return _lib
+
+
+def _f(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _c32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ci(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+def blob_floats(d):
+    return int(lib().twvo_blob_floats(C.byref(d)))
+
+
+def receptive_field(d):
+    return int(lib().twvo_receptive_field(C.byref(d)))
+
+
+def tensor_specs(d):
+    """(name, shape) of every checkpoint tensor in canonical blob order (SURVEY.md 8a names)."""
+    specs = []
+    if d.scalar_input:
+        specs.append(("wavenet/conv1d/kernel", (d.ifw, 1, d.R)))
+    else:
+        specs.append(("wavenet/conv1d/kernel", (2, d.Q, d.R)))
+    if d.G:
+        specs.append(("wavenet/gc_embedding", (d.gc_card, d.G)))
+    for i in range(d.n_layers):
+        p = "wavenet/dilated_stack/layer%d/dilation_layer/" % i
+        for nm in ("conv_filter", "conv_gate"):
+            specs.append((p + nm + "/kernel", (2, d.R, d.D)))
+            if d.use_bias:
+                specs.append((p + nm + "/bias", (d.D,)))
+        if d.G:
+            specs.append((p + "gc_filter/kernel", (1, d.G, d.D)))
+            specs.append((p + "gc_gate/kernel", (1, d.G, d.D)))
+        if d.L:
+            specs.append((p + "lc_filter/kernel", (1, d.L, d.D)))
+            specs.append((p + "lc_gate/kernel", (1, d.L, d.D)))
+        specs.append((p + "dense/kernel", (1, d.D, d.R)))
+        if d.use_bias:
+            specs.append((p + "dense/bias", (d.R,)))
+        specs.append((p + "skip/kernel", (1, d.D, d.S)))
+        if d.use_bias:
+            specs.append((p + "skip/bias", (d.S,)))
+    specs.append(("wavenet/conv1d_1/kernel", (1, d.S, d.S)))
+    if d.use_bias:
+        specs.append(("wavenet/conv1d_1/bias", (d.S,)))
+    specs.append(("wavenet/conv1d_2/kernel", (1, d.S, d.O)))
+    if d.use_bias:
+        specs.append(("wavenet/conv1d_2/bias", (d.O,)))
+    for i in range(d.n_up):
+        specs.append(("wavenet/upsample%d/kernel" % i, (d.up[i], 2, 1, 1)))
+    return specs
+
+
+def blob_from_tensors(d, tensors):
+    parts = [np.asarray(tensors[n], dtype=np.float32).reshape(-1) for n, shp in tensor_specs(d)]
+    blob = np.concatenate(parts).astype(np.float32)
+    assert blob.size == blob_floats(d), (blob.size, blob_floats(d))
+    return blob
+
+
+def random_tensors(d, seed=0, scale=0.05):
+    rng = np.random.RandomState(seed)
+    return {n: (rng.randn(*shp) * scale).astype(np.float32) for n, shp in tensor_specs(d)}
+
+
+def elementwise(name, x):
+    fn = getattr(lib(), "twvo_" + name)
+    x = np.asarray(x)
+    flat = x.reshape(-1)
+    if name.endswith("64"):
+        return np.array([fn(float(v)) for v in flat], dtype=np.float64).reshape(x.shape)
+    return np.array([fn(float(np.float32(v))) for v in flat], dtype=np.float32).reshape(x.shape)
+
+
+def mu_law_encode(audio, Q=256):
+    a = _c32(audio).reshape(-1)
+    out = np.empty(a.size, np.int32)
+    lib().twvo_mu_law_encode(_f(a), a.size, Q, _i(out))
+    return out.reshape(np.shape(audio))
+
+
+def mu_law_decode(q, Q=256):
+    a = _ci(q).reshape(-1)
+    out = np.empty(a.size, np.float32)
+    lib().twvo_mu_law_decode(_i(a), a.size, Q, _f(out))
+    return out.reshape(np.shape(q))
+
+
+def mu_law_expand(y, Q=256):
+    a = _c32(y).reshape(-1)
+    out = np.empty(a.size, np.float32)
+    lib().twvo_mu_law_expand(_f(a), a.size, Q, _f(out))
+    return out.reshape(np.shape(y))
+
+
+def upsample(d, blob, mel):
+    mel = _c32(mel)
+    B, Tm, L = mel.shape
+    hop = int(lib().twvo_hop(C.byref(d)))
+    out = np.empty((B, Tm * hop, L), np.float32)
+    lib().twvo_upsample(C.byref(d), _f(blob), _f(mel), B, Tm, _f(out))
+    return out
+
+
+class State:
+    def __init__(self, d, B):
+        self.d, self.B = d, B
+        self.h = lib().twvo_state_new(C.byref(d), B)
+
+    def reset(self):
+        lib().twvo_state_reset(self.h)
+
+    def __del__(self):
+        try:
+            lib().twvo_state_free(self.h)
+        except Exception:
+            pass
+
+
+def step(d, blob, st, inp, lc=None, gc_ids=None, debug=False):
+    B = st.B
+    raw = np.empty((B, d.O), np.float32)
+    lc = _c32(lc); gc = _ci(gc_ids)
+    dz = np.empty((B, d.n_layers, d.D), np.float32) if debug else None
+    dx = np.empty((B, d.n_layers, d.R), np.float32) if debug else None
+    if d.scalar_input:
+        a = _c32(inp).reshape(B)
+        lib().twvo_step(C.byref(d), _f(blob), st.h, _f(a), None, _f(lc), _i(gc), _f(raw), _f(dz), _f(dx))
+    else:
+        a = _ci(inp).reshape(B)
+        lib().twvo_step(C.byref(d), _f(blob), st.h, None, _i(a), _f(lc), _i(gc), _f(raw), _f(dz), _f(dx))
+    return (raw, dz, dx) if debug else raw
+
+
+def sample_mol(y, u):
+    y = _c32(y); u = _c32(u)
+    return float(lib().twvo_sample_mol(_f(y), y.size // 3, _f(u)))
+
+
+def generate_mol(d, blob, st, U, gc_ids, seed, u):
+    U = _c32(U); u = _c32(u); seed = _c32(seed); gc = _ci(gc_ids)
+    B, T = u.shape[0], u.shape[1]
+    out = np.empty((B, T), np.float32)
+    lib().twvo_generate_mol(C.byref(d), _f(blob), st.h, _f(U), _i(gc), _f(seed), _f(u), B, T, _f(out))
+    return out
+
+
+def sample_categorical(logits, temperature, u):
+    logits = _c32(logits)
+    p = np.empty(logits.size, np.float32)
+    k = lib().twvo_sample_categorical(_f(logits), logits.size, float(temperature), float(u), _f(p))
+    return int(k), p
+
+
+def generate_mulaw(d, blob, st, U, gc_ids, seed, u, temperature=1.0):
+    U = _c32(U); seed = _ci(seed); gc = _ci(gc_ids)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    B, T = u.shape
+    out = np.empty((B, T), np.int32)
+    lib().twvo_generate_mulaw(C.byref(d), _f(blob), st.h, _f(U), _i(gc), _i(seed), _d(u), float(temperature), B, T, _i(out))
+    return out
+
+
+def forward_full(d, blob, inp, lc_up=None, gc_ids=None):
+    B, Tin = np.shape(inp)
+    rf = receptive_field(d)
+    out = np.empty((B, Tin - rf + 1, d.O), np.float32)
+    lc = _c32(lc_up); gc = _ci(gc_ids)
+    Tlc = 0 if lc is None else lc.shape[1]
+    if d.scalar_input:
+        a = _c32(inp)
+        lib().twvo_forward_full(C.byref(d), _f(blob), B, Tin, _f(a), None, _f(lc), Tlc, _i(gc), _f(out))
+    else:
+        a = _ci(inp)
+        lib().twvo_forward_full(C.byref(d), _f(blob), B, Tin, None, _i(a), _f(lc), Tlc, _i(gc), _f(out))
+    return out
