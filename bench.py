@@ -1,0 +1,164 @@
+#!/usr/bin/env python
+"""bench.py -- WaveNet autoregressive synthesis throughput on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic input: B=8 utterances x `--seconds` s of 24 kHz
+audio (default 8 s = 192 000 samples each; BASELINE.json configs[1]), mel -> upsample -> hoisted conditioning ->
+persistent generation kernel -> samples, inputs resident in HBM.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=8.0, help="audio seconds per utterance (8.0 = the BASELINE config)")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--workers", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="oracle sample size in generation steps (0 = auto, about 15 s)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import twvk_amd
+    from twvk_amd.wavenet import WaveNetModel
+    from twvk_amd import weights as W
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    hp = twvk_amd.default_hparams()
+    dil = [2 ** i for i in range(10)] * 3            # BASELINE configs[1]: 30 dilated residual layers
+    B = args.batch
+    Tm = int(round(args.seconds * hp.sample_rate / hp.hop_size))
+    T = Tm * hp.hop_size
+    m = WaveNetModel(B, dil, hp.filter_width, hp.residual_channels, hp.dilation_channels, hp.skip_channels,
+                     quantization_channels=hp.quantization_channels, out_channels=hp.out_channels, use_biases=hp.use_biases,
+                     scalar_input=True, initial_filter_width=hp.initial_filter_width,
+                     global_condition_channels=hp.gc_channels, global_condition_cardinality=2,
+                     local_condition_channels=hp.num_mels, upsample_factor=hp.upsample_factor, train_mode=False, device=dev)
+    if args.workers:
+        m.set_option("workers", args.workers)
+    tensors = W.random_tensors(m.specs, seed=0, scale=0.05)
+    m.load_weights(tensors)
+    rng = np.random.RandomState(1 + rank)
+    mel = torch.from_numpy(rng.uniform(-4, 4, (B, Tm, hp.num_mels)).astype(np.float32)).to(dev)
+    gc = (np.arange(B) % 2).astype(np.int32)
+    seed_in = (2 * rng.rand(B) - 1).astype(np.float32)
+    lo, hi = np.float32(1e-5), np.float32(1 - 1e-5)
+    u = torch.from_numpy((rng.random_sample((B, T, 11)).astype(np.float32) * (hi - lo) + lo)).to(dev)
+
+    gen_ms = []
+
+    def one_pass(timed):
+        m.queue_initializer()
+        U = m.create_upsample(mel)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        # generate() = condition (hoisted projections) + the persistent kernel; events bracket the kernel on ITS stream
+        B_, T_ = B, T
+        cond = m._condition(U, gc, T_)
+        import ctypes as C
+        from twvk_amd import _lib
+        fi = torch.as_tensor(seed_in, device=dev)
+        out = torch.empty((B_, T_), dtype=torch.float32, device=dev)
+        e0.record()
+        _lib.check(m._L.twv_wavenet_generate(m._h, C.c_void_p(m._packed.data_ptr()), C.c_void_p(m._state.data_ptr()),
+                                             C.c_void_p(cond.data_ptr()), C.c_void_p(fi.data_ptr()), C.c_void_p(u.data_ptr()), 1.0,
+                                             B_, T_, C.c_void_p(out.data_ptr()), C.c_void_p(m._status.data_ptr()), None, 0,
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        e1.record()
+        return out, (e0, e1)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out, _ev = one_pass(False)
+    sync_all()
+    t0 = time.perf_counter()
+    evs = []
+    for _ in range(args.steps):
+        out, ev = one_pass(True)
+        evs.append(ev)
+    sync_all()
+    dt = time.perf_counter() - t0
+    _lib_status = m._L.twv_wavenet_status
+    from twvk_amd import _lib
+    import ctypes as C
+    _lib.check(_lib_status(C.c_void_p(m._status.data_ptr()), None))
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    gen_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
+    samples = out.cpu().numpy()
+    assert np.isfinite(samples).all() and np.abs(samples).max() <= 1.0
+
+    if rank == 0:
+        total_samples = world * B * T * args.steps
+        value = total_samples / dt
+        # roofline: algorithmic HBM bytes per generation step for all B streams, weights streamed every step
+        NL = len(dil)
+        per_layer = 2 * (2 * 32 * 32 + 32) + 2 * 80 * 32 + (32 * 32 + 32) + (32 * 512 + 512)   # gc hoisted
+        wfloats = NL * per_layer + (512 * 512 + 512) + (512 * 30 + 30) + 32 * 32
+        bytes_per_step = wfloats * 4 + B * (80 + 1 + 1) * 4
+        k_ms = float(np.mean(gen_ms))
+        achieved = bytes_per_step * T / (k_ms * 1e-3) / 1e9
+        res = {
+            "metric": "WaveNet autoregressive audio samples/sec at 24 kHz, batch=8",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: WaveNet autoregressive synth, 30 dilated residual layers (3x[1..512]), R=D=32, S=512, "
+                                   "MoL-30 output, gc+lc conditioning, 24 kHz, batch=%d x %.2f s (%d samples each) per GPU, random-init weights, "
+                                   "injected uniforms" % (B, T / hp.sample_rate, T),
+                       "batch_per_gpu": B, "samples_per_utterance": T, "sharding": "utterances, one batch of %d per GPU, no collective" % B},
+            "realtime_factor_aggregate": value / hp.sample_rate,
+            "roofline": {"bound": "hbm", "kernel": "wn_generate_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_step * T,
+                         "kernel_ms": k_ms, "us_per_generation_step": k_ms * 1e3 / T},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            from helpers import make_case
+            from oracle import oracle as O
+            d = O.make_dims(dil)
+            blob = O.blob_from_tensors(d, tensors)
+            n = args.cpu_steps or 1200
+            Uc = np.zeros((B, n, 80), np.float32)
+            Uc[:] = rng.uniform(-1, 1, (B, n, 80))
+            uc = u[:, :n].cpu().numpy()
+            st = O.State(d, B)
+            c0 = time.perf_counter()
+            O.generate_mol(d, blob, st, Uc, gc, seed_in, uc)
+            cdt = time.perf_counter() - c0
+            res["cpu_baseline"] = {"value": B * n / cdt, "unit": "samples/s", "cores": 1, "kind": "port",
+                                   "sample": "build's CPU restatement (oracle/, scalar C, 1 thread), same model, B=%d x %d generation steps "
+                                             "(%.1f s of CPU work); NOT the reference generate.py (TensorFlow absent)" % (B, n, cdt)}
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,119 @@
+/* twv_amd.h -- C-ABI of the MI355X (gfx950) WaveNet-vocoder hot path.
+ *
+ * Drop-in boundary for hccho2/Tacotron-Wavenet-Vocoder-Korean's WaveNet generation path.  The reference has
+ * no FFI of its own: the path sits behind Python callables on a TensorFlow session.
+ * Each entry point below names the reference callable it replaces (file:line in /root/reference); the
+ * Python host in tacotron-wavenet-vocoder-korean_amd/ binds them with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions: plain C, raw DEVICE pointers + explicit sizes, no framework types.  Every buffer is owned by
+ * the caller; the handle owns host-side metadata only.  `stream` is a hipStream_t passed as void* (NULL =
+ * default stream).  All calls are asynchronous on `stream` unless stated.  Return 0 = TWV_OK, else a TWV_E_*
+ * code with text in twv_last_error() (thread-local).  One handle per GPU; thread-compatible, not thread-safe.
+ */
+#ifndef TWV_AMD_H
+#define TWV_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TWV_MAX_LAYERS 64
+
+enum { TWV_OK = 0, TWV_E_INVALID = 1, TWV_E_UNSUPPORTED = 2, TWV_E_HIP = 3, TWV_E_KERNEL = 4 };
+
+/* WaveNetModel constructor arguments (wavenet/model.py:8-10) + hparams.upsample_factor (hparams.py:79) */
+typedef struct {
+    int32_t n_layers;
+    int32_t dilations[TWV_MAX_LAYERS];   /* hparams.dilations */
+    int32_t residual_channels;           /* R, must be 32 */
+    int32_t dilation_channels;           /* D, must be 32 */
+    int32_t skip_channels;               /* S, multiple of 64, <= 1024 */
+    int32_t quantization_channels;       /* Q */
+    int32_t out_channels;                /* MoL parameter count (3*nr_mix <= 63); ignored when !scalar_input */
+    int32_t scalar_input;                /* 1: raw/mulaw scalar input + MoL output; 0: one-hot input + Q-way softmax */
+    int32_t initial_filter_width;        /* <= 64 */
+    int32_t use_biases;
+    int32_t gc_channels;                 /* 0 = no global conditioning, else <= 64 */
+    int32_t gc_cardinality;
+    int32_t lc_channels;                 /* num_mels; 0 = no local conditioning, else <= 128 */
+    int32_t n_upsample;                  /* len(upsample_factor) <= 4 */
+    int32_t upsample_factor[4];
+} twv_wavenet_dims;
+
+typedef struct twv_wavenet twv_wavenet;   /* opaque, host-side */
+
+const char* twv_last_error(void);
+const char* twv_version(void);
+
+/* WaveNetModel.__init__ (model.py:8-30): validates the dims, computes layouts.  No device memory is touched. */
+int twv_wavenet_create(const twv_wavenet_dims* dims, twv_wavenet** out);
+void twv_wavenet_destroy(twv_wavenet* h);
+
+/* WaveNetModel.calculate_receptive_field (model.py:31-39) */
+int twv_wavenet_receptive_field(const twv_wavenet* h);
+int twv_wavenet_hop_size(const twv_wavenet* h);              /* prod(upsample_factor) */
+
+/* sizes (bytes unless noted) of the caller-owned device buffers */
+size_t twv_wavenet_blob_floats(const twv_wavenet* h);        /* canonical checkpoint blob, in floats */
+size_t twv_wavenet_packed_bytes(const twv_wavenet* h);       /* streaming-layout weights */
+size_t twv_wavenet_state_bytes(const twv_wavenet* h, int batch);              /* delay lines etc. (model.py:49-64) */
+size_t twv_wavenet_cond_bytes(const twv_wavenet* h, int batch, int n_steps);  /* hoisted lc/gc projections */
+
+/* tf.train.Saver.restore equivalent (generate.py:157-161): re-lays the canonical blob (checkpoint tensors,
+ * TF layouts, order of DESIGN.md) into the streaming layout.  blob and packed are device pointers. */
+int twv_wavenet_pack(const twv_wavenet* h, const float* blob, void* packed, void* stream);
+
+/* net.queue_initializer (model.py:64, generate.py:163): zero every delay line of every stream. */
+int twv_wavenet_reset_state(const twv_wavenet* h, void* state, int batch, void* stream);
+
+/* WaveNetModel.create_upsample (model.py:102-111): mel (B, T_mel, lc) -> out (B, T_mel*hop, lc).
+ * scratch: device buffer of at least the output size (ping-pong for the transposed-conv stages). */
+int twv_wavenet_upsample(const twv_wavenet* h, const void* packed, const float* mel, int batch, int t_mel,
+                         float* out, float* scratch, void* stream);
+
+/* Hoists the per-step 1x1 projections of _create_dilation_layer (model.py:71-83) out of the sample loop:
+ * lc_filter/lc_gate of every layer for all n_steps frames of `upsampled` (B, n_steps, lc), and gc_filter/gc_gate
+ * of gc_embedding[gc_ids] (model.py:181-212).  cond is twv_wavenet_cond_bytes(batch, n_steps). */
+int twv_wavenet_condition(const twv_wavenet* h, const void* packed, const float* upsampled, const int32_t* gc_ids,
+                          int batch, int n_steps, void* cond, void* stream);
+
+/* predict_proba_incremental (model.py:215-245) iterated by the generate.py:202-233 host loop, as ONE persistent
+ * kernel launch per call: n_steps autoregressive steps for `batch` independent streams.
+ *   first_input : (B) the sample fed at step 0 (generate.py:204 waveform[:,-1:]); float32 when scalar_input,
+ *                 int32 class ids otherwise.  Later steps feed back the sample just drawn (generate.py:233).
+ *   uniforms    : scalar_input: (B, n_steps, nr_mix+1) float32 in [1e-5, 1-1e-5] -- the two tf.random_uniform draws
+ *                 of mixture.py:103,110;  one-hot: (B, n_steps) float64 in [0,1) -- np.random.choice's draw
+ *                 (generate.py:231).  Injected so that results are reproducible (the reference is unseeded).
+ *   temperature : generate.py:219-222 (one-hot only).
+ *   out         : (B, n_steps) float32 samples in [-1,1] (scalar_input) or int32 class ids.
+ *   status      : device int32[4]; [0] = 0 on success, else an internal watchdog code (checked by twv_wavenet_status).
+ * State carries over between calls (n_steps=1 reproduces a single sess.run of generate.py:211).
+ * cond must cover the same n_steps as this call (row t = frame pushed at step t). */
+int twv_wavenet_generate(const twv_wavenet* h, const void* packed, void* state, const void* cond,
+                         const void* first_input, const void* uniforms, double temperature,
+                         int batch, int n_steps, void* out, int32_t* status, float* debug, int debug_steps,
+                         void* stream);
+
+/* synchronises `stream` and converts a non-zero status word into TWV_E_KERNEL. */
+int twv_wavenet_status(const int32_t* status, void* stream);
+
+/* launch geometry knobs (performance only, results are bit-identical): workers per stream workgroup. */
+int twv_wavenet_set_option(twv_wavenet* h, const char* name, int value);
+
+/* wavenet/ops.py:22-33 mu_law_encode, ops.py:36-47 mu_law_decode (quantization True / False) */
+int twv_mu_law_encode(const float* audio, int64_t n, int quantization_channels, int32_t* out, void* stream);
+int twv_mu_law_decode(const int32_t* q, int64_t n, int quantization_channels, float* out, void* stream);
+int twv_mu_law_expand(const float* y, int64_t n, int quantization_channels, float* out, void* stream);
+
+/* elementary functions of the arithmetic contract, evaluated on the device (parity tests pin them bit for bit) */
+int twv_eval_elementwise(int fn /*0 tanh,1 sigmoid,2 exp,3 log,4 log1p*/, const float* x, int64_t n, float* out, void* stream);
+int twv_eval_elementwise64(int fn /*0 exp,1 log*/, const double* x, int64_t n, double* out, void* stream);
+
+/* cross-lane primitive self-test (device float[256]); used by the gpu tests to pin v_permlane32_swap / v_readlane semantics */
+int twv_selftest(float* out256, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

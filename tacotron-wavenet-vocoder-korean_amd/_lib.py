@@ -1,0 +1,92 @@
+"""ctypes binding of the C-ABI in include/twv_amd.h (the drop-in boundary).
+
+The HIP library is the product: if libtwv_amd.so is missing or fails to load this module raises --
+there is NO CPU / PyTorch fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtwv_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+MAX_LAYERS = 64
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+
+
+class Dims(C.Structure):
+    """twv_wavenet_dims (include/twv_amd.h) = WaveNetModel.__init__ arguments (wavenet/model.py:8-10)."""
+    _fields_ = [("n_layers", C.c_int32), ("dilations", C.c_int32 * MAX_LAYERS), ("residual_channels", C.c_int32),
+                ("dilation_channels", C.c_int32), ("skip_channels", C.c_int32), ("quantization_channels", C.c_int32),
+                ("out_channels", C.c_int32), ("scalar_input", C.c_int32), ("initial_filter_width", C.c_int32),
+                ("use_biases", C.c_int32), ("gc_channels", C.c_int32), ("gc_cardinality", C.c_int32),
+                ("lc_channels", C.c_int32), ("n_upsample", C.c_int32), ("upsample_factor", C.c_int32 * 4)]
+
+
+def build(force=False, verbose=False):
+    """hipcc cross-compiles the gfx950 library in-tree (works without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "twv_amd.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+        return LIB_PATH
+    hip = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    cmd = ["hipcc"] + HIPCC_FLAGS + hip + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libtwv_amd.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                           "there is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, ip, fp, dp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+    L.twv_last_error.restype = C.c_char_p
+    L.twv_version.restype = C.c_char_p
+    L.twv_wavenet_create.argtypes = [C.POINTER(Dims), C.POINTER(C.c_void_p)]
+    L.twv_wavenet_destroy.argtypes = [vp]; L.twv_wavenet_destroy.restype = None
+    L.twv_wavenet_receptive_field.argtypes = [vp]
+    L.twv_wavenet_hop_size.argtypes = [vp]
+    for n in ("twv_wavenet_blob_floats", "twv_wavenet_packed_bytes"):
+        getattr(L, n).argtypes = [vp]; getattr(L, n).restype = C.c_size_t
+    L.twv_wavenet_state_bytes.argtypes = [vp, C.c_int]; L.twv_wavenet_state_bytes.restype = C.c_size_t
+    L.twv_wavenet_cond_bytes.argtypes = [vp, C.c_int, C.c_int]; L.twv_wavenet_cond_bytes.restype = C.c_size_t
+    L.twv_wavenet_pack.argtypes = [vp, fp, vp, vp]
+    L.twv_wavenet_reset_state.argtypes = [vp, vp, C.c_int, vp]
+    L.twv_wavenet_upsample.argtypes = [vp, vp, fp, C.c_int, C.c_int, fp, fp, vp]
+    L.twv_wavenet_condition.argtypes = [vp, vp, fp, ip, C.c_int, C.c_int, vp, vp]
+    L.twv_wavenet_generate.argtypes = [vp, vp, vp, vp, vp, vp, C.c_double, C.c_int, C.c_int, vp, ip, fp, C.c_int, vp]
+    L.twv_wavenet_status.argtypes = [ip, vp]
+    L.twv_wavenet_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.twv_mu_law_encode.argtypes = [fp, C.c_int64, C.c_int, ip, vp]
+    L.twv_mu_law_decode.argtypes = [ip, C.c_int64, C.c_int, fp, vp]
+    L.twv_mu_law_expand.argtypes = [fp, C.c_int64, C.c_int, fp, vp]
+    L.twv_eval_elementwise.argtypes = [C.c_int, fp, C.c_int64, fp, vp]
+    L.twv_eval_elementwise64.argtypes = [C.c_int, dp, C.c_int64, dp, vp]
+    L.twv_selftest.argtypes = [fp, vp]
+    _lib = L
+    return L
+
+
+EXPORTS = ["twv_last_error", "twv_version", "twv_wavenet_create", "twv_wavenet_destroy", "twv_wavenet_receptive_field",
+           "twv_wavenet_hop_size", "twv_wavenet_blob_floats", "twv_wavenet_packed_bytes", "twv_wavenet_state_bytes",
+           "twv_wavenet_cond_bytes", "twv_wavenet_pack", "twv_wavenet_reset_state", "twv_wavenet_upsample",
+           "twv_wavenet_condition", "twv_wavenet_generate", "twv_wavenet_status", "twv_wavenet_set_option",
+           "twv_mu_law_encode", "twv_mu_law_decode", "twv_mu_law_expand", "twv_eval_elementwise",
+           "twv_eval_elementwise64", "twv_selftest"]
+
+
+class TwvError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise TwvError("twv_amd error %d: %s" % (rc, lib().twv_last_error().decode()))

@@ -1,0 +1,55 @@
+"""wavenet/ops.py:22-47 mu-law codec on the device (HIP C-ABI); torch tensors in, torch tensors out."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def mu_law_encode(audio, quantization_channels, device="cuda:0"):
+    a = torch.as_tensor(audio, dtype=torch.float32, device=device).contiguous()
+    with torch.cuda.device(a.device):
+        out = torch.empty(a.shape, dtype=torch.int32, device=a.device)
+        _lib.check(_lib.lib().twv_mu_law_encode(_ptr(a), a.numel(), int(quantization_channels), _ptr(out), _stream()))
+    return out
+
+
+def mu_law_decode(output, quantization_channels, quantization=True, device="cuda:0"):
+    L = _lib.lib()
+    if quantization:
+        q = torch.as_tensor(output, dtype=torch.int32, device=device).contiguous()
+        with torch.cuda.device(q.device):
+            out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+            _lib.check(L.twv_mu_law_decode(_ptr(q), q.numel(), int(quantization_channels), _ptr(out), _stream()))
+        return out
+    y = torch.as_tensor(output, dtype=torch.float32, device=device).contiguous()
+    with torch.cuda.device(y.device):
+        out = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+        _lib.check(L.twv_mu_law_expand(_ptr(y), y.numel(), int(quantization_channels), _ptr(out), _stream()))
+    return out
+
+
+def eval_elementwise(name, x, device="cuda:0"):
+    """contract functions evaluated on the device (parity tests)."""
+    L = _lib.lib()
+    if name.endswith("64"):
+        fn = {"exp64": 0, "log64": 1}[name]
+        t = torch.as_tensor(x, dtype=torch.float64, device=device).contiguous()
+        with torch.cuda.device(t.device):
+            out = torch.empty_like(t)
+            _lib.check(L.twv_eval_elementwise64(fn, _ptr(t), t.numel(), _ptr(out), _stream()))
+        return out
+    fn = {"tanh": 0, "sigmoid": 1, "exp": 2, "log": 3, "log1p": 4}[name]
+    t = torch.as_tensor(x, dtype=torch.float32, device=device).contiguous()
+    with torch.cuda.device(t.device):
+        out = torch.empty_like(t)
+        _lib.check(L.twv_eval_elementwise(fn, _ptr(t), t.numel(), _ptr(out), _stream()))
+    return out

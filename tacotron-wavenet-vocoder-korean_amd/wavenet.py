@@ -1,0 +1,181 @@
+"""Host-side mirror of the reference's WaveNetModel (wavenet/model.py) over the HIP C-ABI.
+
+Same constructor arguments, `receptive_field`, `create_upsample`, `predict_proba_incremental`,
+`queue_initializer`; plus `generate`, the generate.py:199-233 sample loop as ONE persistent kernel launch.
+PyTorch is used for device memory and streams only.  No fallback: without the HIP library this raises."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import weights as W
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class WaveNetModel(object):
+    def __init__(self, batch_size, dilations, filter_width, residual_channels, dilation_channels, skip_channels,
+                 quantization_channels=2 ** 8, out_channels=30, use_biases=False, scalar_input=False,
+                 initial_filter_width=32, global_condition_channels=None, global_condition_cardinality=None,
+                 local_condition_channels=80, upsample_factor=None, train_mode=True, device="cuda:0"):
+        if filter_width != 2:
+            raise ValueError("filter_width must be 2 (hparams.py:59)")
+        self.batch_size = batch_size
+        self.dilations = list(dilations)
+        self.filter_width = filter_width
+        self.residual_channels = residual_channels
+        self.dilation_channels = dilation_channels
+        self.quantization_channels = quantization_channels
+        self.use_biases = use_biases
+        self.skip_channels = skip_channels
+        self.scalar_input = scalar_input
+        self.initial_filter_width = initial_filter_width
+        self.global_condition_channels = global_condition_channels
+        self.global_condition_cardinality = global_condition_cardinality
+        self.local_condition_channels = local_condition_channels
+        self.upsample_factor = list(upsample_factor) if upsample_factor else []
+        self.train_mode = train_mode
+        self.out_channels = out_channels
+        self.receptive_field = WaveNetModel.calculate_receptive_field(filter_width, self.dilations, scalar_input,
+                                                                      initial_filter_width)
+        self.device = torch.device(device)
+        self.specs = W.tensor_specs(len(self.dilations), residual_channels, dilation_channels, skip_channels,
+                                    quantization_channels, out_channels, scalar_input, initial_filter_width, use_biases,
+                                    global_condition_channels or 0, global_condition_cardinality or 0,
+                                    local_condition_channels or 0, self.upsample_factor)
+        d = _lib.Dims()
+        d.n_layers = len(self.dilations)
+        for i, v in enumerate(self.dilations):
+            d.dilations[i] = int(v)
+        d.residual_channels, d.dilation_channels, d.skip_channels = residual_channels, dilation_channels, skip_channels
+        d.quantization_channels, d.out_channels = quantization_channels, out_channels
+        d.scalar_input, d.initial_filter_width, d.use_biases = int(bool(scalar_input)), initial_filter_width, int(bool(use_biases))
+        d.gc_channels = global_condition_channels or 0
+        d.gc_cardinality = global_condition_cardinality or 0
+        d.lc_channels = local_condition_channels or 0
+        d.n_upsample = len(self.upsample_factor) if local_condition_channels else 0
+        for i, v in enumerate(self.upsample_factor[:4]):
+            d.upsample_factor[i] = int(v)
+        self._dims = d
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(self._L.twv_wavenet_create(C.byref(d), C.byref(h)))
+        self._h = h
+        self.hop_size = self._L.twv_wavenet_hop_size(h)
+        self._packed = None
+        self._state = None
+        self._status = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.twv_wavenet_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def calculate_receptive_field(filter_width, dilations, scalar_input, initial_filter_width):
+        """wavenet/model.py:31-39"""
+        receptive_field = (filter_width - 1) * sum(dilations) + 1
+        receptive_field += (initial_filter_width - 1) if scalar_input else (filter_width - 1)
+        return receptive_field
+
+    def set_option(self, name, value):
+        _lib.check(self._L.twv_wavenet_set_option(self._h, name.encode(), int(value)))
+
+    # ---- weights (tf.train.Saver.restore of generate.py:157-161) ----
+    def load_weights(self, tensors):
+        blob = W.flatten(self.specs, tensors)
+        assert blob.size == self._L.twv_wavenet_blob_floats(self._h), (blob.size, self._L.twv_wavenet_blob_floats(self._h))
+        with torch.cuda.device(self.device):
+            dblob = torch.from_numpy(blob).to(self.device)
+            self._packed = torch.empty(self._L.twv_wavenet_packed_bytes(self._h) // 4, dtype=torch.float32, device=self.device)
+            _lib.check(self._L.twv_wavenet_pack(self._h, _ptr(dblob), _ptr(self._packed), _stream()))
+            torch.cuda.current_stream().synchronize()
+        if self._state is None:
+            self.queue_initializer()
+
+    # ---- net.queue_initializer (model.py:64) ----
+    def queue_initializer(self):
+        with torch.cuda.device(self.device):
+            n = self._L.twv_wavenet_state_bytes(self._h, self.batch_size) // 4
+            if self._state is None:
+                self._state = torch.empty(n, dtype=torch.float32, device=self.device)
+                self._status = torch.zeros(4, dtype=torch.int32, device=self.device)
+            _lib.check(self._L.twv_wavenet_reset_state(self._h, _ptr(self._state), self.batch_size, _stream()))
+
+    # ---- model.py:102-111 ----
+    def create_upsample(self, local_condition_batch):
+        mel = torch.as_tensor(local_condition_batch, dtype=torch.float32, device=self.device).contiguous()
+        B, Tm, Lc = mel.shape
+        assert Lc == self.local_condition_channels
+        with torch.cuda.device(self.device):
+            out = torch.empty((B, Tm * self.hop_size, Lc), dtype=torch.float32, device=self.device)
+            scratch = torch.empty_like(out)
+            _lib.check(self._L.twv_wavenet_upsample(self._h, _ptr(self._packed), _ptr(mel), B, Tm, _ptr(out), _ptr(scratch), _stream()))
+        return out
+
+    def _condition(self, upsampled, gc_ids, n_steps):
+        B = self.batch_size
+        with torch.cuda.device(self.device):
+            cond = torch.empty(self._L.twv_wavenet_cond_bytes(self._h, B, n_steps) // 4, dtype=torch.float32, device=self.device)
+            gc = None
+            if self.global_condition_channels:
+                gc = torch.as_tensor(np.asarray(gc_ids, dtype=np.int32), device=self.device).contiguous()
+            up = None
+            if self.local_condition_channels:
+                up = torch.as_tensor(upsampled, dtype=torch.float32, device=self.device).contiguous()
+                assert tuple(up.shape) == (B, n_steps, self.local_condition_channels), (tuple(up.shape), (B, n_steps))
+            _lib.check(self._L.twv_wavenet_condition(self._h, _ptr(self._packed), _ptr(up), _ptr(gc), B, n_steps, _ptr(cond), _stream()))
+            self._keep = (gc, up)
+        return cond
+
+    # ---- generate.py:199-233 as one persistent launch ----
+    def generate(self, upsampled_local_condition, global_condition, first_input, uniforms, temperature=1.0,
+                 debug_steps=0, check=True):
+        """upsampled_local_condition (B,T,lc) | None; global_condition: (B) ids | None; first_input (B); uniforms
+        (B,T,nr_mix+1) float32 (scalar_input) or (B,T) float64.  Returns (B,T) samples (and the debug dump)."""
+        B = self.batch_size
+        with torch.cuda.device(self.device):
+            if self.scalar_input:
+                u = torch.as_tensor(uniforms, dtype=torch.float32, device=self.device).contiguous()
+                T = u.shape[1]
+                fi = torch.as_tensor(np.asarray(first_input, dtype=np.float32).reshape(B), device=self.device)
+                out = torch.empty((B, T), dtype=torch.float32, device=self.device)
+            else:
+                u = torch.as_tensor(uniforms, dtype=torch.float64, device=self.device).contiguous()
+                T = u.shape[1]
+                fi = torch.as_tensor(np.asarray(first_input, dtype=np.int32).reshape(B), device=self.device)
+                out = torch.empty((B, T), dtype=torch.int32, device=self.device)
+            cond = self._condition(upsampled_local_condition, global_condition, T)
+            dbg = None
+            if debug_steps:
+                opad = (((self.out_channels if self.scalar_input else self.quantization_channels) + 63) // 64) * 64
+                dbg = torch.zeros((B, debug_steps, len(self.dilations) * 64 + opad), dtype=torch.float32, device=self.device)
+            _lib.check(self._L.twv_wavenet_generate(self._h, _ptr(self._packed), _ptr(self._state), _ptr(cond), _ptr(fi), _ptr(u),
+                                                    float(temperature), B, T, _ptr(out), _ptr(self._status), _ptr(dbg),
+                                                    int(debug_steps), _stream()))
+            if check:
+                _lib.check(self._L.twv_wavenet_status(_ptr(self._status), _stream()))
+        return (out, dbg) if debug_steps else out
+
+    # ---- model.py:215-245: one step (a single sess.run of generate.py:211) ----
+    def predict_proba_incremental(self, waveform, upsampled_local_condition=None, global_condition=None, uniforms=None,
+                                  temperature=1.0):
+        B = self.batch_size
+        lc = None
+        if upsampled_local_condition is not None:
+            lc = torch.as_tensor(upsampled_local_condition, dtype=torch.float32, device=self.device).reshape(B, 1, -1)
+        if uniforms is None:
+            raise ValueError("uniforms must be injected (the reference draws unseeded tf.random_uniform / np.random)")
+        u = np.asarray(uniforms)
+        u = u.reshape(B, 1, -1) if self.scalar_input else u.reshape(B, 1)
+        return self.generate(lc, global_condition, np.asarray(waveform).reshape(B), u, temperature)

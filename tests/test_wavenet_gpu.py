@@ -1,0 +1,190 @@
+"""-m gpu: the parity tests proper.  Every check calls the HIP path through the C-ABI (ctypes) and compares it
+with the CPU oracle BIT FOR BIT (float32 == float32; the arithmetic contract of DESIGN.md makes that the bar)."""
+import numpy as np
+import pytest
+
+from helpers import first_mismatch, make_case, make_model, mol_uniforms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def test_native_library_is_loaded(torch_cuda):
+    import twvk_amd
+    L = twvk_amd._lib.lib()
+    assert b"gfx950" in L.twv_version()
+    with open("/proc/self/maps") as f:
+        assert "libtwv_amd.so" in f.read(), "the in-tree HIP library must be the thing that runs"
+
+
+def test_crosslane_primitives(torch_cuda):
+    """pins v_permlane32_swap / v_readlane semantics the chain wave relies on"""
+    import ctypes as C
+    import twvk_amd
+    torch = torch_cuda
+    out = torch.zeros(256, dtype=torch.float32, device="cuda:0")
+    twvk_amd._lib.check(twvk_amd._lib.lib().twv_selftest(C.c_void_p(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().reshape(64, 4)
+    lanes = np.arange(64)
+    assert np.array_equal(o[:, 0], (lanes % 32) + 1), o[:, 0]          # new vdst: low half everywhere
+    assert np.array_equal(o[:, 1], (lanes % 32) + 33), o[:, 1]         # new src: high half everywhere
+    assert np.all(o[:, 2] == 6.0)
+    assert np.array_equal(o[:, 3], (lanes ^ 1) + 1)
+
+
+@pytest.mark.parametrize("name,lo,hi", [("tanh", -12, 12), ("sigmoid", -25, 25), ("exp", -100, 100), ("log1p", 0, 1)])
+def test_elementwise_bit_exact(torch_cuda, oracle, name, lo, hi):
+    from twvk_amd import ops
+    rng = np.random.RandomState(5)
+    x = np.concatenate([rng.uniform(lo, hi, 200000), [0.0, -0.0, lo, hi, 1e-30, -1e-30, 1e-42]]).astype(np.float32)
+    if name == "log1p":
+        x = np.abs(x)
+    got = ops.eval_elementwise(name, x).cpu().numpy()
+    want = oracle.elementwise(name, x)
+    assert first_mismatch(got, want) is None, (name, first_mismatch(got, want))
+
+
+def test_log_bit_exact(torch_cuda, oracle):
+    from twvk_amd import ops
+    rng = np.random.RandomState(6)
+    x = np.concatenate([np.exp(rng.uniform(-80, 80, 200000)), rng.uniform(1e-5, 1, 100000), [1.0, 0.5, 2.0, 1e-38, 1e-42]]).astype(np.float32)
+    got = ops.eval_elementwise("log", x).cpu().numpy()
+    want = oracle.elementwise("log", x)
+    assert first_mismatch(got, want) is None
+
+
+@pytest.mark.parametrize("name", ["exp64", "log64"])
+def test_elementwise64_bit_exact(torch_cuda, oracle, name):
+    from twvk_amd import ops
+    rng = np.random.RandomState(7)
+    x = rng.uniform(-700, 700, 50000) if name == "exp64" else np.exp(rng.uniform(-700, 700, 50000))
+    got = ops.eval_elementwise(name, x).cpu().numpy()
+    want = oracle.elementwise(name, x)
+    assert first_mismatch(got, want) is None
+
+
+def test_mu_law_codec(torch_cuda, oracle):
+    from twvk_amd import ops
+    rng = np.random.RandomState(8)
+    a = np.concatenate([rng.uniform(-1.2, 1.2, 100000), [0.0, 1.0, -1.0, 0.5]]).astype(np.float32)
+    q = ops.mu_law_encode(a, 256).cpu().numpy()
+    assert np.array_equal(q, oracle.mu_law_encode(a, 256))
+    assert q[-4] == 128 and q[-3] == 255 and q[-2] == 0          # ops.py:22-33 known answers
+    allq = np.arange(256, dtype=np.int32)
+    assert first_mismatch(ops.mu_law_decode(allq, 256).cpu().numpy(), oracle.mu_law_decode(allq, 256)) is None
+    y = rng.uniform(-1, 1, 10000).astype(np.float32)
+    assert first_mismatch(ops.mu_law_decode(y, 256, quantization=False).cpu().numpy(), oracle.mu_law_expand(y, 256)) is None
+
+
+def test_upsample(torch_cuda, oracle):
+    dil = [1, 2, 4]
+    d, tensors, blob = make_case(oracle, dil, S=64, scale=0.3)
+    m = make_model(2, dil, tensors, S=64)
+    mel = np.random.RandomState(1).uniform(-4, 4, (2, 7, 80)).astype(np.float32)
+    got = m.create_upsample(mel).cpu().numpy()
+    want = oracle.upsample(d, blob, mel)
+    assert got.shape == (2, 7 * 300, 80)                         # generate.py:152 T_mel * hop_size
+    assert first_mismatch(got, want) is None
+
+
+def _run_mol(oracle, torch, dil, B, Tm, S=512, ifw=32, use_bias=True, G=32, L=80, up=(5, 5, 12), workers=None, scale=0.05,
+             T=None, debug_steps=0, seed=0):
+    d, tensors, blob = make_case(oracle, dil, S=S, ifw=ifw, use_bias=use_bias, G=G, L=L, up=up, seed=seed, scale=scale)
+    m = make_model(B, dil, tensors, S=S, ifw=ifw, use_bias=use_bias, G=G, L=L, up=up, workers=workers)
+    rng = np.random.RandomState(1)
+    hop = int(np.prod(up)) if L else 1
+    T = T or Tm * hop
+    if L:
+        mel = rng.uniform(-4, 4, (B, Tm, L)).astype(np.float32)
+        U_o = oracle.upsample(d, blob, mel)[:, :T]
+        U_g = m.create_upsample(mel)[:, :T].contiguous()
+    else:
+        U_o = U_g = None
+    gc = (np.arange(B) % 2).astype(np.int32) if G else None
+    seed_in = (2 * rng.rand(B) - 1).astype(np.float32)            # generate.py:188
+    u = mol_uniforms(B, T, d.O // 3)
+    st = oracle.State(d, B)
+    want = oracle.generate_mol(d, blob, st, U_o, gc, seed_in, u)
+    res = m.generate(U_g, gc, seed_in, u, debug_steps=debug_steps)
+    return d, blob, m, want, res, (U_o, gc, seed_in, u)
+
+
+def test_generate_small_with_layer_dumps(torch_cuda, oracle):
+    """first line of defence: per-layer z / x and raw outputs of the first steps against the oracle's own dumps"""
+    dil = [1, 2, 4, 8, 1, 2, 4, 8]
+    B, T, dbg = 2, 24, 4
+    d, blob, m, want, (got, dump), (U_o, gc, seed_in, u) = _run_mol(oracle, torch_cuda, dil, B, 1, T=T, debug_steps=dbg, scale=0.2)
+    # oracle step-by-step with dumps
+    st = oracle.State(d, B)
+    inp = seed_in.copy()
+    dump = dump.cpu().numpy()
+    NL = len(dil)
+    for t in range(dbg):
+        raw, dz, dx = oracle.step(d, blob, st, inp, U_o[:, t], gc, debug=True)
+        gz = dump[:, t, :NL * 64].reshape(B, NL, 2, 32)
+        assert first_mismatch(gz[:, :, 0], dz) is None, ("z", t, first_mismatch(gz[:, :, 0], dz))
+        assert first_mismatch(gz[:, :, 1], dx) is None, ("x", t, first_mismatch(gz[:, :, 1], dx))
+        graw = dump[:, t, NL * 64:NL * 64 + d.O]
+        assert first_mismatch(graw, raw) is None, ("raw", t, first_mismatch(graw, raw))
+        inp = want[:, t]
+    assert first_mismatch(got.cpu().numpy(), want) is None
+
+
+@pytest.mark.parametrize("workers", [4, 8])
+def test_generate_c2_shape_short(torch_cuda, oracle, workers):
+    """C2 architecture (3x[1..512], R=D=32, S=512, MoL-30, gc+lc), B=2, 2 mel frames = 600 samples"""
+    dil = [2 ** i for i in range(10)] * 3
+    d, blob, m, want, got, _ = _run_mol(oracle, torch_cuda, dil, 2, 2, workers=workers)
+    got = got.cpu().numpy()
+    assert got.shape == want.shape == (2, 600)
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+    assert np.all(np.abs(got) <= 1.0)
+
+
+def test_generate_past_longest_delay_line(torch_cuda, oracle):
+    """long enough that every delay line (d=512) wraps more than twice"""
+    dil = [1, 4, 16, 64, 256, 512]
+    d, blob, m, want, got, _ = _run_mol(oracle, torch_cuda, dil, 1, 5, S=128, scale=0.15)
+    assert first_mismatch(got.cpu().numpy(), want) is None
+
+
+@pytest.mark.parametrize("kw", [dict(use_bias=False), dict(G=0), dict(L=0), dict(ifw=8), dict(S=64), dict(S=1024, workers=8),
+                                dict(up=(3, 4))])
+def test_generate_variants(torch_cuda, oracle, kw):
+    dil = [1, 2, 4, 8, 16, 1, 2]
+    d, blob, m, want, got, _ = _run_mol(oracle, torch_cuda, dil, 3, 6, T=70 if kw.get("L", 80) else 70, scale=0.1, **kw)
+    assert first_mismatch(got.cpu().numpy(), want) is None, kw
+
+
+def test_state_carries_over_between_calls(torch_cuda, oracle):
+    """generate(T1) then generate(T2) == generate(T1+T2); n_steps=1 calls == one sess.run each (generate.py:211)"""
+    dil = [1, 2, 4, 8] * 2
+    B, T = 2, 40
+    d, tensors, blob = make_case(oracle, dil, S=128, scale=0.1)
+    m = make_model(B, dil, tensors, S=128)
+    rng = np.random.RandomState(3)
+    U = rng.uniform(-1, 1, (B, T, 80)).astype(np.float32)
+    gc = np.array([1, 0], np.int32)
+    seed_in = rng.uniform(-1, 1, B).astype(np.float32)
+    u = mol_uniforms(B, T, 10)
+    want = oracle.generate_mol(d, blob, oracle.State(d, B), U, gc, seed_in, u)
+    a = m.generate(U[:, :15], gc, seed_in, u[:, :15]).cpu().numpy()
+    b = m.generate(U[:, 15:16], gc, a[:, -1], u[:, 15:16]).cpu().numpy()          # a single step
+    c = m.generate(U[:, 16:], gc, b[:, -1], u[:, 16:]).cpu().numpy()
+    got = np.concatenate([a, b, c], axis=1)
+    assert first_mismatch(got, want) is None
+    # queue_initializer really resets (generate.py:163)
+    m.queue_initializer()
+    again = m.generate(U, gc, seed_in, u).cpu().numpy()
+    assert first_mismatch(again, want) is None
+    # predict_proba_incremental == one step
+    m.queue_initializer()
+    one = m.predict_proba_incremental(seed_in, U[:, 0], gc, uniforms=u[:, 0]).cpu().numpy()
+    assert first_mismatch(one[:, 0], want[:, 0]) is None
