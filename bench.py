@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=8.0, help="audio seconds per utterance (8.0 = the BASELINE config)")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--workers", type=int, default=0)
+    ap.add_argument("--groups", type=int, default=-1, help="workgroups per stream (-1 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle sample size in generation steps (0 = auto, about 15 s)")
     args = ap.parse_args()
@@ -57,6 +58,8 @@ def main():
                      local_condition_channels=hp.num_mels, upsample_factor=hp.upsample_factor, train_mode=False, device=dev)
     if args.workers:
         m.set_option("workers", args.workers)
+    if args.groups >= 0:
+        m.set_option("groups", args.groups)
     tensors = W.random_tensors(m.specs, seed=0, scale=0.05)
     m.load_weights(tensors)
     rng = np.random.RandomState(1 + rank)

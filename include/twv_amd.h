@@ -101,6 +101,11 @@ int twv_wavenet_status(const int32_t* status, void* stream);
 /* launch geometry knobs (performance only, results are bit-identical): workers per stream workgroup. */
 int twv_wavenet_set_option(twv_wavenet* h, const char* name, int value);
 
+/* optional in-kernel phase timestamps (tuning aid): device uint64[steps][80]; per step of stream 0's chain wave:
+ * [0] step start, [1] causal layer done, [2] residual stack done, [3..6] the four workgroup barriers (skip sum, conv1d_1,
+ * conv1d_2, sample), [7] wall clock (100 MHz), [8+l] layer l done.  Shader-clock ticks (s_memtime).  NULL disables. */
+int twv_wavenet_set_profile_buffer(twv_wavenet* h, void* dev_u64, int steps);
+
 /* wavenet/ops.py:22-33 mu_law_encode, ops.py:36-47 mu_law_decode (quantization True / False) */
 int twv_mu_law_encode(const float* audio, int64_t n, int quantization_channels, int32_t* out, void* stream);
 int twv_mu_law_decode(const int32_t* q, int64_t n, int quantization_channels, float* out, void* stream);

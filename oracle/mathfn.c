@@ -190,15 +190,42 @@ double twvo_log64(double x)
 }
 
 /* chunked dot product of the arithmetic contract (DESIGN.md "AC-1"):
- * consecutive chunks of 32 terms, each an fma chain from +0 in increasing k; chunk sums added in order. */
+ * consecutive chunks of 32 terms; inside a chunk FOUR interleaved partial sums s_j (j = k mod 4), each an fma chain
+ * from +0 in increasing k; chunk value (s0 + s1) + (s2 + s3); chunk values added in order. */
 float twvo_cdot(const float* w, int wstride, const float* x, int K)
 {
     float r = 0.0f;
     for (int k0 = 0; k0 < K; k0 += 32) {
         const int k1 = k0 + 32 < K ? k0 + 32 : K;
-        float a = 0.0f;
-        for (int k = k0; k < k1; ++k) a = fmaf(w[(size_t)k * wstride], x[k], a);
+        float s[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        for (int k = k0; k < k1; ++k) s[(k - k0) & 3] = fmaf(w[(size_t)k * wstride], x[k], s[(k - k0) & 3]);
+        const float a = (s[0] + s[1]) + (s[2] + s[3]);
         r = (k0 == 0) ? a : r + a;
     }
     return r;
+}
+
+/* The same chunked dot product for `ncols` outputs at once: out[j] = twvo_cdot(w + j, ncols, x, K) for w row-major
+ * (K, ncols).  Per output the order of operations is IDENTICAL to twvo_cdot; looping k outside / j inside only lets
+ * gcc vectorise across outputs. */
+void twvo_cdot_rows(const float* w, int ncols, const float* x, int K, float* out)
+{
+    float s[4][1024];
+    for (int j0 = 0; j0 < ncols; j0 += 1024) {
+        const int n = ncols - j0 < 1024 ? ncols - j0 : 1024;
+        for (int k0 = 0; k0 < K; k0 += 32) {
+            const int k1 = k0 + 32 < K ? k0 + 32 : K;
+            for (int q = 0; q < 4; ++q) for (int j = 0; j < n; ++j) s[q][j] = 0.0f;
+            for (int k = k0; k < k1; ++k) {
+                const float xv = x[k];
+                const float* wr = w + (size_t)k * ncols + j0;
+                float* sq = s[(k - k0) & 3];
+                for (int j = 0; j < n; ++j) sq[j] = fmaf(wr[j], xv, sq[j]);
+            }
+            for (int j = 0; j < n; ++j) {
+                const float a = (s[0][j] + s[1][j]) + (s[2][j] + s[3][j]);
+                out[j0 + j] = (k0 == 0) ? a : out[j0 + j] + a;
+            }
+        }
+    }
 }

@@ -55,6 +55,7 @@ double twvo_exp64(double x);
 double twvo_log64(double x);
 float  twvo_log1p(float x);
 float  twvo_cdot(const float* w, int wstride, const float* x, int K);
+void   twvo_cdot_rows(const float* w, int ncols, const float* x, int K, float* out); /* out[j] = twvo_cdot(w+j, ncols, x, K) */
 
 /* ops.py:22-47 */
 void twvo_mu_law_encode(const float* audio, int n, int Q, int32_t* out);

@@ -182,35 +182,30 @@ static void dilation_layer_at(const twvo_dims* d, const float* blob, const layer
                               float* z, float* transformed, float* skip)
 {
     const int R = d->R, D = d->D, S = d->S;
-    float taps[2 * 512];
+    float taps[2 * 512], f[512], g[512], t1[512], t2[512];
     memcpy(taps, x_old, sizeof(float) * R);
     memcpy(taps + R, x_new, sizeof(float) * R);
-    for (int j = 0; j < D; ++j) {
-        /* model.py:68-69 conv_filter / conv_gate: k=2, dilation d, 'valid', bias */
-        float f = twvo_cdot(blob + l->wf + j, D, taps, 2 * R);
-        float g = twvo_cdot(blob + l->wg + j, D, taps, 2 * R);
-        if (d->use_bias) { f = f + blob[l->bf + j]; g = g + blob[l->bg + j]; }
-        if (emb) { /* model.py:71-73 */
-            f = f + twvo_cdot(blob + l->gcf + j, D, emb, d->G);
-            g = g + twvo_cdot(blob + l->gcg + j, D, emb, d->G);
-        }
-        if (lc) { /* model.py:75-83 */
-            f = f + twvo_cdot(blob + l->lcf + j, D, lc, d->L);
-            g = g + twvo_cdot(blob + l->lcg + j, D, lc, d->L);
-        }
-        z[j] = twvo_tanh(f) * twvo_sigmoid(g); /* model.py:86 */
+    /* model.py:68-69 conv_filter / conv_gate: k=2, dilation d, 'valid', bias */
+    twvo_cdot_rows(blob + l->wf, D, taps, 2 * R, f);
+    twvo_cdot_rows(blob + l->wg, D, taps, 2 * R, g);
+    if (d->use_bias) for (int j = 0; j < D; ++j) { f[j] = f[j] + blob[l->bf + j]; g[j] = g[j] + blob[l->bg + j]; }
+    if (emb) { /* model.py:71-73 */
+        twvo_cdot_rows(blob + l->gcf, D, emb, d->G, t1);
+        twvo_cdot_rows(blob + l->gcg, D, emb, d->G, t2);
+        for (int j = 0; j < D; ++j) { f[j] = f[j] + t1[j]; g[j] = g[j] + t2[j]; }
     }
-    for (int r = 0; r < R; ++r) { /* model.py:89 dense 1x1 */
-        float v = twvo_cdot(blob + l->wd + r, R, z, D);
-        if (d->use_bias) v = v + blob[l->bd + r];
-        transformed[r] = v;
+    if (lc) { /* model.py:75-83 */
+        twvo_cdot_rows(blob + l->lcf, D, lc, d->L, t1);
+        twvo_cdot_rows(blob + l->lcg, D, lc, d->L, t2);
+        for (int j = 0; j < D; ++j) { f[j] = f[j] + t1[j]; g[j] = g[j] + t2[j]; }
     }
-    if (skip)
-        for (int s = 0; s < S; ++s) { /* model.py:96 skip 1x1 */
-            float v = twvo_cdot(blob + l->ws + s, S, z, D);
-            if (d->use_bias) v = v + blob[l->bs + s];
-            skip[s] = v;
-        }
+    for (int j = 0; j < D; ++j) z[j] = twvo_tanh(f[j]) * twvo_sigmoid(g[j]); /* model.py:86 */
+    twvo_cdot_rows(blob + l->wd, R, z, D, transformed); /* model.py:89 dense 1x1 */
+    if (d->use_bias) for (int r = 0; r < R; ++r) transformed[r] = transformed[r] + blob[l->bd + r];
+    if (skip) { /* model.py:96 skip 1x1 */
+        twvo_cdot_rows(blob + l->ws, S, z, D, skip);
+        if (d->use_bias) for (int s = 0; s < S; ++s) skip[s] = skip[s] + blob[l->bs + s];
+    }
 }
 
 /* model.py:150-165 postprocessing at one position: total (S) -> out (O) */
@@ -219,16 +214,14 @@ static void postprocess_at(const twvo_dims* d, const float* blob, const blob_off
     const int S = d->S, O = d->O;
     float* h1 = (float*)malloc(sizeof(float) * S), *h2 = (float*)malloc(sizeof(float) * S);
     for (int s = 0; s < S; ++s) h1[s] = total[s] > 0.0f ? total[s] : 0.0f;        /* model.py:157 relu */
+    twvo_cdot_rows(blob + o->w1, S, h1, S, h2);                                     /* model.py:158 */
     for (int s = 0; s < S; ++s) {
-        float v = twvo_cdot(blob + o->w1 + s, S, h1, S);                           /* model.py:158 */
+        float v = h2[s];
         if (d->use_bias) v = v + blob[o->b1 + s];
         h2[s] = v > 0.0f ? v : 0.0f;                                               /* model.py:160 */
     }
-    for (int c = 0; c < O; ++c) {
-        float v = twvo_cdot(blob + o->w2 + c, O, h2, S);                           /* model.py:161-165 */
-        if (d->use_bias) v = v + blob[o->b2 + c];
-        out[c] = v;
-    }
+    twvo_cdot_rows(blob + o->w2, O, h2, S, out);                                    /* model.py:161-165 */
+    if (d->use_bias) for (int c = 0; c < O; ++c) out[c] = out[c] + blob[o->b2 + c];
     free(h1); free(h2);
 }
 

@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""In-kernel phase timing of the generation kernel (tuning aid): prints per-phase microseconds of stream 0's chain wave."""
+import argparse, ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import twvk_amd
+from twvk_amd.wavenet import WaveNetModel
+from twvk_amd import weights as W, _lib
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=3000)
+ap.add_argument("--batch", type=int, default=8)
+ap.add_argument("--workers", type=int, default=0)
+ap.add_argument("--layers", type=int, default=30)
+ap.add_argument("--groups", type=int, default=-1)
+args = ap.parse_args()
+hp = twvk_amd.default_hparams()
+dil = ([2 ** i for i in range(10)] * 5)[:args.layers]
+B, T = args.batch, args.steps
+m = WaveNetModel(B, dil, 2, 32, 32, 512, out_channels=30, use_biases=True, scalar_input=True, initial_filter_width=32,
+                 global_condition_channels=32, global_condition_cardinality=2, local_condition_channels=80,
+                 upsample_factor=[5, 5, 12], train_mode=False)
+if args.workers: m.set_option("workers", args.workers)
+if args.groups >= 0: m.set_option("groups", args.groups)
+m.load_weights(W.random_tensors(m.specs, 0, 0.05))
+rng = np.random.RandomState(0)
+U = torch.from_numpy(rng.uniform(-1, 1, (B, T, 80)).astype(np.float32)).cuda()
+u = torch.from_numpy(rng.uniform(1e-5, 1 - 1e-5, (B, T, 11)).astype(np.float32)).cuda()
+NP = min(T, 2000)
+prof = torch.zeros((NP, 80), dtype=torch.int64, device="cuda")
+_lib.check(m._L.twv_wavenet_set_profile_buffer(m._h, C.c_void_p(prof.data_ptr()), NP))
+e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+m.generate(U, np.zeros(B, np.int32), np.zeros(B, np.float32), u)   # warm
+m.queue_initializer()
+e0.record(); m.generate(U, np.zeros(B, np.int32), np.zeros(B, np.float32), u, check=False); e1.record(); torch.cuda.synchronize()
+p = prof.cpu().numpy().astype(np.int64)
+s = p[100:NP]   # skip the cold start
+ticks = s[-1, 0] - s[0, 0]; wall = (s[-1, 7] - s[0, 7]) / 100e6
+mhz = ticks / wall / 1e6
+def us(a): return float(np.mean(a)) / mhz
+print("total kernel+cond %.2f ms for %d steps -> %.2f us/step (events); s_memtime clock %.0f MHz" % (e0.elapsed_time(e1), T, e0.elapsed_time(e1) * 1e3 / T, mhz))
+print("step period        %.2f us" % us(np.diff(s[:, 0])))
+print("causal layer       %.2f us" % us(s[:, 1] - s[:, 0]))
+print("residual stack     %.2f us  (%.3f us/layer)" % (us(s[:, 2] - s[:, 1]), us(s[:, 2] - s[:, 1]) / len(dil)))
+print("post (skip wait, conv1d_1, conv1d_2, sampler) %.2f us" % us(s[1:, 0] - s[:-1, 2]))
+lay = np.diff(np.concatenate([s[:, 1:2], s[:, 8:8 + len(dil)]], axis=1), axis=1)
+print("per-layer us:", " ".join("%.2f" % (v / mhz) for v in lay.mean(axis=0)))
+f = s[:, 72:77]
+print("layer 5 fine: wait_ready %.3f | tiles+conv %.3f | bias/act/z publish %.3f | dense+cdone %.3f us" % (
+    us(f[:, 1] - f[:, 0]), us(f[:, 2] - f[:, 1]), us(f[:, 3] - f[:, 2]), us(f[:, 4] - f[:, 3])))

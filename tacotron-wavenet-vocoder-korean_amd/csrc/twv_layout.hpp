@@ -14,15 +14,30 @@ namespace twv {
 constexpr int kTile = 2048;          // floats per tile
 constexpr int kMaxLayers = 64;
 
-// per-layer block of the packed layout (offsets in floats from the layer base)
+// per-layer block of the packed layout (offsets in floats from the layer base).  [T0 .. BD] is the CHAIN block: it is
+// contiguous so that the loader waves stage it into an LDS slot with 21 one-KiB LDS-DMA pieces.
 struct LayerOff {
     static constexpr int T0 = 0;             // conv_filter|conv_gate kernel, tap 0 (x[t-d])   model.py:68-69
     static constexpr int T1 = kTile;         // conv_filter|conv_gate kernel, tap 1 (x[t])
-    static constexpr int WD = 2 * kTile;     // dense kernel, outputs duplicated in both half-waves   model.py:89
-    static constexpr int BFG = 3 * kTile;    // 64: conv_filter bias | conv_gate bias
-    static constexpr int BD = 3 * kTile + 64;   // 64: dense bias duplicated
-    static constexpr int SK = 3 * kTile + 128;  // NSJ tiles: skip kernel   model.py:96
+    static constexpr int WD = 2 * kTile;     // dense kernel, HALF tile [kq=8][32][4]           model.py:89
+    static constexpr int BFG = 2 * kTile + 1024;   // 64: conv_filter bias | conv_gate bias
+    static constexpr int BD = BFG + 64;      // 32: dense bias (+32 pad)
+    static constexpr int SK = BD + 64;       // NSJ tiles: skip kernel   model.py:96
+    static constexpr int CHAIN_FLOATS = SK;  // 5248
     // BS = SK + NSJ*kTile : S floats skip bias
+};
+// LDS slot of one (layer, step) item staged by the loader waves: the layer's [T1|WD|BFG|BD] block (13 one-KiB LDS-DMA
+// pieces, same offsets as LayerOff minus T1), then x[t-d], the lc projection row and the loader-computed tap-0 chunk.
+struct SlotOff {
+    static constexpr int PIECES = 13;                      // ceil((CHAIN_FLOATS - kTile) * 4 / 1024)
+    static constexpr int T1 = 0;
+    static constexpr int WD = LayerOff::WD - LayerOff::T1;     // 2048
+    static constexpr int BFG = LayerOff::BFG - LayerOff::T1;   // 3072
+    static constexpr int BD = LayerOff::BD - LayerOff::T1;     // 3136
+    static constexpr int XO = PIECES * 256;                // 3328: x[t-d] (32, duplicated to 64)
+    static constexpr int LC = XO + 64;                     // lc projection row of this layer (64)
+    static constexpr int A0 = LC + 64;                     // tap-0 chunk of conv_filter|conv_gate (64), by the loader
+    static constexpr int FLOATS = A0 + 64;                 // 3520 floats = 14080 B
 };
 
 struct Layout {
@@ -36,6 +51,7 @@ struct Layout {
     int NLC;   // ceil(L/32)
     int NGC;   // ceil(G/32)
     int nr_mix;
+    int nslot;  // LDS slots of the chain-weight ring
     // packed offsets (floats)
     long long off_meta;      // int32: dil[64], ring_off[64] (ring offsets in floats within a stream's ring area)
     long long off_causal;    // scalar: NCA tiles (outputs duplicated); one-hot: [2][Q][32]

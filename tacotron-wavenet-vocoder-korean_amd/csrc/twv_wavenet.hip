@@ -42,65 +42,33 @@ __device__ __forceinline__ void load_tile(Tile& t, const float* base, int lane)
     }
 }
 
-// one chunk of AC-1: fma chain from +0 over 32 terms, operand vector distributed over lanes 0..31 of `xv`
+// one chunk of AC-1 (four interleaved fma chains, (s0+s1)+(s2+s3)), operand vector distributed over lanes 0..31 of `xv`.
+// The interleave is what hides v_readlane's ~17-cycle result latency (measured: 262 vs 540 ticks per chunk).
 __device__ __forceinline__ float dot_readlane(const Tile& t, float xv)
 {
-    float acc = 0.0f;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
-        const float s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), c));
-        acc = fma_(t.w[c], s, acc);
+    for (int c = 0; c < 32; c += 4) {
+        s0 = fma_(t.w[c + 0], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), c + 0)), s0);
+        s1 = fma_(t.w[c + 1], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), c + 1)), s1);
+        s2 = fma_(t.w[c + 2], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), c + 2)), s2);
+        s3 = fma_(t.w[c + 3], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), c + 3)), s3);
     }
-    return acc;
+    return (s0 + s1) + (s2 + s3);
 }
 
 // one chunk of AC-1, operand vector already in (uniform) registers
 __device__ __forceinline__ float dot_regs(const Tile& t, const float (&x)[32])
 {
-    float acc = 0.0f;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) acc = fma_(t.w[c], x[c], acc);
-    return acc;
-}
-
-// one chunk of AC-1, operand vector in LDS (same address in every lane: broadcast reads)
-__device__ __forceinline__ float dot_lds(const Tile& t, const float* xs)
-{
-    float acc = 0.0f;
-    const float4* p = reinterpret_cast<const float4*>(xs);
-#pragma unroll
-    for (int kq = 0; kq < 8; ++kq) {
-        const float4 q = p[kq];
-        acc = fma_(t.w[4 * kq + 0], q.x, acc);
-        acc = fma_(t.w[4 * kq + 1], q.y, acc);
-        acc = fma_(t.w[4 * kq + 2], q.z, acc);
-        acc = fma_(t.w[4 * kq + 3], q.w, acc);
+    for (int c = 0; c < 32; c += 4) {
+        s0 = fma_(t.w[c + 0], x[c + 0], s0);
+        s1 = fma_(t.w[c + 1], x[c + 1], s1);
+        s2 = fma_(t.w[c + 2], x[c + 2], s2);
+        s3 = fma_(t.w[c + 3], x[c + 3], s3);
     }
-    return acc;
-}
-
-__device__ __forceinline__ void read_lds32(float (&x)[32], const float* xs)
-{
-    const float4* p = reinterpret_cast<const float4*>(xs);
-#pragma unroll
-    for (int kq = 0; kq < 8; ++kq) {
-        const float4 q = p[kq];
-        x[4 * kq + 0] = q.x; x[4 * kq + 1] = q.y; x[4 * kq + 2] = q.z; x[4 * kq + 3] = q.w;
-    }
-}
-
-// bounded wait on an LDS sequence word written by another wave of the same workgroup.
-// Never hangs: after ~2^22 polls it raises the workgroup's abort word and returns.
-__device__ __forceinline__ bool wait_ge(volatile int* flag, int target, volatile int* abortf, int code)
-{
-    if (*flag >= target) return true;
-    for (int it = 0; it < (1 << 22); ++it) {
-        __builtin_amdgcn_s_sleep(1);
-        if (*flag >= target) return true;
-        if (*abortf) return false;
-    }
-    *abortf = code;
-    return false;
+    return (s0 + s1) + (s2 + s3);
 }
 
 // =====================================================================================================
@@ -109,20 +77,21 @@ __device__ __forceinline__ bool wait_ge(volatile int* flag, int target, volatile
 // dst tiles [g][jblk][chunk][kq][lane][4]; element = src[base(half) + g*sg + k*rowlen + jj] (0 outside K x ncols)
 struct PackTiles {
     long long dst_off, dst_gstride, baseA, baseB, src_gstride;
-    int ngroups, njblk, nchunk, K, rowlen, ncols, halves;
+    int ngroups, njblk, nchunk, K, rowlen, ncols, halves, lanes;
 };
 __global__ void wn_pack_tiles_kernel(float* dst, const float* src, PackTiles p)
 {
-    const long long per_g = (long long)p.njblk * p.nchunk * kTile;
+    const int tile = 32 * p.lanes;   // floats per tile: [kq=8][lanes][4]
+    const long long per_g = (long long)p.njblk * p.nchunk * tile;
     const long long total = per_g * p.ngroups;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int g = (int)(i / per_g);
         long long r = i - (long long)g * per_g;
-        const int jb = (int)(r / ((long long)p.nchunk * kTile));
-        r -= (long long)jb * p.nchunk * kTile;
-        const int ch = (int)(r / kTile);
-        const int e = (int)(r - (long long)ch * kTile);
-        const int kq = e >> 8, lane = (e >> 2) & 63, q = e & 3;
+        const int jb = (int)(r / ((long long)p.nchunk * tile));
+        r -= (long long)jb * p.nchunk * tile;
+        const int ch = (int)(r / tile);
+        const int e = (int)(r - (long long)ch * tile);
+        const int kq = e / (p.lanes * 4), lane = (e >> 2) % p.lanes, q = e & 3;
         const int k = ch * 32 + kq * 4 + q;
         const int j = jb * 64 + lane;
         float v = 0.0f;
@@ -134,7 +103,7 @@ __global__ void wn_pack_tiles_kernel(float* dst, const float* src, PackTiles p)
                 v = src[p.baseA + (long long)g * p.src_gstride + (long long)k * p.rowlen + j];
             }
         }
-        dst[p.dst_off + (long long)g * p.dst_gstride + r + (long long)jb * p.nchunk * kTile] = v;
+        dst[p.dst_off + (long long)g * p.dst_gstride + r + (long long)jb * p.nchunk * tile] = v;
     }
 }
 // vectors: dst[g][j] (n entries per group)
@@ -172,9 +141,9 @@ __global__ void wn_upsample_stage_kernel(const float* K, const float* in, float*
         const long long bt = ta / f;              // b*Tin + t
         const float x0 = in[bt * Lc + m];
         const float x1 = m > 0 ? in[bt * Lc + m - 1] : 0.0f;
-        float acc = fma_(K[a * 2 + 0], x0, 0.0f);
-        acc = fma_(K[a * 2 + 1], x1, acc);
-        out[i] = acc;
+        const float s0 = fma_(K[a * 2 + 0], x0, 0.0f);
+        const float s1 = fma_(K[a * 2 + 1], x1, 0.0f);
+        out[i] = (s0 + s1) + (0.0f + 0.0f);   // AC-1 chunk with two terms
     }
 }
 
@@ -195,10 +164,11 @@ __global__ void __launch_bounds__(64) wn_gc_kernel(const float* P, Layout L, con
             Tile t;
             load_tile(t, P + L.off_gcw + (long long)l * L.gcw_stride + (long long)c * kTile, lane);
             const int kn = min(32, L.G - c * 32);
-            float acc = 0.0f;
+            float sj[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int k = 0; k < 32; ++k)
-                if (k < kn) acc = fma_(t.w[k], emb[c * 32 + k], acc);
+                if (k < kn) sj[k & 3] = fma_(t.w[k], emb[c * 32 + k], sj[k & 3]);
+            const float acc = (sj[0] + sj[1]) + (sj[2] + sj[3]);
             res = c == 0 ? acc : res + acc;
         }
         GCv[((long long)b * L.NL + l) * 64 + lane] = res;
@@ -233,17 +203,18 @@ __global__ void __launch_bounds__(256) wn_lc_kernel(const float* P, Layout L, co
             if (c < L.NLC) {
                 const int kqn = min(8, (L.L - c * 32) >> 2);   // L % 4 == 0 (validated on the host)
                 const float4* p = reinterpret_cast<const float4*>(us + r * LP + c * 32);
-                float acc = 0.0f;
+                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
 #pragma unroll
                 for (int kq = 0; kq < 8; ++kq) {
                     if (kq < kqn) {
                         const float4 q = p[kq];
-                        acc = fma_(t[c].w[4 * kq + 0], q.x, acc);
-                        acc = fma_(t[c].w[4 * kq + 1], q.y, acc);
-                        acc = fma_(t[c].w[4 * kq + 2], q.z, acc);
-                        acc = fma_(t[c].w[4 * kq + 3], q.w, acc);
+                        s0 = fma_(t[c].w[4 * kq + 0], q.x, s0);
+                        s1 = fma_(t[c].w[4 * kq + 1], q.y, s1);
+                        s2 = fma_(t[c].w[4 * kq + 2], q.z, s2);
+                        s3 = fma_(t[c].w[4 * kq + 3], q.w, s3);
                     }
                 }
+                const float acc = (s0 + s1) + (s2 + s3);
                 res = c == 0 ? acc : res + acc;
             }
         }
@@ -264,7 +235,11 @@ struct GenArgs {
     int* status;               // [4]
     float* dbg;                // optional [B][dbg_steps][NL*64 + Opad]
     int dbg_steps;
+    unsigned long long* prof;  // optional [prof_steps][80] s_memtime stamps of stream 0's chain wave
+    int prof_steps;
     int B, T;
+    int G;                       // workgroups per stream (each owns 1/G of the skip / conv1d_1 outputs)
+    unsigned long long* exch;    // [B][2][S] {epoch,value} granules: all-gather of relu(skip sum) and relu(conv1d_1)
     float temperature;
     Layout lay;
 };
@@ -274,6 +249,14 @@ extern __shared__ __attribute__((aligned(16))) float lds[];
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 using rsrc_t = __amdgpu_buffer_rsrc_t;
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+// explicit LDS (address space 3) views of lds[]: a C++ cast to a generic pointer would turn the access into a FLAT
+// instruction (vector-memory path, microseconds under load) and hide the 16-byte alignment needed for ds_read_b128.
+#define LDSI(off) (((__attribute__((address_space(3))) int*)lds)[(off)])
+#define LDSVI(off) (((__attribute__((address_space(3))) volatile int*)lds)[(off)])
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define LDS4(off4) (((__attribute__((address_space(3))) f32x4*)lds)[(off4)])   /* offset in float4 units */
 
 // weight tile through a buffer descriptor: ONE per-lane offset VGPR (lane*16), tile position in an SGPR
 __device__ __forceinline__ void load_tile_b(Tile& t, rsrc_t r, int voff16, int soff_bytes)
@@ -290,108 +273,244 @@ __device__ __forceinline__ float load_f32_b(rsrc_t r, int voff4, int soff_bytes)
 {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff4, __builtin_amdgcn_readfirstlane(soff_bytes), 0));
 }
+// tile staged in LDS at float offset fo (same [kq][lane][4] image as in HBM): conflict-free ds_read_b128
+__device__ __forceinline__ void lds_tile(Tile& t, int fo, int lane)
+{
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) {
+        const f32x4 q = LDS4((fo >> 2) + kq * 64 + lane);
+        t.w[4 * kq + 0] = q.x; t.w[4 * kq + 1] = q.y; t.w[4 * kq + 2] = q.z; t.w[4 * kq + 3] = q.w;
+    }
+}
+// half tile [kq][32][4]: lanes l and l+32 read the same 16 bytes (broadcast)
+__device__ __forceinline__ void lds_half_tile(Tile& t, int fo, int lane)
+{
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) {
+        const f32x4 q = LDS4((fo >> 2) + kq * 32 + (lane & 31));
+        t.w[4 * kq + 0] = q.x; t.w[4 * kq + 1] = q.y; t.w[4 * kq + 2] = q.z; t.w[4 * kq + 3] = q.w;
+    }
+}
 
 // one chunk of AC-1, operand vector in LDS at float offset `xo` (same address in every lane: broadcast reads)
 __device__ __forceinline__ float dot_ldso(const Tile& t, int xo)
 {
-    float acc = 0.0f;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
 #pragma unroll
     for (int kq = 0; kq < 8; ++kq) {
-        const float4 q = *reinterpret_cast<const float4*>(&lds[xo + 4 * kq]);
-        acc = fma_(t.w[4 * kq + 0], q.x, acc);
-        acc = fma_(t.w[4 * kq + 1], q.y, acc);
-        acc = fma_(t.w[4 * kq + 2], q.z, acc);
-        acc = fma_(t.w[4 * kq + 3], q.w, acc);
+        const f32x4 q = LDS4((xo >> 2) + kq);
+        s0 = fma_(t.w[4 * kq + 0], q.x, s0);
+        s1 = fma_(t.w[4 * kq + 1], q.y, s1);
+        s2 = fma_(t.w[4 * kq + 2], q.z, s2);
+        s3 = fma_(t.w[4 * kq + 3], q.w, s3);
     }
-    return acc;
+    return (s0 + s1) + (s2 + s3);
 }
 
-// bounded wait on an LDS sequence word (float-offset `fo`) written by another wave of the same workgroup.
-// Never hangs: after ~2^22 polls it raises the workgroup's abort word and returns.
+// Intra-workgroup synchronisation is by monotonically increasing LDS sequence words only (no s_barrier inside the
+// sample loop, so the wave roles run decoupled).  Every wait is BOUNDED: after ~2^22 polls it raises the workgroup's
+// abort word, every other wait then falls through, and the launch ends with a watchdog code instead of hanging.
+enum { C_ZSEQ = 0, C_ABORT = 1, C_SAMPLE = 2, C_CDONE = 3, C_H1CNT = 4, C_H2CNT = 5, C_CPCNT = 6, C_SSEQ = 7, C_P1CNT = 8 };
+
 __device__ __forceinline__ bool wait_seq(int fo_flag, int target, int fo_abort, int code)
 {
-    volatile int* flag = reinterpret_cast<volatile int*>(&lds[fo_flag]);
-    volatile int* abortf = reinterpret_cast<volatile int*>(&lds[fo_abort]);
-    if (*flag >= target) return true;
+    if (LDSVI(fo_flag) >= target) return true;
     for (int it = 0; it < (1 << 22); ++it) {
         __builtin_amdgcn_s_sleep(1);
-        if (*flag >= target) return true;
-        if (*abortf) return false;
+        if (LDSVI(fo_flag) >= target) return true;
+        if (LDSVI(fo_abort)) return false;
     }
-    *abortf = code;
+    LDSVI(fo_abort) = code;
+    return false;
+}
+// All payloads guarded by these words live in LDS, and one wave's LDS operations are performed in issue order, so the
+// only ordering needed is "payload ds_write before flag ds_write" (program order) on the producer and "flag ds_read
+// before payload ds_read" on the consumer.  A workgroup-scope C++ fence would also drain vmcnt -- i.e. wait for every
+// outstanding HBM store/load of the wave (measured: +1.5 us per layer) -- so plain compiler barriers are used instead.
+__device__ __forceinline__ void publish(int fo_flag, int value, int lane)
+{
+    asm volatile("" ::: "memory");
+    if (lane == 0) LDSVI(fo_flag) = value;
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void arrive(int fo_cnt, int lane)
+{
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(&LDSI(fo_cnt), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#define ACQUIRE_WG() asm volatile("" ::: "memory")
+
+// ---- inter-workgroup all-gather (the G workgroups of one stream) -------------------------------------------------
+// Data-tagged 8-byte granules {epoch, value}: ONE naturally aligned agent-scope (sc1, write-through) store per value,
+// readers re-read with agent-scope loads until every tag equals the epoch -- no flag, no fence, placement independent
+// (MI355X per-XCD L2s are not coherent; sc1 accesses bypass the L1 and meet at memory side).  Polls are bounded.
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+__device__ __forceinline__ void granule_store(unsigned long long* p, unsigned epoch, float v)
+{
+    __hip_atomic_store((gu64*)p, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the W worker waves sweep all S granules of X into lds[o_dst .. o_dst+S)
+template <int W>
+__device__ __forceinline__ bool gather_granules(unsigned long long* X, int S, unsigned epoch, int o_dst, int w, int lane,
+                                                int fo_abort, int code)
+{
+    bool done[4] = {false, false, false, false};     // up to 4 granules per lane (S <= 1024 with W*64 = 256 lanes)
+    for (int it = 0; it < (1 << 20); ++it) {
+        bool all_ok = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = w * 64 + lane + k * W * 64;
+            if (idx < S && !done[k]) {
+                const unsigned long long v = __hip_atomic_load((gu64*)(X + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(v >> 32) == epoch) { lds[o_dst + idx] = __uint_as_float((unsigned)v); done[k] = true; }
+                else all_ok = false;
+            }
+        }
+        if (__all(all_ok)) return true;
+        if ((it & 15) == 15 && LDSVI(fo_abort)) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    LDSVI(fo_abort) = code;
     return false;
 }
 
 // per-workgroup context shared by the wave roles (LDS positions are float offsets into lds[])
 struct Ctx {
-    int o_zbuf, o_h1, o_h2, o_cpart, o_hist, o_ringpos, o_ctrl;   // ctrl: +0 zseq, +1 abort, +2 sample
-    int b, lane;
+    int o_zbuf, o_h1, o_h2, o_cpart, o_meta, o_ringpos, o_pos0, o_ready, o_ctrl, o_gc, o_ring1, o_causal, o_cpart1, o_slots;
+    int b, g, lane;
     float* stb;            // this stream's state
-    const int* pmeta;      // dil[64] | ring_off[64]
     float* ring;
     const float *GCv, *LCb;
 };
-#define LDSI(off) (reinterpret_cast<int*>(lds)[(off)])
-#define LDSVI(off) (reinterpret_cast<volatile int*>(lds)[(off)])
 
 // =============================== CHAIN WAVE (wave 0) ===============================
 // Walks model.py:112-149 for one stream: causal layer, then the dilated residual stack, one layer after the other.
+// Everything a layer needs (conv/dense weights, biases, x[t-d], lc projection) has been staged in an LDS slot by the
+// loader waves; the gc projections and the causal kernel are LDS-resident for the whole launch.
+// registers holding everything the chain needs for ONE layer (filled from the layer's LDS slot one layer ahead)
+struct LayerRegs {
+    Tile w1, wd;                       // tap-1 conv tile, dense half tile
+    float pre, bfg, gcv, lcv, bd;      // tap-0 chunk (by the loader), biases, gc / lc projections
+};
+__device__ __forceinline__ void fetch_layer(LayerRegs& r, const Ctx& c, int sb, int l, int lane, bool use_bias, bool has_gc, bool has_lc)
+{
+    lds_tile(r.w1, sb + SlotOff::T1, lane);
+    lds_half_tile(r.wd, sb + SlotOff::WD, lane);
+    r.pre = lds[sb + SlotOff::A0 + lane];
+    r.bfg = use_bias ? lds[sb + SlotOff::BFG + lane] : 0.0f;
+    r.bd = use_bias ? lds[sb + SlotOff::BD + (lane & 31)] : 0.0f;
+    r.gcv = has_gc ? lds[c.o_gc + l * 64 + lane] : 0.0f;
+    r.lcv = has_lc ? lds[sb + SlotOff::LC + lane] : 0.0f;
+}
+
 template <bool SCALAR>
-__device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, rsrc_t rs, int& hpos, int& prev_valid, int& qprev)
+__device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& hpos, int& prev_valid, int& qprev)
 {
     const Layout& L = a.lay;
-    const int NL = L.NL, T = a.T, lane = c.lane, b = c.b;
-    const int v16 = lane * 16, v4 = lane * 4;
+    const int NL = L.NL, T = a.T, lane = c.lane, b = c.b, nslot = L.nslot;
     const bool has_gc = L.G > 0, has_lc = L.L > 0, use_bias = L.use_bias != 0;
-    const int lay0 = (int)L.off_layer0 * 4, lstride = (int)L.layer_stride * 4;   // bytes
     const ActCoef coef = act_coef(lane >= 32);
-    Tile wt0, wt1, wdd;            // tap-0 / tap-1 conv tiles and dense tile of the NEXT layer to process
-    float n_xo = 0.f, n_bfg = 0.f, n_bd = 0.f, n_gc = 0.f, n_lc = 0.f;
+    const int ctl = c.o_ctrl;
+    const long long total = (long long)T * NL;
+    int item = 0, slot = 0;
+    // causal_queue (model.py:52): lane k holds the k-th oldest of the last ifw input samples
+    float hv = SCALAR ? c.stb[L.st_hist + lane] : 0.0f;
+    Tile tc[2];
+    if (SCALAR) {
+        lds_half_tile(tc[0], c.o_causal, lane);
+        if (L.NCA > 1) lds_half_tile(tc[1], c.o_causal + 1024, lane);
+    }
+    LayerRegs RA, RB;
+    float x = 0.0f;
+    bool prof = false;
+    unsigned long long* pp = a.prof;
 
-    auto prefetch_vec = [&](int l, int tt) {
-        const int lb = lay0 + l * lstride;
-        n_xo = c.ring[c.pmeta[64 + l] + LDSI(c.o_ringpos + l) * 32 + (lane & 31)];
-        if (use_bias) { n_bfg = load_f32_b(rs, v4, lb + LayerOff::BFG * 4); n_bd = load_f32_b(rs, v4, lb + LayerOff::BD * 4); }
-        if (has_gc) n_gc = c.GCv[l * 64 + lane];
-        if (has_lc) {
-            // lc frame used at step tt = frame PUSHED at step tt-1 (model.py:79-80: slice from the FRONT of the queue)
-            const float* row = tt == 0 ? (c.stb + L.st_lcprev) : (c.LCb + (long long)(min(tt, T) - 1) * NL * 64);
-            n_lc = row[l * 64 + lane];
+    // one layer: `cur` holds this layer's operands; `nxt` is filled for the following item while the dense conv runs
+    auto layer = [&](LayerRegs& cur, LayerRegs& nxt, int l, int t) {
+        const bool fine = prof && l == 5 && lane == 0;
+        if (fine) pp[72] = __builtin_amdgcn_s_memtime();
+        // model.py:145 dilation queue <- the layer INPUT x[t].  The chain only drops it in LDS; a loader wave moves it to
+        // the stream's delay line in HBM (under streaming load every VMEM instruction issued here would stall the chain).
+        if (lane < 32) lds[c.o_ring1 + l * 32 + lane] = x;
+        // is the NEXT item staged?  (read early, consumed after the gated unit)
+        const int nslot_i = (slot + 1 == nslot) ? 0 : slot + 1;
+        const bool have_next = (long long)item + 1 < total;
+        const int rdy = have_next ? LDSVI(c.o_ready + nslot_i) : 0x7fffffff;
+
+        // model.py:68-69 conv_filter | conv_gate: chunk(tap0) [precomputed by the loader] + chunk(tap1)
+        const float acc1 = dot_readlane(cur.w1, x);
+        float v = cur.pre + acc1;
+        if (use_bias) v = v + cur.bfg;
+        if (has_gc) v = v + cur.gcv;      // model.py:71-73
+        if (has_lc) v = v + cur.lcv;      // model.py:75-83
+        // every operand of THIS item now sits in registers (LDS returns in order): its slot may be refilled
+        publish(ctl + C_CDONE, item + 1, lane);
+        if (fine) pp[74] = __builtin_amdgcn_s_memtime();
+        // model.py:86 tanh(filter) * sigmoid(gate): lanes 0-31 hold tanh, lanes 32-63 the logistic
+        const float act = act_eval(coef, v);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
+        const float z = __uint_as_float(sw[0]) * __uint_as_float(sw[1]);   // every lane: z[lane & 31]
+        if (lane < 32) lds[c.o_zbuf + l * 32 + lane] = z;
+        publish(ctl + C_ZSEQ, item + 1, lane);
+        if (fine) pp[75] = __builtin_amdgcn_s_memtime();
+
+        // stage the next layer's operands into registers (LDS latency hides under the dense conv below)
+        if (have_next) {
+            if (rdy < item + 2) wait_seq(c.o_ready + nslot_i, item + 2, ctl + C_ABORT, 200 + l);
+            ACQUIRE_WG();
+            const int ln = (l + 1 < NL) ? l + 1 : 0;
+            fetch_layer(nxt, c, c.o_slots + nslot_i * SlotOff::FLOATS, ln, lane, use_bias, has_gc, has_lc);
         }
+        // model.py:89 dense 1x1, model.py:98-101 residual
+        float tr = dot_readlane(cur.wd, z);
+        if (use_bias) tr = tr + cur.bd;
+        x = x + tr;
+        if (a.dbg != nullptr && c.g == 0 && t < a.dbg_steps) {
+            float* dp = a.dbg + ((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)l * 64;
+            if (lane < 32) { dp[lane] = z; dp[32 + lane] = x; }
+        }
+        if (fine) pp[76] = __builtin_amdgcn_s_memtime();
+        if (prof && lane == 0) pp[8 + l] = __builtin_amdgcn_s_memtime();
+        ++item;
+        slot = nslot_i;
     };
 
     __builtin_amdgcn_s_setprio(3);
-    load_tile_b(wt0, rs, v16, lay0 + LayerOff::T0 * 4);
-    load_tile_b(wt1, rs, v16, lay0 + LayerOff::T1 * 4);
-    load_tile_b(wdd, rs, v16, lay0 + LayerOff::WD * 4);
-    prefetch_vec(0, 0);
+    // operands of item 0
+    wait_seq(c.o_ready + 0, 1, ctl + C_ABORT, 199);
+    ACQUIRE_WG();
+    fetch_layer(RA, c, c.o_slots, 0, lane, use_bias, has_gc, has_lc);
+    bool curA = true;   // which register set holds the current layer
 
     for (int t = 0; t < T; ++t) {
-        float x;
+        prof = a.prof != nullptr && b == 0 && c.g == 0 && t < a.prof_steps;
+        pp = a.prof + (long long)t * 80;
+        if (t > 0) { wait_seq(ctl + C_SSEQ, t, ctl + C_ABORT, 3); ACQUIRE_WG(); }   // sample t-1 published
+        if (prof && lane == 0) { pp[0] = __builtin_amdgcn_s_memtime(); pp[7] = wall_clock64(); }
         if (SCALAR) {
             // model.py:122 causal_queue shift+append; model.py:41-46 causal conv (k = ifw, no bias)
-            const float s_in = (t == 0) ? reinterpret_cast<const float*>(a.first_input)[b] : lds[c.o_ctrl + 2];
-            if (lane == 0) lds[c.o_hist + hpos] = s_in;
-            hpos = (hpos + 1 == L.ifw) ? 0 : hpos + 1;   // now the position of the OLDEST sample
+            const float s_in = (t == 0) ? reinterpret_cast<const float*>(a.first_input)[b] : lds[ctl + C_SAMPLE];
+            const float sh = __shfl_down(hv, 1);
+            hv = (lane == L.ifw - 1) ? s_in : sh;
             x = 0.0f;
-            for (int ca = 0; ca < L.NCA; ++ca) {
-                Tile tc;
-                load_tile_b(tc, rs, v16, ((int)L.off_causal + ca * kTile) * 4);
-                float acc = 0.0f;
 #pragma unroll
-                for (int k0 = 0; k0 < 32; ++k0) {
-                    const int k = ca * 32 + k0;
-                    if (k < L.ifw) {
-                        int idx = hpos + k;
-                        idx = idx >= L.ifw ? idx - L.ifw : idx;
-                        acc = fma_(tc.w[k0], lds[c.o_hist + idx], acc);
+            for (int ca = 0; ca < 2; ++ca) {
+                if (ca < L.NCA) {
+                    float sj[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int k0 = 0; k0 < 32; ++k0) {
+                        const float hk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), ca * 32 + k0));
+                        const float nacc = fma_(tc[ca].w[k0], hk, sj[k0 & 3]);
+                        sj[k0 & 3] = (ca * 32 + k0 < L.ifw) ? nacc : sj[k0 & 3];
                     }
+                    const float acc = (sj[0] + sj[1]) + (sj[2] + sj[3]);
+                    x = ca == 0 ? acc : x + acc;
                 }
-                x = ca == 0 ? acc : x + acc;
             }
         } else {
             // one-hot input: the k=2 causal conv over one-hot rows is the sum of two kernel rows
-            const int qcur = (t == 0) ? reinterpret_cast<const int*>(a.first_input)[b] : LDSI(c.o_ctrl + 2);
+            const int qcur = (t == 0) ? reinterpret_cast<const int*>(a.first_input)[b] : LDSI(ctl + C_SAMPLE);
             const float w1 = a.P[L.off_causal + ((long long)L.Q + qcur) * 32 + (lane & 31)];
             if (prev_valid) {
                 const float w0 = a.P[L.off_causal + (long long)qprev * 32 + (lane & 31)];
@@ -401,76 +520,138 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, rsrc_
             }
             qprev = qcur; prev_valid = 1;
         }
+        if (prof && lane == 0) pp[1] = __builtin_amdgcn_s_memtime();
 
-        for (int l = 0; l < NL; ++l) {
-            // vectors of this layer were prefetched one layer (or one step) ago
-            const float xo = n_xo, bfg = n_bfg, bd = n_bd, gcv = n_gc, lcv = n_lc;
-            // model.py:145 dilation queue: slot holds x[t-d]; overwrite it with the layer INPUT x[t]
-            const int d = c.pmeta[l];
-            const int pos = LDSI(c.o_ringpos + l);
-            if (lane < 32) c.ring[c.pmeta[64 + l] + pos * 32 + lane] = x;
-            if (lane == 0) LDSI(c.o_ringpos + l) = (pos + 1 == d) ? 0 : pos + 1;
-            const int ln = (l + 1 < NL) ? l + 1 : 0;
-            const int tn = (l + 1 < NL) ? t : t + 1;
-            prefetch_vec(ln, tn);
-            const int lnb = lay0 + ln * lstride;
-
-            // model.py:68-69 conv_filter | conv_gate: chunk(tap0) + chunk(tap1)
-            const float acc0 = dot_readlane(wt0, xo);
-            __builtin_amdgcn_sched_barrier(0);
-            load_tile_b(wt0, rs, v16, lnb + LayerOff::T0 * 4);
-            const float acc1 = dot_readlane(wt1, x);
-            __builtin_amdgcn_sched_barrier(0);
-            load_tile_b(wt1, rs, v16, lnb + LayerOff::T1 * 4);
-            float v = acc0 + acc1;
-            if (use_bias) v = v + bfg;
-            if (has_gc) v = v + gcv;      // model.py:71-73
-            if (has_lc) v = v + lcv;      // model.py:75-83
-            // model.py:86 tanh(filter) * sigmoid(gate): lanes 0-31 hold tanh, lanes 32-63 the logistic
-            const float act = act_eval(coef, v);
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
-            const float z = __uint_as_float(sw[0]) * __uint_as_float(sw[1]);   // every lane: z[lane & 31]
-            if (lane < 32) lds[c.o_zbuf + l * 32 + lane] = z;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) LDSVI(c.o_ctrl + 0) = t * NL + l + 1;
-
-            // model.py:89 dense 1x1, model.py:98-101 residual
-            float tr = dot_readlane(wdd, z);
-            __builtin_amdgcn_sched_barrier(0);
-            load_tile_b(wdd, rs, v16, lnb + LayerOff::WD * 4);
-            if (use_bias) tr = tr + bd;
-            x = x + tr;
-            if (a.dbg != nullptr && t < a.dbg_steps) {
-                float* dp = a.dbg + ((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)l * 64;
-                if (lane < 32) { dp[lane] = z; dp[32 + lane] = x; }
-            }
+        int l = 0;
+        if (!curA && l < NL) { layer(RB, RA, l, t); ++l; curA = true; }
+        for (; l + 1 < NL; l += 2) {
+            layer(RA, RB, l, t);
+            layer(RB, RA, l + 1, t);
         }
-        __syncthreads();   // B1
-        __syncthreads();   // B2
-        __syncthreads();   // B3
-        __syncthreads();   // B4: next input sample published
-        if (LDSVI(c.o_ctrl + 1)) break;
+        if (l < NL) { layer(RA, RB, l, t); curA = false; }
+
+        if (prof && lane == 0) pp[2] = __builtin_amdgcn_s_memtime();
+        if (LDSVI(ctl + C_ABORT)) break;
+    }
+    if (SCALAR) c.stb[L.st_hist + lane] = hv;
+}
+
+// =============================== LOADER WAVES ===============================
+// Stage item i = (layer l, step t) into LDS slot i % nslot, NLD waves taking items round-robin:
+//   the layer's chain block [T0|T1|WD|BFG|BD] as 21 one-KiB LDS-DMA pieces, x[t-d] from the stream's delay line in HBM
+//   (the slot the chain wave will overwrite when it reaches this item), and the hoisted lc projection row.
+template <int NLD>
+__device__ __forceinline__ void loader_main(const GenArgs& a, const Ctx& c, rsrc_t rs, int k)
+{
+    const Layout& L = a.lay;
+    const int NL = L.NL, T = a.T, lane = c.lane, nslot = L.nslot;
+    const bool has_lc = L.L > 0;
+    const int ctl = c.o_ctrl;
+    const int v16 = lane * 16;
+    const long long total = (long long)T * NL;
+    long long nxt = k;                 // next item this wave stages
+    int pend = 0;                      // items in flight (at most 2: the 6-bit vmcnt holds 2 x 24 operations)
+    int slotA = 0, itemA = 0, layA = 0, slotB = 0, itemB = 0, layB = 0;   // A = older, B = newer
+    Tile t0A, t0B;                     // tap-0 conv tiles of the items in flight (never touch LDS)
+
+    // delay-line write-back of item jb = (lb, tb): x_lb[tb] was left in LDS by the chain wave
+    auto write_back = [&](long long jb) {
+        const int tb = (int)(jb / NL), lb = (int)(jb - (long long)tb * NL);
+        const unsigned d = (unsigned)LDSI(c.o_meta + lb);
+        if (d > 1) {
+            const unsigned pos = ((unsigned)LDSI(c.o_pos0 + lb) + (unsigned)tb) % d;
+            const float xv = lds[c.o_ring1 + lb * 32 + (lane & 31)];
+            if (lane < 32) c.ring[LDSI(c.o_meta + 64 + lb) + pos * 32 + lane] = xv;
+        }
+    };
+
+    for (;;) {
+        const bool can_issue = nxt < total && pend < 2 &&
+                               (nxt < nslot || LDSVI(ctl + C_CDONE) >= (int)(nxt - nslot + 1));
+        if (can_issue) {
+            const int t = (int)(nxt / NL), l = (int)(nxt - (long long)t * NL);
+            const int slot = (int)(nxt % nslot);
+            const int sb = c.o_slots + slot * SlotOff::FLOATS;
+            // (1) CDONE >= nxt-nslot+1 says the chain has started item nxt-nslot: its layer input sits in LDS -> HBM
+            if (nxt >= nslot) write_back(nxt - nslot);
+            // (2) tap-0 tile straight into registers, (3) the chain block, x[t-d] and the lc row by LDS-DMA
+            const int lb4 = ((int)L.off_layer0 + l * (int)L.layer_stride) * 4;
+            if (pend == 0) load_tile_b(t0A, rs, v16, lb4 + LayerOff::T0 * 4); else load_tile_b(t0B, rs, v16, lb4 + LayerOff::T0 * 4);
+            const float* src = a.P + L.off_layer0 + (long long)l * L.layer_stride + LayerOff::T1 + lane * 4;
+#pragma unroll
+            for (int p = 0; p < SlotOff::PIECES; ++p)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + p * 256), (lptr_t)(lds + sb + p * 256), 16, 0, 0);
+            {   // x[t-d]: the delay line's write position at step t (it advances by one per step)
+                const unsigned d = (unsigned)LDSI(c.o_meta + l);
+                const unsigned pos = ((unsigned)LDSI(c.o_pos0 + l) + (unsigned)t) % d;
+                const float* xs = c.ring + LDSI(c.o_meta + 64 + l) + pos * 32 + (lane & 31);
+                __builtin_amdgcn_global_load_lds((gptr_t)xs, (lptr_t)(lds + sb + SlotOff::XO), 4, 0, 0);
+            }
+            {
+                // lc frame used at step t = frame PUSHED at step t-1 (model.py:79-80: slice from the FRONT of the queue);
+                // without local conditioning the piece is still issued (from the zeroed lcprev area) to keep counts fixed
+                const float* row = (t == 0 || !has_lc) ? (c.stb + L.st_lcprev) : (c.LCb + (long long)(t - 1) * NL * 64);
+                __builtin_amdgcn_global_load_lds((gptr_t)(row + l * 64 + lane), (lptr_t)(lds + sb + SlotOff::LC), 4, 0, 0);
+            }
+            if (pend == 0) { slotA = slot; itemA = (int)nxt; layA = l; } else { slotB = slot; itemB = (int)nxt; layB = l; }
+            ++pend;
+            nxt += NLD;
+            continue;
+        }
+        if (pend > 0) {
+            // the OLDER item has landed once at most the newer item's 8 + 15 operations are outstanding
+            // (an interleaved write-back store is older than those, so it is covered too)
+            if (pend == 2) asm volatile("s_waitcnt vmcnt(23)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            {
+                // tap-0 chunk of conv_filter|conv_gate (model.py:68-69): depends on x[t-d] only, so it is taken off the
+                // chain wave's critical path: acc0[lane] = sum_c T0[c][lane] * x[t-d][c]   (one AC-1 chunk)
+                const int sbA = c.o_slots + slotA * SlotOff::FLOATS;
+                const int xsrc = LDSI(c.o_meta + layA) == 1 ? c.o_ring1 + layA * 32 : sbA + SlotOff::XO;
+                lds[sbA + SlotOff::A0 + lane] = dot_ldso(t0A, xsrc);
+            }
+            publish(c.o_ready + slotA, itemA + 1, lane);
+            slotA = slotB; itemA = itemB; layA = layB; t0A = t0B;
+            --pend;
+            continue;
+        }
+        if (nxt >= total) break;
+        if (!wait_seq(ctl + C_CDONE, (int)(nxt - nslot + 1), ctl + C_ABORT, 300)) break;
+    }
+    // write-backs of the last nslot items: wait until the chain has run them
+    for (long long jb = nxt - nslot; jb < total; jb += NLD) {
+        if (jb < 0) continue;
+        if (!wait_seq(ctl + C_ZSEQ, (int)(jb + 1), ctl + C_ABORT, 301)) break;
+        write_back(jb);
     }
 }
 
-// =============================== WORKER WAVES (waves 1..W) ===============================
+// =============================== WORKER WAVES ===============================
 // model.py:94-96 skip 1x1 convs and their sum, model.py:150-165 postprocessing, mixture.py:84-114 sampling.
+// Workgroup g of a stream owns the output blocks jb with jb % G == g of the skip sum and of conv1d_1 (local index
+// m = jb / G); the two 512-vectors in between are all-gathered across the G workgroups; conv1d_2 and the sampler run
+// redundantly in every workgroup (identical bits), so each of them feeds its own chain wave without another hop.
 template <int W, int NTW, bool SCALAR>
 __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc_t rs, int w)
 {
     const Layout& L = a.lay;
-    const int NL = L.NL, T = a.T, NSJ = L.NSJ, NCH = L.NCH, lane = c.lane, b = c.b;
+    const int NL = L.NL, T = a.T, NSJ = L.NSJ, NCH = L.NCH, S = L.S, lane = c.lane, b = c.b, G = a.G, g = c.g;
+    const int NSJL = NSJ / G;                       // output blocks owned by this workgroup
+    const bool split1 = NSJL < W;                   // conv1d_1: spread the chunks of a block over the workers
     const int v16 = lane * 16, v4 = lane * 4;
     const bool use_bias = L.use_bias != 0;
+    const int ctl = c.o_ctrl;
     const int lay0 = (int)L.off_layer0 * 4, lstride = (int)L.layer_stride * 4;   // bytes
     const int skb = LayerOff::SK * 4, bsb = (LayerOff::SK + NSJ * kTile) * 4;
+    unsigned long long* X1 = a.exch + ((long long)b * 2 + 0) * S;
+    unsigned long long* X2 = a.exch + ((long long)b * 2 + 1) * S;
     Tile tk[NTW];
     float n_bs[NTW];
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
-        const int jb = w + n * W;
+        const int m = w + n * W, jb = m * G + g;
         n_bs[n] = 0.0f;
-        if (jb < NSJ) {
+        if (m < NSJL) {
             load_tile_b(tk[n], rs, v16, lay0 + skb + jb * kTile * 4);
             if (use_bias) n_bs[n] = load_f32_b(rs, v4, lay0 + bsb + jb * 256);
         }
@@ -481,47 +662,57 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
             float tot[NTW];
 #pragma unroll
             for (int n = 0; n < NTW; ++n) tot[n] = 0.0f;
-            for (int l = 0; l < NL; ++l) {
-                wait_seq(c.o_ctrl + 0, t * NL + l + 1, c.o_ctrl + 1, 100 + l);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                float zz[32];
+            if (w < NSJL) {   // (workers without an output block skip the whole pass)
+                for (int l = 0; l < NL; ++l) {
+                    wait_seq(ctl + C_ZSEQ, t * NL + l + 1, ctl + C_ABORT, 100 + l);
+                    ACQUIRE_WG();
+                    float zz[32];
 #pragma unroll
-                for (int kq = 0; kq < 8; ++kq) {
-                    const float4 q = *reinterpret_cast<const float4*>(&lds[c.o_zbuf + l * 32 + 4 * kq]);
-                    zz[4 * kq + 0] = q.x; zz[4 * kq + 1] = q.y; zz[4 * kq + 2] = q.z; zz[4 * kq + 3] = q.w;
-                }
-                const int ln = (l + 1 < NL) ? l + 1 : 0;
-                const int lnb = lay0 + ln * lstride;
+                    for (int kq = 0; kq < 8; ++kq) {
+                        const f32x4 q = LDS4(((c.o_zbuf + l * 32) >> 2) + kq);
+                        zz[4 * kq + 0] = q.x; zz[4 * kq + 1] = q.y; zz[4 * kq + 2] = q.z; zz[4 * kq + 3] = q.w;
+                    }
+                    const int ln = (l + 1 < NL) ? l + 1 : 0;
+                    const int lnb = lay0 + ln * lstride;
 #pragma unroll
-                for (int n = 0; n < NTW; ++n) {
-                    const int jb = w + n * W;
-                    if (jb < NSJ) {
-                        float v = dot_regs(tk[n], zz);               // model.py:96 skip 1x1
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (use_bias) v = v + n_bs[n];
-                        tot[n] = (l == 0) ? v : tot[n] + v;          // model.py:154 sum(outputs)
-                        load_tile_b(tk[n], rs, v16, lnb + skb + jb * kTile * 4);
-                        if (use_bias) n_bs[n] = load_f32_b(rs, v4, lnb + bsb + jb * 256);
+                    for (int n = 0; n < NTW; ++n) {
+                        const int m = w + n * W, jb = m * G + g;
+                        if (m < NSJL) {
+                            float v = dot_regs(tk[n], zz);               // model.py:96 skip 1x1
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (use_bias) v = v + n_bs[n];
+                            tot[n] = (l == 0) ? v : tot[n] + v;          // model.py:154 sum(outputs)
+                            load_tile_b(tk[n], rs, v16, lnb + skb + jb * kTile * 4);
+                            if (use_bias) n_bs[n] = load_f32_b(rs, v4, lnb + bsb + jb * 256);
+                        }
                     }
                 }
             }
 #pragma unroll
             for (int n = 0; n < NTW; ++n) {
-                const int jb = w + n * W;
-                if (jb < NSJ) lds[c.o_h1 + jb * 64 + lane] = tot[n] > 0.0f ? tot[n] : 0.0f;   // model.py:157 relu
+                const int m = w + n * W, jb = m * G + g;
+                if (m < NSJL) {
+                    const float h = tot[n] > 0.0f ? tot[n] : 0.0f;       // model.py:157 relu
+                    if (G == 1) lds[c.o_h1 + jb * 64 + lane] = h;
+                    else granule_store(X1 + jb * 64 + lane, 2u * (unsigned)t + 1u, h);
+                }
             }
         }
-        __syncthreads();   // B1: h1 complete
-        {
-            // ---- model.py:158-160 conv1d_1 (S->S) + relu: worker owns output blocks jb = w + n*W, all chunks in order
+        if (G > 1) gather_granules<W>(X1, S, 2u * (unsigned)t + 1u, c.o_h1, w, lane, ctl + C_ABORT, 7);
+        arrive(ctl + C_H1CNT, lane);
+        wait_seq(ctl + C_H1CNT, W * (t + 1), ctl + C_ABORT, 4);   // h1 complete in this workgroup's LDS
+        ACQUIRE_WG();
+        // ---- model.py:158-160 conv1d_1 (S->S) + relu for the owned output blocks
+        if (!split1) {
+            // a worker owns whole output blocks m = w + n*W and walks their chunks in order
             int nown = 0;
 #pragma unroll
-            for (int n = 0; n < NTW; ++n) if (w + n * W < NSJ) nown = n + 1;
+            for (int n = 0; n < NTW; ++n) if (w + n * W < NSJL) nown = n + 1;
             const int ntiles = nown * NCH;
             Tile ta, tb;
             auto tile_off = [&](int i) -> int {
                 const int n = i / NCH, ch = i - n * NCH;
-                return ((int)L.off_w1 + ((w + n * W) * NCH + ch) * kTile) * 4;
+                return ((int)L.off_w1 + (((w + n * W) * G + g) * NCH + ch) * kTile) * 4;
             };
             if (ntiles > 0) { load_tile_b(ta, rs, v16, tile_off(0)); load_tile_b(tb, rs, v16, tile_off(1)); }
             float r = 0.0f;
@@ -536,13 +727,49 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                 r = r + acc;
                 if (i + 3 < ntiles) load_tile_b(tb, rs, v16, tile_off(i + 3));
                 if (ch + 2 == NCH) {
-                    const int j = (w + n * W) * 64 + lane;
-                    if (use_bias) r = r + load_f32_b(rs, v4, ((int)L.off_b1 + (w + n * W) * 64) * 4);
-                    lds[c.o_h2 + j] = r > 0.0f ? r : 0.0f;
+                    const int jb = (w + n * W) * G + g;
+                    if (use_bias) r = r + load_f32_b(rs, v4, ((int)L.off_b1 + jb * 64) * 4);
+                    const float h = r > 0.0f ? r : 0.0f;
+                    if (G == 1) lds[c.o_h2 + jb * 64 + lane] = h;
+                    else granule_store(X2 + jb * 64 + lane, 2u * (unsigned)t + 2u, h);
                 }
             }
+        } else {
+            // few output blocks: tiles (m, ch) round-robin over the workers, chunk values summed in order afterwards
+            for (int idx = w; idx < NSJL * NCH; idx += W) {
+                const int m = idx / NCH, ch = idx - m * NCH;
+                Tile tq;
+                load_tile_b(tq, rs, v16, ((int)L.off_w1 + ((m * G + g) * NCH + ch) * kTile) * 4);
+                lds[c.o_cpart1 + idx * 64 + lane] = dot_ldso(tq, c.o_h1 + ch * 32);
+            }
+            arrive(ctl + C_P1CNT, lane);
+            if (w < NSJL) {
+                const int jb = w * G + g;
+                const float b1v = use_bias ? load_f32_b(rs, v4, ((int)L.off_b1 + jb * 64) * 4) : 0.0f;
+                wait_seq(ctl + C_P1CNT, W * (t + 1), ctl + C_ABORT, 8);
+                ACQUIRE_WG();
+                float r = 0.0f;
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const float cp = lds[c.o_cpart1 + (w * NCH + ch) * 64 + lane];
+                    r = (ch == 0) ? cp : r + cp;
+                }
+                if (use_bias) r = r + b1v;
+                const float h = r > 0.0f ? r : 0.0f;
+                if (G == 1) lds[c.o_h2 + jb * 64 + lane] = h;
+                else granule_store(X2 + jb * 64 + lane, 2u * (unsigned)t + 2u, h);
+            }
         }
-        __syncthreads();   // B2: h2 complete
+        // prefetches that do not depend on h2 (the sampler's inputs)
+        float u_pre = 0.5f, b2_pre = 0.0f;
+        if (SCALAR && w == 0) {
+            const float* up = reinterpret_cast<const float*>(a.uniforms) + ((long long)b * T + t) * (L.nr_mix + 1);
+            if (lane <= L.nr_mix) u_pre = up[lane];
+            if (use_bias && lane < L.O) b2_pre = a.P[L.off_b2 + lane];
+        }
+        if (G > 1) gather_granules<W>(X2, S, 2u * (unsigned)t + 2u, c.o_h2, w, lane, ctl + C_ABORT, 9);
+        arrive(ctl + C_H2CNT, lane);
+        wait_seq(ctl + C_H2CNT, W * (t + 1), ctl + C_ABORT, 5);   // h2 complete
+        ACQUIRE_WG();
         {
             // ---- model.py:161-165 conv1d_2 (S->O): chunk partials, summed in order by the sampler wave
             for (int idx = w; idx < L.NOJ * NCH; idx += W) {
@@ -552,8 +779,10 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                 lds[c.o_cpart + idx * 64 + lane] = dot_ldso(tq, c.o_h2 + ch * 32);
             }
         }
-        __syncthreads();   // B3: chunk partials complete
+        arrive(ctl + C_CPCNT, lane);
         if (w == 0) {
+            wait_seq(ctl + C_CPCNT, W * (t + 1), ctl + C_ABORT, 6);   // chunk partials complete
+            ACQUIRE_WG();
             if (SCALAR) {
                 // raw network output y[lane] (lane < O), then mixture.py:84-114
                 float y = 0.0f;
@@ -561,17 +790,16 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                     const float cp = lds[c.o_cpart + ch * 64 + lane];
                     y = (ch == 0) ? cp : y + cp;
                 }
-                if (use_bias && lane < L.O) y = y + a.P[L.off_b2 + lane];
-                if (a.dbg != nullptr && t < a.dbg_steps)
+                if (use_bias && lane < L.O) y = y + b2_pre;
+                if (a.dbg != nullptr && g == 0 && t < a.dbg_steps)
                     a.dbg[((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)NL * 64 + lane] = y;
                 const int nr = L.nr_mix;
-                const float* up = reinterpret_cast<const float*>(a.uniforms) + ((long long)b * T + t) * (nr + 1);
-                const float u = lane <= nr ? up[lane] : 0.5f;
-                const float g = y - log_e(-log_e(u));                        // mixture.py:103 (lanes < nr)
+                const float u = u_pre;
+                const float gmb = y - log_e(-log_e(u));                      // mixture.py:103 (lanes < nr)
                 int k = 0;
-                float best = __shfl(g, 0);
+                float best = __shfl(gmb, 0);
                 for (int i = 1; i < nr; ++i) {
-                    const float gi = __shfl(g, i);
+                    const float gi = __shfl(gmb, i);
                     if (gi > best) { best = gi; k = i; }
                 }
                 const float mean = __shfl(y, nr + k);                        // mixture.py:105
@@ -586,18 +814,20 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                 xs = xs > -1.0f ? xs : -1.0f;                                // mixture.py:113
                 xs = xs < 1.0f ? xs : 1.0f;
                 if (lane == 0) {
-                    reinterpret_cast<float*>(a.out)[(long long)b * T + t] = xs;
-                    lds[c.o_ctrl + 2] = xs;
+                    if (g == 0) reinterpret_cast<float*>(a.out)[(long long)b * T + t] = xs;
+                    lds[ctl + C_SAMPLE] = xs;
                 }
             }
+            publish(ctl + C_SSEQ, t + 1, lane);   // next input sample published
         }
-        __syncthreads();   // B4: next input sample published
-        if (LDSVI(c.o_ctrl + 1)) break;
+        if (LDSVI(ctl + C_ABORT)) break;
     }
 }
 
+constexpr int kLoaders = 3;
+
 template <int W, int NTW, bool SCALAR>
-__global__ void __launch_bounds__((1 + W) * 64) wn_generate_kernel(GenArgs a)
+__global__ void __launch_bounds__((1 + kLoaders + W) * 64) wn_generate_kernel(GenArgs a)
 {
     const Layout& L = a.lay;
     const int NL = L.NL, S = L.S, NCH = L.NCH;
@@ -605,45 +835,67 @@ __global__ void __launch_bounds__((1 + W) * 64) wn_generate_kernel(GenArgs a)
     const int T = a.T;
     Ctx c;
     c.lane = threadIdx.x & 63;
-    c.b = blockIdx.x;
+    c.g = blockIdx.x % a.G;      // blocks of one XCD (blockIdx % 8) share g when G == 8: its L2 keeps only that 1/G slice
+    c.b = blockIdx.x / a.G;
     c.o_zbuf = 0;                                   // [64][32]   gated outputs z_l of the current step
     c.o_h1 = c.o_zbuf + 64 * 32;                    // [S]        relu(sum of skips)
     c.o_h2 = c.o_h1 + S;                            // [S]        relu(post conv 1)
     c.o_cpart = c.o_h2 + S;                         // [NOJ][NCH][64] chunk partials of the last conv
-    c.o_hist = c.o_cpart + L.NOJ * NCH * 64;        // [64]       causal_queue (circular)
-    c.o_ringpos = c.o_hist + 64;                    // [64]       write position of every delay line
-    c.o_ctrl = c.o_ringpos + 64;                    // [16]
-    c.stb = a.state + (long long)c.b * L.state_stride;
-    c.pmeta = reinterpret_cast<const int*>(a.P + L.off_meta);
+    c.o_meta = c.o_cpart + L.NOJ * NCH * 64;        // [128]      dil[64] | ring_off[64]
+    c.o_ringpos = c.o_meta + 128;                   // [64]       write position of every delay line (chain wave)
+    c.o_pos0 = c.o_ringpos + 64;                    // [64]       the same at launch (loader waves, read-only)
+    c.o_ready = c.o_pos0 + 64;                      // [16]       per slot: item number staged + 1
+    c.o_ctrl = c.o_ready + 16;                      // [16]
+    c.o_gc = c.o_ctrl + 16;                         // [NL][64]   gc projections (model.py:71-73), launch-resident
+    c.o_ring1 = c.o_gc + NL * 64;                   // [NL][32]   delay lines with d == 1 (LDS-resident)
+    c.o_causal = c.o_ring1 + NL * 32;               // [NCA][1024] causal kernel half tiles, launch-resident
+    c.o_cpart1 = c.o_causal + L.NCA * 1024;         // [NSJ/G][NCH][64] conv1d_1 chunk partials (only when NSJ/G < W)
+    c.o_slots = c.o_cpart1 + ((L.NSJ / a.G < W) ? (L.NSJ / a.G) * NCH * 64 : 0);   // [nslot][SlotOff::FLOATS]
+    c.stb = a.state + ((long long)c.b * a.G + c.g) * L.state_stride;
+    const int* pmeta = reinterpret_cast<const int*>(a.P + L.off_meta);
     c.ring = c.stb + L.st_ring;
     c.GCv = a.cond + (long long)c.b * NL * 64;
     c.LCb = a.cond + (long long)a.B * NL * 64 + (long long)c.b * T * NL * 64;
     int* meta = reinterpret_cast<int*>(c.stb + L.st_meta);
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.P), 0, (int)(L.packed_floats * 4), 0x00020000);
 
+    if (threadIdx.x < 128) LDSI(c.o_meta + threadIdx.x) = pmeta[threadIdx.x];
     if (threadIdx.x < 64) {
-        lds[c.o_hist + threadIdx.x] = c.stb[L.st_hist + threadIdx.x];
-        LDSI(c.o_ringpos + threadIdx.x) = reinterpret_cast<int*>(c.stb + L.st_ringpos)[threadIdx.x];
+        const int p0 = reinterpret_cast<int*>(c.stb + L.st_ringpos)[threadIdx.x];
+        LDSI(c.o_ringpos + threadIdx.x) = p0;
+        LDSI(c.o_pos0 + threadIdx.x) = p0;
     }
-    if (threadIdx.x < 16) LDSI(c.o_ctrl + threadIdx.x) = 0;
+    if (threadIdx.x < 32) LDSI(c.o_ready + threadIdx.x) = 0;   // ready[16] + ctrl[16]
+    for (int i = threadIdx.x; i < NL * 64; i += blockDim.x) lds[c.o_gc + i] = L.G > 0 ? c.GCv[i] : 0.0f;
+    for (int i = threadIdx.x; i < NL * 32; i += blockDim.x) {
+        const int l = i >> 5;
+        lds[c.o_ring1 + i] = pmeta[l] == 1 ? c.ring[pmeta[64 + l] + (i & 31)] : 0.0f;
+    }
+    if (L.scalar)
+        for (int i = threadIdx.x; i < L.NCA * 1024; i += blockDim.x) lds[c.o_causal + i] = a.P[L.off_causal + i];
     __syncthreads();
 
     int hpos = meta[M_HPOS], prev_valid = meta[M_PREV_VALID], qprev = meta[M_QPREV];
-    if (wid == 0) chain_main<SCALAR>(a, c, rs, hpos, prev_valid, qprev);
-    else worker_main<W, NTW, SCALAR>(a, c, rs, wid - 1);
+    if (wid == 0) chain_main<SCALAR>(a, c, hpos, prev_valid, qprev);
+    else if (wid <= kLoaders) loader_main<kLoaders>(a, c, rs, wid - 1);
+    else worker_main<W, NTW, SCALAR>(a, c, rs, wid - 1 - kLoaders);
 
     // ---------------- persist the per-stream state (model.py:49-64 queues) ----------------
     __syncthreads();
     if (threadIdx.x < 64) {
-        c.stb[L.st_hist + threadIdx.x] = lds[c.o_hist + threadIdx.x];
-        reinterpret_cast<int*>(c.stb + L.st_ringpos)[threadIdx.x] = LDSI(c.o_ringpos + threadIdx.x);
+        const unsigned d = (unsigned)LDSI(c.o_meta + threadIdx.x);
+        reinterpret_cast<int*>(c.stb + L.st_ringpos)[threadIdx.x] = (int)(((unsigned)LDSI(c.o_pos0 + threadIdx.x) + (unsigned)T) % (d ? d : 1u));
     }
     if (wid == 0 && c.lane == 0) {
         meta[M_TABS] = meta[M_TABS] + T;
         meta[M_HPOS] = hpos;
         meta[M_PREV_VALID] = prev_valid;
         meta[M_QPREV] = qprev;
-        if (LDSI(c.o_ctrl + 1)) atomicMax(a.status, LDSI(c.o_ctrl + 1));
+        if (LDSI(c.o_ctrl + C_ABORT)) atomicMax(a.status, LDSI(c.o_ctrl + C_ABORT));
+    }
+    for (int i = threadIdx.x; i < NL * 32; i += blockDim.x) {
+        const int l = i >> 5;
+        if (pmeta[l] == 1) c.ring[pmeta[64 + l] + (i & 31)] = lds[c.o_ring1 + i];
     }
     if (L.L > 0 && T > 0) {
         const float* last = c.LCb + (long long)(T - 1) * NL * 64;
@@ -734,7 +986,10 @@ struct twv_wavenet {
     Layout lay;
     int dil[kMaxLayers];
     int ring_off[kMaxLayers];
-    int workers;   // 4 or 8
+    int workers;   // worker waves per workgroup
+    int groups;    // workgroups per stream (0 = auto)
+    unsigned long long* prof;
+    int prof_steps;
 };
 
 static thread_local std::string g_err;
@@ -787,7 +1042,7 @@ static int build_layout(const twv_wavenet_dims& d, twv_wavenet* h)
     // ---- packed layout
     long long p = 0;
     L.off_meta = p; p += 128;
-    L.off_causal = p; p += L.scalar ? (long long)L.NCA * kTile : (long long)2 * L.Q * 32;
+    L.off_causal = p; p += L.scalar ? (long long)L.NCA * 1024 : (long long)2 * L.Q * 32;
     L.off_layer0 = p;
     L.layer_stride = LayerOff::SK + (long long)L.NSJ * kTile + L.S;
     p += L.layer_stride * L.NL;
@@ -827,7 +1082,43 @@ static int build_layout(const twv_wavenet_dims& d, twv_wavenet* h)
     L.st_lcprev = s; s += (long long)L.NL * 64;
     L.st_ring = s; s += L.ring_floats;
     L.state_stride = align_up(s, 64);
+    if (L.packed_floats * 4 > 0x7fffffffLL) return fail(TWV_E_UNSUPPORTED, "packed weights exceed 2 GiB");
     return TWV_OK;
+}
+
+static int device_cus()
+{
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+}
+// workgroups per stream: explicit option, else the largest of 8/4/2/1 that divides the output blocks and keeps every
+// workgroup of the launch co-resident (one workgroup per CU: the LDS slot ring takes most of the 160 KiB)
+static int resolve_groups(const twv_wavenet* h, int batch)
+{
+    const int NSJ = h->lay.NSJ;
+    if (h->groups > 0) return (NSJ % h->groups == 0) ? h->groups : -1;
+    const int cus = device_cus();
+    for (int g = 8; g >= 1; g >>= 1)
+        if (NSJ % g == 0 && (long long)batch * g <= cus) return g;
+    return 1;
+}
+constexpr int kWorkers = 4;
+// LDS floats of the generation kernel besides the slot ring
+static long long lds_fixed_floats(const Layout& L, int G)
+{
+    const int nsjl = L.NSJ / G;
+    return 64 * 32 + 2LL * L.S + (long long)L.NOJ * L.NCH * 64 + 64 * 4 + 32 + (long long)L.NL * 96 + (long long)L.NCA * 1024 +
+           (nsjl < kWorkers ? (long long)nsjl * L.NCH * 64 : 0);
+}
+static int resolve_nslot(const Layout& L, int G)
+{
+    long long ns = (160 * 1024 / 4 - lds_fixed_floats(L, G)) / SlotOff::FLOATS;
+    if (ns > 8) ns = 8;
+    if (L.NL > 1 && ns > L.NL - 1) ns = L.NL - 1;    // a slot's x[t-d] must have been produced before it is staged
+    if (L.NL == 1) ns = 1;
+    return (int)ns;
 }
 
 extern "C" int twv_wavenet_create(const twv_wavenet_dims* dims, twv_wavenet** out)
@@ -836,8 +1127,11 @@ extern "C" int twv_wavenet_create(const twv_wavenet_dims* dims, twv_wavenet** ou
     twv_wavenet* h = new twv_wavenet();
     h->dims = *dims;
     h->workers = 4;
+    h->groups = 0;
+    h->prof = nullptr; h->prof_steps = 0;
     const int rc = build_layout(*dims, h);
     if (rc != TWV_OK) { delete h; return rc; }
+    if (resolve_nslot(h->lay, 1) < 1) { delete h; return fail(TWV_E_UNSUPPORTED, "model does not fit the 160 KiB LDS budget"); }
     *out = h;
     return TWV_OK;
 }
@@ -857,17 +1151,34 @@ extern "C" int twv_wavenet_hop_size(const twv_wavenet* h)
 }
 extern "C" size_t twv_wavenet_blob_floats(const twv_wavenet* h) { return (size_t)h->lay.blob_floats; }
 extern "C" size_t twv_wavenet_packed_bytes(const twv_wavenet* h) { return (size_t)h->lay.packed_floats * 4; }
-extern "C" size_t twv_wavenet_state_bytes(const twv_wavenet* h, int batch) { return (size_t)h->lay.state_stride * 4 * (size_t)batch; }
+extern "C" size_t twv_wavenet_state_bytes(const twv_wavenet* h, int batch)
+{
+    // per (stream, workgroup) delay lines etc., then the all-gather granules [B][2][S] x 8 bytes
+    int G = resolve_groups(h, batch);
+    if (G < 1) G = 1;
+    return (size_t)h->lay.state_stride * 4 * (size_t)batch * G + (size_t)batch * 2 * h->lay.S * 8;
+}
 extern "C" size_t twv_wavenet_cond_bytes(const twv_wavenet* h, int batch, int n_steps)
 {
     return ((size_t)batch * h->lay.NL * 64 + (size_t)batch * (size_t)n_steps * h->lay.NL * 64) * 4;
+}
+extern "C" int twv_wavenet_set_profile_buffer(twv_wavenet* h, void* dev_u64, int steps)
+{
+    if (!h) return fail(TWV_E_INVALID, "null argument");
+    h->prof = (unsigned long long*)dev_u64; h->prof_steps = dev_u64 ? steps : 0;
+    return TWV_OK;
 }
 extern "C" int twv_wavenet_set_option(twv_wavenet* h, const char* name, int value)
 {
     if (!h || !name) return fail(TWV_E_INVALID, "null argument");
     if (!strcmp(name, "workers")) {
-        if (value != 4 && value != 8) return fail(TWV_E_INVALID, "workers must be 4 or 8");
+        if (value != 4) return fail(TWV_E_INVALID, "workers must be 4");
         h->workers = value;
+        return TWV_OK;
+    }
+    if (!strcmp(name, "groups")) {   // workgroups per stream; set BEFORE sizing / resetting the state buffer
+        if (value != 0 && (value < 1 || value > 16 || h->lay.NSJ % value)) return fail(TWV_E_INVALID, "groups must divide skip_channels/64");
+        h->groups = value;
         return TWV_OK;
     }
     return fail(TWV_E_INVALID, std::string("unknown option ") + name);
@@ -887,9 +1198,9 @@ extern "C" int twv_wavenet_pack(const twv_wavenet* h, const float* blob, void* p
     HIPCHK(hipMemcpyAsync(dst + L.off_meta, metah, sizeof(metah), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));   // metah is a stack buffer
     auto tiles = [&](long long dst_off, long long dst_gs, long long baseA, long long baseB, long long src_gs, int ng, int njb, int nch,
-                     int K, int rowlen, int ncols, int halves) {
-        PackTiles p{dst_off, dst_gs, baseA, baseB, src_gs, ng, njb, nch, K, rowlen, ncols, halves};
-        const long long total = (long long)ng * njb * nch * kTile;
+                     int K, int rowlen, int ncols, int halves, int lanes = 64) {
+        PackTiles p{dst_off, dst_gs, baseA, baseB, src_gs, ng, njb, nch, K, rowlen, ncols, halves, lanes};
+        const long long total = (long long)ng * njb * nch * 32 * lanes;
         hipLaunchKernelGGL(wn_pack_tiles_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, dst, blob, p);
     };
     auto vec = [&](long long dst_off, long long dst_gs, long long baseA, long long baseB, long long src_gs, int ng, int n, int ncols, int halves) {
@@ -898,18 +1209,18 @@ extern "C" int twv_wavenet_pack(const twv_wavenet* h, const float* blob, void* p
     };
     const long long ls = L.layer_stride, cs = L.c_layer_stride, c0 = L.c_layer0, l0 = L.off_layer0;
     if (L.scalar) {
-        tiles(L.off_causal, 0, L.c_causal, L.c_causal, 0, 1, 1, L.NCA, L.ifw, 32, 32, 1);      // wavenet/conv1d/kernel (ifw,1,R)
+        tiles(L.off_causal, 0, L.c_causal, 0, 0, 1, 1, L.NCA, L.ifw, 32, 32, 0, 32);           // wavenet/conv1d/kernel (ifw,1,R), half tiles
     } else {
         hipLaunchKernelGGL(wn_copy_kernel, dim3(grid_for((long long)2 * L.Q * 32, 256)), dim3(256), 0, st, dst + L.off_causal, blob + L.c_causal, (long long)2 * L.Q * 32);
     }
     // conv_filter|conv_gate kernel (2,R,D): tap 0 rows [0,32), tap 1 rows [32,64)
     tiles(l0 + LayerOff::T0, ls, c0 + L.c_wf, c0 + L.c_wg, cs, L.NL, 1, 1, 32, 32, 32, 1);
     tiles(l0 + LayerOff::T1, ls, c0 + L.c_wf + 32 * 32, c0 + L.c_wg + 32 * 32, cs, L.NL, 1, 1, 32, 32, 32, 1);
-    tiles(l0 + LayerOff::WD, ls, c0 + L.c_wd, c0 + L.c_wd, cs, L.NL, 1, 1, 32, 32, 32, 1);    // dense kernel (1,D,R), duplicated
+    tiles(l0 + LayerOff::WD, ls, c0 + L.c_wd, 0, cs, L.NL, 1, 1, 32, 32, 32, 0, 32);           // dense kernel (1,D,R), half tile
     tiles(l0 + LayerOff::SK, ls, c0 + L.c_ws, 0, cs, L.NL, L.NSJ, 1, 32, L.S, L.S, 0);         // skip kernel (1,D,S)
     if (L.use_bias) {
         vec(l0 + LayerOff::BFG, ls, c0 + L.c_bf, c0 + L.c_bg, cs, L.NL, 64, 32, 1);
-        vec(l0 + LayerOff::BD, ls, c0 + L.c_bd, c0 + L.c_bd, cs, L.NL, 64, 32, 1);
+        vec(l0 + LayerOff::BD, ls, c0 + L.c_bd, 0, cs, L.NL, 32, 32, 0);
         vec(l0 + LayerOff::SK + (long long)L.NSJ * kTile, ls, c0 + L.c_bs, 0, cs, L.NL, L.S, L.S, 0);
         vec(L.off_b1, 0, L.c_b1, 0, 0, 1, L.S, L.S, 0);
         vec(L.off_b2, 0, L.c_b2, 0, 0, 1, L.Opad, L.O, 0);
@@ -987,8 +1298,8 @@ template <int W, int NTW, bool SCALAR>
 static int launch_generate(const GenArgs& a, size_t shm, hipStream_t st)
 {
     auto kern = wn_generate_kernel<W, NTW, SCALAR>;
-    if (shm > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(kern, dim3(a.B), dim3((1 + W) * 64), shm, st, a);
+    if (shm > 32 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(kern, dim3(a.B * a.G), dim3((1 + kLoaders + W) * 64), shm, st, a);
     HIPCHK(hipGetLastError());
     return TWV_OK;
 }
@@ -1007,16 +1318,25 @@ extern "C" int twv_wavenet_generate(const twv_wavenet* h, const void* packed, vo
     GenArgs a;
     a.P = (const float*)packed; a.state = (float*)state; a.cond = (const float*)cond; a.first_input = first_input;
     a.uniforms = uniforms; a.out = out; a.status = status; a.dbg = debug; a.dbg_steps = debug ? debug_steps : 0;
+    a.prof = h->prof; a.prof_steps = h->prof ? h->prof_steps : 0;
     a.B = batch; a.T = n_steps; a.temperature = (float)temperature; a.lay = L;
-    const size_t shm = ((size_t)64 * 32 + 2 * (size_t)L.S + (size_t)L.NOJ * L.NCH * 64 + 64 + 64 + 16) * 4;
+    const int G = resolve_groups(h, batch);
+    if (G < 1) return fail(TWV_E_INVALID, "groups option does not divide skip_channels/64");
+    if ((long long)batch * G > device_cus())
+        return fail(TWV_E_UNSUPPORTED, "batch * groups exceeds the CU count: the stream workgroups must all be co-resident");
+    a.G = G;
+    a.exch = reinterpret_cast<unsigned long long*>((float*)state + (size_t)L.state_stride * (size_t)batch * G);
+    HIPCHK(hipMemsetAsync(a.exch, 0, (size_t)batch * 2 * L.S * 8, st));
+    a.lay.nslot = resolve_nslot(L, G);
+    if (a.lay.nslot < 1) return fail(TWV_E_UNSUPPORTED, "model does not fit the 160 KiB LDS budget");
+    const size_t shm = (size_t)(lds_fixed_floats(L, G) + (long long)a.lay.nslot * SlotOff::FLOATS) * 4;
     if (!L.scalar) return fail(TWV_E_UNSUPPORTED, "one-hot (mu-law softmax) generation is not built yet");
-    const int W = h->workers;
-    const int ntw = (L.NSJ + W - 1) / W;
-    if (W == 8 && ntw == 1) return launch_generate<8, 1, true>(a, shm, st);
-    if (W == 8 && ntw == 2) return launch_generate<8, 2, true>(a, shm, st);
-    if (W == 4 && ntw <= 2) return launch_generate<4, 2, true>(a, shm, st);
-    if (W == 4 && ntw <= 4) return launch_generate<4, 4, true>(a, shm, st);
-    return fail(TWV_E_UNSUPPORTED, "skip_channels too large for the selected worker count");
+    const int nsjl = L.NSJ / G;
+    const int ntw = (nsjl + kWorkers - 1) / kWorkers;
+    if (ntw <= 1) return launch_generate<kWorkers, 1, true>(a, shm, st);
+    if (ntw == 2) return launch_generate<kWorkers, 2, true>(a, shm, st);
+    if (ntw <= 4) return launch_generate<kWorkers, 4, true>(a, shm, st);
+    return fail(TWV_E_UNSUPPORTED, "skip_channels too large for the worker count");
 }
 
 extern "C" int twv_wavenet_status(const int32_t* status, void* stream)

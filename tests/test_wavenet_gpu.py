@@ -95,9 +95,9 @@ def test_upsample(torch_cuda, oracle):
 
 
 def _run_mol(oracle, torch, dil, B, Tm, S=512, ifw=32, use_bias=True, G=32, L=80, up=(5, 5, 12), workers=None, scale=0.05,
-             T=None, debug_steps=0, seed=0):
+             T=None, debug_steps=0, seed=0, groups=None):
     d, tensors, blob = make_case(oracle, dil, S=S, ifw=ifw, use_bias=use_bias, G=G, L=L, up=up, seed=seed, scale=scale)
-    m = make_model(B, dil, tensors, S=S, ifw=ifw, use_bias=use_bias, G=G, L=L, up=up, workers=workers)
+    m = make_model(B, dil, tensors, S=S, ifw=ifw, use_bias=use_bias, G=G, L=L, up=up, workers=workers, groups=groups)
     rng = np.random.RandomState(1)
     hop = int(np.prod(up)) if L else 1
     T = T or Tm * hop
@@ -137,11 +137,12 @@ def test_generate_small_with_layer_dumps(torch_cuda, oracle):
     assert first_mismatch(got.cpu().numpy(), want) is None
 
 
-@pytest.mark.parametrize("workers", [4, 8])
-def test_generate_c2_shape_short(torch_cuda, oracle, workers):
-    """C2 architecture (3x[1..512], R=D=32, S=512, MoL-30, gc+lc), B=2, 2 mel frames = 600 samples"""
+@pytest.mark.parametrize("groups", [1, 2, 4, 8])
+def test_generate_c2_shape_short(torch_cuda, oracle, groups):
+    """C2 architecture (3x[1..512], R=D=32, S=512, MoL-30, gc+lc), B=2, 2 mel frames = 600 samples; any number of
+    workgroups per stream (launch geometry) must give the same bits"""
     dil = [2 ** i for i in range(10)] * 3
-    d, blob, m, want, got, _ = _run_mol(oracle, torch_cuda, dil, 2, 2, workers=workers)
+    d, blob, m, want, got, _ = _run_mol(oracle, torch_cuda, dil, 2, 2, groups=groups)
     got = got.cpu().numpy()
     assert got.shape == want.shape == (2, 600)
     assert first_mismatch(got, want) is None, first_mismatch(got, want)
@@ -155,7 +156,7 @@ def test_generate_past_longest_delay_line(torch_cuda, oracle):
     assert first_mismatch(got.cpu().numpy(), want) is None
 
 
-@pytest.mark.parametrize("kw", [dict(use_bias=False), dict(G=0), dict(L=0), dict(ifw=8), dict(S=64), dict(S=1024, workers=8),
+@pytest.mark.parametrize("kw", [dict(use_bias=False), dict(G=0), dict(L=0), dict(ifw=8), dict(S=64), dict(S=1024), dict(S=1024, groups=16), dict(S=128, groups=2), dict(groups=1),
                                 dict(up=(3, 4))])
 def test_generate_variants(torch_cuda, oracle, kw):
     dil = [1, 2, 4, 8, 16, 1, 2]
