@@ -14,6 +14,8 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--workers", type=int, default=0)
 ap.add_argument("--layers", type=int, default=30)
 ap.add_argument("--groups", type=int, default=-1)
+ap.add_argument("--exp", type=int, default=0)
+ap.add_argument("--no-stamps", action="store_true")
 args = ap.parse_args()
 hp = twvk_amd.default_hparams()
 dil = ([2 ** i for i in range(10)] * 5)[:args.layers]
@@ -23,17 +25,20 @@ m = WaveNetModel(B, dil, 2, 32, 32, 512, out_channels=30, use_biases=True, scala
                  upsample_factor=[5, 5, 12], train_mode=False)
 if args.workers: m.set_option("workers", args.workers)
 if args.groups >= 0: m.set_option("groups", args.groups)
+if args.exp: m.set_option("exp", args.exp)
 m.load_weights(W.random_tensors(m.specs, 0, 0.05))
 rng = np.random.RandomState(0)
 U = torch.from_numpy(rng.uniform(-1, 1, (B, T, 80)).astype(np.float32)).cuda()
 u = torch.from_numpy(rng.uniform(1e-5, 1 - 1e-5, (B, T, 11)).astype(np.float32)).cuda()
 NP = min(T, 2000)
 prof = torch.zeros((NP, 80), dtype=torch.int64, device="cuda")
-_lib.check(m._L.twv_wavenet_set_profile_buffer(m._h, C.c_void_p(prof.data_ptr()), NP))
+_lib.check(m._L.twv_wavenet_set_profile_buffer(m._h, C.c_void_p(prof.data_ptr()), 0 if args.no_stamps else NP))
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-m.generate(U, np.zeros(B, np.int32), np.zeros(B, np.float32), u)   # warm
+m.generate(U, np.zeros(B, np.int32), np.zeros(B, np.float32), u, check=not args.exp)   # warm
 m.queue_initializer()
 e0.record(); m.generate(U, np.zeros(B, np.int32), np.zeros(B, np.float32), u, check=False); e1.record(); torch.cuda.synchronize()
+if args.no_stamps or args.exp:
+    print("exp=%d stamps=%s: %.2f us/step (events)" % (args.exp, not args.no_stamps, e0.elapsed_time(e1) * 1e3 / T)); sys.exit(0)
 p = prof.cpu().numpy().astype(np.int64)
 s = p[100:NP]   # skip the cold start
 ticks = s[-1, 0] - s[0, 0]; wall = (s[-1, 7] - s[0, 7]) / 100e6
@@ -49,3 +54,11 @@ print("per-layer us:", " ".join("%.2f" % (v / mhz) for v in lay.mean(axis=0)))
 f = s[:, 72:77]
 print("layer 5 fine: wait_ready %.3f | tiles+conv %.3f | bias/act/z publish %.3f | dense+cdone %.3f us" % (
     us(f[:, 1] - f[:, 0]), us(f[:, 2] - f[:, 1]), us(f[:, 3] - f[:, 2]), us(f[:, 4] - f[:, 3])))
+
+ld = s[:, 40:44]
+print("loader0, layer-6 item: issue %.3f | landed after %.3f | acc0+publish %.3f us ; staged %.2f us before the chain reaches the layer" % (
+    us(ld[:, 1] - ld[:, 0]), us(ld[:, 2] - ld[:, 1]), us(ld[:, 3] - ld[:, 2]), us(s[:, 8 + 5] - ld[:, 3])))
+wk = s[:, 44:52]
+print("worker0: skip pass %.2f (ends %.2f us after chain stack end) | gather h1 %.2f | conv1d_1 %.2f | gather h2 %.2f | conv1d_2 %.2f | wait partials %.2f | sampler %.2f us" % (
+    us(wk[:, 1] - wk[:, 0]), us(wk[:, 1] - s[:, 2]), us(wk[:, 2] - wk[:, 1]), us(wk[:, 3] - wk[:, 2]), us(wk[:, 4] - wk[:, 3]),
+    us(wk[:, 5] - wk[:, 4]), us(wk[:, 6] - wk[:, 5]), us(wk[:, 7] - wk[:, 6])))

@@ -36,8 +36,8 @@ struct SlotOff {
     static constexpr int BD = LayerOff::BD - LayerOff::T1;     // 3136
     static constexpr int XO = PIECES * 256;                // 3328: x[t-d] (32, duplicated to 64)
     static constexpr int LC = XO + 64;                     // lc projection row of this layer (64)
-    static constexpr int A0 = LC + 64;                     // tap-0 chunk of conv_filter|conv_gate (64), by the loader
-    static constexpr int FLOATS = A0 + 64;                 // 3520 floats = 14080 B
+    static constexpr int PK = LC + 64;                     // per lane {tap-0 chunk, conv bias, gc projection, lc projection}: one b128
+    static constexpr int FLOATS = PK + 256;                // 3712 floats = 14848 B
 };
 
 struct Layout {

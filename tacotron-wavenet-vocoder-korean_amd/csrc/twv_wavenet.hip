@@ -238,6 +238,7 @@ struct GenArgs {
     unsigned long long* prof;  // optional [prof_steps][80] s_memtime stamps of stream 0's chain wave
     int prof_steps;
     int B, T;
+    int exp;                     // tuning experiments (bit mask, 0 in production)
     int G;                       // workgroups per stream (each owns 1/G of the skip / conv1d_1 outputs)
     unsigned long long* exch;    // [B][2][S] {epoch,value} granules: all-gather of relu(skip sum) and relu(conv1d_1)
     float temperature;
@@ -310,7 +311,7 @@ __device__ __forceinline__ float dot_ldso(const Tile& t, int xo)
 // Intra-workgroup synchronisation is by monotonically increasing LDS sequence words only (no s_barrier inside the
 // sample loop, so the wave roles run decoupled).  Every wait is BOUNDED: after ~2^22 polls it raises the workgroup's
 // abort word, every other wait then falls through, and the launch ends with a watchdog code instead of hanging.
-enum { C_ZSEQ = 0, C_ABORT = 1, C_SAMPLE = 2, C_CDONE = 3, C_H1CNT = 4, C_H2CNT = 5, C_CPCNT = 6, C_SSEQ = 7, C_P1CNT = 8 };
+enum { C_ZSEQ = 0, C_ABORT = 1, C_SAMPLE = 2, C_CDONE = 3, C_H1CNT = 4, C_H2CNT = 5, C_CPCNT = 6, C_SSEQ = 7, C_P1CNT = 8, C_SKCNT = 9 };
 
 __device__ __forceinline__ bool wait_seq(int fo_flag, int target, int fo_abort, int code)
 {
@@ -377,7 +378,7 @@ __device__ __forceinline__ bool gather_granules(unsigned long long* X, int S, un
 
 // per-workgroup context shared by the wave roles (LDS positions are float offsets into lds[])
 struct Ctx {
-    int o_zbuf, o_h1, o_h2, o_cpart, o_meta, o_ringpos, o_pos0, o_ready, o_ctrl, o_gc, o_ring1, o_causal, o_cpart1, o_slots;
+    int o_zbuf, o_h1, o_h2, o_cpart, o_meta, o_ringpos, o_pos0, o_ready, o_ctrl, o_gc, o_ring1, o_causal, o_cpart1, o_skl, o_slots;
     int b, g, lane;
     float* stb;            // this stream's state
     float* ring;
@@ -388,22 +389,6 @@ struct Ctx {
 // Walks model.py:112-149 for one stream: causal layer, then the dilated residual stack, one layer after the other.
 // Everything a layer needs (conv/dense weights, biases, x[t-d], lc projection) has been staged in an LDS slot by the
 // loader waves; the gc projections and the causal kernel are LDS-resident for the whole launch.
-// registers holding everything the chain needs for ONE layer (filled from the layer's LDS slot one layer ahead)
-struct LayerRegs {
-    Tile w1, wd;                       // tap-1 conv tile, dense half tile
-    float pre, bfg, gcv, lcv, bd;      // tap-0 chunk (by the loader), biases, gc / lc projections
-};
-__device__ __forceinline__ void fetch_layer(LayerRegs& r, const Ctx& c, int sb, int l, int lane, bool use_bias, bool has_gc, bool has_lc)
-{
-    lds_tile(r.w1, sb + SlotOff::T1, lane);
-    lds_half_tile(r.wd, sb + SlotOff::WD, lane);
-    r.pre = lds[sb + SlotOff::A0 + lane];
-    r.bfg = use_bias ? lds[sb + SlotOff::BFG + lane] : 0.0f;
-    r.bd = use_bias ? lds[sb + SlotOff::BD + (lane & 31)] : 0.0f;
-    r.gcv = has_gc ? lds[c.o_gc + l * 64 + lane] : 0.0f;
-    r.lcv = has_lc ? lds[sb + SlotOff::LC + lane] : 0.0f;
-}
-
 template <bool SCALAR>
 __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& hpos, int& prev_valid, int& qprev)
 {
@@ -412,80 +397,37 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
     const bool has_gc = L.G > 0, has_lc = L.L > 0, use_bias = L.use_bias != 0;
     const ActCoef coef = act_coef(lane >= 32);
     const int ctl = c.o_ctrl;
-    const long long total = (long long)T * NL;
+    const int total = T * NL;
     int item = 0, slot = 0;
     // causal_queue (model.py:52): lane k holds the k-th oldest of the last ifw input samples
     float hv = SCALAR ? c.stb[L.st_hist + lane] : 0.0f;
-    Tile tc[2];
-    if (SCALAR) {
-        lds_half_tile(tc[0], c.o_causal, lane);
-        if (L.NCA > 1) lds_half_tile(tc[1], c.o_causal + 1024, lane);
-    }
-    LayerRegs RA, RB;
     float x = 0.0f;
-    bool prof = false;
-    unsigned long long* pp = a.prof;
 
-    // one layer: `cur` holds this layer's operands; `nxt` is filled for the following item while the dense conv runs
-    auto layer = [&](LayerRegs& cur, LayerRegs& nxt, int l, int t) {
-        const bool fine = prof && l == 5 && lane == 0;
-        if (fine) pp[72] = __builtin_amdgcn_s_memtime();
-        // model.py:145 dilation queue <- the layer INPUT x[t].  The chain only drops it in LDS; a loader wave moves it to
-        // the stream's delay line in HBM (under streaming load every VMEM instruction issued here would stall the chain).
-        if (lane < 32) lds[c.o_ring1 + l * 32 + lane] = x;
-        // is the NEXT item staged?  (read early, consumed after the gated unit)
-        const int nslot_i = (slot + 1 == nslot) ? 0 : slot + 1;
-        const bool have_next = (long long)item + 1 < total;
-        const int rdy = have_next ? LDSVI(c.o_ready + nslot_i) : 0x7fffffff;
-
-        // model.py:68-69 conv_filter | conv_gate: chunk(tap0) [precomputed by the loader] + chunk(tap1)
-        const float acc1 = dot_readlane(cur.w1, x);
-        float v = cur.pre + acc1;
-        if (use_bias) v = v + cur.bfg;
-        if (has_gc) v = v + cur.gcv;      // model.py:71-73
-        if (has_lc) v = v + cur.lcv;      // model.py:75-83
-        // every operand of THIS item now sits in registers (LDS returns in order): its slot may be refilled
-        publish(ctl + C_CDONE, item + 1, lane);
-        if (fine) pp[74] = __builtin_amdgcn_s_memtime();
-        // model.py:86 tanh(filter) * sigmoid(gate): lanes 0-31 hold tanh, lanes 32-63 the logistic
-        const float act = act_eval(coef, v);
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
-        const float z = __uint_as_float(sw[0]) * __uint_as_float(sw[1]);   // every lane: z[lane & 31]
-        if (lane < 32) lds[c.o_zbuf + l * 32 + lane] = z;
-        publish(ctl + C_ZSEQ, item + 1, lane);
-        if (fine) pp[75] = __builtin_amdgcn_s_memtime();
-
-        // stage the next layer's operands into registers (LDS latency hides under the dense conv below)
-        if (have_next) {
-            if (rdy < item + 2) wait_seq(c.o_ready + nslot_i, item + 2, ctl + C_ABORT, 200 + l);
-            ACQUIRE_WG();
-            const int ln = (l + 1 < NL) ? l + 1 : 0;
-            fetch_layer(nxt, c, c.o_slots + nslot_i * SlotOff::FLOATS, ln, lane, use_bias, has_gc, has_lc);
-        }
-        // model.py:89 dense 1x1, model.py:98-101 residual
-        float tr = dot_readlane(cur.wd, z);
-        if (use_bias) tr = tr + cur.bd;
-        x = x + tr;
-        if (a.dbg != nullptr && c.g == 0 && t < a.dbg_steps) {
-            float* dp = a.dbg + ((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)l * 64;
-            if (lane < 32) { dp[lane] = z; dp[32 + lane] = x; }
-        }
-        if (fine) pp[76] = __builtin_amdgcn_s_memtime();
-        if (prof && lane == 0) pp[8 + l] = __builtin_amdgcn_s_memtime();
-        ++item;
-        slot = nslot_i;
+    // Operands of the layer about to run.  Single-buffered: each group is re-fetched from the NEXT item's LDS slot
+    // right after its last use in the current layer, so the LDS latency hides under the rest of the layer.
+    Tile w1;                           // tap-1 conv tile                (re-fetched after the conv)
+    Tile wd;                           // dense half tile                (re-fetched after the dense conv)
+    float pre, bfg, gcv, lcv, bd;      // tap-0 chunk (by a loader), biases, gc / lc projections
+    auto fetch_conv = [&](int sb, int l) {
+        lds_tile(w1, sb + SlotOff::T1, lane);
+        const f32x4 q = LDS4(((sb + SlotOff::PK) >> 2) + lane);   // packed by the loader
+        pre = q.x; bfg = q.y; gcv = q.z; lcv = q.w;
+        (void)l;
+    };
+    auto fetch_dense = [&](int sb) {
+        lds_half_tile(wd, sb + SlotOff::WD, lane);
+        bd = use_bias ? lds[sb + SlotOff::BD + (lane & 31)] : 0.0f;
     };
 
     __builtin_amdgcn_s_setprio(3);
-    // operands of item 0
-    wait_seq(c.o_ready + 0, 1, ctl + C_ABORT, 199);
+    wait_seq(c.o_ready + 0, 1, ctl + C_ABORT, 199);     // operands of item 0
     ACQUIRE_WG();
-    fetch_layer(RA, c, c.o_slots, 0, lane, use_bias, has_gc, has_lc);
-    bool curA = true;   // which register set holds the current layer
+    fetch_conv(c.o_slots, 0);
+    fetch_dense(c.o_slots);
 
     for (int t = 0; t < T; ++t) {
-        prof = a.prof != nullptr && b == 0 && c.g == 0 && t < a.prof_steps;
-        pp = a.prof + (long long)t * 80;
+        const bool prof = a.prof != nullptr && b == 0 && c.g == 0 && t < a.prof_steps;
+        unsigned long long* pp = a.prof + (long long)t * 80;
         if (t > 0) { wait_seq(ctl + C_SSEQ, t, ctl + C_ABORT, 3); ACQUIRE_WG(); }   // sample t-1 published
         if (prof && lane == 0) { pp[0] = __builtin_amdgcn_s_memtime(); pp[7] = wall_clock64(); }
         if (SCALAR) {
@@ -494,42 +436,81 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
             const float sh = __shfl_down(hv, 1);
             hv = (lane == L.ifw - 1) ? s_in : sh;
             x = 0.0f;
+            for (int ca = 0; ca < L.NCA; ++ca) {
+                Tile tc;
+                lds_half_tile(tc, c.o_causal + ca * 1024, lane);
+                float sj[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int ca = 0; ca < 2; ++ca) {
-                if (ca < L.NCA) {
-                    float sj[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int k0 = 0; k0 < 32; ++k0) {
-                        const float hk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), ca * 32 + k0));
-                        const float nacc = fma_(tc[ca].w[k0], hk, sj[k0 & 3]);
-                        sj[k0 & 3] = (ca * 32 + k0 < L.ifw) ? nacc : sj[k0 & 3];
-                    }
-                    const float acc = (sj[0] + sj[1]) + (sj[2] + sj[3]);
-                    x = ca == 0 ? acc : x + acc;
+                for (int k0 = 0; k0 < 32; ++k0) {
+                    const float hk = __shfl(hv, ca * 32 + k0);
+                    const float nacc = fma_(tc.w[k0], hk, sj[k0 & 3]);
+                    sj[k0 & 3] = (ca * 32 + k0 < L.ifw) ? nacc : sj[k0 & 3];
                 }
+                const float acc = (sj[0] + sj[1]) + (sj[2] + sj[3]);
+                x = ca == 0 ? acc : x + acc;
             }
         } else {
             // one-hot input: the k=2 causal conv over one-hot rows is the sum of two kernel rows
             const int qcur = (t == 0) ? reinterpret_cast<const int*>(a.first_input)[b] : LDSI(ctl + C_SAMPLE);
-            const float w1 = a.P[L.off_causal + ((long long)L.Q + qcur) * 32 + (lane & 31)];
+            const float w1r = a.P[L.off_causal + ((long long)L.Q + qcur) * 32 + (lane & 31)];
             if (prev_valid) {
-                const float w0 = a.P[L.off_causal + (long long)qprev * 32 + (lane & 31)];
-                x = w0 + w1;
+                const float w0r = a.P[L.off_causal + (long long)qprev * 32 + (lane & 31)];
+                x = w0r + w1r;
             } else {
-                x = w1;
+                x = w1r;
             }
             qprev = qcur; prev_valid = 1;
         }
         if (prof && lane == 0) pp[1] = __builtin_amdgcn_s_memtime();
 
-        int l = 0;
-        if (!curA && l < NL) { layer(RB, RA, l, t); ++l; curA = true; }
-        for (; l + 1 < NL; l += 2) {
-            layer(RA, RB, l, t);
-            layer(RB, RA, l + 1, t);
-        }
-        if (l < NL) { layer(RA, RB, l, t); curA = false; }
+        for (int l = 0; l < NL; ++l) {
+            const bool fine = prof && l == 5 && lane == 0;
+            if (fine) pp[72] = __builtin_amdgcn_s_memtime();
+            // model.py:145 dilation queue <- the layer INPUT x[t].  The chain only drops it in LDS; a loader wave moves it
+            // to the stream's delay line in HBM (under load every VMEM instruction issued here would stall the chain).
+            if (lane < 32) lds[c.o_ring1 + l * 32 + lane] = x;
+            // is the NEXT item staged?  (read early, consumed after the conv)
+            const int slot_n = (slot + 1 == nslot) ? 0 : slot + 1;
+            const int sbn = c.o_slots + slot_n * SlotOff::FLOATS;
+            const int ln = (l + 1 < NL) ? l + 1 : 0;
+            const bool have_next = item + 1 < total;
+            const int rdy = have_next ? LDSVI(c.o_ready + slot_n) : 0x7fffffff;
 
+            // model.py:68-69 conv_filter | conv_gate: chunk(tap0) [precomputed by a loader] + chunk(tap1)
+            const float acc1 = (a.exp & 4) ? x : dot_readlane(w1, x);
+            float v = pre + acc1;
+            if (use_bias) v = v + bfg;
+            if (has_gc) v = v + gcv;      // model.py:71-73
+            if (has_lc) v = v + lcv;      // model.py:75-83
+            if (fine) pp[74] = __builtin_amdgcn_s_memtime();
+            // conv operands of the NEXT item -> registers (latency hides under the gated unit and the dense conv)
+            if (have_next) {
+                if (!(a.exp & 16) && rdy < item + 2) wait_seq(c.o_ready + slot_n, item + 2, ctl + C_ABORT, 200 + l);
+                ACQUIRE_WG();
+                if (!(a.exp & 1)) fetch_conv(sbn, ln);
+            }
+            // model.py:86 tanh(filter) * sigmoid(gate): lanes 0-31 hold tanh, lanes 32-63 the logistic
+            const float act = (a.exp & 8) ? v : act_eval(coef, v);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
+            const float z = __uint_as_float(sw[0]) * __uint_as_float(sw[1]);   // every lane: z[lane & 31]
+            if (lane < 32) lds[c.o_zbuf + l * 32 + lane] = z;
+            publish(ctl + C_ZSEQ, item + 1, lane);
+            if (fine) pp[75] = __builtin_amdgcn_s_memtime();
+
+            // model.py:89 dense 1x1, model.py:98-101 residual
+            float tr = (a.exp & 2) ? z : dot_readlane(wd, z);
+            if (use_bias) tr = tr + bd;
+            x = x + tr;
+            if (have_next && !(a.exp & 1)) fetch_dense(sbn);
+            if (a.dbg != nullptr && c.g == 0 && t < a.dbg_steps) {
+                float* dp = a.dbg + ((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)l * 64;
+                if (lane < 32) { dp[lane] = z; dp[32 + lane] = x; }
+            }
+            if (fine) pp[76] = __builtin_amdgcn_s_memtime();
+            if (prof && lane == 0) pp[8 + l] = __builtin_amdgcn_s_memtime();
+            ++item;
+            slot = slot_n;
+        }
         if (prof && lane == 0) pp[2] = __builtin_amdgcn_s_memtime();
         if (LDSVI(ctl + C_ABORT)) break;
     }
@@ -540,6 +521,12 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
 // Stage item i = (layer l, step t) into LDS slot i % nslot, NLD waves taking items round-robin:
 //   the layer's chain block [T0|T1|WD|BFG|BD] as 21 one-KiB LDS-DMA pieces, x[t-d] from the stream's delay line in HBM
 //   (the slot the chain wave will overwrite when it reaches this item), and the hoisted lc projection row.
+__device__ __forceinline__ unsigned ring_pos(unsigned pos0, unsigned t, unsigned d)
+{
+    const unsigned v = pos0 + t;
+    return (d & (d - 1)) == 0 ? (v & (d - 1)) : v % d;    // dilations are powers of two in every shipped config
+}
+
 template <int NLD>
 __device__ __forceinline__ void loader_main(const GenArgs& a, const Ctx& c, rsrc_t rs, int k)
 {
@@ -548,32 +535,42 @@ __device__ __forceinline__ void loader_main(const GenArgs& a, const Ctx& c, rsrc
     const bool has_lc = L.L > 0;
     const int ctl = c.o_ctrl;
     const int v16 = lane * 16;
-    const long long total = (long long)T * NL;
-    long long nxt = k;                 // next item this wave stages
+    if (a.exp & 128) return;
+    const int total = T * NL;          // < 2^31 (checked on the host)
+    // all item bookkeeping is 32-bit and incremental: integer division is software on the GPU
+    int nxt = k, nt = 0, nl = k, nslot_i = k % nslot;       // next item this wave stages = (layer nl, step nt), its slot
+    while (nl >= NL) { nl -= NL; ++nt; }
+    int wb = k - nslot, wt = 0, wl = k - nslot;             // item whose layer input goes back to HBM with it
+    while (wl < 0) { wl += NL; --wt; }
     int pend = 0;                      // items in flight (at most 2: the 6-bit vmcnt holds 2 x 24 operations)
     int slotA = 0, itemA = 0, layA = 0, slotB = 0, itemB = 0, layB = 0;   // A = older, B = newer
     Tile t0A, t0B;                     // tap-0 conv tiles of the items in flight (never touch LDS)
 
-    // delay-line write-back of item jb = (lb, tb): x_lb[tb] was left in LDS by the chain wave
-    auto write_back = [&](long long jb) {
-        const int tb = (int)(jb / NL), lb = (int)(jb - (long long)tb * NL);
+    // delay-line write-back of item (lb, tb): x_lb[tb] was left in LDS by the chain wave
+    auto write_back = [&](int lb, int tb) {
         const unsigned d = (unsigned)LDSI(c.o_meta + lb);
         if (d > 1) {
-            const unsigned pos = ((unsigned)LDSI(c.o_pos0 + lb) + (unsigned)tb) % d;
+            const unsigned pos = ring_pos((unsigned)LDSI(c.o_pos0 + lb), (unsigned)tb, d);
             const float xv = lds[c.o_ring1 + lb * 32 + (lane & 31)];
             if (lane < 32) c.ring[LDSI(c.o_meta + 64 + lb) + pos * 32 + lane] = xv;
         }
     };
+    auto advance = [&](int& item, int& l, int& t) {
+        item += NLD; l += NLD;
+        while (l >= NL) { l -= NL; ++t; }
+    };
 
     for (;;) {
-        const bool can_issue = nxt < total && pend < 2 &&
-                               (nxt < nslot || LDSVI(ctl + C_CDONE) >= (int)(nxt - nslot + 1));
+        // the slot's previous occupant, item nxt-nslot, was last read (its dense operands) BEFORE the chain wave published
+        // ZSEQ = nxt-nslot+1 -- one wave's LDS operations are performed in order -- so that word also frees the slot
+        const bool can_issue = nxt < total && pend < 2 && (nxt < nslot || LDSVI(ctl + C_ZSEQ) >= nxt - nslot + 1);
         if (can_issue) {
-            const int t = (int)(nxt / NL), l = (int)(nxt - (long long)t * NL);
-            const int slot = (int)(nxt % nslot);
+            const int t = nt, l = nl, slot = nslot_i;
             const int sb = c.o_slots + slot * SlotOff::FLOATS;
-            // (1) CDONE >= nxt-nslot+1 says the chain has started item nxt-nslot: its layer input sits in LDS -> HBM
-            if (nxt >= nslot) write_back(nxt - nslot);
+            const bool lprof = a.prof != nullptr && c.b == 0 && c.g == 0 && k == 0 && l == 6 && t < a.prof_steps && lane == 0;
+            if (lprof) a.prof[(long long)t * 80 + 40] = __builtin_amdgcn_s_memtime();
+            // (1) ZSEQ >= nxt-nslot+1: the chain has run the conv of item nxt-nslot: its layer input sits in LDS -> HBM
+            if (wb >= 0) write_back(wl, wt);
             // (2) tap-0 tile straight into registers, (3) the chain block, x[t-d] and the lc row by LDS-DMA
             const int lb4 = ((int)L.off_layer0 + l * (int)L.layer_stride) * 4;
             if (pend == 0) load_tile_b(t0A, rs, v16, lb4 + LayerOff::T0 * 4); else load_tile_b(t0B, rs, v16, lb4 + LayerOff::T0 * 4);
@@ -583,7 +580,7 @@ __device__ __forceinline__ void loader_main(const GenArgs& a, const Ctx& c, rsrc
                 __builtin_amdgcn_global_load_lds((gptr_t)(src + p * 256), (lptr_t)(lds + sb + p * 256), 16, 0, 0);
             {   // x[t-d]: the delay line's write position at step t (it advances by one per step)
                 const unsigned d = (unsigned)LDSI(c.o_meta + l);
-                const unsigned pos = ((unsigned)LDSI(c.o_pos0 + l) + (unsigned)t) % d;
+                const unsigned pos = ring_pos((unsigned)LDSI(c.o_pos0 + l), (unsigned)t, d);
                 const float* xs = c.ring + LDSI(c.o_meta + 64 + l) + pos * 32 + (lane & 31);
                 __builtin_amdgcn_global_load_lds((gptr_t)xs, (lptr_t)(lds + sb + SlotOff::XO), 4, 0, 0);
             }
@@ -593,9 +590,12 @@ __device__ __forceinline__ void loader_main(const GenArgs& a, const Ctx& c, rsrc
                 const float* row = (t == 0 || !has_lc) ? (c.stb + L.st_lcprev) : (c.LCb + (long long)(t - 1) * NL * 64);
                 __builtin_amdgcn_global_load_lds((gptr_t)(row + l * 64 + lane), (lptr_t)(lds + sb + SlotOff::LC), 4, 0, 0);
             }
-            if (pend == 0) { slotA = slot; itemA = (int)nxt; layA = l; } else { slotB = slot; itemB = (int)nxt; layB = l; }
+            if (lprof) a.prof[(long long)t * 80 + 41] = __builtin_amdgcn_s_memtime();
+            if (pend == 0) { slotA = slot; itemA = nxt; layA = l; } else { slotB = slot; itemB = nxt; layB = l; }
             ++pend;
-            nxt += NLD;
+            advance(nxt, nl, nt);
+            advance(wb, wl, wt);
+            nslot_i += NLD; while (nslot_i >= nslot) nslot_i -= nslot;
             continue;
         }
         if (pend > 0) {
@@ -603,26 +603,35 @@ __device__ __forceinline__ void loader_main(const GenArgs& a, const Ctx& c, rsrc
             // (an interleaved write-back store is older than those, so it is covered too)
             if (pend == 2) asm volatile("s_waitcnt vmcnt(23)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int tA = itemA / NL;
+            const bool aprof = a.prof != nullptr && c.b == 0 && c.g == 0 && k == 0 && layA == 6 && tA < a.prof_steps && lane == 0;
+            if (aprof) a.prof[(long long)tA * 80 + 42] = __builtin_amdgcn_s_memtime();
             {
                 // tap-0 chunk of conv_filter|conv_gate (model.py:68-69): depends on x[t-d] only, so it is taken off the
                 // chain wave's critical path: acc0[lane] = sum_c T0[c][lane] * x[t-d][c]   (one AC-1 chunk)
                 const int sbA = c.o_slots + slotA * SlotOff::FLOATS;
                 const int xsrc = LDSI(c.o_meta + layA) == 1 ? c.o_ring1 + layA * 32 : sbA + SlotOff::XO;
-                lds[sbA + SlotOff::A0 + lane] = dot_ldso(t0A, xsrc);
+                f32x4 pk;
+                pk.x = dot_ldso(t0A, xsrc);
+                pk.y = L.use_bias ? lds[sbA + SlotOff::BFG + lane] : 0.0f;
+                pk.z = L.G > 0 ? lds[c.o_gc + layA * 64 + lane] : 0.0f;
+                pk.w = has_lc ? lds[sbA + SlotOff::LC + lane] : 0.0f;
+                LDS4(((sbA + SlotOff::PK) >> 2) + lane) = pk;
             }
             publish(c.o_ready + slotA, itemA + 1, lane);
+            if (aprof) a.prof[(long long)tA * 80 + 43] = __builtin_amdgcn_s_memtime();
             slotA = slotB; itemA = itemB; layA = layB; t0A = t0B;
             --pend;
             continue;
         }
         if (nxt >= total) break;
-        if (!wait_seq(ctl + C_CDONE, (int)(nxt - nslot + 1), ctl + C_ABORT, 300)) break;
+        if (!wait_seq(ctl + C_ZSEQ, nxt - nslot + 1, ctl + C_ABORT, 300)) break;
     }
     // write-backs of the last nslot items: wait until the chain has run them
-    for (long long jb = nxt - nslot; jb < total; jb += NLD) {
-        if (jb < 0) continue;
-        if (!wait_seq(ctl + C_ZSEQ, (int)(jb + 1), ctl + C_ABORT, 301)) break;
-        write_back(jb);
+    for (; wb < total; advance(wb, wl, wt)) {
+        if (wb < 0) continue;
+        if (!wait_seq(ctl + C_ZSEQ, wb + 1, ctl + C_ABORT, 301)) break;
+        write_back(wl, wt);
     }
 }
 
@@ -651,18 +660,27 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
     for (int n = 0; n < NTW; ++n) {
         const int m = w + n * W, jb = m * G + g;
         n_bs[n] = 0.0f;
-        if (m < NSJL) {
+        if (!split1 && m < NSJL) {
             load_tile_b(tk[n], rs, v16, lay0 + skb + jb * kTile * 4);
             if (use_bias) n_bs[n] = load_f32_b(rs, v4, lay0 + bsb + jb * 256);
         }
     }
+    if (split1 && w < NL) {
+        load_tile_b(tk[0], rs, v16, lay0 + w * lstride + skb + g * kTile * 4);
+        if (use_bias) n_bs[0] = load_f32_b(rs, v4, lay0 + w * lstride + bsb + g * 256);
+    }
 
     for (int t = 0; t < T; ++t) {
+        const bool wprof = a.prof != nullptr && b == 0 && g == 0 && w == 0 && t < a.prof_steps && lane == 0;
+        unsigned long long* wp = a.prof + (long long)t * 80;
+        if (wprof) wp[44] = __builtin_amdgcn_s_memtime();
         {
             float tot[NTW];
 #pragma unroll
             for (int n = 0; n < NTW; ++n) tot[n] = 0.0f;
-            if (w < NSJL) {   // (workers without an output block skip the whole pass)
+            if (a.exp & 64) {
+                wait_seq(ctl + C_ZSEQ, t * NL + NL, ctl + C_ABORT, 100);
+            } else if (!split1) {
                 for (int l = 0; l < NL; ++l) {
                     wait_seq(ctl + C_ZSEQ, t * NL + l + 1, ctl + C_ABORT, 100 + l);
                     ACQUIRE_WG();
@@ -687,21 +705,66 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                         }
                     }
                 }
-            }
 #pragma unroll
-            for (int n = 0; n < NTW; ++n) {
-                const int m = w + n * W, jb = m * G + g;
-                if (m < NSJL) {
-                    const float h = tot[n] > 0.0f ? tot[n] : 0.0f;       // model.py:157 relu
+                for (int n = 0; n < NTW; ++n) {
+                    const int m = w + n * W, jb = m * G + g;
+                    if (m < NSJL) {
+                        const float h = tot[n] > 0.0f ? tot[n] : 0.0f;       // model.py:157 relu
+                        if (G == 1) lds[c.o_h1 + jb * 64 + lane] = h;
+                        else granule_store(X1 + jb * 64 + lane, 2u * (unsigned)t + 1u, h);
+                    }
+                }
+            } else {
+                // few output blocks per workgroup: worker w takes layers l = w, w+W, ... (W-fold latency hiding for the tile
+                // fetch), leaves each layer's skip value in LDS, and the block owners add them up IN LAYER ORDER afterwards
+                for (int l = w; l < NL; l += W) {
+                    wait_seq(ctl + C_ZSEQ, t * NL + l + 1, ctl + C_ABORT, 100 + l);
+                    ACQUIRE_WG();
+                    float zz[32];
+#pragma unroll
+                    for (int kq = 0; kq < 8; ++kq) {
+                        const f32x4 q = LDS4(((c.o_zbuf + l * 32) >> 2) + kq);
+                        zz[4 * kq + 0] = q.x; zz[4 * kq + 1] = q.y; zz[4 * kq + 2] = q.z; zz[4 * kq + 3] = q.w;
+                    }
+                    int ln = l + W;
+                    if (ln >= NL) ln = w < NL ? w : 0;               // first layer of this worker in the next step
+                    const int lnb = lay0 + ln * lstride;
+                    for (int m = 0; m < NSJL; ++m) {
+                        const int jb = m * G + g;
+                        if (m > 0) {                                 // (rare) more than one owned block: fetch on the spot
+                            load_tile_b(tk[0], rs, v16, lay0 + l * lstride + skb + jb * kTile * 4);
+                            if (use_bias) n_bs[0] = load_f32_b(rs, v4, lay0 + l * lstride + bsb + jb * 256);
+                        }
+                        float v = dot_regs(tk[0], zz);               // model.py:96 skip 1x1
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (use_bias) v = v + n_bs[0];
+                        lds[c.o_skl + (m * NL + l) * 64 + lane] = v;
+                    }
+                    load_tile_b(tk[0], rs, v16, lnb + skb + g * kTile * 4);   // block m = 0 of this worker's next layer
+                    if (use_bias) n_bs[0] = load_f32_b(rs, v4, lnb + bsb + g * 256);
+                }
+                arrive(ctl + C_SKCNT, lane);
+                if (w < NSJL) {
+                    wait_seq(ctl + C_SKCNT, W * (t + 1), ctl + C_ABORT, 10);
+                    ACQUIRE_WG();
+                    float tsum = 0.0f;
+                    for (int l = 0; l < NL; ++l) {
+                        const float v = lds[c.o_skl + (w * NL + l) * 64 + lane];
+                        tsum = (l == 0) ? v : tsum + v;               // model.py:154 sum(outputs), in layer order
+                    }
+                    const float h = tsum > 0.0f ? tsum : 0.0f;        // model.py:157 relu
+                    const int jb = w * G + g;
                     if (G == 1) lds[c.o_h1 + jb * 64 + lane] = h;
                     else granule_store(X1 + jb * 64 + lane, 2u * (unsigned)t + 1u, h);
                 }
             }
         }
+        if (wprof) wp[45] = __builtin_amdgcn_s_memtime();
         if (G > 1) gather_granules<W>(X1, S, 2u * (unsigned)t + 1u, c.o_h1, w, lane, ctl + C_ABORT, 7);
         arrive(ctl + C_H1CNT, lane);
         wait_seq(ctl + C_H1CNT, W * (t + 1), ctl + C_ABORT, 4);   // h1 complete in this workgroup's LDS
         ACQUIRE_WG();
+        if (wprof) wp[46] = __builtin_amdgcn_s_memtime();
         // ---- model.py:158-160 conv1d_1 (S->S) + relu for the owned output blocks
         if (!split1) {
             // a worker owns whole output blocks m = w + n*W and walks their chunks in order
@@ -759,6 +822,7 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                 else granule_store(X2 + jb * 64 + lane, 2u * (unsigned)t + 2u, h);
             }
         }
+        if (wprof) wp[47] = __builtin_amdgcn_s_memtime();
         // prefetches that do not depend on h2 (the sampler's inputs)
         float u_pre = 0.5f, b2_pre = 0.0f;
         if (SCALAR && w == 0) {
@@ -770,6 +834,7 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
         arrive(ctl + C_H2CNT, lane);
         wait_seq(ctl + C_H2CNT, W * (t + 1), ctl + C_ABORT, 5);   // h2 complete
         ACQUIRE_WG();
+        if (wprof) wp[48] = __builtin_amdgcn_s_memtime();
         {
             // ---- model.py:161-165 conv1d_2 (S->O): chunk partials, summed in order by the sampler wave
             for (int idx = w; idx < L.NOJ * NCH; idx += W) {
@@ -779,10 +844,12 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                 lds[c.o_cpart + idx * 64 + lane] = dot_ldso(tq, c.o_h2 + ch * 32);
             }
         }
+        if (wprof) wp[49] = __builtin_amdgcn_s_memtime();
         arrive(ctl + C_CPCNT, lane);
         if (w == 0) {
             wait_seq(ctl + C_CPCNT, W * (t + 1), ctl + C_ABORT, 6);   // chunk partials complete
             ACQUIRE_WG();
+            if (wprof) wp[50] = __builtin_amdgcn_s_memtime();
             if (SCALAR) {
                 // raw network output y[lane] (lane < O), then mixture.py:84-114
                 float y = 0.0f;
@@ -819,6 +886,7 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                 }
             }
             publish(ctl + C_SSEQ, t + 1, lane);   // next input sample published
+            if (wprof) wp[51] = __builtin_amdgcn_s_memtime();
         }
         if (LDSVI(ctl + C_ABORT)) break;
     }
@@ -850,7 +918,8 @@ __global__ void __launch_bounds__((1 + kLoaders + W) * 64) wn_generate_kernel(Ge
     c.o_ring1 = c.o_gc + NL * 64;                   // [NL][32]   delay lines with d == 1 (LDS-resident)
     c.o_causal = c.o_ring1 + NL * 32;               // [NCA][1024] causal kernel half tiles, launch-resident
     c.o_cpart1 = c.o_causal + L.NCA * 1024;         // [NSJ/G][NCH][64] conv1d_1 chunk partials (only when NSJ/G < W)
-    c.o_slots = c.o_cpart1 + ((L.NSJ / a.G < W) ? (L.NSJ / a.G) * NCH * 64 : 0);   // [nslot][SlotOff::FLOATS]
+    c.o_skl = c.o_cpart1 + ((L.NSJ / a.G < W) ? (L.NSJ / a.G) * NCH * 64 : 0);     // [NSJ/G][NL][64] per-layer skip values (same condition)
+    c.o_slots = c.o_skl + ((L.NSJ / a.G < W) ? (L.NSJ / a.G) * NL * 64 : 0);   // [nslot][SlotOff::FLOATS]
     c.stb = a.state + ((long long)c.b * a.G + c.g) * L.state_stride;
     const int* pmeta = reinterpret_cast<const int*>(a.P + L.off_meta);
     c.ring = c.stb + L.st_ring;
@@ -988,6 +1057,7 @@ struct twv_wavenet {
     int ring_off[kMaxLayers];
     int workers;   // worker waves per workgroup
     int groups;    // workgroups per stream (0 = auto)
+    int exp;
     unsigned long long* prof;
     int prof_steps;
 };
@@ -1110,7 +1180,7 @@ static long long lds_fixed_floats(const Layout& L, int G)
 {
     const int nsjl = L.NSJ / G;
     return 64 * 32 + 2LL * L.S + (long long)L.NOJ * L.NCH * 64 + 64 * 4 + 32 + (long long)L.NL * 96 + (long long)L.NCA * 1024 +
-           (nsjl < kWorkers ? (long long)nsjl * L.NCH * 64 : 0);
+           (nsjl < kWorkers ? (long long)nsjl * (L.NCH + L.NL) * 64 : 0);
 }
 static int resolve_nslot(const Layout& L, int G)
 {
@@ -1128,6 +1198,7 @@ extern "C" int twv_wavenet_create(const twv_wavenet_dims* dims, twv_wavenet** ou
     h->dims = *dims;
     h->workers = 4;
     h->groups = 0;
+    h->exp = 0;
     h->prof = nullptr; h->prof_steps = 0;
     const int rc = build_layout(*dims, h);
     if (rc != TWV_OK) { delete h; return rc; }
@@ -1176,6 +1247,7 @@ extern "C" int twv_wavenet_set_option(twv_wavenet* h, const char* name, int valu
         h->workers = value;
         return TWV_OK;
     }
+    if (!strcmp(name, "exp")) { h->exp = value; return TWV_OK; }
     if (!strcmp(name, "groups")) {   // workgroups per stream; set BEFORE sizing / resetting the state buffer
         if (value != 0 && (value < 1 || value > 16 || h->lay.NSJ % value)) return fail(TWV_E_INVALID, "groups must divide skip_channels/64");
         h->groups = value;
@@ -1325,6 +1397,7 @@ extern "C" int twv_wavenet_generate(const twv_wavenet* h, const void* packed, vo
     if ((long long)batch * G > device_cus())
         return fail(TWV_E_UNSUPPORTED, "batch * groups exceeds the CU count: the stream workgroups must all be co-resident");
     a.G = G;
+    a.exp = h->exp;
     a.exch = reinterpret_cast<unsigned long long*>((float*)state + (size_t)L.state_stride * (size_t)batch * G);
     HIPCHK(hipMemsetAsync(a.exch, 0, (size_t)batch * 2 * L.S * 8, st));
     a.lay.nslot = resolve_nslot(L, G);
