@@ -1,0 +1,316 @@
+"""-m "not gpu": the oracle against known answers / independent float64 references / its committed restatement
+fixtures, the host logic, and the C-ABI library's exported symbols (no compute calls without a GPU)."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import first_mismatch, make_case, mol_uniforms
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+# ---------------------------------------------------------------- known answers derivable from the reference text
+def test_receptive_fields(oracle):
+    d50, d30 = [2 ** i for i in range(10)] * 5, [2 ** i for i in range(10)] * 3
+    # generate.py:192 comment: 5117 for the 50-layer mu-law model; the rest by model.py:31-39
+    for dil, scalar, want in ((d50, False, 5117), (d50, True, 5147), (d30, False, 3071), (d30, True, 3101)):
+        assert oracle.receptive_field(oracle.make_dims(dil, scalar_input=scalar)) == want
+    import twvk_amd
+    from twvk_amd.wavenet import WaveNetModel
+    assert WaveNetModel.calculate_receptive_field(2, d50, False, 32) == 5117
+    assert WaveNetModel.calculate_receptive_field(2, d30, True, 32) == 3101
+
+
+def test_mu_law_known_answers(oracle):
+    q = oracle.mu_law_encode(np.array([0.0, 1.0, -1.0, 2.0, -3.0], np.float32), 256)
+    assert list(q) == [128, 255, 0, 255, 0]          # ops.py:22-33; generate.py:190 silence = Q/2
+    a = np.linspace(-1, 1, 4001).astype(np.float32)
+    back = oracle.mu_law_decode(oracle.mu_law_encode(a, 256), 256)
+    # round trip: at most half a quantisation step of the companded signal
+    comp = np.sign(a) * np.log1p(255 * np.abs(a)) / np.log1p(255)
+    comp_back = np.sign(back) * np.log1p(255 * np.abs(back)) / np.log1p(255)
+    assert np.abs(comp - comp_back).max() <= 1.0 / 255 + 1e-5
+    assert np.allclose(oracle.mu_law_expand(comp.astype(np.float32), 256), a, atol=2e-5)
+
+
+def test_hparams_surface(tmp_path):
+    import twvk_amd
+    hp = twvk_amd.default_hparams()
+    assert int(np.prod(hp.upsample_factor)) == hp.hop_size == 300        # hparams.py:79
+    assert hp.num_freq == 1025 and hp.frame_shift_ms == 12.5 and hp.frame_length_ms == 50.0   # hparams.py:190-192
+    assert (hp.residual_channels, hp.dilation_channels, hp.skip_channels, hp.out_channels) == (32, 32, 512, 30)
+    assert len(hp.dilations) == 50 and hp.scalar_input and hp.input_type == "raw" and hp.gc_channels == 32
+    # params.json round trip (utils/__init__.py:143-172): unknown keys skipped, known keys overridden
+    hp.dilations = [1, 2, 4]
+    twvk_amd.save_hparams(str(tmp_path), hp)
+    data = json.load(open(tmp_path / "params.json"))
+    data["not_a_hparam"] = 1
+    data["sample_rate"] = 16000
+    json.dump(data, open(tmp_path / "params.json", "w"))
+    hp2 = twvk_amd.load_hparams(twvk_amd.default_hparams(), str(tmp_path))
+    assert hp2.dilations == [1, 2, 4] and hp2.sample_rate == 16000 and not hasattr(hp2, "not_a_hparam")
+
+
+# ---------------------------------------------------------------- elementary functions of the arithmetic contract
+@pytest.mark.parametrize("name,ref,lo,hi,tol", [
+    ("tanh", np.tanh, -12, 12, 3e-7), ("sigmoid", lambda v: 1 / (1 + np.exp(-v)), -25, 25, 2e-7)])
+def test_rationals_accuracy(oracle, name, ref, lo, hi, tol):
+    x = np.linspace(lo, hi, 50001).astype(np.float32)
+    assert np.abs(oracle.elementwise(name, x) - ref(x.astype(np.float64))).max() < tol
+
+
+def test_exp_log_accuracy(oracle):
+    x = np.linspace(-87, 88, 50001).astype(np.float32)
+    e = oracle.elementwise("exp", x).astype(np.float64)
+    assert (np.abs(e - np.exp(x.astype(np.float64))) / np.exp(x.astype(np.float64))).max() < 2e-7
+    xp = np.exp(np.linspace(-80, 80, 50001)).astype(np.float32)
+    l = oracle.elementwise("log", xp).astype(np.float64)
+    assert np.abs(l - np.log(xp.astype(np.float64))).max() < 5e-6
+    xd = np.linspace(-700, 700, 20001)
+    assert (np.abs(oracle.elementwise("exp64", xd) - np.exp(xd)) / np.exp(xd)).max() < 4e-16
+    xl = np.exp(np.linspace(-700, 700, 20001))
+    assert np.abs(oracle.elementwise("log64", xl) - np.log(xl)).max() < 2e-13
+
+
+def test_cdot_is_the_contract(oracle):
+    """AC-1 spelled out in numpy float32 (fma emulated in float64: exact for a product plus an addend)"""
+    rng = np.random.RandomState(0)
+    for K in (2, 16, 32, 80, 512):
+        w = rng.randn(K).astype(np.float32); x = rng.randn(K).astype(np.float32)
+        r = None
+        for k0 in range(0, K, 32):
+            s = [np.float32(0)] * 4
+            for k in range(k0, min(k0 + 32, K)):
+                s[(k - k0) & 3] = np.float32(np.float64(w[k]) * np.float64(x[k]) + np.float64(s[(k - k0) & 3]))
+            a = np.float32(np.float32(s[0] + s[1]) + np.float32(s[2] + s[3]))
+            r = a if r is None else np.float32(r + a)
+        got = oracle.lib().twvo_cdot(w.ctypes.data_as(C.POINTER(C.c_float)), 1, x.ctypes.data_as(C.POINTER(C.c_float)), K)
+        assert np.float32(got) == r, K
+
+
+# ---------------------------------------------------------------- the network
+@pytest.mark.parametrize("scalar", [True, False])
+def test_incremental_equals_full_convolution(oracle, scalar):
+    """the reference's design intent (model.py:236 comment; fast-wavenet): once the delay lines are warm, the
+    incremental network reproduces the full 'valid' convolution -- here bit for bit"""
+    d = oracle.make_dims([1, 2, 4, 1, 2, 4], S=64, Q=16, out_channels=30, scalar_input=scalar, ifw=8, G=32, gc_card=2, L=0)
+    rf = oracle.receptive_field(d)
+    T, B = rf + 40, 2
+    blob = oracle.blob_from_tensors(d, oracle.random_tensors(d, seed=3, scale=0.2))
+    rng = np.random.RandomState(1)
+    inp = rng.uniform(-1, 1, (B, T)).astype(np.float32) if scalar else rng.randint(0, 16, (B, T)).astype(np.int32)
+    gc = np.array([0, 1], np.int32)
+    full = oracle.forward_full(d, blob, inp, None, gc)
+    st = oracle.State(d, B)
+    inc = np.stack([oracle.step(d, blob, st, inp[:, t], None, gc) for t in range(T)], 1)[:, rf - 1:]
+    assert full.shape == (B, T - rf + 1, d.O)
+    assert np.array_equal(inc, full)
+
+
+def test_lc_uses_previous_frame(oracle):
+    """model.py:79-80 slices the lc projection from the FRONT of the 2-deep queue: step t sees the frame pushed at t-1"""
+    d, tensors, blob = make_case(oracle, [1, 2], S=64, G=0, scale=0.3)
+    B = 1
+    x = np.array([0.3], np.float32)
+    f0 = np.full((B, 80), 0.5, np.float32); f1 = np.full((B, 80), -0.7, np.float32)
+    st = oracle.State(d, B); a0 = oracle.step(d, blob, st, x, f0); a1 = oracle.step(d, blob, st, x, f1)
+    st = oracle.State(d, B); b0 = oracle.step(d, blob, st, x, f1); b1 = oracle.step(d, blob, st, x, f1)
+    assert np.array_equal(a0, b0)            # step 0 ignores the frame pushed at step 0 (queue front is still zeros)
+    assert not np.array_equal(a1, b1)        # step 1 sees the frame pushed at step 0
+
+
+def test_upsample_shape_and_linearity(oracle):
+    d, tensors, blob = make_case(oracle, [1], S=64)
+    mel = np.random.RandomState(2).uniform(-4, 4, (2, 5, 80)).astype(np.float32)
+    up = oracle.upsample(d, blob, mel)
+    assert up.shape == (2, 5 * 300, 80)                       # generate.py:152
+    # every output row depends on exactly one input frame (kernel == stride along time)
+    mel2 = mel.copy(); mel2[:, 3] += 1.0
+    diff = np.abs(oracle.upsample(d, blob, mel2) - up).sum(axis=(0, 2))
+    assert np.all(diff[:900] == 0) and np.all(diff[1200:] == 0) and np.all(diff[900:1200] > 0)
+
+
+def test_mol_sampler_against_float64_formula(oracle):
+    """mixture.py:84-114 evaluated independently in float64"""
+    rng = np.random.RandomState(4)
+    for _ in range(200):
+        y = rng.randn(30).astype(np.float32) * 2
+        u = rng.uniform(1e-5, 1 - 1e-5, 11).astype(np.float32)
+        got = oracle.sample_mol(y, u)
+        y64, u64 = y.astype(np.float64), u.astype(np.float64)
+        g = y64[:10] - np.log(-np.log(u64[:10]))
+        order = np.sort(g)
+        if order[-1] - order[-2] < 1e-4:
+            continue                                     # argmax too close to call in float32
+        k = int(np.argmax(g))
+        ls = max(y64[20 + k], np.log(1e-14))
+        want = np.clip(y64[10 + k] + np.exp(ls) * (np.log(u64[10]) - np.log(1 - u64[10])), -1, 1)
+        assert abs(got - want) < 1e-4 * max(1.0, np.exp(ls)), (got, want)
+
+
+def test_categorical_sampler_matches_numpy_legacy_choice(oracle):
+    """generate.py:219-231: float64 softmax -> float32, temperature rescale, np.random.choice == searchsorted(cumsum)"""
+    rng = np.random.RandomState(5)
+    agree = 0
+    for trial in range(300):
+        logits = (rng.randn(256) * 3).astype(np.float32)
+        temp = [1.0, 0.7, 1.3][trial % 3]
+        x = logits.astype(np.float64)
+        p = np.exp(x - x.max()); p = (p / p.sum()).astype(np.float32)              # model.py:243
+        with np.errstate(divide="ignore"):
+            sp = np.log(p) / temp                                                      # generate.py:220
+            sp = sp - np.logaddexp.reduce(sp, axis=-1, keepdims=True)                  # generate.py:221
+            sp = np.exp(sp)                                                            # generate.py:222
+        if temp == 1.0:
+            assert np.allclose(p, sp, atol=1e-5)                                       # generate.py:227-228
+        rs = np.random.RandomState(trial)
+        u = np.random.RandomState(trial).random_sample()
+        want = rs.choice(np.arange(256), p=sp)                                         # generate.py:231
+        got, proba = oracle.sample_categorical(logits, temp, u)
+        assert np.allclose(proba, sp, rtol=2e-5, atol=1e-9)
+        agree += int(got == want)
+    assert agree >= 298        # the two may differ only when u falls within float32 noise of a cdf boundary
+
+
+def test_restatement_fixtures(oracle):
+    """the committed restatement_* fixtures pin the oracle against drift (they are NOT reference goldens)"""
+    f = np.load(os.path.join(GOLD, "restatement_codec_math.npz"))
+    assert np.array_equal(oracle.mu_law_encode(f["audio"], 256), f["q"])
+    assert first_mismatch(oracle.mu_law_decode(np.arange(256, dtype=np.int32), 256), f["dec"]) is None
+    for name in ("tanh", "sigmoid", "exp"):
+        assert first_mismatch(oracle.elementwise(name, f["x"]), f[name]) is None, name
+    assert first_mismatch(oracle.elementwise("log", f["xp"]), f["log"]) is None
+    g = np.load(os.path.join(GOLD, "restatement_wavenet_mol_small.npz"))
+    dil = [int(v) for v in g["dilations"]]
+    d, tensors, blob = make_case(oracle, dil, S=int(g["S"]), scale=float(g["scale"]), seed=int(g["weight_seed"]))
+    U = oracle.upsample(d, blob, g["mel"])
+    assert first_mismatch(U[:, :8], g["upsampled_head"]) is None
+    T = g["uniforms"].shape[1]
+    out = oracle.generate_mol(d, blob, oracle.State(d, 2), U[:, :T], g["gc_ids"], g["first_input"], g["uniforms"])
+    assert first_mismatch(out, g["samples"]) is None
+
+
+# ---------------------------------------------------------------- host side of the product
+def test_blob_layout_agrees_with_oracle(oracle):
+    """the product's canonical blob (weights.py + the C-ABI's count) and the oracle's independent one"""
+    import twvk_amd
+    from twvk_amd import weights as W, _lib
+    for kw in (dict(), dict(scalar_input=False), dict(use_bias=False, G=0), dict(L=0, S=128)):
+        d = oracle.make_dims([1, 2, 4, 8], **kw)
+        tensors = oracle.random_tensors(d, seed=1)
+        specs = W.tensor_specs(4, 32, 32, d.S, d.Q, 30, bool(d.scalar_input), 32, bool(d.use_bias), d.G, d.gc_card, d.L, (5, 5, 12))
+        assert [n for n, _ in specs] == [n for n, _ in oracle.tensor_specs(d)]
+        assert np.array_equal(W.flatten(specs, tensors), oracle.blob_from_tensors(d, tensors))
+        dims = _lib.Dims()
+        dims.n_layers = 4
+        for i, v in enumerate([1, 2, 4, 8]):
+            dims.dilations[i] = v
+        dims.residual_channels = dims.dilation_channels = 32
+        dims.skip_channels, dims.quantization_channels, dims.out_channels = d.S, d.Q, 30
+        dims.scalar_input, dims.initial_filter_width, dims.use_biases = d.scalar_input, 32, d.use_bias
+        dims.gc_channels, dims.gc_cardinality, dims.lc_channels = d.G, d.gc_card, d.L
+        dims.n_upsample = 3 if d.L else 0
+        for i, v in enumerate((5, 5, 12)):
+            dims.upsample_factor[i] = v
+        h = C.c_void_p()
+        L = _lib.lib()
+        _lib.check(L.twv_wavenet_create(C.byref(dims), C.byref(h)))      # host-only: no device is touched
+        assert L.twv_wavenet_blob_floats(h) == oracle.blob_floats(d)
+        assert L.twv_wavenet_receptive_field(h) == oracle.receptive_field(d)
+        assert L.twv_wavenet_hop_size(h) == (300 if d.L else 1)
+        L.twv_wavenet_destroy(h)
+
+
+def test_c_abi_exports_match_header():
+    import twvk_amd
+    from twvk_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "twv_amd.h")).read()
+    declared = set(re.findall(r"\b(twv_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    lib = _lib.lib()
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert set(_lib.EXPORTS) <= declared
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    assert "wn_generate_kernel" in nm or "_Z18wn_generate_kernel" in nm, "gfx950 kernels must be in the library"
+
+
+def test_create_rejects_unsupported_dims():
+    import twvk_amd
+    from twvk_amd.wavenet import WaveNetModel
+    from twvk_amd._lib import TwvError
+    with pytest.raises(TwvError):
+        WaveNetModel(1, [1, 2], 2, 16, 16, 512, scalar_input=True, out_channels=30, device="cpu")     # R, D must be 32
+    with pytest.raises(TwvError):
+        WaveNetModel(1, [1, 2], 2, 32, 32, 500, scalar_input=True, out_channels=30, device="cpu")     # S % 64
+    with pytest.raises(ValueError):
+        WaveNetModel(1, [1, 2], 3, 32, 32, 512, device="cpu")                                          # filter_width
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "tacotron-wavenet-vocoder-korean_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("CPU checker", ""), os.path.join(dirpath, f)
+
+
+# ---------------------------------------------------------------- multi-rank layout (gloo, world_size 2)
+def test_shard_ranges():
+    import twvk_amd
+    from twvk_amd.shard import shard_range
+    for n in (0, 1, 7, 8, 9, 64):
+        for ws in (1, 2, 3, 8):
+            spans = [shard_range(n, ws, r) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import twvk_amd
+from twvk_amd.shard import shard_range, max_over_ranks, gather_on_rank0
+from oracle import oracle as O
+from helpers import make_case, mol_uniforms
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+rank = dist.get_rank()
+# 5 utterances over 2 ranks (ragged 3 + 2): every rank generates ITS utterances; no collective on the data path
+dil = [1, 2, 4]
+d, tensors, blob = make_case(O, dil, S=64, L=0, scale=0.2)
+B, T = 5, 20
+u = mol_uniforms(B, T, 10); seed = np.linspace(-0.5, 0.5, B).astype(np.float32); gc = (np.arange(B) % 2).astype(np.int32)
+a, b = shard_range(B, 2, rank)
+mine = O.generate_mol(d, blob, O.State(d, b - a), None, gc[a:b], seed[a:b], u[a:b])
+wall = max_over_ranks(1.0 + rank)
+parts = gather_on_rank0(mine)
+if rank == 0:
+    whole = O.generate_mol(d, blob, O.State(d, B), None, gc, seed, u)
+    assert wall == 2.0
+    assert np.array_equal(np.concatenate(parts, 0), whole)      # sharding does not change any utterance
+    print("OK")
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_rank_sharding_gloo(tmp_path):
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "OK" in outs[0]

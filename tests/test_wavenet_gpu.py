@@ -189,3 +189,20 @@ def test_state_carries_over_between_calls(torch_cuda, oracle):
     m.queue_initializer()
     one = m.predict_proba_incremental(seed_in, U[:, 0], gc, uniforms=u[:, 0]).cpu().numpy()
     assert first_mismatch(one[:, 0], want[:, 0]) is None
+
+
+def test_committed_restatement_fixture(torch_cuda):
+    """HIP path against the committed restatement_* fixture (no oracle library needed at run time)"""
+    import os
+    from twvk_amd import weights as W
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "restatement_wavenet_mol_small.npz"))
+    dil = [int(v) for v in g["dilations"]]
+    specs = W.tensor_specs(len(dil), 32, 32, int(g["S"]), 256, 30, True, 32, True, 32, 2, 80, (5, 5, 12))
+    rng = np.random.RandomState(int(g["weight_seed"]))
+    tensors = {n: (rng.randn(*shp) * float(g["scale"])).astype(np.float32) for n, shp in specs}
+    m = make_model(2, dil, tensors, S=int(g["S"]))
+    U = m.create_upsample(g["mel"])
+    assert first_mismatch(U[:, :8].cpu().numpy(), g["upsampled_head"]) is None
+    T = g["uniforms"].shape[1]
+    out = m.generate(U[:, :T].contiguous(), g["gc_ids"], g["first_input"], g["uniforms"]).cpu().numpy()
+    assert first_mismatch(out, g["samples"]) is None
