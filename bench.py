@@ -147,17 +147,25 @@ def main():
             from oracle import oracle as O
             d = O.make_dims(dil)
             blob = O.blob_from_tensors(d, tensors)
-            n = args.cpu_steps or 1200
-            Uc = np.zeros((B, n, 80), np.float32)
-            Uc[:] = rng.uniform(-1, 1, (B, n, 80))
-            uc = u[:, :n].cpu().numpy()
             st = O.State(d, B)
+            n = args.cpu_steps
+            if not n:   # size the sample for about 15 s of CPU work
+                probe = 200
+                Up = rng.uniform(-1, 1, (B, probe, 80)).astype(np.float32)
+                c0 = time.perf_counter()
+                O.generate_mol(d, blob, st, Up, gc, seed_in, u[:, :probe].cpu().numpy())
+                per = (time.perf_counter() - c0) / probe
+                n = int(max(probe, min(T, 15.0 / max(per, 1e-9))))
+                st.reset()
+            Uc = rng.uniform(-1, 1, (B, n, 80)).astype(np.float32)
+            uc = u[:, :n].cpu().numpy()
             c0 = time.perf_counter()
             O.generate_mol(d, blob, st, Uc, gc, seed_in, uc)
             cdt = time.perf_counter() - c0
             res["cpu_baseline"] = {"value": B * n / cdt, "unit": "samples/s", "cores": 1, "kind": "port",
-                                   "sample": "build's CPU restatement (oracle/, scalar C, 1 thread), same model, B=%d x %d generation steps "
-                                             "(%.1f s of CPU work); NOT the reference generate.py (TensorFlow absent)" % (B, n, cdt)}
+                                   "sample": "build's CPU restatement (oracle/, plain C, 1 thread) of the same model on the GPU box's host: "
+                                             "B=%d x %d generation steps = %.1f s of CPU work; NOT the reference generate.py "
+                                             "(TensorFlow is absent; parity unpinned)" % (B, n, cdt)}
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()
