@@ -311,7 +311,7 @@ __device__ __forceinline__ float dot_ldso(const Tile& t, int xo)
 // Intra-workgroup synchronisation is by monotonically increasing LDS sequence words only (no s_barrier inside the
 // sample loop, so the wave roles run decoupled).  Every wait is BOUNDED: after ~2^22 polls it raises the workgroup's
 // abort word, every other wait then falls through, and the launch ends with a watchdog code instead of hanging.
-enum { C_ZSEQ = 0, C_ABORT = 1, C_SAMPLE = 2, C_CDONE = 3, C_H1CNT = 4, C_H2CNT = 5, C_CPCNT = 6, C_SSEQ = 7, C_P1CNT = 8, C_SKCNT = 9 };
+enum { C_ZSEQ = 0, C_ABORT = 1, C_SAMPLE = 2, C_CDONE = 3, C_H1CNT = 4, C_H2CNT = 5, C_CPCNT = 6, C_SSEQ = 7, C_P1CNT = 8, C_SKCNT = 9, C_LGCNT = 10 };
 
 __device__ __forceinline__ bool wait_seq(int fo_flag, int target, int fo_abort, int code)
 {
@@ -378,7 +378,7 @@ __device__ __forceinline__ bool gather_granules(unsigned long long* X, int S, un
 
 // per-workgroup context shared by the wave roles (LDS positions are float offsets into lds[])
 struct Ctx {
-    int o_zbuf, o_h1, o_h2, o_cpart, o_meta, o_ringpos, o_pos0, o_ready, o_ctrl, o_gc, o_ring1, o_causal, o_cpart1, o_skl, o_slots;
+    int o_zbuf, o_h1, o_h2, o_cpart, o_meta, o_ringpos, o_pos0, o_ready, o_ctrl, o_gc, o_ring1, o_causal, o_cpart1, o_skl, o_cat, o_slots;
     int b, g, lane;
     float* stb;            // this stream's state
     float* ring;
@@ -846,6 +846,21 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
         }
         if (wprof) wp[49] = __builtin_amdgcn_s_memtime();
         arrive(ctl + C_CPCNT, lane);
+        if (!SCALAR) {
+            // one-hot: every worker assembles the logits of its output blocks (chunk partials in order, then bias)
+            wait_seq(ctl + C_CPCNT, W * (t + 1), ctl + C_ABORT, 6);
+            ACQUIRE_WG();
+            for (int ob = w; ob < L.NOJ; ob += W) {
+                float y = 0.0f;
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const float cp = lds[c.o_cpart + (ob * NCH + ch) * 64 + lane];
+                    y = (ch == 0) ? cp : y + cp;
+                }
+                if (use_bias && ob * 64 + lane < L.O) y = y + a.P[L.off_b2 + ob * 64 + lane];
+                lds[c.o_cat + ob * 64 + lane] = y;
+            }
+            arrive(ctl + C_LGCNT, lane);
+        }
         if (w == 0) {
             wait_seq(ctl + C_CPCNT, W * (t + 1), ctl + C_ABORT, 6);   // chunk partials complete
             ACQUIRE_WG();
@@ -885,6 +900,82 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                     lds[ctl + C_SAMPLE] = xs;
                 }
             }
+            if (!SCALAR) {
+                // ---- one-hot output: model.py:243 float64 softmax -> float32, generate.py:219-222 temperature rescale with a
+                // left-to-right np.logaddexp.reduce, generate.py:231 legacy np.random.choice = searchsorted(cumsum(p)/last, u, 'right')
+                // logits were assembled (chunk partials in order + bias) by the workers into lds[o_cat .. o_cat+Q)
+                wait_seq(ctl + C_LGCNT, W * (t + 1), ctl + C_ABORT, 11);
+                ACQUIRE_WG();
+                const int Q = L.Q;
+                const int o_lg = c.o_cat, o_lp = c.o_cat + L.Opad;                 // float logits / float log-probabilities
+                __attribute__((address_space(3))) double* e64 = (__attribute__((address_space(3))) double*)(lds + c.o_cat + 2 * L.Opad);
+                float xv[16];                                                        // lane owns classes i = lane + 64k
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int i = lane + 64 * k;
+                    xv[k] = (i < Q) ? lds[o_lg + i] : -3.0e38f;
+                    mx = xv[k] > mx ? xv[k] : mx;
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+                if (a.dbg != nullptr && g == 0 && t < a.dbg_steps) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if (lane + 64 * k < Q)
+                            a.dbg[((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)NL * 64 + lane + 64 * k] = xv[k];
+                }
+                const double m64 = (double)mx;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int i = lane + 64 * k;
+                    if (i < Q) e64[i] = exp64_e((double)xv[k] - m64);
+                }
+                double sum = 0.0;                                                    // sequential, class order
+                for (int i = 0; i < Q; ++i) sum += e64[i];
+                const float temp32 = a.temperature;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int i = lane + 64 * k;
+                    if (i < Q) {
+                        const float p32 = (float)(e64[i] / sum);                    // tf.cast(softmax(float64), float32)
+                        lds[o_lp + i] = div_(log_e(p32), temp32);                   // np.log(prediction) / temperature (float32)
+                    }
+                }
+                float lse = lds[o_lp + 0];                                           // np.logaddexp.reduce, left to right
+                for (int i = 1; i < Q; ++i) {
+                    const float y = lds[o_lp + i];
+                    if (lse == y) lse = lse + 0.693147180559945309417232121458176568f;
+                    else {
+                        const float tmp = lse - y;
+                        if (tmp > 0.0f) lse = lse + log1p_e(exp_e(-tmp));
+                        else if (tmp <= 0.0f) lse = y + log1p_e(exp_e(tmp));
+                        else lse = tmp;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int i = lane + 64 * k;
+                    if (i < Q) e64[i] = (double)exp_e(lds[o_lp + i] - lse);        // scaled_prediction, then float64 for the cdf
+                }
+                double cacc = 0.0;                                                   // cdf = p.cumsum() (float64, sequential)
+                for (int i = 0; i < Q; ++i) { cacc += e64[i]; if (lane == 0) e64[i] = cacc; }
+                const double last = cacc;
+                const double uu = reinterpret_cast<const double*>(a.uniforms)[(long long)b * T + t];
+                int idx = Q - 1;
+                bool found = false;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int i = lane + 64 * k;
+                    const bool hit = (i < Q) && (e64[i] / last > uu);                 // cdf /= cdf[-1]; searchsorted(u, 'right')
+                    const unsigned long long mask = __ballot(hit);
+                    if (!found && mask != 0ull) { idx = 64 * k + (int)__ffsll((long long)mask) - 1; found = true; }
+                }
+                if (lane == 0) {
+                    if (g == 0) reinterpret_cast<int*>(a.out)[(long long)b * T + t] = idx;
+                    LDSI(ctl + C_SAMPLE) = idx;
+                }
+            }
             publish(ctl + C_SSEQ, t + 1, lane);   // next input sample published
             if (wprof) wp[51] = __builtin_amdgcn_s_memtime();
         }
@@ -919,7 +1010,8 @@ __global__ void __launch_bounds__((1 + kLoaders + W) * 64) wn_generate_kernel(Ge
     c.o_causal = c.o_ring1 + NL * 32;               // [NCA][1024] causal kernel half tiles, launch-resident
     c.o_cpart1 = c.o_causal + L.NCA * 1024;         // [NSJ/G][NCH][64] conv1d_1 chunk partials (only when NSJ/G < W)
     c.o_skl = c.o_cpart1 + ((L.NSJ / a.G < W) ? (L.NSJ / a.G) * NCH * 64 : 0);     // [NSJ/G][NL][64] per-layer skip values (same condition)
-    c.o_slots = c.o_skl + ((L.NSJ / a.G < W) ? (L.NSJ / a.G) * NL * 64 : 0);   // [nslot][SlotOff::FLOATS]
+    c.o_cat = c.o_skl + ((L.NSJ / a.G < W) ? (L.NSJ / a.G) * NL * 64 : 0);        // one-hot sampler scratch: logits, log-probs, float64 exps/cdf
+    c.o_slots = c.o_cat + (L.scalar ? 0 : 4 * L.Opad);                              // [nslot][SlotOff::FLOATS]
     c.stb = a.state + ((long long)c.b * a.G + c.g) * L.state_stride;
     const int* pmeta = reinterpret_cast<const int*>(a.P + L.off_meta);
     c.ring = c.stb + L.st_ring;
@@ -1180,7 +1272,7 @@ static long long lds_fixed_floats(const Layout& L, int G)
 {
     const int nsjl = L.NSJ / G;
     return 64 * 32 + 2LL * L.S + (long long)L.NOJ * L.NCH * 64 + 64 * 4 + 32 + (long long)L.NL * 96 + (long long)L.NCA * 1024 +
-           (nsjl < kWorkers ? (long long)nsjl * (L.NCH + L.NL) * 64 : 0);
+           (nsjl < kWorkers ? (long long)nsjl * (L.NCH + L.NL) * 64 : 0) + (L.scalar ? 0 : 4LL * L.Opad);
 }
 static int resolve_nslot(const Layout& L, int G)
 {
@@ -1403,12 +1495,18 @@ extern "C" int twv_wavenet_generate(const twv_wavenet* h, const void* packed, vo
     a.lay.nslot = resolve_nslot(L, G);
     if (a.lay.nslot < 1) return fail(TWV_E_UNSUPPORTED, "model does not fit the 160 KiB LDS budget");
     const size_t shm = (size_t)(lds_fixed_floats(L, G) + (long long)a.lay.nslot * SlotOff::FLOATS) * 4;
-    if (!L.scalar) return fail(TWV_E_UNSUPPORTED, "one-hot (mu-law softmax) generation is not built yet");
     const int nsjl = L.NSJ / G;
     const int ntw = (nsjl + kWorkers - 1) / kWorkers;
-    if (ntw <= 1) return launch_generate<kWorkers, 1, true>(a, shm, st);
-    if (ntw == 2) return launch_generate<kWorkers, 2, true>(a, shm, st);
-    if (ntw <= 4) return launch_generate<kWorkers, 4, true>(a, shm, st);
+    if (!L.scalar && L.Q > 1024) return fail(TWV_E_UNSUPPORTED, "quantization_channels must be <= 1024");
+    if (L.scalar) {
+        if (ntw <= 1) return launch_generate<kWorkers, 1, true>(a, shm, st);
+        if (ntw == 2) return launch_generate<kWorkers, 2, true>(a, shm, st);
+        if (ntw <= 4) return launch_generate<kWorkers, 4, true>(a, shm, st);
+    } else {
+        if (ntw <= 1) return launch_generate<kWorkers, 1, false>(a, shm, st);
+        if (ntw == 2) return launch_generate<kWorkers, 2, false>(a, shm, st);
+        if (ntw <= 4) return launch_generate<kWorkers, 4, false>(a, shm, st);
+    }
     return fail(TWV_E_UNSUPPORTED, "skip_channels too large for the worker count");
 }
 

@@ -206,3 +206,52 @@ def test_committed_restatement_fixture(torch_cuda):
     T = g["uniforms"].shape[1]
     out = m.generate(U[:, :T].contiguous(), g["gc_ids"], g["first_input"], g["uniforms"]).cpu().numpy()
     assert first_mismatch(out, g["samples"]) is None
+
+
+def _run_onehot(oracle, dil, B, T, S=512, Q=256, temperature=1.0, groups=None, scale=0.05, L=80, G=32, debug_steps=0):
+    d, tensors, blob = make_case(oracle, dil, scalar_input=False, S=S, Q=Q, scale=scale, L=L, G=G)
+    m = make_model(B, dil, tensors, scalar_input=False, S=S, Q=Q, L=L, G=G, groups=groups)
+    rng = np.random.RandomState(1)
+    U = rng.uniform(-4, 4, (B, T, L)).astype(np.float32) if L else None
+    gc = (np.arange(B) % 2).astype(np.int32) if G else None
+    seed_in = rng.randint(Q, size=B).astype(np.int32)              # generate.py:192
+    u = np.random.RandomState(2).random_sample((B, T))             # np.random.choice's single draw per sample
+    want = oracle.generate_mulaw(d, blob, oracle.State(d, B), U, gc, seed_in, u, temperature)
+    res = m.generate(U, gc, seed_in, u, temperature=temperature, debug_steps=debug_steps)
+    return d, blob, want, res, (U, gc, seed_in, u)
+
+
+@pytest.mark.parametrize("temperature", [1.0, 0.8])
+def test_generate_onehot_small_with_dumps(torch_cuda, oracle, temperature):
+    dil = [1, 2, 4, 8, 1, 2, 4, 8]
+    B, T, dbg = 2, 40, 3
+    d, blob, want, (got, dump), (U, gc, seed_in, u) = _run_onehot(oracle, dil, B, T, S=128, temperature=temperature, scale=0.3,
+                                                                  debug_steps=dbg)
+    dump = dump.cpu().numpy()
+    st = oracle.State(d, B)
+    inp = seed_in.copy()
+    NL = len(dil)
+    for t in range(dbg):
+        raw, dz, dx = oracle.step(d, blob, st, inp, U[:, t], gc, debug=True)
+        gz = dump[:, t, :NL * 64].reshape(B, NL, 2, 32)
+        assert first_mismatch(gz[:, :, 0], dz) is None, ("z", t)
+        assert first_mismatch(gz[:, :, 1], dx) is None, ("x", t)
+        assert first_mismatch(dump[:, t, NL * 64:NL * 64 + 256], raw) is None, ("logits", t)
+        inp = want[:, t]
+    assert np.array_equal(got.cpu().numpy(), want), first_mismatch(got.cpu().numpy(), want)
+
+
+def test_generate_c1_config(torch_cuda, oracle):
+    """BASELINE configs[0]: mu-law-256, default 50 layers, 54 mel frames x 300 = 16 200 samples (about 1 s at 16 kHz), B=1"""
+    dil = [2 ** i for i in range(10)] * 5
+    d, blob, want, got, _ = _run_onehot(oracle, dil, 1, 54 * 300)
+    got = got.cpu().numpy()
+    assert got.dtype == np.int32 and got.shape == (1, 16200)
+    assert np.array_equal(got, want), first_mismatch(got, want)
+    assert got.min() >= 0 and got.max() <= 255
+
+
+@pytest.mark.parametrize("kw", [dict(groups=1), dict(groups=2, Q=64), dict(L=0, G=0, Q=16)])
+def test_generate_onehot_variants(torch_cuda, oracle, kw):
+    d, blob, want, got, _ = _run_onehot(oracle, [1, 2, 4, 8, 16], 3, 50, S=128, scale=0.3, **kw)
+    assert np.array_equal(got.cpu().numpy(), want), kw
