@@ -95,6 +95,12 @@ int twv_wavenet_generate(const twv_wavenet* h, const void* packed, void* state, 
                          int batch, int n_steps, void* out, int32_t* status, float* debug, int debug_steps,
                          void* stream);
 
+/* Priming (generate.py:168-180, --wav_seed): feeds `inputs` (B, n_steps; float32 | int32 ids) one per step WITHOUT sampling,
+ * exactly like the reference's priming loop that discards next_sample: only the causal queue and the delay lines advance.
+ * cond as for twv_wavenet_generate (the reference primes with an all-zero local condition). */
+int twv_wavenet_prime(const twv_wavenet* h, const void* packed, void* state, const void* cond, const void* inputs,
+                      int batch, int n_steps, int32_t* status, void* stream);
+
 /* synchronises `stream` and converts a non-zero status word into TWV_E_KERNEL. */
 int twv_wavenet_status(const int32_t* status, void* stream);
 

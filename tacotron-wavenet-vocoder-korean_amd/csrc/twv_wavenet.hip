@@ -230,6 +230,7 @@ struct GenArgs {
     float* state;              // per-stream delay lines etc.
     const float* cond;         // [B][NL][64] gc  then  [B][T][NL][64] lc
     const void* first_input;   // (B)
+    const void* forced;        // optional (B,T): teacher-forced inputs (priming, generate.py:177-180); no sampling then
     const void* uniforms;      // (B,T,nr_mix+1) f32  |  (B,T) f64
     void* out;                 // (B,T)
     int* status;               // [4]
@@ -428,11 +429,12 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
     for (int t = 0; t < T; ++t) {
         const bool prof = a.prof != nullptr && b == 0 && c.g == 0 && t < a.prof_steps;
         unsigned long long* pp = a.prof + (long long)t * 80;
-        if (t > 0) { wait_seq(ctl + C_SSEQ, t, ctl + C_ABORT, 3); ACQUIRE_WG(); }   // sample t-1 published
+        if (t > 0 && a.forced == nullptr) { wait_seq(ctl + C_SSEQ, t, ctl + C_ABORT, 3); ACQUIRE_WG(); }   // sample t-1 published
         if (prof && lane == 0) { pp[0] = __builtin_amdgcn_s_memtime(); pp[7] = wall_clock64(); }
         if (SCALAR) {
             // model.py:122 causal_queue shift+append; model.py:41-46 causal conv (k = ifw, no bias)
-            const float s_in = (t == 0) ? reinterpret_cast<const float*>(a.first_input)[b] : lds[ctl + C_SAMPLE];
+            const float s_in = a.forced != nullptr ? reinterpret_cast<const float*>(a.forced)[(long long)b * T + t]
+                               : ((t == 0) ? reinterpret_cast<const float*>(a.first_input)[b] : lds[ctl + C_SAMPLE]);
             const float sh = __shfl_down(hv, 1);
             hv = (lane == L.ifw - 1) ? s_in : sh;
             x = 0.0f;
@@ -451,7 +453,8 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
             }
         } else {
             // one-hot input: the k=2 causal conv over one-hot rows is the sum of two kernel rows
-            const int qcur = (t == 0) ? reinterpret_cast<const int*>(a.first_input)[b] : LDSI(ctl + C_SAMPLE);
+            const int qcur = a.forced != nullptr ? reinterpret_cast<const int*>(a.forced)[(long long)b * T + t]
+                             : ((t == 0) ? reinterpret_cast<const int*>(a.first_input)[b] : LDSI(ctl + C_SAMPLE));
             const float w1r = a.P[L.off_causal + ((long long)L.Q + qcur) * 32 + (lane & 31)];
             if (prev_valid) {
                 const float w0r = a.P[L.off_causal + (long long)qprev * 32 + (lane & 31)];
@@ -645,6 +648,7 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
 {
     const Layout& L = a.lay;
     const int NL = L.NL, T = a.T, NSJ = L.NSJ, NCH = L.NCH, S = L.S, lane = c.lane, b = c.b, G = a.G, g = c.g;
+    if (a.forced != nullptr) return;                // priming only advances the delay lines (chain + loader waves)
     const int NSJL = NSJ / G;                       // output blocks owned by this workgroup
     const bool split1 = NSJL < W;                   // conv1d_1: spread the chunks of a block over the workers
     const int v16 = lane * 16, v4 = lane * 4;
@@ -1468,12 +1472,12 @@ static int launch_generate(const GenArgs& a, size_t shm, hipStream_t st)
     return TWV_OK;
 }
 
-extern "C" int twv_wavenet_generate(const twv_wavenet* h, const void* packed, void* state, const void* cond,
-                                    const void* first_input, const void* uniforms, double temperature,
-                                    int batch, int n_steps, void* out, int32_t* status, float* debug, int debug_steps,
-                                    void* stream)
+static int generate_impl(const twv_wavenet* h, const void* packed, void* state, const void* cond,
+                         const void* first_input, const void* forced, const void* uniforms, double temperature,
+                         int batch, int n_steps, void* out, int32_t* status, float* debug, int debug_steps, void* stream)
 {
-    if (!h || !packed || !state || !cond || !first_input || !uniforms || !out || !status) return fail(TWV_E_INVALID, "null argument");
+    if (!h || !packed || !state || !cond || !status) return fail(TWV_E_INVALID, "null argument");
+    if (!forced && (!first_input || !uniforms || !out)) return fail(TWV_E_INVALID, "null argument");
     if (batch < 1 || n_steps < 1) return fail(TWV_E_INVALID, "batch and n_steps must be >= 1");
     const Layout& L = h->lay;
     if ((long long)n_steps * L.NL > 2000000000LL) return fail(TWV_E_INVALID, "n_steps too large for one call");
@@ -1481,6 +1485,7 @@ extern "C" int twv_wavenet_generate(const twv_wavenet* h, const void* packed, vo
     HIPCHK(hipMemsetAsync(status, 0, 16, st));
     GenArgs a;
     a.P = (const float*)packed; a.state = (float*)state; a.cond = (const float*)cond; a.first_input = first_input;
+    a.forced = forced;
     a.uniforms = uniforms; a.out = out; a.status = status; a.dbg = debug; a.dbg_steps = debug ? debug_steps : 0;
     a.prof = h->prof; a.prof_steps = h->prof ? h->prof_steps : 0;
     a.B = batch; a.T = n_steps; a.temperature = (float)temperature; a.lay = L;
@@ -1508,6 +1513,21 @@ extern "C" int twv_wavenet_generate(const twv_wavenet* h, const void* packed, vo
         if (ntw <= 4) return launch_generate<kWorkers, 4, false>(a, shm, st);
     }
     return fail(TWV_E_UNSUPPORTED, "skip_channels too large for the worker count");
+}
+
+extern "C" int twv_wavenet_generate(const twv_wavenet* h, const void* packed, void* state, const void* cond,
+                                    const void* first_input, const void* uniforms, double temperature,
+                                    int batch, int n_steps, void* out, int32_t* status, float* debug, int debug_steps,
+                                    void* stream)
+{
+    return generate_impl(h, packed, state, cond, first_input, nullptr, uniforms, temperature, batch, n_steps, out, status, debug,
+                         debug_steps, stream);
+}
+extern "C" int twv_wavenet_prime(const twv_wavenet* h, const void* packed, void* state, const void* cond, const void* inputs,
+                                 int batch, int n_steps, int32_t* status, void* stream)
+{
+    if (!inputs) return fail(TWV_E_INVALID, "null argument");
+    return generate_impl(h, packed, state, cond, nullptr, inputs, nullptr, 1.0, batch, n_steps, nullptr, status, nullptr, 0, stream);
 }
 
 extern "C" int twv_wavenet_status(const int32_t* status, void* stream)

@@ -167,6 +167,22 @@ class WaveNetModel(object):
                 _lib.check(self._L.twv_wavenet_status(_ptr(self._status), _stream()))
         return (out, dbg) if debug_steps else out
 
+    # ---- generate.py:168-180 priming loop: feed the seed samples, discard the predictions ----
+    def prime(self, inputs, upsampled_local_condition=None, global_condition=None, check=True):
+        """inputs (B, n): n teacher-forced steps; upsampled_local_condition defaults to zeros like generate.py:180."""
+        B = self.batch_size
+        with torch.cuda.device(self.device):
+            dt = torch.float32 if self.scalar_input else torch.int32
+            x = torch.as_tensor(np.asarray(inputs), dtype=dt, device=self.device).reshape(B, -1).contiguous()
+            n = x.shape[1]
+            if upsampled_local_condition is None and self.local_condition_channels:
+                upsampled_local_condition = torch.zeros((B, n, self.local_condition_channels), dtype=torch.float32, device=self.device)
+            cond = self._condition(upsampled_local_condition, global_condition, n)
+            _lib.check(self._L.twv_wavenet_prime(self._h, _ptr(self._packed), _ptr(self._state), _ptr(cond), _ptr(x), B, n,
+                                                 _ptr(self._status), _stream()))
+            if check:
+                _lib.check(self._L.twv_wavenet_status(_ptr(self._status), _stream()))
+
     # ---- model.py:215-245: one step (a single sess.run of generate.py:211) ----
     def predict_proba_incremental(self, waveform, upsampled_local_condition=None, global_condition=None, uniforms=None,
                                   temperature=1.0):

@@ -255,3 +255,52 @@ def test_generate_c1_config(torch_cuda, oracle):
 def test_generate_onehot_variants(torch_cuda, oracle, kw):
     d, blob, want, got, _ = _run_onehot(oracle, [1, 2, 4, 8, 16], 3, 50, S=128, scale=0.3, **kw)
     assert np.array_equal(got.cpu().numpy(), want), kw
+
+
+@pytest.mark.parametrize("scalar", [True, False])
+def test_priming_then_generation(torch_cuda, oracle, scalar):
+    """generate.py:168-180: prime with RF-1 seed samples (zero lc, predictions discarded), then generate"""
+    dil = [1, 2, 4, 8, 16]
+    B, T = 2, 30
+    d, tensors, blob = make_case(oracle, dil, scalar_input=scalar, S=128, Q=64, scale=0.25)
+    m = make_model(B, dil, tensors, scalar_input=scalar, S=128, Q=64)
+    rf = oracle.receptive_field(d)
+    rng = np.random.RandomState(9)
+    seedwave = rng.uniform(-1, 1, (B, rf)).astype(np.float32) if scalar else rng.randint(64, size=(B, rf)).astype(np.int32)
+    U = rng.uniform(-4, 4, (B, T, 80)).astype(np.float32)
+    gc = np.array([0, 1], np.int32)
+    st = oracle.State(d, B)
+    zeros = np.zeros((B, 80), np.float32)
+    for i in range(rf - 1):                                   # generate.py:177-180
+        oracle.step(d, blob, st, seedwave[:, i], zeros, gc)
+    if scalar:
+        u = mol_uniforms(B, T, 10)
+        want = oracle.generate_mol(d, blob, st, U, gc, seedwave[:, -1], u)
+    else:
+        u = np.random.RandomState(3).random_sample((B, T))
+        want = oracle.generate_mulaw(d, blob, st, U, gc, seedwave[:, -1], u, 1.0)
+    m.prime(seedwave[:, :rf - 1], None, gc)
+    got = m.generate(U, gc, seedwave[:, -1], u).cpu().numpy()
+    assert first_mismatch(got, want) is None
+
+
+def test_generate_cli(torch_cuda, tmp_path):
+    """generate.py surface: flags, params.json override, output files (generate.py:52-69,109,261)"""
+    import json
+    from scipy.io import wavfile
+    import twvk_amd
+    from twvk_amd.generate import main
+    ck = tmp_path / "ckpt"; ck.mkdir()
+    json.dump({"dilations": [1, 2, 4, 8, 16, 32], "skip_channels": 128}, open(ck / "params.json", "w"))
+    mel = np.random.RandomState(0).uniform(-4, 4, (2, 80)).astype(np.float32)
+    np.save(tmp_path / "mel.npy", mel)
+    paths = main([str(ck), "--mel", str(tmp_path / "mel.npy"), "--gc_cardinality", "2", "--gc_id", "1", "--batch_size", "2",
+                  "--logdir", str(tmp_path / "log"), "--seed", "3", "--random_init"])
+    assert len(paths) == 2 and paths[0].endswith("test-0.wav")
+    rate, data = wavfile.read(paths[1])
+    assert rate == 24000 and data.dtype == np.int16 and data.shape == (600,) and np.abs(data).max() == 32767
+    with pytest.raises(ValueError):
+        main([str(ck), "--mel", str(tmp_path / "mel.npy"), "--random_init"])       # gc_cardinality required (generate.py:72-77)
+    # restore defaults for the other tests (hparams is a module singleton, like the reference's)
+    d = twvk_amd.default_hparams()
+    twvk_amd.hparams.__dict__.update(d.__dict__)
