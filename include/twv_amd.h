@@ -121,6 +121,33 @@ int twv_mu_law_expand(const float* y, int64_t n, int quantization_channels, floa
 int twv_eval_elementwise(int fn /*0 tanh,1 sigmoid,2 exp,3 log,4 log1p*/, const float* x, int64_t n, float* out, void* stream);
 int twv_eval_elementwise64(int fn /*0 exp,1 log*/, const double* x, int64_t n, double* out, void* stream);
 
+/* ======================================= Tacotron text -> mel inference =======================================
+ * Replaces the graph synthesizer.py:56 builds with Tacotron.initialize(inputs, input_lengths, num_speakers, speaker_id,
+ * rnn_decoder_test_mode=True) (tacotron/tacotron.py:36-235) and runs in one sess.run (synthesizer.py:160); default
+ * hparams path: model_type 'deepvoice' with num_speakers > 1, attention_type 'bah_mon_norm'.  Fields = hparams.py:126-165. */
+typedef struct {
+    int32_t n_symbols, embedding_size, num_speakers, speaker_embedding_size;
+    int32_t enc_prenet_sizes[2], enc_bank_size, enc_bank_channel_size, enc_proj_sizes[2], enc_proj_width, enc_highway_depth, enc_rnn_size;
+    int32_t attention_size, attention_state_size;
+    int32_t dec_prenet_sizes[2], dec_layer_num, dec_rnn_size;
+    int32_t post_bank_size, post_bank_channel_size, post_proj_sizes[2], post_proj_width, post_highway_depth, post_rnn_size;
+    int32_t num_mels, reduction_factor, num_freq, max_iters;
+} twv_tacotron_dims;
+typedef struct twv_tacotron twv_tacotron;
+
+int twv_tacotron_create(const twv_tacotron_dims* dims, twv_tacotron** out);          /* Tacotron(hparams) */
+void twv_tacotron_destroy(twv_tacotron* h);
+size_t twv_tacotron_blob_floats(const twv_tacotron* h);     /* canonical blob: checkpoint tensors in the order of weights.tacotron_specs,
+                                                               batch-norm (gamma,beta,mean,var) replaced by the derived (inv, shift) pair */
+size_t twv_tacotron_packed_bytes(const twv_tacotron* h);
+size_t twv_tacotron_workspace_bytes(const twv_tacotron* h, int batch, int t_in);
+int twv_tacotron_pack(const twv_tacotron* h, const float* blob, void* packed, void* stream);     /* saver.restore, synthesizer.py:69-70 */
+/* one synthesize() pass (synthesizer.py:126-160): tokens (B,T_in) int32 (0 pad, 1 EOS), input_lengths (B), speaker ids (B) ->
+ * mel (B, max_iters*r, num_mels), linear (B, max_iters*r, num_freq) or NULL, alignments (B, T_in, max_iters) or NULL. */
+int twv_tacotron_infer(const twv_tacotron* h, const void* packed, const int32_t* tokens, const int32_t* lengths,
+                       const int32_t* speaker_ids, int batch, int t_in, void* workspace, float* mel, float* linear,
+                       float* alignments, int32_t* status, void* stream);
+
 /* cross-lane primitive self-test (device float[256]); used by the gpu tests to pin v_permlane32_swap / v_readlane semantics */
 int twv_selftest(float* out256, void* stream);
 

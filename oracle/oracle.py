@@ -276,3 +276,159 @@ def forward_full(d, blob, inp, lc_up=None, gc_ids=None):
         a = _ci(inp)
         lib().twvo_forward_full(C.byref(d), _f(blob), B, Tin, None, _i(a), _f(lc), Tlc, _i(gc), _f(out))
     return out
+
+
+# =====================================================================================================================
+#  Tacotron text -> mel inference (oracle/tacotron.c)
+# =====================================================================================================================
+class TacoDims(C.Structure):
+    _fields_ = [("n_symbols", C.c_int), ("emb", C.c_int), ("n_speakers", C.c_int), ("spk_emb", C.c_int),
+                ("enc_prenet", C.c_int * 2), ("enc_bank", C.c_int), ("enc_bank_ch", C.c_int), ("enc_proj", C.c_int * 2),
+                ("enc_proj_w", C.c_int), ("enc_hw_depth", C.c_int), ("enc_rnn", C.c_int), ("att", C.c_int), ("att_state", C.c_int),
+                ("dec_prenet", C.c_int * 2), ("dec_layers", C.c_int), ("dec_rnn", C.c_int), ("post_bank", C.c_int),
+                ("post_bank_ch", C.c_int), ("post_proj", C.c_int * 2), ("post_proj_w", C.c_int), ("post_hw_depth", C.c_int),
+                ("post_rnn", C.c_int), ("num_mels", C.c_int), ("r", C.c_int), ("num_freq", C.c_int), ("max_iters", C.c_int)]
+
+
+def taco_dims(n_symbols=80, emb=256, n_speakers=2, spk_emb=16, enc_prenet=(256, 128), enc_bank=16, enc_bank_ch=128,
+              enc_proj=(128, 128), enc_proj_w=3, enc_hw_depth=4, enc_rnn=128, att=256, att_state=256, dec_prenet=(256, 128),
+              dec_layers=2, dec_rnn=256, post_bank=8, post_bank_ch=128, post_proj=(256, 80), post_proj_w=3, post_hw_depth=4,
+              post_rnn=128, num_mels=80, r=5, num_freq=1025, max_iters=200):
+    """defaults = hparams.py:126-165"""
+    d = TacoDims()
+    d.n_symbols, d.emb, d.n_speakers, d.spk_emb = n_symbols, emb, n_speakers, spk_emb
+    d.enc_prenet[0], d.enc_prenet[1] = enc_prenet
+    d.enc_bank, d.enc_bank_ch, d.enc_proj_w, d.enc_hw_depth, d.enc_rnn = enc_bank, enc_bank_ch, enc_proj_w, enc_hw_depth, enc_rnn
+    d.enc_proj[0], d.enc_proj[1] = enc_proj
+    d.att, d.att_state = att, att_state
+    d.dec_prenet[0], d.dec_prenet[1] = dec_prenet
+    d.dec_layers, d.dec_rnn = dec_layers, dec_rnn
+    d.post_bank, d.post_bank_ch, d.post_proj_w, d.post_hw_depth, d.post_rnn = post_bank, post_bank_ch, post_proj_w, post_hw_depth, post_rnn
+    d.post_proj[0], d.post_proj[1] = post_proj
+    d.num_mels, d.r, d.num_freq, d.max_iters = num_mels, r, num_freq, max_iters
+    assert enc_proj[1] == enc_prenet[1] and post_proj[1] == num_mels        # the residual connections of modules.py:47-53
+    assert att_state == dec_rnn and 2 * enc_rnn <= 1024
+    return d
+
+
+def _cbhg_specs(scope, cin, bank, bch, proj, pw, depth, rnn):
+    s = []
+    for k in range(1, bank + 1):
+        p = "%s/conv_bank/conv1d_%d/" % (scope, k)
+        s += [(p + "conv1d/kernel", (k, cin, bch)), (p + "conv1d/bias", (bch,)), (p + "batch_normalization", (4, bch))]
+    c = bank * bch
+    for i in range(2):
+        p = "%s/proj_%d/" % (scope, i + 1)
+        s += [(p + "conv1d/kernel", (pw, c, proj[i])), (p + "conv1d/bias", (proj[i],)), (p + "batch_normalization", (4, proj[i]))]
+        c = proj[i]
+    if proj[1] != rnn:
+        s += [(scope + "/dense/kernel", (proj[1], rnn)), (scope + "/dense/bias", (rnn,))]
+    for i in range(depth):
+        p = "%s/highway_%d/" % (scope, i + 1)
+        s += [(p + "H/kernel", (rnn, rnn)), (p + "H/bias", (rnn,)), (p + "T/kernel", (rnn, rnn)), (p + "T/bias", (rnn,))]
+    for dr in ("fw", "bw"):
+        p = "%s/bidirectional_rnn/%s/gru_cell/" % (scope, dr)
+        s += [(p + "gates/kernel", (2 * rnn, 2 * rnn)), (p + "gates/bias", (2 * rnn,)),
+              (p + "candidate/kernel", (2 * rnn, rnn)), (p + "candidate/bias", (rnn,))]
+    return s
+
+
+def taco_tensor_specs(d):
+    """checkpoint tensors in canonical blob order.  Names follow the variable scopes of tacotron.py / modules.py / rnn_wrappers.py
+    with TF's automatic numbering ([RECALLED-TF], unverified).  `batch_normalization` entries are (4, C): gamma, beta,
+    moving_mean, moving_variance; the blob stores the derived (inv, shift) pair instead (see taco_blob)."""
+    E, SE, P0, P1, RN, A, AS, DR, M, R = d.emb, d.spk_emb, d.enc_prenet[0], d.enc_prenet[1], d.enc_rnn, d.att, d.att_state, d.dec_rnn, d.num_mels, d.r
+    ENC = 2 * RN
+    s = [("embedding", (d.n_symbols, E)), ("speaker_embedding", (d.n_speakers, SE))]
+    dn = [P1, 2 * RN, AS] + [DR] * d.dec_layers
+    for i, n in enumerate(dn):
+        nm = "dense" if i == 0 else "dense_%d" % i
+        s += [(nm + "/kernel", (SE, n)), (nm + "/bias", (n,))]
+    s += [("prenet/dense_1/kernel", (E, P0)), ("prenet/dense_1/bias", (P0,)), ("prenet/dense_2/kernel", (P0, P1)), ("prenet/dense_2/bias", (P1,))]
+    s += _cbhg_specs("encoder_cbhg", P1, d.enc_bank, d.enc_bank_ch, tuple(d.enc_proj), d.enc_proj_w, d.enc_hw_depth, RN)
+    s += [("memory_layer/kernel", (ENC, A)), ("decoder/bahdanau_monotonic_attention/query_layer/kernel", (AS, A)),
+          ("decoder/bahdanau_monotonic_attention/attention_v", (A,)), ("decoder/bahdanau_monotonic_attention/attention_g", (1,)),
+          ("decoder/bahdanau_monotonic_attention/attention_b", (A,)), ("decoder/bahdanau_monotonic_attention/attention_score_bias", (1,))]
+    D0, D1 = d.dec_prenet[0], d.dec_prenet[1]
+    s += [("decoder/decoder_prenet/dense_1/kernel", (M, D0)), ("decoder/decoder_prenet/dense_1/bias", (D0,)),
+          ("decoder/decoder_prenet/dense_2/kernel", (D0, D1)), ("decoder/decoder_prenet/dense_2/bias", (D1,))]
+    ain = D1 + ENC
+    p = "decoder/attention_wrapper/gru_cell/"
+    s += [(p + "gates/kernel", (ain + AS, 2 * AS)), (p + "gates/bias", (2 * AS,)), (p + "candidate/kernel", (ain + AS, AS)), (p + "candidate/bias", (AS,))]
+    s += [("decoder/output_projection_wrapper/multi_rnn_cell/cell_0/output_projection_wrapper/kernel", (AS + ENC, DR)),
+          ("decoder/output_projection_wrapper/multi_rnn_cell/cell_0/output_projection_wrapper/bias", (DR,))]
+    for i in range(d.dec_layers):
+        p = "decoder/output_projection_wrapper/multi_rnn_cell/cell_%d/gru_cell/" % (i + 1)
+        s += [(p + "gates/kernel", (2 * DR, 2 * DR)), (p + "gates/bias", (2 * DR,)), (p + "candidate/kernel", (2 * DR, DR)), (p + "candidate/bias", (DR,))]
+    s += [("decoder/output_projection_wrapper/kernel", (DR, M * R)), ("decoder/output_projection_wrapper/bias", (M * R,))]
+    s += _cbhg_specs("post_cbhg", M, d.post_bank, d.post_bank_ch, tuple(d.post_proj), d.post_proj_w, d.post_hw_depth, d.post_rnn)
+    nm = "dense_%d" % len(dn)
+    s += [(nm + "/kernel", (2 * d.post_rnn, d.num_freq)), (nm + "/bias", (d.num_freq,))]
+    return s
+
+
+BN_EPS = np.float32(1e-3)      # tf.layers.batch_normalization default epsilon [RECALLED-TF]
+
+
+def bn_inference_vectors(bn):
+    """(4,C) gamma, beta, moving_mean, moving_variance -> (inv, shift) in float32, as tf.nn.batch_normalization does:
+    inv = rsqrt(var + eps) * gamma ; y = x*inv + (beta - mean*inv)   [RECALLED-TF]"""
+    gamma, beta, mean, var = [np.asarray(v, np.float32) for v in bn]
+    inv = (np.float32(1.0) / np.sqrt(var + BN_EPS)).astype(np.float32) * gamma
+    shift = (beta - (mean * inv).astype(np.float32)).astype(np.float32)
+    return inv.astype(np.float32), shift
+
+
+def taco_random_tensors(d, seed=0, scale=0.08):
+    rng = np.random.RandomState(seed)
+    t = {}
+    for n, shp in taco_tensor_specs(d):
+        if n.endswith("batch_normalization"):
+            C_ = shp[1]
+            t[n] = np.stack([1 + 0.1 * rng.randn(C_), 0.1 * rng.randn(C_), 0.1 * rng.randn(C_), 1 + 0.2 * rng.rand(C_)]).astype(np.float32)
+        elif n.endswith("gates/bias"):
+            t[n] = (1.0 + 0.05 * rng.randn(*shp)).astype(np.float32)          # GRUCell gate bias init 1.0
+        elif n.endswith("T/bias"):
+            t[n] = (-1.0 + 0.05 * rng.randn(*shp)).astype(np.float32)         # modules.py:87 highway T bias init -1
+        elif n.endswith("attention_g"):
+            t[n] = np.array([np.sqrt(1.0 / d.att)], np.float32)
+        elif n.endswith("attention_score_bias"):
+            t[n] = np.array([0.0], np.float32)
+        elif n in ("embedding", "speaker_embedding"):
+            t[n] = (rng.randn(*shp) * 0.5).astype(np.float32)                 # truncated_normal(stddev=0.5), tacotron.py:51,67
+        else:
+            fan_in = int(np.prod(shp[:-1])) if len(shp) > 1 else 1
+            t[n] = (rng.randn(*shp) * (scale if len(shp) == 1 else min(1.0, 1.2 / np.sqrt(fan_in)))).astype(np.float32)
+    return t
+
+
+def taco_blob(d, tensors):
+    parts = []
+    for n, shp in taco_tensor_specs(d):
+        a = np.asarray(tensors[n], np.float32)
+        assert tuple(a.shape) == tuple(shp), (n, a.shape, shp)
+        if n.endswith("batch_normalization"):
+            inv, shift = bn_inference_vectors(a)
+            parts += [inv, shift]
+        else:
+            parts.append(a.reshape(-1))
+    blob = np.concatenate(parts).astype(np.float32)
+    L = lib()
+    L.twvo_taco_blob_floats.restype = C.c_size_t
+    L.twvo_taco_blob_floats.argtypes = [C.POINTER(TacoDims)]
+    assert blob.size == L.twvo_taco_blob_floats(C.byref(d)), (blob.size, L.twvo_taco_blob_floats(C.byref(d)))
+    return blob
+
+
+def taco_infer(d, blob, tokens, lengths, speaker_ids, want_linear=True, want_align=True):
+    tokens = _ci(tokens); lengths = _ci(lengths); speaker_ids = _ci(speaker_ids)
+    N, T = tokens.shape
+    TO = d.max_iters * d.r
+    mel = np.empty((N, TO, d.num_mels), np.float32)
+    lin = np.empty((N, TO, d.num_freq), np.float32) if want_linear else None
+    al = np.empty((N, T, d.max_iters), np.float32) if want_align else None
+    L = lib()
+    L.twvo_taco_infer.argtypes = [C.POINTER(TacoDims), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.twvo_taco_infer(C.byref(d), _f(blob), _i(tokens), _i(lengths), _i(speaker_ids), N, T, _f(mel), _f(lin), _f(al))
+    return mel, lin, al

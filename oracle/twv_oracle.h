@@ -97,6 +97,20 @@ int  twvo_sample_categorical(const float* logits, int Q, double temperature, dou
 void twvo_forward_full(const twvo_dims* d, const float* blob, int B, int Tin, const float* in_scalar, const int32_t* in_q,
                        const float* lc_up, int Tlc, const int32_t* gc_ids, float* raw_out);
 
+/* ---------------- Tacotron text -> mel inference (tacotron.c) ---------------- */
+typedef struct {
+    int n_symbols, emb, n_speakers, spk_emb;        /* 80, 256, >=2, 16 */
+    int enc_prenet[2];                              /* 256, 128 */
+    int enc_bank, enc_bank_ch, enc_proj[2], enc_proj_w, enc_hw_depth, enc_rnn;   /* 16,128,[128,128],3,4,128 */
+    int att, att_state;                             /* 256, 256 */
+    int dec_prenet[2], dec_layers, dec_rnn;         /* [256,128], 2, 256 */
+    int post_bank, post_bank_ch, post_proj[2], post_proj_w, post_hw_depth, post_rnn;  /* 8,128,[256,80],3,4,128 */
+    int num_mels, r, num_freq, max_iters;           /* 80, 5, 1025, 200 */
+} twvo_taco_dims;
+size_t twvo_taco_blob_floats(const twvo_taco_dims* d);
+void twvo_taco_infer(const twvo_taco_dims* d, const float* blob, const int32_t* tokens, const int32_t* lengths,
+                     const int32_t* speaker_ids, int N, int T, float* mel_out, float* linear_out, float* align_out);
+
 #ifdef __cplusplus
 }
 #endif

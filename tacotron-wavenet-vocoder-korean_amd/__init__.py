@@ -11,6 +11,9 @@ def __getattr__(name):
     if name in ("WaveNetModel",):
         from .wavenet import WaveNetModel
         return WaveNetModel
+    if name in ("Tacotron", "Synthesizer"):
+        from . import tacotron
+        return getattr(tacotron, name)
     if name in ("mu_law_encode", "mu_law_decode", "mu_law_expand"):
         from . import ops
         return getattr(ops, name)

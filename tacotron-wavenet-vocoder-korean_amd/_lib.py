@@ -73,6 +73,13 @@ def lib():
     L.twv_eval_elementwise.argtypes = [C.c_int, fp, C.c_int64, fp, vp]
     L.twv_eval_elementwise64.argtypes = [C.c_int, dp, C.c_int64, dp, vp]
     L.twv_selftest.argtypes = [fp, vp]
+    L.twv_tacotron_create.argtypes = [C.POINTER(TacoDims), C.POINTER(C.c_void_p)]
+    L.twv_tacotron_destroy.argtypes = [vp]; L.twv_tacotron_destroy.restype = None
+    for n in ("twv_tacotron_blob_floats", "twv_tacotron_packed_bytes"):
+        getattr(L, n).argtypes = [vp]; getattr(L, n).restype = C.c_size_t
+    L.twv_tacotron_workspace_bytes.argtypes = [vp, C.c_int, C.c_int]; L.twv_tacotron_workspace_bytes.restype = C.c_size_t
+    L.twv_tacotron_pack.argtypes = [vp, fp, vp, vp]
+    L.twv_tacotron_infer.argtypes = [vp, vp, ip, ip, ip, C.c_int, C.c_int, vp, fp, fp, fp, ip, vp]
     _lib = L
     return L
 
@@ -82,7 +89,20 @@ EXPORTS = ["twv_last_error", "twv_version", "twv_wavenet_create", "twv_wavenet_d
            "twv_wavenet_cond_bytes", "twv_wavenet_pack", "twv_wavenet_reset_state", "twv_wavenet_upsample",
            "twv_wavenet_condition", "twv_wavenet_generate", "twv_wavenet_prime", "twv_wavenet_status", "twv_wavenet_set_option", "twv_wavenet_set_profile_buffer",
            "twv_mu_law_encode", "twv_mu_law_decode", "twv_mu_law_expand", "twv_eval_elementwise",
-           "twv_eval_elementwise64", "twv_selftest"]
+           "twv_eval_elementwise64", "twv_selftest", "twv_tacotron_create", "twv_tacotron_destroy", "twv_tacotron_blob_floats",
+           "twv_tacotron_packed_bytes", "twv_tacotron_workspace_bytes", "twv_tacotron_pack", "twv_tacotron_infer"]
+
+
+class TacoDims(C.Structure):
+    """twv_tacotron_dims (include/twv_amd.h) = the Tacotron hyper-parameters of hparams.py:126-165"""
+    _fields_ = [("n_symbols", C.c_int32), ("embedding_size", C.c_int32), ("num_speakers", C.c_int32), ("speaker_embedding_size", C.c_int32),
+                ("enc_prenet_sizes", C.c_int32 * 2), ("enc_bank_size", C.c_int32), ("enc_bank_channel_size", C.c_int32),
+                ("enc_proj_sizes", C.c_int32 * 2), ("enc_proj_width", C.c_int32), ("enc_highway_depth", C.c_int32), ("enc_rnn_size", C.c_int32),
+                ("attention_size", C.c_int32), ("attention_state_size", C.c_int32),
+                ("dec_prenet_sizes", C.c_int32 * 2), ("dec_layer_num", C.c_int32), ("dec_rnn_size", C.c_int32),
+                ("post_bank_size", C.c_int32), ("post_bank_channel_size", C.c_int32), ("post_proj_sizes", C.c_int32 * 2),
+                ("post_proj_width", C.c_int32), ("post_highway_depth", C.c_int32), ("post_rnn_size", C.c_int32),
+                ("num_mels", C.c_int32), ("reduction_factor", C.c_int32), ("num_freq", C.c_int32), ("max_iters", C.c_int32)]
 
 
 class TwvError(RuntimeError):

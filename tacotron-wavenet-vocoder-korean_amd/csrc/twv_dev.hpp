@@ -1,0 +1,129 @@
+// twv_dev.hpp -- device-side helpers shared by the gfx950 translation units: the 64x32 weight TILE and the chunk
+// evaluators of the arithmetic contract, explicit LDS address-space accessors, buffer-descriptor loads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include "twv_layout.hpp"
+#include "twv_math.hpp"
+
+using namespace twv;
+
+struct Tile { float w[32]; };
+
+__device__ __forceinline__ void load_tile(Tile& t, const float* base, int lane)
+{
+    const float4* p = reinterpret_cast<const float4*>(base) + lane;
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) {
+        const float4 q = p[kq * 64];
+        t.w[4 * kq + 0] = q.x; t.w[4 * kq + 1] = q.y; t.w[4 * kq + 2] = q.z; t.w[4 * kq + 3] = q.w;
+    }
+}
+
+// one chunk of AC-1 (four interleaved fma chains, (s0+s1)+(s2+s3)), operand vector distributed over lanes 0..31 of `xv`.
+// The interleave is what hides v_readlane's ~17-cycle result latency (measured: 262 vs 540 ticks per chunk).
+__device__ __forceinline__ float dot_readlane(const Tile& t, float xv)
+{
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 32; c += 4) {
+        s0 = fma_(t.w[c + 0], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), c + 0)), s0);
+        s1 = fma_(t.w[c + 1], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), c + 1)), s1);
+        s2 = fma_(t.w[c + 2], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), c + 2)), s2);
+        s3 = fma_(t.w[c + 3], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), c + 3)), s3);
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+
+// one chunk of AC-1, operand vector already in (uniform) registers
+__device__ __forceinline__ float dot_regs(const Tile& t, const float (&x)[32])
+{
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 32; c += 4) {
+        s0 = fma_(t.w[c + 0], x[c + 0], s0);
+        s1 = fma_(t.w[c + 1], x[c + 1], s1);
+        s2 = fma_(t.w[c + 2], x[c + 2], s2);
+        s3 = fma_(t.w[c + 3], x[c + 3], s3);
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+
+
+// ---- LDS of the generation kernel: one file-scope symbol + integer offsets keeps every access a ds_* instruction
+extern __shared__ __attribute__((aligned(16))) float lds[];
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+// explicit LDS (address space 3) views of lds[]: a C++ cast to a generic pointer would turn the access into a FLAT
+// instruction (vector-memory path, microseconds under load) and hide the 16-byte alignment needed for ds_read_b128.
+#define LDSI(off) (((__attribute__((address_space(3))) int*)lds)[(off)])
+#define LDSVI(off) (((__attribute__((address_space(3))) volatile int*)lds)[(off)])
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define LDS4(off4) (((__attribute__((address_space(3))) f32x4*)lds)[(off4)])   /* offset in float4 units */
+
+// weight tile through a buffer descriptor: ONE per-lane offset VGPR (lane*16), tile position in an SGPR
+__device__ __forceinline__ void load_tile_b(Tile& t, rsrc_t r, int voff16, int soff_bytes)
+{
+    const int so = __builtin_amdgcn_readfirstlane(soff_bytes);
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) {
+        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, voff16 + (kq & 3) * 1024, so + (kq >> 2) * 4096, 0);
+        t.w[4 * kq + 0] = __uint_as_float(q.x); t.w[4 * kq + 1] = __uint_as_float(q.y);
+        t.w[4 * kq + 2] = __uint_as_float(q.z); t.w[4 * kq + 3] = __uint_as_float(q.w);
+    }
+}
+__device__ __forceinline__ float load_f32_b(rsrc_t r, int voff4, int soff_bytes)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff4, __builtin_amdgcn_readfirstlane(soff_bytes), 0));
+}
+// tile staged in LDS at float offset fo (same [kq][lane][4] image as in HBM): conflict-free ds_read_b128
+__device__ __forceinline__ void lds_tile(Tile& t, int fo, int lane)
+{
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) {
+        const f32x4 q = LDS4((fo >> 2) + kq * 64 + lane);
+        t.w[4 * kq + 0] = q.x; t.w[4 * kq + 1] = q.y; t.w[4 * kq + 2] = q.z; t.w[4 * kq + 3] = q.w;
+    }
+}
+// half tile [kq][32][4]: lanes l and l+32 read the same 16 bytes (broadcast)
+__device__ __forceinline__ void lds_half_tile(Tile& t, int fo, int lane)
+{
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) {
+        const f32x4 q = LDS4((fo >> 2) + kq * 32 + (lane & 31));
+        t.w[4 * kq + 0] = q.x; t.w[4 * kq + 1] = q.y; t.w[4 * kq + 2] = q.z; t.w[4 * kq + 3] = q.w;
+    }
+}
+
+// one chunk of AC-1, operand vector in LDS at float offset `xo` (same address in every lane: broadcast reads)
+__device__ __forceinline__ float dot_ldso(const Tile& t, int xo)
+{
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) {
+        const f32x4 q = LDS4((xo >> 2) + kq);
+        s0 = fma_(t.w[4 * kq + 0], q.x, s0);
+        s1 = fma_(t.w[4 * kq + 1], q.y, s1);
+        s2 = fma_(t.w[4 * kq + 2], q.z, s2);
+        s3 = fma_(t.w[4 * kq + 3], q.w, s3);
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+
+
+// ---- host-side helpers implemented in twv_wavenet.hip -------------------------------------------------------------
+// dst tiles [g][jblk][chunk][kq][lane][4]; element = src[base(half) + g*sg + k*rowlen + jj] (0 outside K x ncols)
+struct PackTiles {
+    long long dst_off, dst_gstride, baseA, baseB, src_gstride;
+    int ngroups, njblk, nchunk, K, rowlen, ncols, halves, lanes;
+};
+struct PackVec {
+    long long dst_off, dst_gstride, baseA, baseB, src_gstride;
+    int ngroups, n, ncols, halves;
+};
+void twv_launch_pack_tiles(float* dst, const float* src, const PackTiles& p, hipStream_t st);
+void twv_launch_copy(float* dst, const float* src, long long n, hipStream_t st);
+int twv_fail(int code, const std::string& msg);

@@ -1,0 +1,84 @@
+"""-m gpu: Tacotron text -> mel inference, HIP path (through the C-ABI) vs the CPU oracle, bit for bit."""
+import copy
+
+import numpy as np
+import pytest
+
+from helpers import first_mismatch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _hp(**kw):
+    import twvk_amd
+    hp = twvk_amd.default_hparams()
+    for k, v in kw.items():
+        setattr(hp, k, v)
+    return hp
+
+
+def _case(oracle, hp, N, T, lengths, seed=0):
+    from twvk_amd.tacotron import Tacotron
+    d = oracle.taco_dims(enc_bank=hp.enc_bank_size, post_bank=hp.post_bank_size, enc_hw_depth=hp.enc_highway_depth,
+                         post_hw_depth=hp.post_highway_depth, dec_layers=hp.dec_layer_num, max_iters=hp.max_iters, num_freq=hp.num_freq,
+                         r=hp.reduction_factor)
+    tensors = oracle.taco_random_tensors(d, seed=seed)
+    blob = oracle.taco_blob(d, tensors)
+    rng = np.random.RandomState(seed + 1)
+    tok = rng.randint(2, 80, (N, T)).astype(np.int32)
+    for n, ln in enumerate(lengths):
+        tok[n, ln - 1] = 1                      # EOS
+        tok[n, ln:] = 0                         # pad
+    spk = (np.arange(N) % 2).astype(np.int32)
+    m = Tacotron(hp, num_speakers=2)
+    assert [n for n, _ in m.specs] == [n for n, _ in oracle.taco_tensor_specs(d)]
+    m.load_weights(tensors)
+    return d, blob, tok, np.asarray(lengths, np.int32), spk, m
+
+
+def test_tacotron_small(torch_cuda, oracle):
+    hp = _hp(max_iters=6, enc_bank_size=4, post_bank_size=3, num_freq=129)
+    d, blob, tok, ln, spk, m = _case(oracle, hp, 3, 19, [19, 12, 7])
+    mel_o, lin_o, al_o = oracle.taco_infer(d, blob, tok, ln, spk)
+    mel, lin, al = m.infer(tok, ln, spk)
+    assert mel.shape == (3, 30, 80) and lin.shape == (3, 30, 129) and al.shape == (3, 19, 6)
+    assert first_mismatch(al.cpu().numpy(), al_o) is None, ("alignments", first_mismatch(al.cpu().numpy(), al_o))
+    assert first_mismatch(mel.cpu().numpy(), mel_o) is None, ("mel", first_mismatch(mel.cpu().numpy(), mel_o))
+    assert first_mismatch(lin.cpu().numpy(), lin_o) is None, ("linear", first_mismatch(lin.cpu().numpy(), lin_o))
+    assert np.all(al.cpu().numpy()[1, 12:] == 0)                       # nothing attends past input_lengths
+
+
+def test_tacotron_default_dims(torch_cuda, oracle):
+    """default hparams (hparams.py:126-165) with a shortened decode: N=2, T_in=40, 25 decoder steps -> 125 mel frames"""
+    hp = _hp(max_iters=25)
+    d, blob, tok, ln, spk, m = _case(oracle, hp, 2, 40, [40, 31], seed=3)
+    mel_o, lin_o, al_o = oracle.taco_infer(d, blob, tok, ln, spk)
+    mel, lin, al = m.infer(tok, ln, spk)
+    assert mel.shape == (2, 125, 80) and lin.shape == (2, 125, 1025) and al.shape == (2, 40, 25)   # tacotron.py:204,219,223
+    assert first_mismatch(mel.cpu().numpy(), mel_o) is None
+    assert first_mismatch(al.cpu().numpy(), al_o) is None
+    assert first_mismatch(lin.cpu().numpy(), lin_o) is None
+    # north_star tolerance for float mel frames is 1e-4; bit-exact is stricter
+    assert np.abs(mel.cpu().numpy() - mel_o).max() <= 1e-4
+
+
+def test_synthesizer_surface(torch_cuda, oracle):
+    import twvk_amd
+    from twvk_amd.tacotron import Synthesizer
+    hp = _hp(max_iters=4, num_freq=65)
+    d = oracle.taco_dims(max_iters=4, num_freq=65)
+    tensors = oracle.taco_random_tensors(d, seed=5)
+    syn = Synthesizer()
+    syn.load(tensors, num_speakers=2, hparams=hp)
+    out = syn.synthesize(tokens=[[5, 9, 33, 12, 1], [7, 7, 1]], speaker_ids=[1, 0])
+    assert out["input_lengths"] == [5, 3]                               # synthesizer.py:126 argmax(seq == 1) + 1
+    tok = np.array([[5, 9, 33, 12, 1], [7, 7, 1, 0, 0]], np.int32)
+    mel_o, _, _ = oracle.taco_infer(d, oracle.taco_blob(d, tensors), tok, np.array([5, 3], np.int32), np.array([1, 0], np.int32))
+    assert first_mismatch(out["mel"].cpu().numpy(), mel_o) is None
