@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--workers", type=int, default=0)
     ap.add_argument("--groups", type=int, default=-1, help="workgroups per stream (-1 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tacotron", action="store_true", help="skip the secondary Tacotron mel-frames/s measurement")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle sample size in generation steps (0 = auto, about 15 s)")
     args = ap.parse_args()
 
@@ -169,6 +170,39 @@ def main():
                                    "sample": "build's CPU restatement (oracle/, plain C, 1 thread) of the same model on the GPU box's host: "
                                              "B=%d x %d generation steps = %.1f s of CPU work; NOT the reference generate.py "
                                              "(TensorFlow is absent; parity unpinned)" % (B, n, cdt)}
+        if not args.no_tacotron and world == 1:
+            # secondary half of BASELINE.json's metric: Tacotron mel frames/sec at configs[2] (B=32, 100 tokens + EOS, 200 decoder steps)
+            try:
+                from twvk_amd.tacotron import Tacotron
+                tm = Tacotron(hp, num_speakers=2, device=dev)
+                trng = np.random.RandomState(7)
+                tt = {}
+                for n_, shp in tm.specs:
+                    if n_.endswith("batch_normalization"):
+                        c_ = shp[1]; tt[n_] = np.stack([np.ones(c_), np.zeros(c_), np.zeros(c_), np.ones(c_)]).astype(np.float32)
+                    elif n_.endswith("gates/bias"): tt[n_] = np.ones(shp, np.float32)
+                    elif n_.endswith("T/bias"): tt[n_] = -np.ones(shp, np.float32)
+                    elif n_.endswith("attention_g"): tt[n_] = np.array([np.sqrt(1.0 / hp.attention_size)], np.float32)
+                    elif n_.endswith("attention_score_bias"): tt[n_] = np.zeros(1, np.float32)
+                    else:
+                        fan = int(np.prod(shp[:-1])) if len(shp) > 1 else 1
+                        tt[n_] = (trng.randn(*shp) * (0.05 if len(shp) == 1 else min(0.5, 1.2 / np.sqrt(fan)))).astype(np.float32)
+                tm.load_weights(tt)
+                TN, TT = 32, 101
+                tok = trng.randint(2, 80, (TN, TT)).astype(np.int32); tok[:, -1] = 1
+                tln = np.full(TN, TT, np.int32); tsp = (np.arange(TN) % 2).astype(np.int32)
+                tm.infer(tok, tln, tsp); torch.cuda.synchronize()
+                q0 = time.perf_counter()
+                for _ in range(3): tmel, _, _ = tm.infer(tok, tln, tsp)
+                torch.cuda.synchronize()
+                qdt = (time.perf_counter() - q0) / 3
+                res["tacotron"] = {"metric": "Tacotron mel frames/sec", "value": TN * hp.max_iters * hp.reduction_factor / qdt,
+                                   "unit": "mel frames/s", "ms_per_pass": qdt * 1e3, "dtype": "f32",
+                                   "config": {"workload": "configs[2]: Tacotron text->mel (CBHG encoder, monotonic Bahdanau attention decoder, post-CBHG, "
+                                                          "linear), batch=32, 101 tokens, 200 decoder steps = 1000 mel frames/utterance, random-init weights"},
+                                   "finite": bool(torch.isfinite(tmel).all().item())}
+            except Exception as e:   # the headline metric must still be reported
+                res["tacotron"] = {"error": repr(e)}
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -12,7 +12,7 @@
 //                                                                                         workgroup per utterance
 //   tacotron/tacotron.py:204-219  post CBHG + linear projection                        -> the same CBHG kernels + tc_gemm_kernel
 // Arithmetic: the contract of DESIGN.md (AC-1 chunked dot products, AC-2 rationals); results are compared bit for bit with the
-// CPU checker.  TF-contrib internals (GRUCell, monotonic attention, ...) are restated from memory -- see oracle/tacotron.c.
+// CPU checker.  TF-contrib internals (GRUCell, monotonic attention, ...) are restated from memory -- see DESIGN.md.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -499,7 +499,7 @@ struct twv_tacotron {
 
 static inline long long tiles_floats(int K, int N) { return (long long)((N + 63) / 64) * ((K + 31) / 32) * kTile; }
 
-// Walks the canonical blob order (oracle/tacotron.c take() sequence == weights.tacotron_specs) and lays out the packed buffer.
+// Walks the canonical blob order (tacotron.py tacotron_specs) and lays out the packed buffer.
 static void taco_build(twv_tacotron* h)
 {
     const twv_tacotron_dims& d = h->d;

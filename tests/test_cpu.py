@@ -314,3 +314,43 @@ def test_two_rank_sharding_gloo(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "OK" in outs[0]
+
+
+# ---------------------------------------------------------------- Tacotron restatement (oracle/tacotron.c)
+def test_tacotron_oracle_invariants(oracle):
+    d = oracle.taco_dims(max_iters=10, enc_bank=3, post_bank=2, num_freq=33)
+    tensors = oracle.taco_random_tensors(d, seed=2)
+    blob = oracle.taco_blob(d, tensors)
+    rng = np.random.RandomState(0)
+    N, T = 2, 17
+    tok = rng.randint(2, 80, (N, T)).astype(np.int32)
+    tok[0, -1] = 1; tok[1, 9] = 1; tok[1, 10:] = 0
+    ln = np.array([17, 10], np.int32)
+    mel, lin, al = oracle.taco_infer(d, blob, tok, ln, np.array([0, 1], np.int32))
+    assert mel.shape == (N, 10 * 5, 80) and lin.shape == (N, 50, 33) and al.shape == (N, T, 10)    # tacotron.py:204,219,223
+    assert np.isfinite(mel).all() and np.isfinite(lin).all()
+    assert al.min() >= 0 and np.all(al[1, 10:] == 0)                   # masked past input_lengths
+    mass = al.sum(axis=1)
+    assert np.all(mass <= 1 + 1e-5) and np.all(np.diff(mass, axis=1) <= 1e-6)     # monotonic attention only loses mass
+    centre = (al * np.arange(T)[None, :, None]).sum(1) / np.maximum(mass, 1e-9)
+    assert np.all(np.diff(centre[0]) >= -1e-4)                         # ... and only moves forward
+    # utterances are independent: utterance 1 alone gives the same rows
+    mel1, _, _ = oracle.taco_infer(d, blob, tok[1:], ln[1:], np.array([1], np.int32))
+    assert np.array_equal(mel1[0], mel[1])
+    # token 0 embeds to zeros (tacotron.py:56): changing the embedding row 0 changes nothing
+    t2 = dict(tensors); e = t2["embedding"].copy(); e[0] += 1.0; t2["embedding"] = e
+    mel2, _, _ = oracle.taco_infer(d, oracle.taco_blob(d, t2), tok, ln, np.array([0, 1], np.int32))
+    assert np.array_equal(mel2, mel)
+
+
+def test_tacotron_blob_layout_agrees(oracle):
+    import twvk_amd
+    from twvk_amd import tacotron as TP, _lib
+    hp = twvk_amd.default_hparams()
+    d = oracle.taco_dims()
+    specs = TP.tacotron_specs(hp, 2)
+    assert specs == oracle.taco_tensor_specs(d)
+    tensors = oracle.taco_random_tensors(d, seed=1)
+    assert np.array_equal(TP.flatten(specs, tensors), oracle.taco_blob(d, tensors))
+    m = TP.Tacotron(hp, num_speakers=2, device="cpu")                   # host-only: create touches no device
+    assert _lib.lib().twv_tacotron_blob_floats(m._h) == oracle.taco_blob(d, tensors).size
