@@ -148,6 +148,28 @@ int twv_tacotron_infer(const twv_tacotron* h, const void* packed, const int32_t*
                        const int32_t* speaker_ids, int batch, int t_in, void* workspace, float* mel, float* linear,
                        float* alignments, int32_t* status, void* stream);
 
+/* ======================================= WaveNet teacher-forced training step =======================================
+ * Replaces one `sess.run([net.loss, net.optimize])` of train_vocoder.py:155-181 for the scalar-input (MoL) model:
+ * add_loss (wavenet/model.py:247-312: drop last sample, create_upsample, 'valid' convolution network with the
+ * front-sliced local condition, discretized_mix_logistic_loss(num_class=2**16) mean) and add_optimizer
+ * (model.py:314-346: Adam with TF defaults, then ExponentialMovingAverage(0.9999).apply).  Parameters and gradients are
+ * flat float32 device arrays in the canonical checkpoint order (twv_wavenet_blob_floats / weights.tensor_specs).
+ * Data-parallel training all-reduces `grads` between the two calls (host side, RCCL). */
+typedef struct twv_wavenet_trainer twv_wavenet_trainer;
+/* batch = hparams.wavenet_batch_size, n_samples = crop length fed by DataFeederWavenet (a multiple of the hop size) */
+int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch, int n_samples, twv_wavenet_trainer** out);
+void twv_wavenet_train_destroy(twv_wavenet_trainer* h);
+size_t twv_wavenet_train_param_floats(const twv_wavenet_trainer* h);
+size_t twv_wavenet_train_workspace_bytes(const twv_wavenet_trainer* h);
+int twv_wavenet_train_output_width(const twv_wavenet_trainer* h);          /* n_samples - receptive_field (model.py:135) */
+/* loss (device float[1]) and d loss / d params (device float[param_floats], overwritten).
+ * audio (B, n_samples) float in [-1,1]; lc (B, n_samples/hop, lc_channels); gc_ids (B) int32. */
+int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* params, const float* audio, const float* lc,
+                                const int32_t* gc_ids, void* workspace, float* loss, float* grads, void* stream);
+/* tf.train.AdamOptimizer.apply_gradients (t = 1-based update count) on grads*grad_scale, then the EMA shadow update. */
+int twv_adam_ema_step(float* params, const float* grads, float* m, float* v, float* ema, int64_t n, double lr, double beta1,
+                      double beta2, double eps, int64_t t, double ema_decay, double grad_scale, void* stream);
+
 /* cross-lane primitive self-test (device float[256]); used by the gpu tests to pin v_permlane32_swap / v_readlane semantics */
 int twv_selftest(float* out256, void* stream);
 

@@ -1,0 +1,560 @@
+// twv_train.hip -- MI355X (gfx950) teacher-forced WaveNet training step + its C-ABI (include/twv_amd.h).
+//
+// Replaces, for hccho2/Tacotron-Wavenet-Vocoder-Korean (citations into /root/reference), one `sess.run([loss, optimize])`
+// of train_vocoder.py:155-181 for the scalar-input (MoL) model:
+//   wavenet/model.py:247-312  add_loss: drop last sample, create_upsample, full 'valid' convolution network
+//                             (model.py:112-167 with train_mode=True), discretized_mix_logistic_loss (mixture.py:27-81), mean
+//   wavenet/model.py:314-346  add_optimizer: exponential-decay LR, Adam (TF defaults), then EMA(0.9999).apply
+// The reference runs on ONE device; data parallelism (one process per GPU, gradient all-reduce over RCCL between
+// compute_gradients and apply_gradients) is added by the host (train.py) on the flat gradient buffer this file fills.
+//
+// Layout: every layer's activations are kept RIGHT-ALIGNED at the full length Tn = T-1 (row = (batch, t)), positions before a
+// layer's receptive offset are masked.  A 'valid' dilated conv is then two plain GEMMs over all rows with a row-shifted
+// operand, and every weight gradient is ONE GEMM reducing over all rows -- plain library GEMMs (rocBLAS).  The gated
+// unit, conditioning adds, MoL loss (forward + analytic backward), column sums, the transposed-conv upsampler and the
+// Adam/EMA update are hand-written HIP kernels.  Parameters and gradients stay in the canonical checkpoint layout
+// (TF variable order, kernels (K, N) row-major), which is exactly what row-major GEMMs want.
+// This is a floating-point training step: parity is by tolerance against an independent PyTorch-CPU fp32 autograd model.
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include "../../include/twv_amd.h"
+#include "twv_dev.hpp"
+
+#define HIPCHK(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess) return twv_fail(TWV_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+#define BLASCHK(expr)                                                                                             \
+    do {                                                                                                          \
+        rocblas_status s_ = (expr);                                                                               \
+        if (s_ != rocblas_status_success) return twv_fail(TWV_E_HIP, std::string(#expr) + ": rocblas status " + std::to_string((int)s_)); \
+    } while (0)
+
+struct TrainLayerOff { long long wf, bf, wg, bg, gcf, gcg, lcf, lcg, wd, bd, ws, bs; };
+struct twv_wavenet_trainer {
+    twv_wavenet_dims d;
+    int B, T, Tn, rf, ow, NL, S, O, L, G, ifw, hop;
+    int off[TWV_MAX_LAYERS + 1];          // receptive offset of layer l's INPUT (off[0] = ifw-1), off[NL] = rf-1
+    long long c_causal, c_gcemb, c_layer0, c_lstride, c_w1, c_b1, c_w2, c_b2, c_up[4], nparams;
+    TrainLayerOff lo;                     // offsets inside a layer block
+    rocblas_handle blas;
+    long long ws_floats;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+//  kernels
+// ---------------------------------------------------------------------------------------------------------------
+#define GRID_STRIDE(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+static inline int tg(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 32768 ? 32768 : g)); }
+
+// model.py:102-111 one transposed-conv stage: out[b, t*f+a, m] = K[a,0]*in[b,t,m] + K[a,1]*in[b,t,m-1]
+__global__ void tr_up_fwd_kernel(const float* K, const float* in, float* out, long long total, int f, int Lc)
+{
+    GRID_STRIDE(i, total) {
+        const int m = (int)(i % Lc);
+        const long long ta = i / Lc;
+        const int a = (int)(ta % f);
+        const long long bt = ta / f;
+        const float x0 = in[bt * Lc + m], x1 = m > 0 ? in[bt * Lc + m - 1] : 0.0f;
+        out[i] = K[a * 2] * x0 + K[a * 2 + 1] * x1;
+    }
+}
+// backward of the stage: din[b,t,m] = sum_a K[a,0] dout[tf+a,m] + K[a,1] dout[tf+a,m+1]; dK by atomics of per-thread partials
+__global__ void tr_up_bwd_in_kernel(const float* K, const float* dout, float* din, long long total_in, int f, int Lc)
+{
+    GRID_STRIDE(i, total_in) {
+        const int m = (int)(i % Lc);
+        const long long bt = i / Lc;
+        float acc = 0.0f;
+        for (int a = 0; a < f; ++a) {
+            const long long o = (bt * f + a) * Lc + m;
+            acc += K[a * 2] * dout[o];
+            if (m + 1 < Lc) acc += K[a * 2 + 1] * dout[o + 1];
+        }
+        din[i] = acc;
+    }
+}
+__global__ void tr_up_bwd_k_kernel(const float* in, const float* dout, float* dK, long long rows_in, int f, int Lc)
+{
+    // one block per tap a; reduce over (row, m)
+    const int a = blockIdx.x;
+    float s0 = 0.0f, s1 = 0.0f;
+    for (long long i = threadIdx.x; i < rows_in * Lc; i += blockDim.x) {
+        const int m = (int)(i % Lc);
+        const long long bt = i / Lc;
+        const float d = dout[(bt * f + a) * Lc + m];
+        s0 += d * in[i];
+        if (m > 0) s1 += d * in[i - 1];
+    }
+    __shared__ float r0[256], r1[256];
+    r0[threadIdx.x] = s0; r1[threadIdx.x] = s1;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) { r0[threadIdx.x] += r0[threadIdx.x + st]; r1[threadIdx.x] += r1[threadIdx.x + st]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { dK[a * 2] = r0[0]; dK[a * 2 + 1] = r1[0]; }
+}
+
+// causal layer input unfolded: xunf[(b,t)][k] = in[b, t-(ifw-1)+k]  (0 before the start)   model.py:41-46
+__global__ void tr_unfold_kernel(const float* audio, float* xunf, int B, int T, int Tn, int ifw)
+{
+    const long long total = (long long)B * Tn * ifw;
+    GRID_STRIDE(i, total) {
+        const int k = (int)(i % ifw);
+        const long long r = i / ifw;
+        const int t = (int)(r % Tn), b = (int)(r / Tn);
+        const int ts = t - (ifw - 1) + k;
+        xunf[i] = ts >= 0 ? audio[(long long)b * T + ts] : 0.0f;
+    }
+}
+// gated unit forward (model.py:68-86): pre (R,64) holds conv_filter|conv_gate sums; adds bias, gc[b], lc[b, t-o]; masked below o
+__global__ void tr_gate_fwd_kernel(const float* pre, const float* bf, const float* bg, const float* gcp, const float* lcp,
+                                   float* th, float* sg, float* z, int B, int Tn, int T, int o)
+{
+    const long long total = (long long)B * Tn * 32;
+    GRID_STRIDE(i, total) {
+        const int j = (int)(i & 31);
+        const long long r = i >> 5;
+        const int t = (int)(r % Tn), b = (int)(r / Tn);
+        float tv = 0.0f, sv = 0.0f;
+        if (t >= o) {
+            float f = pre[r * 64 + j], g = pre[r * 64 + 32 + j];
+            if (bf) { f += bf[j]; g += bg[j]; }
+            if (gcp) { f += gcp[b * 64 + j]; g += gcp[b * 64 + 32 + j]; }
+            if (lcp) { const long long lr = (long long)b * T + (t - o); f += lcp[lr * 64 + j]; g += lcp[lr * 64 + 32 + j]; }
+            tv = tanh_e(f); sv = sigmoid_e(g);
+        }
+        th[i] = tv; sg[i] = sv; z[i] = tv * sv;
+    }
+}
+// gated unit backward: dpre (R,64) from dz (R,32)
+__global__ void tr_gate_bwd_kernel(const float* dz, const float* th, const float* sg, float* dpre, int B, int Tn, int o)
+{
+    const long long total = (long long)B * Tn * 32;
+    GRID_STRIDE(i, total) {
+        const int j = (int)(i & 31);
+        const long long r = i >> 5;
+        const int t = (int)(r % Tn);
+        float df = 0.0f, dg = 0.0f;
+        if (t >= o) {
+            const float d = dz[i], tv = th[i], sv = sg[i];
+            df = d * sv * (1.0f - tv * tv);
+            dg = d * tv * sv * (1.0f - sv);
+        }
+        dpre[r * 64 + j] = df; dpre[r * 64 + 32 + j] = dg;
+    }
+}
+// xn = x + bias (R,32)
+__global__ void tr_add_bias32_kernel(const float* x, const float* bias, float* xn, long long n)
+{
+    GRID_STRIDE(i, n) xn[i] = x[i] + (bias ? bias[i & 31] : 0.0f);
+}
+// compact the last `ow` positions of every batch: zc[(b,p)] = z[(b, Tn-ow+p)]   (model.py:94-95 skip_cut)
+__global__ void tr_compact_kernel(const float* z, float* zc, int B, int Tn, int ow)
+{
+    const long long total = (long long)B * ow * 32;
+    GRID_STRIDE(i, total) {
+        const int j = (int)(i & 31);
+        const long long r = i >> 5;
+        const int p = (int)(r % ow), b = (int)(r / ow);
+        zc[i] = z[((long long)b * Tn + (Tn - ow + p)) * 32 + j];
+    }
+}
+__global__ void tr_scatter_add_kernel(const float* dzc, float* dz, int B, int Tn, int ow)
+{
+    const long long total = (long long)B * ow * 32;
+    GRID_STRIDE(i, total) {
+        const int j = (int)(i & 31);
+        const long long r = i >> 5;
+        const int p = (int)(r % ow), b = (int)(r / ow);
+        dz[((long long)b * Tn + (Tn - ow + p)) * 32 + j] += dzc[i];
+    }
+}
+// y[r][c] = relu(x[r][c] + bias_sum[c])  (bias_sum = one or several bias vectors added together)
+__global__ void tr_bias_relu_kernel(float* x, const float* biases, int nb, long long strideb, const float* bias, int C, long long n)
+{
+    GRID_STRIDE(i, n) {
+        const int c = (int)(i % C);
+        float v = x[i];
+        if (bias) v += bias[c];
+        for (int k = 0; k < nb; ++k) v += biases[(long long)k * strideb + c];
+        x[i] = v > 0.0f ? v : 0.0f;
+    }
+}
+__global__ void tr_bias_add_kernel(float* x, const float* bias, int C, long long n) { GRID_STRIDE(i, n) x[i] += bias[i % C]; }
+__global__ void tr_relu_bwd_kernel(float* dx, const float* y, long long n) { GRID_STRIDE(i, n) if (!(y[i] > 0.0f)) dx[i] = 0.0f; }
+__global__ void tr_fill_kernel(float* p, float v, long long n) { GRID_STRIDE(i, n) p[i] = v; }
+__global__ void tr_add_kernel(float* a, const float* b, long long n) { GRID_STRIDE(i, n) a[i] += b[i]; }
+// column sums: out[c] = sum_r x[r][c]; grid = C/64 blocks x 256 threads (4 row groups), C multiple of... any (guarded)
+__global__ void tr_colsum_kernel(const float* x, long long rows, int C, float* out)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float s = 0.0f;
+    if (c < C) for (long long r = grp; r < rows; r += 4) s += x[r * C + c];
+    __shared__ float sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < C) out[c] = sh[threadIdx.x] + sh[threadIdx.x + 64] + sh[threadIdx.x + 128] + sh[threadIdx.x + 192];
+}
+// per-batch sums over time: out[b][c] = sum_t x[(b,t)][c]
+__global__ void tr_batchsum_kernel(const float* x, int Tn, int C, float* out)
+{
+    const int b = blockIdx.x, c = threadIdx.x;
+    if (c >= C) return;
+    float s = 0.0f;
+    for (int t = 0; t < Tn; ++t) s += x[((long long)b * Tn + t) * C + c];
+    out[b * C + c] = s;
+}
+// dlcp[(b,tt)][c] = dpre[(b, tt+o)][c] for tt+o < Tn else 0
+__global__ void tr_shift_lc_kernel(const float* dpre, float* dlcp, int B, int Tn, int T, int o)
+{
+    const long long total = (long long)B * T * 64;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i & 63);
+        const long long r = i >> 6;
+        const int tt = (int)(r % T), b = (int)(r / T);
+        dlcp[i] = (tt + o < Tn) ? dpre[((long long)b * Tn + tt + o) * 64 + c] : 0.0f;
+    }
+}
+__global__ void tr_gather_emb_kernel(const float* table, const int32_t* ids, float* out, int B, int G)
+{
+    GRID_STRIDE(i, (long long)B * G) out[i] = table[(long long)ids[i / G] * G + (i % G)];
+}
+__global__ void tr_scatter_emb_kernel(const float* demb, const int32_t* ids, float* dtable, int B, int G)
+{
+    GRID_STRIDE(i, (long long)B * G) atomicAdd(&dtable[(long long)ids[i / G] * G + (i % G)], demb[i]);
+}
+
+// mixture.py:27-81 discretized_mix_logistic_loss(num_class=2**16, reduce=False) + model.py:290 mean, and its gradient.
+// one thread per (b, p); y (rows, 3*nr), target = audio[b, p + rf]
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigm_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+__global__ void tr_mol_loss_kernel(const float* y, const float* audio, int B, int T, int ow, int rf, int nr, float inv_count,
+                                   float* loss_sum, float* dy)
+{
+    const long long rows = (long long)B * ow;
+    GRID_STRIDE(r, rows) {
+        const int p = (int)(r % ow), b = (int)(r / ow);
+        const float tgt = audio[(long long)b * T + p + rf];
+        const float* yr = y + r * 3 * nr;
+        const float lsmin = -32.23619130191664f, h = 1.0f / 65535.0f, logc = logf(65535.0f / 2.0f);
+        float lm = -3.0e38f;
+        for (int i = 0; i < nr; ++i) lm = fmaxf(lm, yr[i]);
+        float se = 0.0f;
+        for (int i = 0; i < nr; ++i) se += expf(yr[i] - lm);
+        const float lse_logit = lm + logf(se);
+        float a[32], dplus[32], dmin[32], dmid[32], dsdirect[32];
+        float amax = -3.0e38f;
+        for (int i = 0; i < nr; ++i) {
+            const float mu = yr[nr + i], sraw = yr[2 * nr + i];
+            const float s = fmaxf(sraw, lsmin);
+            const float cen = tgt - mu, inv = expf(-s);
+            const float plus = inv * (cen + h), mn = inv * (cen - h), mid = inv * cen;
+            const float cp = sigm_f(plus), cm = sigm_f(mn), delta = cp - cm;
+            float lp;
+            dplus[i] = dmin[i] = dmid[i] = dsdirect[i] = 0.0f;
+            if (tgt < -0.999f) { lp = plus - softplus_f(plus); dplus[i] = 1.0f - cp; }
+            else if (tgt > 0.999f) { lp = -softplus_f(mn); dmin[i] = -cm; }
+            else if (delta > 1e-5f) { lp = logf(fmaxf(delta, 1e-12f)); dplus[i] = cp * (1.0f - cp) / delta; dmin[i] = -cm * (1.0f - cm) / delta; }
+            else { lp = mid - s - 2.0f * softplus_f(mid) - logc; dmid[i] = 1.0f - 2.0f * sigm_f(mid); dsdirect[i] = -1.0f; }
+            a[i] = lp + (yr[i] - lse_logit);
+            amax = fmaxf(amax, a[i]);
+        }
+        float sa = 0.0f;
+        for (int i = 0; i < nr; ++i) sa += expf(a[i] - amax);
+        const float lse = amax + logf(sa);
+        atomicAdd(loss_sum, -lse * inv_count);
+        float* dr = dy + r * 3 * nr;
+        for (int i = 0; i < nr; ++i) {
+            const float w = expf(a[i] - lse);                      // softmax(a)
+            const float sm = expf(yr[i] - lse_logit);              // softmax(logits)
+            const float mu = yr[nr + i], sraw = yr[2 * nr + i];
+            const float s = fmaxf(sraw, lsmin);
+            const float cen = tgt - mu, inv = expf(-s);
+            const float plus = inv * (cen + h), mn = inv * (cen - h), mid = inv * cen;
+            const float dlp = -w;                                   // dL/dlp_i
+            const float gmu = dlp * (-(inv)) * (dplus[i] + dmin[i] + dmid[i]);
+            const float gs = dlp * (-(dplus[i] * plus + dmin[i] * mn + dmid[i] * mid) + dsdirect[i]);
+            dr[i] = (sm - w) * inv_count;
+            dr[nr + i] = gmu * inv_count;
+            dr[2 * nr + i] = (sraw > lsmin ? gs : 0.0f) * inv_count;
+        }
+    }
+}
+
+// model.py:314-346 add_optimizer: AdamOptimizer(lr) with TF defaults, then ExponentialMovingAverage(decay).apply
+__global__ void tr_adam_ema_kernel(float* p, const float* g, float* m, float* v, float* ema, long long n, float lr_t, float b1, float b2,
+                                   float eps, float decay, float gscale)
+{
+    GRID_STRIDE(i, n) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float pi = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+        p[i] = pi;
+        ema[i] = ema[i] - (1.0f - decay) * (ema[i] - pi);           // shadow -= (1 - decay) * (shadow - var)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+//  host
+// ---------------------------------------------------------------------------------------------------------------
+// row-major C[M,N] (ldc) = alpha * op(A)[M,K] * op(B)[K,N] + beta * C, op = transpose when t* is set (A stored [K,M] / B stored [N,K])
+static rocblas_status gemm_rm(rocblas_handle h, bool tA, bool tB, int M, int N, int K, float alpha, const float* A, int lda,
+                              const float* B, int ldb, float beta, float* C, int ldc)
+{
+    return rocblas_sgemm(h, tB ? rocblas_operation_transpose : rocblas_operation_none, tA ? rocblas_operation_transpose : rocblas_operation_none,
+                         N, M, K, &alpha, B, ldb, A, lda, &beta, C, ldc);
+}
+
+extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch, int n_samples, twv_wavenet_trainer** out)
+{
+    if (!dims || !out || batch < 1) return twv_fail(TWV_E_INVALID, "bad argument");
+    const twv_wavenet_dims& d = *dims;
+    if (!d.scalar_input) return twv_fail(TWV_E_UNSUPPORTED, "the training step is built for scalar_input (MoL) models (hparams default)");
+    if (d.residual_channels != 32 || d.dilation_channels != 32) return twv_fail(TWV_E_UNSUPPORTED, "residual/dilation channels must be 32");
+    if (d.out_channels % 3 || d.out_channels > 96) return twv_fail(TWV_E_UNSUPPORTED, "out_channels must be 3*nr_mix <= 96");
+    if (!d.lc_channels || !d.gc_channels) return twv_fail(TWV_E_UNSUPPORTED, "the training step expects local and global conditioning (train_vocoder.py)");
+    twv_wavenet_trainer* h = new twv_wavenet_trainer();
+    h->d = d; h->B = batch; h->T = n_samples; h->Tn = n_samples - 1; h->NL = d.n_layers; h->S = d.skip_channels; h->O = d.out_channels;
+    h->L = d.lc_channels; h->G = d.gc_channels; h->ifw = d.initial_filter_width;
+    h->hop = 1;
+    for (int i = 0; i < d.n_upsample; ++i) h->hop *= d.upsample_factor[i];
+    if (n_samples % h->hop) { delete h; return twv_fail(TWV_E_INVALID, "n_samples must be a multiple of the hop size (datafeeder_wavenet.py:41-47)"); }
+    h->off[0] = h->ifw - 1;
+    for (int l = 0; l < h->NL; ++l) h->off[l + 1] = h->off[l] + d.dilations[l];
+    h->rf = h->off[h->NL] + 1;
+    h->ow = n_samples - h->rf;                                        // model.py:135 output_width
+    if (h->ow < 1) { delete h; return twv_fail(TWV_E_INVALID, "n_samples must exceed the receptive field"); }
+    // canonical blob offsets (same order as weights.tensor_specs / the generation path)
+    long long c = 0;
+    const int R = 32, D = 32, ub = d.use_biases ? 1 : 0;
+    h->c_causal = c; c += (long long)h->ifw * R;
+    h->c_gcemb = c; c += (long long)d.gc_cardinality * h->G;
+    h->c_layer0 = c;
+    long long q = 0;
+    h->lo.wf = q; q += 2 * R * D; h->lo.bf = q; q += ub * D;
+    h->lo.wg = q; q += 2 * R * D; h->lo.bg = q; q += ub * D;
+    h->lo.gcf = q; q += (long long)h->G * D; h->lo.gcg = q; q += (long long)h->G * D;
+    h->lo.lcf = q; q += (long long)h->L * D; h->lo.lcg = q; q += (long long)h->L * D;
+    h->lo.wd = q; q += D * R; h->lo.bd = q; q += ub * R;
+    h->lo.ws = q; q += (long long)D * h->S; h->lo.bs = q; q += (long long)ub * h->S;
+    h->c_lstride = q; c += q * h->NL;
+    h->c_w1 = c; c += (long long)h->S * h->S; h->c_b1 = c; c += (long long)ub * h->S;
+    h->c_w2 = c; c += (long long)h->S * h->O; h->c_b2 = c; c += (long long)ub * h->O;
+    for (int i = 0; i < d.n_upsample; ++i) { h->c_up[i] = c; c += (long long)d.upsample_factor[i] * 2; }
+    h->nparams = c;
+    h->blas = nullptr;
+    // workspace
+    const long long Rr = (long long)batch * h->Tn, RT = (long long)batch * n_samples, RO = (long long)batch * h->ow;
+    long long f = 0;
+    f += RT * h->L * 3;                         // upsample stages (ping, pong, final U) -- generous
+    f += RT * h->L;                             // dU
+    f += Rr * h->ifw;                           // xunf
+    f += Rr * 32 * (h->NL + 1);                 // X[l]
+    f += Rr * 32 * 3 * h->NL;                   // TH, SG, Z per layer
+    f += RO * 32 * h->NL;                       // Zc per layer
+    f += Rr * 64 * 2;                           // PRE / dPRE, LCP / dLCP (RT rows >= Rr rows: sized below)
+    f += RT * 64 * 2;
+    f += Rr * 32 * 3;                           // dX ping/pong, dZ
+    f += RO * 32;                               // dZc
+    f += RO * h->S * 3;                         // SK/H1, C1/H2, dSK/dC1
+    f += RO * h->O * 2;                         // Y, dY
+    f += (long long)batch * 64 * (h->NL + 2) + (long long)batch * h->G * 2 + 4096;
+    h->ws_floats = f;
+    *out = h;
+    return TWV_OK;
+}
+extern "C" void twv_wavenet_train_destroy(twv_wavenet_trainer* h)
+{
+    if (h && h->blas) rocblas_destroy_handle(h->blas);
+    delete h;
+}
+extern "C" size_t twv_wavenet_train_param_floats(const twv_wavenet_trainer* h) { return (size_t)h->nparams; }
+extern "C" size_t twv_wavenet_train_workspace_bytes(const twv_wavenet_trainer* h) { return (size_t)h->ws_floats * 4; }
+extern "C" int twv_wavenet_train_output_width(const twv_wavenet_trainer* h) { return h->ow; }
+
+extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* params, const float* audio, const float* lc,
+                                           const int32_t* gc_ids, void* workspace, float* loss, float* grads, void* stream)
+{
+    if (!h || !params || !audio || !lc || !gc_ids || !workspace || !loss || !grads) return twv_fail(TWV_E_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (!h->blas) BLASCHK(rocblas_create_handle(&h->blas));
+    BLASCHK(rocblas_set_stream(h->blas, st));
+    BLASCHK(rocblas_set_pointer_mode(h->blas, rocblas_pointer_mode_host));
+    rocblas_handle bl = h->blas;
+    const twv_wavenet_dims& d = h->d;
+    const int B = h->B, T = h->T, Tn = h->Tn, NL = h->NL, S = h->S, O = h->O, L = h->L, G = h->G, ow = h->ow, rf = h->rf, nr = O / 3;
+    const long long Rr = (long long)B * Tn, RT = (long long)B * T, RO = (long long)B * ow;
+    const bool ub = d.use_biases != 0;
+    const float* P = params;
+    float* Gd = grads;
+    HIPCHK(hipMemsetAsync(grads, 0, (size_t)h->nparams * 4, st));
+    HIPCHK(hipMemsetAsync(loss, 0, 4, st));
+    // ---- workspace carve
+    float* w = (float*)workspace;
+    auto take = [&](long long n) { float* p = w; w += (n + 63) / 64 * 64; return p; };
+    float* ups[5]; long long upT[5];
+    upT[0] = T / h->hop;
+    for (int i = 0; i < d.n_upsample; ++i) upT[i + 1] = upT[i] * d.upsample_factor[i];
+    ups[0] = const_cast<float*>(lc);
+    for (int i = 1; i <= d.n_upsample; ++i) ups[i] = take((long long)B * upT[i] * L);
+    float* U = ups[d.n_upsample];
+    float* dUa = take(RT * L); float* dUb = take(RT * L);
+    float* xunf = take(Rr * h->ifw);
+    float** X = new float*[NL + 1];
+    float **TH = new float*[NL], **SG = new float*[NL], **Z = new float*[NL], **ZC = new float*[NL];
+    for (int l = 0; l <= NL; ++l) X[l] = take(Rr * 32);
+    for (int l = 0; l < NL; ++l) { TH[l] = take(Rr * 32); SG[l] = take(Rr * 32); Z[l] = take(Rr * 32); ZC[l] = take(RO * 32); }
+    float* PRE = take(Rr * 64);
+    float* LCP = take(RT * 64);
+    float* dXa = take(Rr * 32); float* dXb = take(Rr * 32); float* dZ = take(Rr * 32); float* dZc = take(RO * 32);
+    float* SK = take(RO * S); float* C1 = take(RO * S); float* dS = take(RO * S);
+    float* Y = take(RO * O); float* dY = take(RO * O);
+    float* emb = take((long long)B * G); float* demb = take((long long)B * G);
+    float* GCP = take((long long)B * 64 * NL); float* dGCP = take((long long)B * 64);
+    int rc = TWV_OK;
+#define K1(kern, n, ...) hipLaunchKernelGGL(kern, dim3(tg(n)), dim3(256), 0, st, __VA_ARGS__)
+#define LP(l) (P + h->c_layer0 + (long long)(l) * h->c_lstride)
+#define LG(l) (Gd + h->c_layer0 + (long long)(l) * h->c_lstride)
+    do {
+        // ================= forward =================
+        for (int i = 0; i < d.n_upsample; ++i)     // model.py:276 create_upsample
+            K1(tr_up_fwd_kernel, (long long)B * upT[i + 1] * L, P + h->c_up[i], ups[i], ups[i + 1], (long long)B * upT[i + 1] * L, d.upsample_factor[i], L);
+        K1(tr_gather_emb_kernel, (long long)B * G, P + h->c_gcemb, gc_ids, emb, B, G);   // model.py:197-198
+        K1(tr_unfold_kernel, Rr * h->ifw, audio, xunf, B, T, Tn, h->ifw);
+        if ((rc = gemm_rm(bl, false, false, (int)Rr, 32, h->ifw, 1.f, xunf, h->ifw, P + h->c_causal, 32, 0.f, X[0], 32))) break;   // model.py:131
+        for (int l = 0; l < NL && !rc; ++l) {
+            const int dl = d.dilations[l], o = h->off[l + 1];
+            const float* Lp = LP(l);
+            // model.py:68-69 conv_filter | conv_gate, taps x[t-d] and x[t]  (rows d .. R-1)
+            const int M = (int)(Rr - dl);
+            rc |= gemm_rm(bl, false, false, M, 32, 32, 1.f, X[l], 32, Lp + h->lo.wf, 32, 0.f, PRE + (long long)dl * 64, 64);
+            rc |= gemm_rm(bl, false, false, M, 32, 32, 1.f, X[l] + (long long)dl * 32, 32, Lp + h->lo.wf + 1024, 32, 1.f, PRE + (long long)dl * 64, 64);
+            rc |= gemm_rm(bl, false, false, M, 32, 32, 1.f, X[l], 32, Lp + h->lo.wg, 32, 0.f, PRE + (long long)dl * 64 + 32, 64);
+            rc |= gemm_rm(bl, false, false, M, 32, 32, 1.f, X[l] + (long long)dl * 32, 32, Lp + h->lo.wg + 1024, 32, 1.f, PRE + (long long)dl * 64 + 32, 64);
+            // model.py:71-83 gc / lc 1x1 projections
+            float* gcp = GCP + (long long)l * B * 64;
+            rc |= gemm_rm(bl, false, false, B, 32, G, 1.f, emb, G, Lp + h->lo.gcf, 32, 0.f, gcp, 64);
+            rc |= gemm_rm(bl, false, false, B, 32, G, 1.f, emb, G, Lp + h->lo.gcg, 32, 0.f, gcp + 32, 64);
+            rc |= gemm_rm(bl, false, false, (int)RT, 32, L, 1.f, U, L, Lp + h->lo.lcf, 32, 0.f, LCP, 64);
+            rc |= gemm_rm(bl, false, false, (int)RT, 32, L, 1.f, U, L, Lp + h->lo.lcg, 32, 0.f, LCP + 32, 64);
+            K1(tr_gate_fwd_kernel, Rr * 32, PRE, ub ? Lp + h->lo.bf : nullptr, ub ? Lp + h->lo.bg : nullptr, gcp, LCP, TH[l], SG[l], Z[l], B, Tn, T, o);
+            // model.py:89,98-101 dense + residual ; model.py:94-96 skip on the last `ow` positions
+            K1(tr_add_bias32_kernel, Rr * 32, X[l], ub ? Lp + h->lo.bd : nullptr, X[l + 1], Rr * 32);
+            rc |= gemm_rm(bl, false, false, (int)Rr, 32, 32, 1.f, Z[l], 32, Lp + h->lo.wd, 32, 1.f, X[l + 1], 32);
+            K1(tr_compact_kernel, RO * 32, Z[l], ZC[l], B, Tn, ow);
+            rc |= gemm_rm(bl, false, false, (int)RO, S, 32, 1.f, ZC[l], 32, Lp + h->lo.ws, S, l == 0 ? 0.f : 1.f, SK, S);
+        }
+        if (rc) break;
+        // model.py:150-165 postprocessing: sum(skips) incl. their biases -> relu -> 1x1 -> relu -> 1x1
+        K1(tr_bias_relu_kernel, RO * S, SK, ub ? LP(0) + h->lo.bs : nullptr, ub ? NL : 0, h->c_lstride, nullptr, S, RO * S);
+        if ((rc = gemm_rm(bl, false, false, (int)RO, S, S, 1.f, SK, S, P + h->c_w1, S, 0.f, C1, S))) break;
+        K1(tr_bias_relu_kernel, RO * S, C1, nullptr, 0, 0, ub ? P + h->c_b1 : nullptr, S, RO * S);
+        if ((rc = gemm_rm(bl, false, false, (int)RO, O, S, 1.f, C1, S, P + h->c_w2, O, 0.f, Y, O))) break;
+        if (ub) K1(tr_bias_add_kernel, RO * O, Y, P + h->c_b2, O, RO * O);
+        // model.py:286-290 loss
+        K1(tr_mol_loss_kernel, RO, Y, audio, B, T, ow, rf, nr, 1.0f / (float)RO, loss, dY);
+        // ================= backward =================
+        rc |= gemm_rm(bl, true, false, S, O, (int)RO, 1.f, C1, S, dY, O, 0.f, Gd + h->c_w2, O);                 // dW2 = H2^T dY
+        if (ub) hipLaunchKernelGGL(tr_colsum_kernel, dim3((O + 63) / 64), dim3(256), 0, st, dY, RO, O, Gd + h->c_b2);
+        rc |= gemm_rm(bl, false, true, (int)RO, S, O, 1.f, dY, O, P + h->c_w2, O, 0.f, dS, S);                   // dH2
+        K1(tr_relu_bwd_kernel, RO * S, dS, C1, RO * S);
+        rc |= gemm_rm(bl, true, false, S, S, (int)RO, 1.f, SK, S, dS, S, 0.f, Gd + h->c_w1, S);                  // dW1 = H1^T dC1
+        if (ub) hipLaunchKernelGGL(tr_colsum_kernel, dim3((S + 63) / 64), dim3(256), 0, st, dS, RO, S, Gd + h->c_b1);
+        rc |= gemm_rm(bl, false, true, (int)RO, S, S, 1.f, dS, S, P + h->c_w1, S, 0.f, C1, S);                   // dH1 -> C1 buffer
+        K1(tr_relu_bwd_kernel, RO * S, C1, SK, RO * S);                                                           // dSK
+        float* dSK = C1;
+        if (rc) break;
+        float* dXn = dXa; float* dXc = dXb;
+        K1(tr_fill_kernel, Rr * 32, dXn, 0.0f, Rr * 32);
+        K1(tr_fill_kernel, RT * L, dUa, 0.0f, RT * L);
+        K1(tr_fill_kernel, (long long)B * G, demb, 0.0f, (long long)B * G);
+        for (int l = NL - 1; l >= 0 && !rc; --l) {
+            const int dl = d.dilations[l], o = h->off[l + 1];
+            const float* Lp = LP(l);
+            float* Lg = LG(l);
+            const int M = (int)(Rr - dl);
+            // skip 1x1: dWs, dbs, dZc ; dense 1x1: dWd, dbd, dZ
+            rc |= gemm_rm(bl, true, false, 32, S, (int)RO, 1.f, ZC[l], 32, dSK, S, 0.f, Lg + h->lo.ws, S);
+            if (ub) hipLaunchKernelGGL(tr_colsum_kernel, dim3((S + 63) / 64), dim3(256), 0, st, dSK, RO, S, Lg + h->lo.bs);
+            rc |= gemm_rm(bl, false, true, (int)RO, 32, S, 1.f, dSK, S, Lp + h->lo.ws, S, 0.f, dZc, 32);
+            rc |= gemm_rm(bl, true, false, 32, 32, (int)Rr, 1.f, Z[l], 32, dXn, 32, 0.f, Lg + h->lo.wd, 32);
+            if (ub) hipLaunchKernelGGL(tr_colsum_kernel, dim3(1), dim3(256), 0, st, dXn, Rr, 32, Lg + h->lo.bd);
+            rc |= gemm_rm(bl, false, true, (int)Rr, 32, 32, 1.f, dXn, 32, Lp + h->lo.wd, 32, 0.f, dZ, 32);
+            K1(tr_scatter_add_kernel, RO * 32, dZc, dZ, B, Tn, ow);
+            // gated unit
+            K1(tr_gate_bwd_kernel, Rr * 32, dZ, TH[l], SG[l], PRE, B, Tn, o);
+            float* dPRE = PRE;
+            if (ub) {   // conv biases: first / second 32 columns
+                hipLaunchKernelGGL(tr_colsum_kernel, dim3(1), dim3(256), 0, st, dPRE, Rr, 64, dGCP);
+                HIPCHK(hipMemcpyAsync(Lg + h->lo.bf, dGCP, 32 * 4, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(Lg + h->lo.bg, dGCP + 32, 32 * 4, hipMemcpyDeviceToDevice, st));
+            }
+            // gc: dGCP[b] = sum_t dPRE ; dWgc = emb^T dGCP ; demb += dGCP Wgc^T
+            hipLaunchKernelGGL(tr_batchsum_kernel, dim3(B), dim3(64), 0, st, dPRE, Tn, 64, dGCP);
+            rc |= gemm_rm(bl, true, false, G, 32, B, 1.f, emb, G, dGCP, 64, 0.f, Lg + h->lo.gcf, 32);
+            rc |= gemm_rm(bl, true, false, G, 32, B, 1.f, emb, G, dGCP + 32, 64, 0.f, Lg + h->lo.gcg, 32);
+            rc |= gemm_rm(bl, false, true, B, G, 32, 1.f, dGCP, 64, Lp + h->lo.gcf, 32, 1.f, demb, G);
+            rc |= gemm_rm(bl, false, true, B, G, 32, 1.f, dGCP + 32, 64, Lp + h->lo.gcg, 32, 1.f, demb, G);
+            // lc: dLCP = shifted dPRE ; dWlc = U^T dLCP ; dU += dLCP Wlc^T
+            K1(tr_shift_lc_kernel, RT * 64, dPRE, LCP, B, Tn, T, o);
+            rc |= gemm_rm(bl, true, false, L, 32, (int)RT, 1.f, U, L, LCP, 64, 0.f, Lg + h->lo.lcf, 32);
+            rc |= gemm_rm(bl, true, false, L, 32, (int)RT, 1.f, U, L, LCP + 32, 64, 0.f, Lg + h->lo.lcg, 32);
+            rc |= gemm_rm(bl, false, true, (int)RT, L, 32, 1.f, LCP, 64, Lp + h->lo.lcf, 32, 1.f, dUa, L);
+            rc |= gemm_rm(bl, false, true, (int)RT, L, 32, 1.f, LCP + 32, 64, Lp + h->lo.lcg, 32, 1.f, dUa, L);
+            // conv weights: tap 0 pairs dPRE[r] with X[r-d], tap 1 with X[r]
+            rc |= gemm_rm(bl, true, false, 32, 32, M, 1.f, X[l], 32, dPRE + (long long)dl * 64, 64, 0.f, Lg + h->lo.wf, 32);
+            rc |= gemm_rm(bl, true, false, 32, 32, M, 1.f, X[l] + (long long)dl * 32, 32, dPRE + (long long)dl * 64, 64, 0.f, Lg + h->lo.wf + 1024, 32);
+            rc |= gemm_rm(bl, true, false, 32, 32, M, 1.f, X[l], 32, dPRE + (long long)dl * 64 + 32, 64, 0.f, Lg + h->lo.wg, 32);
+            rc |= gemm_rm(bl, true, false, 32, 32, M, 1.f, X[l] + (long long)dl * 32, 32, dPRE + (long long)dl * 64 + 32, 64, 0.f, Lg + h->lo.wg + 1024, 32);
+            // dX_l = dX_{l+1} (residual) + taps
+            HIPCHK(hipMemcpyAsync(dXc, dXn, (size_t)Rr * 32 * 4, hipMemcpyDeviceToDevice, st));
+            rc |= gemm_rm(bl, false, true, M, 32, 32, 1.f, dPRE + (long long)dl * 64, 64, Lp + h->lo.wf, 32, 1.f, dXc, 32);
+            rc |= gemm_rm(bl, false, true, M, 32, 32, 1.f, dPRE + (long long)dl * 64 + 32, 64, Lp + h->lo.wg, 32, 1.f, dXc, 32);
+            rc |= gemm_rm(bl, false, true, M, 32, 32, 1.f, dPRE + (long long)dl * 64, 64, Lp + h->lo.wf + 1024, 32, 1.f, dXc + (long long)dl * 32, 32);
+            rc |= gemm_rm(bl, false, true, M, 32, 32, 1.f, dPRE + (long long)dl * 64 + 32, 64, Lp + h->lo.wg + 1024, 32, 1.f, dXc + (long long)dl * 32, 32);
+            float* tsw = dXn; dXn = dXc; dXc = tsw;
+        }
+        if (rc) break;
+        // causal layer, gc embedding table, upsampler
+        rc |= gemm_rm(bl, true, false, h->ifw, 32, (int)Rr, 1.f, xunf, h->ifw, dXn, 32, 0.f, Gd + h->c_causal, 32);
+        K1(tr_scatter_emb_kernel, (long long)B * G, demb, gc_ids, Gd + h->c_gcemb, B, G);
+        {
+            float* dcur = dUa; float* dnxt = dUb;
+            for (int i = d.n_upsample - 1; i >= 0; --i) {
+                hipLaunchKernelGGL(tr_up_bwd_k_kernel, dim3(d.upsample_factor[i]), dim3(256), 0, st, ups[i], dcur, Gd + h->c_up[i],
+                                   (long long)B * upT[i], d.upsample_factor[i], L);
+                if (i > 0) {
+                    K1(tr_up_bwd_in_kernel, (long long)B * upT[i] * L, P + h->c_up[i], dcur, dnxt, (long long)B * upT[i] * L, d.upsample_factor[i], L);
+                    float* tsw = dcur; dcur = dnxt; dnxt = tsw;
+                }
+            }
+        }
+    } while (0);
+    delete[] X; delete[] TH; delete[] SG; delete[] Z; delete[] ZC;
+    if (rc) return twv_fail(TWV_E_HIP, "rocBLAS call failed with status " + std::to_string(rc));
+    HIPCHK(hipGetLastError());
+    if ((long long)(w - (float*)workspace) > h->ws_floats) return twv_fail(TWV_E_INVALID, "internal: workspace overrun");
+    return TWV_OK;
+}
+
+extern "C" int twv_adam_ema_step(float* params, const float* grads, float* m, float* v, float* ema, int64_t n, double lr, double beta1,
+                                 double beta2, double eps, int64_t t, double ema_decay, double grad_scale, void* stream)
+{
+    if (!params || !grads || !m || !v || !ema || n < 0 || t < 1) return twv_fail(TWV_E_INVALID, "bad argument");
+    // tf.train.AdamOptimizer: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+    double b1t = 1.0, b2t = 1.0;
+    for (int64_t i = 0; i < t && (b1t > 1e-300 || b2t > 1e-300); ++i) { b1t *= beta1; b2t *= beta2; }
+    const float lr_t = (float)(lr * sqrt(1.0 - b2t) / (1.0 - b1t));
+    if (n) hipLaunchKernelGGL(tr_adam_ema_kernel, dim3(tg(n)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, ema, (long long)n, lr_t,
+                              (float)beta1, (float)beta2, (float)eps, (float)ema_decay, (float)grad_scale);
+    HIPCHK(hipGetLastError());
+    return TWV_OK;
+}

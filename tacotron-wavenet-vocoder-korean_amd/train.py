@@ -1,0 +1,152 @@
+"""Host-side mirror of the WaveNet training step (train_vocoder.py:86-182) over the HIP C-ABI.
+
+    net = WaveNetModel(batch_size=hparams.wavenet_batch_size, ..., train_mode=True)   # train_vocoder.py:100-115
+    trainer = WaveNetTrainer(net, hparams, sample_size=7800)
+    trainer.load_weights(tensors)                       # or trainer.init_weights(seed)
+    loss = trainer.step(audio, local_condition, gc_ids) # == sess.run([net.loss, net.optimize]), train_vocoder.py:163/174
+
+`add_loss` (wavenet/model.py:247-312) and `add_optimizer` (model.py:314-346) run as twv_wavenet_train_loss_grad and
+twv_adam_ema_step.  The reference trains on one device; with an initialised torch.distributed process group the flat
+gradient buffer is all-reduced (sum, then 1/world folded into the Adam kernel) between the two calls -- one process per
+GPU, backend "nccl" (RCCL over xGMI); replicas must start from identical weights.
+PyTorch is used for device memory, streams and the collective only."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import weights as W
+from .wavenet import _ptr, _stream
+
+
+def allreduce_sum_(flat, group=None):
+    """in-place sum of one flat gradient buffer over all ranks (no-op without a process group); returns world size."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return dist.get_world_size(group)
+
+
+def exponential_decay(lr0, global_step, decay_steps, decay_rate):
+    """tf.train.exponential_decay (model.py:320), staircase=False"""
+    return float(lr0) * float(decay_rate) ** (float(global_step) / float(decay_steps))
+
+
+def crop_length(sample_size, hop_size):
+    """datafeeder_wavenet.py:41-47: sample_size is floored to a multiple of the hop size"""
+    return int(sample_size) // int(hop_size) * int(hop_size)
+
+
+class WaveNetTrainer(object):
+    def __init__(self, net, hparams=None, sample_size=None, learning_rate=1e-3, decay_steps=300000, decay_rate=0.5,
+                 ema_decay=0.9999, beta1=0.9, beta2=0.999, epsilon=1e-8, group=None):
+        self.net = net
+        if hparams is not None:
+            learning_rate = getattr(hparams, "wavenet_learning_rate", learning_rate)
+            decay_steps = getattr(hparams, "wavenet_decay_steps", decay_steps)
+            decay_rate = getattr(hparams, "wavenet_decay_rate", decay_rate)
+            if getattr(hparams, "wavenet_clip_gradients", False):
+                raise NotImplementedError("wavenet_clip_gradients=True (hparams.py:94 default False) is not built")
+            if getattr(hparams, "l2_regularization_strength", 0):
+                raise NotImplementedError("l2_regularization_strength != 0 (hparams.py:54 default 0) is not built")
+            if sample_size is None:
+                sample_size = hparams.sample_size
+        self.lr0, self.decay_steps, self.decay_rate = learning_rate, decay_steps, decay_rate
+        self.ema_decay, self.beta1, self.beta2, self.epsilon = ema_decay, beta1, beta2, epsilon
+        self.group = group
+        self.batch_size = net.batch_size
+        self.sample_size = crop_length(sample_size, net.hop_size)
+        self.device = net.device
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(self._L.twv_wavenet_train_create(C.byref(net._dims), self.batch_size, self.sample_size, C.byref(h)))
+        self._h = h
+        self.n_params = self._L.twv_wavenet_train_param_floats(h)
+        self.output_width = self._L.twv_wavenet_train_output_width(h)
+        self.global_step = 0
+        self.params = None
+        with torch.cuda.device(self.device):
+            self._ws = torch.empty(self._L.twv_wavenet_train_workspace_bytes(h) // 4, dtype=torch.float32, device=self.device)
+            self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+            self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.twv_wavenet_train_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- variables: tf.global_variables_initializer / saver.restore (train_vocoder.py:139-152) ----
+    def load_weights(self, tensors):
+        blob = W.flatten(self.net.specs, tensors)
+        assert blob.size == self.n_params, (blob.size, self.n_params)
+        self.params = torch.from_numpy(blob).to(self.device)
+        self.m = torch.zeros_like(self.params)
+        self.v = torch.zeros_like(self.params)
+        self.ema = self.params.clone()                      # EMA shadow variables start at the variable's value
+        self.global_step = 0
+
+    def init_weights(self, seed=0, scale=0.05):
+        self.load_weights(W.random_tensors(self.net.specs, seed=seed, scale=scale))
+
+    def _named(self, flat):
+        out, o = {}, 0
+        host = flat.detach().cpu().numpy()
+        for name, shape in self.net.specs:
+            n = int(np.prod(shape))
+            out[name] = host[o:o + n].reshape(shape).copy()
+            o += n
+        return out
+
+    def weights(self):
+        return self._named(self.params)
+
+    def ema_weights(self):
+        """what the reference's eval/generate restores (model.py:30, generate.py:157)"""
+        return self._named(self.ema)
+
+    def gradients(self):
+        return self._named(self.grads)
+
+    # ---- add_loss + compute_gradients ----
+    def loss_and_gradients(self, audio, local_condition, gc_ids):
+        """audio (B, sample_size) float32, local_condition (B, sample_size/hop, num_mels), gc_ids (B) -> loss (device scalar);
+        self.grads holds d loss / d params in the canonical order."""
+        B, T = self.batch_size, self.sample_size
+        audio = torch.as_tensor(audio, dtype=torch.float32).to(self.device).contiguous()
+        lc = torch.as_tensor(local_condition, dtype=torch.float32).to(self.device).contiguous()
+        gc = torch.as_tensor(gc_ids, dtype=torch.int32).to(self.device).contiguous()
+        if tuple(audio.shape) != (B, T):
+            raise ValueError("audio must be (%d, %d), got %s" % (B, T, tuple(audio.shape)))
+        if tuple(lc.shape) != (B, T // self.net.hop_size, self.net.local_condition_channels):
+            raise ValueError("local_condition must be (%d, %d, %d), got %s" % (B, T // self.net.hop_size,
+                                                                              self.net.local_condition_channels, tuple(lc.shape)))
+        if int(gc.numel()) != B:
+            raise ValueError("gc_ids must hold %d ids" % B)
+        if self.params is None:
+            raise RuntimeError("no weights: call load_weights / init_weights first")
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.twv_wavenet_train_loss_grad(self._h, _ptr(self.params), _ptr(audio), _ptr(lc), _ptr(gc), _ptr(self._ws),
+                                                          _ptr(self.loss), _ptr(self.grads), _stream()))
+        return self.loss
+
+    # ---- apply_gradients + ema.apply ----
+    def apply_gradients(self, world=1):
+        lr = exponential_decay(self.lr0, self.global_step, self.decay_steps, self.decay_rate)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.twv_adam_ema_step(_ptr(self.params), _ptr(self.grads), _ptr(self.m), _ptr(self.v), _ptr(self.ema),
+                                                self.n_params, lr, self.beta1, self.beta2, self.epsilon, self.global_step + 1,
+                                                self.ema_decay, 1.0 / world, _stream()))
+        self.global_step += 1
+        return lr
+
+    def step(self, audio, local_condition, gc_ids):
+        """one sess.run([net.loss, net.optimize]) (train_vocoder.py:163); returns the (local) loss as a device tensor"""
+        loss = self.loss_and_gradients(audio, local_condition, gc_ids)
+        world = allreduce_sum_(self.grads, self.group)
+        self.apply_gradients(world)
+        return loss

@@ -1,0 +1,124 @@
+"""C4: the teacher-forced WaveNet training step on the MI355X vs a plain PyTorch fp32 (CPU autograd) model of the same op.
+
+Floating-point work -> tolerance parity (written at each assert).  The GPU path sums in a different order (rocBLAS
+GEMMs over all rows, atomics for the loss), so agreement is to fp32 round-off of the reductions, not bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import torch_train_ref as R
+from helpers import make_model
+
+pytestmark = pytest.mark.gpu
+
+UP = (5, 5, 12)
+
+
+def _case(dil, B, Tm, S=64, seed=0, scale=0.05, ls_bias=None, clip_audio=False, use_bias=True):
+    import twvk_amd  # noqa: F401
+    from twvk_amd import weights as W
+    from twvk_amd.train import WaveNetTrainer
+    specs = W.tensor_specs(len(dil), S=S, use_biases=use_bias)
+    tensors = W.random_tensors(specs, seed=seed, scale=scale)
+    if ls_bias is not None:
+        tensors["wavenet/conv1d_2/bias"][20:30] = ls_bias          # log-scales: exercises the cdf_delta > 1e-5 branch
+    T = Tm * 300
+    rng = np.random.RandomState(seed + 1)
+    audio = ((rng.rand(B, T) - 0.5) * 1.6).astype(np.float32)
+    if clip_audio:
+        audio = np.clip(audio * 1.5, -1.0, 1.0).astype(np.float32)  # some targets at +-1: the two edge branches
+    lc = (rng.randn(B, Tm, 80) * 0.5).astype(np.float32)
+    gc = rng.randint(0, 2, size=B).astype(np.int32)
+    net = make_model(B, dil, tensors, S=S, use_bias=use_bias)
+    tr = WaveNetTrainer(net, sample_size=T)
+    tr.load_weights(tensors)
+    cfg = dict(dilations=dil, initial_filter_width=32, use_biases=use_bias, upsample_factor=UP)
+    return tr, tensors, cfg, audio, lc, gc
+
+
+def _check_grads(got, ref, rtol):
+    worst = ("", 0.0)
+    for name, r in ref.items():
+        g = got[name]
+        scale = max(float(np.abs(r).max()), 1e-12)
+        err = float(np.abs(g - r).max()) / scale
+        if err > worst[1]:
+            worst = (name, err)
+        assert np.isfinite(g).all(), name
+        assert err <= rtol, "%s: max|diff| = %.3g of max|ref| %.3g" % (name, err, scale)
+    return worst
+
+
+@pytest.mark.parametrize("kw", [
+    dict(dil=[1, 2, 4, 1, 2], B=2, Tm=3),
+    dict(dil=[1, 2, 4, 8, 16, 32, 64, 128, 256, 512], B=3, Tm=6, S=128),
+    dict(dil=[1, 2, 4, 1, 2], B=2, Tm=3, ls_bias=-4.0, clip_audio=True),
+    dict(dil=[1, 2, 4], B=1, Tm=2, use_bias=False),
+], ids=["small", "one-cycle", "mol-branches", "no-bias"])
+def test_loss_and_gradients_match_torch_fp32(kw):
+    tr, tensors, cfg, audio, lc, gc = _case(**kw)
+    loss = float(tr.loss_and_gradients(audio, lc, gc).item())
+    ref_loss, ref_g = R.loss_and_grads(tensors, cfg, audio, lc, gc)
+    # tolerance: the loss is a mean of O(10) terms over B*out_w rows summed by float atomics -> 2e-5 relative
+    assert abs(loss - ref_loss) <= 2e-5 * abs(ref_loss), (loss, ref_loss)
+    # tolerance: every gradient tensor within 2e-3 of its own max magnitude (fp32 reductions over up to B*T rows in a
+    # different order; float64 torch agrees with float32 torch to ~1e-4 on the same scale)
+    _check_grads(tr.gradients(), ref_g, 2e-3)
+
+
+def test_gradients_against_float64_reference_are_closer_than_float32_noise():
+    """the fp32 torch model itself deviates from float64 by round-off; the HIP path must be in the same league"""
+    tr, tensors, cfg, audio, lc, gc = _case(dil=[1, 2, 4, 1, 2], B=2, Tm=3)
+    tr.loss_and_gradients(audio, lc, gc)
+    got = tr.gradients()
+    _, g64 = R.loss_and_grads(tensors, cfg, audio, lc, gc, dtype=torch.float64)
+    _, g32 = R.loss_and_grads(tensors, cfg, audio, lc, gc, dtype=torch.float32)
+    e_hip = max(float(np.abs(got[k] - g64[k]).max()) / max(float(np.abs(g64[k]).max()), 1e-12) for k in g64)
+    e_t32 = max(float(np.abs(g32[k] - g64[k]).max()) / max(float(np.abs(g64[k]).max()), 1e-12) for k in g64)
+    assert e_hip <= max(20 * e_t32, 1e-4), (e_hip, e_t32)
+
+
+def test_adam_and_ema_update_match_tf_formulas():
+    tr, tensors, cfg, audio, lc, gc = _case(dil=[1, 2, 4, 1, 2], B=2, Tm=3)
+    p = tr.params.cpu().numpy().astype(np.float64)
+    m = np.zeros_like(p); v = np.zeros_like(p); ema = p.copy()
+    for it in range(3):
+        tr.loss_and_gradients(audio, lc, gc)
+        g = tr.grads.cpu().numpy().astype(np.float64)
+        lr = tr.apply_gradients()
+        assert lr == pytest.approx(1e-3 * 0.5 ** (it / 300000.0), rel=1e-12)          # model.py:320
+        p, m, v, ema = R.adam_ema(p, g, m, v, ema, it + 1, lr)
+        # tolerance: one fp32 update of O(lr) on O(0.05) weights -> 1e-6 absolute
+        np.testing.assert_allclose(tr.params.cpu().numpy(), p, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(tr.ema.cpu().numpy(), ema, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(tr.m.cpu().numpy(), m, rtol=1e-5, atol=1e-12)
+        # (1 - beta2) is formed in float32 as TF's kernel does: 1 - 0.999f carries a 1.3e-5 relative rounding
+        np.testing.assert_allclose(tr.v.cpu().numpy(), v, rtol=5e-5, atol=1e-20)
+        p = tr.params.cpu().numpy().astype(np.float64); m = tr.m.cpu().numpy().astype(np.float64)
+        v = tr.v.cpu().numpy().astype(np.float64); ema = tr.ema.cpu().numpy().astype(np.float64)
+    assert tr.global_step == 3
+
+
+def test_training_reduces_the_loss_and_trained_weights_generate():
+    """a few steps on one fixed batch: the loss must fall; the EMA weights load into the generation path"""
+    tr, tensors, cfg, audio, lc, gc = _case(dil=[1, 2, 4, 8, 1, 2, 4, 8], B=4, Tm=4, S=64)
+    losses = [float(tr.step(audio, lc, gc).item()) for _ in range(30)]
+    assert np.isfinite(losses).all()
+    assert losses[-1] < losses[0] - 0.5, losses
+    gen = make_model(1, [1, 2, 4, 8, 1, 2, 4, 8], tr.ema_weights(), S=64)
+    from helpers import mol_uniforms
+    up = gen.create_upsample(torch.from_numpy(lc[:1]).cuda())
+    out = gen.generate(up, [int(gc[0])], np.zeros(1, np.float32), mol_uniforms(1, 300, 10))
+    assert np.isfinite(out.cpu().numpy()).all()
+
+
+def test_bad_shapes_are_rejected():
+    tr, tensors, cfg, audio, lc, gc = _case(dil=[1, 2, 4], B=2, Tm=2)
+    with pytest.raises(ValueError):
+        tr.loss_and_gradients(audio[:, :-1], lc, gc)
+    with pytest.raises(ValueError):
+        tr.loss_and_gradients(audio, lc[:, :1], gc)
+    from twvk_amd.train import WaveNetTrainer
+    from twvk_amd._lib import TwvError
+    with pytest.raises(TwvError):
+        WaveNetTrainer(tr.net, sample_size=0)        # shorter than the receptive field

@@ -1,0 +1,114 @@
+"""Plain PyTorch fp32 (CPU, autograd) restatement of the reference's WaveNet training graph -- TEST INFRASTRUCTURE ONLY.
+
+The training step is floating-point work, so its checker is a torch fp32 model of the same op (not the bit-exact C
+restatement).  Follows /root/reference:
+  wavenet/model.py:247-312 add_loss, :102-111 create_upsample, :66-101 _create_dilation_layer (train_mode=True, 'valid'
+  convs, local condition sliced from the FRONT), :112-167 _create_network, wavenet/mixture.py:27-81
+  discretized_mix_logistic_loss(num_class=2**16, reduce=False) -> mean, model.py:314-346 Adam (TF formulation) + EMA.
+Parity unpinned: TensorFlow is not installed here, so this restatement has not been run against the reference itself."""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def log_sum_exp(x, axis=-1):
+    m = x.max(dim=axis, keepdim=True)[0]
+    return (m + torch.log(torch.sum(torch.exp(x - m), dim=axis, keepdim=True))).squeeze(axis)
+
+
+def mol_loss(y_hat, y, num_class=2 ** 16, log_scale_min=float(np.log(1e-14))):
+    """y_hat (B, T, 3*nr), y (B, T, 1) -> (B, T) negative log-likelihood   [mixture.py:27-81]"""
+    nr = y_hat.shape[-1] // 3
+    logit_probs = y_hat[:, :, :nr]
+    means = y_hat[:, :, nr:2 * nr]
+    log_scales = torch.clamp(y_hat[:, :, 2 * nr:3 * nr], min=log_scale_min)
+    y = y.expand(-1, -1, nr)
+    centered = y - means
+    inv_stdv = torch.exp(-log_scales)
+    plus_in = inv_stdv * (centered + 1.0 / (num_class - 1))
+    cdf_plus = torch.sigmoid(plus_in)
+    min_in = inv_stdv * (centered - 1.0 / (num_class - 1))
+    cdf_min = torch.sigmoid(min_in)
+    log_cdf_plus = plus_in - F.softplus(plus_in)
+    log_one_minus_cdf_min = -F.softplus(min_in)
+    cdf_delta = cdf_plus - cdf_min
+    mid_in = inv_stdv * centered
+    log_pdf_mid = mid_in - log_scales - 2.0 * F.softplus(mid_in)
+    log_probs = torch.where(y < -0.999, log_cdf_plus,
+                            torch.where(y > 0.999, log_one_minus_cdf_min,
+                                        torch.where(cdf_delta > 1e-5, torch.log(torch.clamp(cdf_delta, min=1e-12)),
+                                                    log_pdf_mid - math.log((num_class - 1) / 2))))
+    log_probs = log_probs + F.log_softmax(logit_probs, dim=-1)
+    return -log_sum_exp(log_probs)
+
+
+def upsample(lc, kernels, factors):
+    """conv2d_transpose(filters=1, kernel=(f,2), strides=(f,1), 'same'): out[t*f+a, m] = K[a,0] in[t,m] + K[a,1] in[t,m-1]"""
+    x = lc                                                     # (B, T, L)
+    for K, f in zip(kernels, factors):
+        K = K.reshape(f, 2)
+        xl = F.pad(x, (1, 0))[:, :, :-1]                       # in[t, m-1]
+        out = x[:, :, None, :] * K[None, None, :, 0, None] + xl[:, :, None, :] * K[None, None, :, 1, None]
+        x = out.reshape(x.shape[0], x.shape[1] * f, x.shape[2])
+    return x
+
+
+def network(P, cfg, net_in, U, gc_ids):
+    """_create_network(train_mode=True): net_in (B,1,Tn) scalar input, U (B,Tlc,L) upsampled lc -> raw output (B, Tn-rf+1, O)"""
+    dil, ifw, ub = cfg["dilations"], cfg["initial_filter_width"], cfg["use_biases"]
+    rf = sum(dil) + 1 + ifw - 1
+    Uc = U.transpose(1, 2)                                     # (B, L, Tlc)
+    gc = P["wavenet/gc_embedding"][gc_ids.long()][:, :, None]  # (B, G, 1)
+
+    def conv(x, name, dilation=1, bias=True):                  # TF kernel (W, in, out) -> torch (out, in, W)
+        w = P[name + "/kernel"].permute(2, 1, 0)
+        b = P[name + "/bias"] if (bias and ub and (name + "/bias") in P) else None
+        return F.conv1d(x, w, b, dilation=dilation)
+
+    cur = F.conv1d(net_in, P["wavenet/conv1d/kernel"].permute(2, 1, 0))     # model.py:41-46 (no bias)
+    out_w = net_in.shape[2] - rf + 1
+    skips = []
+    for i, d in enumerate(dil):
+        p = "wavenet/dilated_stack/layer%d/dilation_layer/" % i
+        f = conv(cur, p + "conv_filter", d)
+        g = conv(cur, p + "conv_gate", d)
+        f = f + conv(gc, p + "gc_filter", bias=False)
+        g = g + conv(gc, p + "gc_gate", bias=False)
+        n = f.shape[2]
+        f = f + conv(Uc, p + "lc_filter", bias=False)[:, :, :n]            # model.py:79-80 slice from the front
+        g = g + conv(Uc, p + "lc_gate", bias=False)[:, :, :n]
+        z = torch.tanh(f) * torch.sigmoid(g)
+        skips.append(conv(z[:, :, n - out_w:], p + "skip"))
+        cur = cur[:, :, cur.shape[2] - n:] + conv(z, p + "dense")
+    total = sum(skips)
+    c1 = conv(F.relu(total), "wavenet/conv1d_1")
+    return conv(F.relu(c1), "wavenet/conv1d_2").transpose(1, 2)             # (B, out_w, 3*nr)
+
+
+def loss_fn(P, cfg, audio, lc, gc_ids):
+    """P: dict TF-name -> torch tensor (TF layouts); audio (B,T); lc (B,T/hop,L); gc_ids (B) -> scalar loss."""
+    rf = sum(cfg["dilations"]) + 1 + cfg["initial_filter_width"] - 1
+    net_in = audio[:, None, :-1]                               # model.py:267-269 (B,1,T-1)
+    U = upsample(lc, [P["wavenet/upsample%d/kernel" % i] for i in range(len(cfg["upsample_factor"]))], cfg["upsample_factor"])
+    y = network(P, cfg, net_in, U, gc_ids)
+    target = audio[:, rf:, None]                                            # model.py:286
+    return mol_loss(y, target).mean()
+
+
+def loss_and_grads(tensors, cfg, audio, lc, gc_ids, dtype=torch.float32):
+    P = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in tensors.items()}
+    loss = loss_fn(P, cfg, torch.tensor(audio, dtype=dtype), torch.tensor(lc, dtype=dtype), torch.tensor(np.asarray(gc_ids)))
+    loss.backward()
+    return float(loss.item()), {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape, np.float32)) for k, v in P.items()}
+
+
+def adam_ema(p, g, m, v, ema, t, lr, b1=0.9, b2=0.999, eps=1e-8, decay=0.9999):
+    """tf.train.AdamOptimizer._apply_dense + ExponentialMovingAverage.apply (no num_updates) in float64 numpy"""
+    lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    p = p - lr_t * m / (np.sqrt(v) + eps)
+    ema = ema - (1 - decay) * (ema - p)
+    return p, m, v, ema
