@@ -78,26 +78,28 @@ __global__ void tr_up_bwd_in_kernel(const float* K, const float* dout, float* di
         din[i] = acc;
     }
 }
-__global__ void tr_up_bwd_k_kernel(const float* in, const float* dout, float* dK, long long rows_in, int f, int Lc)
+__global__ __launch_bounds__(256) void tr_up_bwd_k_kernel(const float* in, const float* dout, float* part, long long rows_in, int f, int Lc, int nchunk)
 {
-    // one block per tap a; reduce over (row, m)
-    const int a = blockIdx.x;
+    // block (chunk, tap a): partial sums over its slab of input rows -> part[chunk][a*2 + j]
+    const int a = blockIdx.y;
+    const long long per = (rows_in + nchunk - 1) / nchunk;
+    const long long r0 = (long long)blockIdx.x * per, r1 = r0 + per < rows_in ? r0 + per : rows_in;
     float s0 = 0.0f, s1 = 0.0f;
-    for (long long i = threadIdx.x; i < rows_in * Lc; i += blockDim.x) {
+    for (long long i = r0 * Lc + threadIdx.x; i < r1 * Lc; i += 256) {
         const int m = (int)(i % Lc);
         const long long bt = i / Lc;
         const float d = dout[(bt * f + a) * Lc + m];
         s0 += d * in[i];
         if (m > 0) s1 += d * in[i - 1];
     }
-    __shared__ float r0[256], r1[256];
-    r0[threadIdx.x] = s0; r1[threadIdx.x] = s1;
+    __shared__ float r0s[256], r1s[256];
+    r0s[threadIdx.x] = s0; r1s[threadIdx.x] = s1;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) { r0[threadIdx.x] += r0[threadIdx.x + st]; r1[threadIdx.x] += r1[threadIdx.x + st]; }
+        if ((int)threadIdx.x < st) { r0s[threadIdx.x] += r0s[threadIdx.x + st]; r1s[threadIdx.x] += r1s[threadIdx.x + st]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { dK[a * 2] = r0[0]; dK[a * 2 + 1] = r1[0]; }
+    if (threadIdx.x == 0) { part[(long long)blockIdx.x * 2 * f + a * 2] = r0s[0]; part[(long long)blockIdx.x * 2 * f + a * 2 + 1] = r1s[0]; }
 }
 
 // causal layer input unfolded: xunf[(b,t)][k] = in[b, t-(ifw-1)+k]  (0 before the start)   model.py:41-46
@@ -155,24 +157,24 @@ __global__ void tr_add_bias32_kernel(const float* x, const float* bias, float* x
     GRID_STRIDE(i, n) xn[i] = x[i] + (bias ? bias[i & 31] : 0.0f);
 }
 // compact the last `ow` positions of every batch: zc[(b,p)] = z[(b, Tn-ow+p)]   (model.py:94-95 skip_cut)
-__global__ void tr_compact_kernel(const float* z, float* zc, int B, int Tn, int ow)
+__global__ void tr_compact_kernel(const float* z, float* zc, int B, int Tn, int ow, int ldz)
 {
     const long long total = (long long)B * ow * 32;
     GRID_STRIDE(i, total) {
         const int j = (int)(i & 31);
         const long long r = i >> 5;
         const int p = (int)(r % ow), b = (int)(r / ow);
-        zc[i] = z[((long long)b * Tn + (Tn - ow + p)) * 32 + j];
+        zc[r * ldz + j] = z[((long long)b * Tn + (Tn - ow + p)) * 32 + j];
     }
 }
-__global__ void tr_scatter_add_kernel(const float* dzc, float* dz, int B, int Tn, int ow)
+__global__ void tr_scatter_add_kernel(const float* dzc, float* dz, int B, int Tn, int ow, int ldz)
 {
     const long long total = (long long)B * ow * 32;
     GRID_STRIDE(i, total) {
         const int j = (int)(i & 31);
         const long long r = i >> 5;
         const int p = (int)(r % ow), b = (int)(r / ow);
-        dz[((long long)b * Tn + (Tn - ow + p)) * 32 + j] += dzc[i];
+        dz[((long long)b * Tn + (Tn - ow + p)) * 32 + j] += dzc[r * ldz + j];
     }
 }
 // y[r][c] = relu(x[r][c] + bias_sum[c])  (bias_sum = one or several bias vectors added together)
@@ -190,25 +192,115 @@ __global__ void tr_bias_add_kernel(float* x, const float* bias, int C, long long
 __global__ void tr_relu_bwd_kernel(float* dx, const float* y, long long n) { GRID_STRIDE(i, n) if (!(y[i] > 0.0f)) dx[i] = 0.0f; }
 __global__ void tr_fill_kernel(float* p, float v, long long n) { GRID_STRIDE(i, n) p[i] = v; }
 __global__ void tr_add_kernel(float* a, const float* b, long long n) { GRID_STRIDE(i, n) a[i] += b[i]; }
-// column sums: out[c] = sum_r x[r][c]; grid = C/64 blocks x 256 threads (4 row groups), C multiple of... any (guarded)
-__global__ void tr_colsum_kernel(const float* x, long long rows, int C, float* out)
+// column sums, two deterministic stages.  stage 1: block (chunk, col tile, segment) sums its row chunk of segment z
+// (segments = consecutive `rows`-row slabs, e.g. one per batch entry) into part[(z*nchunk + chunk)*C + c].
+__global__ __launch_bounds__(256) void tr_colsum_partial_kernel(const float* x, long long rows, int C, int ldx, int nchunk, float* part)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    const long long per = (rows + nchunk - 1) / nchunk;
+    const long long r0 = (long long)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+    const float* xs = x + (long long)blockIdx.z * rows * ldx;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (c < C) {
+        long long r = r0 + grp;
+        for (; r + 4 < r1; r += 8) { s0 += xs[r * ldx + c]; s1 += xs[(r + 4) * ldx + c]; }
+        if (r < r1) s0 += xs[r * ldx + c];
+    }
+    __shared__ float sh[256];
+    sh[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < C)
+        part[((long long)blockIdx.z * nchunk + blockIdx.x) * C + c] = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+}
+// stage 2: out[z*ldo + c] = sum over chunks (fixed order: 4 interleaved partial sums, then pairwise); block = 64 outputs x 4 groups
+__global__ __launch_bounds__(256) void tr_colsum_final_kernel(const float* part, int nchunk, int C, int nseg, float* out, int ldo)
+{
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    const int z = i / C, c = i % C;
     float s = 0.0f;
-    if (c < C) for (long long r = grp; r < rows; r += 4) s += x[r * C + c];
+    if (i < nseg * C)
+        for (int k = grp; k < nchunk; k += 4) s += part[((long long)z * nchunk + k) * C + c];
     __shared__ float sh[256];
     sh[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x < 64 && c < C) out[c] = sh[threadIdx.x] + sh[threadIdx.x + 64] + sh[threadIdx.x + 128] + sh[threadIdx.x + 192];
+    if (threadIdx.x < 64 && i < nseg * C) out[(long long)z * ldo + c] = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
 }
-// per-batch sums over time: out[b][c] = sum_t x[(b,t)][c]
-__global__ void tr_batchsum_kernel(const float* x, int Tn, int C, float* out)
+
+// Tall-skinny weight-gradient contraction on the f32 matrix cores:  C[m][n] = sum_k A[k][m] * B[k][n],  K ~ 5e5, M,N <= 96.
+// v_mfma_f32_32x32x2_f32: lane l feeds A[k = l>>5][m = l&31] and B[k = l>>5][n = l&31] -- for row-major (k, channel)
+// activations that is two coalesced 128-byte rows per operand, no transposition or LDS staging needed.
+// Block = 4 waves; wave w owns k rows {2*(4*i + w), +1} of its chunk; per-wave partial tiles go to part[...] and are summed
+// in a fixed order by tr_tn_reduce_kernel (deterministic, no atomics).  grid = (chunks, m-blocks, n-blocks).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void tr_tn_partial_kernel(const float* A, int lda, const float* B, int ldb, long long K, int M, int N,
+                                                            long long rows_per_chunk, float* part)
 {
-    const int b = blockIdx.x, c = threadIdx.x;
-    if (c >= C) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.y * 32 + (lane & 31), n = blockIdx.z * 32 + (lane & 31);
+    const bool mok = m < M, nok = n < N;
+    const long long k0 = (long long)blockIdx.x * rows_per_chunk;
+    const long long k1 = k0 + rows_per_chunk < K ? k0 + rows_per_chunk : K;
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float* ap = A + m;
+    const float* bp = B + n;
+#pragma unroll 8
+    for (long long k = k0 + 2 * wave + (lane >> 5); k < k1 + (lane >> 5); k += 8) {
+        const bool kok = k < k1;
+        const float a = (mok && kok) ? ap[k * lda] : 0.0f;
+        const float b = (nok && kok) ? bp[k * ldb] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    // C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  The four waves' tiles are summed through LDS (fixed order).
+    __shared__ float red[4][32][33];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][lane & 31] = acc[r];
+    __syncthreads();
+    const int Mp = gridDim.y * 32, Np = gridDim.z * 32;
+    float* out = part + ((long long)blockIdx.x * Mp + blockIdx.y * 32) * Np + blockIdx.z * 32;
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        const int row = i >> 5, col = i & 31;
+        out[(long long)row * Np + col] = (red[0][row][col] + red[1][row][col]) + (red[2][row][col] + red[3][row][col]);
+    }
+}
+// C[m][n] = sum over slabs (fixed order: 4 interleaved partial sums, then pairwise); block = 64 outputs x 4 slab groups
+__global__ __launch_bounds__(256) void tr_tn_reduce_kernel(const float* part, int nslab, int Mp, int Np, int M, int N, float* C, int ldc)
+{
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     float s = 0.0f;
-    for (int t = 0; t < Tn; ++t) s += x[((long long)b * Tn + t) * C + c];
-    out[b * C + c] = s;
+    const int m = i / N, n = i % N;
+    if (i < M * N)
+        for (int k = grp; k < nslab; k += 4) s += part[((long long)k * Mp + m) * Np + n];
+    __shared__ float sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && i < M * N) C[(long long)m * ldc + n] = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+}
+// training-time weight views: per layer [tap0 (32x64) = wf[0]|wg[0]] [tap1 (32x64)] [lc (L x 64) = lcf|lcg] [gc (G x 64)] and the
+// stacked skip kernel (NL*32 x S).  dir 0: canonical -> views, dir 1: views (gradients) -> canonical.
+__global__ void tr_views_kernel(float* canon, float* views, float* wsall, int NL, long long c_layer0, long long lstride, long long o_wf, long long o_wg,
+                                long long o_lcf, long long o_lcg, long long o_gcf, long long o_gcg, long long o_ws, int L, int G, int S, int dir)
+{
+    const long long vstride = 64LL * (64 + L + G);
+    const long long per = vstride + 32LL * S;
+    GRID_STRIDE(i, per * NL) {
+        const int l = (int)(i / per);
+        long long q = i % per;
+        float* cl = canon + c_layer0 + l * lstride;
+        float* cp; float* vp;
+        if (q < vstride) {
+            vp = views + l * vstride + q;
+            const int col = (int)(q & 63), half = col >> 5, j = col & 31;
+            const long long row = q >> 6;
+            if (row < 64) cp = cl + (half ? o_wg : o_wf) + row * 32 + j;                       // (2,32,32): tap*1024 + in*32 + out
+            else if (row < 64 + L) cp = cl + (half ? o_lcg : o_lcf) + (row - 64) * 32 + j;
+            else cp = cl + (half ? o_gcg : o_gcf) + (row - 64 - L) * 32 + j;
+        } else {
+            q -= vstride;
+            vp = wsall + (long long)l * 32 * S + q;
+            cp = cl + o_ws + q;
+        }
+        if (dir == 0) *vp = *cp; else *cp = *vp;
+    }
 }
 // dlcp[(b,tt)][c] = dpre[(b, tt+o)][c] for tt+o < Tn else 0
 __global__ void tr_shift_lc_kernel(const float* dpre, float* dlcp, int B, int Tn, int T, int o)
@@ -351,22 +443,23 @@ extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch,
     for (int i = 0; i < d.n_upsample; ++i) { h->c_up[i] = c; c += (long long)d.upsample_factor[i] * 2; }
     h->nparams = c;
     h->blas = nullptr;
-    // workspace
+    // workspace (generous upper bound of what loss_grad carves, each piece rounded up to 64 floats)
     const long long Rr = (long long)batch * h->Tn, RT = (long long)batch * n_samples, RO = (long long)batch * h->ow;
     long long f = 0;
-    f += RT * h->L * 3;                         // upsample stages (ping, pong, final U) -- generous
-    f += RT * h->L;                             // dU
+    f += RT * h->L * 2;                         // upsample stages
+    f += RT * h->L * 2;                         // dU ping/pong
     f += Rr * h->ifw;                           // xunf
     f += Rr * 32 * (h->NL + 1);                 // X[l]
     f += Rr * 32 * 3 * h->NL;                   // TH, SG, Z per layer
-    f += RO * 32 * h->NL;                       // Zc per layer
-    f += Rr * 64 * 2;                           // PRE / dPRE, LCP / dLCP (RT rows >= Rr rows: sized below)
-    f += RT * 64 * 2;
+    f += RO * 32 * h->NL * 2;                   // ZCall, dZCall
+    f += Rr * 64 + RT * 64;                     // PRE / dPRE, LCP / dLCP
     f += Rr * 32 * 3;                           // dX ping/pong, dZ
-    f += RO * 32;                               // dZc
-    f += RO * h->S * 3;                         // SK/H1, C1/H2, dSK/dC1
+    f += RO * h->S * 3;                         // SK/H1, C1/H2, dC1
     f += RO * h->O * 2;                         // Y, dY
-    f += (long long)batch * 64 * (h->NL + 2) + (long long)batch * h->G * 2 + 4096;
+    f += (long long)batch * 64 * (h->NL + 2) + (long long)batch * h->G * 2;
+    f += 2 * ((long long)h->NL * (64LL * (64 + h->L + h->G) + 32LL * h->S));   // weight views + their gradients
+    f += 512LL * 96 * 64 + 1024LL * 512;        // reduction partials
+    f += 64 * 64;                               // rounding slack
     h->ws_floats = f;
     *out = h;
     return TWV_OK;
@@ -409,22 +502,45 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
     float* dUa = take(RT * L); float* dUb = take(RT * L);
     float* xunf = take(Rr * h->ifw);
     float** X = new float*[NL + 1];
-    float **TH = new float*[NL], **SG = new float*[NL], **Z = new float*[NL], **ZC = new float*[NL];
+    float **TH = new float*[NL], **SG = new float*[NL], **Z = new float*[NL];
     for (int l = 0; l <= NL; ++l) X[l] = take(Rr * 32);
-    for (int l = 0; l < NL; ++l) { TH[l] = take(Rr * 32); SG[l] = take(Rr * 32); Z[l] = take(Rr * 32); ZC[l] = take(RO * 32); }
+    for (int l = 0; l < NL; ++l) { TH[l] = take(Rr * 32); SG[l] = take(Rr * 32); Z[l] = take(Rr * 32); }
+    const int ZW = NL * 32;                                  // stacked skip input: ZC[(b,p)][l*32 + j]
+    float* ZC = take(RO * ZW); float* dZC = take(RO * ZW);
     float* PRE = take(Rr * 64);
     float* LCP = take(RT * 64);
-    float* dXa = take(Rr * 32); float* dXb = take(Rr * 32); float* dZ = take(Rr * 32); float* dZc = take(RO * 32);
+    float* dXa = take(Rr * 32); float* dXb = take(Rr * 32); float* dZ = take(Rr * 32);
     float* SK = take(RO * S); float* C1 = take(RO * S); float* dS = take(RO * S);
     float* Y = take(RO * O); float* dY = take(RO * O);
     float* emb = take((long long)B * G); float* demb = take((long long)B * G);
     float* GCP = take((long long)B * 64 * NL); float* dGCP = take((long long)B * 64);
+    const long long vstride = 64LL * (64 + L + G);
+    float* WV = take(vstride * NL); float* WS = take((long long)ZW * S);       // weight views
+    float* GV = take(vstride * NL); float* GS = take((long long)ZW * S);       // gradient views
+    float* part = take(512LL * 96 * 64 + 1024LL * 512);
     int rc = TWV_OK;
 #define K1(kern, n, ...) hipLaunchKernelGGL(kern, dim3(tg(n)), dim3(256), 0, st, __VA_ARGS__)
 #define LP(l) (P + h->c_layer0 + (long long)(l) * h->c_lstride)
 #define LG(l) (Gd + h->c_layer0 + (long long)(l) * h->c_lstride)
+    // out[seg][c] = column sums of x (nseg slabs of `rows` rows); deterministic two-stage reduction
+    auto colsum = [&](const float* x, long long rows, int C, int ldx, int nseg, float* out, int ldo) {
+        int nchunk = (int)(rows / 256); const int cap = nseg > 8 ? 32 : 256; nchunk = nchunk < 1 ? 1 : (nchunk > cap ? cap : nchunk);
+        hipLaunchKernelGGL(tr_colsum_partial_kernel, dim3(nchunk, (C + 63) / 64, nseg), dim3(256), 0, st, x, rows, C, ldx, nchunk, part);
+        hipLaunchKernelGGL(tr_colsum_final_kernel, dim3((nseg * C + 63) / 64), dim3(256), 0, st, part, nchunk, C, nseg, out, ldo);
+    };
+    // C[M x N](ldc) = A^T B over K rows (tall-skinny weight gradient); optional second output for columns [N, 2N) (filter|gate split)
+    auto wgrad = [&](const float* A, int lda, const float* Bm, int ldb, long long K, int M, int N, float* C, int ldc) {
+        int chunks = (int)(K / 1024); chunks = chunks < 1 ? 1 : (chunks > 256 ? 256 : chunks);
+        long long rpc = (K + chunks - 1) / chunks; rpc = (rpc + 7) / 8 * 8;
+        chunks = (int)((K + rpc - 1) / rpc);
+        const int mb = (M + 31) / 32, nb = (N + 31) / 32;
+        hipLaunchKernelGGL(tr_tn_partial_kernel, dim3(chunks, mb, nb), dim3(256), 0, st, A, lda, Bm, ldb, K, M, N, rpc, part);
+        hipLaunchKernelGGL(tr_tn_reduce_kernel, dim3((M * N + 63) / 64), dim3(256), 0, st, part, chunks, mb * 32, nb * 32, M, N, C, ldc);
+    };
     do {
         // ================= forward =================
+        K1(tr_views_kernel, (vstride + 32LL * S) * NL, const_cast<float*>(P), WV, WS, NL, h->c_layer0, h->c_lstride, h->lo.wf, h->lo.wg, h->lo.lcf, h->lo.lcg,
+           h->lo.gcf, h->lo.gcg, h->lo.ws, L, G, S, 0);
         for (int i = 0; i < d.n_upsample; ++i)     // model.py:276 create_upsample
             K1(tr_up_fwd_kernel, (long long)B * upT[i + 1] * L, P + h->c_up[i], ups[i], ups[i + 1], (long long)B * upT[i + 1] * L, d.upsample_factor[i], L);
         K1(tr_gather_emb_kernel, (long long)B * G, P + h->c_gcemb, gc_ids, emb, B, G);   // model.py:197-198
@@ -433,27 +549,25 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         for (int l = 0; l < NL && !rc; ++l) {
             const int dl = d.dilations[l], o = h->off[l + 1];
             const float* Lp = LP(l);
+            const float* Wv = WV + l * vstride;                 // tap0 | tap1 | lc | gc views, 64 columns = filter|gate
             // model.py:68-69 conv_filter | conv_gate, taps x[t-d] and x[t]  (rows d .. R-1)
             const int M = (int)(Rr - dl);
-            rc |= gemm_rm(bl, false, false, M, 32, 32, 1.f, X[l], 32, Lp + h->lo.wf, 32, 0.f, PRE + (long long)dl * 64, 64);
-            rc |= gemm_rm(bl, false, false, M, 32, 32, 1.f, X[l] + (long long)dl * 32, 32, Lp + h->lo.wf + 1024, 32, 1.f, PRE + (long long)dl * 64, 64);
-            rc |= gemm_rm(bl, false, false, M, 32, 32, 1.f, X[l], 32, Lp + h->lo.wg, 32, 0.f, PRE + (long long)dl * 64 + 32, 64);
-            rc |= gemm_rm(bl, false, false, M, 32, 32, 1.f, X[l] + (long long)dl * 32, 32, Lp + h->lo.wg + 1024, 32, 1.f, PRE + (long long)dl * 64 + 32, 64);
+            rc |= gemm_rm(bl, false, false, M, 64, 32, 1.f, X[l], 32, Wv, 64, 0.f, PRE + (long long)dl * 64, 64);
+            rc |= gemm_rm(bl, false, false, M, 64, 32, 1.f, X[l] + (long long)dl * 32, 32, Wv + 32 * 64, 64, 1.f, PRE + (long long)dl * 64, 64);
             // model.py:71-83 gc / lc 1x1 projections
             float* gcp = GCP + (long long)l * B * 64;
-            rc |= gemm_rm(bl, false, false, B, 32, G, 1.f, emb, G, Lp + h->lo.gcf, 32, 0.f, gcp, 64);
-            rc |= gemm_rm(bl, false, false, B, 32, G, 1.f, emb, G, Lp + h->lo.gcg, 32, 0.f, gcp + 32, 64);
-            rc |= gemm_rm(bl, false, false, (int)RT, 32, L, 1.f, U, L, Lp + h->lo.lcf, 32, 0.f, LCP, 64);
-            rc |= gemm_rm(bl, false, false, (int)RT, 32, L, 1.f, U, L, Lp + h->lo.lcg, 32, 0.f, LCP + 32, 64);
+            rc |= gemm_rm(bl, false, false, B, 64, G, 1.f, emb, G, Wv + (64 + L) * 64, 64, 0.f, gcp, 64);
+            rc |= gemm_rm(bl, false, false, (int)RT, 64, L, 1.f, U, L, Wv + 64 * 64, 64, 0.f, LCP, 64);
             K1(tr_gate_fwd_kernel, Rr * 32, PRE, ub ? Lp + h->lo.bf : nullptr, ub ? Lp + h->lo.bg : nullptr, gcp, LCP, TH[l], SG[l], Z[l], B, Tn, T, o);
-            // model.py:89,98-101 dense + residual ; model.py:94-96 skip on the last `ow` positions
+            // model.py:89,98-101 dense + residual ; model.py:94-96 skip input = the last `ow` positions
             K1(tr_add_bias32_kernel, Rr * 32, X[l], ub ? Lp + h->lo.bd : nullptr, X[l + 1], Rr * 32);
             rc |= gemm_rm(bl, false, false, (int)Rr, 32, 32, 1.f, Z[l], 32, Lp + h->lo.wd, 32, 1.f, X[l + 1], 32);
-            K1(tr_compact_kernel, RO * 32, Z[l], ZC[l], B, Tn, ow);
-            rc |= gemm_rm(bl, false, false, (int)RO, S, 32, 1.f, ZC[l], 32, Lp + h->lo.ws, S, l == 0 ? 0.f : 1.f, SK, S);
+            K1(tr_compact_kernel, RO * 32, Z[l], ZC + l * 32, B, Tn, ow, ZW);
         }
         if (rc) break;
-        // model.py:150-165 postprocessing: sum(skips) incl. their biases -> relu -> 1x1 -> relu -> 1x1
+        // model.py:94-96,150-165: sum over layers of the skip 1x1 convs == ONE GEMM against the stacked skip kernels, then
+        // (+ all skip biases) relu -> 1x1 -> relu -> 1x1
+        if ((rc = gemm_rm(bl, false, false, (int)RO, S, ZW, 1.f, ZC, ZW, WS, S, 0.f, SK, S))) break;
         K1(tr_bias_relu_kernel, RO * S, SK, ub ? LP(0) + h->lo.bs : nullptr, ub ? NL : 0, h->c_lstride, nullptr, S, RO * S);
         if ((rc = gemm_rm(bl, false, false, (int)RO, S, S, 1.f, SK, S, P + h->c_w1, S, 0.f, C1, S))) break;
         K1(tr_bias_relu_kernel, RO * S, C1, nullptr, 0, 0, ub ? P + h->c_b1 : nullptr, S, RO * S);
@@ -463,14 +577,21 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         K1(tr_mol_loss_kernel, RO, Y, audio, B, T, ow, rf, nr, 1.0f / (float)RO, loss, dY);
         // ================= backward =================
         rc |= gemm_rm(bl, true, false, S, O, (int)RO, 1.f, C1, S, dY, O, 0.f, Gd + h->c_w2, O);                 // dW2 = H2^T dY
-        if (ub) hipLaunchKernelGGL(tr_colsum_kernel, dim3((O + 63) / 64), dim3(256), 0, st, dY, RO, O, Gd + h->c_b2);
+        if (ub) colsum(dY, RO, O, O, 1, Gd + h->c_b2, O);
         rc |= gemm_rm(bl, false, true, (int)RO, S, O, 1.f, dY, O, P + h->c_w2, O, 0.f, dS, S);                   // dH2
         K1(tr_relu_bwd_kernel, RO * S, dS, C1, RO * S);
         rc |= gemm_rm(bl, true, false, S, S, (int)RO, 1.f, SK, S, dS, S, 0.f, Gd + h->c_w1, S);                  // dW1 = H1^T dC1
-        if (ub) hipLaunchKernelGGL(tr_colsum_kernel, dim3((S + 63) / 64), dim3(256), 0, st, dS, RO, S, Gd + h->c_b1);
+        if (ub) colsum(dS, RO, S, S, 1, Gd + h->c_b1, S);
         rc |= gemm_rm(bl, false, true, (int)RO, S, S, 1.f, dS, S, P + h->c_w1, S, 0.f, C1, S);                   // dH1 -> C1 buffer
         K1(tr_relu_bwd_kernel, RO * S, C1, SK, RO * S);                                                           // dSK
         float* dSK = C1;
+        // all skip convs at once: dWs (stacked) = ZC^T dSK ; dZC = dSK WS^T ; dbs (identical for every layer) = colsum(dSK)
+        rc |= gemm_rm(bl, true, false, ZW, S, (int)RO, 1.f, ZC, ZW, dSK, S, 0.f, GS, S);
+        if (ub) {
+            colsum(dSK, RO, S, S, 1, LG(0) + h->lo.bs, S);
+            for (int l = 1; l < NL; ++l) HIPCHK(hipMemcpyAsync(LG(l) + h->lo.bs, LG(0) + h->lo.bs, (size_t)S * 4, hipMemcpyDeviceToDevice, st));
+        }
+        rc |= gemm_rm(bl, false, true, (int)RO, ZW, S, 1.f, dSK, S, WS, S, 0.f, dZC, ZW);
         if (rc) break;
         float* dXn = dXa; float* dXc = dXb;
         K1(tr_fill_kernel, Rr * 32, dXn, 0.0f, Rr * 32);
@@ -480,57 +601,53 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             const int dl = d.dilations[l], o = h->off[l + 1];
             const float* Lp = LP(l);
             float* Lg = LG(l);
+            const float* Wv = WV + l * vstride;
+            float* Gv = GV + l * vstride;
             const int M = (int)(Rr - dl);
-            // skip 1x1: dWs, dbs, dZc ; dense 1x1: dWd, dbd, dZ
-            rc |= gemm_rm(bl, true, false, 32, S, (int)RO, 1.f, ZC[l], 32, dSK, S, 0.f, Lg + h->lo.ws, S);
-            if (ub) hipLaunchKernelGGL(tr_colsum_kernel, dim3((S + 63) / 64), dim3(256), 0, st, dSK, RO, S, Lg + h->lo.bs);
-            rc |= gemm_rm(bl, false, true, (int)RO, 32, S, 1.f, dSK, S, Lp + h->lo.ws, S, 0.f, dZc, 32);
-            rc |= gemm_rm(bl, true, false, 32, 32, (int)Rr, 1.f, Z[l], 32, dXn, 32, 0.f, Lg + h->lo.wd, 32);
-            if (ub) hipLaunchKernelGGL(tr_colsum_kernel, dim3(1), dim3(256), 0, st, dXn, Rr, 32, Lg + h->lo.bd);
+            // dense 1x1: dWd, dbd, dZ (+ the skip path's share on the last `ow` positions)
+            wgrad(Z[l], 32, dXn, 32, Rr, 32, 32, Lg + h->lo.wd, 32);
+            if (ub) colsum(dXn, Rr, 32, 32, 1, Lg + h->lo.bd, 32);
             rc |= gemm_rm(bl, false, true, (int)Rr, 32, 32, 1.f, dXn, 32, Lp + h->lo.wd, 32, 0.f, dZ, 32);
-            K1(tr_scatter_add_kernel, RO * 32, dZc, dZ, B, Tn, ow);
+            K1(tr_scatter_add_kernel, RO * 32, dZC + l * 32, dZ, B, Tn, ow, ZW);
             // gated unit
             K1(tr_gate_bwd_kernel, Rr * 32, dZ, TH[l], SG[l], PRE, B, Tn, o);
             float* dPRE = PRE;
-            if (ub) {   // conv biases: first / second 32 columns
-                hipLaunchKernelGGL(tr_colsum_kernel, dim3(1), dim3(256), 0, st, dPRE, Rr, 64, dGCP);
-                HIPCHK(hipMemcpyAsync(Lg + h->lo.bf, dGCP, 32 * 4, hipMemcpyDeviceToDevice, st));
-                HIPCHK(hipMemcpyAsync(Lg + h->lo.bg, dGCP + 32, 32 * 4, hipMemcpyDeviceToDevice, st));
+            // gc: dGCP[b] = sum_t dPRE[b,t] ; conv biases = sum_b dGCP[b] ; dWgc = emb^T dGCP ; demb += dGCP Wgc^T
+            colsum(dPRE, Tn, 64, 64, B, dGCP, 64);
+            if (ub) {
+                colsum(dGCP, B, 64, 64, 1, part + 1024LL * 512 + 4096, 64);     // 64 sums parked behind the partials
+                HIPCHK(hipMemcpyAsync(Lg + h->lo.bf, part + 1024LL * 512 + 4096, 32 * 4, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(Lg + h->lo.bg, part + 1024LL * 512 + 4096 + 32, 32 * 4, hipMemcpyDeviceToDevice, st));
             }
-            // gc: dGCP[b] = sum_t dPRE ; dWgc = emb^T dGCP ; demb += dGCP Wgc^T
-            hipLaunchKernelGGL(tr_batchsum_kernel, dim3(B), dim3(64), 0, st, dPRE, Tn, 64, dGCP);
-            rc |= gemm_rm(bl, true, false, G, 32, B, 1.f, emb, G, dGCP, 64, 0.f, Lg + h->lo.gcf, 32);
-            rc |= gemm_rm(bl, true, false, G, 32, B, 1.f, emb, G, dGCP + 32, 64, 0.f, Lg + h->lo.gcg, 32);
-            rc |= gemm_rm(bl, false, true, B, G, 32, 1.f, dGCP, 64, Lp + h->lo.gcf, 32, 1.f, demb, G);
-            rc |= gemm_rm(bl, false, true, B, G, 32, 1.f, dGCP + 32, 64, Lp + h->lo.gcg, 32, 1.f, demb, G);
+            rc |= gemm_rm(bl, true, false, G, 64, B, 1.f, emb, G, dGCP, 64, 0.f, Gv + (64 + L) * 64, 64);
+            rc |= gemm_rm(bl, false, true, B, G, 64, 1.f, dGCP, 64, Wv + (64 + L) * 64, 64, 1.f, demb, G);
             // lc: dLCP = shifted dPRE ; dWlc = U^T dLCP ; dU += dLCP Wlc^T
             K1(tr_shift_lc_kernel, RT * 64, dPRE, LCP, B, Tn, T, o);
-            rc |= gemm_rm(bl, true, false, L, 32, (int)RT, 1.f, U, L, LCP, 64, 0.f, Lg + h->lo.lcf, 32);
-            rc |= gemm_rm(bl, true, false, L, 32, (int)RT, 1.f, U, L, LCP + 32, 64, 0.f, Lg + h->lo.lcg, 32);
-            rc |= gemm_rm(bl, false, true, (int)RT, L, 32, 1.f, LCP, 64, Lp + h->lo.lcf, 32, 1.f, dUa, L);
-            rc |= gemm_rm(bl, false, true, (int)RT, L, 32, 1.f, LCP + 32, 64, Lp + h->lo.lcg, 32, 1.f, dUa, L);
+            wgrad(U, L, LCP, 64, RT, L, 64, Gv + 64 * 64, 64);
+            rc |= gemm_rm(bl, false, true, (int)RT, L, 64, 1.f, LCP, 64, Wv + 64 * 64, 64, 1.f, dUa, L);
             // conv weights: tap 0 pairs dPRE[r] with X[r-d], tap 1 with X[r]
-            rc |= gemm_rm(bl, true, false, 32, 32, M, 1.f, X[l], 32, dPRE + (long long)dl * 64, 64, 0.f, Lg + h->lo.wf, 32);
-            rc |= gemm_rm(bl, true, false, 32, 32, M, 1.f, X[l] + (long long)dl * 32, 32, dPRE + (long long)dl * 64, 64, 0.f, Lg + h->lo.wf + 1024, 32);
-            rc |= gemm_rm(bl, true, false, 32, 32, M, 1.f, X[l], 32, dPRE + (long long)dl * 64 + 32, 64, 0.f, Lg + h->lo.wg, 32);
-            rc |= gemm_rm(bl, true, false, 32, 32, M, 1.f, X[l] + (long long)dl * 32, 32, dPRE + (long long)dl * 64 + 32, 64, 0.f, Lg + h->lo.wg + 1024, 32);
+            wgrad(X[l], 32, dPRE + (long long)dl * 64, 64, M, 32, 64, Gv, 64);
+            wgrad(X[l] + (long long)dl * 32, 32, dPRE + (long long)dl * 64, 64, M, 32, 64, Gv + 32 * 64, 64);
             // dX_l = dX_{l+1} (residual) + taps
             HIPCHK(hipMemcpyAsync(dXc, dXn, (size_t)Rr * 32 * 4, hipMemcpyDeviceToDevice, st));
-            rc |= gemm_rm(bl, false, true, M, 32, 32, 1.f, dPRE + (long long)dl * 64, 64, Lp + h->lo.wf, 32, 1.f, dXc, 32);
-            rc |= gemm_rm(bl, false, true, M, 32, 32, 1.f, dPRE + (long long)dl * 64 + 32, 64, Lp + h->lo.wg, 32, 1.f, dXc, 32);
-            rc |= gemm_rm(bl, false, true, M, 32, 32, 1.f, dPRE + (long long)dl * 64, 64, Lp + h->lo.wf + 1024, 32, 1.f, dXc + (long long)dl * 32, 32);
-            rc |= gemm_rm(bl, false, true, M, 32, 32, 1.f, dPRE + (long long)dl * 64 + 32, 64, Lp + h->lo.wg + 1024, 32, 1.f, dXc + (long long)dl * 32, 32);
+            rc |= gemm_rm(bl, false, true, M, 32, 64, 1.f, dPRE + (long long)dl * 64, 64, Wv, 64, 1.f, dXc, 32);
+            rc |= gemm_rm(bl, false, true, M, 32, 64, 1.f, dPRE + (long long)dl * 64, 64, Wv + 32 * 64, 64, 1.f, dXc + (long long)dl * 32, 32);
             float* tsw = dXn; dXn = dXc; dXc = tsw;
         }
         if (rc) break;
-        // causal layer, gc embedding table, upsampler
-        rc |= gemm_rm(bl, true, false, h->ifw, 32, (int)Rr, 1.f, xunf, h->ifw, dXn, 32, 0.f, Gd + h->c_causal, 32);
+        // causal layer, gc embedding table, upsampler, and the gradient views back into the canonical order
+        wgrad(xunf, h->ifw, dXn, 32, Rr, h->ifw, 32, Gd + h->c_causal, 32);
         K1(tr_scatter_emb_kernel, (long long)B * G, demb, gc_ids, Gd + h->c_gcemb, B, G);
+        K1(tr_views_kernel, (vstride + 32LL * S) * NL, Gd, GV, GS, NL, h->c_layer0, h->c_lstride, h->lo.wf, h->lo.wg, h->lo.lcf, h->lo.lcg,
+           h->lo.gcf, h->lo.gcg, h->lo.ws, L, G, S, 1);
         {
             float* dcur = dUa; float* dnxt = dUb;
             for (int i = d.n_upsample - 1; i >= 0; --i) {
-                hipLaunchKernelGGL(tr_up_bwd_k_kernel, dim3(d.upsample_factor[i]), dim3(256), 0, st, ups[i], dcur, Gd + h->c_up[i],
-                                   (long long)B * upT[i], d.upsample_factor[i], L);
+                const long long rin = (long long)B * upT[i];
+                int nch = (int)(rin / 64); nch = nch < 1 ? 1 : (nch > 256 ? 256 : nch);
+                hipLaunchKernelGGL(tr_up_bwd_k_kernel, dim3(nch, d.upsample_factor[i]), dim3(256), 0, st, ups[i], dcur, part, rin, d.upsample_factor[i], L, nch);
+                hipLaunchKernelGGL(tr_colsum_final_kernel, dim3((2 * d.upsample_factor[i] + 63) / 64), dim3(256), 0, st, part, nch, 2 * d.upsample_factor[i], 1,
+                                   Gd + h->c_up[i], 2 * d.upsample_factor[i]);
                 if (i > 0) {
                     K1(tr_up_bwd_in_kernel, (long long)B * upT[i] * L, P + h->c_up[i], dcur, dnxt, (long long)B * upT[i] * L, d.upsample_factor[i], L);
                     float* tsw = dcur; dcur = dnxt; dnxt = tsw;
@@ -538,7 +655,7 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             }
         }
     } while (0);
-    delete[] X; delete[] TH; delete[] SG; delete[] Z; delete[] ZC;
+    delete[] X; delete[] TH; delete[] SG; delete[] Z;
     if (rc) return twv_fail(TWV_E_HIP, "rocBLAS call failed with status " + std::to_string(rc));
     HIPCHK(hipGetLastError());
     if ((long long)(w - (float*)workspace) > h->ws_floats) return twv_fail(TWV_E_INVALID, "internal: workspace overrun");

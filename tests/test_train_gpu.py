@@ -91,9 +91,10 @@ def test_adam_and_ema_update_match_tf_formulas():
         # tolerance: one fp32 update of O(lr) on O(0.05) weights -> 1e-6 absolute
         np.testing.assert_allclose(tr.params.cpu().numpy(), p, rtol=0, atol=1e-6)
         np.testing.assert_allclose(tr.ema.cpu().numpy(), ema, rtol=0, atol=1e-6)
-        np.testing.assert_allclose(tr.m.cpu().numpy(), m, rtol=1e-5, atol=1e-12)
+        # m, v: fp32 accumulators; elements where beta*m and (1-beta)*g cancel lose relative accuracy -> atol scaled to max|.|
+        np.testing.assert_allclose(tr.m.cpu().numpy(), m, rtol=1e-5, atol=1e-6 * np.abs(m).max())
         # (1 - beta2) is formed in float32 as TF's kernel does: 1 - 0.999f carries a 1.3e-5 relative rounding
-        np.testing.assert_allclose(tr.v.cpu().numpy(), v, rtol=5e-5, atol=1e-20)
+        np.testing.assert_allclose(tr.v.cpu().numpy(), v, rtol=5e-5, atol=1e-6 * np.abs(v).max())
         p = tr.params.cpu().numpy().astype(np.float64); m = tr.m.cpu().numpy().astype(np.float64)
         v = tr.v.cpu().numpy().astype(np.float64); ema = tr.ema.cpu().numpy().astype(np.float64)
     assert tr.global_step == 3
@@ -108,7 +109,7 @@ def test_training_reduces_the_loss_and_trained_weights_generate():
     gen = make_model(1, [1, 2, 4, 8, 1, 2, 4, 8], tr.ema_weights(), S=64)
     from helpers import mol_uniforms
     up = gen.create_upsample(torch.from_numpy(lc[:1]).cuda())
-    out = gen.generate(up, [int(gc[0])], np.zeros(1, np.float32), mol_uniforms(1, 300, 10))
+    out = gen.generate(up[:, :300].contiguous(), [int(gc[0])], np.zeros(1, np.float32), mol_uniforms(1, 300, 10))
     assert np.isfinite(out.cpu().numpy()).all()
 
 
