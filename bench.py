@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--groups", type=int, default=-1, help="workgroups per stream (-1 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tacotron", action="store_true", help="skip the secondary Tacotron mel-frames/s measurement")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement (configs[3], RCCL all-reduce at N>1)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle sample size in generation steps (0 = auto, about 15 s)")
     args = ap.parse_args()
 
@@ -119,6 +120,45 @@ def main():
     samples = out.cpu().numpy()
     assert np.isfinite(samples).all() and np.abs(samples).max() <= 1.0
 
+    # secondary: configs[3] teacher-forced training step, per-GPU batch 64 x 8000 (cropped to 7800) samples, data-parallel with a
+    # gradient all-reduce over RCCL when N > 1 -- every rank takes part, so it runs before the rank-0 report is assembled
+    train_res = None
+    if not args.no_train:
+        try:
+            from twvk_amd.train import WaveNetTrainer
+            tnet = WaveNetModel(64, dil, hp.filter_width, hp.residual_channels, hp.dilation_channels, hp.skip_channels,
+                                quantization_channels=hp.quantization_channels, out_channels=hp.out_channels, use_biases=hp.use_biases,
+                                scalar_input=True, initial_filter_width=hp.initial_filter_width, global_condition_channels=hp.gc_channels,
+                                global_condition_cardinality=2, local_condition_channels=hp.num_mels, upsample_factor=hp.upsample_factor,
+                                train_mode=True, device=dev)
+            trn = WaveNetTrainer(tnet, hp, sample_size=8000)
+            trn.init_weights(seed=0)                                   # identical replicas
+            TT_ = trn.sample_size
+            trng = np.random.RandomState(100 + rank)
+            taudio = torch.from_numpy((trng.rand(64, TT_) - 0.5).astype(np.float32)).to(dev)
+            tlc = torch.from_numpy((trng.randn(64, TT_ // tnet.hop_size, hp.num_mels) * 0.5).astype(np.float32)).to(dev)
+            tgc = torch.from_numpy(trng.randint(0, 2, 64).astype(np.int32)).to(dev)
+            l0 = float(trn.step(taudio, tlc, tgc).item())
+            sync_all()
+            q0 = time.perf_counter()
+            for _ in range(5):
+                tl = trn.step(taudio, tlc, tgc)
+            sync_all()
+            qdt = (time.perf_counter() - q0) / 5
+            if dist is not None:
+                tq = torch.tensor([qdt], dtype=torch.float64, device=dev)
+                dist.all_reduce(tq, op=dist.ReduceOp.MAX)
+                qdt = float(tq.item())
+            train_res = {"metric": "WaveNet training audio samples/sec (teacher-forced step: MoL loss, backward, all-reduce, Adam, EMA)",
+                         "value": world * 64 * TT_ / qdt, "unit": "audio samples/s", "steps_per_s": 1.0 / qdt, "ms_per_step": qdt * 1e3,
+                         "n_gpus": world, "scaling": "weak", "dtype": "f32",
+                         "collective": "all-reduce(sum) of one flat f32 gradient buffer, %d elements, RCCL" % trn.n_params if world > 1 else "none (1 GPU)",
+                         "config": {"workload": "configs[3]: train_vocoder.py step, 30 layers, per-GPU batch 64 x %d samples, random-init weights" % TT_},
+                         "loss_first": l0, "loss_last": float(tl.item())}
+            del trn, tnet, taudio, tlc
+        except Exception as e:       # the headline metric must still be reported
+            train_res = {"error": repr(e)}
+
     if rank == 0:
         total_samples = world * B * T * args.steps
         value = total_samples / dt
@@ -203,6 +243,8 @@ def main():
                                    "finite": bool(torch.isfinite(tmel).all().item())}
             except Exception as e:   # the headline metric must still be reported
                 res["tacotron"] = {"error": repr(e)}
+        if train_res is not None:
+            res["train"] = train_res
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -316,6 +316,83 @@ def test_two_rank_sharding_gloo(tmp_path):
     assert "OK" in outs[0]
 
 
+_TRAIN_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import twvk_amd
+from twvk_amd import weights as W
+from twvk_amd.train import allreduce_sum_
+import torch_train_ref as R
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+rank = dist.get_rank()
+# data-parallel training step (SURVEY.md 8e): every rank differentiates the mean loss of ITS crops, the flat gradient buffer is
+# summed over ranks and scaled by 1/world == the gradient of the mean loss over the global batch
+dil = [1, 2]
+specs = W.tensor_specs(len(dil), S=64)
+tensors = W.random_tensors(specs, seed=0, scale=0.1)           # identical on both ranks
+cfg = dict(dilations=dil, initial_filter_width=32, use_biases=True, upsample_factor=(5, 5, 12))
+rng = np.random.RandomState(5)
+audio = (rng.rand(4, 300) - 0.5).astype(np.float32); lc = rng.randn(4, 1, 80).astype(np.float32); gc = np.array([0, 1, 1, 0], np.int32)
+a, b = 2 * rank, 2 * rank + 2
+_, g = R.loss_and_grads(tensors, cfg, audio[a:b], lc[a:b], gc[a:b])
+flat = torch.from_numpy(W.flatten(specs, g))
+world = allreduce_sum_(flat)
+flat *= 1.0 / world
+assert world == 2
+_, gw = R.loss_and_grads(tensors, cfg, audio, lc, gc)
+whole = W.flatten(specs, gw)
+err = np.abs(flat.numpy() - whole).max() / np.abs(whole).max()
+assert err < 1e-5, err                                       # fp32 round-off of two half-batch means vs one full-batch mean
+print("OK")
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gradient_allreduce_gloo(tmp_path):
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "train_worker.py"
+    script.write_text(_TRAIN_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "OK" in outs[0] and "OK" in outs[1]
+
+
+def test_training_host_helpers():
+    import twvk_amd
+    from twvk_amd.train import exponential_decay, crop_length, allreduce_sum_
+    assert crop_length(8000, 300) == 7800 and crop_length(15000, 300) == 15000       # datafeeder_wavenet.py:41-47
+    assert exponential_decay(1e-3, 0, 300000, 0.5) == 1e-3
+    assert abs(exponential_decay(1e-3, 300000, 300000, 0.5) - 5e-4) < 1e-18              # model.py:320
+    import torch
+    t = torch.ones(3)
+    assert allreduce_sum_(t) == 1 and t.tolist() == [1.0, 1.0, 1.0]                       # no process group: identity
+
+
+def test_torch_training_reference_agrees_with_the_c_restatement(oracle):
+    """the two checkers (torch fp32 autograd model for C4, bit-exact C restatement) compute the same train-mode network"""
+    import torch
+    import torch_train_ref as R
+    dil = [1, 2, 4, 1, 2]
+    d, tensors, blob = make_case(oracle, dil, S=64)
+    rng = np.random.RandomState(1)
+    B, Tm = 2, 2
+    audio = (rng.rand(B, Tm * 300).astype(np.float32) - 0.5)
+    lc = (rng.randn(B, Tm, 80) * 0.5).astype(np.float32)
+    gc = np.array([0, 1], np.int32)
+    U = oracle.upsample(d, blob, lc)
+    raw = oracle.forward_full(d, blob, audio[:, :-1], U, gc)
+    P = {k: torch.tensor(v) for k, v in tensors.items()}
+    Ut = R.upsample(torch.tensor(lc), [P["wavenet/upsample%d/kernel" % i] for i in range(3)], (5, 5, 12))
+    assert np.abs(Ut.numpy() - U).max() < 1e-6
+    cfg = dict(dilations=dil, initial_filter_width=32, use_biases=True, upsample_factor=(5, 5, 12))
+    y = R.network(P, cfg, torch.tensor(audio[:, None, :-1]), Ut, torch.tensor(gc)).numpy()
+    assert y.shape == raw.shape and np.abs(y - raw).max() < 1e-5     # tolerance: fp32 sums in a different order
+
+
 # ---------------------------------------------------------------- Tacotron restatement (oracle/tacotron.c)
 def test_tacotron_oracle_invariants(oracle):
     d = oracle.taco_dims(max_iters=10, enc_bank=3, post_bank=2, num_freq=33)
