@@ -14,6 +14,12 @@ def __getattr__(name):
     if name in ("Tacotron", "Synthesizer"):
         from . import tacotron
         return getattr(tacotron, name)
+    if name in ("WaveNetTrainer",):
+        from .train import WaveNetTrainer
+        return WaveNetTrainer
+    if name in ("text_to_wave",):
+        from .e2e import text_to_wave
+        return text_to_wave
     if name in ("mu_law_encode", "mu_law_decode", "mu_law_expand"):
         from . import ops
         return getattr(ops, name)

@@ -393,6 +393,24 @@ def test_torch_training_reference_agrees_with_the_c_restatement(oracle):
     assert y.shape == raw.shape and np.abs(y - raw).max() < 1e-5     # tolerance: fp32 sums in a different order
 
 
+def test_attention_trim_rule():
+    """synthesizer.py:232-256: stop at the decoder step where attention has sat on the last token (<= 5 steps) or moves past it"""
+    import twvk_amd
+    from twvk_amd.e2e import attention_trim_frames, shard_utterances
+    al = np.zeros((4, 10), np.float32)                 # (T_in, T_dec): argmax path 0,0,1,1,2,3,3,3,3,3
+    for j, i in enumerate([0, 0, 1, 1, 2, 3, 3, 3, 3, 3]):
+        al[i, j] = 1.0
+    # end_idx = min(len-1, max argmax) = 3, it occurs 5 times -> max_counter 5 -> breaks at jdx = 9 (5th hit) ... the loop's
+    # `len > jdx + 1` guard ends it at the last step; r = 5 -> 5*9 + 3
+    assert attention_trim_frames(al, 4, 5) == 5 * 9 + 3
+    al2 = np.zeros((4, 10), np.float32)
+    for j, i in enumerate([0, 1, 2, 2, 2, 3, 3, 3, 3, 3]):
+        al2[i, j] = 1.0
+    # sequence_length 3 -> end_idx = 2; first hit at jdx 2, leaves token 2 for a later one after jdx 4 -> break at jdx 4
+    assert attention_trim_frames(al2, 3, 5) == 5 * 4 + 3
+    assert [shard_utterances(8, 8, r) for r in range(8)] == [(r, r + 1) for r in range(8)]
+
+
 # ---------------------------------------------------------------- Tacotron restatement (oracle/tacotron.c)
 def test_tacotron_oracle_invariants(oracle):
     d = oracle.taco_dims(max_iters=10, enc_bank=3, post_bank=2, num_freq=33)
