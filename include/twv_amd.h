@@ -148,6 +148,14 @@ int twv_tacotron_infer(const twv_tacotron* h, const void* packed, const int32_t*
                        const int32_t* speaker_ids, int batch, int t_in, void* workspace, float* mel, float* linear,
                        float* alignments, int32_t* status, void* stream);
 
+/* launch geometry (performance only, results are bit-identical): "decoder_groups" = workgroups per utterance in the decoder
+ * (0 auto, 1/2/4/8, -1 = the single-workgroup kernel). */
+int twv_tacotron_set_option(twv_tacotron* h, const char* name, int value);
+/* optional decoder phase timestamps (tuning aid): device uint64[max_iters][16], s_memtime ticks of utterance 0's workgroup at the
+ * phase boundaries of every decoder step (prenet, attention GRU, query, score, recurrence, context, projection, residual GRUs,
+ * output).  NULL disables. */
+int twv_tacotron_set_profile_buffer(twv_tacotron* h, void* dev_u64);
+
 /* ======================================= WaveNet teacher-forced training step =======================================
  * Replaces one `sess.run([net.loss, net.optimize])` of train_vocoder.py:155-181 for the scalar-input (MoL) model:
  * add_loss (wavenet/model.py:247-312: drop last sample, create_upsample, 'valid' convolution network with the

@@ -250,32 +250,37 @@ struct DecArgs {
     float* mel;            // [N][iters*R][M]
     float* align;          // [N][T][iters] or nullptr
     int32_t* status;
+    long long packed_bytes;
+    unsigned long long* prof;   // optional [iters][16] s_memtime stamps of workgroup 0 (tuning aid)
 };
 // LDS map of the decoder (float offsets)
 struct DecLds { int cat, vec, h[5], frame, ctx, part, sc, p, cp, lg, al, q; };
 
 // y_part[(nb*nchunk + ch)*64 + lane] = chunk(nb, ch) of W (tiles at wt) applied to the LDS vector at xo; tiles round-robin over
 // the 8 waves, two named buffers so that the next tile travels while the current one is used
-__device__ __forceinline__ void dec_gemv_partials(const float* wt, int K, int N, int xo, int o_part, int wave, int lane)
+__device__ __noinline__ void dec_gemv_partials(rsrc_t rs, int wt_bytes, int K, int N, int xo, int o_part, int wave, int lane)
 {
     const int nchunk = (K + 31) / 32, ntile = ((N + 63) / 64) * nchunk;
-    Tile ta, tb;
-    if (wave < ntile) load_tile(ta, wt + (long long)wave * kTile, lane);
-    if (wave + 8 < ntile) load_tile(tb, wt + (long long)(wave + 8) * kTile, lane);
-    for (int i = wave; i < ntile; i += 16) {
-        {
-            const float r = dot_ldso(ta, xo + (i % nchunk) * 32);
-            __builtin_amdgcn_sched_barrier(0);
-            lds[o_part + i * 64 + lane] = r;
-            if (i + 16 < ntile) load_tile(ta, wt + (long long)(i + 16) * kTile, lane);
-        }
-        if (i + 8 < ntile) {
-            const float r = dot_ldso(tb, xo + ((i + 8) % nchunk) * 32);
-            __builtin_amdgcn_sched_barrier(0);
-            lds[o_part + (i + 8) * 64 + lane] = r;
-            if (i + 24 < ntile) load_tile(tb, wt + (long long)(i + 24) * kTile, lane);
-        }
+    const int vo = lane * 16;
+    Tile t0, t1, t2, t3;                                  // four tiles in flight per wave: the stream is L2-latency bound
+    if (wave < ntile) load_tile_b(t0, rs, vo, wt_bytes + wave * (kTile * 4));
+    if (wave + 8 < ntile) load_tile_b(t1, rs, vo, wt_bytes + (wave + 8) * (kTile * 4));
+    if (wave + 16 < ntile) load_tile_b(t2, rs, vo, wt_bytes + (wave + 16) * (kTile * 4));
+    if (wave + 24 < ntile) load_tile_b(t3, rs, vo, wt_bytes + (wave + 24) * (kTile * 4));
+#define TWV_DEC_STEP(tt, j)                                                                      \
+    if ((j) < ntile) {                                                                           \
+        const float r = dot_ldso(tt, xo + ((j) % nchunk) * 32);                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        lds[o_part + (j) * 64 + lane] = r;                                                       \
+        if ((j) + 32 < ntile) load_tile_b(tt, rs, vo, wt_bytes + ((j) + 32) * (kTile * 4));      \
     }
+    for (int i = wave; i < ntile; i += 32) {
+        TWV_DEC_STEP(t0, i)
+        TWV_DEC_STEP(t1, i + 8)
+        TWV_DEC_STEP(t2, i + 16)
+        TWV_DEC_STEP(t3, i + 24)
+    }
+#undef TWV_DEC_STEP
 }
 // chunk values of output column j summed in chunk order (AC-1)
 __device__ __forceinline__ float dec_combine(int o_part, int K, int j)
@@ -290,10 +295,10 @@ __device__ __forceinline__ float dec_combine(int o_part, int K, int j)
 }
 // tf.contrib.rnn.GRUCell on the LDS vector cat = [x (nin) | h (U)] : h <- u*h + (1-u)*tanh([x, r*h].Wc + bc), returns nothing;
 // the new state is written to lds[o_hout .. +U).  All 512 threads call it.
-__device__ __forceinline__ void dec_gru(const float* P, long long oWg, long long obg, long long oWc, long long obc, int nin, int U,
+__device__ __forceinline__ void dec_gru(rsrc_t rs, const float* P, long long oWg, long long obg, long long oWc, long long obc, int nin, int U,
                                         int o_cat, int o_hout, int o_part, int o_vec, int tid, int wave, int lane)
 {
-    dec_gemv_partials(P + oWg, nin + U, 2 * U, o_cat, o_part, wave, lane);
+    dec_gemv_partials(rs, (int)((oWg) * 4), nin + U, 2 * U, o_cat, o_part, wave, lane);
     __syncthreads();
     float g = 0.0f;
     if (tid < 2 * U) g = sigmoid_e(dec_combine(o_part, nin + U, tid) + P[obg + tid]);
@@ -301,7 +306,7 @@ __device__ __forceinline__ void dec_gru(const float* P, long long oWg, long long
     if (tid < U) { lds[o_vec + tid] = lds[o_cat + nin + tid]; lds[o_cat + nin + tid] = g * lds[o_cat + nin + tid]; }   // keep h, cat <- [x, r*h]
     else if (tid < 2 * U) lds[o_vec + tid] = g;          // u
     __syncthreads();
-    dec_gemv_partials(P + oWc, nin + U, U, o_cat, o_part, wave, lane);
+    dec_gemv_partials(rs, (int)((oWc) * 4), nin + U, U, o_cat, o_part, wave, lane);
     __syncthreads();
     if (tid < U) {
         const float c = tanh_e(dec_combine(o_part, nin + U, tid) + P[obc + tid]);
@@ -320,6 +325,7 @@ __global__ void __launch_bounds__(512) tc_decoder_kernel(DecArgs a)
     const int T = a.T, M = a.M, R = a.R, A = a.A, AS = a.AS, ENC = a.ENC, DR = a.DR, D0 = a.D0, D1 = a.D1;
     const int len = a.lengths[n];
     const float* P = a.P;
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.P), 0, (int)a.packed_bytes, 0x00020000);
     const float* keys = a.keys + (long long)n * T * A;
     const float* memo = a.memo + (long long)n * T * ENC;
     // ---- LDS carve (all multiples of 4 floats)
@@ -352,25 +358,30 @@ __global__ void __launch_bounds__(512) tc_decoder_kernel(DecArgs a)
     __syncthreads();
     const int nAch = A / 32;
 
+#define TWV_STAMP(k) if (a.prof && n == 0 && tid == 0) a.prof[it * 16 + (k)] = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < a.iters; ++it) {
+        TWV_STAMP(0)
         // ---- rnn_wrappers.py:425 decoder prenet: dense(M -> D0) relu, dense(D0 -> D1) relu
-        dec_gemv_partials(P + a.w.dp1, M, D0, o_frame, o_part, wave, lane);
+        dec_gemv_partials(rs, (int)((a.w.dp1) * 4), M, D0, o_frame, o_part, wave, lane);
         __syncthreads();
         if (tid < D0) { const float v = dec_combine(o_part, M, tid) + P[a.w.dp1b + tid]; lds[o_vec + tid] = v > 0.0f ? v : 0.0f; }
         __syncthreads();
-        dec_gemv_partials(P + a.w.dp2, D0, D1, o_vec, o_part, wave, lane);
+        dec_gemv_partials(rs, (int)((a.w.dp2) * 4), D0, D1, o_vec, o_part, wave, lane);
         __syncthreads();
         // ---- rnn_wrappers.py:310-312 cell_inputs = [prenet_out | attention]; attention GRU on state ha
         if (tid < D1) { const float v = dec_combine(o_part, D0, tid) + P[a.w.dp2b + tid]; lds[o_cat + tid] = v > 0.0f ? v : 0.0f; }
         for (int i = tid; i < ENC; i += 512) lds[o_cat + D1 + i] = lds[o_ctx + i];
         for (int i = tid; i < AS; i += 512) lds[o_cat + D1 + ENC + i] = lds[o_ha + i];
         __syncthreads();
-        dec_gru(P, a.w.aWg, a.w.abg, a.w.aWc, a.w.abc, D1 + ENC, AS, o_cat, o_ha, o_part, o_vec, tid, wave, lane);
+        TWV_STAMP(1)
+        dec_gru(rs, P, a.w.aWg, a.w.abg, a.w.aWc, a.w.abc, D1 + ENC, AS, o_cat, o_ha, o_part, o_vec, tid, wave, lane);
+        TWV_STAMP(2)
         // ---- attention [RECALLED-TF BahdanauMonotonicAttention.__call__]: query layer
-        dec_gemv_partials(P + a.w.Wq, AS, A, o_ha, o_part, wave, lane);
+        dec_gemv_partials(rs, (int)((a.w.Wq) * 4), AS, A, o_ha, o_part, wave, lane);
         __syncthreads();
         if (tid < A) lds[o_pq + tid] = dec_combine(o_part, AS, tid);
         __syncthreads();
+        TWV_STAMP(3)
         // score[t] = cdot_j normed_v[j] * tanh((keys[t][j] + pq[j]) + b[j]) + score_bias ; one (t, chunk) per thread
         for (int task = tid; task < T * nAch; task += 512) {
             const int t = task / nAch, ch = task - t * nAch;
@@ -387,6 +398,7 @@ __global__ void __launch_bounds__(512) tc_decoder_kernel(DecArgs a)
             lds[o_scp + t * 8 + ch] = (s0 + s1) + (s2 + s3);
         }
         __syncthreads();
+        TWV_STAMP(4)
         // p = sigmoid(score) (0 past the length: _maybe_mask_score(-inf)); safe_cumprod pieces
         for (int t = tid; t < T; t += 512) {
             float sc = 0.0f;
@@ -426,6 +438,7 @@ __global__ void __launch_bounds__(512) tc_decoder_kernel(DecArgs a)
         }
         for (int t = T + tid; t < Tp; t += 512) lds[o_al + t] = 0.0f;
         __syncthreads();
+        TWV_STAMP(5)
         // ---- rnn_wrappers.py:390 context = alignments . values : cdot over t (AC-1 chunks of 32 time steps)
         if (tid < ENC) {
             float v = 0.0f;
@@ -439,24 +452,27 @@ __global__ void __launch_bounds__(512) tc_decoder_kernel(DecArgs a)
             lds[o_ctx + tid] = v;
         }
         __syncthreads();
+        TWV_STAMP(6)
         // ---- rnn_wrappers.py:463 concat(output, attention) -> OutputProjectionWrapper(dec_rnn)
         for (int i = tid; i < AS; i += 512) lds[o_cat + i] = lds[o_ha + i];
         for (int i = tid; i < ENC; i += 512) lds[o_cat + AS + i] = lds[o_ctx + i];
         __syncthreads();
-        dec_gemv_partials(P + a.w.cW, AS + ENC, DR, o_cat, o_part, wave, lane);
+        dec_gemv_partials(rs, (int)((a.w.cW) * 4), AS + ENC, DR, o_cat, o_part, wave, lane);
         __syncthreads();
         if (tid < DR) lds[o_y + tid] = dec_combine(o_part, AS + ENC, tid) + P[a.w.cb + tid];
         __syncthreads();
+        TWV_STAMP(7)
         // ---- tacotron.py:167 ResidualWrapper(GRUCell(dec_rnn)): y <- y + GRU(y, h_l)
         for (int l = 0; l < a.layers; ++l) {
             for (int i = tid; i < DR; i += 512) { lds[o_cat + i] = lds[o_y + i]; lds[o_cat + DR + i] = lds[o_hr[l] + i]; }
             __syncthreads();
-            dec_gru(P, a.w.rWg[l], a.w.rbg[l], a.w.rWc[l], a.w.rbc[l], DR, DR, o_cat, o_hr[l], o_part, o_vec, tid, wave, lane);
+            dec_gru(rs, P, a.w.rWg[l], a.w.rbg[l], a.w.rWc[l], a.w.rbc[l], DR, DR, o_cat, o_hr[l], o_part, o_vec, tid, wave, lane);
             if (tid < DR) lds[o_y + tid] = lds[o_y + tid] + lds[o_hr[l] + tid];
             __syncthreads();
         }
+        TWV_STAMP(8)
         // ---- tacotron.py:173 OutputProjectionWrapper(num_mels * r); helpers.py:40 last frame fed back
-        dec_gemv_partials(P + a.w.oW, DR, M * R, o_y, o_part, wave, lane);
+        dec_gemv_partials(rs, (int)((a.w.oW) * 4), DR, M * R, o_y, o_part, wave, lane);
         __syncthreads();
         if (tid < M * R) {
             const float v = dec_combine(o_part, DR, tid) + P[a.w.ob + tid];
@@ -464,7 +480,392 @@ __global__ void __launch_bounds__(512) tc_decoder_kernel(DecArgs a)
             if (tid >= M * (R - 1)) lds[o_frame + tid - M * (R - 1)] = v;
         }
         __syncthreads();
+        TWV_STAMP(9)
     }
+#undef TWV_STAMP
+}
+
+// -----------------------------------------------------------------------------------------------------
+//  decoder, G workgroups per utterance (the default when N*G workgroups fit the chip)
+// -----------------------------------------------------------------------------------------------------
+// The 1.6 M decoder weights (6.4 MB) do not fit one XCD's 4 MB L2, so one workgroup per utterance streams them from the
+// memory side every step.  Here workgroup (n, g) owns the 64-column output blocks jb = g, g+G, ... of every wide matvec,
+// and blockIdx -> (n = id / G, g = id % G) puts slice g of the weights into XCD g's L2 (0.8 MB at G = 8).  Each workgroup
+// keeps a full replica of the utterance's recurrent state in LDS; after a split matvec the activated outputs travel as
+// {epoch, value} granules (one agent-scope store each, readers poll -- same mechanism as the WaveNet generation kernel),
+// two alternating buffers: a workgroup can only publish exchange e+2 after it gathered e+1, which needs every workgroup
+// to have finished reading e.  Small matvecs (prenet, query) and the attention recurrence run redundantly.
+// Arithmetic is unchanged: every output column's chunks are still summed in order inside one workgroup.
+constexpr int kExN = 1024;          // granules per exchange buffer
+typedef __attribute__((address_space(1))) unsigned long long tgu64;
+
+struct DecGArgs {
+    DecArgs d;
+    int G;
+    unsigned long long* exch;       // [N][2][kExN]
+};
+
+struct DecgPos { int m, ch; };
+__device__ __forceinline__ void decg_adv(DecgPos& p, int step, int nchunk)
+{
+    p.ch += step;
+    while (p.ch >= nchunk) { p.ch -= nchunk; ++p.m; }
+}
+__device__ __forceinline__ int decg_off(int wt_bytes, const DecgPos& p, int nchunk, int g, int lg)
+{
+    return wt_bytes + ((((p.m << lg) + g) * nchunk + p.ch) << 13);        // kTile * 4 = 8192 bytes per tile
+}
+// local block m, lane l: chunk values summed in order (AC-1)
+__device__ __forceinline__ float decg_combine(int o_part, int nchunk, int m, int l)
+{
+    float v = 0.0f;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const float c = lds[o_part + (m * nchunk + ch) * 64 + l];
+        v = ch == 0 ? c : v + c;
+    }
+    return v;
+}
+// all 512 threads: collect n values of exchange `epoch` into lds[o_dst ..)
+__device__ __forceinline__ bool decg_gather(unsigned long long* X, int n, unsigned epoch, int o_dst, int tid, int o_abort)
+{
+    bool done0 = tid >= n, done1 = tid + 512 >= n;
+    for (int it = 0; it < (1 << 20); ++it) {
+        if (!done0) {
+            const unsigned long long v = __hip_atomic_load((tgu64*)(X + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(v >> 32) == epoch) { lds[o_dst + tid] = __uint_as_float((unsigned)v); done0 = true; }
+        }
+        if (!done1) {
+            const unsigned long long v = __hip_atomic_load((tgu64*)(X + tid + 512), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(v >> 32) == epoch) { lds[o_dst + tid + 512] = __uint_as_float((unsigned)v); done1 = true; }
+        }
+        if (__all(done0 && done1)) return true;
+        if ((it & 63) == 63 && LDSVI(o_abort)) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    LDSVI(o_abort) = 1;
+    return false;
+}
+__device__ __forceinline__ void decg_store(unsigned long long* p, unsigned epoch, float v)
+{
+    __hip_atomic_store((tgu64*)p, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+// running sums over lds[o .. o+T) in index order (one add chain), one wave, staged through registers
+__device__ __forceinline__ void decg_scan(int o, int T, int lane, bool inclusive)
+{
+    float run = 0.0f;
+    for (int base = 0; base < T; base += 64) {
+        const int n = T - base < 64 ? T - base : 64;
+        const float v = (base + lane < T) ? lds[o + base + lane] : 0.0f;
+        float res = 0.0f;
+        for (int i = 0; i < n; ++i) {
+            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
+            const float nxt = run + x;
+            if (lane == i) res = inclusive ? nxt : run;
+            run = nxt;
+        }
+        if (base + lane < T) lds[o + base + lane] = res;
+    }
+}
+
+// The decoder step is a table-driven sequence of matvec stages, so the tile-streaming code exists ONCE (inlined in the stage
+// loop): twelve inlined copies made the register allocator spill ~1000 VGPRs, and a real call costs ~4000 cycles because the
+// callee saves its VGPRs to scratch (scripts/ubench/gemv_call.hip).
+enum { DS_W = 0, DS_BIAS, DS_K, DS_N, DS_X, DS_DST, DS_ACT, DS_SPLIT, DS_POST, DS_P0, DS_P1, DS_P2, DS_STRIDE };
+enum { DP_NONE = 0, DP_CAT_ATT, DP_GATES, DP_CAND, DP_QUERY, DP_PROJ, DP_OUT };
+enum { DA_NONE = 0, DA_SIGMOID, DA_TANH, DA_RELU };
+
+__global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
+{
+    const DecArgs& a = ga.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lg = ga.G == 8 ? 3 : (ga.G == 4 ? 2 : (ga.G == 2 ? 1 : 0)), G = 1 << lg;
+    const int n = blockIdx.x >> lg, g = blockIdx.x & (G - 1);
+    const int T = a.T, M = a.M, R = a.R, A = a.A, AS = a.AS, ENC = a.ENC, DR = a.DR, D0 = a.D0, D1 = a.D1;
+    const int len = a.lengths[n];
+    const float* P = a.P;
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.P), 0, (int)a.packed_bytes, 0x00020000);
+    const float* keys = a.keys + (long long)n * T * A;
+    const float* memo = a.memo + (long long)n * T * ENC;
+    unsigned long long* X = ga.exch + (long long)n * 2 * kExN;
+    // ---- LDS carve
+    int o = 0;
+    const int o_cat = o; o += 1024;
+    const int o_vec = o; o += 1024;                       // gathered gates (r | u), prenet hidden
+    const int o_cand = o; o += 512;
+    const int o_keep = o; o += 512;                       // h before the update
+    const int o_ha = o; o += AS;
+    const int o_hr0 = o; o += a.layers * DR;              // residual GRU states, layer l at o_hr0 + l*DR
+    const int o_frame = o; o += ((M + 31) / 32) * 32;
+    const int o_ctx = o; o += ENC;
+    const int o_y = o; o += DR;
+    const int o_out = o; o += ((M * R + 63) / 64) * 64;
+    const int Tp = ((T + 3) / 4) * 4;
+    const int o_al = o; o += Tp;
+    const int o_p = o; o += Tp;
+    const int o_cp = o; o += Tp;
+    const int o_q = o; o += Tp;
+    const int o_pq = o; o += A;
+    const int o_scp = o; o += Tp * 8;
+    const int o_abort = o; o += 4;
+    const int o_tab = o; o += 16 * DS_STRIDE;             // stage table
+    const int o_part = o;
+
+    const float* init = a.init + (long long)n * (AS + a.layers * DR);
+    for (int i = tid; i < AS; i += 512) lds[o_ha + i] = init[i];
+    for (int i = tid; i < a.layers * DR; i += 512) lds[o_hr0 + i] = init[AS + i];
+    for (int i = tid; i < ((M + 31) / 32) * 32; i += 512) lds[o_frame + i] = 0.0f;
+    for (int i = tid; i < ENC; i += 512) lds[o_ctx + i] = 0.0f;
+    for (int i = tid; i < Tp; i += 512) lds[o_al + i] = i == 0 ? 1.0f : 0.0f;
+    if (tid < 4) LDSI(o_abort + tid) = 0;
+    const int nst = 7 + 2 * a.layers;
+    if (tid == 0) {
+        int s = 0;
+        auto put = [&](long long w, long long b, int K, int N, int x, int dst, int act, int split, int post, int p0, int p1, int p2) {
+            const int q = o_tab + s * DS_STRIDE;
+            LDSI(q + DS_W) = (int)(w * 4); LDSI(q + DS_BIAS) = (int)b; LDSI(q + DS_K) = K; LDSI(q + DS_N) = N; LDSI(q + DS_X) = x;
+            LDSI(q + DS_DST) = dst; LDSI(q + DS_ACT) = act; LDSI(q + DS_SPLIT) = split; LDSI(q + DS_POST) = post;
+            LDSI(q + DS_P0) = p0; LDSI(q + DS_P1) = p1; LDSI(q + DS_P2) = p2;
+            ++s;
+        };
+        // rnn_wrappers.py:425 decoder prenet (redundant in every workgroup: 28 tiles)
+        put(a.w.dp1, a.w.dp1b, M, D0, o_frame, o_vec, DA_RELU, 0, DP_NONE, 0, 0, 0);
+        put(a.w.dp2, a.w.dp2b, D0, D1, o_vec, o_cat, DA_RELU, 0, DP_CAT_ATT, 0, 0, 0);
+        // rnn_wrappers.py:310-312 attention GRU on [prenet_out | attention | ha]
+        put(a.w.aWg, a.w.abg, D1 + ENC + AS, 2 * AS, o_cat, o_vec, DA_SIGMOID, 1, DP_GATES, D1 + ENC, AS, 0);
+        put(a.w.aWc, a.w.abc, D1 + ENC + AS, AS, o_cat, o_cand, DA_TANH, 1, DP_CAND, AS, o_ha, -1);
+        // attention query layer (redundant: 32 tiles), then score / recurrence / context
+        put(a.w.Wq, -1, AS, A, o_ha, o_pq, DA_NONE, 0, DP_QUERY, 0, 0, 0);
+        // rnn_wrappers.py:463 concat(output, attention) -> OutputProjectionWrapper(dec_rnn)
+        put(a.w.cW, a.w.cb, AS + ENC, DR, o_cat, o_y, DA_NONE, 1, DP_PROJ, 0, 0, 0);
+        // tacotron.py:167 ResidualWrapper(GRUCell(dec_rnn)): y <- y + GRU(y, h_l)
+        for (int l = 0; l < a.layers; ++l) {
+            put(a.w.rWg[l], a.w.rbg[l], 2 * DR, 2 * DR, o_cat, o_vec, DA_SIGMOID, 1, DP_GATES, DR, DR, 0);
+            put(a.w.rWc[l], a.w.rbc[l], 2 * DR, DR, o_cat, o_cand, DA_TANH, 1, DP_CAND, DR, o_hr0 + l * DR, l + 1 < a.layers ? o_hr0 + (l + 1) * DR : 0);
+        }
+        // tacotron.py:173 OutputProjectionWrapper(num_mels * r)
+        put(a.w.oW, a.w.ob, DR, M * R, o_y, o_out, DA_NONE, 1, DP_OUT, 0, 0, 0);
+    }
+    __syncthreads();
+    const int nAch = A / 32;
+    unsigned ep = 0;                                      // exchanges completed so far
+    bool ok = true;
+#define TWV_STAMP(k) if (a.prof && blockIdx.x == 0 && tid == 0) a.prof[it * 16 + (k)] = __builtin_amdgcn_s_memtime();
+
+    for (int it = 0; it < a.iters && ok; ++it) {
+        for (int st = 0; st < nst && ok; ++st) {
+            const int q = o_tab + st * DS_STRIDE;
+            const int w_bytes = __builtin_amdgcn_readfirstlane(LDSI(q + DS_W)), bias = __builtin_amdgcn_readfirstlane(LDSI(q + DS_BIAS));
+            const int K = __builtin_amdgcn_readfirstlane(LDSI(q + DS_K)), N = __builtin_amdgcn_readfirstlane(LDSI(q + DS_N));
+            const int xo = __builtin_amdgcn_readfirstlane(LDSI(q + DS_X)), dst = __builtin_amdgcn_readfirstlane(LDSI(q + DS_DST));
+            const int act = __builtin_amdgcn_readfirstlane(LDSI(q + DS_ACT)), split = __builtin_amdgcn_readfirstlane(LDSI(q + DS_SPLIT));
+            const int post = __builtin_amdgcn_readfirstlane(LDSI(q + DS_POST));
+            const int gg = split ? g : 0, lgg = split ? lg : 0, GG = 1 << lgg;
+            const int nchunk = (K + 31) >> 5, nblk = (N + 63) >> 6;
+            const int nmine = nblk > gg ? (nblk - gg + GG - 1) >> lgg : 0;
+            const int ntile = nmine * nchunk;
+            if (st == 0) { TWV_STAMP(0) }
+            // ---- this workgroup's tiles: wave w takes local tiles w, w+8, ... (three in flight), partials to LDS
+            {
+                const int vo = lane * 16;
+                Tile t0, t1, t2;
+                DecgPos p0{0, 0}, p1, p2;
+                decg_adv(p0, wave, nchunk);
+                p1 = p0; decg_adv(p1, 8, nchunk);
+                p2 = p1; decg_adv(p2, 8, nchunk);
+                if (wave < ntile) load_tile_b(t0, rs, vo, decg_off(w_bytes, p0, nchunk, gg, lgg));
+                if (wave + 8 < ntile) load_tile_b(t1, rs, vo, decg_off(w_bytes, p1, nchunk, gg, lgg));
+                if (wave + 16 < ntile) load_tile_b(t2, rs, vo, decg_off(w_bytes, p2, nchunk, gg, lgg));
+                for (int i = wave; i < ntile; i += 24) {
+                    {
+                        const float r = dot_ldso(t0, xo + p0.ch * 32);
+                        __builtin_amdgcn_sched_barrier(0);
+                        lds[o_part + i * 64 + lane] = r;
+                        decg_adv(p0, 24, nchunk);
+                        if (i + 24 < ntile) load_tile_b(t0, rs, vo, decg_off(w_bytes, p0, nchunk, gg, lgg));
+                    }
+                    if (i + 8 < ntile) {
+                        const float r = dot_ldso(t1, xo + p1.ch * 32);
+                        __builtin_amdgcn_sched_barrier(0);
+                        lds[o_part + (i + 8) * 64 + lane] = r;
+                        decg_adv(p1, 24, nchunk);
+                        if (i + 32 < ntile) load_tile_b(t1, rs, vo, decg_off(w_bytes, p1, nchunk, gg, lgg));
+                    }
+                    if (i + 16 < ntile) {
+                        const float r = dot_ldso(t2, xo + p2.ch * 32);
+                        __builtin_amdgcn_sched_barrier(0);
+                        lds[o_part + (i + 16) * 64 + lane] = r;
+                        decg_adv(p2, 24, nchunk);
+                        if (i + 40 < ntile) load_tile_b(t2, rs, vo, decg_off(w_bytes, p2, nchunk, gg, lgg));
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- epilogue: chunk sums in order (AC-1) + bias + activation; split stages publish and all-gather
+            {
+                const bool xch = split && G > 1;
+                unsigned long long* Xb = X;
+                if (xch) { ++ep; Xb = X + (ep & 1) * kExN; }
+                for (int qq = tid; qq < nmine * 64; qq += 512) {
+                    const int m = qq >> 6, j = (((m << lgg) + gg) << 6) + (qq & 63);
+                    if (j < N) {
+                        float v = decg_combine(o_part, nchunk, m, qq & 63);
+                        if (bias >= 0) v = v + P[bias + j];
+                        if (act == DA_SIGMOID) v = sigmoid_e(v);
+                        else if (act == DA_TANH) v = tanh_e(v);
+                        else if (act == DA_RELU) v = v > 0.0f ? v : 0.0f;
+                        if (xch) decg_store(Xb + j, ep, v); else lds[dst + j] = v;
+                    }
+                }
+                if (xch) decg_gather(Xb, N, ep, dst, tid, o_abort);
+                __syncthreads();
+                ok = LDSI(o_abort) == 0;
+            }
+            // ---- what follows the matvec
+            if (post == DP_CAT_ATT) {
+                for (int i = tid; i < ENC; i += 512) lds[o_cat + D1 + i] = lds[o_ctx + i];
+                for (int i = tid; i < AS; i += 512) lds[o_cat + D1 + ENC + i] = lds[o_ha + i];
+                __syncthreads();
+                TWV_STAMP(1)
+            } else if (post == DP_GATES) {               // tf.contrib.rnn.GRUCell, gate order r | u: keep h, cat <- [x, r*h]
+                const int nin = __builtin_amdgcn_readfirstlane(LDSI(q + DS_P0)), U = __builtin_amdgcn_readfirstlane(LDSI(q + DS_P1));
+                for (int i = tid; i < U; i += 512) {
+                    const float h = lds[o_cat + nin + i];
+                    lds[o_keep + i] = h;
+                    lds[o_cat + nin + i] = lds[o_vec + i] * h;
+                }
+                __syncthreads();
+            } else if (post == DP_CAND) {                // h <- u*h + (1-u)*c
+                const int U = __builtin_amdgcn_readfirstlane(LDSI(q + DS_P0)), o_h = __builtin_amdgcn_readfirstlane(LDSI(q + DS_P1));
+                const int o_next = __builtin_amdgcn_readfirstlane(LDSI(q + DS_P2));
+                for (int i = tid; i < U; i += 512) {
+                    const float c = lds[o_cand + i], u = lds[o_vec + U + i], h = lds[o_keep + i];
+                    const float t1 = u * h, t2 = 1.0f - u, t3 = t2 * c;
+                    const float hn = t1 + t3;
+                    lds[o_h + i] = hn;
+                    if (o_next >= 0) {                   // residual layer: y <- y + h ; next layer's input [y | h_next]
+                        const float yn = lds[o_y + i] + hn;
+                        lds[o_y + i] = yn;
+                        if (o_next > 0) { lds[o_cat + i] = yn; lds[o_cat + DR + i] = lds[o_next + i]; }
+                    }
+                }
+                __syncthreads();
+                if (o_next < 0) { TWV_STAMP(2) }
+            } else if (post == DP_PROJ) {
+                for (int i = tid; i < DR; i += 512) { lds[o_cat + i] = lds[o_y + i]; lds[o_cat + DR + i] = lds[o_hr0 + i]; }
+                __syncthreads();
+                TWV_STAMP(7)
+            } else if (post == DP_OUT) {                 // tacotron.py:204 reshape; helpers.py:40 last frame fed back
+                for (int i = tid; i < M * R; i += 512) {
+                    const float v = lds[o_out + i];
+                    if (g == 0) a.mel[((long long)n * a.iters + it) * M * R + i] = v;
+                    if (i >= M * (R - 1)) lds[o_frame + i - M * (R - 1)] = v;
+                }
+                __syncthreads();
+                TWV_STAMP(9)
+            } else if (post == DP_QUERY) {
+                TWV_STAMP(3)
+                // [RECALLED-TF BahdanauMonotonicAttention.__call__] score for the time steps t = g, g+G, ...: one (t, chunk) per thread
+                const int nt = T > g ? (T - g + G - 1) >> lg : 0;
+                for (int task = tid; task < nt * nAch; task += 512) {
+                    const int tl = task / nAch, ch = task - tl * nAch, t = (tl << lg) + g;
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                    const float* kr = keys + (long long)t * A + ch * 32;
+#pragma unroll 2
+                    for (int j = 0; j < 32; j += 4) {
+                        const int jj = ch * 32 + j;
+                        s0 = fma_(P[a.w.nv + jj + 0], tanh_e((kr[j + 0] + lds[o_pq + jj + 0]) + P[a.w.ab + jj + 0]), s0);
+                        s1 = fma_(P[a.w.nv + jj + 1], tanh_e((kr[j + 1] + lds[o_pq + jj + 1]) + P[a.w.ab + jj + 1]), s1);
+                        s2 = fma_(P[a.w.nv + jj + 2], tanh_e((kr[j + 2] + lds[o_pq + jj + 2]) + P[a.w.ab + jj + 2]), s2);
+                        s3 = fma_(P[a.w.nv + jj + 3], tanh_e((kr[j + 3] + lds[o_pq + jj + 3]) + P[a.w.ab + jj + 3]), s3);
+                    }
+                    lds[o_scp + tl * 8 + ch] = (s0 + s1) + (s2 + s3);
+                }
+                __syncthreads();
+                {
+                    ++ep;
+                    unsigned long long* Xb = X + (ep & 1) * kExN;
+                    for (int tl = tid; tl < nt; tl += 512) {
+                        const int t = (tl << lg) + g;
+                        float sc = 0.0f;
+                        for (int ch = 0; ch < nAch; ++ch) { const float c = lds[o_scp + tl * 8 + ch]; sc = ch == 0 ? c : sc + c; }
+                        sc = sc + P[a.w.asb];
+                        const float pv = t < len ? sigmoid_e(sc) : 0.0f;       // _maybe_mask_score(-inf) -> p = 0
+                        if (G == 1) lds[o_p + t] = pv; else decg_store(Xb + t, ep, pv);
+                    }
+                    if (G > 1) decg_gather(Xb, T, ep, o_p, tid, o_abort);
+                    __syncthreads();
+                    ok = LDSI(o_abort) == 0;
+                }
+                TWV_STAMP(4)
+                // monotonic attention recurrence (redundant): safe_cumprod pieces, two sequential sums
+                for (int t = tid; t < T; t += 512) {
+                    float om = 1.0f - lds[o_p + t];
+                    const float tiny = 1.17549435e-38f;
+                    om = om < tiny ? tiny : (om > 1.0f ? 1.0f : om);
+                    lds[o_q + t] = log_e(om);
+                }
+                __syncthreads();
+                if (wave == 0) decg_scan(o_q, T, lane, false);
+                __syncthreads();
+                for (int t = tid; t < T; t += 512) {
+                    const float cpv = exp_e(lds[o_q + t]);
+                    lds[o_cp + t] = cpv;
+                    float den = cpv;
+                    den = den < 1e-10f ? 1e-10f : (den > 1.0f ? 1.0f : den);
+                    lds[o_q + t] = div_(lds[o_al + t], den);
+                }
+                __syncthreads();
+                if (wave == 0) decg_scan(o_q, T, lane, true);
+                __syncthreads();
+                for (int t = tid; t < T; t += 512) {
+                    const float pc = lds[o_p + t] * lds[o_cp + t];
+                    const float al = pc * lds[o_q + t];
+                    lds[o_al + t] = al;
+                    if (a.align && g == 0) a.align[((long long)n * T + t) * a.iters + it] = al;      // tacotron.py:223
+                }
+                for (int t = T + tid; t < Tp; t += 512) lds[o_al + t] = 0.0f;
+                __syncthreads();
+                TWV_STAMP(5)
+                // rnn_wrappers.py:390 context = alignments . values: workgroup g takes the columns [g*ENC/G, (g+1)*ENC/G) -- its XCD's
+                // L2 then only ever sees that column slice of the encoder memory -- one thread per (column, 32-step chunk), all-gather
+                {
+                    const int nch = (T + 31) / 32, ncol = ENC >> lg, c0 = g * ncol;
+                    for (int task = tid; task < ncol * nch; task += 512) {
+                        const int cl = task % ncol, ch = task / ncol;
+                        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                        const int ta = ch * 32, tb = T < ta + 32 ? T : ta + 32;
+                        const float* mp = memo + c0 + cl;
+                        for (int t = ta; t < tb; t += 4) {
+                            s0 = fma_(mp[(long long)t * ENC], lds[o_al + t], s0);
+                            if (t + 1 < tb) s1 = fma_(mp[(long long)(t + 1) * ENC], lds[o_al + t + 1], s1);
+                            if (t + 2 < tb) s2 = fma_(mp[(long long)(t + 2) * ENC], lds[o_al + t + 2], s2);
+                            if (t + 3 < tb) s3 = fma_(mp[(long long)(t + 3) * ENC], lds[o_al + t + 3], s3);
+                        }
+                        lds[o_part + ch * ncol + cl] = (s0 + s1) + (s2 + s3);
+                    }
+                    __syncthreads();
+                    ++ep;
+                    unsigned long long* Xb = X + (ep & 1) * kExN;
+                    if (tid < ncol) {
+                        float v = 0.0f;
+                        for (int ch = 0; ch < nch; ++ch) { const float c = lds[o_part + ch * ncol + tid]; v = ch == 0 ? c : v + c; }
+                        if (G == 1) lds[o_ctx + tid] = v; else decg_store(Xb + c0 + tid, ep, v);
+                    }
+                    if (G > 1) decg_gather(Xb, ENC, ep, o_ctx, tid, o_abort);
+                    __syncthreads();
+                    ok = LDSI(o_abort) == 0;
+                }
+                TWV_STAMP(6)
+                for (int i = tid; i < AS; i += 512) lds[o_cat + i] = lds[o_ha + i];
+                for (int i = tid; i < ENC; i += 512) lds[o_cat + AS + i] = lds[o_ctx + i];
+                __syncthreads();
+            }
+        }
+    }
+    if (!ok && tid == 0) a.status[0] = 21;                    // exchange watchdog
+#undef TWV_STAMP
 }
 
 // =====================================================================================================
@@ -481,6 +882,8 @@ struct TCbhg {
 };
 struct twv_tacotron {
     twv_tacotron_dims d;
+    unsigned long long* prof = nullptr;
+    int dec_groups = 0;             // 0 auto (8, halved until N*G fits the CUs), -1 single-workgroup kernel
     long long blob_floats, packed_floats;
     TMat emb, semb;                 // raw tables (K rows x N)
     TMat dW[8]; TVec db[8]; int ndense, dn[8];
@@ -579,6 +982,17 @@ extern "C" int twv_tacotron_create(const twv_tacotron_dims* dims, twv_tacotron**
 }
 extern "C" void twv_tacotron_destroy(twv_tacotron* h) { delete h; }
 extern "C" size_t twv_tacotron_blob_floats(const twv_tacotron* h) { return (size_t)h->blob_floats; }
+extern "C" int twv_tacotron_set_option(twv_tacotron* h, const char* name, int value)
+{
+    if (!h || !name) return twv_fail(TWV_E_INVALID, "null argument");
+    if (!strcmp(name, "decoder_groups")) {
+        if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return twv_fail(TWV_E_INVALID, "decoder_groups must be -1, 0, 1, 2, 4 or 8");
+        h->dec_groups = value;
+        return TWV_OK;
+    }
+    return twv_fail(TWV_E_INVALID, "unknown option");
+}
+extern "C" int twv_tacotron_set_profile_buffer(twv_tacotron* h, void* dev_u64) { if (!h) return 1; h->prof = (unsigned long long*)dev_u64; return 0; }
 extern "C" size_t twv_tacotron_packed_bytes(const twv_tacotron* h) { return (size_t)h->packed_floats * 4; }
 
 __global__ void tc_normed_v_kernel(float* P, long long av, long long ag, long long nv, int A)
@@ -631,6 +1045,7 @@ static long long taco_ws_floats(const twv_tacotron* h, int N, int T)
     f += rowsE * 256 * 2;               // encoder output (memory), keys
     f += (long long)N * 4096;           // speaker-dependent vectors
     f += rowsP * 256;                   // post CBHG output
+    f += (long long)N * 4096;           // decoder exchange granules
     return f + 1024;
 }
 extern "C" size_t twv_tacotron_workspace_bytes(const twv_tacotron* h, int batch, int t_in) { return (size_t)taco_ws_floats(h, batch, t_in) * 4; }
@@ -715,6 +1130,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
     float* keys = w; w += (long long)rows * 256;
     float* spk = w; w += (long long)N * 4096;
     float* postout = w; w += (long long)rowsP * 256;
+    float* exch = w; w += (long long)N * 2 * kExN * 2;      // decoder exchange granules (8 bytes each)
     // ---- tacotron.py:51-60 embedding, :67-82 speaker embedding + deep_dense (softsign)
     hipLaunchKernelGGL(tc_embed_kernel, dim3(tgrid((long long)rows * E)), dim3(256), 0, st, P + h->emb.off, tokens, rows, E, ra);
     hipLaunchKernelGGL(tc_gather_rows_kernel, dim3(tgrid((long long)N * SE)), dim3(256), 0, st, P + h->semb.off, speaker_ids, N, SE, spk);
@@ -747,17 +1163,42 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
     da.keys = keys; da.memo = memo; da.init = dinit; da.lengths = lengths;
     da.N = N; da.T = T; da.M = M; da.R = R; da.D0 = d.dec_prenet_sizes[0]; da.D1 = d.dec_prenet_sizes[1]; da.A = A; da.AS = AS; da.ENC = ENC;
     da.DR = DR; da.layers = d.dec_layer_num; da.iters = d.max_iters; da.mel = mel; da.align = alignments; da.status = status;
+    da.packed_bytes = (long long)h->packed_floats * 4;
+    da.prof = h->prof;
     {
         const int Tp = (T + 3) / 4 * 4;
         const int ain = da.D1 + ENC;
         const int kmax = (ain + AS) > 2 * DR ? (ain + AS) : 2 * DR;
         const long long part = (long long)((kmax + 31) / 32) * ((2 * (AS > DR ? AS : DR) + 63) / 64) * 64;
         const long long part2 = (long long)((DR + 31) / 32) * ((M * R + 63) / 64) * 64;
-        const long long fl = 2048 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + Tp * 4 + A + Tp * 8 + (part > part2 ? part : part2);
-        const size_t shm = (size_t)fl * 4;
-        if (shm > 160 * 1024) return twv_fail(TWV_E_UNSUPPORTED, "decoder LDS footprint exceeds 160 KiB (t_in too large)");
-        HIPCHK(hipFuncSetAttribute((const void*)tc_decoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        hipLaunchKernelGGL(tc_decoder_kernel, dim3(N), dim3(512), shm, st, da);
+        const long long part3 = (long long)((T + 31) / 32) * ENC;
+        long long pmax = part > part2 ? part : part2;
+        pmax = pmax > part3 ? pmax : part3;
+        // G workgroups per utterance, all N*G co-resident (they exchange through polled granules)
+        int cus = 0, devid = 0;
+        HIPCHK(hipGetDevice(&devid));
+        HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid));
+        int G = h->dec_groups > 0 ? h->dec_groups : 8;
+        while (G > 1 && (long long)N * G > cus) G >>= 1;
+        if (2 * (AS > DR ? AS : DR) > kExN || M * R > kExN || T > kExN || ENC > kExN) G = 1;
+        while (G > 1 && ENC % G) G >>= 1;
+        if (h->dec_groups == -1) {       // the single-workgroup kernel (kept as a cross-check of the split one)
+            const long long fl = 2048 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + Tp * 4 + A + Tp * 8 + pmax;
+            const size_t shm = (size_t)fl * 4;
+            if (shm > 160 * 1024) return twv_fail(TWV_E_UNSUPPORTED, "decoder LDS footprint exceeds 160 KiB (t_in too large)");
+            HIPCHK(hipFuncSetAttribute((const void*)tc_decoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            hipLaunchKernelGGL(tc_decoder_kernel, dim3(N), dim3(512), shm, st, da);
+        } else {
+            DecGArgs ga;
+            ga.d = da; ga.G = G; ga.exch = reinterpret_cast<unsigned long long*>(exch);
+            HIPCHK(hipMemsetAsync(exch, 0, (size_t)N * 2 * kExN * 8, st));
+            const long long fl = 1024 * 2 + 512 * 2 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + (M * R + 63) / 64 * 64 + Tp * 4 + A +
+                                 Tp * 8 + 4 + 16 * 12 + pmax;
+            const size_t shm = (size_t)fl * 4;
+            if (shm > 160 * 1024) return twv_fail(TWV_E_UNSUPPORTED, "decoder LDS footprint exceeds 160 KiB (t_in too large)");
+            HIPCHK(hipFuncSetAttribute((const void*)tc_decoder_g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            hipLaunchKernelGGL(tc_decoder_g_kernel, dim3(N * G), dim3(512), shm, st, ga);
+        }
     }
     // ---- tacotron.py:209 post CBHG (no lengths, zero init), :219 linear projection
     if (linear) {

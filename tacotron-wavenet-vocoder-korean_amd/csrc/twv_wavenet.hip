@@ -878,8 +878,10 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
 
 constexpr int kLoaders = 3;
 
-template <int W, int NTW, bool SCALAR>
-__global__ void __launch_bounds__((1 + kLoaders + W) * 64) wn_generate_kernel(GenArgs a)
+// D = 1 parks an idle wave at index 1 + kLoaders: waves i and i+4 of a workgroup share a SIMD (scripts/ubench/simd_map.hip), so
+// with 3 loaders the chain wave (wave 0) then has its SIMD to itself.
+template <int W, int NTW, bool SCALAR, int D = 0>
+__global__ void __launch_bounds__((1 + kLoaders + D + W) * 64) wn_generate_kernel(GenArgs a)
 {
     const Layout& L = a.lay;
     const int NL = L.NL, S = L.S, NCH = L.NCH;
@@ -932,7 +934,8 @@ __global__ void __launch_bounds__((1 + kLoaders + W) * 64) wn_generate_kernel(Ge
     int hpos = meta[M_HPOS], prev_valid = meta[M_PREV_VALID], qprev = meta[M_QPREV];
     if (wid == 0) chain_main<SCALAR>(a, c, hpos, prev_valid, qprev);
     else if (wid <= kLoaders) loader_main<kLoaders>(a, c, rs, wid - 1);
-    else worker_main<W, NTW, SCALAR>(a, c, rs, wid - 1 - kLoaders);
+    else if (D && wid == kLoaders + 1) {}
+    else worker_main<W, NTW, SCALAR>(a, c, rs, wid - 1 - kLoaders - D);
 
     // ---------------- persist the per-stream state (model.py:49-64 queues) ----------------
     __syncthreads();
@@ -1228,7 +1231,7 @@ extern "C" int twv_wavenet_set_option(twv_wavenet* h, const char* name, int valu
 {
     if (!h || !name) return fail(TWV_E_INVALID, "null argument");
     if (!strcmp(name, "workers")) {
-        if (value != 4) return fail(TWV_E_INVALID, "workers must be 4");
+        if (value != 4 && value != 3) return fail(TWV_E_INVALID, "workers must be 4 or 3 (3 = idle wave beside the chain wave)");
         h->workers = value;
         return TWV_OK;
     }
@@ -1365,12 +1368,12 @@ extern "C" int twv_wavenet_condition(const twv_wavenet* h, const void* packed, c
     return TWV_OK;
 }
 
-template <int W, int NTW, bool SCALAR>
+template <int W, int NTW, bool SCALAR, int D = 0>
 static int launch_generate(const GenArgs& a, size_t shm, hipStream_t st)
 {
-    auto kern = wn_generate_kernel<W, NTW, SCALAR>;
+    auto kern = wn_generate_kernel<W, NTW, SCALAR, D>;
     if (shm > 32 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(kern, dim3(a.B * a.G), dim3((1 + kLoaders + W) * 64), shm, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.B * a.G), dim3((1 + kLoaders + D + W) * 64), shm, st, a);
     HIPCHK(hipGetLastError());
     return TWV_OK;
 }
@@ -1406,6 +1409,10 @@ static int generate_impl(const twv_wavenet* h, const void* packed, void* state, 
     const int nsjl = L.NSJ / G;
     const int ntw = (nsjl + kWorkers - 1) / kWorkers;
     if (!L.scalar && L.Q > 1024) return fail(TWV_E_UNSUPPORTED, "quantization_channels must be <= 1024");
+    if (L.scalar && h->workers == 3) {
+        if (nsjl <= 3) return launch_generate<3, 1, true, 1>(a, shm, st);
+        return fail(TWV_E_UNSUPPORTED, "workers=3 needs skip_channels/64/groups <= 3");
+    }
     if (L.scalar) {
         if (ntw <= 1) return launch_generate<kWorkers, 1, true>(a, shm, st);
         if (ntw == 2) return launch_generate<kWorkers, 2, true>(a, shm, st);

@@ -133,6 +133,10 @@ class Tacotron(object):
         self._packed = None
         self._ws = None
 
+    def set_option(self, name, value):
+        """launch geometry (performance only): "decoder_groups" = workgroups per utterance in the decoder (0 auto, 1/2/4/8, -1 old kernel)"""
+        _lib.check(self._L.twv_tacotron_set_option(self._h, name.encode(), int(value)))
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

@@ -82,3 +82,18 @@ def test_synthesizer_surface(torch_cuda, oracle):
     tok = np.array([[5, 9, 33, 12, 1], [7, 7, 1, 0, 0]], np.int32)
     mel_o, _, _ = oracle.taco_infer(d, oracle.taco_blob(d, tensors), tok, np.array([5, 3], np.int32), np.array([1, 0], np.int32))
     assert first_mismatch(out["mel"].cpu().numpy(), mel_o) is None
+
+
+@pytest.mark.parametrize("groups", [-1, 1, 2, 4, 8])
+def test_decoder_launch_geometry_does_not_change_results(torch_cuda, oracle, groups):
+    """decoder split over G workgroups per utterance (exchange through polled granules) == single-workgroup kernel == oracle"""
+    hp = _hp(max_iters=7, enc_bank_size=3, post_bank_size=2, num_freq=65)
+    d, blob, tok, ln, spk, m = _case(oracle, hp, 3, 37, [37, 20, 5], seed=11)
+    mel_o, lin_o, al_o = oracle.taco_infer(d, blob, tok, ln, spk)
+    m.set_option("decoder_groups", groups)
+    mel, lin, al = m.infer(tok, ln, spk)
+    assert first_mismatch(al.cpu().numpy(), al_o) is None, ("alignments", first_mismatch(al.cpu().numpy(), al_o))
+    assert first_mismatch(mel.cpu().numpy(), mel_o) is None, ("mel", first_mismatch(mel.cpu().numpy(), mel_o))
+    assert first_mismatch(lin.cpu().numpy(), lin_o) is None
+    mel2, _, _ = m.infer(tok, ln, spk)                                  # a second pass reuses the exchange buffers
+    assert first_mismatch(mel2.cpu().numpy(), mel_o) is None
