@@ -27,4 +27,6 @@ names = ["prenet", "attn GRU", "query", "score", "recurrence", "context", "proj"
 tot = (p[:, 8] - p[:, 0]).mean()
 for nme, v in zip(names, d):
     print("%-12s %8.0f ticks %5.1f%%" % (nme, v, 100 * v / tot))
+q = prof.cpu().numpy().reshape(-1, 16)[20:180].astype(np.float64)
+print("proj stage (wave 0 of WG 0): params %.0f | dots %.0f | prefetch issue %.0f | barrier %.0f | combine+publish %.0f | gather %.0f | barrier+post -> stamp7 %.0f" % tuple((q[:, b] - q[:, a]).mean() for a, b in ((6, 10), (10, 11), (11, 12), (12, 13), (13, 14), (14, 15), (15, 7))))
 print("step total %8.0f ticks (s_memtime @100 MHz -> %.1f us)" % (tot, tot / 100.0))

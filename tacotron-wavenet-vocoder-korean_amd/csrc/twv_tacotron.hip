@@ -21,6 +21,7 @@
 #include "../../include/twv_amd.h"
 #include "twv_dev.hpp"
 
+static int g_gemm_valu = 0;            // "gemm_valu" option: 1 = the VALU kernel (cross-check of the MFMA one)
 enum { TACT_NONE = 0, TACT_RELU = 1, TACT_TANH = 2, TACT_SIGMOID = 3, TACT_SOFTSIGN = 4 };
 __device__ __forceinline__ float tc_act(float v, int act)
 {
@@ -107,6 +108,114 @@ __global__ void __launch_bounds__(256) tc_gemm_kernel(GemmArgs a)
                         if (a.add2) v = v + a.add2[(long long)(row / a.T) * a.ld2 + n];
                         a.Y[(long long)row * a.ldy + a.col0 + n] = v;
                     }
+                }
+            }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+//  The same GEMM on the f32 matrix cores.  v_mfma_f32_32x32x2_f32 is bitwise an ascending-k fmaf chain starting from C,
+//  subnormals included (scripts/ubench/mfma_f32_order.hip), so AC-1 maps onto it exactly: chain s_j of a 32-term chunk
+//  (k = j, j+4, ..., j+28 from +0) is four dependent MFMAs whose two k's are (j+8i, j+8i+4); the four chains are four
+//  independent accumulators; chunk = (s0+s1)+(s2+s3) and the running total are VALU adds that overlap the next MFMAs.
+//  Workgroup = 4 waves on a 64-row x 128-column output tile, wave (wr, wc) owns 32 rows x 64 columns (two column halves).  No LDS: lane l
+//  reads its row's X' (implicit 'same' conv window) straight from global as four float4 per chunk -- lanes l and l+32 together
+//  consume the row's whole 128-byte chunk;
+//  the B operand of both column halves comes out of ONE v_permlane32_swap of two registers of the usual 64 x 32 weight tile.
+// -----------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMmRows = 64;
+
+// the lane's four float4 of one 32-term chunk of X': k = 8i + 4*(lane>>5) + {0..3}, i = 0..3 (q[i][j] feeds chain j, pair i)
+struct MmA { f32x4 q[4]; };
+struct MmRow { const float* seq; int t; bool ok; };          // this lane's row: start of its sequence, time index, in range
+__device__ __forceinline__ void mm_load_a(MmA& A, const GemmArgs& a, const MmRow& r, int kg /* first k of the lane's first float4 */, int& tap, int& c)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r.ok && kg + 8 * i < a.K) {
+            if (a.kw == 1) v = *reinterpret_cast<const f32x4*>(r.seq + (long long)r.t * a.ldx + kg + 8 * i);
+            else {
+                const int ts = r.t + tap - a.pl;
+                if (ts >= 0 && ts < a.T) v = *reinterpret_cast<const f32x4*>(r.seq + (long long)ts * a.ldx + c);
+            }
+        }
+        A.q[i] = v;
+        c += 8;
+        if (c >= a.Cin) { c -= a.Cin; ++tap; }
+    }
+}
+
+__global__ void __launch_bounds__(256) tc_gemm_mfma_kernel(GemmArgs a)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;                  // wave tile: rows wr*32.., columns (2*blockIdx.y + wc)*64..
+    const int row0 = blockIdx.x * kMmRows + wr * 32;
+    const int nblk_total = (a.N + 63) / 64, nchunk = (a.K + 31) / 32;
+    const int nb = blockIdx.y * 2 + wc;
+    if (nb >= nblk_total) return;
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 tot0 = zero, tot1 = zero;                          // column halves
+    MmRow r;
+    {
+        const int row = row0 + (lane & 31);
+        r.ok = row < a.rows;
+        r.t = r.ok ? row % a.T : 0;
+        r.seq = a.X + (long long)(r.ok ? row - r.t : 0) * a.ldx;
+    }
+    const int hh = (lane >> 5) * 4;
+    int tap = 0, c = hh;                                      // conv window position of the lane's next float4 (Cin >= 8, multiple of 4)
+    const float* wt = a.Wt + (long long)nb * nchunk * kTile;
+    Tile tl;
+    MmA A;
+    load_tile(tl, wt, lane);
+    mm_load_a(A, a, r, hh, tap, c);
+    for (int ch = 0; ch < nchunk; ++ch) {
+        Tile tn;
+        MmA An;
+        if (ch + 1 < nchunk) {                                // next chunk's operands travel while this chunk's 32 MFMAs run
+            load_tile(tn, wt + (long long)(ch + 1) * kTile, lane);
+            mm_load_a(An, a, r, (ch + 1) * 32 + hh, tap, c);
+        }
+        f32x16 acc0[4], acc1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                         // k pair (j + 8i, j + 8i + 4)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                     // chain
+                const int ka = j + 8 * i;
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tl.w[ka]), __float_as_uint(tl.w[ka + 4]), false, false);
+                const float b0 = __uint_as_float(sw[0]), b1 = __uint_as_float(sw[1]);
+                const float a0 = A.q[i][j];
+                acc0[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, i == 0 ? zero : acc0[j], 0, 0, 0);
+                acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, i == 0 ? zero : acc1[j], 0, 0, 0);
+            }
+        }
+        const f32x16 c0 = (acc0[0] + acc0[1]) + (acc0[2] + acc0[3]);
+        const f32x16 c1 = (acc1[0] + acc1[1]) + (acc1[2] + acc1[3]);
+        tot0 = ch == 0 ? c0 : tot0 + c0;
+        tot1 = ch == 0 ? c1 : tot1 + c1;
+        if (ch + 1 < nchunk) { tl = tn; A = An; }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int n = nb * 64 + h * 32 + (lane & 31);
+        if (n < a.N) {
+            const float bv = a.bias ? a.bias[n] : 0.0f;
+            const float iv = a.bn_inv ? a.bn_inv[n] : 1.0f, sv = a.bn_inv ? a.bn_shift[n] : 0.0f;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = row0 + (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
+                if (row < a.rows) {
+                    float v = h == 0 ? tot0[rr] : tot1[rr];
+                    if (a.bias) v = v + bv;
+                    v = tc_act(v, a.act);
+                    if (a.bn_inv) { const float y = v * iv; v = y + sv; }          // x*inv + (beta - mean*inv)
+                    if (a.add1) v = v + a.add1[(long long)row * a.ld1 + n];
+                    if (a.add2) v = v + a.add2[(long long)(row / a.T) * a.ld2 + n];
+                    a.Y[(long long)row * a.ldy + a.col0 + n] = v;
                 }
             }
         }
@@ -252,6 +361,7 @@ struct DecArgs {
     int32_t* status;
     long long packed_bytes;
     unsigned long long* prof;   // optional [iters][16] s_memtime stamps of workgroup 0 (tuning aid)
+    int nbias;                  // total bias floats over the decoder stages
 };
 // LDS map of the decoder (float offsets)
 struct DecLds { int cat, vec, h[5], frame, ctx, part, sc, p, cp, lg, al, q; };
@@ -515,14 +625,17 @@ __device__ __forceinline__ int decg_off(int wt_bytes, const DecgPos& p, int nchu
 {
     return wt_bytes + ((((p.m << lg) + g) * nchunk + p.ch) << 13);        // kTile * 4 = 8192 bytes per tile
 }
-// local block m, lane l: chunk values summed in order (AC-1)
+// local block m, lane l: chunk values summed in order (AC-1); the LDS reads of four chunks are issued together
 __device__ __forceinline__ float decg_combine(int o_part, int nchunk, int m, int l)
 {
-    float v = 0.0f;
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const float c = lds[o_part + (m * nchunk + ch) * 64 + l];
-        v = ch == 0 ? c : v + c;
+    const int b = o_part + m * nchunk * 64 + l;
+    float v = lds[b];
+    int ch = 1;
+    for (; ch + 3 < nchunk; ch += 4) {
+        const float c0 = lds[b + ch * 64], c1 = lds[b + (ch + 1) * 64], c2 = lds[b + (ch + 2) * 64], c3 = lds[b + (ch + 3) * 64];
+        v = v + c0; v = v + c1; v = v + c2; v = v + c3;
     }
+    for (; ch < nchunk; ++ch) v = v + lds[b + ch * 64];
     return v;
 }
 // all 512 threads: collect n values of exchange `epoch` into lds[o_dst ..)
@@ -550,7 +663,8 @@ __device__ __forceinline__ void decg_store(unsigned long long* p, unsigned epoch
     __hip_atomic_store((tgu64*)p, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 }
-// running sums over lds[o .. o+T) in index order (one add chain), one wave, staged through registers
+// running sums over lds[o .. o+T) in index order (one add chain), one wave, staged through registers; eight v_readlane
+// are issued ahead of the dependent adds (padding lanes hold 0 and their results are never stored)
 __device__ __forceinline__ void decg_scan(int o, int T, int lane, bool inclusive)
 {
     float run = 0.0f;
@@ -558,11 +672,18 @@ __device__ __forceinline__ void decg_scan(int o, int T, int lane, bool inclusive
         const int n = T - base < 64 ? T - base : 64;
         const float v = (base + lane < T) ? lds[o + base + lane] : 0.0f;
         float res = 0.0f;
-        for (int i = 0; i < n; ++i) {
-            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
-            const float nxt = run + x;
-            if (lane == i) res = inclusive ? nxt : run;
-            run = nxt;
+        for (int i = 0; i < n; i += 8) {
+            float x[8], r[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (i + k) & 63));
+            float prev = run;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                r[k] = prev + x[k];
+                if (lane == i + k) res = inclusive ? r[k] : prev;
+                prev = r[k];
+            }
+            run = prev;
         }
         if (base + lane < T) lds[o + base + lane] = res;
     }
@@ -571,7 +692,7 @@ __device__ __forceinline__ void decg_scan(int o, int T, int lane, bool inclusive
 // The decoder step is a table-driven sequence of matvec stages, so the tile-streaming code exists ONCE (inlined in the stage
 // loop): twelve inlined copies made the register allocator spill ~1000 VGPRs, and a real call costs ~4000 cycles because the
 // callee saves its VGPRs to scratch (scripts/ubench/gemv_call.hip).
-enum { DS_W = 0, DS_BIAS, DS_K, DS_N, DS_X, DS_DST, DS_ACT, DS_SPLIT, DS_POST, DS_P0, DS_P1, DS_P2, DS_STRIDE };
+enum { DS_W = 0, DS_BIAS, DS_K, DS_N, DS_X, DS_DST, DS_ACT, DS_SPLIT, DS_POST, DS_P0, DS_P1, DS_P2, DS_BIASG, DS_STRIDE };
 enum { DP_NONE = 0, DP_CAT_ATT, DP_GATES, DP_CAND, DP_QUERY, DP_PROJ, DP_OUT };
 enum { DA_NONE = 0, DA_SIGMOID, DA_TANH, DA_RELU };
 
@@ -610,6 +731,9 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     const int o_scp = o; o += Tp * 8;
     const int o_abort = o; o += 4;
     const int o_tab = o; o += 16 * DS_STRIDE;             // stage table
+    const int o_nv = o; o += A;                           // normed_v, attention bias
+    const int o_ab = o; o += A;
+    const int o_bias = o; o += a.nbias;                   // every stage's bias vector, in stage order
     const int o_part = o;
 
     const float* init = a.init + (long long)n * (AS + a.layers * DR);
@@ -619,12 +743,14 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     for (int i = tid; i < ENC; i += 512) lds[o_ctx + i] = 0.0f;
     for (int i = tid; i < Tp; i += 512) lds[o_al + i] = i == 0 ? 1.0f : 0.0f;
     if (tid < 4) LDSI(o_abort + tid) = 0;
+    for (int i = tid; i < A; i += 512) { lds[o_nv + i] = P[a.w.nv + i]; lds[o_ab + i] = P[a.w.ab + i]; }
     const int nst = 7 + 2 * a.layers;
     if (tid == 0) {
-        int s = 0;
+        int s = 0, bo = o_bias;
         auto put = [&](long long w, long long b, int K, int N, int x, int dst, int act, int split, int post, int p0, int p1, int p2) {
             const int q = o_tab + s * DS_STRIDE;
-            LDSI(q + DS_W) = (int)(w * 4); LDSI(q + DS_BIAS) = (int)b; LDSI(q + DS_K) = K; LDSI(q + DS_N) = N; LDSI(q + DS_X) = x;
+            LDSI(q + DS_W) = (int)(w * 4); LDSI(q + DS_BIAS) = b >= 0 ? bo : -1; LDSI(q + DS_BIASG) = (int)b;
+            if (b >= 0) bo += N; LDSI(q + DS_K) = K; LDSI(q + DS_N) = N; LDSI(q + DS_X) = x;
             LDSI(q + DS_DST) = dst; LDSI(q + DS_ACT) = act; LDSI(q + DS_SPLIT) = split; LDSI(q + DS_POST) = post;
             LDSI(q + DS_P0) = p0; LDSI(q + DS_P1) = p1; LDSI(q + DS_P2) = p2;
             ++s;
@@ -648,9 +774,33 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
         put(a.w.oW, a.w.ob, DR, M * R, o_y, o_out, DA_NONE, 1, DP_OUT, 0, 0, 0);
     }
     __syncthreads();
+    for (int st = 0; st < nst; ++st) {                    // bias vectors -> LDS
+        const int q = o_tab + st * DS_STRIDE, bl = LDSI(q + DS_BIAS), bg = LDSI(q + DS_BIASG), N = LDSI(q + DS_N);
+        if (bl >= 0) for (int i = tid; i < N; i += 512) lds[bl + i] = P[bg + i];
+    }
+    __syncthreads();
     const int nAch = A / 32;
     unsigned ep = 0;                                      // exchanges completed so far
     bool ok = true;
+    Tile t0, t1, t2;
+    // request the first three tiles of stage `sn` for this wave
+#define DECG_PREFETCH(sn)                                                                                                       \
+    {                                                                                                                            \
+        const int qn_ = o_tab + (sn) * DS_STRIDE;                                                                                \
+        const int wn_ = __builtin_amdgcn_readfirstlane(LDSI(qn_ + DS_W)), Kn_ = __builtin_amdgcn_readfirstlane(LDSI(qn_ + DS_K)); \
+        const int Nn_ = __builtin_amdgcn_readfirstlane(LDSI(qn_ + DS_N)), sp_ = __builtin_amdgcn_readfirstlane(LDSI(qn_ + DS_SPLIT)); \
+        const int gn_ = sp_ ? g : 0, lgn_ = sp_ ? lg : 0;                                                                        \
+        const int ncn_ = (Kn_ + 31) >> 5, nbn_ = (Nn_ + 63) >> 6;                                                                \
+        const int ntn_ = nbn_ > gn_ ? ((nbn_ - gn_ + (1 << lgn_) - 1) >> lgn_) * ncn_ : 0;                                       \
+        DecgPos q0_{0, 0}, q1_, q2_;                                                                                             \
+        decg_adv(q0_, wave, ncn_);                                                                                               \
+        q1_ = q0_; decg_adv(q1_, 8, ncn_);                                                                                       \
+        q2_ = q1_; decg_adv(q2_, 8, ncn_);                                                                                       \
+        if (wave < ntn_) load_tile_b(t0, rs, lane * 16, decg_off(wn_, q0_, ncn_, gn_, lgn_));                                    \
+        if (wave + 8 < ntn_) load_tile_b(t1, rs, lane * 16, decg_off(wn_, q1_, ncn_, gn_, lgn_));                                \
+        if (wave + 16 < ntn_) load_tile_b(t2, rs, lane * 16, decg_off(wn_, q2_, ncn_, gn_, lgn_));                               \
+    }
+    DECG_PREFETCH(0)
 #define TWV_STAMP(k) if (a.prof && blockIdx.x == 0 && tid == 0) a.prof[it * 16 + (k)] = __builtin_amdgcn_s_memtime();
 
     for (int it = 0; it < a.iters && ok; ++it) {
@@ -666,17 +816,15 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
             const int nmine = nblk > gg ? (nblk - gg + GG - 1) >> lgg : 0;
             const int ntile = nmine * nchunk;
             if (st == 0) { TWV_STAMP(0) }
-            // ---- this workgroup's tiles: wave w takes local tiles w, w+8, ... (three in flight), partials to LDS
+            if (st == 5) { TWV_STAMP(10) }
+            // ---- this workgroup's tiles: wave w takes local tiles w, w+8, ... (three in flight), partials to LDS.  The first three
+            // were requested while the previous stage was still combining / exchanging (weights do not depend on data).
             {
                 const int vo = lane * 16;
-                Tile t0, t1, t2;
                 DecgPos p0{0, 0}, p1, p2;
                 decg_adv(p0, wave, nchunk);
                 p1 = p0; decg_adv(p1, 8, nchunk);
                 p2 = p1; decg_adv(p2, 8, nchunk);
-                if (wave < ntile) load_tile_b(t0, rs, vo, decg_off(w_bytes, p0, nchunk, gg, lgg));
-                if (wave + 8 < ntile) load_tile_b(t1, rs, vo, decg_off(w_bytes, p1, nchunk, gg, lgg));
-                if (wave + 16 < ntile) load_tile_b(t2, rs, vo, decg_off(w_bytes, p2, nchunk, gg, lgg));
                 for (int i = wave; i < ntile; i += 24) {
                     {
                         const float r = dot_ldso(t0, xo + p0.ch * 32);
@@ -700,8 +848,12 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                         if (i + 40 < ntile) load_tile_b(t2, rs, vo, decg_off(w_bytes, p2, nchunk, gg, lgg));
                     }
                 }
+                if (st == 5) { TWV_STAMP(11) }
+                DECG_PREFETCH(st + 1 < nst ? st + 1 : 0)
             }
+            if (st == 5) { TWV_STAMP(12) }
             __syncthreads();
+            if (st == 5) { TWV_STAMP(13) }
             // ---- epilogue: chunk sums in order (AC-1) + bias + activation; split stages publish and all-gather
             {
                 const bool xch = split && G > 1;
@@ -711,14 +863,16 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                     const int m = qq >> 6, j = (((m << lgg) + gg) << 6) + (qq & 63);
                     if (j < N) {
                         float v = decg_combine(o_part, nchunk, m, qq & 63);
-                        if (bias >= 0) v = v + P[bias + j];
+                        if (bias >= 0) v = v + lds[bias + j];
                         if (act == DA_SIGMOID) v = sigmoid_e(v);
                         else if (act == DA_TANH) v = tanh_e(v);
                         else if (act == DA_RELU) v = v > 0.0f ? v : 0.0f;
                         if (xch) decg_store(Xb + j, ep, v); else lds[dst + j] = v;
                     }
                 }
+                if (st == 5) { TWV_STAMP(14) }
                 if (xch) decg_gather(Xb, N, ep, dst, tid, o_abort);
+                if (st == 5) { TWV_STAMP(15) }
                 __syncthreads();
                 ok = LDSI(o_abort) == 0;
             }
@@ -768,19 +922,22 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                 TWV_STAMP(3)
                 // [RECALLED-TF BahdanauMonotonicAttention.__call__] score for the time steps t = g, g+G, ...: one (t, chunk) per thread
                 const int nt = T > g ? (T - g + G - 1) >> lg : 0;
-                for (int task = tid; task < nt * nAch; task += 512) {
-                    const int tl = task / nAch, ch = task - tl * nAch, t = (tl << lg) + g;
-                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-                    const float* kr = keys + (long long)t * A + ch * 32;
-#pragma unroll 2
-                    for (int j = 0; j < 32; j += 4) {
-                        const int jj = ch * 32 + j;
-                        s0 = fma_(P[a.w.nv + jj + 0], tanh_e((kr[j + 0] + lds[o_pq + jj + 0]) + P[a.w.ab + jj + 0]), s0);
-                        s1 = fma_(P[a.w.nv + jj + 1], tanh_e((kr[j + 1] + lds[o_pq + jj + 1]) + P[a.w.ab + jj + 1]), s1);
-                        s2 = fma_(P[a.w.nv + jj + 2], tanh_e((kr[j + 2] + lds[o_pq + jj + 2]) + P[a.w.ab + jj + 2]), s2);
-                        s3 = fma_(P[a.w.nv + jj + 3], tanh_e((kr[j + 3] + lds[o_pq + jj + 3]) + P[a.w.ab + jj + 3]), s3);
-                    }
-                    lds[o_scp + tl * 8 + ch] = (s0 + s1) + (s2 + s3);
+                // one thread per (t, chunk, chain k): s_k = fma chain over j = k, k+4, ..., k+28; the four chains of a chunk sit in
+                // adjacent lanes and are combined as (s0+s1)+(s2+s3)
+                for (int task0 = 0; task0 < nt * nAch * 4; task0 += 512) {
+                    const int task = task0 + tid;
+                    const bool live = task < nt * nAch * 4;
+                    const int k = task & 3, tc = task >> 2;
+                    const int tl = live ? tc / nAch : 0, ch = live ? tc - tl * nAch : 0, t = (tl << lg) + g;
+                    float sk = 0.f;
+                    const float* kr = keys + (long long)t * A + ch * 32 + k;
+                    const int jb = ch * 32 + k;
+#pragma unroll
+                    for (int j = 0; j < 32; j += 4) sk = fma_(lds[o_nv + jb + j], tanh_e((kr[j] + lds[o_pq + jb + j]) + lds[o_ab + jb + j]), sk);
+                    const float s1 = __shfl_xor(sk, 1);
+                    const float pr = (k & 1) ? s1 + sk : sk + s1;       // lanes k=0,1 hold s0+s1 ; k=2,3 hold s2+s3 (operand order as written)
+                    const float p2 = __shfl_xor(pr, 2);
+                    if (live && k == 0) lds[o_scp + tl * 8 + ch] = pr + p2;
                 }
                 __syncthreads();
                 {
@@ -866,6 +1023,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     }
     if (!ok && tid == 0) a.status[0] = 21;                    // exchange watchdog
 #undef TWV_STAMP
+#undef DECG_PREFETCH
 }
 
 // =====================================================================================================
@@ -985,6 +1143,7 @@ extern "C" size_t twv_tacotron_blob_floats(const twv_tacotron* h) { return (size
 extern "C" int twv_tacotron_set_option(twv_tacotron* h, const char* name, int value)
 {
     if (!h || !name) return twv_fail(TWV_E_INVALID, "null argument");
+    if (!strcmp(name, "gemm_valu")) { g_gemm_valu = value ? 1 : 0; return TWV_OK; }
     if (!strcmp(name, "decoder_groups")) {
         if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return twv_fail(TWV_E_INVALID, "decoder_groups must be -1, 0, 1, 2, 4 or 8");
         h->dec_groups = value;
@@ -1062,7 +1221,11 @@ static void launch_gemm(hipStream_t st, const float* P, const float* X, int ldx,
     a.bias = bias ? P + bias->off : nullptr; a.act = act;
     a.bn_inv = inv ? P + inv->off : nullptr; a.bn_shift = shift ? P + shift->off : nullptr;
     a.add1 = add1; a.ld1 = ld1; a.add2 = add2; a.ld2 = ld2; a.Y = Y; a.ldy = ldy; a.col0 = col0;
-    hipLaunchKernelGGL(tc_gemm_kernel, dim3((rows + kGemmRows - 1) / kGemmRows), dim3(256), kGemmRows * kGemmKS * 4, st, a);
+    if (g_gemm_valu)
+        hipLaunchKernelGGL(tc_gemm_kernel, dim3((rows + kGemmRows - 1) / kGemmRows), dim3(256), kGemmRows * kGemmKS * 4, st, a);
+    else {
+        hipLaunchKernelGGL(tc_gemm_mfma_kernel, dim3((rows + kMmRows - 1) / kMmRows, (W.N + 127) / 128), dim3(256), 0, st, a);
+    }
 }
 
 // modules.py:25-74 for `rows` = N*T rows
@@ -1165,6 +1328,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
     da.DR = DR; da.layers = d.dec_layer_num; da.iters = d.max_iters; da.mel = mel; da.align = alignments; da.status = status;
     da.packed_bytes = (long long)h->packed_floats * 4;
     da.prof = h->prof;
+    da.nbias = da.D0 + da.D1 + 3 * AS + DR + d.dec_layer_num * 3 * DR + M * R;
     {
         const int Tp = (T + 3) / 4 * 4;
         const int ain = da.D1 + ENC;
@@ -1193,7 +1357,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             ga.d = da; ga.G = G; ga.exch = reinterpret_cast<unsigned long long*>(exch);
             HIPCHK(hipMemsetAsync(exch, 0, (size_t)N * 2 * kExN * 8, st));
             const long long fl = 1024 * 2 + 512 * 2 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + (M * R + 63) / 64 * 64 + Tp * 4 + A +
-                                 Tp * 8 + 4 + 16 * 12 + pmax;
+                                 Tp * 8 + 4 + 16 * 13 + 2 * A + da.nbias + pmax;
             const size_t shm = (size_t)fl * 4;
             if (shm > 160 * 1024) return twv_fail(TWV_E_UNSUPPORTED, "decoder LDS footprint exceeds 160 KiB (t_in too large)");
             HIPCHK(hipFuncSetAttribute((const void*)tc_decoder_g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
