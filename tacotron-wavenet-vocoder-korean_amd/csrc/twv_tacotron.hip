@@ -613,6 +613,7 @@ struct DecGArgs {
     DecArgs d;
     int G;
     unsigned long long* exch;       // [N][2][kExN]
+    int kv_lds;                     // 1: key rows / memory columns of the workgroup fit in LDS
 };
 
 struct DecgPos { int m, ch; };
@@ -689,6 +690,27 @@ __device__ __forceinline__ void decg_scan(int o, int T, int lane, bool inclusive
     }
 }
 
+// one batch of a running sum in index order: lane i holds element i (padding lanes hold 0); returns the lane's exclusive or
+// inclusive prefix continued from `run` and advances `run` past the batch (one add chain, eight v_readlane issued ahead)
+__device__ __forceinline__ float decg_scan_regs(float v, float& run, int n, int lane, bool inclusive)
+{
+    float res = 0.0f;
+    for (int i = 0; i < n; i += 8) {
+        float x[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) x[kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (i + kk) & 63));
+        float prev = run;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const float nx = prev + x[kk];
+            if (lane == i + kk) res = inclusive ? nx : prev;
+            prev = nx;
+        }
+        run = prev;
+    }
+    return res;
+}
+
 // The decoder step is a table-driven sequence of matvec stages, so the tile-streaming code exists ONCE (inlined in the stage
 // loop): twelve inlined copies made the register allocator spill ~1000 VGPRs, and a real call costs ~4000 cycles because the
 // callee saves its VGPRs to scratch (scripts/ubench/gemv_call.hip).
@@ -734,6 +756,10 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     const int o_nv = o; o += A;                           // normed_v, attention bias
     const int o_ab = o; o += A;
     const int o_bias = o; o += a.nbias;                   // every stage's bias vector, in stage order
+    const bool kv = ga.kv_lds != 0;                       // this workgroup's key rows / memory columns held in LDS
+    const int nt_all = T > g ? (T - g + G - 1) >> lg : 0;
+    const int o_keys = o; o += kv ? ((T + G - 1) >> lg) * A : 0;
+    const int o_memo = o; o += kv ? T * (ENC >> lg) : 0;
     const int o_part = o;
 
     const float* init = a.init + (long long)n * (AS + a.layers * DR);
@@ -744,6 +770,11 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     for (int i = tid; i < Tp; i += 512) lds[o_al + i] = i == 0 ? 1.0f : 0.0f;
     if (tid < 4) LDSI(o_abort + tid) = 0;
     for (int i = tid; i < A; i += 512) { lds[o_nv + i] = P[a.w.nv + i]; lds[o_ab + i] = P[a.w.ab + i]; }
+    if (kv) {
+        for (int i = tid; i < nt_all * A; i += 512) { const int tl = i / A, j = i - tl * A; lds[o_keys + i] = keys[(long long)((tl << lg) + g) * A + j]; }
+        const int ncol = ENC >> lg;
+        for (int i = tid; i < T * ncol; i += 512) { const int t = i / ncol, cl = i - t * ncol; lds[o_memo + i] = memo[(long long)t * ENC + g * ncol + cl]; }
+    }
     const int nst = 7 + 2 * a.layers;
     if (tid == 0) {
         int s = 0, bo = o_bias;
@@ -931,9 +962,14 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                     const int tl = live ? tc / nAch : 0, ch = live ? tc - tl * nAch : 0, t = (tl << lg) + g;
                     float sk = 0.f;
                     const float* kr = keys + (long long)t * A + ch * 32 + k;
-                    const int jb = ch * 32 + k;
+                    const int jb = ch * 32 + k, kl = o_keys + tl * A + jb;
+                    if (kv) {
 #pragma unroll
-                    for (int j = 0; j < 32; j += 4) sk = fma_(lds[o_nv + jb + j], tanh_e((kr[j] + lds[o_pq + jb + j]) + lds[o_ab + jb + j]), sk);
+                        for (int j = 0; j < 32; j += 4) sk = fma_(lds[o_nv + jb + j], tanh_e((lds[kl + j] + lds[o_pq + jb + j]) + lds[o_ab + jb + j]), sk);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 32; j += 4) sk = fma_(lds[o_nv + jb + j], tanh_e((kr[j] + lds[o_pq + jb + j]) + lds[o_ab + jb + j]), sk);
+                    }
                     const float s1 = __shfl_xor(sk, 1);
                     const float pr = (k & 1) ? s1 + sk : sk + s1;       // lanes k=0,1 hold s0+s1 ; k=2,3 hold s2+s3 (operand order as written)
                     const float p2 = __shfl_xor(pr, 2);
@@ -956,33 +992,34 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                     ok = LDSI(o_abort) == 0;
                 }
                 TWV_STAMP(4)
-                // monotonic attention recurrence (redundant): safe_cumprod pieces, two sequential sums
-                for (int t = tid; t < T; t += 512) {
-                    float om = 1.0f - lds[o_p + t];
-                    const float tiny = 1.17549435e-38f;
-                    om = om < tiny ? tiny : (om > 1.0f ? 1.0f : om);
-                    lds[o_q + t] = log_e(om);
+                // monotonic attention recurrence (redundant in every workgroup), all in wave 0 and in registers:
+                // cumprod(1 - p) as exp(exclusive cumsum(log(clip(1 - p)))) [RECALLED-TF safe_cumprod], then
+                // alignments = p * cumprod * inclusive cumsum(previous / clip(cumprod, 1e-10, 1))
+                if (wave == 0) {
+                    float run = 0.0f, run2 = 0.0f;
+                    for (int base = 0; base < T; base += 64) {
+                        const int t = base + lane, nb_ = T - base < 64 ? T - base : 64;
+                        const bool live = t < T;
+                        const float pv = live ? lds[o_p + t] : 0.0f;
+                        float om = 1.0f - pv;
+                        const float tiny = 1.17549435e-38f;
+                        om = om < tiny ? tiny : (om > 1.0f ? 1.0f : om);
+                        const float lq = live ? log_e(om) : 0.0f;
+                        const float ex = decg_scan_regs(lq, run, nb_, lane, false);
+                        const float cpv = exp_e(ex);
+                        float den = cpv;
+                        den = den < 1e-10f ? 1e-10f : (den > 1.0f ? 1.0f : den);
+                        const float q2 = live ? div_(lds[o_al + t], den) : 0.0f;
+                        const float cs = decg_scan_regs(q2, run2, nb_, lane, true);
+                        if (live) {
+                            const float pc = pv * cpv;
+                            const float al = pc * cs;
+                            lds[o_al + t] = al;
+                            if (a.align && g == 0) a.align[((long long)n * T + t) * a.iters + it] = al;      // tacotron.py:223
+                        }
+                    }
+                    for (int t = T + lane; t < Tp; t += 64) lds[o_al + t] = 0.0f;
                 }
-                __syncthreads();
-                if (wave == 0) decg_scan(o_q, T, lane, false);
-                __syncthreads();
-                for (int t = tid; t < T; t += 512) {
-                    const float cpv = exp_e(lds[o_q + t]);
-                    lds[o_cp + t] = cpv;
-                    float den = cpv;
-                    den = den < 1e-10f ? 1e-10f : (den > 1.0f ? 1.0f : den);
-                    lds[o_q + t] = div_(lds[o_al + t], den);
-                }
-                __syncthreads();
-                if (wave == 0) decg_scan(o_q, T, lane, true);
-                __syncthreads();
-                for (int t = tid; t < T; t += 512) {
-                    const float pc = lds[o_p + t] * lds[o_cp + t];
-                    const float al = pc * lds[o_q + t];
-                    lds[o_al + t] = al;
-                    if (a.align && g == 0) a.align[((long long)n * T + t) * a.iters + it] = al;      // tacotron.py:223
-                }
-                for (int t = T + tid; t < Tp; t += 512) lds[o_al + t] = 0.0f;
                 __syncthreads();
                 TWV_STAMP(5)
                 // rnn_wrappers.py:390 context = alignments . values: workgroup g takes the columns [g*ENC/G, (g+1)*ENC/G) -- its XCD's
@@ -993,12 +1030,22 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                         const int cl = task % ncol, ch = task / ncol;
                         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
                         const int ta = ch * 32, tb = T < ta + 32 ? T : ta + 32;
-                        const float* mp = memo + c0 + cl;
-                        for (int t = ta; t < tb; t += 4) {
-                            s0 = fma_(mp[(long long)t * ENC], lds[o_al + t], s0);
-                            if (t + 1 < tb) s1 = fma_(mp[(long long)(t + 1) * ENC], lds[o_al + t + 1], s1);
-                            if (t + 2 < tb) s2 = fma_(mp[(long long)(t + 2) * ENC], lds[o_al + t + 2], s2);
-                            if (t + 3 < tb) s3 = fma_(mp[(long long)(t + 3) * ENC], lds[o_al + t + 3], s3);
+                        if (kv) {
+                            const int mo = o_memo + cl;
+                            for (int t = ta; t < tb; t += 4) {
+                                s0 = fma_(lds[mo + t * ncol], lds[o_al + t], s0);
+                                if (t + 1 < tb) s1 = fma_(lds[mo + (t + 1) * ncol], lds[o_al + t + 1], s1);
+                                if (t + 2 < tb) s2 = fma_(lds[mo + (t + 2) * ncol], lds[o_al + t + 2], s2);
+                                if (t + 3 < tb) s3 = fma_(lds[mo + (t + 3) * ncol], lds[o_al + t + 3], s3);
+                            }
+                        } else {
+                            const float* mp = memo + c0 + cl;
+                            for (int t = ta; t < tb; t += 4) {
+                                s0 = fma_(mp[(long long)t * ENC], lds[o_al + t], s0);
+                                if (t + 1 < tb) s1 = fma_(mp[(long long)(t + 1) * ENC], lds[o_al + t + 1], s1);
+                                if (t + 2 < tb) s2 = fma_(mp[(long long)(t + 2) * ENC], lds[o_al + t + 2], s2);
+                                if (t + 3 < tb) s3 = fma_(mp[(long long)(t + 3) * ENC], lds[o_al + t + 3], s3);
+                            }
                         }
                         lds[o_part + ch * ncol + cl] = (s0 + s1) + (s2 + s3);
                     }
@@ -1356,8 +1403,11 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             DecGArgs ga;
             ga.d = da; ga.G = G; ga.exch = reinterpret_cast<unsigned long long*>(exch);
             HIPCHK(hipMemsetAsync(exch, 0, (size_t)N * 2 * kExN * 8, st));
-            const long long fl = 1024 * 2 + 512 * 2 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + (M * R + 63) / 64 * 64 + Tp * 4 + A +
-                                 Tp * 8 + 4 + 16 * 13 + 2 * A + da.nbias + pmax;
+            long long fl = 1024 * 2 + 512 * 2 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + (M * R + 63) / 64 * 64 + Tp * 4 + A +
+                           Tp * 8 + 4 + 16 * 13 + 2 * A + da.nbias + pmax;
+            const long long kvf = (long long)((T + G - 1) / G) * A + (long long)T * (ENC / G);
+            ga.kv_lds = (fl + kvf) * 4 <= 160 * 1024 ? 1 : 0;
+            if (ga.kv_lds) fl += kvf;
             const size_t shm = (size_t)fl * 4;
             if (shm > 160 * 1024) return twv_fail(TWV_E_UNSUPPORTED, "decoder LDS footprint exceeds 160 KiB (t_in too large)");
             HIPCHK(hipFuncSetAttribute((const void*)tc_decoder_g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
