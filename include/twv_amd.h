@@ -174,6 +174,13 @@ int twv_wavenet_train_output_width(const twv_wavenet_trainer* h);          /* n_
  * audio (B, n_samples) float in [-1,1]; lc (B, n_samples/hop, lc_channels); gc_ids (B) int32. */
 int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* params, const float* audio, const float* lc,
                                 const int32_t* gc_ids, void* workspace, float* loss, float* grads, void* stream);
+/* model.py:300-312 optional L2 term over the non-bias variables (after loss_grad): loss += strength*sum(w^2)/2, grads += strength*w.
+ * workspace: the trainer's workspace (reused). */
+int twv_wavenet_train_l2(twv_wavenet_trainer* h, const float* params, double strength, void* workspace, float* loss, float* grads,
+                         void* stream);
+/* model.py:330-331 tf.clip_by_global_norm on the flat gradient buffer: grads <- grads*pre_scale * clip_norm / max(||grads*pre_scale||, clip_norm).
+ * scratch: n + 1024 floats. */
+int twv_clip_by_global_norm(float* grads, int64_t n, double pre_scale, double clip_norm, void* scratch, void* stream);
 /* tf.train.AdamOptimizer.apply_gradients (t = 1-based update count) on grads*grad_scale, then the EMA shadow update. */
 int twv_adam_ema_step(float* params, const float* grads, float* m, float* v, float* ema, int64_t n, double lr, double beta1,
                       double beta2, double eps, int64_t t, double ema_decay, double grad_scale, void* stream);

@@ -88,6 +88,8 @@ def lib():
         getattr(L, n).argtypes = [vp]; getattr(L, n).restype = C.c_size_t
     L.twv_wavenet_train_output_width.argtypes = [vp]
     L.twv_wavenet_train_loss_grad.argtypes = [vp, fp, fp, fp, ip, vp, fp, fp, vp]
+    L.twv_wavenet_train_l2.argtypes = [vp, fp, C.c_double, vp, fp, fp, vp]
+    L.twv_clip_by_global_norm.argtypes = [fp, C.c_int64, C.c_double, C.c_double, vp, vp]
     L.twv_adam_ema_step.argtypes = [fp, fp, fp, fp, fp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
                                     C.c_double, C.c_double, vp]
     _lib = L
@@ -102,7 +104,8 @@ EXPORTS = ["twv_last_error", "twv_version", "twv_wavenet_create", "twv_wavenet_d
            "twv_eval_elementwise64", "twv_selftest", "twv_tacotron_create", "twv_tacotron_destroy", "twv_tacotron_blob_floats",
            "twv_tacotron_packed_bytes", "twv_tacotron_workspace_bytes", "twv_tacotron_pack", "twv_tacotron_infer", "twv_tacotron_set_profile_buffer", "twv_tacotron_set_option",
            "twv_wavenet_train_create", "twv_wavenet_train_destroy", "twv_wavenet_train_param_floats", "twv_wavenet_train_workspace_bytes",
-           "twv_wavenet_train_output_width", "twv_wavenet_train_loss_grad", "twv_adam_ema_step"]
+           "twv_wavenet_train_output_width", "twv_wavenet_train_loss_grad", "twv_adam_ema_step", "twv_wavenet_train_l2",
+           "twv_clip_by_global_norm"]
 
 
 class TacoDims(C.Structure):

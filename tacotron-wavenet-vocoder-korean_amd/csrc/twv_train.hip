@@ -379,6 +379,99 @@ __global__ void tr_mol_loss_kernel(const float* y, const float* audio, int B, in
     }
 }
 
+
+// ---- one-hot (mu-law) input model: model.py:257-271 (mu_law_encode -> one_hot -> causal conv of width 2 over Q channels) ----
+// x0[(b,t)][j] = Wc[0][q[b,t-1]][j] + Wc[1][q[b,t]][j]   (a one-hot row times a kernel is a row gather); t = 0 is masked
+__global__ void tr_onehot_causal_fwd_kernel(const float* Wc, const int32_t* q, float* x0, int B, int T, int Tn, int Q)
+{
+    const long long total = (long long)B * Tn * 32;
+    GRID_STRIDE(i, total) {
+        const int j = (int)(i & 31);
+        const long long r = i >> 5;
+        const int t = (int)(r % Tn), b = (int)(r / Tn);
+        float v = 0.0f;
+        if (t >= 1) {
+            const int qa = q[(long long)b * T + t - 1], qb = q[(long long)b * T + t];
+            v = Wc[(long long)qa * 32 + j] + Wc[((long long)Q + qb) * 32 + j];
+        }
+        x0[i] = v;
+    }
+}
+// dWc partial tables: block-local LDS accumulation (ds_add_f32), one (2, Q, 32) table per block, reduced afterwards in a fixed order
+__global__ __launch_bounds__(256) void tr_onehot_causal_bwd_kernel(const float* dx0, const int32_t* q, float* part, int B, int T, int Tn, int Q, long long rows_per_block)
+{
+    extern __shared__ float tab[];
+    const int n = 2 * Q * 32;
+    for (int i = threadIdx.x; i < n; i += 256) tab[i] = 0.0f;
+    __syncthreads();
+    const long long R = (long long)B * Tn;
+    const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    const int c = threadIdx.x & 31;
+    for (long long r = r0 + (threadIdx.x >> 5); r < r1; r += 8) {
+        const int t = (int)(r % Tn), b = (int)(r / Tn);
+        if (t >= 1) {
+            const float g = dx0[r * 32 + c];
+            atomicAdd(&tab[(long long)q[(long long)b * T + t - 1] * 32 + c], g);
+            atomicAdd(&tab[((long long)Q + q[(long long)b * T + t]) * 32 + c], g);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) part[(long long)blockIdx.x * n + i] = tab[i];
+}
+// model.py:293-296 softmax_cross_entropy_with_logits_v2(one-hot target) mean; one wave per row of Q logits; dy = (softmax - onehot)/count
+__global__ __launch_bounds__(256) void tr_softmax_ce_kernel(const float* y, const int32_t* q, int B, int T, int ow, int rf, int Q, float inv_count,
+                                                           float* row_loss, float* dy)
+{
+    const int lane = threadIdx.x & 63;
+    const long long rows = (long long)B * ow;
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
+        const int p = (int)(r % ow), b = (int)(r / ow);
+        const int tgt = q[(long long)b * T + p + rf];
+        const float* yr = y + r * Q;
+        float m = -3.0e38f;
+        for (int i = lane; i < Q; i += 64) m = fmaxf(m, yr[i]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float se = 0.0f;
+        for (int i = lane; i < Q; i += 64) se += expf(yr[i] - m);
+        for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+        const float lse = m + logf(se);
+        for (int i = lane; i < Q; i += 64) dy[r * Q + i] = (expf(yr[i] - lse) - (i == tgt ? 1.0f : 0.0f)) * inv_count;
+        if (lane == 0) row_loss[r] = (lse - yr[tgt]) * inv_count;
+    }
+}
+// MoL variant writes per-row losses too; the scalar loss is their deterministic two-stage sum
+
+
+// model.py:300-312 optional L2 on every non-bias variable: loss += strength * sum(w^2)/2, grad += strength * w
+struct L2Layout { long long c_layer0, lstride, nl, bf, bg, bd, bs, D, R, S, c_b1, c_b2, O, ub; };
+__device__ __forceinline__ bool tr_is_bias(long long i, const L2Layout& L)
+{
+    if (!L.ub) return false;
+    if (i >= L.c_b1 && i < L.c_b1 + L.S) return true;
+    if (i >= L.c_b2 && i < L.c_b2 + L.O) return true;
+    if (i < L.c_layer0 || i >= L.c_layer0 + L.lstride * L.nl) return false;
+    const long long q = (i - L.c_layer0) % L.lstride;
+    return (q >= L.bf && q < L.bf + L.D) || (q >= L.bg && q < L.bg + L.D) || (q >= L.bd && q < L.bd + L.R) || (q >= L.bs && q < L.bs + L.S);
+}
+__global__ void tr_l2_kernel(const float* p, float* g, float* sq, long long n, float strength, L2Layout L)
+{
+    GRID_STRIDE(i, n) {
+        const bool b = tr_is_bias(i, L);
+        const float w = p[i];
+        sq[i] = b ? 0.0f : 0.5f * w * w;
+        if (!b) g[i] += strength * w;
+    }
+}
+__global__ void tr_axpy1_kernel(float* loss, const float* l2sum, float strength) { if (threadIdx.x == 0 && blockIdx.x == 0) loss[0] += strength * l2sum[0]; }
+// tf.clip_by_global_norm(gradients, clip_norm): g <- g * pre * clip / max(||g * pre||, clip)
+__global__ void tr_square_kernel(const float* g, float* sq, long long n, float pre) { GRID_STRIDE(i, n) { const float v = g[i] * pre; sq[i] = v * v; } }
+__global__ void tr_clip_scale_kernel(float* g, long long n, float pre, float clip, const float* norm2)
+{
+    const float nrm = sqrtf(norm2[0]);
+    const float sc = pre * clip / (nrm > clip ? nrm : clip);
+    GRID_STRIDE(i, n) g[i] *= sc;
+}
+
 // model.py:314-346 add_optimizer: AdamOptimizer(lr) with TF defaults, then ExponentialMovingAverage(decay).apply
 __global__ void tr_adam_ema_kernel(float* p, const float* g, float* m, float* v, float* ema, long long n, float lr_t, float b1, float b2,
                                    float eps, float decay, float gscale)
@@ -409,13 +502,13 @@ extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch,
 {
     if (!dims || !out || batch < 1) return twv_fail(TWV_E_INVALID, "bad argument");
     const twv_wavenet_dims& d = *dims;
-    if (!d.scalar_input) return twv_fail(TWV_E_UNSUPPORTED, "the training step is built for scalar_input (MoL) models (hparams default)");
     if (d.residual_channels != 32 || d.dilation_channels != 32) return twv_fail(TWV_E_UNSUPPORTED, "residual/dilation channels must be 32");
-    if (d.out_channels % 3 || d.out_channels > 96) return twv_fail(TWV_E_UNSUPPORTED, "out_channels must be 3*nr_mix <= 96");
+    if (d.scalar_input && (d.out_channels % 3 || d.out_channels > 96)) return twv_fail(TWV_E_UNSUPPORTED, "out_channels must be 3*nr_mix <= 96");
+    if (!d.scalar_input && (d.quantization_channels < 2 || d.quantization_channels > 512)) return twv_fail(TWV_E_UNSUPPORTED, "quantization_channels must be in [2, 512] for training");
     if (!d.lc_channels || !d.gc_channels) return twv_fail(TWV_E_UNSUPPORTED, "the training step expects local and global conditioning (train_vocoder.py)");
     twv_wavenet_trainer* h = new twv_wavenet_trainer();
-    h->d = d; h->B = batch; h->T = n_samples; h->Tn = n_samples - 1; h->NL = d.n_layers; h->S = d.skip_channels; h->O = d.out_channels;
-    h->L = d.lc_channels; h->G = d.gc_channels; h->ifw = d.initial_filter_width;
+    h->d = d; h->B = batch; h->T = n_samples; h->Tn = n_samples - 1; h->NL = d.n_layers; h->S = d.skip_channels; h->O = d.scalar_input ? d.out_channels : d.quantization_channels;
+    h->L = d.lc_channels; h->G = d.gc_channels; h->ifw = d.scalar_input ? d.initial_filter_width : 2;   // model.py:36-39
     h->hop = 1;
     for (int i = 0; i < d.n_upsample; ++i) h->hop *= d.upsample_factor[i];
     if (n_samples % h->hop) { delete h; return twv_fail(TWV_E_INVALID, "n_samples must be a multiple of the hop size (datafeeder_wavenet.py:41-47)"); }
@@ -427,7 +520,7 @@ extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch,
     // canonical blob offsets (same order as weights.tensor_specs / the generation path)
     long long c = 0;
     const int R = 32, D = 32, ub = d.use_biases ? 1 : 0;
-    h->c_causal = c; c += (long long)h->ifw * R;
+    h->c_causal = c; c += d.scalar_input ? (long long)h->ifw * R : 2LL * d.quantization_channels * R;
     h->c_gcemb = c; c += (long long)d.gc_cardinality * h->G;
     h->c_layer0 = c;
     long long q = 0;
@@ -448,7 +541,8 @@ extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch,
     long long f = 0;
     f += RT * h->L * 2;                         // upsample stages
     f += RT * h->L * 2;                         // dU ping/pong
-    f += Rr * h->ifw;                           // xunf
+    f += Rr * h->ifw + RT;                      // xunf / quantized input
+    f += d.scalar_input ? 0 : 256LL * 2 * d.quantization_channels * 32;   // one-hot causal gradient partial tables
     f += Rr * 32 * (h->NL + 1);                 // X[l]
     f += Rr * 32 * 3 * h->NL;                   // TH, SG, Z per layer
     f += RO * 32 * h->NL * 2;                   // ZCall, dZCall
@@ -501,6 +595,8 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
     float* U = ups[d.n_upsample];
     float* dUa = take(RT * L); float* dUb = take(RT * L);
     float* xunf = take(Rr * h->ifw);
+    int32_t* qin = reinterpret_cast<int32_t*>(take(RT));
+    float* ohpart = take(d.scalar_input ? 0 : 256LL * 2 * d.quantization_channels * 32);
     float** X = new float*[NL + 1];
     float **TH = new float*[NL], **SG = new float*[NL], **Z = new float*[NL];
     for (int l = 0; l <= NL; ++l) X[l] = take(Rr * 32);
@@ -544,8 +640,13 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         for (int i = 0; i < d.n_upsample; ++i)     // model.py:276 create_upsample
             K1(tr_up_fwd_kernel, (long long)B * upT[i + 1] * L, P + h->c_up[i], ups[i], ups[i + 1], (long long)B * upT[i + 1] * L, d.upsample_factor[i], L);
         K1(tr_gather_emb_kernel, (long long)B * G, P + h->c_gcemb, gc_ids, emb, B, G);   // model.py:197-198
-        K1(tr_unfold_kernel, Rr * h->ifw, audio, xunf, B, T, Tn, h->ifw);
-        if ((rc = gemm_rm(bl, false, false, (int)Rr, 32, h->ifw, 1.f, xunf, h->ifw, P + h->c_causal, 32, 0.f, X[0], 32))) break;   // model.py:131
+        if (d.scalar_input) {
+            K1(tr_unfold_kernel, Rr * h->ifw, audio, xunf, B, T, Tn, h->ifw);
+            if ((rc = gemm_rm(bl, false, false, (int)Rr, 32, h->ifw, 1.f, xunf, h->ifw, P + h->c_causal, 32, 0.f, X[0], 32))) break;   // model.py:131
+        } else {
+            if ((rc = twv_mu_law_encode(audio, RT, d.quantization_channels, qin, st))) break;                                         // model.py:257
+            K1(tr_onehot_causal_fwd_kernel, Rr * 32, P + h->c_causal, qin, X[0], B, T, Tn, d.quantization_channels);
+        }
         for (int l = 0; l < NL && !rc; ++l) {
             const int dl = d.dilations[l], o = h->off[l + 1];
             const float* Lp = LP(l);
@@ -574,7 +675,12 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         if ((rc = gemm_rm(bl, false, false, (int)RO, O, S, 1.f, C1, S, P + h->c_w2, O, 0.f, Y, O))) break;
         if (ub) K1(tr_bias_add_kernel, RO * O, Y, P + h->c_b2, O, RO * O);
         // model.py:286-290 loss
-        K1(tr_mol_loss_kernel, RO, Y, audio, B, T, ow, rf, nr, 1.0f / (float)RO, loss, dY);
+        if (d.scalar_input) K1(tr_mol_loss_kernel, RO, Y, audio, B, T, ow, rf, nr, 1.0f / (float)RO, loss, dY);
+        else {
+            float* row_loss = dS;                                   // (RO) scratch: dS is not written before the backward pass
+            hipLaunchKernelGGL(tr_softmax_ce_kernel, dim3(tg(RO * 64)), dim3(256), 0, st, Y, qin, B, T, ow, rf, O, 1.0f / (float)RO, row_loss, dY);
+            colsum(row_loss, RO, 1, 1, 1, loss, 1);
+        }
         // ================= backward =================
         rc |= gemm_rm(bl, true, false, S, O, (int)RO, 1.f, C1, S, dY, O, 0.f, Gd + h->c_w2, O);                 // dW2 = H2^T dY
         if (ub) colsum(dY, RO, O, O, 1, Gd + h->c_b2, O);
@@ -636,7 +742,14 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         }
         if (rc) break;
         // causal layer, gc embedding table, upsampler, and the gradient views back into the canonical order
-        wgrad(xunf, h->ifw, dXn, 32, Rr, h->ifw, 32, Gd + h->c_causal, 32);
+        if (d.scalar_input) wgrad(xunf, h->ifw, dXn, 32, Rr, h->ifw, 32, Gd + h->c_causal, 32);
+        else {
+            const int Q = d.quantization_channels, nblk = 256;
+            const long long rpb = (Rr + nblk - 1) / nblk;
+            HIPCHK(hipFuncSetAttribute((const void*)tr_onehot_causal_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Q * 32 * 4));
+            hipLaunchKernelGGL(tr_onehot_causal_bwd_kernel, dim3(nblk), dim3(256), 2 * Q * 32 * 4, st, dXn, qin, ohpart, B, T, Tn, Q, rpb);
+            hipLaunchKernelGGL(tr_colsum_final_kernel, dim3((2 * Q * 32 + 63) / 64), dim3(256), 0, st, ohpart, nblk, 2 * Q * 32, 1, Gd + h->c_causal, 2 * Q * 32);
+        }
         K1(tr_scatter_emb_kernel, (long long)B * G, demb, gc_ids, Gd + h->c_gcemb, B, G);
         K1(tr_views_kernel, (vstride + 32LL * S) * NL, Gd, GV, GS, NL, h->c_layer0, h->c_lstride, h->lo.wf, h->lo.wg, h->lo.lcf, h->lo.lcg,
            h->lo.gcf, h->lo.gcg, h->lo.ws, L, G, S, 1);
@@ -659,6 +772,40 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
     if (rc) return twv_fail(TWV_E_HIP, "rocBLAS call failed with status " + std::to_string(rc));
     HIPCHK(hipGetLastError());
     if ((long long)(w - (float*)workspace) > h->ws_floats) return twv_fail(TWV_E_INVALID, "internal: workspace overrun");
+    return TWV_OK;
+}
+
+
+// deterministic two-stage sum of n floats -> out[0]
+static void tr_sum(const float* x, long long n, float* part, float* out, hipStream_t st)
+{
+    int nchunk = (int)(n / 1024); nchunk = nchunk < 1 ? 1 : (nchunk > 256 ? 256 : nchunk);
+    hipLaunchKernelGGL(tr_colsum_partial_kernel, dim3(nchunk, 1, 1), dim3(256), 0, st, x, n, 1, 1, nchunk, part);
+    hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(1), dim3(256), 0, st, part, nchunk, 1, 1, out, 1);
+}
+extern "C" int twv_wavenet_train_l2(twv_wavenet_trainer* h, const float* params, double strength, void* workspace, float* loss, float* grads, void* stream)
+{
+    if (!h || !params || !workspace || !loss || !grads) return twv_fail(TWV_E_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    float* sq = (float*)workspace;                       // nparams floats, then 256 partials + the sum
+    float* part = sq + (h->nparams + 63) / 64 * 64;
+    L2Layout L{h->c_layer0, h->c_lstride, h->NL, h->lo.bf, h->lo.bg, h->lo.bd, h->lo.bs, 32, 32, h->S, h->c_b1, h->c_b2, h->O, h->d.use_biases};
+    hipLaunchKernelGGL(tr_l2_kernel, dim3(tg(h->nparams)), dim3(256), 0, st, params, grads, sq, h->nparams, (float)strength, L);
+    tr_sum(sq, h->nparams, part, part + 512, st);
+    hipLaunchKernelGGL(tr_axpy1_kernel, dim3(1), dim3(64), 0, st, loss, part + 512, (float)strength);
+    HIPCHK(hipGetLastError());
+    return TWV_OK;
+}
+extern "C" int twv_clip_by_global_norm(float* grads, int64_t n, double pre_scale, double clip_norm, void* scratch, void* stream)
+{
+    if (!grads || !scratch || n < 1 || clip_norm <= 0) return twv_fail(TWV_E_INVALID, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    float* sq = (float*)scratch;                         // n floats, then 256 partials + the sum
+    float* part = sq + (n + 63) / 64 * 64;
+    hipLaunchKernelGGL(tr_square_kernel, dim3(tg(n)), dim3(256), 0, st, grads, sq, (long long)n, (float)pre_scale);
+    tr_sum(sq, n, part, part + 512, st);
+    hipLaunchKernelGGL(tr_clip_scale_kernel, dim3(tg(n)), dim3(256), 0, st, grads, (long long)n, (float)pre_scale, (float)clip_norm, part + 512);
+    HIPCHK(hipGetLastError());
     return TWV_OK;
 }
 

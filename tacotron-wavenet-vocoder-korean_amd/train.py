@@ -41,21 +41,21 @@ def crop_length(sample_size, hop_size):
 
 class WaveNetTrainer(object):
     def __init__(self, net, hparams=None, sample_size=None, learning_rate=1e-3, decay_steps=300000, decay_rate=0.5,
-                 ema_decay=0.9999, beta1=0.9, beta2=0.999, epsilon=1e-8, group=None):
+                 ema_decay=0.9999, beta1=0.9, beta2=0.999, epsilon=1e-8, group=None, clip_gradients=False, l2_regularization_strength=0.0):
         self.net = net
         if hparams is not None:
             learning_rate = getattr(hparams, "wavenet_learning_rate", learning_rate)
             decay_steps = getattr(hparams, "wavenet_decay_steps", decay_steps)
             decay_rate = getattr(hparams, "wavenet_decay_rate", decay_rate)
-            if getattr(hparams, "wavenet_clip_gradients", False):
-                raise NotImplementedError("wavenet_clip_gradients=True (hparams.py:94 default False) is not built")
-            if getattr(hparams, "l2_regularization_strength", 0):
-                raise NotImplementedError("l2_regularization_strength != 0 (hparams.py:54 default 0) is not built")
+            clip_gradients = bool(getattr(hparams, "wavenet_clip_gradients", clip_gradients))
+            l2_regularization_strength = getattr(hparams, "l2_regularization_strength", l2_regularization_strength) or 0.0
             if sample_size is None:
                 sample_size = hparams.sample_size
         self.lr0, self.decay_steps, self.decay_rate = learning_rate, decay_steps, decay_rate
         self.ema_decay, self.beta1, self.beta2, self.epsilon = ema_decay, beta1, beta2, epsilon
         self.group = group
+        self.clip_gradients = clip_gradients                      # model.py:330-331 clip_by_global_norm(gradients, 1.)
+        self.l2 = float(l2_regularization_strength or 0.0)       # train_vocoder.py:118-119: 0 -> None
         self.batch_size = net.batch_size
         self.sample_size = crop_length(sample_size, net.hop_size)
         self.device = net.device
@@ -132,12 +132,18 @@ class WaveNetTrainer(object):
         with torch.cuda.device(self.device):
             _lib.check(self._L.twv_wavenet_train_loss_grad(self._h, _ptr(self.params), _ptr(audio), _ptr(lc), _ptr(gc), _ptr(self._ws),
                                                           _ptr(self.loss), _ptr(self.grads), _stream()))
+            if self.l2:
+                _lib.check(self._L.twv_wavenet_train_l2(self._h, _ptr(self.params), self.l2, _ptr(self._ws), _ptr(self.loss), _ptr(self.grads),
+                                                       _stream()))
         return self.loss
 
     # ---- apply_gradients + ema.apply ----
     def apply_gradients(self, world=1):
         lr = exponential_decay(self.lr0, self.global_step, self.decay_steps, self.decay_rate)
         with torch.cuda.device(self.device):
+            if self.clip_gradients:
+                _lib.check(self._L.twv_clip_by_global_norm(_ptr(self.grads), self.n_params, 1.0 / world, 1.0, _ptr(self._ws), _stream()))
+                world = 1
             _lib.check(self._L.twv_adam_ema_step(_ptr(self.params), _ptr(self.grads), _ptr(self.m), _ptr(self.v), _ptr(self.ema),
                                                 self.n_params, lr, self.beta1, self.beta2, self.epsilon, self.global_step + 1,
                                                 self.ema_decay, 1.0 / world, _stream()))

@@ -123,3 +123,58 @@ def test_bad_shapes_are_rejected():
     from twvk_amd._lib import TwvError
     with pytest.raises(TwvError):
         WaveNetTrainer(tr.net, sample_size=0)        # shorter than the receptive field
+
+
+def test_onehot_mulaw_model_loss_and_gradients():
+    """scalar_input=False: mu-law one-hot input, width-2 causal conv over Q channels, softmax cross-entropy (model.py:257-296)"""
+    import twvk_amd  # noqa: F401
+    from twvk_amd import weights as W
+    from twvk_amd.ops import mu_law_encode
+    from twvk_amd.train import WaveNetTrainer
+    dil, B, Tm, S, Q = [1, 2, 4, 8, 1, 2], 2, 2, 64, 256
+    specs = W.tensor_specs(len(dil), S=S, Q=Q, scalar_input=False)
+    tensors = W.random_tensors(specs, seed=3, scale=0.1)
+    T = Tm * 300
+    rng = np.random.RandomState(4)
+    audio = ((rng.rand(B, T) - 0.5) * 1.8).astype(np.float32)
+    lc = (rng.randn(B, Tm, 80) * 0.5).astype(np.float32)
+    gc = np.array([1, 0], np.int32)
+    net = make_model(B, dil, tensors, S=S, Q=Q, scalar_input=False)
+    tr = WaveNetTrainer(net, sample_size=T)
+    tr.load_weights(tensors)
+    loss = float(tr.loss_and_gradients(audio, lc, gc).item())
+    q = mu_law_encode(torch.from_numpy(audio).cuda(), Q).cpu().numpy()      # the quantizer itself is pinned bit-exact elsewhere
+    cfg = dict(dilations=dil, initial_filter_width=32, use_biases=True, upsample_factor=UP, scalar_input=False, Q=Q)
+    ref_loss, ref_g = R.loss_and_grads(tensors, cfg, audio, lc, gc, quantized=q)
+    assert abs(loss - ref_loss) <= 2e-5 * abs(ref_loss), (loss, ref_loss)      # tolerance: fp32 mean over B*out_w rows
+    _check_grads(tr.gradients(), ref_g, 2e-3)                                  # tolerance: as for the MoL model
+    l0 = float(tr.step(audio, lc, gc).item())
+    for _ in range(20):
+        l1 = float(tr.step(audio, lc, gc).item())
+    assert l1 < l0
+
+
+def test_l2_and_gradient_clipping_options():
+    """model.py:300-312 (L2 on non-bias variables) and model.py:330-331 (clip_by_global_norm(gradients, 1.))"""
+    tr, tensors, cfg, audio, lc, gc = _case(dil=[1, 2, 4, 1, 2], B=2, Tm=3, scale=0.3)
+    base_loss, base_g = R.loss_and_grads(tensors, cfg, audio, lc, gc)
+    lam = 0.01
+    tr.l2 = lam
+    loss = float(tr.loss_and_gradients(audio, lc, gc).item())
+    l2 = sum(0.5 * float((np.asarray(v, np.float64) ** 2).sum()) for k, v in tensors.items() if "bias" not in k)
+    assert abs(loss - (base_loss + lam * l2)) <= 2e-5 * abs(base_loss + lam * l2)
+    want = {k: base_g[k] + (0 if "bias" in k else lam * tensors[k]) for k in base_g}
+    _check_grads(tr.gradients(), want, 2e-3)
+    # clipping: the flat gradient is rescaled to global norm <= 1 before Adam (here the norm is far above 1 with lam large)
+    tr.l2 = 50.0
+    tr.clip_gradients = True
+    tr.loss_and_gradients(audio, lc, gc)
+    g = tr.grads.cpu().numpy().astype(np.float64)
+    nrm = np.sqrt((g ** 2).sum())
+    assert nrm > 1.0
+    p0 = tr.params.cpu().numpy().astype(np.float64)
+    lr = tr.apply_gradients()
+    gc_ = g / max(nrm, 1.0)
+    p1, _, _, _ = R.adam_ema(p0, gc_, np.zeros_like(p0), np.zeros_like(p0), p0.copy(), 1, lr)
+    np.testing.assert_allclose(tr.params.cpu().numpy(), p1, rtol=0, atol=2e-6)     # tolerance: one fp32 Adam update of size lr
+    np.testing.assert_allclose(np.sqrt((tr.grads.cpu().numpy().astype(np.float64) ** 2).sum()), 1.0, rtol=1e-5)

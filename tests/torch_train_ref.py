@@ -55,10 +55,15 @@ def upsample(lc, kernels, factors):
     return x
 
 
+def receptive_field(cfg):
+    """model.py:31-39"""
+    return sum(cfg["dilations"]) + 1 + ((cfg["initial_filter_width"] - 1) if cfg.get("scalar_input", True) else 1)
+
+
 def network(P, cfg, net_in, U, gc_ids):
     """_create_network(train_mode=True): net_in (B,1,Tn) scalar input, U (B,Tlc,L) upsampled lc -> raw output (B, Tn-rf+1, O)"""
     dil, ifw, ub = cfg["dilations"], cfg["initial_filter_width"], cfg["use_biases"]
-    rf = sum(dil) + 1 + ifw - 1
+    rf = receptive_field(cfg)
     Uc = U.transpose(1, 2)                                     # (B, L, Tlc)
     gc = P["wavenet/gc_embedding"][gc_ids.long()][:, :, None]  # (B, G, 1)
 
@@ -87,19 +92,26 @@ def network(P, cfg, net_in, U, gc_ids):
     return conv(F.relu(c1), "wavenet/conv1d_2").transpose(1, 2)             # (B, out_w, 3*nr)
 
 
-def loss_fn(P, cfg, audio, lc, gc_ids):
-    """P: dict TF-name -> torch tensor (TF layouts); audio (B,T); lc (B,T/hop,L); gc_ids (B) -> scalar loss."""
-    rf = sum(cfg["dilations"]) + 1 + cfg["initial_filter_width"] - 1
-    net_in = audio[:, None, :-1]                               # model.py:267-269 (B,1,T-1)
+def loss_fn(P, cfg, audio, lc, gc_ids, quantized=None):
+    """P: dict TF-name -> torch tensor (TF layouts); audio (B,T); lc (B,T/hop,L); gc_ids (B) -> scalar loss.
+    one-hot model (scalar_input False): `quantized` = mu_law_encode(audio) ints (B,T), model.py:257-260"""
+    rf = receptive_field(cfg)
     U = upsample(lc, [P["wavenet/upsample%d/kernel" % i] for i in range(len(cfg["upsample_factor"]))], cfg["upsample_factor"])
-    y = network(P, cfg, net_in, U, gc_ids)
-    target = audio[:, rf:, None]                                            # model.py:286
-    return mol_loss(y, target).mean()
+    if cfg.get("scalar_input", True):
+        net_in = audio[:, None, :-1]                           # model.py:267-269 (B,1,T-1)
+        y = network(P, cfg, net_in, U, gc_ids)
+        target = audio[:, rf:, None]                                        # model.py:286
+        return mol_loss(y, target).mean()
+    enc = F.one_hot(quantized.long(), cfg["Q"]).to(audio.dtype)            # (B,T,Q)
+    y = network(P, cfg, enc[:, :-1].transpose(1, 2), U, gc_ids)             # (B, out_w, Q)
+    tgt = quantized[:, rf:].long()                                          # model.py:286, 293-296
+    return F.cross_entropy(y.reshape(-1, cfg["Q"]), tgt.reshape(-1), reduction="mean")
 
 
-def loss_and_grads(tensors, cfg, audio, lc, gc_ids, dtype=torch.float32):
+def loss_and_grads(tensors, cfg, audio, lc, gc_ids, dtype=torch.float32, quantized=None):
     P = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in tensors.items()}
-    loss = loss_fn(P, cfg, torch.tensor(audio, dtype=dtype), torch.tensor(lc, dtype=dtype), torch.tensor(np.asarray(gc_ids)))
+    loss = loss_fn(P, cfg, torch.tensor(audio, dtype=dtype), torch.tensor(lc, dtype=dtype), torch.tensor(np.asarray(gc_ids)),
+                   None if quantized is None else torch.tensor(np.asarray(quantized)))
     loss.backward()
     return float(loss.item()), {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape, np.float32)) for k, v in P.items()}
 
