@@ -48,6 +48,7 @@ struct twv_wavenet_trainer {
 // ---------------------------------------------------------------------------------------------------------------
 //  kernels
 // ---------------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GRID_STRIDE(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
 static inline int tg(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 32768 ? 32768 : g)); }
 
@@ -190,6 +191,7 @@ __global__ void tr_bias_relu_kernel(float* x, const float* biases, int nb, long 
 }
 __global__ void tr_bias_add_kernel(float* x, const float* bias, int C, long long n) { GRID_STRIDE(i, n) x[i] += bias[i % C]; }
 __global__ void tr_relu_bwd_kernel(float* dx, const float* y, long long n) { GRID_STRIDE(i, n) if (!(y[i] > 0.0f)) dx[i] = 0.0f; }
+__global__ void tr_mul_kernel(const float* a, const float* b, float* c, long long n) { GRID_STRIDE(i, n) c[i] = a[i] * b[i]; }
 __global__ void tr_fill_kernel(float* p, float v, long long n) { GRID_STRIDE(i, n) p[i] = v; }
 __global__ void tr_add_kernel(float* a, const float* b, long long n) { GRID_STRIDE(i, n) a[i] += b[i]; }
 // column sums, two deterministic stages.  stage 1: block (chunk, col tile, segment) sums its row chunk of segment z
@@ -231,7 +233,6 @@ __global__ __launch_bounds__(256) void tr_colsum_final_kernel(const float* part,
 // activations that is two coalesced 128-byte rows per operand, no transposition or LDS staging needed.
 // Block = 4 waves; wave w owns k rows {2*(4*i + w), +1} of its chunk; per-wave partial tiles go to part[...] and are summed
 // in a fixed order by tr_tn_reduce_kernel (deterministic, no atomics).  grid = (chunks, m-blocks, n-blocks).
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void tr_tn_partial_kernel(const float* A, int lda, const float* B, int ldb, long long K, int M, int N,
                                                             long long rows_per_chunk, float* part)
 {
@@ -379,6 +380,140 @@ __global__ void tr_mol_loss_kernel(const float* y, const float* audio, int B, in
     }
 }
 
+
+
+// ===================================================================================================================
+//  Fused residual layer, forward (model.py:66-101 train mode) on the f32 matrix cores.
+//  One wave owns 32-row tiles (rows = consecutive t of one batch entry).  Per tile:
+//      pre[32 x 64] = X[t-d] W0 + X[t] W1 + U[t-o] Wlc            144-deep contraction, 2 x 72 v_mfma_f32_32x32x2_f32
+//      th, sg = tanh / sigmoid(pre + bias + gc[b])  (masked below the layer's receptive offset o), z = th*sg
+//      x_next = X[t] + z Wd + bd                                   16 MFMAs; z goes C-layout -> A-layout through 4.6 KB of LDS
+//  The layer's weights live in registers for the whole launch as MFMA B operands (lane (n, hh): W[k = 8i + 4hh + j][n]), A
+//  operands are float4 row loads (lane (row, hh): k = 8i + 4hh .. +3), the next tile's rows are requested before the
+//  current tile's MFMAs.  Writes TH, SG (for the backward pass), x_next and the skip input slice ZC -- no pre-activation
+//  or conditioning buffer ever reaches HBM.  Any accumulation order is fine here: training parity is by tolerance.
+// ===================================================================================================================
+typedef float f32x4t __attribute__((ext_vector_type(4)));
+struct LayerFwdArgs {
+    const float* X; const float* U; const float* gcp;        // (B*Tn,32) (B*T,L=80) (B,64)
+    const float* W0; const float* W1; const float* Wlc;      // views (32,64) (32,64) (80,64): columns filter | gate
+    const float* Wd;                                         // (32,32)
+    const float* bf; const float* bg; const float* bd;       // nullable
+    float* TH; float* SG; float* XN; float* ZC;              // ZC already offset to this layer's 32 columns
+    int B, T, Tn, d, o, ow, ldz, tpb;                        // tpb = tiles per batch entry = ceil(Tn / 32)
+};
+constexpr int kLcSteps = 10;                                 // 80 / 8
+
+__device__ __forceinline__ f32x4t tr_ld4(const float* p, bool ok) { f32x4t z = {0.f, 0.f, 0.f, 0.f}; return ok ? *reinterpret_cast<const f32x4t*>(p) : z; }
+
+struct LayerA { f32x4t x0[4], x1[4], u[kLcSteps]; };
+__device__ __forceinline__ void tr_layer_load(LayerA& A, const LayerFwdArgs& a, int tile, int lane)
+{
+    const int b = tile / a.tpb, t = (tile - b * a.tpb) * 32 + (lane & 31), hh = (lane >> 5) * 4;
+    const bool in = tile < a.B * a.tpb && t < a.Tn;
+    const float* xr = a.X + ((long long)b * a.Tn + t) * 32 + hh;
+    const float* ur = a.U + ((long long)b * a.T + (t - a.o)) * 80 + hh;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        A.x0[i] = tr_ld4(xr - (long long)a.d * 32 + 8 * i, in && t >= a.d);
+        A.x1[i] = tr_ld4(xr + 8 * i, in);
+    }
+#pragma unroll
+    for (int i = 0; i < kLcSteps; ++i) A.u[i] = tr_ld4(ur + 8 * i, in && t >= a.o);
+}
+
+__global__ void __launch_bounds__(256) tr_layer_fwd_kernel(LayerFwdArgs a)
+{
+    __shared__ float zt[4][32 * 36];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, hh = lane >> 5;
+    // ---- B operands in registers
+    float b0f[16], b0g[16], b1f[16], b1g[16], blf[4 * kLcSteps], blg[4 * kLcSteps], bdn[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 8 * i + 4 * hh + j;
+            b0f[4 * i + j] = a.W0[k * 64 + n]; b0g[4 * i + j] = a.W0[k * 64 + 32 + n];
+            b1f[4 * i + j] = a.W1[k * 64 + n]; b1g[4 * i + j] = a.W1[k * 64 + 32 + n];
+            bdn[4 * i + j] = a.Wd[k * 32 + n];
+        }
+#pragma unroll
+    for (int i = 0; i < kLcSteps; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 8 * i + 4 * hh + j;
+            blf[4 * i + j] = a.Wlc[k * 64 + n]; blg[4 * i + j] = a.Wlc[k * 64 + 32 + n];
+        }
+    const float vbf = a.bf ? a.bf[n] : 0.0f, vbg = a.bg ? a.bg[n] : 0.0f, vbd = a.bd ? a.bd[n] : 0.0f;
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int ntiles = a.B * a.tpb, nwaves = gridDim.x * 4;
+    int tile = blockIdx.x * 4 + wave;
+    LayerA A;
+    tr_layer_load(A, a, tile, lane);
+    for (; tile < ntiles; tile += nwaves) {
+        LayerA An;
+        tr_layer_load(An, a, tile + nwaves, lane);           // next tile's rows travel during this tile's 160 MFMAs
+        f32x16 cf = zero, cg = zero;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cf = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x0[i][j], b0f[4 * i + j], cf, 0, 0, 0);
+                cg = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x0[i][j], b0g[4 * i + j], cg, 0, 0, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cf = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x1[i][j], b1f[4 * i + j], cf, 0, 0, 0);
+                cg = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x1[i][j], b1g[4 * i + j], cg, 0, 0, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < kLcSteps; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cf = __builtin_amdgcn_mfma_f32_32x32x2f32(A.u[i][j], blf[4 * i + j], cf, 0, 0, 0);
+                cg = __builtin_amdgcn_mfma_f32_32x32x2f32(A.u[i][j], blg[4 * i + j], cg, 0, 0, 0);
+            }
+        // ---- gated unit (C layout: lane = channel n, register r = row (r&3) + 8(r>>2) + 4hh)
+        const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
+        const float gcf = a.gcp ? a.gcp[b * 64 + n] : 0.0f, gcg = a.gcp ? a.gcp[b * 64 + 32 + n] : 0.0f;
+        float xres[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh, t = t0 + rl;
+            const bool in = t < a.Tn, valid = in && t >= a.o;
+            float th = 0.0f, sg = 0.0f;
+            if (valid) { th = tanh_e((cf[r] + vbf) + gcf); sg = sigmoid_e((cg[r] + vbg) + gcg); }
+            const float z = th * sg;
+            const long long row = (long long)b * a.Tn + t;
+            if (in) {
+                a.TH[row * 32 + n] = th; a.SG[row * 32 + n] = sg;
+                xres[r] = a.X[row * 32 + n];
+                if (t >= a.Tn - a.ow) a.ZC[((long long)b * a.ow + (t - (a.Tn - a.ow))) * a.ldz + n] = z;
+            } else xres[r] = 0.0f;
+            zt[wave][rl * 36 + n] = z;
+        }
+        // ---- dense 1x1 + residual: z as A operand (row layout) back from this wave's LDS patch
+        f32x16 cd = zero;
+        {
+            const float* zr = &zt[wave][(lane & 31) * 36 + 4 * hh];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4t q = *reinterpret_cast<const f32x4t*>(zr + 8 * i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cd = __builtin_amdgcn_mfma_f32_32x32x2f32(q[j], bdn[4 * i + j], cd, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (t < a.Tn) a.XN[((long long)b * a.Tn + t) * 32 + n] = (xres[r] + cd[r]) + vbd;
+        }
+        A = An;
+    }
+}
 
 // ---- one-hot (mu-law) input model: model.py:257-271 (mu_law_encode -> one_hot -> causal conv of width 2 over Q channels) ----
 // x0[(b,t)][j] = Wc[0][q[b,t-1]][j] + Wc[1][q[b,t]][j]   (a one-hot row times a kernel is a row gather); t = 0 is masked
@@ -600,7 +735,8 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
     float** X = new float*[NL + 1];
     float **TH = new float*[NL], **SG = new float*[NL], **Z = new float*[NL];
     for (int l = 0; l <= NL; ++l) X[l] = take(Rr * 32);
-    for (int l = 0; l < NL; ++l) { TH[l] = take(Rr * 32); SG[l] = take(Rr * 32); Z[l] = take(Rr * 32); }
+    for (int l = 0; l < NL; ++l) { TH[l] = take(Rr * 32); SG[l] = take(Rr * 32); Z[l] = nullptr; }
+    Z[0] = take(Rr * 32);
     const int ZW = NL * 32;                                  // stacked skip input: ZC[(b,p)][l*32 + j]
     float* ZC = take(RO * ZW); float* dZC = take(RO * ZW);
     float* PRE = take(Rr * 64);
@@ -651,19 +787,20 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             const int dl = d.dilations[l], o = h->off[l + 1];
             const float* Lp = LP(l);
             const float* Wv = WV + l * vstride;                 // tap0 | tap1 | lc | gc views, 64 columns = filter|gate
-            // model.py:68-69 conv_filter | conv_gate, taps x[t-d] and x[t]  (rows d .. R-1)
-            const int M = (int)(Rr - dl);
-            rc |= gemm_rm(bl, false, false, M, 64, 32, 1.f, X[l], 32, Wv, 64, 0.f, PRE + (long long)dl * 64, 64);
-            rc |= gemm_rm(bl, false, false, M, 64, 32, 1.f, X[l] + (long long)dl * 32, 32, Wv + 32 * 64, 64, 1.f, PRE + (long long)dl * 64, 64);
-            // model.py:71-83 gc / lc 1x1 projections
+            // model.py:71-73 gc projection (tiny), then the fused layer: conv_filter | conv_gate taps, lc projection, gated unit,
+            // dense + residual, skip input slice
             float* gcp = GCP + (long long)l * B * 64;
             rc |= gemm_rm(bl, false, false, B, 64, G, 1.f, emb, G, Wv + (64 + L) * 64, 64, 0.f, gcp, 64);
-            rc |= gemm_rm(bl, false, false, (int)RT, 64, L, 1.f, U, L, Wv + 64 * 64, 64, 0.f, LCP, 64);
-            K1(tr_gate_fwd_kernel, Rr * 32, PRE, ub ? Lp + h->lo.bf : nullptr, ub ? Lp + h->lo.bg : nullptr, gcp, LCP, TH[l], SG[l], Z[l], B, Tn, T, o);
-            // model.py:89,98-101 dense + residual ; model.py:94-96 skip input = the last `ow` positions
-            K1(tr_add_bias32_kernel, Rr * 32, X[l], ub ? Lp + h->lo.bd : nullptr, X[l + 1], Rr * 32);
-            rc |= gemm_rm(bl, false, false, (int)Rr, 32, 32, 1.f, Z[l], 32, Lp + h->lo.wd, 32, 1.f, X[l + 1], 32);
-            K1(tr_compact_kernel, RO * 32, Z[l], ZC + l * 32, B, Tn, ow, ZW);
+            LayerFwdArgs fa;
+            fa.X = X[l]; fa.U = U; fa.gcp = gcp; fa.W0 = Wv; fa.W1 = Wv + 32 * 64; fa.Wlc = Wv + 64 * 64; fa.Wd = Lp + h->lo.wd;
+            fa.bf = ub ? Lp + h->lo.bf : nullptr; fa.bg = ub ? Lp + h->lo.bg : nullptr; fa.bd = ub ? Lp + h->lo.bd : nullptr;
+            fa.TH = TH[l]; fa.SG = SG[l]; fa.XN = X[l + 1]; fa.ZC = ZC + l * 32;
+            fa.B = B; fa.T = T; fa.Tn = Tn; fa.d = dl; fa.o = o; fa.ow = ow; fa.ldz = ZW; fa.tpb = (Tn + 31) / 32;
+            {
+                const int ntiles = B * fa.tpb;
+                int nwg = (ntiles + 3) / 4; nwg = nwg > 512 ? 512 : nwg;
+                hipLaunchKernelGGL(tr_layer_fwd_kernel, dim3(nwg), dim3(256), 0, st, fa);
+            }
         }
         if (rc) break;
         // model.py:94-96,150-165: sum over layers of the skip 1x1 convs == ONE GEMM against the stacked skip kernels, then
@@ -711,7 +848,8 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             float* Gv = GV + l * vstride;
             const int M = (int)(Rr - dl);
             // dense 1x1: dWd, dbd, dZ (+ the skip path's share on the last `ow` positions)
-            wgrad(Z[l], 32, dXn, 32, Rr, 32, 32, Lg + h->lo.wd, 32);
+            K1(tr_mul_kernel, Rr * 32, TH[l], SG[l], Z[0], Rr * 32);          // z = tanh * sigmoid (not stored by the fused forward)
+            wgrad(Z[0], 32, dXn, 32, Rr, 32, 32, Lg + h->lo.wd, 32);
             if (ub) colsum(dXn, Rr, 32, 32, 1, Lg + h->lo.bd, 32);
             rc |= gemm_rm(bl, false, true, (int)Rr, 32, 32, 1.f, dXn, 32, Lp + h->lo.wd, 32, 0.f, dZ, 32);
             K1(tr_scatter_add_kernel, RO * 32, dZC + l * 32, dZ, B, Tn, ow, ZW);
