@@ -394,6 +394,9 @@ __global__ void tr_mol_loss_kernel(const float* y, const float* audio, int B, in
 //  or conditioning buffer ever reaches HBM.  Any accumulation order is fine here: training parity is by tolerance.
 // ===================================================================================================================
 typedef float f32x4t __attribute__((ext_vector_type(4)));
+// training-time activations on the transcendental unit (v_exp_f32 / v_rcp_f32, ~1e-6 relative): parity here is by tolerance
+__device__ __forceinline__ float tr_sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tr_tanh_fast(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
 struct LayerFwdArgs {
     const float* X; const float* U; const float* gcp;        // (B*Tn,32) (B*T,L=80) (B,64)
     const float* W0; const float* W1; const float* Wlc;      // views (32,64) (32,64) (80,64): columns filter | gate
@@ -454,6 +457,15 @@ __global__ void __launch_bounds__(256) tr_layer_fwd_kernel(LayerFwdArgs a)
     for (; tile < ntiles; tile += nwaves) {
         LayerA An;
         tr_layer_load(An, a, tile + nwaves, lane);           // next tile's rows travel during this tile's 160 MFMAs
+        // residual operand and gc projection in the output (C) layout: requested now, consumed after the MFMAs
+        const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
+        const float gcf = a.gcp ? a.gcp[b * 64 + n] : 0.0f, gcg = a.gcp ? a.gcp[b * 64 + 32 + n] : 0.0f;
+        float xres[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            xres[r] = t < a.Tn ? a.X[((long long)b * a.Tn + t) * 32 + n] : 0.0f;
+        }
         f32x16 cf = zero, cg = zero;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -477,22 +489,18 @@ __global__ void __launch_bounds__(256) tr_layer_fwd_kernel(LayerFwdArgs a)
                 cg = __builtin_amdgcn_mfma_f32_32x32x2f32(A.u[i][j], blg[4 * i + j], cg, 0, 0, 0);
             }
         // ---- gated unit (C layout: lane = channel n, register r = row (r&3) + 8(r>>2) + 4hh)
-        const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
-        const float gcf = a.gcp ? a.gcp[b * 64 + n] : 0.0f, gcg = a.gcp ? a.gcp[b * 64 + 32 + n] : 0.0f;
-        float xres[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh, t = t0 + rl;
             const bool in = t < a.Tn, valid = in && t >= a.o;
             float th = 0.0f, sg = 0.0f;
-            if (valid) { th = tanh_e((cf[r] + vbf) + gcf); sg = sigmoid_e((cg[r] + vbg) + gcg); }
+            if (valid) { th = tr_tanh_fast((cf[r] + vbf) + gcf); sg = tr_sigmoid_fast((cg[r] + vbg) + gcg); }
             const float z = th * sg;
             const long long row = (long long)b * a.Tn + t;
             if (in) {
                 a.TH[row * 32 + n] = th; a.SG[row * 32 + n] = sg;
-                xres[r] = a.X[row * 32 + n];
                 if (t >= a.Tn - a.ow) a.ZC[((long long)b * a.ow + (t - (a.Tn - a.ow))) * a.ldz + n] = z;
-            } else xres[r] = 0.0f;
+            }
             zt[wave][rl * 36 + n] = z;
         }
         // ---- dense 1x1 + residual: z as A operand (row layout) back from this wave's LDS patch
@@ -512,6 +520,184 @@ __global__ void __launch_bounds__(256) tr_layer_fwd_kernel(LayerFwdArgs a)
             if (t < a.Tn) a.XN[((long long)b * a.Tn + t) * 32 + n] = (xres[r] + cd[r]) + vbd;
         }
         A = An;
+    }
+}
+
+
+// ===================================================================================================================
+//  Fused residual layer, backward.  Two kernels per layer, both on v_mfma_f32_32x32x2_f32 with 32-row tiles per wave:
+//  K1 (tr_layer_bwd1_kernel): dZ = dXn Wd^T (+ the skip path's dZC) -> gated-unit backward -> dPRE (stored once, row major)
+//      and EVERY weight gradient of the layer.  The MFMA C layout (lane = channel n, register r = row rho(r,hh)) is exactly
+//      the B operand of a "rows are the contraction" MFMA step, so dF / dG feed X^T dPRE, U^T dPRE, Z^T dXn straight from
+//      registers; the A operands are coalesced scalar loads (lane = channel).  Eleven 32x32 gradient tiles accumulate in
+//      registers over all tiles of the wave, are summed over the 4 waves through LDS and leave as one slab per workgroup
+//      (fixed-order reduction afterwards: deterministic).  Bias / gc sums leave as per-tile column sums.
+//  K2 (tr_layer_bwd2_kernel): dX = dXn + dPRE[t] W1^T + dPRE[t+d] W0^T and dU[t-o] += dPRE[t] Wlc^T with the transposed
+//      weights register-resident.
+// ===================================================================================================================
+struct LayerBwdArgs {
+    const float* dXn; const float* dZC;                      // (B*Tn,32), skip share (B*ow rows, ld ldz) already offset to the layer
+    const float* TH; const float* SG; const float* X; const float* U;
+    const float* W0; const float* W1; const float* Wlc; const float* Wd;
+    float* dPRE;                                             // (B*Tn,64)
+    float* slabs;                                            // [gridDim.x][11][32][32] gradient tiles
+    float* tsum;                                             // [ntiles][96]: column sums of dF | dG | dXn
+    float* dX; float* dU;                                    // K2 outputs
+    int B, T, Tn, d, o, ow, ldz, tpb;
+};
+enum { GQ_W1F = 0, GQ_W1G, GQ_W0F, GQ_W0G, GQ_LCF0, GQ_LCF1, GQ_LCF2, GQ_LCG0, GQ_LCG1, GQ_LCG2, GQ_WD, GQ_N };
+
+__global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
+{
+    __shared__ float red[4][32 * 33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, hh = lane >> 5;
+    float bwd[16];                                           // Wd^T as B operand: lane (n, hh): Wd[n][k = 8i + 4hh + j]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bwd[4 * i + j] = a.Wd[n * 32 + 8 * i + 4 * hh + j];
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 g[GQ_N];
+#pragma unroll
+    for (int q = 0; q < GQ_N; ++q) g[q] = zero;
+    const int ntiles = a.B * a.tpb, nwaves = gridDim.x * 4;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += nwaves) {
+        const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
+        // ---- dZ = dXn Wd^T
+        f32x16 cz = zero;
+        {
+            const int t = t0 + (lane & 31);
+            const float* p = a.dXn + ((long long)b * a.Tn + t) * 32 + 4 * hh;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4t q = tr_ld4(p + 8 * i, t < a.Tn);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cz = __builtin_amdgcn_mfma_f32_32x32x2f32(q[j], bwd[4 * i + j], cz, 0, 0, 0);
+            }
+        }
+        // ---- C layout operands: lane = channel n, register r = row rho
+        float dF[16], dG[16], zc[16], dxc[16], x1[16], x0[16], u0[16], u1[16], u2[16];
+        float sf = 0.0f, sg_ = 0.0f, sx = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const bool in = t < a.Tn, valid = in && t >= a.o;
+            const long long row = (long long)b * a.Tn + t;
+            float dz = cz[r];
+            if (in && t >= a.Tn - a.ow) dz += a.dZC[((long long)b * a.ow + (t - (a.Tn - a.ow))) * a.ldz + n];
+            const float th = in ? a.TH[row * 32 + n] : 0.0f, sg = in ? a.SG[row * 32 + n] : 0.0f;
+            float df = 0.0f, dg = 0.0f;
+            if (valid) { df = dz * sg * (1.0f - th * th); dg = dz * th * sg * (1.0f - sg); }
+            dF[r] = df; dG[r] = dg; zc[r] = th * sg;
+            dxc[r] = in ? a.dXn[row * 32 + n] : 0.0f;
+            x1[r] = in ? a.X[row * 32 + n] : 0.0f;
+            x0[r] = (in && t >= a.d) ? a.X[(row - a.d) * 32 + n] : 0.0f;
+            const float* ur = a.U + ((long long)b * a.T + (t - a.o)) * 80;
+            u0[r] = valid ? ur[n] : 0.0f; u1[r] = valid ? ur[32 + n] : 0.0f; u2[r] = (valid && n < 16) ? ur[64 + n] : 0.0f;
+            if (in) { a.dPRE[row * 64 + n] = df; a.dPRE[row * 64 + 32 + n] = dg; }
+            sf += df; sg_ += dg; sx += dxc[r];
+        }
+        // per-tile column sums (bias and gc gradients): halves combined, lanes 0..31 write
+        {
+            const float of = __shfl_xor(sf, 32), og = __shfl_xor(sg_, 32), ox = __shfl_xor(sx, 32);
+            if (hh == 0) { a.tsum[(long long)tile * 96 + n] = sf + of; a.tsum[(long long)tile * 96 + 32 + n] = sg_ + og; a.tsum[(long long)tile * 96 + 64 + n] = sx + ox; }
+        }
+        // ---- weight gradients: A = [row rho][channel], B = dF / dG / dXn registers
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            g[GQ_W1F] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[r], dF[r], g[GQ_W1F], 0, 0, 0);
+            g[GQ_W1G] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[r], dG[r], g[GQ_W1G], 0, 0, 0);
+            g[GQ_W0F] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[r], dF[r], g[GQ_W0F], 0, 0, 0);
+            g[GQ_W0G] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[r], dG[r], g[GQ_W0G], 0, 0, 0);
+            g[GQ_LCF0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0[r], dF[r], g[GQ_LCF0], 0, 0, 0);
+            g[GQ_LCG0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0[r], dG[r], g[GQ_LCG0], 0, 0, 0);
+            g[GQ_LCF1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1[r], dF[r], g[GQ_LCF1], 0, 0, 0);
+            g[GQ_LCG1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1[r], dG[r], g[GQ_LCG1], 0, 0, 0);
+            g[GQ_LCF2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2[r], dF[r], g[GQ_LCF2], 0, 0, 0);
+            g[GQ_LCG2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2[r], dG[r], g[GQ_LCG2], 0, 0, 0);
+            g[GQ_WD] = __builtin_amdgcn_mfma_f32_32x32x2f32(zc[r], dxc[r], g[GQ_WD], 0, 0, 0);
+        }
+    }
+    // ---- one slab per workgroup: the four waves' tiles summed through LDS in a fixed order
+    float* slab = a.slabs + (long long)blockIdx.x * GQ_N * 1024;
+#pragma unroll
+    for (int q = 0; q < GQ_N; ++q) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][((r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + n] = g[q][r];
+        __syncthreads();
+        for (int i = threadIdx.x; i < 1024; i += 256) {
+            const int rr = i >> 5, cc = i & 31;
+            slab[q * 1024 + i] = (red[0][rr * 33 + cc] + red[1][rr * 33 + cc]) + (red[2][rr * 33 + cc] + red[3][rr * 33 + cc]);
+        }
+    }
+}
+// out[(m, n)] of gradient tile q = sum over slabs (fixed order); rows >= mrows are dropped (lc block 2 has 16 rows)
+__global__ __launch_bounds__(256) void tr_slab_reduce_kernel(const float* slabs, int nslab, int q, int mrows, float* out, int ldo)
+{
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float s = 0.0f;
+    if (i < 1024)
+        for (int k = grp; k < nslab; k += 4) s += slabs[((long long)k * GQ_N + q) * 1024 + i];
+    __shared__ float sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && i < 1024 && (i >> 5) < mrows)
+        out[(long long)(i >> 5) * ldo + (i & 31)] = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+}
+
+__global__ void __launch_bounds__(256) tr_layer_bwd2_kernel(LayerBwdArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, hh = lane >> 5;
+    // transposed weights as B operands: lane (n, hh) holds W[n][k = 8i + 4hh + j], k over the 64 filter|gate columns
+    float w1t[32], w0t[32], wl0[32], wl1[32], wl2[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 8 * i + 4 * hh + j;
+            w1t[4 * i + j] = a.W1[n * 64 + k]; w0t[4 * i + j] = a.W0[n * 64 + k];
+            wl0[4 * i + j] = a.Wlc[n * 64 + k]; wl1[4 * i + j] = a.Wlc[(32 + n) * 64 + k];
+            wl2[4 * i + j] = n < 16 ? a.Wlc[(64 + n) * 64 + k] : 0.0f;
+        }
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int ntiles = a.B * a.tpb, nwaves = gridDim.x * 4;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += nwaves) {
+        const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
+        const int t = t0 + (lane & 31);
+        const float* p = a.dPRE + ((long long)b * a.Tn + t) * 64 + 4 * hh;
+        f32x4t qa[8], qb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            qa[i] = tr_ld4(p + 8 * i, t < a.Tn);
+            qb[i] = tr_ld4(p + (long long)a.d * 64 + 8 * i, t + a.d < a.Tn);
+        }
+        f32x16 cx = zero, c0 = zero, c1 = zero, c2 = zero;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cx = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], w1t[4 * i + j], cx, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], wl0[4 * i + j], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], wl1[4 * i + j], c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], wl2[4 * i + j], c2, 0, 0, 0);
+                cx = __builtin_amdgcn_mfma_f32_32x32x2f32(qb[i][j], w0t[4 * i + j], cx, 0, 0, 0);
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tt = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (tt < a.Tn) {
+                const long long row = (long long)b * a.Tn + tt;
+                a.dX[row * 32 + n] = a.dXn[row * 32 + n] + cx[r];
+                if (tt >= a.o) {
+                    float* ur = a.dU + ((long long)b * a.T + (tt - a.o)) * 80;
+                    ur[n] += c0[r]; ur[32 + n] += c1[r];
+                    if (n < 16) ur[64 + n] += c2[r];
+                }
+            }
+        }
     }
 }
 
@@ -640,7 +826,7 @@ extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch,
     if (d.residual_channels != 32 || d.dilation_channels != 32) return twv_fail(TWV_E_UNSUPPORTED, "residual/dilation channels must be 32");
     if (d.scalar_input && (d.out_channels % 3 || d.out_channels > 96)) return twv_fail(TWV_E_UNSUPPORTED, "out_channels must be 3*nr_mix <= 96");
     if (!d.scalar_input && (d.quantization_channels < 2 || d.quantization_channels > 512)) return twv_fail(TWV_E_UNSUPPORTED, "quantization_channels must be in [2, 512] for training");
-    if (!d.lc_channels || !d.gc_channels) return twv_fail(TWV_E_UNSUPPORTED, "the training step expects local and global conditioning (train_vocoder.py)");
+    if (d.lc_channels != 80 || !d.gc_channels) return twv_fail(TWV_E_UNSUPPORTED, "the training step expects num_mels = 80 local and global conditioning (train_vocoder.py, hparams.py:30)");
     twv_wavenet_trainer* h = new twv_wavenet_trainer();
     h->d = d; h->B = batch; h->T = n_samples; h->Tn = n_samples - 1; h->NL = d.n_layers; h->S = d.skip_channels; h->O = d.scalar_input ? d.out_channels : d.quantization_channels;
     h->L = d.lc_channels; h->G = d.gc_channels; h->ifw = d.scalar_input ? d.initial_filter_width : 2;   // model.py:36-39
@@ -688,6 +874,7 @@ extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch,
     f += (long long)batch * 64 * (h->NL + 2) + (long long)batch * h->G * 2;
     f += 2 * ((long long)h->NL * (64LL * (64 + h->L + h->G) + 32LL * h->S));   // weight views + their gradients
     f += 512LL * 96 * 64 + 1024LL * 512;        // reduction partials
+    f += 256LL * 11 * 1024 + (long long)batch * ((h->Tn + 31) / 32) * 96;   // fused-backward gradient slabs, per-tile column sums
     f += 64 * 64;                               // rounding slack
     h->ws_floats = f;
     *out = h;
@@ -750,6 +937,8 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
     float* WV = take(vstride * NL); float* WS = take((long long)ZW * S);       // weight views
     float* GV = take(vstride * NL); float* GS = take((long long)ZW * S);       // gradient views
     float* part = take(512LL * 96 * 64 + 1024LL * 512);
+    float* slabs = take(256LL * GQ_N * 1024);
+    float* tsum = take((long long)B * ((Tn + 31) / 32) * 96);
     int rc = TWV_OK;
 #define K1(kern, n, ...) hipLaunchKernelGGL(kern, dim3(tg(n)), dim3(256), 0, st, __VA_ARGS__)
 #define LP(l) (P + h->c_layer0 + (long long)(l) * h->c_lstride)
@@ -798,7 +987,7 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             fa.B = B; fa.T = T; fa.Tn = Tn; fa.d = dl; fa.o = o; fa.ow = ow; fa.ldz = ZW; fa.tpb = (Tn + 31) / 32;
             {
                 const int ntiles = B * fa.tpb;
-                int nwg = (ntiles + 3) / 4; nwg = nwg > 512 ? 512 : nwg;
+                int nwg = (ntiles + 3) / 4; nwg = nwg > 256 ? 256 : nwg;      // one workgroup per CU, each wave walks its tiles
                 hipLaunchKernelGGL(tr_layer_fwd_kernel, dim3(nwg), dim3(256), 0, st, fa);
             }
         }
@@ -846,36 +1035,35 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             float* Lg = LG(l);
             const float* Wv = WV + l * vstride;
             float* Gv = GV + l * vstride;
-            const int M = (int)(Rr - dl);
-            // dense 1x1: dWd, dbd, dZ (+ the skip path's share on the last `ow` positions)
-            K1(tr_mul_kernel, Rr * 32, TH[l], SG[l], Z[0], Rr * 32);          // z = tanh * sigmoid (not stored by the fused forward)
-            wgrad(Z[0], 32, dXn, 32, Rr, 32, 32, Lg + h->lo.wd, 32);
-            if (ub) colsum(dXn, Rr, 32, 32, 1, Lg + h->lo.bd, 32);
-            rc |= gemm_rm(bl, false, true, (int)Rr, 32, 32, 1.f, dXn, 32, Lp + h->lo.wd, 32, 0.f, dZ, 32);
-            K1(tr_scatter_add_kernel, RO * 32, dZC + l * 32, dZ, B, Tn, ow, ZW);
-            // gated unit
-            K1(tr_gate_bwd_kernel, Rr * 32, dZ, TH[l], SG[l], PRE, B, Tn, o);
-            float* dPRE = PRE;
-            // gc: dGCP[b] = sum_t dPRE[b,t] ; conv biases = sum_b dGCP[b] ; dWgc = emb^T dGCP ; demb += dGCP Wgc^T
-            colsum(dPRE, Tn, 64, 64, B, dGCP, 64);
+            LayerBwdArgs ba;
+            ba.dXn = dXn; ba.dZC = dZC + l * 32; ba.TH = TH[l]; ba.SG = SG[l]; ba.X = X[l]; ba.U = U;
+            ba.W0 = Wv; ba.W1 = Wv + 32 * 64; ba.Wlc = Wv + 64 * 64; ba.Wd = Lp + h->lo.wd;
+            ba.dPRE = PRE; ba.slabs = slabs; ba.tsum = tsum; ba.dX = dXc; ba.dU = dUa;
+            ba.B = B; ba.T = T; ba.Tn = Tn; ba.d = dl; ba.o = o; ba.ow = ow; ba.ldz = ZW; ba.tpb = (Tn + 31) / 32;
+            const int ntiles = B * ba.tpb;
+            int nwg = (ntiles + 3) / 4; nwg = nwg > 256 ? 256 : nwg;
+            hipLaunchKernelGGL(tr_layer_bwd1_kernel, dim3(nwg), dim3(256), 0, st, ba);
+            hipLaunchKernelGGL(tr_layer_bwd2_kernel, dim3(nwg), dim3(256), 0, st, ba);
+            // gradient tiles -> views / canonical slots
+            auto slabred = [&](int q, int mrows, float* out, int ldo) {
+                hipLaunchKernelGGL(tr_slab_reduce_kernel, dim3(16), dim3(256), 0, st, slabs, nwg, q, mrows, out, ldo);
+            };
+            slabred(GQ_W0F, 32, Gv, 64); slabred(GQ_W0G, 32, Gv + 32, 64);
+            slabred(GQ_W1F, 32, Gv + 32 * 64, 64); slabred(GQ_W1G, 32, Gv + 32 * 64 + 32, 64);
+            slabred(GQ_LCF0, 32, Gv + 64 * 64, 64); slabred(GQ_LCG0, 32, Gv + 64 * 64 + 32, 64);
+            slabred(GQ_LCF1, 32, Gv + 96 * 64, 64); slabred(GQ_LCG1, 32, Gv + 96 * 64 + 32, 64);
+            slabred(GQ_LCF2, L - 64, Gv + 128 * 64, 64); slabred(GQ_LCG2, L - 64, Gv + 128 * 64 + 32, 64);
+            slabred(GQ_WD, 32, Lg + h->lo.wd, 32);
+            // gc: dGCP[b] = sum_t dPRE[b,t] (from the per-tile sums) ; conv biases = sum_b dGCP[b] ; dWgc = emb^T dGCP ; demb += dGCP Wgc^T
+            colsum(tsum, ba.tpb, 64, 96, B, dGCP, 64);
             if (ub) {
+                colsum(tsum + 64, ntiles, 32, 96, 1, Lg + h->lo.bd, 32);
                 colsum(dGCP, B, 64, 64, 1, part + 1024LL * 512 + 4096, 64);     // 64 sums parked behind the partials
                 HIPCHK(hipMemcpyAsync(Lg + h->lo.bf, part + 1024LL * 512 + 4096, 32 * 4, hipMemcpyDeviceToDevice, st));
                 HIPCHK(hipMemcpyAsync(Lg + h->lo.bg, part + 1024LL * 512 + 4096 + 32, 32 * 4, hipMemcpyDeviceToDevice, st));
             }
             rc |= gemm_rm(bl, true, false, G, 64, B, 1.f, emb, G, dGCP, 64, 0.f, Gv + (64 + L) * 64, 64);
             rc |= gemm_rm(bl, false, true, B, G, 64, 1.f, dGCP, 64, Wv + (64 + L) * 64, 64, 1.f, demb, G);
-            // lc: dLCP = shifted dPRE ; dWlc = U^T dLCP ; dU += dLCP Wlc^T
-            K1(tr_shift_lc_kernel, RT * 64, dPRE, LCP, B, Tn, T, o);
-            wgrad(U, L, LCP, 64, RT, L, 64, Gv + 64 * 64, 64);
-            rc |= gemm_rm(bl, false, true, (int)RT, L, 64, 1.f, LCP, 64, Wv + 64 * 64, 64, 1.f, dUa, L);
-            // conv weights: tap 0 pairs dPRE[r] with X[r-d], tap 1 with X[r]
-            wgrad(X[l], 32, dPRE + (long long)dl * 64, 64, M, 32, 64, Gv, 64);
-            wgrad(X[l] + (long long)dl * 32, 32, dPRE + (long long)dl * 64, 64, M, 32, 64, Gv + 32 * 64, 64);
-            // dX_l = dX_{l+1} (residual) + taps
-            HIPCHK(hipMemcpyAsync(dXc, dXn, (size_t)Rr * 32 * 4, hipMemcpyDeviceToDevice, st));
-            rc |= gemm_rm(bl, false, true, M, 32, 64, 1.f, dPRE + (long long)dl * 64, 64, Wv, 64, 1.f, dXc, 32);
-            rc |= gemm_rm(bl, false, true, M, 32, 64, 1.f, dPRE + (long long)dl * 64, 64, Wv + 32 * 64, 64, 1.f, dXc + (long long)dl * 32, 32);
             float* tsw = dXn; dXn = dXc; dXc = tsw;
         }
         if (rc) break;
