@@ -633,18 +633,19 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
         }
     }
 }
-// out[(m, n)] of gradient tile q = sum over slabs (fixed order); rows >= mrows are dropped (lc block 2 has 16 rows)
-__global__ __launch_bounds__(256) void tr_slab_reduce_kernel(const float* slabs, int nslab, int q, int mrows, float* out, int ldo)
+// every gradient tile q of a layer: out_q[(m, n)] = sum over slabs (fixed order); rows >= mrows are dropped (lc block 2 has 16 rows)
+struct SlabDst { float* out[GQ_N]; int ldo[GQ_N]; int mrows[GQ_N]; };
+__global__ __launch_bounds__(256) void tr_slab_reduce_kernel(const float* slabs, int nslab, SlabDst dst)
 {
+    const int q = blockIdx.y;
     const int i = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     float s = 0.0f;
-    if (i < 1024)
-        for (int k = grp; k < nslab; k += 4) s += slabs[((long long)k * GQ_N + q) * 1024 + i];
+    for (int k = grp; k < nslab; k += 4) s += slabs[((long long)k * GQ_N + q) * 1024 + i];
     __shared__ float sh[256];
     sh[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x < 64 && i < 1024 && (i >> 5) < mrows)
-        out[(long long)(i >> 5) * ldo + (i & 31)] = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+    if (threadIdx.x < 64 && (i >> 5) < dst.mrows[q])
+        dst.out[q][(long long)(i >> 5) * dst.ldo[q] + (i & 31)] = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
 }
 
 __global__ void __launch_bounds__(256) tr_layer_bwd2_kernel(LayerBwdArgs a)
@@ -674,6 +675,16 @@ __global__ void __launch_bounds__(256) tr_layer_bwd2_kernel(LayerBwdArgs a)
             qa[i] = tr_ld4(p + 8 * i, t < a.Tn);
             qb[i] = tr_ld4(p + (long long)a.d * 64 + 8 * i, t + a.d < a.Tn);
         }
+        // operands of the read-modify-writes in the output (C) layout: requested before the MFMAs
+        float rx[16], r0[16], r1[16], r2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tt = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const bool in = tt < a.Tn, v = in && tt >= a.o;
+            rx[r] = in ? a.dXn[((long long)b * a.Tn + tt) * 32 + n] : 0.0f;
+            const float* ur = a.dU + ((long long)b * a.T + (tt - a.o)) * 80;
+            r0[r] = v ? ur[n] : 0.0f; r1[r] = v ? ur[32 + n] : 0.0f; r2[r] = (v && n < 16) ? ur[64 + n] : 0.0f;
+        }
         f32x16 cx = zero, c0 = zero, c1 = zero, c2 = zero;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -689,12 +700,11 @@ __global__ void __launch_bounds__(256) tr_layer_bwd2_kernel(LayerBwdArgs a)
         for (int r = 0; r < 16; ++r) {
             const int tt = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (tt < a.Tn) {
-                const long long row = (long long)b * a.Tn + tt;
-                a.dX[row * 32 + n] = a.dXn[row * 32 + n] + cx[r];
+                a.dX[((long long)b * a.Tn + tt) * 32 + n] = rx[r] + cx[r];
                 if (tt >= a.o) {
                     float* ur = a.dU + ((long long)b * a.T + (tt - a.o)) * 80;
-                    ur[n] += c0[r]; ur[32 + n] += c1[r];
-                    if (n < 16) ur[64 + n] += c2[r];
+                    ur[n] = r0[r] + c0[r]; ur[32 + n] = r1[r] + c1[r];
+                    if (n < 16) ur[64 + n] = r2[r] + c2[r];
                 }
             }
         }
@@ -1045,15 +1055,17 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             hipLaunchKernelGGL(tr_layer_bwd1_kernel, dim3(nwg), dim3(256), 0, st, ba);
             hipLaunchKernelGGL(tr_layer_bwd2_kernel, dim3(nwg), dim3(256), 0, st, ba);
             // gradient tiles -> views / canonical slots
-            auto slabred = [&](int q, int mrows, float* out, int ldo) {
-                hipLaunchKernelGGL(tr_slab_reduce_kernel, dim3(16), dim3(256), 0, st, slabs, nwg, q, mrows, out, ldo);
-            };
-            slabred(GQ_W0F, 32, Gv, 64); slabred(GQ_W0G, 32, Gv + 32, 64);
-            slabred(GQ_W1F, 32, Gv + 32 * 64, 64); slabred(GQ_W1G, 32, Gv + 32 * 64 + 32, 64);
-            slabred(GQ_LCF0, 32, Gv + 64 * 64, 64); slabred(GQ_LCG0, 32, Gv + 64 * 64 + 32, 64);
-            slabred(GQ_LCF1, 32, Gv + 96 * 64, 64); slabred(GQ_LCG1, 32, Gv + 96 * 64 + 32, 64);
-            slabred(GQ_LCF2, L - 64, Gv + 128 * 64, 64); slabred(GQ_LCG2, L - 64, Gv + 128 * 64 + 32, 64);
-            slabred(GQ_WD, 32, Lg + h->lo.wd, 32);
+            {
+                SlabDst sd;
+                auto put = [&](int q, int mrows, float* out, int ldo) { sd.out[q] = out; sd.ldo[q] = ldo; sd.mrows[q] = mrows; };
+                put(GQ_W0F, 32, Gv, 64); put(GQ_W0G, 32, Gv + 32, 64);
+                put(GQ_W1F, 32, Gv + 32 * 64, 64); put(GQ_W1G, 32, Gv + 32 * 64 + 32, 64);
+                put(GQ_LCF0, 32, Gv + 64 * 64, 64); put(GQ_LCG0, 32, Gv + 64 * 64 + 32, 64);
+                put(GQ_LCF1, 32, Gv + 96 * 64, 64); put(GQ_LCG1, 32, Gv + 96 * 64 + 32, 64);
+                put(GQ_LCF2, L - 64, Gv + 128 * 64, 64); put(GQ_LCG2, L - 64, Gv + 128 * 64 + 32, 64);
+                put(GQ_WD, 32, Lg + h->lo.wd, 32);
+                hipLaunchKernelGGL(tr_slab_reduce_kernel, dim3(16, GQ_N), dim3(256), 0, st, slabs, nwg, sd);
+            }
             // gc: dGCP[b] = sum_t dPRE[b,t] (from the per-tile sums) ; conv biases = sum_b dGCP[b] ; dWgc = emb^T dGCP ; demb += dGCP Wgc^T
             colsum(tsum, ba.tpb, 64, 96, B, dGCP, 64);
             if (ub) {
