@@ -222,6 +222,91 @@ __global__ void __launch_bounds__(256) tc_gemm_mfma_kernel(GemmArgs a)
     }
 }
 
+// Few rows, deep contraction (encoder CBHG: 3232 rows, K up to 6144): the 64-row kernel would fill ~50 CUs and run 192 chunks
+// back to back per wave.  Here a workgroup owns ONE 32-row x 64-column tile and its 4 waves take the chunks round-robin; the
+// chunk values meet in LDS and are added to the running total strictly in chunk order (AC-1), each wave keeping a quarter of it.
+__global__ void __launch_bounds__(256) tc_gemm_mfma_ck_kernel(GemmArgs a)
+{
+    __shared__ float cv[4][2][16][64];                        // [chunk slot][column half][register][lane]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * 32;
+    const int nchunk = (a.K + 31) / 32;
+    const int nb = blockIdx.y;
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float tot[2][4];                                          // registers 4*wave .. 4*wave+3 of both halves
+    MmRow r;
+    {
+        const int row = row0 + (lane & 31);
+        r.ok = row < a.rows;
+        r.t = r.ok ? row % a.T : 0;
+        r.seq = a.X + (long long)(r.ok ? row - r.t : 0) * a.ldx;
+    }
+    const int hh = (lane >> 5) * 4;
+    const float* wt = a.Wt + (long long)nb * nchunk * kTile;
+    for (int c0 = 0; c0 < nchunk; c0 += 4) {
+        const int ch = c0 + wave;
+        if (ch < nchunk) {
+            Tile tl;
+            MmA A;
+            load_tile(tl, wt + (long long)ch * kTile, lane);
+            int kg = ch * 32 + hh, tap = 0, c = kg;
+            if (a.kw > 1) { tap = kg / a.Cin; c = kg - tap * a.Cin; }
+            mm_load_a(A, a, r, kg, tap, c);
+            f32x16 acc0[4], acc1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ka = j + 8 * i;
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tl.w[ka]), __float_as_uint(tl.w[ka + 4]), false, false);
+                    const float b0 = __uint_as_float(sw[0]), b1 = __uint_as_float(sw[1]);
+                    const float a0 = A.q[i][j];
+                    acc0[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, i == 0 ? zero : acc0[j], 0, 0, 0);
+                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, i == 0 ? zero : acc1[j], 0, 0, 0);
+                }
+            }
+            const f32x16 v0 = (acc0[0] + acc0[1]) + (acc0[2] + acc0[3]);
+            const f32x16 v1 = (acc1[0] + acc1[1]) + (acc1[2] + acc1[3]);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { cv[wave][0][q][lane] = v0[q]; cv[wave][1][q][lane] = v1[q]; }
+        }
+        __syncthreads();
+        const int nl = min(4, nchunk - c0);
+        for (int s = 0; s < nl; ++s)                           // chunk order
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = cv[s][h][4 * wave + q][lane];
+                    tot[h][q] = (c0 == 0 && s == 0) ? v : tot[h][q] + v;
+                }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int n = nb * 64 + h * 32 + (lane & 31);
+        if (n < a.N) {
+            const float bv = a.bias ? a.bias[n] : 0.0f;
+            const float iv = a.bn_inv ? a.bn_inv[n] : 1.0f, sv = a.bn_inv ? a.bn_shift[n] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = 4 * wave + q;
+                const int row = row0 + (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
+                if (row < a.rows) {
+                    float v = tot[h][q];
+                    if (a.bias) v = v + bv;
+                    v = tc_act(v, a.act);
+                    if (a.bn_inv) { const float y = v * iv; v = y + sv; }
+                    if (a.add1) v = v + a.add1[(long long)row * a.ld1 + n];
+                    if (a.add2) v = v + a.add2[(long long)(row / a.T) * a.ld2 + n];
+                    a.Y[(long long)row * a.ldy + a.col0 + n] = v;
+                }
+            }
+        }
+    }
+}
+
 // ---- small elementwise kernels ----------------------------------------------------------------------------------------
 // tacotron.py:51-60 embedding lookup with row 0 forced to zeros
 __global__ void tc_embed_kernel(const float* table, const int32_t* tokens, int rows, int E, float* out)
@@ -1271,7 +1356,12 @@ static void launch_gemm(hipStream_t st, const float* P, const float* X, int ldx,
     if (g_gemm_valu)
         hipLaunchKernelGGL(tc_gemm_kernel, dim3((rows + kGemmRows - 1) / kGemmRows), dim3(256), kGemmRows * kGemmKS * 4, st, a);
     else {
-        hipLaunchKernelGGL(tc_gemm_mfma_kernel, dim3((rows + kMmRows - 1) / kMmRows, (W.N + 127) / 128), dim3(256), 0, st, a);
+        const int nchunk_ = (W.K + 31) / 32;
+        const long long wgs = (long long)((rows + kMmRows - 1) / kMmRows) * ((W.N + 127) / 128);
+        if (wgs < 192 && nchunk_ >= 8)      // too few tiles for the chip and a deep contraction: chunk-parallel waves
+            hipLaunchKernelGGL(tc_gemm_mfma_ck_kernel, dim3((rows + 31) / 32, (W.N + 63) / 64), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL(tc_gemm_mfma_kernel, dim3((rows + kMmRows - 1) / kMmRows, (W.N + 127) / 128), dim3(256), 0, st, a);
     }
 }
 
