@@ -43,6 +43,8 @@ def flatten(specs, tensors):
     """dict name -> array  ==>  canonical float32 blob."""
     parts = []
     for name, shape in specs:
+        if name not in tensors:
+            raise ValueError("checkpoint tensor %s is missing" % name)
         t = np.asarray(tensors[name], dtype=np.float32)
         if tuple(t.shape) != tuple(shape):
             raise ValueError("tensor %s has shape %s, expected %s" % (name, t.shape, shape))

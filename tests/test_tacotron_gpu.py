@@ -97,3 +97,31 @@ def test_decoder_launch_geometry_does_not_change_results(torch_cuda, oracle, gro
     assert first_mismatch(lin.cpu().numpy(), lin_o) is None
     mel2, _, _ = m.infer(tok, ln, spk)                                  # a second pass reuses the exchange buffers
     assert first_mismatch(mel2.cpu().numpy(), mel_o) is None
+
+
+def test_tacotron_minimal_and_long_inputs(torch_cuda, oracle):
+    """edge cases: a single EOS token; one utterance; an input longer than 256 tokens (more than one key row per thread)"""
+    hp = _hp(max_iters=3, enc_bank_size=2, post_bank_size=2, num_freq=33)
+    for N, T, lengths in ((1, 1, [1]), (2, 2, [2, 1]), (1, 300, [300])):
+        d, blob, tok, ln, spk, m = _case(oracle, hp, N, T, lengths, seed=7)
+        mel_o, lin_o, al_o = oracle.taco_infer(d, blob, tok, ln, spk)
+        mel, lin, al = m.infer(tok, ln, spk)
+        assert first_mismatch(mel.cpu().numpy(), mel_o) is None, (N, T)
+        assert first_mismatch(al.cpu().numpy(), al_o) is None, (N, T)
+        assert first_mismatch(lin.cpu().numpy(), lin_o) is None, (N, T)
+
+
+def test_tacotron_gemm_kernels_agree(torch_cuda, oracle):
+    """the VALU GEMM (option gemm_valu) and the MFMA GEMM give the same bits (both equal the oracle)"""
+    hp = _hp(max_iters=4, enc_bank_size=5, post_bank_size=3, num_freq=65)
+    d, blob, tok, ln, spk, m = _case(oracle, hp, 2, 33, [33, 17], seed=13)
+    mel_a, lin_a, _ = m.infer(tok, ln, spk)
+    m.set_option("gemm_valu", 1)
+    try:
+        mel_b, lin_b, _ = m.infer(tok, ln, spk)
+    finally:
+        m.set_option("gemm_valu", 0)
+    assert first_mismatch(mel_a.cpu().numpy(), mel_b.cpu().numpy()) is None
+    assert first_mismatch(lin_a.cpu().numpy(), lin_b.cpu().numpy()) is None
+    mel_o, lin_o, _ = oracle.taco_infer(d, blob, tok, ln, spk)
+    assert first_mismatch(mel_a.cpu().numpy(), mel_o) is None and first_mismatch(lin_a.cpu().numpy(), lin_o) is None

@@ -304,3 +304,36 @@ def test_generate_cli(torch_cuda, tmp_path):
     # restore defaults for the other tests (hparams is a module singleton, like the reference's)
     d = twvk_amd.default_hparams()
     twvk_amd.hparams.__dict__.update(d.__dict__)
+
+
+# ---------------------------------------------------------------- edge cases
+def test_generate_single_step_and_ragged_lengths(torch_cuda, oracle):
+    """T = 1 (one sample), then odd lengths that are not a multiple of anything"""
+    dil = [1, 2, 4, 8]
+    for T in (1, 3, 37):
+        d, blob, m, want, got, _ = _run_mol(oracle, torch_cuda, dil, 2, 1, T=T, S=64, scale=0.2)
+        assert got.shape == (2, T)
+        assert first_mismatch(got.cpu().numpy(), want) is None, T
+
+
+def test_generate_large_batch(torch_cuda, oracle):
+    """B = 40 streams: groups falls back so that all stream workgroups stay co-resident (B*G <= CUs)"""
+    dil = [1, 2, 4]
+    d, blob, m, want, got, _ = _run_mol(oracle, torch_cuda, dil, 40, 1, T=12, S=64, scale=0.2)
+    assert first_mismatch(got.cpu().numpy(), want) is None
+
+
+def test_generate_rejects_bad_arguments(torch_cuda, oracle):
+    import twvk_amd
+    from twvk_amd._lib import TwvError
+    from helpers import make_case, make_model, mol_uniforms
+    dil = [1, 2]
+    d, tensors, blob = make_case(oracle, dil, S=64)
+    m = make_model(2, dil, tensors, S=64)
+    up = m.create_upsample(np.zeros((2, 1, 80), np.float32))
+    with pytest.raises(Exception):
+        m.generate(up[:, :10].contiguous(), [0, 1], np.zeros(2, np.float32), mol_uniforms(2, 12, 10))      # lc shorter than T
+    with pytest.raises(TwvError):
+        make_model(2, dil, tensors, S=96)                                                                  # skip_channels not a multiple of 64
+    with pytest.raises(ValueError):
+        make_model(2, dil, {k: v for k, v in list(tensors.items())[1:]}, S=64)                             # a checkpoint tensor is missing
