@@ -117,6 +117,10 @@ int twv_mu_law_encode(const float* audio, int64_t n, int quantization_channels, 
 int twv_mu_law_decode(const int32_t* q, int64_t n, int quantization_channels, float* out, void* stream);
 int twv_mu_law_expand(const float* y, int64_t n, int quantization_channels, float* out, void* stream);
 
+/* utils/audio.py:14-17 save_wav's peak normalisation, per row: out = int16(wav * float32(32767 / max(0.01, max|wav|))).
+ * wav (rows, n) float, out (rows, n) int16, scratch: rows*64 floats. */
+int twv_wav_to_int16(const float* wav, int rows, int64_t n, int16_t* out, float* scratch, void* stream);
+
 /* elementary functions of the arithmetic contract, evaluated on the device (parity tests pin them bit for bit) */
 int twv_eval_elementwise(int fn /*0 tanh,1 sigmoid,2 exp,3 log,4 log1p*/, const float* x, int64_t n, float* out, void* stream);
 int twv_eval_elementwise64(int fn /*0 exp,1 log*/, const double* x, int64_t n, double* out, void* stream);

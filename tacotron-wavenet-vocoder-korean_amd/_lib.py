@@ -70,6 +70,7 @@ def lib():
     L.twv_mu_law_encode.argtypes = [fp, C.c_int64, C.c_int, ip, vp]
     L.twv_mu_law_decode.argtypes = [ip, C.c_int64, C.c_int, fp, vp]
     L.twv_mu_law_expand.argtypes = [fp, C.c_int64, C.c_int, fp, vp]
+    L.twv_wav_to_int16.argtypes = [fp, C.c_int, C.c_int64, vp, fp, vp]
     L.twv_eval_elementwise.argtypes = [C.c_int, fp, C.c_int64, fp, vp]
     L.twv_eval_elementwise64.argtypes = [C.c_int, dp, C.c_int64, dp, vp]
     L.twv_selftest.argtypes = [fp, vp]
@@ -100,7 +101,7 @@ EXPORTS = ["twv_last_error", "twv_version", "twv_wavenet_create", "twv_wavenet_d
            "twv_wavenet_hop_size", "twv_wavenet_blob_floats", "twv_wavenet_packed_bytes", "twv_wavenet_state_bytes",
            "twv_wavenet_cond_bytes", "twv_wavenet_pack", "twv_wavenet_reset_state", "twv_wavenet_upsample",
            "twv_wavenet_condition", "twv_wavenet_generate", "twv_wavenet_prime", "twv_wavenet_status", "twv_wavenet_set_option", "twv_wavenet_set_profile_buffer",
-           "twv_mu_law_encode", "twv_mu_law_decode", "twv_mu_law_expand", "twv_eval_elementwise",
+           "twv_mu_law_encode", "twv_mu_law_decode", "twv_mu_law_expand", "twv_wav_to_int16", "twv_eval_elementwise",
            "twv_eval_elementwise64", "twv_selftest", "twv_tacotron_create", "twv_tacotron_destroy", "twv_tacotron_blob_floats",
            "twv_tacotron_packed_bytes", "twv_tacotron_workspace_bytes", "twv_tacotron_pack", "twv_tacotron_infer", "twv_tacotron_set_profile_buffer", "twv_tacotron_set_option",
            "twv_wavenet_train_create", "twv_wavenet_train_destroy", "twv_wavenet_train_param_floats", "twv_wavenet_train_workspace_bytes",

@@ -1023,6 +1023,32 @@ __global__ void wn_eval64_kernel(int fn, const double* x, long long n, double* o
         out[i] = fn == 0 ? exp64_e(x[i]) : log64_e(x[i]);
 }
 
+
+// utils/audio.py:14-17 save_wav: wav *= 32767 / max(0.01, max|wav|); astype(int16) -- per utterance (row), on the device
+__global__ void __launch_bounds__(256) wn_wav_peak_kernel(const float* wav, long long n, int nchunk, float* part)
+{
+    // grid (nchunk, rows): partial max |x| of a chunk of row blockIdx.y   (max is exact in any order)
+    const float* x = wav + (long long)blockIdx.y * n;
+    const long long per = (n + nchunk - 1) / nchunk, i0 = (long long)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+    float m = 0.0f;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) m = fmaxf(m, fabsf(x[i]));
+    __shared__ float sh[256];
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if ((int)threadIdx.x < st) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + st]); __syncthreads(); }
+    if (threadIdx.x == 0) part[blockIdx.y * nchunk + blockIdx.x] = sh[0];
+}
+__global__ void wn_wav_int16_kernel(const float* wav, long long n, int nchunk, const float* part, int16_t* out)
+{
+    const int row = blockIdx.y;
+    float m = 0.0f;
+    for (int k = 0; k < nchunk; ++k) m = fmaxf(m, part[row * nchunk + k]);
+    const double md = (double)m;
+    const float scale = (float)(32767.0 / (md > 0.01 ? md : 0.01));          // python float division, then the float32 in-place multiply
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[(long long)row * n + i] = (int16_t)(int)(wav[(long long)row * n + i] * scale);   // astype(int16): truncation toward zero
+}
+
 // cross-lane primitive self-test: out[lane] = {permlane32_swap result 0, result 1, readlane(5), shfl(lane^1)}
 __global__ void wn_selftest_kernel(float* out)
 {
@@ -1467,6 +1493,16 @@ extern "C" int twv_mu_law_expand(const float* y, int64_t n, int Q, float* out, v
 {
     if (!y || !out || n < 0 || Q < 2) return fail(TWV_E_INVALID, "bad argument");
     if (n) hipLaunchKernelGGL(wn_mulaw_expand_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, y, (long long)n, Q, out);
+    HIPCHK(hipGetLastError());
+    return TWV_OK;
+}
+
+extern "C" int twv_wav_to_int16(const float* wav, int rows, int64_t n, int16_t* out, float* scratch, void* stream)
+{
+    if (!wav || !out || !scratch || rows < 1 || n < 1) return fail(TWV_E_INVALID, "bad argument");
+    const int nchunk = 64;
+    hipLaunchKernelGGL(wn_wav_peak_kernel, dim3(nchunk, rows), dim3(256), 0, (hipStream_t)stream, wav, (long long)n, nchunk, scratch);
+    hipLaunchKernelGGL(wn_wav_int16_kernel, dim3(grid_for(n, 256), rows), dim3(256), 0, (hipStream_t)stream, wav, (long long)n, nchunk, scratch, out);
     HIPCHK(hipGetLastError());
     return TWV_OK;
 }

@@ -38,12 +38,10 @@ def get_arguments(argv=None):
     return args
 
 
-def save_wav(wav, path, sr):
-    """utils/audio.py:14-17: peak-normalise to int16"""
+def save_wav(wav_int16, path, sr):
+    """utils/audio.py:14-17: the peak normalisation / int16 conversion already ran on the device (ops.wav_to_int16)"""
     from scipy.io import wavfile
-    wav = np.array(wav, dtype=np.float32)
-    wav *= 32767 / max(0.01, np.max(np.abs(wav)))
-    wavfile.write(path, sr, wav.astype(np.int16))
+    wavfile.write(path, sr, np.asarray(wav_int16, dtype=np.int16))
 
 
 def _load_seed(path, sr):
@@ -133,11 +131,13 @@ def main(argv=None):
     print('Sample {0}/{0}, ({1:.3f} sec)'.format(sample_size, time.time() - start_time))
 
     if hparams.input_type == 'raw':                                                    # generate.py:249-256
-        wav = out.cpu().numpy()
+        wav = out
     elif hparams.input_type == 'mulaw':
-        wav = mu_law_decode(out, Q, quantization=False).cpu().numpy()
+        wav = mu_law_decode(out, Q, quantization=False)
     else:
-        wav = mu_law_decode(out, Q, quantization=True).cpu().numpy()
+        wav = mu_law_decode(out, Q, quantization=True)
+    from .ops import wav_to_int16
+    wav = wav_to_int16(wav).cpu().numpy()
     paths = []
     for i in range(B):                                                                 # generate.py:259-262
         path = config.wav_out_path if (config.wav_out_path and B == 1) else logdir + '/test-{}.wav'.format(i)

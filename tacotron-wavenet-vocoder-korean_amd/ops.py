@@ -53,3 +53,14 @@ def eval_elementwise(name, x, device="cuda:0"):
         out = torch.empty_like(t)
         _lib.check(L.twv_eval_elementwise(fn, _ptr(t), t.numel(), _ptr(out), _stream()))
     return out
+
+
+def wav_to_int16(wav, device="cuda:0"):
+    """utils/audio.py:14-17 save_wav's peak normalisation + int16 conversion on the device; wav (n,) or (rows, n) -> int16 tensor"""
+    a = torch.as_tensor(wav, dtype=torch.float32, device=device).contiguous()
+    rows, n = (1, a.numel()) if a.dim() == 1 else (a.shape[0], a.shape[1])
+    with torch.cuda.device(a.device):
+        out = torch.empty(a.shape, dtype=torch.int16, device=a.device)
+        scratch = torch.empty(rows * 64, dtype=torch.float32, device=a.device)
+        _lib.check(_lib.lib().twv_wav_to_int16(_ptr(a), rows, n, _ptr(out), _ptr(scratch), _stream()))
+    return out

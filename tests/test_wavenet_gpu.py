@@ -337,3 +337,16 @@ def test_generate_rejects_bad_arguments(torch_cuda, oracle):
         make_model(2, dil, tensors, S=96)                                                                  # skip_channels not a multiple of 64
     with pytest.raises(ValueError):
         make_model(2, dil, {k: v for k, v in list(tensors.items())[1:]}, S=64)                             # a checkpoint tensor is missing
+
+
+def test_wav_to_int16_matches_numpy_save_wav(torch_cuda):
+    """utils/audio.py:14-17: wav *= 32767 / max(0.01, max|wav|); astype(int16) -- bit for bit, including the quiet-signal floor"""
+    from twvk_amd.ops import wav_to_int16
+    rng = np.random.RandomState(3)
+    for scale in (0.7, 1.0, 0.003, 0.0):
+        wav = (rng.randn(3, 10001) * 0.2 * scale).astype(np.float32)
+        got = wav_to_int16(wav).cpu().numpy()
+        for i in range(3):
+            ref = wav[i].copy()
+            ref *= 32767 / max(0.01, np.max(np.abs(ref)))
+            assert np.array_equal(got[i], ref.astype(np.int16)), (scale, i)
