@@ -70,7 +70,46 @@ __global__ void k(float* out, unsigned long long* cyc, const float* w)
     float x = w[lane] * 0.01f;
     int item = 0, slot = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    if (MODE >= 5) {
+    if (MODE == 6) {
+        // weights straight from global/L2 into registers, requested one layer ahead (no LDS weight slots); pre-activation inputs packed b128 from LDS
+        auto gload = [&](Tile& a, Tile& b, int l) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(w + (l * 3072) % 60000);
+#pragma unroll
+            for (int kq = 0; kq < 8; ++kq) { const f32x4 q = p[kq * 64 + lane]; a.w[4*kq]=q.x; a.w[4*kq+1]=q.y; a.w[4*kq+2]=q.z; a.w[4*kq+3]=q.w; }
+#pragma unroll
+            for (int kq = 0; kq < 8; ++kq) { const f32x4 q = p[512 + kq * 32 + (lane & 31)]; b.w[4*kq]=q.x; b.w[4*kq+1]=q.y; b.w[4*kq+2]=q.z; b.w[4*kq+3]=q.w; }
+        };
+        Tile a0, b0, a1, b1;
+        gload(a0, b0, 0);
+        for (int t = 0; t < STEPS; ++t) {
+            for (int l = 0; l < NL; l += 2) {
+#define LAYER(A, B, AN, BN, LL)                                                                                   \
+                {                                                                                                 \
+                    const int slot_n = (slot + 1 == NSLOT) ? 0 : slot + 1;                                        \
+                    const int sb = O_SLOTS + slot * SLOTF;                                                        \
+                    const int rdy = LDSVI(O_CTL + 16 + slot_n);                                                   \
+                    gload(AN, BN, (LL) + 1 < NL ? (LL) + 1 : 0);                                                  \
+                    if (lane < 32) lds[O_X + (LL) * 32 + lane] = x;                                               \
+                    const f32x4 q = LDS4(((sb + 3328) >> 2) + lane);                                              \
+                    const float acc1 = dot_readlane(A, x);                                                        \
+                    float v = q.x + acc1; v = v + q.y; v = v + q.z; v = v + q.w;                                  \
+                    const float act = act_eval(coef, v);                                                          \
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false); \
+                    const float z = __uint_as_float(sw[0]) * __uint_as_float(sw[1]);                              \
+                    if (lane < 32) lds[O_Z + (LL) * 32 + lane] = z;                                               \
+                    asm volatile("" ::: "memory"); if (lane == 0) LDSVI(O_CTL + 0) = item + 1; asm volatile("" ::: "memory"); \
+                    if (rdy < item + 2) { while (LDSVI(O_CTL + 16 + slot_n) < item + 2) __builtin_amdgcn_s_sleep(1); }       \
+                    float tr = dot_readlane(B, z); tr = tr + lds[sb + 3136 + (lane & 31)]; x = x + tr;            \
+                    ++item; slot = slot_n;                                                                        \
+                }
+                LAYER(a0, b0, a1, b1, l)
+                LAYER(a1, b1, a0, b0, l + 1)
+#undef LAYER
+            }
+            x = x * 0.5f;
+        }
+    } else
+    if (MODE == 5) {
         // double-buffered tiles: w1 (cur) / w1n (being fetched during the dense dot); wd (cur) / wdn (fetched during the conv dot)
         Tile w1n, wdn;
         for (int t = 0; t < STEPS; ++t) {
@@ -134,11 +173,11 @@ int main()
     for (size_t i = 0; i < hw.size(); ++i) hw[i] = (float)((i * 7919) % 1000) * 1e-3f - 0.5f;
     hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
     const size_t shm = (O_SLOTS + NSLOT * SLOTF) * 4;
-    const char* names[] = {"product shape", "no flags/ready", "no flags, no LDS fetch", "math only", "product shape, packed small vectors", "interleaved fetch, packed, single flag"};
+    const char* names[] = {"product shape", "no flags/ready", "no flags, no LDS fetch", "math only", "product shape, packed small vectors", "interleaved fetch, packed, single flag", "weights from global one layer ahead, packed, single flag"};
 #define RUN(M) { hipFuncSetAttribute((const void*)k<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
     hipLaunchKernelGGL(k<M>, dim3(1), dim3(64), shm, 0, out, cyc, w); hipDeviceSynchronize(); \
     hipLaunchKernelGGL(k<M>, dim3(1), dim3(64), shm, 0, out, cyc, w); hipDeviceSynchronize(); \
     unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); printf("%-40s %8.1f ticks/layer\n", names[M], (double)c / (STEPS * NL)); }
-    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5)
+    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6)
     return 0;
 }
