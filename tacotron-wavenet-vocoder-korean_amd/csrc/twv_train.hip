@@ -543,15 +543,49 @@ struct LayerBwdArgs {
     float* slabs;                                            // [gridDim.x][11][32][32] gradient tiles
     float* tsum;                                             // [ntiles][96]: column sums of dF | dG | dXn
     float* dX; float* dU;                                    // K2 outputs
+    const float* zeros;                                      // >= 1 KB of zeros (masked LDS-DMA lanes read here)
     int B, T, Tn, d, o, ow, ldz, tpb;
 };
 enum { GQ_W1F = 0, GQ_W1G, GQ_W0F, GQ_W0G, GQ_LCF0, GQ_LCF1, GQ_LCF2, GQ_LCG0, GQ_LCG1, GQ_LCG2, GQ_WD, GQ_N };
 
+// LDS staging of one tile's operands (floats, per wave): LDS-DMA (global_load_lds b128) fills it for tile i+1 while tile i's MFMAs run
+enum { BS_TH = 0, BS_SG = 1024, BS_DXN = 2048, BS_DZC = 3072, BS_X1 = 4096, BS_X0 = 5120, BS_U = 6144, BS_FLOATS = 6144 + 2560 };
+
+__device__ __forceinline__ void tr_bwd1_stage(const LayerBwdArgs& a, int tile, int lane, int base /* float offset of the wave's region in lds[] */)
+{
+    const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
+    const long long row0 = (long long)b * a.Tn + t0;
+    // four arrays whose 32-row tile is 4 KB contiguous: piece p = 1 KB = 8 rows
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const long long off = row0 * 32 + p * 256 + lane * 4;
+        __builtin_amdgcn_global_load_lds((gptr_t)(a.TH + off), (lptr_t)(lds + base + BS_TH + p * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(a.SG + off), (lptr_t)(lds + base + BS_SG + p * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(a.dXn + off), (lptr_t)(lds + base + BS_DXN + p * 256), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(a.X + off), (lptr_t)(lds + base + BS_X1 + p * 256), 16, 0, 0);
+        // x[t-d]: rows before the start of the buffer come from the zero page
+        const long long offd = off - (long long)a.d * 32;
+        __builtin_amdgcn_global_load_lds((gptr_t)(offd >= 0 ? a.X + offd : a.zeros + lane * 4), (lptr_t)(lds + base + BS_X0 + p * 256), 16, 0, 0);
+        // skip share: row r = p*8 + lane/8 of the tile, 4 columns per lane, only the last `ow` positions exist
+        const int r = p * 8 + (lane >> 3), t = t0 + r, pz = t - (a.Tn - a.ow);
+        const bool zok = t < a.Tn && pz >= 0;
+        __builtin_amdgcn_global_load_lds((gptr_t)(zok ? a.dZC + ((long long)b * a.ow + pz) * a.ldz + (lane & 7) * 4 : a.zeros + lane * 4),
+                                         (lptr_t)(lds + base + BS_DZC + p * 256), 16, 0, 0);
+    }
+    // U rows t0-o .. t0-o+31: 10 KB contiguous
+    const long long ubase = ((long long)b * a.T + (t0 - a.o)) * 80;
+#pragma unroll
+    for (int p = 0; p < 10; ++p) {
+        const long long off = ubase + p * 256 + lane * 4;
+        __builtin_amdgcn_global_load_lds((gptr_t)(off >= 0 ? a.U + off : a.zeros + lane * 4), (lptr_t)(lds + base + BS_U + p * 256), 16, 0, 0);
+    }
+}
+
 __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
 {
-    __shared__ float red[4][32 * 33];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, hh = lane >> 5;
+    const int base = wave * BS_FLOATS;
     float bwd[16];                                           // Wd^T as B operand: lane (n, hh): Wd[n][k = 8i + 4hh + j]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -562,46 +596,59 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
 #pragma unroll
     for (int q = 0; q < GQ_N; ++q) g[q] = zero;
     const int ntiles = a.B * a.tpb, nwaves = gridDim.x * 4;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += nwaves) {
+    int tile = blockIdx.x * 4 + wave;
+    if (tile < ntiles) tr_bwd1_stage(a, tile, lane, base);
+    for (; tile < ntiles; tile += nwaves) {
         const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
-        // ---- dZ = dXn Wd^T
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this tile's operands are in LDS
+        // ---- dZ = dXn Wd^T  (A operand: row layout, float4 from the staged tile)
         f32x16 cz = zero;
         {
             const int t = t0 + (lane & 31);
-            const float* p = a.dXn + ((long long)b * a.Tn + t) * 32 + 4 * hh;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const f32x4t q = tr_ld4(p + 8 * i, t < a.Tn);
+                f32x4t q = *reinterpret_cast<const f32x4t*>(&lds[base + BS_DXN + (lane & 31) * 32 + 8 * i + 4 * hh]);
+                if (t >= a.Tn) q = f32x4t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) cz = __builtin_amdgcn_mfma_f32_32x32x2f32(q[j], bwd[4 * i + j], cz, 0, 0, 0);
             }
         }
-        // ---- C layout operands: lane = channel n, register r = row rho
-        float dF[16], dG[16], zc[16], dxc[16], x1[16], x0[16], u0[16], u1[16], u2[16];
-        float sf = 0.0f, sg_ = 0.0f, sx = 0.0f;
+        // ---- C layout operands from LDS: lane = channel n, register r = row rho
+        float th_[16], sg_[16], dzc[16], dxc[16], x1[16], x0[16], u0[16], u1[16], u2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh, t = t0 + rl;
+            const bool in = t < a.Tn, valid = in && t >= a.o;
+            th_[r] = in ? lds[base + BS_TH + rl * 32 + n] : 0.0f;
+            sg_[r] = in ? lds[base + BS_SG + rl * 32 + n] : 0.0f;
+            dxc[r] = in ? lds[base + BS_DXN + rl * 32 + n] : 0.0f;
+            dzc[r] = lds[base + BS_DZC + rl * 32 + n];
+            x1[r] = in ? lds[base + BS_X1 + rl * 32 + n] : 0.0f;
+            x0[r] = (in && t >= a.d) ? lds[base + BS_X0 + rl * 32 + n] : 0.0f;
+            u0[r] = valid ? lds[base + BS_U + rl * 80 + n] : 0.0f;
+            u1[r] = valid ? lds[base + BS_U + rl * 80 + 32 + n] : 0.0f;
+            u2[r] = (valid && n < 16) ? lds[base + BS_U + rl * 80 + 64 + n] : 0.0f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read has returned: the region may be refilled
+        if (tile + nwaves < ntiles) tr_bwd1_stage(a, tile + nwaves, lane, base);
+        float dF[16], dG[16], zc[16];
+        float sf = 0.0f, sgs = 0.0f, sx = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             const bool in = t < a.Tn, valid = in && t >= a.o;
-            const long long row = (long long)b * a.Tn + t;
-            float dz = cz[r];
-            if (in && t >= a.Tn - a.ow) dz += a.dZC[((long long)b * a.ow + (t - (a.Tn - a.ow))) * a.ldz + n];
-            const float th = in ? a.TH[row * 32 + n] : 0.0f, sg = in ? a.SG[row * 32 + n] : 0.0f;
+            const float dz = cz[r] + dzc[r];
+            const float th = th_[r], sg = sg_[r];
             float df = 0.0f, dg = 0.0f;
             if (valid) { df = dz * sg * (1.0f - th * th); dg = dz * th * sg * (1.0f - sg); }
             dF[r] = df; dG[r] = dg; zc[r] = th * sg;
-            dxc[r] = in ? a.dXn[row * 32 + n] : 0.0f;
-            x1[r] = in ? a.X[row * 32 + n] : 0.0f;
-            x0[r] = (in && t >= a.d) ? a.X[(row - a.d) * 32 + n] : 0.0f;
-            const float* ur = a.U + ((long long)b * a.T + (t - a.o)) * 80;
-            u0[r] = valid ? ur[n] : 0.0f; u1[r] = valid ? ur[32 + n] : 0.0f; u2[r] = (valid && n < 16) ? ur[64 + n] : 0.0f;
-            if (in) { a.dPRE[row * 64 + n] = df; a.dPRE[row * 64 + 32 + n] = dg; }
-            sf += df; sg_ += dg; sx += dxc[r];
+            if (in) { const long long row = (long long)b * a.Tn + t; a.dPRE[row * 64 + n] = df; a.dPRE[row * 64 + 32 + n] = dg; }
+            sf += df; sgs += dg; sx += dxc[r];
         }
         // per-tile column sums (bias and gc gradients): halves combined, lanes 0..31 write
         {
-            const float of = __shfl_xor(sf, 32), og = __shfl_xor(sg_, 32), ox = __shfl_xor(sx, 32);
-            if (hh == 0) { a.tsum[(long long)tile * 96 + n] = sf + of; a.tsum[(long long)tile * 96 + 32 + n] = sg_ + og; a.tsum[(long long)tile * 96 + 64 + n] = sx + ox; }
+            const float of = __shfl_xor(sf, 32), og = __shfl_xor(sgs, 32), ox = __shfl_xor(sx, 32);
+            if (hh == 0) { a.tsum[(long long)tile * 96 + n] = sf + of; a.tsum[(long long)tile * 96 + 32 + n] = sgs + og; a.tsum[(long long)tile * 96 + 64 + n] = sx + ox; }
         }
         // ---- weight gradients: A = [row rho][channel], B = dF / dG / dXn registers
 #pragma unroll
@@ -619,17 +666,17 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
             g[GQ_WD] = __builtin_amdgcn_mfma_f32_32x32x2f32(zc[r], dxc[r], g[GQ_WD], 0, 0, 0);
         }
     }
-    // ---- one slab per workgroup: the four waves' tiles summed through LDS in a fixed order
+    // ---- one slab per workgroup: the four waves' tiles summed through LDS (the staging area is free now) in a fixed order
     float* slab = a.slabs + (long long)blockIdx.x * GQ_N * 1024;
 #pragma unroll
     for (int q = 0; q < GQ_N; ++q) {
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave][((r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + n] = g[q][r];
+        for (int r = 0; r < 16; ++r) lds[wave * 1056 + ((r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + n] = g[q][r];
         __syncthreads();
         for (int i = threadIdx.x; i < 1024; i += 256) {
-            const int rr = i >> 5, cc = i & 31;
-            slab[q * 1024 + i] = (red[0][rr * 33 + cc] + red[1][rr * 33 + cc]) + (red[2][rr * 33 + cc] + red[3][rr * 33 + cc]);
+            const int rr = i >> 5, cc = i & 31, o = rr * 33 + cc;
+            slab[q * 1024 + i] = (lds[o] + lds[1056 + o]) + (lds[2112 + o] + lds[3168 + o]);
         }
     }
 }
@@ -884,7 +931,7 @@ extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch,
     f += (long long)batch * 64 * (h->NL + 2) + (long long)batch * h->G * 2;
     f += 2 * ((long long)h->NL * (64LL * (64 + h->L + h->G) + 32LL * h->S));   // weight views + their gradients
     f += 512LL * 96 * 64 + 1024LL * 512;        // reduction partials
-    f += 256LL * 11 * 1024 + (long long)batch * ((h->Tn + 31) / 32) * 96;   // fused-backward gradient slabs, per-tile column sums
+    f += 256LL * 11 * 1024 + 1024 + 64 + (long long)batch * ((h->Tn + 31) / 32) * 96;   // fused-backward gradient slabs, per-tile column sums
     f += 64 * 64;                               // rounding slack
     h->ws_floats = f;
     *out = h;
@@ -948,6 +995,9 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
     float* GV = take(vstride * NL); float* GS = take((long long)ZW * S);       // gradient views
     float* part = take(512LL * 96 * 64 + 1024LL * 512);
     float* slabs = take(256LL * GQ_N * 1024);
+    float* zpage = take(1024);
+    HIPCHK(hipMemsetAsync(zpage, 0, 4096, st));
+    HIPCHK(hipFuncSetAttribute((const void*)tr_layer_bwd1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BS_FLOATS * 4));
     float* tsum = take((long long)B * ((Tn + 31) / 32) * 96);
     int rc = TWV_OK;
 #define K1(kern, n, ...) hipLaunchKernelGGL(kern, dim3(tg(n)), dim3(256), 0, st, __VA_ARGS__)
@@ -1052,7 +1102,8 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             ba.B = B; ba.T = T; ba.Tn = Tn; ba.d = dl; ba.o = o; ba.ow = ow; ba.ldz = ZW; ba.tpb = (Tn + 31) / 32;
             const int ntiles = B * ba.tpb;
             int nwg = (ntiles + 3) / 4; nwg = nwg > 256 ? 256 : nwg;
-            hipLaunchKernelGGL(tr_layer_bwd1_kernel, dim3(nwg), dim3(256), 0, st, ba);
+            ba.zeros = zpage;
+            hipLaunchKernelGGL(tr_layer_bwd1_kernel, dim3(nwg), dim3(256), 4 * BS_FLOATS * 4, st, ba);
             hipLaunchKernelGGL(tr_layer_bwd2_kernel, dim3(nwg), dim3(256), 0, st, ba);
             // gradient tiles -> views / canonical slots
             {
