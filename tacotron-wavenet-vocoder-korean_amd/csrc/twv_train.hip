@@ -425,38 +425,36 @@ __device__ __forceinline__ void tr_layer_load(LayerA& A, const LayerFwdArgs& a, 
     for (int i = 0; i < kLcSteps; ++i) A.u[i] = tr_ld4(ur + 8 * i, in && t >= a.o);
 }
 
-__global__ void __launch_bounds__(256) tr_layer_fwd_kernel(LayerFwdArgs a)
+// Two waves per SIMD (8 per workgroup, <= 256 registers each): while one wave runs its gated-unit epilogue on the VALU the other
+// wave's MFMAs keep the matrix pipe busy -- a lone wave issues in order and never overlaps the two (SQ_VALU_MFMA_COEXEC_CYCLES = 0
+// with one wave per SIMD).  The B operands therefore live in LDS, one conflict-free ds_read_b64 (filter, gate) per MFMA pair.
+constexpr int kFwdSteps = 32 + 4 * kLcSteps;                 // tap0 16 + tap1 16 + lc 40 = 72 MFMA steps per column half
+__global__ void __launch_bounds__(512) tr_layer_fwd_kernel(LayerFwdArgs a)
 {
-    __shared__ float zt[4][32 * 36];
+    __shared__ float bt[kFwdSteps * 128];                    // [step][lane][filter, gate]
+    __shared__ float bdt[16 * 64];                           // dense: [step][lane]
+    __shared__ float zt[8][32 * 36];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 31, hh = lane >> 5;
-    // ---- B operands in registers
-    float b0f[16], b0g[16], b1f[16], b1g[16], blf[4 * kLcSteps], blg[4 * kLcSteps], bdn[16];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = 8 * i + 4 * hh + j;
-            b0f[4 * i + j] = a.W0[k * 64 + n]; b0g[4 * i + j] = a.W0[k * 64 + 32 + n];
-            b1f[4 * i + j] = a.W1[k * 64 + n]; b1g[4 * i + j] = a.W1[k * 64 + 32 + n];
-            bdn[4 * i + j] = a.Wd[k * 32 + n];
-        }
-#pragma unroll
-    for (int i = 0; i < kLcSteps; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = 8 * i + 4 * hh + j;
-            blf[4 * i + j] = a.Wlc[k * 64 + n]; blg[4 * i + j] = a.Wlc[k * 64 + 32 + n];
-        }
+    for (int e = threadIdx.x; e < kFwdSteps * 64; e += 512) {
+        const int s = e >> 6, l = e & 63, nn = l & 31, h2 = l >> 5;
+        const float* W; int ij;
+        if (s < 16) { W = a.W0; ij = s; } else if (s < 32) { W = a.W1; ij = s - 16; } else { W = a.Wlc; ij = s - 32; }
+        const int k = 8 * (ij >> 2) + 4 * h2 + (ij & 3);
+        bt[e * 2] = W[k * 64 + nn]; bt[e * 2 + 1] = W[k * 64 + 32 + nn];
+    }
+    for (int e = threadIdx.x; e < 16 * 64; e += 512) {
+        const int s = e >> 6, l = e & 63;
+        bdt[e] = a.Wd[(8 * (s >> 2) + 4 * (l >> 5) + (s & 3)) * 32 + (l & 31)];
+    }
+    __syncthreads();
+    typedef float f32x2t __attribute__((ext_vector_type(2)));
     const float vbf = a.bf ? a.bf[n] : 0.0f, vbg = a.bg ? a.bg[n] : 0.0f, vbd = a.bd ? a.bd[n] : 0.0f;
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int ntiles = a.B * a.tpb, nwaves = gridDim.x * 4;
-    int tile = blockIdx.x * 4 + wave;
-    LayerA A;
-    tr_layer_load(A, a, tile, lane);
-    for (; tile < ntiles; tile += nwaves) {
-        LayerA An;
-        tr_layer_load(An, a, tile + nwaves, lane);           // next tile's rows travel during this tile's 160 MFMAs
+    const int ntiles = a.B * a.tpb, nwaves = gridDim.x * 8;
+    for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += nwaves) {
+        LayerA A;
+        tr_layer_load(A, a, tile, lane);
         // residual operand and gc projection in the output (C) layout: requested now, consumed after the MFMAs
         const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
         const float gcf = a.gcp ? a.gcp[b * 64 + n] : 0.0f, gcg = a.gcp ? a.gcp[b * 64 + 32 + n] : 0.0f;
@@ -471,22 +469,25 @@ __global__ void __launch_bounds__(256) tr_layer_fwd_kernel(LayerFwdArgs a)
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                cf = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x0[i][j], b0f[4 * i + j], cf, 0, 0, 0);
-                cg = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x0[i][j], b0g[4 * i + j], cg, 0, 0, 0);
+                const f32x2t w = *reinterpret_cast<const f32x2t*>(&bt[((4 * i + j) * 64 + lane) * 2]);
+                cf = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x0[i][j], w[0], cf, 0, 0, 0);
+                cg = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x0[i][j], w[1], cg, 0, 0, 0);
             }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                cf = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x1[i][j], b1f[4 * i + j], cf, 0, 0, 0);
-                cg = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x1[i][j], b1g[4 * i + j], cg, 0, 0, 0);
+                const f32x2t w = *reinterpret_cast<const f32x2t*>(&bt[((16 + 4 * i + j) * 64 + lane) * 2]);
+                cf = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x1[i][j], w[0], cf, 0, 0, 0);
+                cg = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x1[i][j], w[1], cg, 0, 0, 0);
             }
 #pragma unroll
         for (int i = 0; i < kLcSteps; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                cf = __builtin_amdgcn_mfma_f32_32x32x2f32(A.u[i][j], blf[4 * i + j], cf, 0, 0, 0);
-                cg = __builtin_amdgcn_mfma_f32_32x32x2f32(A.u[i][j], blg[4 * i + j], cg, 0, 0, 0);
+                const f32x2t w = *reinterpret_cast<const f32x2t*>(&bt[((32 + 4 * i + j) * 64 + lane) * 2]);
+                cf = __builtin_amdgcn_mfma_f32_32x32x2f32(A.u[i][j], w[0], cf, 0, 0, 0);
+                cg = __builtin_amdgcn_mfma_f32_32x32x2f32(A.u[i][j], w[1], cg, 0, 0, 0);
             }
         // ---- gated unit (C layout: lane = channel n, register r = row (r&3) + 8(r>>2) + 4hh)
 #pragma unroll
@@ -511,7 +512,7 @@ __global__ void __launch_bounds__(256) tr_layer_fwd_kernel(LayerFwdArgs a)
             for (int i = 0; i < 4; ++i) {
                 const f32x4t q = *reinterpret_cast<const f32x4t*>(zr + 8 * i);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cd = __builtin_amdgcn_mfma_f32_32x32x2f32(q[j], bdn[4 * i + j], cd, 0, 0, 0);
+                for (int j = 0; j < 4; ++j) cd = __builtin_amdgcn_mfma_f32_32x32x2f32(q[j], bdt[(4 * i + j) * 64 + lane], cd, 0, 0, 0);
             }
         }
 #pragma unroll
@@ -519,10 +520,8 @@ __global__ void __launch_bounds__(256) tr_layer_fwd_kernel(LayerFwdArgs a)
             const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (t < a.Tn) a.XN[((long long)b * a.Tn + t) * 32 + n] = (xres[r] + cd[r]) + vbd;
         }
-        A = An;
     }
 }
-
 
 // ===================================================================================================================
 //  Fused residual layer, backward.  Two kernels per layer, both on v_mfma_f32_32x32x2_f32 with 32-row tiles per wave:
@@ -1047,8 +1046,8 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             fa.B = B; fa.T = T; fa.Tn = Tn; fa.d = dl; fa.o = o; fa.ow = ow; fa.ldz = ZW; fa.tpb = (Tn + 31) / 32;
             {
                 const int ntiles = B * fa.tpb;
-                int nwg = (ntiles + 3) / 4; nwg = nwg > 256 ? 256 : nwg;      // one workgroup per CU, each wave walks its tiles
-                hipLaunchKernelGGL(tr_layer_fwd_kernel, dim3(nwg), dim3(256), 0, st, fa);
+                int nwg = (ntiles + 7) / 8; nwg = nwg > 256 ? 256 : nwg;      // one workgroup (8 waves, 2 per SIMD) per CU, each wave walks its tiles
+                hipLaunchKernelGGL(tr_layer_fwd_kernel, dim3(nwg), dim3(512), 0, st, fa);
             }
         }
         if (rc) break;
