@@ -189,6 +189,20 @@ int twv_clip_by_global_norm(float* grads, int64_t n, double pre_scale, double cl
 int twv_adam_ema_step(float* params, const float* grads, float* m, float* v, float* ema, int64_t n, double lr, double beta1,
                       double beta2, double eps, int64_t t, double ema_decay, double grad_scale, void* stream);
 
+/* ======================================= spectrogram -> waveform (Griffin-Lim) =======================================
+ * Replaces synthesizer.py:258 `inv_linear_spectrogram(wav.T, hparams)` (utils/audio.py:77-92, 127-146, 27-30): denormalise,
+ * dB -> amplitude, ** power, Griffin-Lim with librosa's stft/istft conventions, inverse pre-emphasis.  FFTs by hipFFT. */
+typedef struct twv_griffin_lim twv_griffin_lim;
+/* n_fft = hparams.fft_size, hop = hop_size, win_length = win_size; n_frames spectrogram frames per utterance */
+int twv_griffin_lim_create(int n_fft, int hop, int win_length, int n_frames, int batch, twv_griffin_lim** out);
+void twv_griffin_lim_destroy(twv_griffin_lim* h);
+int twv_griffin_lim_samples(const twv_griffin_lim* h);                 /* hop * (n_frames - 1) samples per utterance */
+size_t twv_griffin_lim_workspace_bytes(const twv_griffin_lim* h);
+/* lin (batch, n_frames, n_fft/2+1): the normalised linear spectrogram exactly as twv_tacotron_infer emits it; uniforms (same shape)
+ * in [0,1) replace np.random.rand of utils/audio.py:131; out (batch, samples).  iters = hparams.griffin_lim_iters. */
+int twv_inv_linear_spectrogram(twv_griffin_lim* h, const float* lin, const float* uniforms, int iters, double power, double ref_level_db,
+                               double max_abs_value, double min_level_db, double preemphasis, void* workspace, float* out, void* stream);
+
 /* cross-lane primitive self-test (device float[256]); used by the gpu tests to pin v_permlane32_swap / v_readlane semantics */
 int twv_selftest(float* out256, void* stream);
 

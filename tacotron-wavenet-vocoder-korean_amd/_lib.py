@@ -29,7 +29,7 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
         return LIB_PATH
     hip = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
-    cmd = ["hipcc"] + HIPCC_FLAGS + hip + ["-o", LIB_PATH, "-L/opt/rocm/lib", "-lrocblas", "-Wl,-rpath,/opt/rocm/lib"]
+    cmd = ["hipcc"] + HIPCC_FLAGS + hip + ["-o", LIB_PATH, "-L/opt/rocm/lib", "-lrocblas", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -70,6 +70,11 @@ def lib():
     L.twv_mu_law_encode.argtypes = [fp, C.c_int64, C.c_int, ip, vp]
     L.twv_mu_law_decode.argtypes = [ip, C.c_int64, C.c_int, fp, vp]
     L.twv_mu_law_expand.argtypes = [fp, C.c_int64, C.c_int, fp, vp]
+    L.twv_griffin_lim_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.twv_griffin_lim_destroy.argtypes = [vp]; L.twv_griffin_lim_destroy.restype = None
+    L.twv_griffin_lim_samples.argtypes = [vp]
+    L.twv_griffin_lim_workspace_bytes.argtypes = [vp]; L.twv_griffin_lim_workspace_bytes.restype = C.c_size_t
+    L.twv_inv_linear_spectrogram.argtypes = [vp, fp, fp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, vp, fp, vp]
     L.twv_wav_to_int16.argtypes = [fp, C.c_int, C.c_int64, vp, fp, vp]
     L.twv_eval_elementwise.argtypes = [C.c_int, fp, C.c_int64, fp, vp]
     L.twv_eval_elementwise64.argtypes = [C.c_int, dp, C.c_int64, dp, vp]
@@ -106,7 +111,8 @@ EXPORTS = ["twv_last_error", "twv_version", "twv_wavenet_create", "twv_wavenet_d
            "twv_tacotron_packed_bytes", "twv_tacotron_workspace_bytes", "twv_tacotron_pack", "twv_tacotron_infer", "twv_tacotron_set_profile_buffer", "twv_tacotron_set_option",
            "twv_wavenet_train_create", "twv_wavenet_train_destroy", "twv_wavenet_train_param_floats", "twv_wavenet_train_workspace_bytes",
            "twv_wavenet_train_output_width", "twv_wavenet_train_loss_grad", "twv_adam_ema_step", "twv_wavenet_train_l2",
-           "twv_clip_by_global_norm"]
+           "twv_clip_by_global_norm", "twv_griffin_lim_create", "twv_griffin_lim_destroy", "twv_griffin_lim_samples",
+           "twv_griffin_lim_workspace_bytes", "twv_inv_linear_spectrogram"]
 
 
 class TacoDims(C.Structure):

@@ -411,6 +411,25 @@ def test_attention_trim_rule():
     assert [shard_utterances(8, 8, r) for r in range(8)] == [(r, r + 1) for r in range(8)]
 
 
+def test_audio_restatement_against_scipy():
+    """oracle/audio_np.py (librosa's stft/istft restated): perfect reconstruction away from the edges, scipy's periodic Hann,
+    scipy's lfilter for the inverse pre-emphasis, frame count 1 + len//hop"""
+    from oracle import audio_np as A
+    from scipy import signal
+    rng = np.random.RandomState(0)
+    y = rng.randn(300 * 20)
+    D = A.stft(y, 2048, 300, 1200)
+    assert D.shape == (1025, 21)
+    yr = A.istft(D, 300, 1200)
+    assert len(yr) == 300 * 20 and np.abs(yr[2048:-2048] - y[2048:len(yr) - 2048]).max() < 1e-12
+    assert np.abs(signal.get_window("hann", 1200, fftbins=True) - A.hann_padded(1200, 1200)).max() < 1e-15
+    assert A.hann_padded(1200, 2048)[:424].max() == 0 and A.hann_padded(1200, 2048)[1624:].max() == 0
+    x = rng.randn(500)
+    assert np.abs(signal.lfilter([1], [1, -0.97], x) - A.inv_preemphasis(x, 0.97)).max() < 1e-12
+    assert A.denormalize(np.array([-9.0, -4.0, 0.0, 4.0, 9.0])).tolist() == [-100.0, -100.0, -50.0, 0.0, 0.0]     # utils/audio.py:225-227
+    assert abs(A.db_to_amp(20.0) - 10.0) < 1e-12
+
+
 # ---------------------------------------------------------------- Tacotron restatement (oracle/tacotron.c)
 def test_tacotron_oracle_invariants(oracle):
     d = oracle.taco_dims(max_iters=10, enc_bank=3, post_bank=2, num_freq=33)
