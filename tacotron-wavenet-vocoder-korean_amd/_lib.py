@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtwv_amd.so")
+LIB_PATH = os.environ.get("TWV_AMD_LIB") or os.path.join(_HERE, "libtwv_amd.so")      # TWV_AMD_LIB: A/B-test another build of the library
 CSRC = os.path.join(_HERE, "csrc")
 MAX_LAYERS = 64
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]

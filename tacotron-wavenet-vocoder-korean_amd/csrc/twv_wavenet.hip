@@ -567,6 +567,17 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
         const bool wprof = a.prof != nullptr && b == 0 && g == 0 && w == 0 && t < a.prof_steps && lane == 0;
         unsigned long long* wp = a.prof + (long long)t * 80;
         if (wprof) wp[44] = __builtin_amdgcn_s_memtime();
+        // the sampler's noise terms depend only on the injected uniforms: evaluated here, a whole residual stack ahead of their use
+        // (mixture.py:103 -log(-log u) per mixture lane; mixture.py:110-111 log u - log(1 - u) of the last draw)
+        float s_lnl = 0.0f, s_tq = 0.0f, b2_pre = 0.0f;
+        if (SCALAR && w == 0) {
+            const float* up = reinterpret_cast<const float*>(a.uniforms) + ((long long)b * T + t) * (L.nr_mix + 1);
+            const float u = lane <= L.nr_mix ? up[lane] : 0.5f;
+            s_lnl = log_e(-log_e(u));
+            const float uu = __shfl(u, L.nr_mix);
+            s_tq = log_e(uu) - log_e(1.0f - uu);
+            if (use_bias && lane < L.O) b2_pre = a.P[L.off_b2 + lane];
+        }
         {
             float tot[NTW];
 #pragma unroll
@@ -717,12 +728,6 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
         }
         if (wprof) wp[47] = __builtin_amdgcn_s_memtime();
         // prefetches that do not depend on h2 (the sampler's inputs)
-        float u_pre = 0.5f, b2_pre = 0.0f;
-        if (SCALAR && w == 0) {
-            const float* up = reinterpret_cast<const float*>(a.uniforms) + ((long long)b * T + t) * (L.nr_mix + 1);
-            if (lane <= L.nr_mix) u_pre = up[lane];
-            if (use_bias && lane < L.O) b2_pre = a.P[L.off_b2 + lane];
-        }
         if (G > 1) gather_granules<W>(X2, S, 2u * (unsigned)t + 2u, c.o_h2, w, lane, ctl + C_ABORT, 9);
         arrive(ctl + C_H2CNT, lane);
         wait_seq(ctl + C_H2CNT, W * (t + 1), ctl + C_ABORT, 5);   // h2 complete
@@ -769,8 +774,7 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                 if (a.dbg != nullptr && g == 0 && t < a.dbg_steps)
                     a.dbg[((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)NL * 64 + lane] = y;
                 const int nr = L.nr_mix;
-                const float u = u_pre;
-                const float gmb = y - log_e(-log_e(u));                      // mixture.py:103 (lanes < nr)
+                const float gmb = y - s_lnl;                                 // mixture.py:103 (lanes < nr)
                 int k = 0;
                 float best = __shfl(gmb, 0);
                 for (int i = 1; i < nr; ++i) {
@@ -779,10 +783,9 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                 }
                 const float mean = __shfl(y, nr + k);                        // mixture.py:105
                 float ls = __shfl(y, 2 * nr + k);                            // mixture.py:107
-                const float uu = __shfl(u, nr);
                 const float lsmin = (float)-32.23619130191664;
                 ls = ls > lsmin ? ls : lsmin;
-                const float tq = log_e(uu) - log_e(1.0f - uu);               // mixture.py:110-111
+                const float tq = s_tq;                                       // mixture.py:110-111
                 const float e = exp_e(ls);
                 const float prod = e * tq;
                 float xs = mean + prod;
