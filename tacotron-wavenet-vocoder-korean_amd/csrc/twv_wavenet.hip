@@ -532,14 +532,15 @@ __device__ __forceinline__ void loader_main(const GenArgs& a, const Ctx& c, rsrc
 // Workgroup g of a stream owns the output blocks jb with jb % G == g of the skip sum and of conv1d_1 (local index
 // m = jb / G); the two 512-vectors in between are all-gathered across the G workgroups; conv1d_2 and the sampler run
 // redundantly in every workgroup (identical bits), so each of them feeds its own chain wave without another hop.
-template <int W, int NTW, bool SCALAR>
+template <int W, int NTW, bool SCALAR, bool SPLIT1>
 __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc_t rs, int w)
 {
     const Layout& L = a.lay;
     const int NL = L.NL, T = a.T, NSJ = L.NSJ, NCH = L.NCH, S = L.S, lane = c.lane, b = c.b, G = a.G, g = c.g;
     if (a.forced != nullptr) return;                // priming only advances the delay lines (chain + loader waves)
     const int NSJL = NSJ / G;                       // output blocks owned by this workgroup
-    const bool split1 = NSJL < W;                   // conv1d_1: spread the chunks of a block over the workers
+    constexpr bool split1 = SPLIT1;                 // == (NSJL < W), a launch-time fact made a template parameter: only one of the two
+                                                    // post-phase shapes is compiled into a kernel (the other one's registers spilled)
     const int v16 = lane * 16, v4 = lane * 4;
     const bool use_bias = L.use_bias != 0;
     const int ctl = c.o_ctrl;
@@ -664,6 +665,15 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
             }
         }
         if (wprof) wp[45] = __builtin_amdgcn_s_memtime();
+        // post-phase weights do not depend on data: the first two tiles of this worker's conv1d_1 share are requested before the
+        // all-gather of h1 (and, further down, conv1d_2's before the all-gather of h2)
+        Tile qa, qb;
+        const int n1 = NSJL * NCH;
+        auto w1_off = [&](int idx) -> int { const int m = idx / NCH, ch = idx - m * NCH; return ((int)L.off_w1 + ((m * G + g) * NCH + ch) * kTile) * 4; };
+        if (split1) {
+            if (w < n1) load_tile_b(qa, rs, v16, w1_off(w));
+            if (w + W < n1) load_tile_b(qb, rs, v16, w1_off(w + W));
+        }
         if (G > 1) gather_granules<W>(X1, S, 2u * (unsigned)t + 1u, c.o_h1, w, lane, ctl + C_ABORT, 7);
         arrive(ctl + C_H1CNT, lane);
         wait_seq(ctl + C_H1CNT, W * (t + 1), ctl + C_ABORT, 4);   // h1 complete in this workgroup's LDS
@@ -703,11 +713,19 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
             }
         } else {
             // few output blocks: tiles (m, ch) round-robin over the workers, chunk values summed in order afterwards
-            for (int idx = w; idx < NSJL * NCH; idx += W) {
-                const int m = idx / NCH, ch = idx - m * NCH;
-                Tile tq;
-                load_tile_b(tq, rs, v16, ((int)L.off_w1 + ((m * G + g) * NCH + ch) * kTile) * 4);
-                lds[c.o_cpart1 + idx * 64 + lane] = dot_ldso(tq, c.o_h1 + ch * 32);
+            for (int idx = w; idx < n1; idx += 2 * W) {
+                {
+                    const float r = dot_ldso(qa, c.o_h1 + (idx % NCH) * 32);
+                    __builtin_amdgcn_sched_barrier(0);
+                    lds[c.o_cpart1 + idx * 64 + lane] = r;
+                    if (idx + 2 * W < n1) load_tile_b(qa, rs, v16, w1_off(idx + 2 * W));
+                }
+                if (idx + W < n1) {
+                    const float r = dot_ldso(qb, c.o_h1 + ((idx + W) % NCH) * 32);
+                    __builtin_amdgcn_sched_barrier(0);
+                    lds[c.o_cpart1 + (idx + W) * 64 + lane] = r;
+                    if (idx + 3 * W < n1) load_tile_b(qb, rs, v16, w1_off(idx + 3 * W));
+                }
             }
             arrive(ctl + C_P1CNT, lane);
             if (w < NSJL) {
@@ -728,6 +746,9 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
         }
         if (wprof) wp[47] = __builtin_amdgcn_s_memtime();
         // prefetches that do not depend on h2 (the sampler's inputs)
+        const int n2 = L.NOJ * NCH;
+        if (w < n2) load_tile_b(qa, rs, v16, ((int)L.off_w2 + w * kTile) * 4);
+        if (w + W < n2) load_tile_b(qb, rs, v16, ((int)L.off_w2 + (w + W) * kTile) * 4);
         if (G > 1) gather_granules<W>(X2, S, 2u * (unsigned)t + 2u, c.o_h2, w, lane, ctl + C_ABORT, 9);
         arrive(ctl + C_H2CNT, lane);
         wait_seq(ctl + C_H2CNT, W * (t + 1), ctl + C_ABORT, 5);   // h2 complete
@@ -735,11 +756,19 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
         if (wprof) wp[48] = __builtin_amdgcn_s_memtime();
         {
             // ---- model.py:161-165 conv1d_2 (S->O): chunk partials, summed in order by the sampler wave
-            for (int idx = w; idx < L.NOJ * NCH; idx += W) {
-                const int ch = idx % NCH;
-                Tile tq;
-                load_tile_b(tq, rs, v16, ((int)L.off_w2 + idx * kTile) * 4);
-                lds[c.o_cpart + idx * 64 + lane] = dot_ldso(tq, c.o_h2 + ch * 32);
+            for (int idx = w; idx < n2; idx += 2 * W) {
+                {
+                    const float r = dot_ldso(qa, c.o_h2 + (idx % NCH) * 32);
+                    __builtin_amdgcn_sched_barrier(0);
+                    lds[c.o_cpart + idx * 64 + lane] = r;
+                    if (idx + 2 * W < n2) load_tile_b(qa, rs, v16, ((int)L.off_w2 + (idx + 2 * W) * kTile) * 4);
+                }
+                if (idx + W < n2) {
+                    const float r = dot_ldso(qb, c.o_h2 + ((idx + W) % NCH) * 32);
+                    __builtin_amdgcn_sched_barrier(0);
+                    lds[c.o_cpart + (idx + W) * 64 + lane] = r;
+                    if (idx + 3 * W < n2) load_tile_b(qb, rs, v16, ((int)L.off_w2 + (idx + 3 * W) * kTile) * 4);
+                }
             }
         }
         if (wprof) wp[49] = __builtin_amdgcn_s_memtime();
@@ -883,7 +912,7 @@ constexpr int kLoaders = 3;
 
 // D = 1 parks an idle wave at index 1 + kLoaders: waves i and i+4 of a workgroup share a SIMD (scripts/ubench/simd_map.hip), so
 // with 3 loaders the chain wave (wave 0) then has its SIMD to itself.
-template <int W, int NTW, bool SCALAR, int D = 0>
+template <int W, int NTW, bool SCALAR, int D = 0, bool SPLIT1 = false>
 __global__ void __launch_bounds__((1 + kLoaders + D + W) * 64) wn_generate_kernel(GenArgs a)
 {
     const Layout& L = a.lay;
@@ -938,7 +967,7 @@ __global__ void __launch_bounds__((1 + kLoaders + D + W) * 64) wn_generate_kerne
     if (wid == 0) chain_main<SCALAR>(a, c, hpos, prev_valid, qprev);
     else if (wid <= kLoaders) loader_main<kLoaders>(a, c, rs, wid - 1);
     else if (D && wid == kLoaders + 1) {}
-    else worker_main<W, NTW, SCALAR>(a, c, rs, wid - 1 - kLoaders - D);
+    else worker_main<W, NTW, SCALAR, SPLIT1>(a, c, rs, wid - 1 - kLoaders - D);
 
     // ---------------- persist the per-stream state (model.py:49-64 queues) ----------------
     __syncthreads();
@@ -1397,10 +1426,10 @@ extern "C" int twv_wavenet_condition(const twv_wavenet* h, const void* packed, c
     return TWV_OK;
 }
 
-template <int W, int NTW, bool SCALAR, int D = 0>
+template <int W, int NTW, bool SCALAR, int D = 0, bool SPLIT1 = false>
 static int launch_generate(const GenArgs& a, size_t shm, hipStream_t st)
 {
-    auto kern = wn_generate_kernel<W, NTW, SCALAR, D>;
+    auto kern = wn_generate_kernel<W, NTW, SCALAR, D, SPLIT1>;
     if (shm > 32 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipLaunchKernelGGL(kern, dim3(a.B * a.G), dim3((1 + kLoaders + D + W) * 64), shm, st, a);
     HIPCHK(hipGetLastError());
@@ -1439,17 +1468,19 @@ static int generate_impl(const twv_wavenet* h, const void* packed, void* state, 
     const int ntw = (nsjl + kWorkers - 1) / kWorkers;
     if (!L.scalar && L.Q > 1024) return fail(TWV_E_UNSUPPORTED, "quantization_channels must be <= 1024");
     if (L.scalar && h->workers == 3) {
-        if (nsjl <= 3) return launch_generate<3, 1, true, 1>(a, shm, st);
+        if (nsjl < 3) return launch_generate<3, 1, true, 1, true>(a, shm, st);
+        if (nsjl == 3) return launch_generate<3, 1, true, 1, false>(a, shm, st);
         return fail(TWV_E_UNSUPPORTED, "workers=3 needs skip_channels/64/groups <= 3");
     }
+    const bool sp = nsjl < kWorkers;                 // few output blocks per workgroup: tiles round-robin over the workers
     if (L.scalar) {
-        if (ntw <= 1) return launch_generate<kWorkers, 1, true>(a, shm, st);
-        if (ntw == 2) return launch_generate<kWorkers, 2, true>(a, shm, st);
-        if (ntw <= 4) return launch_generate<kWorkers, 4, true>(a, shm, st);
+        if (ntw <= 1) return sp ? launch_generate<kWorkers, 1, true, 0, true>(a, shm, st) : launch_generate<kWorkers, 1, true, 0, false>(a, shm, st);
+        if (ntw == 2) return launch_generate<kWorkers, 2, true, 0, false>(a, shm, st);
+        if (ntw <= 4) return launch_generate<kWorkers, 4, true, 0, false>(a, shm, st);
     } else {
-        if (ntw <= 1) return launch_generate<kWorkers, 1, false>(a, shm, st);
-        if (ntw == 2) return launch_generate<kWorkers, 2, false>(a, shm, st);
-        if (ntw <= 4) return launch_generate<kWorkers, 4, false>(a, shm, st);
+        if (ntw <= 1) return sp ? launch_generate<kWorkers, 1, false, 0, true>(a, shm, st) : launch_generate<kWorkers, 1, false, 0, false>(a, shm, st);
+        if (ntw == 2) return launch_generate<kWorkers, 2, false, 0, false>(a, shm, st);
+        if (ntw <= 4) return launch_generate<kWorkers, 4, false, 0, false>(a, shm, st);
     }
     return fail(TWV_E_UNSUPPORTED, "skip_channels too large for the worker count");
 }
