@@ -747,8 +747,10 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
         if (wprof) wp[47] = __builtin_amdgcn_s_memtime();
         // prefetches that do not depend on h2 (the sampler's inputs)
         const int n2 = L.NOJ * NCH;
-        if (w < n2) load_tile_b(qa, rs, v16, ((int)L.off_w2 + w * kTile) * 4);
-        if (w + W < n2) load_tile_b(qb, rs, v16, ((int)L.off_w2 + (w + W) * kTile) * 4);
+        if (split1) {
+            if (w < n2) load_tile_b(qa, rs, v16, ((int)L.off_w2 + w * kTile) * 4);
+            if (w + W < n2) load_tile_b(qb, rs, v16, ((int)L.off_w2 + (w + W) * kTile) * 4);
+        }
         if (G > 1) gather_granules<W>(X2, S, 2u * (unsigned)t + 2u, c.o_h2, w, lane, ctl + C_ABORT, 9);
         arrive(ctl + C_H2CNT, lane);
         wait_seq(ctl + C_H2CNT, W * (t + 1), ctl + C_ABORT, 5);   // h2 complete
@@ -756,18 +758,26 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
         if (wprof) wp[48] = __builtin_amdgcn_s_memtime();
         {
             // ---- model.py:161-165 conv1d_2 (S->O): chunk partials, summed in order by the sampler wave
-            for (int idx = w; idx < n2; idx += 2 * W) {
-                {
-                    const float r = dot_ldso(qa, c.o_h2 + (idx % NCH) * 32);
-                    __builtin_amdgcn_sched_barrier(0);
-                    lds[c.o_cpart + idx * 64 + lane] = r;
-                    if (idx + 2 * W < n2) load_tile_b(qa, rs, v16, ((int)L.off_w2 + (idx + 2 * W) * kTile) * 4);
+            if (split1) {
+                for (int idx = w; idx < n2; idx += 2 * W) {
+                    {
+                        const float r = dot_ldso(qa, c.o_h2 + (idx % NCH) * 32);
+                        __builtin_amdgcn_sched_barrier(0);
+                        lds[c.o_cpart + idx * 64 + lane] = r;
+                        if (idx + 2 * W < n2) load_tile_b(qa, rs, v16, ((int)L.off_w2 + (idx + 2 * W) * kTile) * 4);
+                    }
+                    if (idx + W < n2) {
+                        const float r = dot_ldso(qb, c.o_h2 + ((idx + W) % NCH) * 32);
+                        __builtin_amdgcn_sched_barrier(0);
+                        lds[c.o_cpart + (idx + W) * 64 + lane] = r;
+                        if (idx + 3 * W < n2) load_tile_b(qb, rs, v16, ((int)L.off_w2 + (idx + 3 * W) * kTile) * 4);
+                    }
                 }
-                if (idx + W < n2) {
-                    const float r = dot_ldso(qb, c.o_h2 + ((idx + W) % NCH) * 32);
-                    __builtin_amdgcn_sched_barrier(0);
-                    lds[c.o_cpart + (idx + W) * 64 + lane] = r;
-                    if (idx + 3 * W < n2) load_tile_b(qb, rs, v16, ((int)L.off_w2 + (idx + 3 * W) * kTile) * 4);
+            } else {
+                for (int idx = w; idx < n2; idx += W) {
+                    Tile tq;
+                    load_tile_b(tq, rs, v16, ((int)L.off_w2 + idx * kTile) * 4);
+                    lds[c.o_cpart + idx * 64 + lane] = dot_ldso(tq, c.o_h2 + (idx % NCH) * 32);
                 }
             }
         }
