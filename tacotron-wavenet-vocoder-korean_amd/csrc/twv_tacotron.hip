@@ -965,7 +965,6 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                     }
                 }
                 if (st == 5) { TWV_STAMP(11) }
-                DECG_PREFETCH(st + 1 < nst ? st + 1 : 0)
             }
             if (st == 5) { TWV_STAMP(12) }
             __syncthreads();
@@ -987,6 +986,8 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                     }
                 }
                 if (st == 5) { TWV_STAMP(14) }
+                // the next stage's first tiles are requested only now: this workgroup's values are already on their way to the others
+                DECG_PREFETCH(st + 1 < nst ? st + 1 : 0)
                 if (xch) decg_gather(Xb, N, ep, dst, tid, o_abort);
                 if (st == 5) { TWV_STAMP(15) }
                 __syncthreads();
