@@ -14,7 +14,6 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--workers", type=int, default=0)
 ap.add_argument("--layers", type=int, default=30)
 ap.add_argument("--groups", type=int, default=-1)
-ap.add_argument("--exp", type=int, default=0)
 ap.add_argument("--no-stamps", action="store_true")
 args = ap.parse_args()
 hp = twvk_amd.default_hparams()
@@ -25,7 +24,6 @@ m = WaveNetModel(B, dil, 2, 32, 32, 512, out_channels=30, use_biases=True, scala
                  upsample_factor=[5, 5, 12], train_mode=False)
 if args.workers: m.set_option("workers", args.workers)
 if args.groups >= 0: m.set_option("groups", args.groups)
-if args.exp: m.set_option("exp", args.exp)
 m.load_weights(W.random_tensors(m.specs, 0, 0.05))
 rng = np.random.RandomState(0)
 U = torch.from_numpy(rng.uniform(-1, 1, (B, T, 80)).astype(np.float32)).cuda()
@@ -34,11 +32,11 @@ NP = min(T, 2000)
 prof = torch.zeros((NP, 80), dtype=torch.int64, device="cuda")
 _lib.check(m._L.twv_wavenet_set_profile_buffer(m._h, C.c_void_p(prof.data_ptr()), 0 if args.no_stamps else NP))
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-m.generate(U, np.zeros(B, np.int32), np.zeros(B, np.float32), u, check=not args.exp)   # warm
+m.generate(U, np.zeros(B, np.int32), np.zeros(B, np.float32), u, check=True)   # warm
 m.queue_initializer()
 e0.record(); m.generate(U, np.zeros(B, np.int32), np.zeros(B, np.float32), u, check=False); e1.record(); torch.cuda.synchronize()
-if args.no_stamps or args.exp:
-    print("exp=%d stamps=%s: %.2f us/step (events)" % (args.exp, not args.no_stamps, e0.elapsed_time(e1) * 1e3 / T)); sys.exit(0)
+if args.no_stamps:
+    print("no stamps: %.2f us/step (events)" % (e0.elapsed_time(e1) * 1e3 / T)); sys.exit(0)
 p = prof.cpu().numpy().astype(np.int64)
 s = p[100:NP]   # skip the cold start
 ticks = s[-1, 0] - s[0, 0]; wall = (s[-1, 7] - s[0, 7]) / 100e6

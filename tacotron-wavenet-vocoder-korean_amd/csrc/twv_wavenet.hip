@@ -191,7 +191,6 @@ struct GenArgs {
     unsigned long long* prof;  // optional [prof_steps][80] s_memtime stamps of stream 0's chain wave
     int prof_steps;
     int B, T;
-    int exp;                     // tuning experiments (bit mask, 0 in production)
     int G;                       // workgroups per stream (each owns 1/G of the skip / conv1d_1 outputs)
     unsigned long long* exch;    // [B][2][S] {epoch,value} granules: all-gather of relu(skip sum) and relu(conv1d_1)
     float temperature;
@@ -369,7 +368,7 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
             const int rdy = have_next ? LDSVI(c.o_ready + slot_n) : 0x7fffffff;
 
             // model.py:68-69 conv_filter | conv_gate: chunk(tap0) [precomputed by a loader] + chunk(tap1)
-            const float acc1 = (a.exp & 4) ? x : dot_readlane(w1, x);
+            const float acc1 = dot_readlane(w1, x);
             float v = pre + acc1;
             if (use_bias) v = v + bfg;
             if (has_gc) v = v + gcv;      // model.py:71-73
@@ -377,12 +376,12 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
             if (fine) pp[74] = __builtin_amdgcn_s_memtime();
             // conv operands of the NEXT item -> registers (latency hides under the gated unit and the dense conv)
             if (have_next) {
-                if (!(a.exp & 16) && rdy < item + 2) wait_seq(c.o_ready + slot_n, item + 2, ctl + C_ABORT, 200 + l);
+                if (rdy < item + 2) wait_seq(c.o_ready + slot_n, item + 2, ctl + C_ABORT, 200 + l);
                 ACQUIRE_WG();
-                if (!(a.exp & 1)) fetch_conv(sbn, ln);
+                fetch_conv(sbn, ln);
             }
             // model.py:86 tanh(filter) * sigmoid(gate): lanes 0-31 hold tanh, lanes 32-63 the logistic
-            const float act = (a.exp & 8) ? v : act_eval(coef, v);
+            const float act = act_eval(coef, v);
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
             const float z = __uint_as_float(sw[0]) * __uint_as_float(sw[1]);   // every lane: z[lane & 31]
             if (lane < 32) lds[c.o_zbuf + l * 32 + lane] = z;
@@ -390,10 +389,10 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
             if (fine) pp[75] = __builtin_amdgcn_s_memtime();
 
             // model.py:89 dense 1x1, model.py:98-101 residual
-            float tr = (a.exp & 2) ? z : dot_readlane(wd, z);
+            float tr = dot_readlane(wd, z);
             if (use_bias) tr = tr + bd;
             x = x + tr;
-            if (have_next && !(a.exp & 1)) fetch_dense(sbn);
+            if (have_next) fetch_dense(sbn);
             if (a.dbg != nullptr && c.g == 0 && t < a.dbg_steps) {
                 float* dp = a.dbg + ((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)l * 64;
                 if (lane < 32) { dp[lane] = z; dp[32 + lane] = x; }
@@ -427,7 +426,6 @@ __device__ __forceinline__ void loader_main(const GenArgs& a, const Ctx& c, rsrc
     const bool has_lc = L.L > 0;
     const int ctl = c.o_ctrl;
     const int v16 = lane * 16;
-    if (a.exp & 128) return;
     const int total = T * NL;          // < 2^31 (checked on the host)
     // all item bookkeeping is 32-bit and incremental: integer division is software on the GPU
     int nxt = k, nt = 0, nl = k, nslot_i = k % nslot;       // next item this wave stages = (layer nl, step nt), its slot
@@ -583,9 +581,7 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
             float tot[NTW];
 #pragma unroll
             for (int n = 0; n < NTW; ++n) tot[n] = 0.0f;
-            if (a.exp & 64) {
-                wait_seq(ctl + C_ZSEQ, t * NL + NL, ctl + C_ABORT, 100);
-            } else if (!split1) {
+            if (!split1) {
                 for (int l = 0; l < NL; ++l) {
                     wait_seq(ctl + C_ZSEQ, t * NL + l + 1, ctl + C_ABORT, 100 + l);
                     ACQUIRE_WG();
@@ -1113,7 +1109,6 @@ struct twv_wavenet {
     int ring_off[kMaxLayers];
     int workers;   // worker waves per workgroup
     int groups;    // workgroups per stream (0 = auto)
-    int exp;
     unsigned long long* prof;
     int prof_steps;
 };
@@ -1254,7 +1249,6 @@ extern "C" int twv_wavenet_create(const twv_wavenet_dims* dims, twv_wavenet** ou
     h->dims = *dims;
     h->workers = 4;
     h->groups = 0;
-    h->exp = 0;
     h->prof = nullptr; h->prof_steps = 0;
     const int rc = build_layout(*dims, h);
     if (rc != TWV_OK) { delete h; return rc; }
@@ -1303,7 +1297,6 @@ extern "C" int twv_wavenet_set_option(twv_wavenet* h, const char* name, int valu
         h->workers = value;
         return TWV_OK;
     }
-    if (!strcmp(name, "exp")) { h->exp = value; return TWV_OK; }
     if (!strcmp(name, "groups")) {   // workgroups per stream; set BEFORE sizing / resetting the state buffer
         if (value != 0 && (value < 1 || value > 16 || h->lay.NSJ % value)) return fail(TWV_E_INVALID, "groups must divide skip_channels/64");
         h->groups = value;
@@ -1468,7 +1461,6 @@ static int generate_impl(const twv_wavenet* h, const void* packed, void* state, 
     if ((long long)batch * G > device_cus())
         return fail(TWV_E_UNSUPPORTED, "batch * groups exceeds the CU count: the stream workgroups must all be co-resident");
     a.G = G;
-    a.exp = h->exp;
     a.exch = reinterpret_cast<unsigned long long*>((float*)state + (size_t)L.state_stride * (size_t)batch * G);
     HIPCHK(hipMemsetAsync(a.exch, 0, (size_t)batch * 2 * L.S * 8, st));
     a.lay.nslot = resolve_nslot(L, G);
