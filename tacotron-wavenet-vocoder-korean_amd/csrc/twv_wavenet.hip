@@ -375,11 +375,11 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
             if (has_lc) v = v + lcv;      // model.py:75-83
             if (fine) pp[74] = __builtin_amdgcn_s_memtime();
             // conv operands of the NEXT item -> registers (latency hides under the gated unit and the dense conv)
-            if (have_next) {
-                if (rdy < item + 2) wait_seq(c.o_ready + slot_n, item + 2, ctl + C_ABORT, 200 + l);
-                ACQUIRE_WG();
-                fetch_conv(sbn, ln);
-            }
+            // (fetched unconditionally: guarding the fetch with `have_next` made the tile a two-way merge and cost 33 register
+            //  moves per layer; after the very last item the slot's contents are simply never used)
+            if (have_next && rdy < item + 2) wait_seq(c.o_ready + slot_n, item + 2, ctl + C_ABORT, 200 + l);
+            ACQUIRE_WG();
+            fetch_conv(sbn, ln);
             // model.py:86 tanh(filter) * sigmoid(gate): lanes 0-31 hold tanh, lanes 32-63 the logistic
             const float act = act_eval(coef, v);
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
@@ -392,7 +392,7 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
             float tr = dot_readlane(wd, z);
             if (use_bias) tr = tr + bd;
             x = x + tr;
-            if (have_next) fetch_dense(sbn);
+            fetch_dense(sbn);
             if (a.dbg != nullptr && c.g == 0 && t < a.dbg_steps) {
                 float* dp = a.dbg + ((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)l * 64;
                 if (lane < 32) { dp[lane] = z; dp[32 + lane] = x; }
