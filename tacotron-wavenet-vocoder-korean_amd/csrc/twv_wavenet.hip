@@ -278,7 +278,7 @@ struct Ctx {
 // Walks model.py:112-149 for one stream: causal layer, then the dilated residual stack, one layer after the other.
 // Everything a layer needs (conv/dense weights, biases, x[t-d], lc projection) has been staged in an LDS slot by the
 // loader waves; the gc projections and the causal kernel are LDS-resident for the whole launch.
-template <bool SCALAR>
+template <bool SCALAR, bool INSTR>
 __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& hpos, int& prev_valid, int& qprev)
 {
     const Layout& L = a.lay;
@@ -315,7 +315,7 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
     fetch_dense(c.o_slots);
 
     for (int t = 0; t < T; ++t) {
-        const bool prof = a.prof != nullptr && b == 0 && c.g == 0 && t < a.prof_steps;
+        const bool prof = INSTR && a.prof != nullptr && b == 0 && c.g == 0 && t < a.prof_steps;   // INSTR: instrumented build (phase stamps, dumps)
         unsigned long long* pp = a.prof + (long long)t * 80;
         if (t > 0 && a.forced == nullptr) { wait_seq(ctl + C_SSEQ, t, ctl + C_ABORT, 3); ACQUIRE_WG(); }   // sample t-1 published
         if (prof && lane == 0) { pp[0] = __builtin_amdgcn_s_memtime(); pp[7] = wall_clock64(); }
@@ -393,7 +393,7 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
             if (use_bias) tr = tr + bd;
             x = x + tr;
             fetch_dense(sbn);
-            if (a.dbg != nullptr && c.g == 0 && t < a.dbg_steps) {
+            if (INSTR && a.dbg != nullptr && c.g == 0 && t < a.dbg_steps) {
                 float* dp = a.dbg + ((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)l * 64;
                 if (lane < 32) { dp[lane] = z; dp[32 + lane] = x; }
             }
@@ -418,7 +418,7 @@ __device__ __forceinline__ unsigned ring_pos(unsigned pos0, unsigned t, unsigned
     return (d & (d - 1)) == 0 ? (v & (d - 1)) : v % d;    // dilations are powers of two in every shipped config
 }
 
-template <int NLD>
+template <int NLD, bool INSTR>
 __device__ __forceinline__ void loader_main(const GenArgs& a, const Ctx& c, rsrc_t rs, int k)
 {
     const Layout& L = a.lay;
@@ -457,7 +457,7 @@ __device__ __forceinline__ void loader_main(const GenArgs& a, const Ctx& c, rsrc
         if (can_issue) {
             const int t = nt, l = nl, slot = nslot_i;
             const int sb = c.o_slots + slot * SlotOff::FLOATS;
-            const bool lprof = a.prof != nullptr && c.b == 0 && c.g == 0 && k == 0 && l == 6 && t < a.prof_steps && lane == 0;
+            const bool lprof = INSTR && a.prof != nullptr && c.b == 0 && c.g == 0 && k == 0 && l == 6 && t < a.prof_steps && lane == 0;
             if (lprof) a.prof[(long long)t * 80 + 40] = __builtin_amdgcn_s_memtime();
             // (1) ZSEQ >= nxt-nslot+1: the chain has run the conv of item nxt-nslot: its layer input sits in LDS -> HBM
             if (wb >= 0) write_back(wl, wt);
@@ -530,7 +530,7 @@ __device__ __forceinline__ void loader_main(const GenArgs& a, const Ctx& c, rsrc
 // Workgroup g of a stream owns the output blocks jb with jb % G == g of the skip sum and of conv1d_1 (local index
 // m = jb / G); the two 512-vectors in between are all-gathered across the G workgroups; conv1d_2 and the sampler run
 // redundantly in every workgroup (identical bits), so each of them feeds its own chain wave without another hop.
-template <int W, int NTW, bool SCALAR, bool SPLIT1>
+template <int W, int NTW, bool SCALAR, bool SPLIT1, bool INSTR>
 __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc_t rs, int w)
 {
     const Layout& L = a.lay;
@@ -563,7 +563,7 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
     }
 
     for (int t = 0; t < T; ++t) {
-        const bool wprof = a.prof != nullptr && b == 0 && g == 0 && w == 0 && t < a.prof_steps && lane == 0;
+        const bool wprof = INSTR && a.prof != nullptr && b == 0 && g == 0 && w == 0 && t < a.prof_steps && lane == 0;
         unsigned long long* wp = a.prof + (long long)t * 80;
         if (wprof) wp[44] = __builtin_amdgcn_s_memtime();
         // the sampler's noise terms depend only on the injected uniforms: evaluated here, a whole residual stack ahead of their use
@@ -806,7 +806,7 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                     y = (ch == 0) ? cp : y + cp;
                 }
                 if (use_bias && lane < L.O) y = y + b2_pre;
-                if (a.dbg != nullptr && g == 0 && t < a.dbg_steps)
+                if (INSTR && a.dbg != nullptr && g == 0 && t < a.dbg_steps)
                     a.dbg[((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)NL * 64 + lane] = y;
                 const int nr = L.nr_mix;
                 const float gmb = y - s_lnl;                                 // mixture.py:103 (lanes < nr)
@@ -850,7 +850,7 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                 }
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
-                if (a.dbg != nullptr && g == 0 && t < a.dbg_steps) {
+                if (INSTR && a.dbg != nullptr && g == 0 && t < a.dbg_steps) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k)
                         if (lane + 64 * k < Q)
@@ -918,7 +918,7 @@ constexpr int kLoaders = 3;
 
 // D = 1 parks an idle wave at index 1 + kLoaders: waves i and i+4 of a workgroup share a SIMD (scripts/ubench/simd_map.hip), so
 // with 3 loaders the chain wave (wave 0) then has its SIMD to itself.
-template <int W, int NTW, bool SCALAR, int D = 0, bool SPLIT1 = false>
+template <int W, int NTW, bool SCALAR, int D = 0, bool SPLIT1 = false, bool INSTR = false>
 __global__ void __launch_bounds__((1 + kLoaders + D + W) * 64) wn_generate_kernel(GenArgs a)
 {
     const Layout& L = a.lay;
@@ -970,10 +970,10 @@ __global__ void __launch_bounds__((1 + kLoaders + D + W) * 64) wn_generate_kerne
     __syncthreads();
 
     int hpos = meta[M_HPOS], prev_valid = meta[M_PREV_VALID], qprev = meta[M_QPREV];
-    if (wid == 0) chain_main<SCALAR>(a, c, hpos, prev_valid, qprev);
-    else if (wid <= kLoaders) loader_main<kLoaders>(a, c, rs, wid - 1);
+    if (wid == 0) chain_main<SCALAR, INSTR>(a, c, hpos, prev_valid, qprev);
+    else if (wid <= kLoaders) loader_main<kLoaders, INSTR>(a, c, rs, wid - 1);
     else if (D && wid == kLoaders + 1) {}
-    else worker_main<W, NTW, SCALAR, SPLIT1>(a, c, rs, wid - 1 - kLoaders - D);
+    else worker_main<W, NTW, SCALAR, SPLIT1, INSTR>(a, c, rs, wid - 1 - kLoaders - D);
 
     // ---------------- persist the per-stream state (model.py:49-64 queues) ----------------
     __syncthreads();
@@ -1429,14 +1429,21 @@ extern "C" int twv_wavenet_condition(const twv_wavenet* h, const void* packed, c
     return TWV_OK;
 }
 
-template <int W, int NTW, bool SCALAR, int D = 0, bool SPLIT1 = false>
-static int launch_generate(const GenArgs& a, size_t shm, hipStream_t st)
+template <int W, int NTW, bool SCALAR, int D, bool SPLIT1, bool INSTR>
+static int launch_generate2(const GenArgs& a, size_t shm, hipStream_t st)
 {
-    auto kern = wn_generate_kernel<W, NTW, SCALAR, D, SPLIT1>;
+    auto kern = wn_generate_kernel<W, NTW, SCALAR, D, SPLIT1, INSTR>;
     if (shm > 32 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipLaunchKernelGGL(kern, dim3(a.B * a.G), dim3((1 + kLoaders + D + W) * 64), shm, st, a);
     HIPCHK(hipGetLastError());
     return TWV_OK;
+}
+// the instrumented build (phase stamps, per-layer dumps) is a separate instantiation: production launches carry none of its branches
+template <int W, int NTW, bool SCALAR, int D = 0, bool SPLIT1 = false>
+static int launch_generate(const GenArgs& a, size_t shm, hipStream_t st)
+{
+    if (a.prof != nullptr || a.dbg != nullptr) return launch_generate2<W, NTW, SCALAR, D, SPLIT1, true>(a, shm, st);
+    return launch_generate2<W, NTW, SCALAR, D, SPLIT1, false>(a, shm, st);
 }
 
 static int generate_impl(const twv_wavenet* h, const void* packed, void* state, const void* cond,
