@@ -205,6 +205,9 @@ enum { C_ZSEQ = 0, C_ABORT = 1, C_SAMPLE = 2, C_CDONE = 3, C_H1CNT = 4, C_H2CNT 
 __device__ __forceinline__ bool wait_seq(int fo_flag, int target, int fo_abort, int code)
 {
     if (LDSVI(fo_flag) >= target) return true;
+    // not unrolled: fifteen call sites x an 8-fold unrolled spin loop was a third of the kernel's code, and the three roles of a
+    // workgroup share one instruction cache
+#pragma nounroll
     for (int it = 0; it < (1 << 22); ++it) {
         __builtin_amdgcn_s_sleep(1);
         if (LDSVI(fo_flag) >= target) return true;
