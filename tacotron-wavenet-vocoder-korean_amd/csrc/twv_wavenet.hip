@@ -249,6 +249,7 @@ __device__ __forceinline__ bool gather_granules(unsigned long long* X, int S, un
                                                 int fo_abort, int code)
 {
     bool done[4] = {false, false, false, false};     // up to 4 granules per lane (S <= 1024 with W*64 = 256 lanes)
+#pragma nounroll
     for (int it = 0; it < (1 << 20); ++it) {
         bool all_ok = true;
 #pragma unroll
