@@ -385,7 +385,7 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
             ACQUIRE_WG();
             fetch_conv(sbn, ln);
             // model.py:86 tanh(filter) * sigmoid(gate): lanes 0-31 hold tanh, lanes 32-63 the logistic
-            const float act = act_eval(coef, v);
+            const float act = act_eval_pk(coef, v);
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
             const float z = __uint_as_float(sw[0]) * __uint_as_float(sw[1]);   // every lane: z[lane & 31]
             if (lane < 32) lds[c.o_zbuf + l * 32 + lane] = z;
