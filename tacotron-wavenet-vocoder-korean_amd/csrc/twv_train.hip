@@ -458,11 +458,23 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(LayerFwdArgs a)
         // residual operand and gc projection in the output (C) layout: requested now, consumed after the MFMAs
         const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
         const float gcf = a.gcp ? a.gcp[b * 64 + n] : 0.0f, gcg = a.gcp ? a.gcp[b * 64 + 32 + n] : 0.0f;
+        // interior tile: every row is inside the utterance, above the layer's receptive offset and on one side of the skip cut --
+        // no per-row predicates, and every access is (per-lane pointer) + (compile-time row offset): the 64 stores and 16 loads
+        // of the epilogue then need no address arithmetic at all
+        const int cut = a.Tn - a.ow;
+        const bool interior = t0 >= a.o && t0 + 32 <= a.Tn && (t0 >= cut || t0 + 32 <= cut);
+        const long long lrow = ((long long)b * a.Tn + t0 + 4 * hh) * 32 + n;      // this lane's element of tile row 4*hh
         float xres[16];
+        if (interior) {
+            const float* xp = a.X + lrow;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            xres[r] = t < a.Tn ? a.X[((long long)b * a.Tn + t) * 32 + n] : 0.0f;
+            for (int r = 0; r < 16; ++r) xres[r] = xp[((r & 3) + 8 * (r >> 2)) * 32];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                xres[r] = t < a.Tn ? a.X[((long long)b * a.Tn + t) * 32 + n] : 0.0f;
+            }
         }
         f32x16 cf = zero, cg = zero;
 #pragma unroll
@@ -490,19 +502,35 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(LayerFwdArgs a)
                 cg = __builtin_amdgcn_mfma_f32_32x32x2f32(A.u[i][j], w[1], cg, 0, 0, 0);
             }
         // ---- gated unit (C layout: lane = channel n, register r = row (r&3) + 8(r>>2) + 4hh)
+        if (interior) {
+            float* thp = a.TH + lrow; float* sgp = a.SG + lrow;
+            float* zrow = &zt[wave][4 * hh * 36 + n];
+            const bool skip = t0 >= cut;
+            float* zcp = a.ZC + ((long long)b * a.ow + (t0 - cut) + 4 * hh) * a.ldz + n;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh, t = t0 + rl;
-            const bool in = t < a.Tn, valid = in && t >= a.o;
-            float th = 0.0f, sg = 0.0f;
-            if (valid) { th = tr_tanh_fast((cf[r] + vbf) + gcf); sg = tr_sigmoid_fast((cg[r] + vbg) + gcg); }
-            const float z = th * sg;
-            const long long row = (long long)b * a.Tn + t;
-            if (in) {
-                a.TH[row * 32 + n] = th; a.SG[row * 32 + n] = sg;
-                if (t >= a.Tn - a.ow) a.ZC[((long long)b * a.ow + (t - (a.Tn - a.ow))) * a.ldz + n] = z;
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                const float th = tr_tanh_fast((cf[r] + vbf) + gcf), sg = tr_sigmoid_fast((cg[r] + vbg) + gcg);
+                const float z = th * sg;
+                thp[ro * 32] = th; sgp[ro * 32] = sg;
+                if (skip) zcp[(long long)ro * a.ldz] = z;
+                zrow[ro * 36] = z;
             }
-            zt[wave][rl * 36 + n] = z;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh, t = t0 + rl;
+                const bool in = t < a.Tn, valid = in && t >= a.o;
+                float th = 0.0f, sg = 0.0f;
+                if (valid) { th = tr_tanh_fast((cf[r] + vbf) + gcf); sg = tr_sigmoid_fast((cg[r] + vbg) + gcg); }
+                const float z = th * sg;
+                const long long row = (long long)b * a.Tn + t;
+                if (in) {
+                    a.TH[row * 32 + n] = th; a.SG[row * 32 + n] = sg;
+                    if (t >= cut) a.ZC[((long long)b * a.ow + (t - cut)) * a.ldz + n] = z;
+                }
+                zt[wave][rl * 36 + n] = z;
+            }
         }
         // ---- dense 1x1 + residual: z as A operand (row layout) back from this wave's LDS patch
         f32x16 cd = zero;
@@ -515,10 +543,16 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(LayerFwdArgs a)
                 for (int j = 0; j < 4; ++j) cd = __builtin_amdgcn_mfma_f32_32x32x2f32(q[j], bdt[(4 * i + j) * 64 + lane], cd, 0, 0, 0);
             }
         }
+        if (interior) {
+            float* xnp = a.XN + lrow;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (t < a.Tn) a.XN[((long long)b * a.Tn + t) * 32 + n] = (xres[r] + cd[r]) + vbd;
+            for (int r = 0; r < 16; ++r) xnp[((r & 3) + 8 * (r >> 2)) * 32] = (xres[r] + cd[r]) + vbd;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (t < a.Tn) a.XN[((long long)b * a.Tn + t) * 32 + n] = (xres[r] + cd[r]) + vbd;
+            }
         }
     }
 }
