@@ -755,15 +755,29 @@ __global__ void __launch_bounds__(256) tr_layer_bwd2_kernel(LayerBwdArgs a)
             qa[i] = tr_ld4(p + 8 * i, t < a.Tn);
             qb[i] = tr_ld4(p + (long long)a.d * 64 + 8 * i, t + a.d < a.Tn);
         }
-        // operands of the read-modify-writes in the output (C) layout: requested before the MFMAs
+        // operands of the read-modify-writes in the output (C) layout: requested before the MFMAs.  Interior tiles (all rows inside
+        // the utterance and above the layer's receptive offset) use per-lane pointers + compile-time row offsets, no predicates.
+        const bool interior = t0 >= a.o && t0 + 32 <= a.Tn;
+        const long long lrow = ((long long)b * a.Tn + t0 + 4 * hh) * 32 + n;
+        float* up = a.dU + ((long long)b * a.T + (t0 - a.o) + 4 * hh) * 80 + n;
         float rx[16], r0[16], r1[16], r2[16];
+        if (interior) {
+            const float* xp = a.dXn + lrow;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int tt = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const bool in = tt < a.Tn, v = in && tt >= a.o;
-            rx[r] = in ? a.dXn[((long long)b * a.Tn + tt) * 32 + n] : 0.0f;
-            const float* ur = a.dU + ((long long)b * a.T + (tt - a.o)) * 80;
-            r0[r] = v ? ur[n] : 0.0f; r1[r] = v ? ur[32 + n] : 0.0f; r2[r] = (v && n < 16) ? ur[64 + n] : 0.0f;
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                rx[r] = xp[ro * 32];
+                r0[r] = up[ro * 80]; r1[r] = up[ro * 80 + 32]; r2[r] = n < 16 ? up[ro * 80 + 64] : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tt = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const bool in = tt < a.Tn, v = in && tt >= a.o;
+                rx[r] = in ? a.dXn[((long long)b * a.Tn + tt) * 32 + n] : 0.0f;
+                const float* ur = a.dU + ((long long)b * a.T + (tt - a.o)) * 80;
+                r0[r] = v ? ur[n] : 0.0f; r1[r] = v ? ur[32 + n] : 0.0f; r2[r] = (v && n < 16) ? ur[64 + n] : 0.0f;
+            }
         }
         f32x16 cx = zero, c0 = zero, c1 = zero, c2 = zero;
 #pragma unroll
@@ -776,15 +790,26 @@ __global__ void __launch_bounds__(256) tr_layer_bwd2_kernel(LayerBwdArgs a)
                 c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], wl2[4 * i + j], c2, 0, 0, 0);
                 cx = __builtin_amdgcn_mfma_f32_32x32x2f32(qb[i][j], w0t[4 * i + j], cx, 0, 0, 0);
             }
+        if (interior) {
+            float* dxp = a.dX + lrow;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int tt = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (tt < a.Tn) {
-                a.dX[((long long)b * a.Tn + tt) * 32 + n] = rx[r] + cx[r];
-                if (tt >= a.o) {
-                    float* ur = a.dU + ((long long)b * a.T + (tt - a.o)) * 80;
-                    ur[n] = r0[r] + c0[r]; ur[32 + n] = r1[r] + c1[r];
-                    if (n < 16) ur[64 + n] = r2[r] + c2[r];
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                dxp[ro * 32] = rx[r] + cx[r];
+                up[ro * 80] = r0[r] + c0[r]; up[ro * 80 + 32] = r1[r] + c1[r];
+                if (n < 16) up[ro * 80 + 64] = r2[r] + c2[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tt = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (tt < a.Tn) {
+                    a.dX[((long long)b * a.Tn + tt) * 32 + n] = rx[r] + cx[r];
+                    if (tt >= a.o) {
+                        float* ur = a.dU + ((long long)b * a.T + (tt - a.o)) * 80;
+                        ur[n] = r0[r] + c0[r]; ur[32 + n] = r1[r] + c1[r];
+                        if (n < 16) ur[64 + n] = r2[r] + c2[r];
+                    }
                 }
             }
         }
