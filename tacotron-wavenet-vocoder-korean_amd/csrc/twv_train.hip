@@ -728,24 +728,25 @@ __global__ __launch_bounds__(256) void tr_slab_reduce_kernel(const float* slabs,
         dst.out[q][(long long)(i >> 5) * dst.ldo[q] + (i & 31)] = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
 }
 
-__global__ void __launch_bounds__(256) tr_layer_bwd2_kernel(LayerBwdArgs a)
+// Two waves per SIMD as in the forward kernel: the transposed weights (B operands) live in LDS, [step][lane][8] with
+// (W1^T, W0^T, Wlc^T block 0, 1, 2) per lane, fetched as one ds_read_b128 + one ds_read_b32 per MFMA group.
+__global__ void __launch_bounds__(512) tr_layer_bwd2_kernel(LayerBwdArgs a)
 {
+    __shared__ __attribute__((aligned(16))) float bt2[32 * 64 * 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 31, hh = lane >> 5;
-    // transposed weights as B operands: lane (n, hh) holds W[n][k = 8i + 4hh + j], k over the 64 filter|gate columns
-    float w1t[32], w0t[32], wl0[32], wl1[32], wl2[32];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = 8 * i + 4 * hh + j;
-            w1t[4 * i + j] = a.W1[n * 64 + k]; w0t[4 * i + j] = a.W0[n * 64 + k];
-            wl0[4 * i + j] = a.Wlc[n * 64 + k]; wl1[4 * i + j] = a.Wlc[(32 + n) * 64 + k];
-            wl2[4 * i + j] = n < 16 ? a.Wlc[(64 + n) * 64 + k] : 0.0f;
-        }
+    for (int e = threadIdx.x; e < 32 * 64; e += 512) {
+        const int s_ = e >> 6, l = e & 63, nn = l & 31, h2 = l >> 5;
+        const int k = 8 * (s_ >> 2) + 4 * h2 + (s_ & 3);
+        float* q = &bt2[e * 8];
+        q[0] = a.W1[nn * 64 + k]; q[1] = a.W0[nn * 64 + k];
+        q[2] = a.Wlc[nn * 64 + k]; q[3] = a.Wlc[(32 + nn) * 64 + k];
+        q[4] = nn < 16 ? a.Wlc[(64 + nn) * 64 + k] : 0.0f;
+    }
+    __syncthreads();
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int ntiles = a.B * a.tpb, nwaves = gridDim.x * 4;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += nwaves) {
+    const int ntiles = a.B * a.tpb, nwaves = gridDim.x * 8;
+    for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += nwaves) {
         const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
         const int t = t0 + (lane & 31);
         const float* p = a.dPRE + ((long long)b * a.Tn + t) * 64 + 4 * hh;
@@ -784,11 +785,14 @@ __global__ void __launch_bounds__(256) tr_layer_bwd2_kernel(LayerBwdArgs a)
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                cx = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], w1t[4 * i + j], cx, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], wl0[4 * i + j], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], wl1[4 * i + j], c1, 0, 0, 0);
-                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], wl2[4 * i + j], c2, 0, 0, 0);
-                cx = __builtin_amdgcn_mfma_f32_32x32x2f32(qb[i][j], w0t[4 * i + j], cx, 0, 0, 0);
+                const float* wq = &bt2[((4 * i + j) * 64 + lane) * 8];
+                const f32x4t w4 = *reinterpret_cast<const f32x4t*>(wq);
+                const float w5 = wq[4];
+                cx = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], w4[0], cx, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], w4[2], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], w4[3], c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], w5, c2, 0, 0, 0);
+                cx = __builtin_amdgcn_mfma_f32_32x32x2f32(qb[i][j], w4[1], cx, 0, 0, 0);
             }
         if (interior) {
             float* dxp = a.dX + lrow;
@@ -1160,9 +1164,10 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             ba.B = B; ba.T = T; ba.Tn = Tn; ba.d = dl; ba.o = o; ba.ow = ow; ba.ldz = ZW; ba.tpb = (Tn + 31) / 32;
             const int ntiles = B * ba.tpb;
             int nwg = (ntiles + 3) / 4; nwg = nwg > 256 ? 256 : nwg;
+            int nwg2 = (ntiles + 7) / 8; nwg2 = nwg2 > 256 ? 256 : nwg2;
             ba.zeros = zpage;
             hipLaunchKernelGGL(tr_layer_bwd1_kernel, dim3(nwg), dim3(256), 4 * BS_FLOATS * 4, st, ba);
-            hipLaunchKernelGGL(tr_layer_bwd2_kernel, dim3(nwg), dim3(256), 0, st, ba);
+            hipLaunchKernelGGL(tr_layer_bwd2_kernel, dim3(nwg2), dim3(512), 0, st, ba);
             // gradient tiles -> views / canonical slots
             {
                 SlabDst sd;
