@@ -646,37 +646,64 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
                 for (int j = 0; j < 4; ++j) cz = __builtin_amdgcn_mfma_f32_32x32x2f32(q[j], bwd[4 * i + j], cz, 0, 0, 0);
             }
         }
-        // ---- C layout operands from LDS: lane = channel n, register r = row rho
+        // ---- C layout operands from LDS: lane = channel n, register r = row rho.  Interior tiles (all rows inside the utterance, above
+        // the receptive offset and the dilation) need no predicates and use per-lane bases + compile-time offsets.
+        const bool interior = t0 >= a.o && t0 >= a.d && t0 + 32 <= a.Tn;
         float th_[16], sg_[16], dzc[16], dxc[16], x1[16], x0[16], u0[16], u1[16], u2[16];
+        if (interior) {
+            const int lb = base + 4 * hh * 32 + n, ub = base + BS_U + 4 * hh * 80 + n;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh, t = t0 + rl;
-            const bool in = t < a.Tn, valid = in && t >= a.o;
-            th_[r] = in ? lds[base + BS_TH + rl * 32 + n] : 0.0f;
-            sg_[r] = in ? lds[base + BS_SG + rl * 32 + n] : 0.0f;
-            dxc[r] = in ? lds[base + BS_DXN + rl * 32 + n] : 0.0f;
-            dzc[r] = lds[base + BS_DZC + rl * 32 + n];
-            x1[r] = in ? lds[base + BS_X1 + rl * 32 + n] : 0.0f;
-            x0[r] = (in && t >= a.d) ? lds[base + BS_X0 + rl * 32 + n] : 0.0f;
-            u0[r] = valid ? lds[base + BS_U + rl * 80 + n] : 0.0f;
-            u1[r] = valid ? lds[base + BS_U + rl * 80 + 32 + n] : 0.0f;
-            u2[r] = (valid && n < 16) ? lds[base + BS_U + rl * 80 + 64 + n] : 0.0f;
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                th_[r] = lds[lb + BS_TH + ro * 32]; sg_[r] = lds[lb + BS_SG + ro * 32]; dxc[r] = lds[lb + BS_DXN + ro * 32];
+                dzc[r] = lds[lb + BS_DZC + ro * 32]; x1[r] = lds[lb + BS_X1 + ro * 32]; x0[r] = lds[lb + BS_X0 + ro * 32];
+                u0[r] = lds[ub + ro * 80]; u1[r] = lds[ub + ro * 80 + 32]; u2[r] = n < 16 ? lds[ub + ro * 80 + 64] : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh, t = t0 + rl;
+                const bool in = t < a.Tn, valid = in && t >= a.o;
+                th_[r] = in ? lds[base + BS_TH + rl * 32 + n] : 0.0f;
+                sg_[r] = in ? lds[base + BS_SG + rl * 32 + n] : 0.0f;
+                dxc[r] = in ? lds[base + BS_DXN + rl * 32 + n] : 0.0f;
+                dzc[r] = lds[base + BS_DZC + rl * 32 + n];
+                x1[r] = in ? lds[base + BS_X1 + rl * 32 + n] : 0.0f;
+                x0[r] = (in && t >= a.d) ? lds[base + BS_X0 + rl * 32 + n] : 0.0f;
+                u0[r] = valid ? lds[base + BS_U + rl * 80 + n] : 0.0f;
+                u1[r] = valid ? lds[base + BS_U + rl * 80 + 32 + n] : 0.0f;
+                u2[r] = (valid && n < 16) ? lds[base + BS_U + rl * 80 + 64 + n] : 0.0f;
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read has returned: the region may be refilled
         if (tile + nwaves < ntiles) tr_bwd1_stage(a, tile + nwaves, lane, base);
         float dF[16], dG[16], zc[16];
         float sf = 0.0f, sgs = 0.0f, sx = 0.0f;
+        if (interior) {
+            float* pp = a.dPRE + ((long long)b * a.Tn + t0 + 4 * hh) * 64 + n;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const bool in = t < a.Tn, valid = in && t >= a.o;
-            const float dz = cz[r] + dzc[r];
-            const float th = th_[r], sg = sg_[r];
-            float df = 0.0f, dg = 0.0f;
-            if (valid) { df = dz * sg * (1.0f - th * th); dg = dz * th * sg * (1.0f - sg); }
-            dF[r] = df; dG[r] = dg; zc[r] = th * sg;
-            if (in) { const long long row = (long long)b * a.Tn + t; a.dPRE[row * 64 + n] = df; a.dPRE[row * 64 + 32 + n] = dg; }
-            sf += df; sgs += dg; sx += dxc[r];
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                const float dz = cz[r] + dzc[r];
+                const float th = th_[r], sg = sg_[r];
+                const float df = dz * sg * (1.0f - th * th), dg = dz * th * sg * (1.0f - sg);
+                dF[r] = df; dG[r] = dg; zc[r] = th * sg;
+                pp[ro * 64] = df; pp[ro * 64 + 32] = dg;
+                sf += df; sgs += dg; sx += dxc[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const bool in = t < a.Tn, valid = in && t >= a.o;
+                const float dz = cz[r] + dzc[r];
+                const float th = th_[r], sg = sg_[r];
+                float df = 0.0f, dg = 0.0f;
+                if (valid) { df = dz * sg * (1.0f - th * th); dg = dz * th * sg * (1.0f - sg); }
+                dF[r] = df; dG[r] = dg; zc[r] = th * sg;
+                if (in) { const long long row = (long long)b * a.Tn + t; a.dPRE[row * 64 + n] = df; a.dPRE[row * 64 + 32 + n] = dg; }
+                sf += df; sgs += dg; sx += dxc[r];
+            }
         }
         // per-tile column sums (bias and gc gradients): halves combined, lanes 0..31 write
         {
