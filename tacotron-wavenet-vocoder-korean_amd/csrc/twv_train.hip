@@ -115,69 +115,6 @@ __global__ void tr_unfold_kernel(const float* audio, float* xunf, int B, int T, 
         xunf[i] = ts >= 0 ? audio[(long long)b * T + ts] : 0.0f;
     }
 }
-// gated unit forward (model.py:68-86): pre (R,64) holds conv_filter|conv_gate sums; adds bias, gc[b], lc[b, t-o]; masked below o
-__global__ void tr_gate_fwd_kernel(const float* pre, const float* bf, const float* bg, const float* gcp, const float* lcp,
-                                   float* th, float* sg, float* z, int B, int Tn, int T, int o)
-{
-    const long long total = (long long)B * Tn * 32;
-    GRID_STRIDE(i, total) {
-        const int j = (int)(i & 31);
-        const long long r = i >> 5;
-        const int t = (int)(r % Tn), b = (int)(r / Tn);
-        float tv = 0.0f, sv = 0.0f;
-        if (t >= o) {
-            float f = pre[r * 64 + j], g = pre[r * 64 + 32 + j];
-            if (bf) { f += bf[j]; g += bg[j]; }
-            if (gcp) { f += gcp[b * 64 + j]; g += gcp[b * 64 + 32 + j]; }
-            if (lcp) { const long long lr = (long long)b * T + (t - o); f += lcp[lr * 64 + j]; g += lcp[lr * 64 + 32 + j]; }
-            tv = tanh_e(f); sv = sigmoid_e(g);
-        }
-        th[i] = tv; sg[i] = sv; z[i] = tv * sv;
-    }
-}
-// gated unit backward: dpre (R,64) from dz (R,32)
-__global__ void tr_gate_bwd_kernel(const float* dz, const float* th, const float* sg, float* dpre, int B, int Tn, int o)
-{
-    const long long total = (long long)B * Tn * 32;
-    GRID_STRIDE(i, total) {
-        const int j = (int)(i & 31);
-        const long long r = i >> 5;
-        const int t = (int)(r % Tn);
-        float df = 0.0f, dg = 0.0f;
-        if (t >= o) {
-            const float d = dz[i], tv = th[i], sv = sg[i];
-            df = d * sv * (1.0f - tv * tv);
-            dg = d * tv * sv * (1.0f - sv);
-        }
-        dpre[r * 64 + j] = df; dpre[r * 64 + 32 + j] = dg;
-    }
-}
-// xn = x + bias (R,32)
-__global__ void tr_add_bias32_kernel(const float* x, const float* bias, float* xn, long long n)
-{
-    GRID_STRIDE(i, n) xn[i] = x[i] + (bias ? bias[i & 31] : 0.0f);
-}
-// compact the last `ow` positions of every batch: zc[(b,p)] = z[(b, Tn-ow+p)]   (model.py:94-95 skip_cut)
-__global__ void tr_compact_kernel(const float* z, float* zc, int B, int Tn, int ow, int ldz)
-{
-    const long long total = (long long)B * ow * 32;
-    GRID_STRIDE(i, total) {
-        const int j = (int)(i & 31);
-        const long long r = i >> 5;
-        const int p = (int)(r % ow), b = (int)(r / ow);
-        zc[r * ldz + j] = z[((long long)b * Tn + (Tn - ow + p)) * 32 + j];
-    }
-}
-__global__ void tr_scatter_add_kernel(const float* dzc, float* dz, int B, int Tn, int ow, int ldz)
-{
-    const long long total = (long long)B * ow * 32;
-    GRID_STRIDE(i, total) {
-        const int j = (int)(i & 31);
-        const long long r = i >> 5;
-        const int p = (int)(r % ow), b = (int)(r / ow);
-        dz[((long long)b * Tn + (Tn - ow + p)) * 32 + j] += dzc[r * ldz + j];
-    }
-}
 // y[r][c] = relu(x[r][c] + bias_sum[c])  (bias_sum = one or several bias vectors added together)
 __global__ void tr_bias_relu_kernel(float* x, const float* biases, int nb, long long strideb, const float* bias, int C, long long n)
 {
@@ -191,9 +128,7 @@ __global__ void tr_bias_relu_kernel(float* x, const float* biases, int nb, long 
 }
 __global__ void tr_bias_add_kernel(float* x, const float* bias, int C, long long n) { GRID_STRIDE(i, n) x[i] += bias[i % C]; }
 __global__ void tr_relu_bwd_kernel(float* dx, const float* y, long long n) { GRID_STRIDE(i, n) if (!(y[i] > 0.0f)) dx[i] = 0.0f; }
-__global__ void tr_mul_kernel(const float* a, const float* b, float* c, long long n) { GRID_STRIDE(i, n) c[i] = a[i] * b[i]; }
 __global__ void tr_fill_kernel(float* p, float v, long long n) { GRID_STRIDE(i, n) p[i] = v; }
-__global__ void tr_add_kernel(float* a, const float* b, long long n) { GRID_STRIDE(i, n) a[i] += b[i]; }
 // column sums, two deterministic stages.  stage 1: block (chunk, col tile, segment) sums its row chunk of segment z
 // (segments = consecutive `rows`-row slabs, e.g. one per batch entry) into part[(z*nchunk + chunk)*C + c].
 __global__ __launch_bounds__(256) void tr_colsum_partial_kernel(const float* x, long long rows, int C, int ldx, int nchunk, float* part)
@@ -301,17 +236,6 @@ __global__ void tr_views_kernel(float* canon, float* views, float* wsall, int NL
             cp = cl + o_ws + q;
         }
         if (dir == 0) *vp = *cp; else *cp = *vp;
-    }
-}
-// dlcp[(b,tt)][c] = dpre[(b, tt+o)][c] for tt+o < Tn else 0
-__global__ void tr_shift_lc_kernel(const float* dpre, float* dlcp, int B, int Tn, int T, int o)
-{
-    const long long total = (long long)B * T * 64;
-    GRID_STRIDE(i, total) {
-        const int c = (int)(i & 63);
-        const long long r = i >> 6;
-        const int tt = (int)(r % T), b = (int)(r / T);
-        dlcp[i] = (tt + o < Tn) ? dpre[((long long)b * Tn + tt + o) * 64 + c] : 0.0f;
     }
 }
 __global__ void tr_gather_emb_kernel(const float* table, const int32_t* ids, float* out, int B, int G)
@@ -1066,15 +990,13 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
     int32_t* qin = reinterpret_cast<int32_t*>(take(RT));
     float* ohpart = take(d.scalar_input ? 0 : 256LL * 2 * d.quantization_channels * 32);
     float** X = new float*[NL + 1];
-    float **TH = new float*[NL], **SG = new float*[NL], **Z = new float*[NL];
+    float **TH = new float*[NL], **SG = new float*[NL];
     for (int l = 0; l <= NL; ++l) X[l] = take(Rr * 32);
-    for (int l = 0; l < NL; ++l) { TH[l] = take(Rr * 32); SG[l] = take(Rr * 32); Z[l] = nullptr; }
-    Z[0] = take(Rr * 32);
+    for (int l = 0; l < NL; ++l) { TH[l] = take(Rr * 32); SG[l] = take(Rr * 32); }
     const int ZW = NL * 32;                                  // stacked skip input: ZC[(b,p)][l*32 + j]
     float* ZC = take(RO * ZW); float* dZC = take(RO * ZW);
     float* PRE = take(Rr * 64);
-    float* LCP = take(RT * 64);
-    float* dXa = take(Rr * 32); float* dXb = take(Rr * 32); float* dZ = take(Rr * 32);
+    float* dXa = take(Rr * 32); float* dXb = take(Rr * 32);
     float* SK = take(RO * S); float* C1 = take(RO * S); float* dS = take(RO * S);
     float* Y = take(RO * O); float* dY = take(RO * O);
     float* emb = take((long long)B * G); float* demb = take((long long)B * G);
@@ -1247,7 +1169,7 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             }
         }
     } while (0);
-    delete[] X; delete[] TH; delete[] SG; delete[] Z;
+    delete[] X; delete[] TH; delete[] SG;
     if (rc) return twv_fail(TWV_E_HIP, "rocBLAS call failed with status " + std::to_string(rc));
     HIPCHK(hipGetLastError());
     if ((long long)(w - (float*)workspace) > h->ws_floats) return twv_fail(TWV_E_INVALID, "internal: workspace overrun");
