@@ -1,7 +1,7 @@
 // twv_train.hip -- MI355X (gfx950) teacher-forced WaveNet training step + its C-ABI (include/twv_amd.h).
 //
 // Replaces, for hccho2/Tacotron-Wavenet-Vocoder-Korean (citations into /root/reference), one `sess.run([loss, optimize])`
-// of train_vocoder.py:155-181 for the scalar-input (MoL) model:
+// of train_vocoder.py:155-181 (scalar-input MoL model and the one-hot mu-law model):
 //   wavenet/model.py:247-312  add_loss: drop last sample, create_upsample, full 'valid' convolution network
 //                             (model.py:112-167 with train_mode=True), discretized_mix_logistic_loss (mixture.py:27-81), mean
 //   wavenet/model.py:314-346  add_optimizer: exponential-decay LR, Adam (TF defaults), then EMA(0.9999).apply
@@ -9,11 +9,13 @@
 // compute_gradients and apply_gradients) is added by the host (train.py) on the flat gradient buffer this file fills.
 //
 // Layout: every layer's activations are kept RIGHT-ALIGNED at the full length Tn = T-1 (row = (batch, t)), positions before a
-// layer's receptive offset are masked.  A 'valid' dilated conv is then two plain GEMMs over all rows with a row-shifted
-// operand, and every weight gradient is ONE GEMM reducing over all rows -- plain library GEMMs (rocBLAS).  The gated
-// unit, conditioning adds, MoL loss (forward + analytic backward), column sums, the transposed-conv upsampler and the
-// Adam/EMA update are hand-written HIP kernels.  Parameters and gradients stay in the canonical checkpoint layout
-// (TF variable order, kernels (K, N) row-major), which is exactly what row-major GEMMs want.
+// layer's receptive offset are masked.  A 'valid' dilated conv is then a contraction over all rows with a row-shifted operand
+// and every weight gradient is ONE reduction over all rows.  The residual stack runs as three fused kernels per layer on the
+// f32 matrix cores (tr_layer_fwd / tr_layer_bwd1 / tr_layer_bwd2_kernel: weights as MFMA B operands in registers or LDS,
+// 32-row tiles per wave, no pre-activation or conditioning buffer in HBM); the stacked skip 1x1, conv1d_1/2 and their
+// gradients are plain library GEMMs (rocBLAS).  MoL / softmax-CE loss (forward + analytic backward), deterministic
+// reductions, the transposed-conv upsampler and the Adam/EMA update are hand-written HIP kernels.  Parameters and gradients
+// stay in the canonical checkpoint layout (TF variable order, kernels (K, N) row-major).
 // This is a floating-point training step: parity is by tolerance against an independent PyTorch-CPU fp32 autograd model.
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
