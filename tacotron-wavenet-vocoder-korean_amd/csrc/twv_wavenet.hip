@@ -8,12 +8,14 @@
 //   wavenet/model.py:71-83,181-212   (gc/lc 1x1 projections)      -> hoisted: wn_gc_kernel / wn_lc_kernel
 //   wavenet/ops.py:22-47             (mu-law codec)               -> wn_mulaw_*_kernel
 //
-// Design: one workgroup per utterance (stream).  Wave 0 is the CHAIN wave: it walks the dilated
-// residual stack layer by layer (the strictly serial part), every lane owning one filter/gate output, operands
-// broadcast with v_readlane, gated tanh*sigmoid evaluated as one instruction stream with per-half-wave
-// coefficients.  Waves 1..W are WORKERS: they stream the wide 1x1 convolutions (skip, post) as 64x32 weight tiles
-// straight into registers (coalesced 16 B/lane), following the chain through an LDS sequence flag.  The
-// discretised-mixture-of-logistics sampler runs on worker 0 and feeds the next step through LDS.
+// Design: G workgroups per utterance (stream), 8 waves each.  Wave 0 is the CHAIN wave: it walks the dilated
+// residual stack layer by layer (the strictly serial part), every lane owning one filter/gate output, operands broadcast
+// with v_readlane into packed fmas, the gated tanh*sigmoid evaluated as one instruction stream with per-half-wave
+// coefficients.  Waves 1..3 are LOADERS: they stage each layer's chain weights, x[t-d] and conditioning row into a ring
+// of LDS slots by LDS-DMA, compute the tap-0 chunk and keep the delay lines in HBM up to date.  Waves 4..7 are WORKERS:
+// they stream the wide 1x1 convolutions (skip, post) as 64x32 weight tiles into registers and run the sampler.  All G
+// workgroups of a stream run the same chain (identical bits) and own 1/G of the skip / conv1d_1 output blocks; two
+// all-gathers per step travel as {epoch, value} granules.  Waves synchronise through LDS sequence words only.
 // All arithmetic follows the arithmetic contract: results are bit-identical to the
 // CPU checker for any launch geometry.
 #include <hip/hip_runtime.h>
