@@ -803,6 +803,7 @@ enum { DS_W = 0, DS_BIAS, DS_K, DS_N, DS_X, DS_DST, DS_ACT, DS_SPLIT, DS_POST, D
 enum { DP_NONE = 0, DP_CAT_ATT, DP_GATES, DP_CAND, DP_QUERY, DP_PROJ, DP_OUT };
 enum { DA_NONE = 0, DA_SIGMOID, DA_TANH, DA_RELU };
 
+template <bool PROF>
 __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
 {
     const DecArgs& a = ga.d;
@@ -917,7 +918,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
         if (wave + 16 < ntn_) load_tile_b(t2, rs, lane * 16, decg_off(wn_, q2_, ncn_, gn_, lgn_));                               \
     }
     DECG_PREFETCH(0)
-#define TWV_STAMP(k) if (a.prof && blockIdx.x == 0 && tid == 0) a.prof[it * 16 + (k)] = __builtin_amdgcn_s_memtime();
+#define TWV_STAMP(k) if (PROF && a.prof && blockIdx.x == 0 && tid == 0) a.prof[it * 16 + (k)] = __builtin_amdgcn_s_memtime();
 
     for (int it = 0; it < a.iters && ok; ++it) {
         for (int st = 0; st < nst && ok; ++st) {
@@ -932,7 +933,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
             const int nmine = nblk > gg ? (nblk - gg + GG - 1) >> lgg : 0;
             const int ntile = nmine * nchunk;
             if (st == 0) { TWV_STAMP(0) }
-            if (st == 5) { TWV_STAMP(10) }
+            if (PROF && st == 5) { TWV_STAMP(10) }
             // ---- this workgroup's tiles: wave w takes local tiles w, w+8, ... (three in flight), partials to LDS.  The first three
             // were requested while the previous stage was still combining / exchanging (weights do not depend on data).
             {
@@ -964,11 +965,11 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                         if (i + 40 < ntile) load_tile_b(t2, rs, vo, decg_off(w_bytes, p2, nchunk, gg, lgg));
                     }
                 }
-                if (st == 5) { TWV_STAMP(11) }
+                if (PROF && st == 5) { TWV_STAMP(11) }
             }
-            if (st == 5) { TWV_STAMP(12) }
+            if (PROF && st == 5) { TWV_STAMP(12) }
             __syncthreads();
-            if (st == 5) { TWV_STAMP(13) }
+            if (PROF && st == 5) { TWV_STAMP(13) }
             // ---- epilogue: chunk sums in order (AC-1) + bias + activation; split stages publish and all-gather
             {
                 const bool xch = split && G > 1;
@@ -985,11 +986,11 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                         if (xch) decg_store(Xb + j, ep, v); else lds[dst + j] = v;
                     }
                 }
-                if (st == 5) { TWV_STAMP(14) }
+                if (PROF && st == 5) { TWV_STAMP(14) }
                 // the next stage's first tiles are requested only now: this workgroup's values are already on their way to the others
                 DECG_PREFETCH(st + 1 < nst ? st + 1 : 0)
                 if (xch) decg_gather(Xb, N, ep, dst, tid, o_abort);
-                if (st == 5) { TWV_STAMP(15) }
+                if (PROF && st == 5) { TWV_STAMP(15) }
                 __syncthreads();
                 ok = LDSI(o_abort) == 0;
             }
@@ -1501,8 +1502,13 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             if (ga.kv_lds) fl += kvf;
             const size_t shm = (size_t)fl * 4;
             if (shm > 160 * 1024) return twv_fail(TWV_E_UNSUPPORTED, "decoder LDS footprint exceeds 160 KiB (t_in too large)");
-            HIPCHK(hipFuncSetAttribute((const void*)tc_decoder_g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-            hipLaunchKernelGGL(tc_decoder_g_kernel, dim3(N * G), dim3(512), shm, st, ga);
+            if (da.prof) {     // the instrumented build (phase stamps) is its own instantiation
+                HIPCHK(hipFuncSetAttribute((const void*)tc_decoder_g_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+                hipLaunchKernelGGL(tc_decoder_g_kernel<true>, dim3(N * G), dim3(512), shm, st, ga);
+            } else {
+                HIPCHK(hipFuncSetAttribute((const void*)tc_decoder_g_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+                hipLaunchKernelGGL(tc_decoder_g_kernel<false>, dim3(N * G), dim3(512), shm, st, ga);
+            }
         }
     }
     // ---- tacotron.py:209 post CBHG (no lengths, zero init), :219 linear projection
