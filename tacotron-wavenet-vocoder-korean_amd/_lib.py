@@ -46,6 +46,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libtwv_amd.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
                            "there is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm ships its own libamdhip64.so (SONAME libamdhip64.so.7) and must be the FIRST HIP runtime in the process:
+    # loaded after it, this library binds to the same copy; loaded before it, /opt/rocm's copy comes in, torch then adds
+    # its own, and the second runtime in one process fails with "no ROCm-capable device is detected".
+    try:
+        import torch                                 # noqa: F401
+    except ImportError:
+        pass                                         # symbol checks / builds still work without torch
     L = C.CDLL(LIB_PATH)
     vp, ip, fp, dp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
     L.twv_last_error.restype = C.c_char_p

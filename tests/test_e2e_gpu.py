@@ -37,3 +37,17 @@ def test_text_to_wave_matches_chained_oracles(oracle):
     # host-side trim rule (synthesizer.py:232-256) runs on the alignments without error and stays inside the decode
     k = attention_trim_frames(al_o[0][:5], 5, hp.reduction_factor)
     assert 3 <= k <= hp.reduction_factor * hp.max_iters + 3
+
+
+@pytest.mark.gpu
+def test_driver_hooks_in_one_fresh_process():
+    """build() loads the C-ABI library before anything has imported torch; smoke() must still see the GPU afterwards
+    (PyTorch-ROCm carries its own HIP runtime: a second runtime in the process reports "no ROCm-capable device")."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "smoke ok" in r.stdout
