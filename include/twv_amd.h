@@ -206,6 +206,12 @@ int twv_inv_linear_spectrogram(twv_griffin_lim* h, const float* lin, const float
 /* cross-lane primitive self-test (device float[256]); used by the gpu tests to pin v_permlane32_swap / v_readlane semantics */
 int twv_selftest(float* out256, void* stream);
 
+/* ---- checkpoint helper (host only) ----
+ * CRC-32C of `n` bytes, continuing from `crc` (0 to start): the per-tensor / per-block checksum of the TensorFlow
+ * tensor-bundle files that tf.train.Saver writes (train_vocoder.py:133,176 / generate.py:158-161); used by
+ * checkpoint.py to verify bundles on read and to stamp the ones it writes.  No device work. */
+uint32_t twv_crc32c(const void* data, size_t n, uint32_t crc);
+
 #ifdef __cplusplus
 }
 #endif

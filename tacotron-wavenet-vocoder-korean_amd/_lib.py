@@ -105,6 +105,7 @@ def lib():
     L.twv_clip_by_global_norm.argtypes = [fp, C.c_int64, C.c_double, C.c_double, vp, vp]
     L.twv_adam_ema_step.argtypes = [fp, fp, fp, fp, fp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
                                     C.c_double, C.c_double, vp]
+    L.twv_crc32c.argtypes = [vp, C.c_size_t, C.c_uint32]; L.twv_crc32c.restype = C.c_uint32
     _lib = L
     return L
 
@@ -119,7 +120,7 @@ EXPORTS = ["twv_last_error", "twv_version", "twv_wavenet_create", "twv_wavenet_d
            "twv_wavenet_train_create", "twv_wavenet_train_destroy", "twv_wavenet_train_param_floats", "twv_wavenet_train_workspace_bytes",
            "twv_wavenet_train_output_width", "twv_wavenet_train_loss_grad", "twv_adam_ema_step", "twv_wavenet_train_l2",
            "twv_clip_by_global_norm", "twv_griffin_lim_create", "twv_griffin_lim_destroy", "twv_griffin_lim_samples",
-           "twv_griffin_lim_workspace_bytes", "twv_inv_linear_spectrogram"]
+           "twv_griffin_lim_workspace_bytes", "twv_inv_linear_spectrogram", "twv_crc32c"]
 
 
 class TacoDims(C.Structure):

@@ -244,9 +244,15 @@ __global__ void tr_gather_emb_kernel(const float* table, const int32_t* ids, flo
 {
     GRID_STRIDE(i, (long long)B * G) out[i] = table[(long long)ids[i / G] * G + (i % G)];
 }
-__global__ void tr_scatter_emb_kernel(const float* demb, const int32_t* ids, float* dtable, int B, int G)
+// one thread per table element, batch rows added in order: reproducible (no float atomics)
+__global__ void tr_scatter_emb_kernel(const float* demb, const int32_t* ids, float* dtable, int B, int G, int card)
 {
-    GRID_STRIDE(i, (long long)B * G) atomicAdd(&dtable[(long long)ids[i / G] * G + (i % G)], demb[i]);
+    GRID_STRIDE(i, (long long)card * G) {
+        const int row = (int)(i / G), g = (int)(i % G);
+        float s = 0.0f;
+        for (int b = 0; b < B; ++b) if (ids[b] == row) s += demb[(long long)b * G + g];
+        dtable[i] += s;
+    }
 }
 
 // mixture.py:27-81 discretized_mix_logistic_loss(num_class=2**16, reduce=False) + model.py:290 mean, and its gradient.
@@ -254,7 +260,7 @@ __global__ void tr_scatter_emb_kernel(const float* demb, const int32_t* ids, flo
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigm_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 __global__ void tr_mol_loss_kernel(const float* y, const float* audio, int B, int T, int ow, int rf, int nr, float inv_count,
-                                   float* loss_sum, float* dy)
+                                   float* row_loss, float* dy)
 {
     const long long rows = (long long)B * ow;
     GRID_STRIDE(r, rows) {
@@ -287,7 +293,7 @@ __global__ void tr_mol_loss_kernel(const float* y, const float* audio, int B, in
         float sa = 0.0f;
         for (int i = 0; i < nr; ++i) sa += expf(a[i] - amax);
         const float lse = amax + logf(sa);
-        atomicAdd(loss_sum, -lse * inv_count);
+        row_loss[r] = -lse * inv_count;
         float* dr = dy + r * 3 * nr;
         for (int i = 0; i < nr; ++i) {
             const float w = expf(a[i] - lse);                      // softmax(a)
@@ -1074,12 +1080,11 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         if ((rc = gemm_rm(bl, false, false, (int)RO, O, S, 1.f, C1, S, P + h->c_w2, O, 0.f, Y, O))) break;
         if (ub) K1(tr_bias_add_kernel, RO * O, Y, P + h->c_b2, O, RO * O);
         // model.py:286-290 loss
-        if (d.scalar_input) K1(tr_mol_loss_kernel, RO, Y, audio, B, T, ow, rf, nr, 1.0f / (float)RO, loss, dY);
-        else {
-            float* row_loss = dS;                                   // (RO) scratch: dS is not written before the backward pass
-            hipLaunchKernelGGL(tr_softmax_ce_kernel, dim3(tg(RO * 64)), dim3(256), 0, st, Y, qin, B, T, ow, rf, O, 1.0f / (float)RO, row_loss, dY);
-            colsum(row_loss, RO, 1, 1, 1, loss, 1);
-        }
+        // per-row terms, then the same two-stage column sum as the bias gradients: the loss is bit-reproducible run to run
+        float* row_loss = dS;                                       // (RO) scratch: dS is not written before the backward pass
+        if (d.scalar_input) K1(tr_mol_loss_kernel, RO, Y, audio, B, T, ow, rf, nr, 1.0f / (float)RO, row_loss, dY);
+        else hipLaunchKernelGGL(tr_softmax_ce_kernel, dim3(tg(RO * 64)), dim3(256), 0, st, Y, qin, B, T, ow, rf, O, 1.0f / (float)RO, row_loss, dY);
+        colsum(row_loss, RO, 1, 1, 1, loss, 1);
         // ================= backward =================
         rc |= gemm_rm(bl, true, false, S, O, (int)RO, 1.f, C1, S, dY, O, 0.f, Gd + h->c_w2, O);                 // dW2 = H2^T dY
         if (ub) colsum(dY, RO, O, O, 1, Gd + h->c_b2, O);
@@ -1153,7 +1158,7 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             hipLaunchKernelGGL(tr_onehot_causal_bwd_kernel, dim3(nblk), dim3(256), 2 * Q * 32 * 4, st, dXn, qin, ohpart, B, T, Tn, Q, rpb);
             hipLaunchKernelGGL(tr_colsum_final_kernel, dim3((2 * Q * 32 + 63) / 64), dim3(256), 0, st, ohpart, nblk, 2 * Q * 32, 1, Gd + h->c_causal, 2 * Q * 32);
         }
-        K1(tr_scatter_emb_kernel, (long long)B * G, demb, gc_ids, Gd + h->c_gcemb, B, G);
+        K1(tr_scatter_emb_kernel, (long long)d.gc_cardinality * G, demb, gc_ids, Gd + h->c_gcemb, B, G, d.gc_cardinality);
         K1(tr_views_kernel, (vstride + 32LL * S) * NL, Gd, GV, GS, NL, h->c_layer0, h->c_lstride, h->lo.wf, h->lo.wg, h->lo.lcf, h->lo.lcg,
            h->lo.gcf, h->lo.gcg, h->lo.ws, L, G, S, 1);
         {

@@ -2,8 +2,9 @@
 output files (`<logdir>/generate/<timestamp>/test-{i}.wav`), the per-sample `sess.run` loop replaced by ONE persistent
 kernel launch.
 
-Differences that are deliberate and visible: the checkpoint is `<checkpoint_dir>/wavenet_weights.npz` (numpy arrays keyed
-by the TF variable names of wavenet/model.py -- a real `model.ckpt-*` bundle needs TensorFlow to read); `--wav_seed` takes
+Differences that are deliberate and visible: the checkpoint is the `model.ckpt-N` bundle the directory's `checkpoint`
+file names (read by checkpoint.py without TensorFlow; unpinned against a TF-written file) or, without one,
+`<checkpoint_dir>/wavenet_weights.npz` (numpy arrays keyed by the TF variable names of wavenet/model.py); `--wav_seed` takes
 a wav at the model's sample rate or a .npy (no librosa resampling / silence trimming, both are host DSP outside the
 path); `--seed` makes the sampler's uniforms reproducible (the reference is unseeded)."""
 import argparse
@@ -86,8 +87,15 @@ def main(argv=None):
                        initial_filter_width=hparams.initial_filter_width, global_condition_channels=hparams.gc_channels,
                        global_condition_cardinality=config.gc_cardinality, local_condition_channels=hparams.num_mels,
                        upsample_factor=hparams.upsample_factor, train_mode=False)      # generate.py:121-137
+    from . import checkpoint as ckpt
     wpath = os.path.join(config.checkpoint_dir, 'wavenet_weights.npz')
-    if os.path.exists(wpath):
+    if ckpt.latest_checkpoint(config.checkpoint_dir):                                  # utils/__init__.py:75-90 load()
+        prefix = ckpt.latest_checkpoint(config.checkpoint_dir)
+        print('Restoring model from {}'.format(config.checkpoint_dir))
+        print("  Checkpoint found: {}".format(prefix))
+        print("  Global step was: {}".format(ckpt.checkpoint_step(prefix)))
+        tensors = ckpt.wavenet_tensors(ckpt.read_bundle(prefix), net.specs)           # raw variables by name (generate.py:157)
+    elif os.path.exists(wpath):
         print('Restoring model from {}'.format(config.checkpoint_dir))
         tensors = dict(np.load(wpath))
     elif config.random_init:

@@ -4,6 +4,7 @@ rnn_decoder_test_mode=True)` and synthesizer.py `Synthesizer.load / synthesize`)
 Default hparams path only (model_type 'deepvoice', num_speakers > 1, attention_type 'bah_mon_norm'); tokens in, mel /
 linear / alignments out.  Text -> token ids (text/*, jamo) and Griffin-Lim are host DSP outside this path."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -183,7 +184,13 @@ class Synthesizer(object):
         from .hparams import hparams as default_hp
         self.num_speakers = num_speakers
         self.model = Tacotron(hparams or default_hp, num_speakers, device=device)
-        tensors = dict(np.load(checkpoint)) if isinstance(checkpoint, str) else checkpoint
+        if isinstance(checkpoint, str) and not checkpoint.endswith(".npz"):
+            # synthesizer.py:37-41,69-70: a logdir (most recent model.ckpt-N) or one bundle prefix, restored by variable name
+            from . import checkpoint as ckpt
+            prefix = ckpt.most_recent_checkpoint(checkpoint) if os.path.isdir(checkpoint) else ckpt.resolve(checkpoint)
+            tensors = ckpt.tacotron_tensors(ckpt.read_bundle(prefix), self.model.specs)
+        else:
+            tensors = dict(np.load(checkpoint)) if isinstance(checkpoint, str) else checkpoint
         self.model.load_weights(tensors)
 
     def synthesize(self, tokens, speaker_ids=None, want_linear=True):

@@ -106,8 +106,55 @@ class WaveNetTrainer(object):
         return self._named(self.params)
 
     def ema_weights(self):
-        """what the reference's eval/generate restores (model.py:30, generate.py:157)"""
+        """the ExponentialMovingAverage shadows (model.py:30,346).  NOTE: the reference's generate.py:157-158 restores the RAW
+        variables by name, not these -- `weights()` is what its generation path loads."""
         return self._named(self.ema)
+
+    # ---- saver.save / load (utils/__init__.py:62-90; train_vocoder.py:133-152,175-176) ----
+    def save(self, logdir, step=None, include_optimizer=True):
+        """writes `logdir/model.ckpt-<step>` as a TensorFlow V2 bundle + the `checkpoint` state file (checkpoint.py).
+        Variables carry the reference graph's names: the weights under their own names, their EMA shadows under
+        `<name>/ExponentialMovingAverage`, `global_step`; with include_optimizer the Adam moments under
+        `optimizer/<name>/Adam`, `/Adam_1` and `optimizer/beta{1,2}_power` ([RECALLED-TF] slot naming, unverified)."""
+        import os
+        from . import checkpoint as ckpt
+        step = self.global_step if step is None else int(step)
+        var = dict(self.weights())
+        for k, v in self.ema_weights().items():
+            var[k + ckpt.EMA_SUFFIX] = v
+        var["global_step"] = np.asarray(step, np.int32)
+        if include_optimizer:
+            for k, v in self._named(self.m).items():
+                var["optimizer/" + k + "/Adam"] = v
+            for k, v in self._named(self.v).items():
+                var["optimizer/" + k + "/Adam_1"] = v
+            var["optimizer/beta1_power"] = np.asarray(self.beta1 ** (self.global_step + 1), np.float32)
+            var["optimizer/beta2_power"] = np.asarray(self.beta2 ** (self.global_step + 1), np.float32)
+        prefix = os.path.join(logdir, "model.ckpt-%d" % step)
+        ckpt.write_bundle(prefix, var)
+        ckpt.write_checkpoint_state(logdir, prefix)
+        return prefix
+
+    def restore(self, path, verify=False):
+        """`load(saver, sess, logdir)`: logdir or bundle prefix -> global step.  Weights are required; EMA shadows / Adam
+        moments are taken when the bundle has them (else EMA = weights, moments = 0, like a fresh optimizer)."""
+        from . import checkpoint as ckpt
+        prefix = ckpt.resolve(path)
+        var = ckpt.read_bundle(prefix, verify=verify)
+        self.load_weights(ckpt.wavenet_tensors(var, self.net.specs))
+
+        def opt(fmt):
+            got = {n: var.get(fmt % n) for n, _ in self.net.specs}
+            if any(v is None for v in got.values()):
+                return None
+            return torch.from_numpy(W.flatten(self.net.specs, got)).to(self.device)
+        ema, m, v = opt("%s" + ckpt.EMA_SUFFIX), opt("optimizer/%s/Adam"), opt("optimizer/%s/Adam_1")
+        if ema is not None:
+            self.ema = ema
+        if m is not None and v is not None:
+            self.m, self.v = m, v
+        self.global_step = int(var["global_step"]) if "global_step" in var else ckpt.checkpoint_step(prefix)
+        return self.global_step
 
     def gradients(self):
         return self._named(self.grads)

@@ -1,7 +1,7 @@
 """C4: the teacher-forced WaveNet training step on the MI355X vs a plain PyTorch fp32 (CPU autograd) model of the same op.
 
 Floating-point work -> tolerance parity (written at each assert).  The GPU path sums in a different order (rocBLAS
-GEMMs over all rows, atomics for the loss), so agreement is to fp32 round-off of the reductions, not bit-exact."""
+GEMMs over all rows, chunked column sums), so agreement is to fp32 round-off of the reductions, not bit-exact."""
 import numpy as np
 import pytest
 import torch
