@@ -202,7 +202,7 @@ struct GenArgs {
 // Intra-workgroup synchronisation is by monotonically increasing LDS sequence words only (no s_barrier inside the
 // sample loop, so the wave roles run decoupled).  Every wait is BOUNDED: after ~2^22 polls it raises the workgroup's
 // abort word, every other wait then falls through, and the launch ends with a watchdog code instead of hanging.
-enum { C_ZSEQ = 0, C_ABORT = 1, C_SAMPLE = 2, C_CDONE = 3, C_H1CNT = 4, C_H2CNT = 5, C_CPCNT = 6, C_SSEQ = 7, C_P1CNT = 8, C_SKCNT = 9, C_LGCNT = 10 };
+enum { C_ZSEQ = 0, C_ABORT = 1, C_SAMPLE = 2, C_CDONE = 3, C_H1CNT = 4, C_H2CNT = 5, C_CPCNT = 6, C_SSEQ = 7, C_P1CNT = 8, C_SKCNT = 9, C_LGCNT = 10, C_SKP = 11 /* ..14: per-worker skip progress */ };
 
 __device__ __forceinline__ bool wait_seq(int fo_flag, int target, int fo_abort, int code)
 {
@@ -536,7 +536,7 @@ __device__ __forceinline__ void loader_main(const GenArgs& a, const Ctx& c, rsrc
 // Workgroup g of a stream owns the output blocks jb with jb % G == g of the skip sum and of conv1d_1 (local index
 // m = jb / G); the two 512-vectors in between are all-gathered across the G workgroups; conv1d_2 and the sampler run
 // redundantly in every workgroup (identical bits), so each of them feeds its own chain wave without another hop.
-template <int W, int NTW, bool SCALAR, bool SPLIT1, bool INSTR>
+template <int W, int NTW, bool SCALAR, bool SPLIT1, bool INSTR, bool HELP>
 __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc_t rs, int w)
 {
     const Layout& L = a.lay;
@@ -623,7 +623,19 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                 }
             } else {
                 // few output blocks per workgroup: worker w takes layers l = w, w+W, ... (W-fold latency hiding for the tile
-                // fetch), leaves each layer's skip value in LDS, and the block owners add them up IN LAYER ORDER afterwards
+                // fetch), leaves each layer's skip value in LDS and advances its progress word; the owner of block m (worker m)
+                // adds the values up IN LAYER ORDER as they appear, so after the last layer only one value is left to add
+                int nextl = 0;
+                float tsum = 0.0f;
+                auto drain = [&](int upto) {                         // owner: layers nextl..upto of block w join the sum
+                    for (; nextl <= upto; ++nextl) {
+                        const int ow = nextl % W;
+                        if (ow != w) wait_seq(ctl + C_SKP + ow, t * NL + nextl + 1, ctl + C_ABORT, 10);
+                        ACQUIRE_WG();
+                        const float v = lds[c.o_skl + (w * NL + nextl) * 64 + lane];
+                        tsum = (nextl == 0) ? v : tsum + v;          // model.py:154 sum(outputs), in layer order
+                    }
+                };
                 for (int l = w; l < NL; l += W) {
                     wait_seq(ctl + C_ZSEQ, t * NL + l + 1, ctl + C_ABORT, 100 + l);
                     ACQUIRE_WG();
@@ -647,18 +659,13 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                         if (use_bias) v = v + n_bs[0];
                         lds[c.o_skl + (m * NL + l) * 64 + lane] = v;
                     }
+                    publish(ctl + C_SKP + w, t * NL + l + 1, lane);
                     load_tile_b(tk[0], rs, v16, lnb + skb + g * kTile * 4);   // block m = 0 of this worker's next layer
                     if (use_bias) n_bs[0] = load_f32_b(rs, v4, lnb + bsb + g * 256);
+                    if (w < NSJL) drain(l);
                 }
-                arrive(ctl + C_SKCNT, lane);
                 if (w < NSJL) {
-                    wait_seq(ctl + C_SKCNT, W * (t + 1), ctl + C_ABORT, 10);
-                    ACQUIRE_WG();
-                    float tsum = 0.0f;
-                    for (int l = 0; l < NL; ++l) {
-                        const float v = lds[c.o_skl + (w * NL + l) * 64 + lane];
-                        tsum = (l == 0) ? v : tsum + v;               // model.py:154 sum(outputs), in layer order
-                    }
+                    drain(NL - 1);
                     const float h = tsum > 0.0f ? tsum : 0.0f;        // model.py:157 relu
                     const int jb = w * G + g;
                     if (G == 1) lds[c.o_h1 + jb * 64 + lane] = h;
@@ -672,6 +679,9 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
         Tile qa, qb;
         const int n1 = NSJL * NCH;
         auto w1_off = [&](int idx) -> int { const int m = idx / NCH, ch = idx - m * NCH; return ((int)L.off_w1 + ((m * G + g) * NCH + ch) * kTile) * 4; };
+        // HELP: conv1d_1 of this slice runs in the stream's helper workgroup (helper_main), straight from the h1 granules to the h2
+        // granules; this workgroup goes on to wait for h2
+        if (!HELP) {
         if (split1) {
             if (w < n1) load_tile_b(qa, rs, v16, w1_off(w));
             if (w + W < n1) load_tile_b(qb, rs, v16, w1_off(w + W));
@@ -746,6 +756,7 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                 else granule_store(X2 + jb * 64 + lane, 2u * (unsigned)t + 2u, h);
             }
         }
+        }   // !HELP
         if (wprof) wp[47] = __builtin_amdgcn_s_memtime();
         // prefetches that do not depend on h2 (the sampler's inputs)
         const int n2 = L.NOJ * NCH;
@@ -920,14 +931,113 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
     }
 }
 
+// =============================== HELPER WORKGROUP (one per stream slice, optional) ===============================
+// model.py:158-160 conv1d_1 + relu for the output blocks of slice g, off the stream workgroups: the 8 waves keep the slice's
+// chunk tiles RESIDENT in registers for the whole launch (2 tiles = 64 VGPRs per wave; the stream workgroups have neither the
+// registers nor the LDS for that and re-stream the 128 KB every step), poll the h1 granules of exactly their own chunks
+// (one granule per lane), and the block owner publishes the h2 granules.  Same arithmetic, same order (AC-1 chunk partials
+// added in chunk order, then bias): the h2 bits do not depend on who computes them.
+template <int OFF>
+__device__ __forceinline__ float dot_readlane_off(const Tile& t, float xv)
+{
+    f32x2p s01 = {0.0f, 0.0f}, s23 = {0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < 32; c += 4) {
+        const f32x2p x01 = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), OFF + c + 0)),
+                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), OFF + c + 1))};
+        const f32x2p x23 = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), OFF + c + 2)),
+                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), OFF + c + 3))};
+        s01 = pk_fma(f32x2p{t.w[c + 0], t.w[c + 1]}, x01, s01);
+        s23 = pk_fma(f32x2p{t.w[c + 2], t.w[c + 3]}, x23, s23);
+    }
+    return (s01[0] + s01[1]) + (s23[0] + s23[1]);
+}
+constexpr int kHelperTiles = 16;      // 8 waves x 2 resident tiles
+__device__ __forceinline__ void helper_main(const GenArgs& a, int b, int g)
+{
+    const Layout& L = a.lay;
+    const int NCH = L.NCH, S = L.S, G = a.G, T = a.T;
+    const int NSJL = L.NSJ / G, n1 = NSJL * NCH;
+    const int v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const bool use_bias = L.use_bias != 0;
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.P), 0, (int)(L.packed_floats * 4), 0x00020000);
+    unsigned long long* X1 = a.exch + ((long long)b * 2 + 0) * S;
+    unsigned long long* X2 = a.exch + ((long long)b * 2 + 1) * S;
+    const int o_part = 0, o_cnt = kHelperTiles * 64, o_abort = o_cnt + 1;      // LDS: chunk partials | arrival counter | abort code
+    if (threadIdx.x == 0) { LDSI(o_cnt) = 0; LDSI(o_abort) = 0; }
+    __syncthreads();
+    const int i0 = 2 * v, i1 = 2 * v + 1;
+    const bool has0 = i0 < n1, has1 = i1 < n1;
+    if (!has0) return;                                                          // fewer tiles than waves: the rest has nothing to do
+    const int nact = (n1 + 1) / 2;
+    auto w1_off = [&](int idx) -> int { const int m = idx / NCH, ch = idx - m * NCH; return ((int)L.off_w1 + ((m * G + g) * NCH + ch) * kTile) * 4; };
+    Tile ta, tb;
+    load_tile_b(ta, rs, lane * 16, w1_off(i0));
+    load_tile_b(tb, rs, lane * 16, w1_off(has1 ? i1 : i0));
+    const int ch0 = i0 % NCH, ch1 = (has1 ? i1 : i0) % NCH;
+    const int gi = lane < 32 ? ch0 * 32 + lane : ch1 * 32 + lane - 32;         // the h1 element this lane fetches
+    float b1v = 0.0f;
+    if (v < NSJL && use_bias) b1v = load_f32_b(rs, lane * 4, ((int)L.off_b1 + (v * G + g) * 64) * 4);
+    // h1 arrives once per generation step: after each arrival the wave sleeps through most of the measured step period before it
+    // polls again (64 helper workgroups x 8 waves polling flat out are terabytes per second of agent-scope loads on the fabric)
+    unsigned long long t_arr = 0, period = 0;
+    for (int t = 0; t < T; ++t) {
+        const unsigned epoch = 2u * (unsigned)t + 1u;
+        unsigned long long q = 0;
+        bool ok = false;
+        if (period) {
+            const unsigned long long target = t_arr + period - (period >> 2);
+#pragma nounroll
+            for (int it = 0; it < 4096 && __builtin_amdgcn_s_memtime() < target; ++it) __builtin_amdgcn_s_sleep(16);
+        }
+#pragma nounroll
+        for (int it = 0; it < (1 << 22); ++it) {
+            q = __hip_atomic_load((gu64*)(X1 + gi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = __all((unsigned)(q >> 32) == epoch);
+            if (ok) break;
+            if ((it & 15) == 15 && LDSVI(o_abort)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) { if (!LDSVI(o_abort)) LDSVI(o_abort) = 12; break; }
+        {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            const unsigned long long d = now - t_arr;
+            period = (t_arr != 0 && d < (1ull << 20)) ? d : 0;                // no estimate after the first step or a long gap
+            t_arr = now;
+        }
+        const float x = __uint_as_float((unsigned)q);
+        lds[o_part + i0 * 64 + lane] = dot_readlane_off<0>(ta, x);
+        if (has1) lds[o_part + i1 * 64 + lane] = dot_readlane_off<32>(tb, x);
+        arrive(o_cnt, lane);
+        if (v < NSJL) {                                                         // owner of output block m = v
+            if (!wait_seq(o_cnt, nact * (t + 1), o_abort, 13)) break;
+            ACQUIRE_WG();
+            float r = 0.0f;
+            for (int ch = 0; ch < NCH; ++ch) {
+                const float cp = lds[o_part + (v * NCH + ch) * 64 + lane];
+                r = (ch == 0) ? cp : r + cp;
+            }
+            if (use_bias) r = r + b1v;
+            const float h = r > 0.0f ? r : 0.0f;
+            granule_store(X2 + (v * G + g) * 64 + lane, 2u * (unsigned)t + 2u, h);
+        }
+    }
+    if (lane == 0 && LDSVI(o_abort)) atomicMax(a.status, LDSI(o_abort));
+}
+
 constexpr int kLoaders = 3;
 
 // D = 1 parks an idle wave at index 1 + kLoaders: waves i and i+4 of a workgroup share a SIMD (scripts/ubench/simd_map.hip), so
 // with 3 loaders the chain wave (wave 0) then has its SIMD to itself.
-template <int W, int NTW, bool SCALAR, int D = 0, bool SPLIT1 = false, bool INSTR = false>
+template <int W, int NTW, bool SCALAR, int D = 0, bool SPLIT1 = false, bool INSTR = false, bool HELP = false>
 __global__ void __launch_bounds__((1 + kLoaders + D + W) * 64) wn_generate_kernel(GenArgs a)
 {
     const Layout& L = a.lay;
+    if (HELP && (int)blockIdx.x >= a.B * a.G) {      // the second half of the grid: one helper workgroup per (stream, slice)
+        const int hb = (int)blockIdx.x - a.B * a.G;
+        helper_main(a, hb / a.G, hb % a.G);
+        return;
+    }
     const int NL = L.NL, S = L.S, NCH = L.NCH;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int T = a.T;
@@ -979,7 +1089,7 @@ __global__ void __launch_bounds__((1 + kLoaders + D + W) * 64) wn_generate_kerne
     if (wid == 0) chain_main<SCALAR, INSTR>(a, c, hpos, prev_valid, qprev);
     else if (wid <= kLoaders) loader_main<kLoaders, INSTR>(a, c, rs, wid - 1);
     else if (D && wid == kLoaders + 1) {}
-    else worker_main<W, NTW, SCALAR, SPLIT1, INSTR>(a, c, rs, wid - 1 - kLoaders - D);
+    else worker_main<W, NTW, SCALAR, SPLIT1, INSTR, HELP>(a, c, rs, wid - 1 - kLoaders - D);
 
     // ---------------- persist the per-stream state (model.py:49-64 queues) ----------------
     __syncthreads();
@@ -1115,6 +1225,7 @@ struct twv_wavenet {
     int ring_off[kMaxLayers];
     int workers;   // worker waves per workgroup
     int groups;    // workgroups per stream (0 = auto)
+    int helpers;   // 1 = conv1d_1 in helper workgroups when the launch qualifies (default), 0 = never
     unsigned long long* prof;
     int prof_steps;
 };
@@ -1254,6 +1365,7 @@ extern "C" int twv_wavenet_create(const twv_wavenet_dims* dims, twv_wavenet** ou
     twv_wavenet* h = new twv_wavenet();
     h->dims = *dims;
     h->workers = 4;
+    h->helpers = 1;
     h->groups = 0;
     h->prof = nullptr; h->prof_steps = 0;
     const int rc = build_layout(*dims, h);
@@ -1298,6 +1410,11 @@ extern "C" int twv_wavenet_set_profile_buffer(twv_wavenet* h, void* dev_u64, int
 extern "C" int twv_wavenet_set_option(twv_wavenet* h, const char* name, int value)
 {
     if (!h || !name) return fail(TWV_E_INVALID, "null argument");
+    if (!strcmp(name, "helpers")) {
+        if (value != 0 && value != 1) return fail(TWV_E_INVALID, "helpers must be 0 or 1");
+        h->helpers = value;
+        return TWV_OK;
+    }
     if (!strcmp(name, "workers")) {
         if (value != 4 && value != 3) return fail(TWV_E_INVALID, "workers must be 4 or 3 (3 = idle wave beside the chain wave)");
         h->workers = value;
@@ -1435,21 +1552,21 @@ extern "C" int twv_wavenet_condition(const twv_wavenet* h, const void* packed, c
     return TWV_OK;
 }
 
-template <int W, int NTW, bool SCALAR, int D, bool SPLIT1, bool INSTR>
+template <int W, int NTW, bool SCALAR, int D, bool SPLIT1, bool INSTR, bool HELP>
 static int launch_generate2(const GenArgs& a, size_t shm, hipStream_t st)
 {
-    auto kern = wn_generate_kernel<W, NTW, SCALAR, D, SPLIT1, INSTR>;
+    auto kern = wn_generate_kernel<W, NTW, SCALAR, D, SPLIT1, INSTR, HELP>;
     if (shm > 32 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(kern, dim3(a.B * a.G), dim3((1 + kLoaders + D + W) * 64), shm, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.B * a.G * (HELP ? 2 : 1)), dim3((1 + kLoaders + D + W) * 64), shm, st, a);
     HIPCHK(hipGetLastError());
     return TWV_OK;
 }
 // the instrumented build (phase stamps, per-layer dumps) is a separate instantiation: production launches carry none of its branches
-template <int W, int NTW, bool SCALAR, int D = 0, bool SPLIT1 = false>
+template <int W, int NTW, bool SCALAR, int D = 0, bool SPLIT1 = false, bool HELP = false>
 static int launch_generate(const GenArgs& a, size_t shm, hipStream_t st)
 {
-    if (a.prof != nullptr || a.dbg != nullptr) return launch_generate2<W, NTW, SCALAR, D, SPLIT1, true>(a, shm, st);
-    return launch_generate2<W, NTW, SCALAR, D, SPLIT1, false>(a, shm, st);
+    if (a.prof != nullptr || a.dbg != nullptr) return launch_generate2<W, NTW, SCALAR, D, SPLIT1, true, HELP>(a, shm, st);
+    return launch_generate2<W, NTW, SCALAR, D, SPLIT1, false, HELP>(a, shm, st);
 }
 
 static int generate_impl(const twv_wavenet* h, const void* packed, void* state, const void* cond,
@@ -1489,6 +1606,10 @@ static int generate_impl(const twv_wavenet* h, const void* packed, void* state, 
     }
     const bool sp = nsjl < kWorkers;                 // few output blocks per workgroup: tiles round-robin over the workers
     if (L.scalar) {
+        // helper workgroups (conv1d_1 from resident registers): generation only, more than one workgroup per stream, at most
+        // kHelperTiles conv1d_1 tiles per slice, and twice the workgroups must still be co-resident
+        const bool help = h->helpers != 0 && sp && G > 1 && !forced && nsjl * L.NCH <= kHelperTiles && 2LL * batch * G <= device_cus();
+        if (ntw <= 1 && help) return launch_generate<kWorkers, 1, true, 0, true, true>(a, shm, st);
         if (ntw <= 1) return sp ? launch_generate<kWorkers, 1, true, 0, true>(a, shm, st) : launch_generate<kWorkers, 1, true, 0, false>(a, shm, st);
         if (ntw == 2) return launch_generate<kWorkers, 2, true, 0, false>(a, shm, st);
         if (ntw <= 4) return launch_generate<kWorkers, 4, true, 0, false>(a, shm, st);
