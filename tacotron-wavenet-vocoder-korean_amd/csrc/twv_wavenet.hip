@@ -536,7 +536,7 @@ __device__ __forceinline__ void loader_main(const GenArgs& a, const Ctx& c, rsrc
 // Workgroup g of a stream owns the output blocks jb with jb % G == g of the skip sum and of conv1d_1 (local index
 // m = jb / G); the two 512-vectors in between are all-gathered across the G workgroups; conv1d_2 and the sampler run
 // redundantly in every workgroup (identical bits), so each of them feeds its own chain wave without another hop.
-template <int W, int NTW, bool SCALAR, bool SPLIT1, bool INSTR, bool HELP>
+template <int W, int NTW, bool SCALAR, bool SPLIT1, bool INSTR, int HELP>
 __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc_t rs, int w)
 {
     const Layout& L = a.lay;
@@ -760,16 +760,18 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
         if (wprof) wp[47] = __builtin_amdgcn_s_memtime();
         // prefetches that do not depend on h2 (the sampler's inputs)
         const int n2 = L.NOJ * NCH;
-        if (split1) {
+        // HELP == 2: the helper workgroups go on from their h2 slice to conv1d_2's chunk partials of that slice (chunks 2g, 2g+1,
+        // 32 output lanes each): what is all-gathered here is the [NCH][32] partial table, and conv1d_2 is not computed at all
+        if (split1 && HELP != 2) {
             if (w < n2) load_tile_b(qa, rs, v16, ((int)L.off_w2 + w * kTile) * 4);
             if (w + W < n2) load_tile_b(qb, rs, v16, ((int)L.off_w2 + (w + W) * kTile) * 4);
         }
-        if (G > 1) gather_granules<W>(X2, S, 2u * (unsigned)t + 2u, c.o_h2, w, lane, ctl + C_ABORT, 9);
+        if (G > 1) gather_granules<W>(X2, S, 2u * (unsigned)t + 2u, HELP == 2 ? c.o_cpart : c.o_h2, w, lane, ctl + C_ABORT, 9);
         arrive(ctl + C_H2CNT, lane);
-        wait_seq(ctl + C_H2CNT, W * (t + 1), ctl + C_ABORT, 5);   // h2 complete
+        wait_seq(ctl + C_H2CNT, W * (t + 1), ctl + C_ABORT, 5);   // h2 (or the partial table) complete
         ACQUIRE_WG();
         if (wprof) wp[48] = __builtin_amdgcn_s_memtime();
-        {
+        if (HELP != 2) {
             // ---- model.py:161-165 conv1d_2 (S->O): chunk partials, summed in order by the sampler wave
             if (split1) {
                 for (int idx = w; idx < n2; idx += 2 * W) {
@@ -795,7 +797,7 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
             }
         }
         if (wprof) wp[49] = __builtin_amdgcn_s_memtime();
-        arrive(ctl + C_CPCNT, lane);
+        if (HELP != 2) arrive(ctl + C_CPCNT, lane);
         if (!SCALAR) {
             // one-hot: every worker assembles the logits of its output blocks (chunk partials in order, then bias)
             wait_seq(ctl + C_CPCNT, W * (t + 1), ctl + C_ABORT, 6);
@@ -812,14 +814,14 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
             arrive(ctl + C_LGCNT, lane);
         }
         if (w == 0) {
-            wait_seq(ctl + C_CPCNT, W * (t + 1), ctl + C_ABORT, 6);   // chunk partials complete
+            if (HELP != 2) wait_seq(ctl + C_CPCNT, W * (t + 1), ctl + C_ABORT, 6);   // chunk partials complete
             ACQUIRE_WG();
             if (wprof) wp[50] = __builtin_amdgcn_s_memtime();
             if (SCALAR) {
                 // raw network output y[lane] (lane < O), then mixture.py:84-114
                 float y = 0.0f;
                 for (int ch = 0; ch < NCH; ++ch) {
-                    const float cp = lds[c.o_cpart + ch * 64 + lane];
+                    const float cp = HELP == 2 ? lds[c.o_cpart + ch * 32 + (lane & 31)] : lds[c.o_cpart + ch * 64 + lane];
                     y = (ch == 0) ? cp : y + cp;
                 }
                 if (use_bias && lane < L.O) y = y + b2_pre;
@@ -953,6 +955,9 @@ __device__ __forceinline__ float dot_readlane_off(const Tile& t, float xv)
     return (s01[0] + s01[1]) + (s23[0] + s23[1]);
 }
 constexpr int kHelperTiles = 16;      // 8 waves x 2 resident tiles
+// CONV2: the owner wave also keeps conv1d_2's two chunk tiles of its h2 slice (chunks 2g, 2g+1; needs one output block per
+// slice and O <= 32) and publishes those chunk partials instead of h2 (model.py:161-165; the bias joins after the ordered sum)
+template <bool CONV2>
 __device__ __forceinline__ void helper_main(const GenArgs& a, int b, int g)
 {
     const Layout& L = a.lay;
@@ -978,6 +983,11 @@ __device__ __forceinline__ void helper_main(const GenArgs& a, int b, int g)
     const int gi = lane < 32 ? ch0 * 32 + lane : ch1 * 32 + lane - 32;         // the h1 element this lane fetches
     float b1v = 0.0f;
     if (v < NSJL && use_bias) b1v = load_f32_b(rs, lane * 4, ((int)L.off_b1 + (v * G + g) * 64) * 4);
+    Tile t2a, t2b;
+    if (CONV2 && v == 0) {
+        load_tile_b(t2a, rs, lane * 16, ((int)L.off_w2 + (2 * g) * kTile) * 4);
+        load_tile_b(t2b, rs, lane * 16, ((int)L.off_w2 + (2 * g + 1) * kTile) * 4);
+    }
     // h1 arrives once per generation step: after each arrival the wave sleeps through most of the measured step period before it
     // polls again (64 helper workgroups x 8 waves polling flat out are terabytes per second of agent-scope loads on the fabric)
     unsigned long long t_arr = 0, period = 0;
@@ -1019,7 +1029,15 @@ __device__ __forceinline__ void helper_main(const GenArgs& a, int b, int g)
             }
             if (use_bias) r = r + b1v;
             const float h = r > 0.0f ? r : 0.0f;
-            granule_store(X2 + (v * G + g) * 64 + lane, 2u * (unsigned)t + 2u, h);
+            if (CONV2) {
+                const float p0 = dot_readlane_off<0>(t2a, h), p1 = dot_readlane_off<32>(t2b, h);
+                if (lane < 32) {
+                    granule_store(X2 + (2 * g) * 32 + lane, 2u * (unsigned)t + 2u, p0);
+                    granule_store(X2 + (2 * g + 1) * 32 + lane, 2u * (unsigned)t + 2u, p1);
+                }
+            } else {
+                granule_store(X2 + (v * G + g) * 64 + lane, 2u * (unsigned)t + 2u, h);
+            }
         }
     }
     if (lane == 0 && LDSVI(o_abort)) atomicMax(a.status, LDSI(o_abort));
@@ -1029,13 +1047,13 @@ constexpr int kLoaders = 3;
 
 // D = 1 parks an idle wave at index 1 + kLoaders: waves i and i+4 of a workgroup share a SIMD (scripts/ubench/simd_map.hip), so
 // with 3 loaders the chain wave (wave 0) then has its SIMD to itself.
-template <int W, int NTW, bool SCALAR, int D = 0, bool SPLIT1 = false, bool INSTR = false, bool HELP = false>
+template <int W, int NTW, bool SCALAR, int D = 0, bool SPLIT1 = false, bool INSTR = false, int HELP = 0>
 __global__ void __launch_bounds__((1 + kLoaders + D + W) * 64) wn_generate_kernel(GenArgs a)
 {
     const Layout& L = a.lay;
     if (HELP && (int)blockIdx.x >= a.B * a.G) {      // the second half of the grid: one helper workgroup per (stream, slice)
         const int hb = (int)blockIdx.x - a.B * a.G;
-        helper_main(a, hb / a.G, hb % a.G);
+        helper_main<HELP == 2>(a, hb / a.G, hb % a.G);
         return;
     }
     const int NL = L.NL, S = L.S, NCH = L.NCH;
@@ -1225,7 +1243,8 @@ struct twv_wavenet {
     int ring_off[kMaxLayers];
     int workers;   // worker waves per workgroup
     int groups;    // workgroups per stream (0 = auto)
-    int helpers;   // 1 = conv1d_1 in helper workgroups when the launch qualifies (default), 0 = never
+    int helpers;   // 1 = helper workgroups when the launch qualifies (conv1d_1, and conv1d_2's partials if O <= 32; default),
+                   // 2 = conv1d_1 only, 0 = never
     unsigned long long* prof;
     int prof_steps;
 };
@@ -1411,7 +1430,7 @@ extern "C" int twv_wavenet_set_option(twv_wavenet* h, const char* name, int valu
 {
     if (!h || !name) return fail(TWV_E_INVALID, "null argument");
     if (!strcmp(name, "helpers")) {
-        if (value != 0 && value != 1) return fail(TWV_E_INVALID, "helpers must be 0 or 1");
+        if (value < 0 || value > 2) return fail(TWV_E_INVALID, "helpers must be 0 (off), 1 (auto) or 2 (conv1d_1 only)");
         h->helpers = value;
         return TWV_OK;
     }
@@ -1552,7 +1571,7 @@ extern "C" int twv_wavenet_condition(const twv_wavenet* h, const void* packed, c
     return TWV_OK;
 }
 
-template <int W, int NTW, bool SCALAR, int D, bool SPLIT1, bool INSTR, bool HELP>
+template <int W, int NTW, bool SCALAR, int D, bool SPLIT1, bool INSTR, int HELP>
 static int launch_generate2(const GenArgs& a, size_t shm, hipStream_t st)
 {
     auto kern = wn_generate_kernel<W, NTW, SCALAR, D, SPLIT1, INSTR, HELP>;
@@ -1562,7 +1581,7 @@ static int launch_generate2(const GenArgs& a, size_t shm, hipStream_t st)
     return TWV_OK;
 }
 // the instrumented build (phase stamps, per-layer dumps) is a separate instantiation: production launches carry none of its branches
-template <int W, int NTW, bool SCALAR, int D = 0, bool SPLIT1 = false, bool HELP = false>
+template <int W, int NTW, bool SCALAR, int D = 0, bool SPLIT1 = false, int HELP = 0>
 static int launch_generate(const GenArgs& a, size_t shm, hipStream_t st)
 {
     if (a.prof != nullptr || a.dbg != nullptr) return launch_generate2<W, NTW, SCALAR, D, SPLIT1, true, HELP>(a, shm, st);
@@ -1609,7 +1628,8 @@ static int generate_impl(const twv_wavenet* h, const void* packed, void* state, 
         // helper workgroups (conv1d_1 from resident registers): generation only, more than one workgroup per stream, at most
         // kHelperTiles conv1d_1 tiles per slice, and twice the workgroups must still be co-resident
         const bool help = h->helpers != 0 && sp && G > 1 && !forced && nsjl * L.NCH <= kHelperTiles && 2LL * batch * G <= device_cus();
-        if (ntw <= 1 && help) return launch_generate<kWorkers, 1, true, 0, true, true>(a, shm, st);
+        if (ntw <= 1 && help && h->helpers == 1 && nsjl == 1 && L.NOJ == 1 && L.O <= 32) return launch_generate<kWorkers, 1, true, 0, true, 2>(a, shm, st);
+        if (ntw <= 1 && help) return launch_generate<kWorkers, 1, true, 0, true, 1>(a, shm, st);
         if (ntw <= 1) return sp ? launch_generate<kWorkers, 1, true, 0, true>(a, shm, st) : launch_generate<kWorkers, 1, true, 0, false>(a, shm, st);
         if (ntw == 2) return launch_generate<kWorkers, 2, true, 0, false>(a, shm, st);
         if (ntw <= 4) return launch_generate<kWorkers, 4, true, 0, false>(a, shm, st);
