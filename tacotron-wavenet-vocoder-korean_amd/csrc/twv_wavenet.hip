@@ -766,10 +766,50 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
             if (w < n2) load_tile_b(qa, rs, v16, ((int)L.off_w2 + w * kTile) * 4);
             if (w + W < n2) load_tile_b(qb, rs, v16, ((int)L.off_w2 + (w + W) * kTile) * 4);
         }
-        if (G > 1) gather_granules<W>(X2, S, 2u * (unsigned)t + 2u, HELP == 2 ? c.o_cpart : c.o_h2, w, lane, ctl + C_ABORT, 9);
-        arrive(ctl + C_H2CNT, lane);
-        wait_seq(ctl + C_H2CNT, W * (t + 1), ctl + C_ABORT, 5);   // h2 (or the partial table) complete
-        ACQUIRE_WG();
+        float y_help = 0.0f;
+        if (HELP == 2) {
+            // the sampler wave alone collects the [NCH][32] partial table straight into registers -- lanes 0-31 the first half of
+            // the chunks of output (lane & 31), lanes 32-63 the second half -- and adds them up in chunk order (the upper half
+            // crosses over with v_permlane32_swap): no LDS staging, no hand-off between the workers
+            if (w == 0) {
+                const int H = (NCH + 1) >> 1, half = lane >> 5;
+                const unsigned epoch = 2u * (unsigned)t + 2u;
+                unsigned long long q[8];
+                bool ok = false;
+#pragma nounroll
+                for (int it = 0; it < (1 << 20); ++it) {
+                    bool good = true;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int ch = half * H + k;
+                        q[k] = ((unsigned long long)epoch) << 32;
+                        if (k < H && ch < NCH) q[k] = __hip_atomic_load((gu64*)(X2 + ch * 32 + (lane & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) good = good && ((unsigned)(q[k] >> 32) == epoch);
+                    ok = __all(good);
+                    if (ok) break;
+                    if ((it & 15) == 15 && LDSVI(ctl + C_ABORT)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!ok && !LDSVI(ctl + C_ABORT)) LDSVI(ctl + C_ABORT) = 9;
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < H) { const float v = __uint_as_float((unsigned)q[k]); acc = (k == 0) ? v : acc + v; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)q[k], (unsigned)q[k], false, false);
+                    if (H + k < NCH) acc = acc + __uint_as_float(sw[1]);     // the upper half-wave's chunk H+k of the same output
+                }
+                y_help = acc;
+            }
+        } else {
+            if (G > 1) gather_granules<W>(X2, S, 2u * (unsigned)t + 2u, c.o_h2, w, lane, ctl + C_ABORT, 9);
+            arrive(ctl + C_H2CNT, lane);
+            wait_seq(ctl + C_H2CNT, W * (t + 1), ctl + C_ABORT, 5);   // h2 complete
+            ACQUIRE_WG();
+        }
         if (wprof) wp[48] = __builtin_amdgcn_s_memtime();
         if (HELP != 2) {
             // ---- model.py:161-165 conv1d_2 (S->O): chunk partials, summed in order by the sampler wave
@@ -819,10 +859,12 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
             if (wprof) wp[50] = __builtin_amdgcn_s_memtime();
             if (SCALAR) {
                 // raw network output y[lane] (lane < O), then mixture.py:84-114
-                float y = 0.0f;
-                for (int ch = 0; ch < NCH; ++ch) {
-                    const float cp = HELP == 2 ? lds[c.o_cpart + ch * 32 + (lane & 31)] : lds[c.o_cpart + ch * 64 + lane];
-                    y = (ch == 0) ? cp : y + cp;
+                float y = y_help;
+                if (HELP != 2) {
+                    for (int ch = 0; ch < NCH; ++ch) {
+                        const float cp = lds[c.o_cpart + ch * 64 + lane];
+                        y = (ch == 0) ? cp : y + cp;
+                    }
                 }
                 if (use_bias && lane < L.O) y = y + b2_pre;
                 if (INSTR && a.dbg != nullptr && g == 0 && t < a.dbg_steps)
