@@ -60,3 +60,7 @@ wk = s[:, 44:52]
 print("worker0: skip pass %.2f (ends %.2f us after chain stack end) | gather h1 %.2f | conv1d_1 %.2f | gather h2 %.2f | conv1d_2 %.2f | wait partials %.2f | sampler %.2f us" % (
     us(wk[:, 1] - wk[:, 0]), us(wk[:, 1] - s[:, 2]), us(wk[:, 2] - wk[:, 1]), us(wk[:, 3] - wk[:, 2]), us(wk[:, 4] - wk[:, 3]),
     us(wk[:, 5] - wk[:, 4]), us(wk[:, 6] - wk[:, 5]), us(wk[:, 7] - wk[:, 6])))
+hh = s[:, 52:57]
+if hh[:, 0].any():
+    print("helper(0,0) wave 0: h1 published -> seen %.2f | two chunk dots %.2f | wait all partials %.2f | ordered sum %.2f | conv1d_2 partials + publish %.2f | -> table complete in the sampler wave %.2f us" % (
+        us(hh[:, 0] - wk[:, 1]), us(hh[:, 1] - hh[:, 0]), us(hh[:, 2] - hh[:, 1]), us(hh[:, 3] - hh[:, 2]), us(hh[:, 4] - hh[:, 3]), us(wk[:, 4] - hh[:, 4])))

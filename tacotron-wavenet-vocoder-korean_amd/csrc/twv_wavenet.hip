@@ -757,7 +757,8 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
             }
         }
         }   // !HELP
-        if (wprof) wp[47] = __builtin_amdgcn_s_memtime();
+        if (wprof && HELP) wp[46] = wp[45];
+        if (wprof) wp[47] = HELP ? wp[45] : __builtin_amdgcn_s_memtime();
         // prefetches that do not depend on h2 (the sampler's inputs)
         const int n2 = L.NOJ * NCH;
         // HELP == 2: the helper workgroups go on from their h2 slice to conv1d_2's chunk partials of that slice (chunks 2g, 2g+1,
@@ -999,7 +1000,7 @@ __device__ __forceinline__ float dot_readlane_off(const Tile& t, float xv)
 constexpr int kHelperTiles = 16;      // 8 waves x 2 resident tiles
 // CONV2: the owner wave also keeps conv1d_2's two chunk tiles of its h2 slice (chunks 2g, 2g+1; needs one output block per
 // slice and O <= 32) and publishes those chunk partials instead of h2 (model.py:161-165; the bias joins after the ordered sum)
-template <bool CONV2>
+template <bool CONV2, bool INSTR>
 __device__ __forceinline__ void helper_main(const GenArgs& a, int b, int g)
 {
     const Layout& L = a.lay;
@@ -1023,12 +1024,17 @@ __device__ __forceinline__ void helper_main(const GenArgs& a, int b, int g)
     load_tile_b(tb, rs, lane * 16, w1_off(has1 ? i1 : i0));
     const int ch0 = i0 % NCH, ch1 = (has1 ? i1 : i0) % NCH;
     const int gi = lane < 32 ? ch0 * 32 + lane : ch1 * 32 + lane - 32;         // the h1 element this lane fetches
+    // CONV2 (one output block per slice): waves 0 and 1 BOTH add up the chunk partials (same bits), so that each of them has the
+    // h2 slice in its lanes and they take one conv1d_2 chunk each, side by side; with a single active wave, wave 0 takes both
+    const bool two = CONV2 && nact >= 2;
+    const bool summer = CONV2 ? (v == 0 || (two && v == 1)) : (v < NSJL);
+    const int mb = CONV2 ? 0 : v;                                               // the output block this wave sums
     float b1v = 0.0f;
-    if (v < NSJL && use_bias) b1v = load_f32_b(rs, lane * 4, ((int)L.off_b1 + (v * G + g) * 64) * 4);
+    if (summer && use_bias) b1v = load_f32_b(rs, lane * 4, ((int)L.off_b1 + (mb * G + g) * 64) * 4);
     Tile t2a, t2b;
-    if (CONV2 && v == 0) {
-        load_tile_b(t2a, rs, lane * 16, ((int)L.off_w2 + (2 * g) * kTile) * 4);
-        load_tile_b(t2b, rs, lane * 16, ((int)L.off_w2 + (2 * g + 1) * kTile) * 4);
+    if (CONV2 && summer) {
+        load_tile_b(t2a, rs, lane * 16, ((int)L.off_w2 + (2 * g + (v == 1 ? 1 : 0)) * kTile) * 4);
+        if (!two) load_tile_b(t2b, rs, lane * 16, ((int)L.off_w2 + (2 * g + 1) * kTile) * 4);
     }
     // h1 arrives once per generation step: after each arrival the wave sleeps through most of the measured step period before it
     // polls again (64 helper workgroups x 8 waves polling flat out are terabytes per second of agent-scope loads on the fabric)
@@ -1057,29 +1063,53 @@ __device__ __forceinline__ void helper_main(const GenArgs& a, int b, int g)
             period = (t_arr != 0 && d < (1ull << 20)) ? d : 0;                // no estimate after the first step or a long gap
             t_arr = now;
         }
+        const bool hprof = INSTR && a.prof != nullptr && b == 0 && g == 0 && v == 0 && t < a.prof_steps && lane == 0;
+        unsigned long long* hp = a.prof + (long long)t * 80;
+        if (hprof) hp[52] = __builtin_amdgcn_s_memtime();      // h1 seen
         const float x = __uint_as_float((unsigned)q);
         lds[o_part + i0 * 64 + lane] = dot_readlane_off<0>(ta, x);
         if (has1) lds[o_part + i1 * 64 + lane] = dot_readlane_off<32>(tb, x);
         arrive(o_cnt, lane);
-        if (v < NSJL) {                                                         // owner of output block m = v
+        if (hprof) hp[53] = __builtin_amdgcn_s_memtime();      // own partials stored
+        if (summer) {                                                           // owner of output block mb
             if (!wait_seq(o_cnt, nact * (t + 1), o_abort, 13)) break;
             ACQUIRE_WG();
+            if (hprof) hp[54] = __builtin_amdgcn_s_memtime();  // all partials in LDS
             float r = 0.0f;
-            for (int ch = 0; ch < NCH; ++ch) {
-                const float cp = lds[o_part + (v * NCH + ch) * 64 + lane];
-                r = (ch == 0) ? cp : r + cp;
+            if (NCH == 16) {
+                // all sixteen loads in flight before the first add (the compiler's own schedule waits for every pair of them)
+                float cp[16];
+#pragma unroll
+                for (int ch = 0; ch < 16; ++ch) cp[ch] = lds[o_part + (mb * 16 + ch) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+                r = cp[0];
+#pragma unroll
+                for (int ch = 1; ch < 16; ++ch) r = r + cp[ch];
+            } else {
+                for (int ch = 0; ch < NCH; ++ch) {
+                    const float cp = lds[o_part + (mb * NCH + ch) * 64 + lane];
+                    r = (ch == 0) ? cp : r + cp;
+                }
             }
             if (use_bias) r = r + b1v;
             const float h = r > 0.0f ? r : 0.0f;
+            if (hprof) hp[55] = __builtin_amdgcn_s_memtime();  // h2 slice
             if (CONV2) {
-                const float p0 = dot_readlane_off<0>(t2a, h), p1 = dot_readlane_off<32>(t2b, h);
-                if (lane < 32) {
-                    granule_store(X2 + (2 * g) * 32 + lane, 2u * (unsigned)t + 2u, p0);
-                    granule_store(X2 + (2 * g + 1) * 32 + lane, 2u * (unsigned)t + 2u, p1);
+                const unsigned ep2 = 2u * (unsigned)t + 2u;
+                if (two) {
+                    const float p = (v == 0) ? dot_readlane_off<0>(t2a, h) : dot_readlane_off<32>(t2a, h);
+                    if (lane < 32) granule_store(X2 + (2 * g + v) * 32 + lane, ep2, p);
+                } else {
+                    const float p0 = dot_readlane_off<0>(t2a, h), p1 = dot_readlane_off<32>(t2b, h);
+                    if (lane < 32) {
+                        granule_store(X2 + (2 * g) * 32 + lane, ep2, p0);
+                        if (2 * g + 1 < NCH) granule_store(X2 + (2 * g + 1) * 32 + lane, ep2, p1);
+                    }
                 }
             } else {
-                granule_store(X2 + (v * G + g) * 64 + lane, 2u * (unsigned)t + 2u, h);
+                granule_store(X2 + (mb * G + g) * 64 + lane, 2u * (unsigned)t + 2u, h);
             }
+            if (hprof) hp[56] = __builtin_amdgcn_s_memtime();  // published
         }
     }
     if (lane == 0 && LDSVI(o_abort)) atomicMax(a.status, LDSI(o_abort));
@@ -1095,7 +1125,7 @@ __global__ void __launch_bounds__((1 + kLoaders + D + W) * 64) wn_generate_kerne
     const Layout& L = a.lay;
     if (HELP && (int)blockIdx.x >= a.B * a.G) {      // the second half of the grid: one helper workgroup per (stream, slice)
         const int hb = (int)blockIdx.x - a.B * a.G;
-        helper_main<HELP == 2>(a, hb / a.G, hb % a.G);
+        helper_main<HELP == 2, INSTR>(a, hb / a.G, hb % a.G);
         return;
     }
     const int NL = L.NL, S = L.S, NCH = L.NCH;
