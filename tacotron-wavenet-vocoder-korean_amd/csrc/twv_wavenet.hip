@@ -320,16 +320,33 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
     fetch_conv(c.o_slots, 0);
     fetch_dense(c.o_slots);
 
+    // the first input sample is fetched once, outside the loop: a select between this global load and the LDS read of the later
+    // samples is otherwise merged into ONE flat load through a selected pointer (vector-memory path) on every step
+    const float first_in = (SCALAR && a.forced == nullptr) ? reinterpret_cast<const float*>(a.first_input)[b] : 0.0f;
+    const bool full_causal = SCALAR && L.NCA == 1 && L.ifw == 32;     // one unmasked AC-1 chunk (hparams default)
     for (int t = 0; t < T; ++t) {
         const bool prof = INSTR && a.prof != nullptr && b == 0 && c.g == 0 && t < a.prof_steps;   // INSTR: instrumented build (phase stamps, dumps)
         unsigned long long* pp = a.prof + (long long)t * 80;
+        // what does not depend on the new sample is done BEFORE waiting for it: the causal kernel tile, the queue shift
+        Tile tc0;
+        float sh = 0.0f;
+        if (SCALAR) {
+            if (full_causal) lds_half_tile(tc0, c.o_causal, lane);
+            sh = __shfl_down(hv, 1);
+        }
         if (t > 0 && a.forced == nullptr) { wait_seq(ctl + C_SSEQ, t, ctl + C_ABORT, 3); ACQUIRE_WG(); }   // sample t-1 published
         if (prof && lane == 0) { pp[0] = __builtin_amdgcn_s_memtime(); pp[7] = wall_clock64(); }
-        if (SCALAR) {
-            // model.py:122 causal_queue shift+append; model.py:41-46 causal conv (k = ifw, no bias)
-            const float s_in = a.forced != nullptr ? reinterpret_cast<const float*>(a.forced)[(long long)b * T + t]
-                               : ((t == 0) ? reinterpret_cast<const float*>(a.first_input)[b] : lds[ctl + C_SAMPLE]);
-            const float sh = __shfl_down(hv, 1);
+        if (SCALAR && full_causal) {
+            // model.py:122 causal_queue shift+append; model.py:41-46 causal conv (k = ifw = 32, no bias): one AC-1 chunk
+            const float s_lds = lds[ctl + C_SAMPLE];
+            float s_in = (t == 0) ? first_in : s_lds;
+            if (a.forced != nullptr) s_in = reinterpret_cast<const float*>(a.forced)[(long long)b * T + t];
+            hv = (lane == 31) ? s_in : sh;
+            x = dot_readlane(tc0, hv);
+        } else if (SCALAR) {
+            const float s_lds = lds[ctl + C_SAMPLE];
+            float s_in = (t == 0) ? first_in : s_lds;
+            if (a.forced != nullptr) s_in = reinterpret_cast<const float*>(a.forced)[(long long)b * T + t];
             hv = (lane == L.ifw - 1) ? s_in : sh;
             x = 0.0f;
             for (int ca = 0; ca < L.NCA; ++ca) {
