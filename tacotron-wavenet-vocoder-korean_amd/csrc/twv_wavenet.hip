@@ -889,14 +889,16 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                     a.dbg[((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)NL * 64 + lane] = y;
                 const int nr = L.nr_mix;
                 const float gmb = y - s_lnl;                                 // mixture.py:103 (lanes < nr)
+                // argmax over the nr mixture lanes with v_readlane (uniform values, no LDS crossbar round trips)
                 int k = 0;
-                float best = __shfl(gmb, 0);
+                float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gmb), 0));
                 for (int i = 1; i < nr; ++i) {
-                    const float gi = __shfl(gmb, i);
+                    const float gi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gmb), i));
                     if (gi > best) { best = gi; k = i; }
                 }
-                const float mean = __shfl(y, nr + k);                        // mixture.py:105
-                float ls = __shfl(y, 2 * nr + k);                            // mixture.py:107
+                k = __builtin_amdgcn_readfirstlane(k);
+                const float mean = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), nr + k));       // mixture.py:105
+                float ls = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), 2 * nr + k));            // mixture.py:107
                 const float lsmin = (float)-32.23619130191664;
                 ls = ls > lsmin ? ls : lsmin;
                 const float tq = s_tq;                                       // mixture.py:110-111
