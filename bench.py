@@ -182,8 +182,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "wn_generate_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0,
                          # HBM bytes per launch from rocprofv3 PMC (separate --pmc passes, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
-                         # measured per generated step on this kernel (profiles/r01_rocprofv3_pmc_fetch_write_generate_0.5s_v2.csv)
-                         "traffic": (1.127e6 + 0.226e6) * T if (B == 8 and NL == 30) else None, "algorithmic_bytes_per_launch": bytes_per_step * T,
+                         # measured per generated step on this kernel (profiles/r01_rocprofv3_pmc_fetch_write_generate_0.5s_v3.csv)
+                         "traffic": (1.135e6 + 0.214e6) * T if (B == 8 and NL == 30) else None, "algorithmic_bytes_per_launch": bytes_per_step * T,
                          "kernel_ms": k_ms, "us_per_generation_step": k_ms * 1e3 / T},
         }
         if not args.no_cpu_baseline and world == 1:

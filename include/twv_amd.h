@@ -104,7 +104,9 @@ int twv_wavenet_prime(const twv_wavenet* h, const void* packed, void* state, con
 /* synchronises `stream` and converts a non-zero status word into TWV_E_KERNEL. */
 int twv_wavenet_status(const int32_t* status, void* stream);
 
-/* launch geometry knobs (performance only, results are bit-identical): workers per stream workgroup. */
+/* launch geometry knobs (performance only, results are bit-identical): "groups" = workgroups per stream (0 auto), "workers" =
+ * worker waves per stream workgroup (4 | 3), "helpers" = 1 (default: conv1d_1 and conv1d_2's chunk partials run in one helper
+ * workgroup per stream slice when twice the workgroups are co-resident) | 2 (conv1d_1 only) | 0 (none). */
 int twv_wavenet_set_option(twv_wavenet* h, const char* name, int value);
 
 /* optional in-kernel phase timestamps (tuning aid): device uint64[steps][80]; per step of stream 0's chain wave:

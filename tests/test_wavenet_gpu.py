@@ -149,6 +149,27 @@ def test_generate_c2_shape_short(torch_cuda, oracle, groups):
     assert np.all(np.abs(got) <= 1.0)
 
 
+@pytest.mark.parametrize("helpers,S,groups", [(0, 512, 8), (1, 512, 8), (2, 512, 8), (1, 512, 4), (1, 128, 2), (2, 256, 4), (1, 256, 2)])
+def test_helper_workgroups_do_not_change_results(torch_cuda, oracle, helpers, S, groups):
+    """`helpers`: 0 = every stream workgroup runs conv1d_1 / conv1d_2 itself, 2 = conv1d_1 in helper workgroups, 1 (default) = conv1d_1
+    and conv1d_2's chunk partials in helper workgroups -- a launch-geometry choice, the bits must not move; state carries over"""
+    dil = [1, 2, 4, 8, 16, 32, 64, 128]
+    d, tensors, blob = make_case(oracle, dil, S=S)
+    m = make_model(2, dil, tensors, S=S, groups=groups)
+    m.set_option("helpers", helpers)
+    rng = np.random.RandomState(4)
+    mel = rng.uniform(-4, 4, (2, 2, 80)).astype(np.float32)
+    U_o = oracle.upsample(d, blob, mel); U_g = m.create_upsample(mel)
+    gc = np.array([1, 0], np.int32)
+    seed_in = (2 * rng.rand(2) - 1).astype(np.float32)
+    u = mol_uniforms(2, 600, d.O // 3)
+    want = oracle.generate_mol(d, blob, oracle.State(d, 2), U_o, gc, seed_in, u)
+    a = m.generate(U_g[:, :250].contiguous(), gc, seed_in, u[:, :250]).cpu().numpy()          # two launches: the state carries over
+    b = m.generate(U_g[:, 250:].contiguous(), gc, a[:, -1], u[:, 250:]).cpu().numpy()
+    got = np.concatenate([a, b], axis=1)
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+
+
 def test_generate_past_longest_delay_line(torch_cuda, oracle):
     """long enough that every delay line (d=512) wraps more than twice"""
     dil = [1, 4, 16, 64, 256, 512]
