@@ -130,6 +130,47 @@ __global__ void tr_bias_relu_kernel(float* x, const float* biases, int nb, long 
 }
 __global__ void tr_bias_add_kernel(float* x, const float* bias, int C, long long n) { GRID_STRIDE(i, n) x[i] += bias[i % C]; }
 __global__ void tr_relu_bwd_kernel(float* dx, const float* y, long long n) { GRID_STRIDE(i, n) if (!(y[i] > 0.0f)) dx[i] = 0.0f; }
+// float4 forms of the two relu passes over the (rows, 512) post-processing activations (C % 4 == 0, n % 4 == 0): HBM-bound
+__global__ void tr_bias_relu4_kernel(float4* x, const float4* bias, int C4, long long n4)
+{
+    GRID_STRIDE(i, n4) {
+        float4 v = x[i];
+        if (bias) { const float4 b = bias[i % C4]; v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        v.x = v.x > 0.0f ? v.x : 0.0f; v.y = v.y > 0.0f ? v.y : 0.0f; v.z = v.z > 0.0f ? v.z : 0.0f; v.w = v.w > 0.0f ? v.w : 0.0f;
+        x[i] = v;
+    }
+}
+__global__ void tr_relu_bwd4_kernel(float4* dx, const float4* y, long long n4)
+{
+    GRID_STRIDE(i, n4) {
+        const float4 yy = y[i];
+        if (!(yy.x > 0.0f) || !(yy.y > 0.0f) || !(yy.z > 0.0f) || !(yy.w > 0.0f)) {
+            float4 d = dx[i];
+            if (!(yy.x > 0.0f)) d.x = 0.0f;
+            if (!(yy.y > 0.0f)) d.y = 0.0f;
+            if (!(yy.z > 0.0f)) d.z = 0.0f;
+            if (!(yy.w > 0.0f)) d.w = 0.0f;
+            dx[i] = d;
+        }
+    }
+}
+// out[c] = sum over the nb layers of biases[k * strideb + c], k ascending (the skip biases all land on the same sum, model.py:154)
+__global__ void tr_bias_sum_kernel(const float* biases, int nb, long long strideb, float* out, int C)
+{
+    GRID_STRIDE(c, C) {
+        float s = 0.0f;
+        for (int k = 0; k < nb; ++k) s += biases[(long long)k * strideb + c];
+        out[c] = s;
+    }
+}
+// dst_k[c] = src[c] for k = 1..nb-1 (the skip-bias gradient is the same vector for every layer)
+__global__ void tr_bcast_rows_kernel(float* base, long long strideb, int nb, int C)
+{
+    GRID_STRIDE(i, (long long)(nb - 1) * C) {
+        const int k = 1 + (int)(i / C), c = (int)(i % C);
+        base[(long long)k * strideb + c] = base[c];
+    }
+}
 __global__ void tr_fill_kernel(float* p, float v, long long n) { GRID_STRIDE(i, n) p[i] = v; }
 // column sums, two deterministic stages.  stage 1: block (chunk, col tile, segment) sums its row chunk of segment z
 // (segments = consecutive `rows`-row slabs, e.g. one per batch entry) into part[(z*nchunk + chunk)*C + c].
@@ -1074,9 +1115,16 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         // model.py:94-96,150-165: sum over layers of the skip 1x1 convs == ONE GEMM against the stacked skip kernels, then
         // (+ all skip biases) relu -> 1x1 -> relu -> 1x1
         if ((rc = gemm_rm(bl, false, false, (int)RO, S, ZW, 1.f, ZC, ZW, WS, S, 0.f, SK, S))) break;
-        K1(tr_bias_relu_kernel, RO * S, SK, ub ? LP(0) + h->lo.bs : nullptr, ub ? NL : 0, h->c_lstride, nullptr, S, RO * S);
+        if ((S & 3) == 0) {
+            float* bsum = part;                                   // S floats; `part` is free between the column sums
+            if (ub) K1(tr_bias_sum_kernel, S, LP(0) + h->lo.bs, NL, h->c_lstride, bsum, S);
+            K1(tr_bias_relu4_kernel, RO * S / 4, (float4*)SK, ub ? (const float4*)bsum : nullptr, S / 4, RO * S / 4);
+        } else {
+            K1(tr_bias_relu_kernel, RO * S, SK, ub ? LP(0) + h->lo.bs : nullptr, ub ? NL : 0, h->c_lstride, nullptr, S, RO * S);
+        }
         if ((rc = gemm_rm(bl, false, false, (int)RO, S, S, 1.f, SK, S, P + h->c_w1, S, 0.f, C1, S))) break;
-        K1(tr_bias_relu_kernel, RO * S, C1, nullptr, 0, 0, ub ? P + h->c_b1 : nullptr, S, RO * S);
+        if ((S & 3) == 0 && (h->c_b1 & 3) == 0) K1(tr_bias_relu4_kernel, RO * S / 4, (float4*)C1, ub ? (const float4*)(P + h->c_b1) : nullptr, S / 4, RO * S / 4);
+        else K1(tr_bias_relu_kernel, RO * S, C1, nullptr, 0, 0, ub ? P + h->c_b1 : nullptr, S, RO * S);
         if ((rc = gemm_rm(bl, false, false, (int)RO, O, S, 1.f, C1, S, P + h->c_w2, O, 0.f, Y, O))) break;
         if (ub) K1(tr_bias_add_kernel, RO * O, Y, P + h->c_b2, O, RO * O);
         // model.py:286-290 loss
@@ -1089,17 +1137,19 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         rc |= gemm_rm(bl, true, false, S, O, (int)RO, 1.f, C1, S, dY, O, 0.f, Gd + h->c_w2, O);                 // dW2 = H2^T dY
         if (ub) colsum(dY, RO, O, O, 1, Gd + h->c_b2, O);
         rc |= gemm_rm(bl, false, true, (int)RO, S, O, 1.f, dY, O, P + h->c_w2, O, 0.f, dS, S);                   // dH2
-        K1(tr_relu_bwd_kernel, RO * S, dS, C1, RO * S);
+        if ((S & 3) == 0) K1(tr_relu_bwd4_kernel, RO * S / 4, (float4*)dS, (const float4*)C1, RO * S / 4);
+        else K1(tr_relu_bwd_kernel, RO * S, dS, C1, RO * S);
         rc |= gemm_rm(bl, true, false, S, S, (int)RO, 1.f, SK, S, dS, S, 0.f, Gd + h->c_w1, S);                  // dW1 = H1^T dC1
         if (ub) colsum(dS, RO, S, S, 1, Gd + h->c_b1, S);
         rc |= gemm_rm(bl, false, true, (int)RO, S, S, 1.f, dS, S, P + h->c_w1, S, 0.f, C1, S);                   // dH1 -> C1 buffer
-        K1(tr_relu_bwd_kernel, RO * S, C1, SK, RO * S);                                                           // dSK
+        if ((S & 3) == 0) K1(tr_relu_bwd4_kernel, RO * S / 4, (float4*)C1, (const float4*)SK, RO * S / 4);        // dSK
+        else K1(tr_relu_bwd_kernel, RO * S, C1, SK, RO * S);
         float* dSK = C1;
         // all skip convs at once: dWs (stacked) = ZC^T dSK ; dZC = dSK WS^T ; dbs (identical for every layer) = colsum(dSK)
         rc |= gemm_rm(bl, true, false, ZW, S, (int)RO, 1.f, ZC, ZW, dSK, S, 0.f, GS, S);
         if (ub) {
             colsum(dSK, RO, S, S, 1, LG(0) + h->lo.bs, S);
-            for (int l = 1; l < NL; ++l) HIPCHK(hipMemcpyAsync(LG(l) + h->lo.bs, LG(0) + h->lo.bs, (size_t)S * 4, hipMemcpyDeviceToDevice, st));
+            if (NL > 1) K1(tr_bcast_rows_kernel, (long long)(NL - 1) * S, LG(0) + h->lo.bs, h->c_lstride, NL, S);
         }
         rc |= gemm_rm(bl, false, true, (int)RO, ZW, S, 1.f, dSK, S, WS, S, 0.f, dZC, ZW);
         if (rc) break;
