@@ -938,6 +938,33 @@ static rocblas_status gemm_rm(rocblas_handle h, bool tA, bool tB, int M, int N, 
                          N, M, K, &alpha, B, ldb, A, lda, &beta, C, ldc);
 }
 
+// row-major C[M,N] (ldc) = A^T B over K rows, A stored [K, lda], B stored [K, ldb] (a weight gradient: tall K, small M x N).
+// One rocBLAS call leaves most of the chip idle here (M*N/(256*64) output tiles for 256 CUs) -- the K range is cut into
+// `nsplit` equal slabs computed as ONE strided-batched GEMM into `partials` [nsplit][M][N], and the slabs are added in slab
+// order (deterministic).  K must be a multiple of nsplit.
+__global__ void tr_splitk_reduce_kernel(const float* part, int nsplit, long long mn, int N, float* C, int ldc)
+{
+    GRID_STRIDE(i, mn) {
+        float s = part[i];
+        for (int p = 1; p < nsplit; ++p) s += part[(long long)p * mn + i];
+        C[(i / N) * ldc + (i % N)] = s;
+    }
+}
+static rocblas_status gemm_tn_splitk(rocblas_handle h, hipStream_t st, int M, int N, long long K, const float* A, int lda, const float* B, int ldb,
+                                     float* C, int ldc, int nsplit, float* partials)
+{
+    const float one = 1.0f, zero = 0.0f;
+    if (nsplit <= 1) return gemm_rm(h, true, false, M, N, (int)K, 1.f, A, lda, B, ldb, 0.f, C, ldc);
+    const long long kc = K / nsplit;
+    rocblas_status rs = rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, N, M, (int)kc, &one,
+                                                      B, ldb, kc * ldb, A, lda, kc * lda, &zero, partials, N, (long long)M * N, nsplit);
+    if (rs != rocblas_status_success) return rs;
+    const long long mn = (long long)M * N;
+    const long long nb = (mn + 255) / 256;
+    hipLaunchKernelGGL(tr_splitk_reduce_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, st, partials, nsplit, mn, N, C, ldc);
+    return rocblas_status_success;
+}
+
 extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch, int n_samples, twv_wavenet_trainer** out)
 {
     if (!dims || !out || batch < 1) return twv_fail(TWV_E_INVALID, "bad argument");
@@ -994,6 +1021,7 @@ extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch,
     f += 2 * ((long long)h->NL * (64LL * (64 + h->L + h->G) + 32LL * h->S));   // weight views + their gradients
     f += 512LL * 96 * 64 + 1024LL * 512;        // reduction partials
     f += 256LL * 11 * 1024 + 1024 + 64 + (long long)batch * ((h->Tn + 31) / 32) * 96;   // fused-backward gradient slabs, per-tile column sums
+    f += 16LL * ((long long)h->NL * 32 > h->S ? (long long)h->NL * 32 : h->S) * h->S;   // split-K partials of the wide weight gradients
     f += 64 * 64;                               // rounding slack
     h->ws_floats = f;
     *out = h;
@@ -1056,6 +1084,9 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
     float* part = take(512LL * 96 * 64 + 1024LL * 512);
     float* slabs = take(256LL * GQ_N * 1024);
     float* zpage = take(1024);
+    float* kpart = take(16LL * (ZW > S ? ZW : S) * S);       // split-K partials (dW1, dW2, stacked dWs)
+    int nsplit = 1;
+    for (int c = 2; c <= 16 && c <= B; ++c) if (B % c == 0) nsplit = c;   // slabs of whole batch entries: RO = B * ow rows
     HIPCHK(hipMemsetAsync(zpage, 0, 4096, st));
     HIPCHK(hipFuncSetAttribute((const void*)tr_layer_bwd1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BS_FLOATS * 4));
     float* tsum = take((long long)B * ((Tn + 31) / 32) * 96);
@@ -1134,19 +1165,19 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         else hipLaunchKernelGGL(tr_softmax_ce_kernel, dim3(tg(RO * 64)), dim3(256), 0, st, Y, qin, B, T, ow, rf, O, 1.0f / (float)RO, row_loss, dY);
         colsum(row_loss, RO, 1, 1, 1, loss, 1);
         // ================= backward =================
-        rc |= gemm_rm(bl, true, false, S, O, (int)RO, 1.f, C1, S, dY, O, 0.f, Gd + h->c_w2, O);                 // dW2 = H2^T dY
+        rc |= gemm_tn_splitk(bl, st, S, O, RO, C1, S, dY, O, Gd + h->c_w2, O, nsplit, kpart);                    // dW2 = H2^T dY
         if (ub) colsum(dY, RO, O, O, 1, Gd + h->c_b2, O);
         rc |= gemm_rm(bl, false, true, (int)RO, S, O, 1.f, dY, O, P + h->c_w2, O, 0.f, dS, S);                   // dH2
         if ((S & 3) == 0) K1(tr_relu_bwd4_kernel, RO * S / 4, (float4*)dS, (const float4*)C1, RO * S / 4);
         else K1(tr_relu_bwd_kernel, RO * S, dS, C1, RO * S);
-        rc |= gemm_rm(bl, true, false, S, S, (int)RO, 1.f, SK, S, dS, S, 0.f, Gd + h->c_w1, S);                  // dW1 = H1^T dC1
+        rc |= gemm_tn_splitk(bl, st, S, S, RO, SK, S, dS, S, Gd + h->c_w1, S, nsplit, kpart);                     // dW1 = H1^T dC1
         if (ub) colsum(dS, RO, S, S, 1, Gd + h->c_b1, S);
         rc |= gemm_rm(bl, false, true, (int)RO, S, S, 1.f, dS, S, P + h->c_w1, S, 0.f, C1, S);                   // dH1 -> C1 buffer
         if ((S & 3) == 0) K1(tr_relu_bwd4_kernel, RO * S / 4, (float4*)C1, (const float4*)SK, RO * S / 4);        // dSK
         else K1(tr_relu_bwd_kernel, RO * S, C1, SK, RO * S);
         float* dSK = C1;
         // all skip convs at once: dWs (stacked) = ZC^T dSK ; dZC = dSK WS^T ; dbs (identical for every layer) = colsum(dSK)
-        rc |= gemm_rm(bl, true, false, ZW, S, (int)RO, 1.f, ZC, ZW, dSK, S, 0.f, GS, S);
+        rc |= gemm_tn_splitk(bl, st, ZW, S, RO, ZC, ZW, dSK, S, GS, S, nsplit, kpart);
         if (ub) {
             colsum(dSK, RO, S, S, 1, LG(0) + h->lo.bs, S);
             if (NL > 1) K1(tr_bcast_rows_kernel, (long long)(NL - 1) * S, LG(0) + h->lo.bs, h->c_lstride, NL, S);
