@@ -44,8 +44,45 @@ def codec_and_math():
                         sigmoid=O.elementwise("sigmoid", x), exp=O.elementwise("exp", x), xp=xp, log=O.elementwise("log", xp))
 
 
+def wavenet_mulaw_small():
+    """one-hot mu-law model (scalar_input False, Q = 256): float64 softmax, temperature rescale, legacy np.random.choice"""
+    dil = [1, 2, 4, 8, 1, 2, 4, 8]
+    B, T = 2, 48
+    d, tensors, blob = make_case(O, dil, scalar_input=False, S=128, Q=256, scale=0.3, seed=31)
+    rng = np.random.RandomState(32)
+    U = rng.uniform(-4, 4, (B, T, 80)).astype(np.float32)
+    gc = np.array([0, 1], np.int32)
+    seed_in = rng.randint(256, size=B).astype(np.int32)
+    u = np.random.RandomState(33).random_sample((B, T))
+    out = {}
+    for temp in (1.0, 0.8):
+        out[temp] = O.generate_mulaw(d, blob, O.State(d, B), U, gc, seed_in, u, temp)
+    np.savez_compressed(os.path.join(HERE, "restatement_wavenet_mulaw_small.npz"), dilations=np.array(dil), S=128, Q=256, scale=0.3,
+                        weight_seed=31, upsampled=U, gc_ids=gc, first_input=seed_in, uniforms=u, samples_t10=out[1.0], samples_t08=out[0.8])
+
+
+def tacotron_small():
+    """Tacotron inference on a reduced configuration (banks 4 / 3, 6 decoder steps, 129 linear bins), ragged input lengths"""
+    kw = dict(enc_bank=4, post_bank=3, max_iters=6, num_freq=129)
+    d = O.taco_dims(**kw)
+    tensors = O.taco_random_tensors(d, seed=41)
+    blob = O.taco_blob(d, tensors)
+    rng = np.random.RandomState(42)
+    N, T, lengths = 3, 17, [17, 11, 6]
+    tok = rng.randint(2, 80, (N, T)).astype(np.int32)
+    for n, ln in enumerate(lengths):
+        tok[n, ln - 1] = 1
+        tok[n, ln:] = 0
+    spk = np.array([0, 1, 0], np.int32)
+    mel, lin, al = O.taco_infer(d, blob, tok, np.asarray(lengths, np.int32), spk)
+    np.savez_compressed(os.path.join(HERE, "restatement_tacotron_small.npz"), weight_seed=41, tokens=tok, lengths=np.asarray(lengths, np.int32),
+                        speaker_ids=spk, mel=mel, linear=lin, alignments=al, **{"dims_" + k: v for k, v in kw.items()})
+
+
 if __name__ == "__main__":
     O.build()
     wavenet_mol_small()
     codec_and_math()
+    wavenet_mulaw_small()
+    tacotron_small()
     print("written", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))

@@ -197,6 +197,24 @@ def test_restatement_fixtures(oracle):
     assert first_mismatch(out, g["samples"]) is None
 
 
+def test_restatement_fixtures_mulaw_and_tacotron(oracle):
+    """drift pins for the one-hot mu-law generation path and the Tacotron restatement (again: NOT reference goldens)"""
+    g = np.load(os.path.join(GOLD, "restatement_wavenet_mulaw_small.npz"))
+    dil = [int(v) for v in g["dilations"]]
+    d, tensors, blob = make_case(oracle, dil, scalar_input=False, S=int(g["S"]), Q=int(g["Q"]), scale=float(g["scale"]), seed=int(g["weight_seed"]))
+    for temp, key in ((1.0, "samples_t10"), (0.8, "samples_t08")):
+        out = oracle.generate_mulaw(d, blob, oracle.State(d, 2), g["upsampled"], g["gc_ids"], g["first_input"], g["uniforms"], temp)
+        assert np.array_equal(out, g[key]), key
+    assert not np.array_equal(g["samples_t10"], g["samples_t08"])                # the temperature does something
+    t = np.load(os.path.join(GOLD, "restatement_tacotron_small.npz"))
+    d = oracle.taco_dims(enc_bank=int(t["dims_enc_bank"]), post_bank=int(t["dims_post_bank"]), max_iters=int(t["dims_max_iters"]),
+                         num_freq=int(t["dims_num_freq"]))
+    blob = oracle.taco_blob(d, oracle.taco_random_tensors(d, seed=int(t["weight_seed"])))
+    mel, lin, al = oracle.taco_infer(d, blob, t["tokens"], t["lengths"], t["speaker_ids"])
+    assert first_mismatch(mel, t["mel"]) is None and first_mismatch(lin, t["linear"]) is None and first_mismatch(al, t["alignments"]) is None
+    assert t["mel"].shape == (3, 30, 80) and t["linear"].shape == (3, 30, 129) and t["alignments"].shape == (3, 17, 6)
+
+
 # ---------------------------------------------------------------- host side of the product
 def test_blob_layout_agrees_with_oracle(oracle):
     """the product's canonical blob (weights.py + the C-ABI's count) and the oracle's independent one"""

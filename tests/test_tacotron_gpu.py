@@ -1,6 +1,8 @@
 """-m gpu: Tacotron text -> mel inference, HIP path (through the C-ABI) vs the CPU oracle, bit for bit."""
 import copy
 
+import os
+
 import numpy as np
 import pytest
 
@@ -53,6 +55,21 @@ def test_tacotron_small(torch_cuda, oracle):
     assert first_mismatch(mel.cpu().numpy(), mel_o) is None, ("mel", first_mismatch(mel.cpu().numpy(), mel_o))
     assert first_mismatch(lin.cpu().numpy(), lin_o) is None, ("linear", first_mismatch(lin.cpu().numpy(), lin_o))
     assert np.all(al.cpu().numpy()[1, 12:] == 0)                       # nothing attends past input_lengths
+
+
+def test_committed_restatement_fixture_tacotron(torch_cuda, oracle):
+    """HIP Tacotron against the committed fixture's mel / linear / alignments (the oracle is only asked for the seeded weights)"""
+    t = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "restatement_tacotron_small.npz"))
+    from twvk_amd.tacotron import Tacotron
+    hp = _hp(max_iters=int(t["dims_max_iters"]), enc_bank_size=int(t["dims_enc_bank"]), post_bank_size=int(t["dims_post_bank"]),
+             num_freq=int(t["dims_num_freq"]))
+    d = oracle.taco_dims(enc_bank=hp.enc_bank_size, post_bank=hp.post_bank_size, max_iters=hp.max_iters, num_freq=hp.num_freq)
+    m = Tacotron(hp, num_speakers=2)
+    m.load_weights(oracle.taco_random_tensors(d, seed=int(t["weight_seed"])))
+    mel, lin, al = m.infer(t["tokens"], t["lengths"], t["speaker_ids"])
+    assert first_mismatch(mel.cpu().numpy(), t["mel"]) is None
+    assert first_mismatch(lin.cpu().numpy(), t["linear"]) is None
+    assert first_mismatch(al.cpu().numpy(), t["alignments"]) is None
 
 
 def test_tacotron_default_dims(torch_cuda, oracle):

@@ -229,6 +229,20 @@ def test_committed_restatement_fixture(torch_cuda):
     assert first_mismatch(out, g["samples"]) is None
 
 
+def test_committed_restatement_fixture_mulaw(torch_cuda):
+    """one-hot mu-law model against the committed fixture (no oracle library at run time), both temperatures"""
+    import os
+    from twvk_amd import weights as W
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "restatement_wavenet_mulaw_small.npz"))
+    dil = [int(v) for v in g["dilations"]]
+    specs = W.tensor_specs(len(dil), S=int(g["S"]), Q=int(g["Q"]), scalar_input=False)
+    tensors = W.random_tensors(specs, seed=int(g["weight_seed"]), scale=float(g["scale"]))
+    for temp, key in ((1.0, "samples_t10"), (0.8, "samples_t08")):
+        m = make_model(2, dil, tensors, scalar_input=False, S=int(g["S"]), Q=int(g["Q"]))
+        out = m.generate(g["upsampled"], g["gc_ids"], g["first_input"], g["uniforms"], temperature=temp).cpu().numpy()
+        assert np.array_equal(out, g[key]), (key, first_mismatch(out.astype(np.float32), g[key].astype(np.float32)))
+
+
 def _run_onehot(oracle, dil, B, T, S=512, Q=256, temperature=1.0, groups=None, scale=0.05, L=80, G=32, debug_steps=0):
     d, tensors, blob = make_case(oracle, dil, scalar_input=False, S=S, Q=Q, scale=scale, L=L, G=G)
     m = make_model(B, dil, tensors, scalar_input=False, S=S, Q=Q, L=L, G=G, groups=groups)
