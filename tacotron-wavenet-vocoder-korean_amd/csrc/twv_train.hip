@@ -192,6 +192,37 @@ __global__ __launch_bounds__(256) void tr_colsum_partial_kernel(const float* x, 
     if (threadIdx.x < 64 && c < C)
         part[((long long)blockIdx.z * nchunk + blockIdx.x) * C + c] = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
 }
+// relu backward fused with stage 1 of the bias gradient: dx[r][c] = y[r][c] > 0 ? dx[r][c] : 0 is written back and summed per column
+// in the same pass (same blocking and partial layout as tr_colsum_partial_kernel, one segment); saves one read of the (rows, C) array
+__global__ __launch_bounds__(256) void tr_relu_bwd_colsum_kernel(float* dx, const float* y, long long rows, int C, int nchunk, float* part)
+{
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    const long long per = (rows + nchunk - 1) / nchunk;
+    const long long r0 = (long long)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (c < C) {
+        long long r = r0 + grp;
+        for (; r + 4 < r1; r += 8) {
+            const long long i0 = r * C + c, i1 = (r + 4) * C + c;
+            float d0 = dx[i0], d1 = dx[i1];
+            const float y0 = y[i0], y1 = y[i1];
+            if (!(y0 > 0.0f)) { d0 = 0.0f; dx[i0] = 0.0f; }
+            if (!(y1 > 0.0f)) { d1 = 0.0f; dx[i1] = 0.0f; }
+            s0 += d0; s1 += d1;
+        }
+        if (r < r1) {
+            const long long i0 = r * C + c;
+            float d0 = dx[i0];
+            if (!(y[i0] > 0.0f)) { d0 = 0.0f; dx[i0] = 0.0f; }
+            s0 += d0;
+        }
+    }
+    __shared__ float sh[256];
+    sh[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < C)
+        part[(long long)blockIdx.x * C + c] = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+}
 // stage 2: out[z*ldo + c] = sum over chunks (fixed order: 4 interleaved partial sums, then pairwise); block = 64 outputs x 4 groups
 __global__ __launch_bounds__(256) void tr_colsum_final_kernel(const float* part, int nchunk, int C, int nseg, float* out, int ldo)
 {
@@ -1100,12 +1131,20 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         hipLaunchKernelGGL(tr_colsum_partial_kernel, dim3(nchunk, (C + 63) / 64, nseg), dim3(256), 0, st, x, rows, C, ldx, nchunk, part);
         hipLaunchKernelGGL(tr_colsum_final_kernel, dim3((nseg * C + 63) / 64), dim3(256), 0, st, part, nchunk, C, nseg, out, ldo);
     };
+    // dx <- relu'(y) * dx over (rows, C) and, with biases, out[c] = column sums of the result
+    auto relu_bwd_colsum = [&](float* dx, const float* y, long long rows, int C, float* out) {
+        int nchunk = (int)(rows / 256); nchunk = nchunk < 1 ? 1 : (nchunk > 256 ? 256 : nchunk);
+        hipLaunchKernelGGL(tr_relu_bwd_colsum_kernel, dim3(nchunk, (C + 63) / 64, 1), dim3(256), 0, st, dx, y, rows, C, nchunk, part);
+        hipLaunchKernelGGL(tr_colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, part, nchunk, C, 1, out, C);
+    };
     // C[M x N](ldc) = A^T B over K rows (tall-skinny weight gradient); optional second output for columns [N, 2N) (filter|gate split)
     auto wgrad = [&](const float* A, int lda, const float* Bm, int ldb, long long K, int M, int N, float* C, int ldc) {
+        const int mb = (M + 31) / 32, nb = (N + 31) / 32;
+        const long long cap = (512LL * 96 * 64 + 1024LL * 512) / ((long long)mb * nb * 1024);     // `part` holds chunks x (mb*32) x (nb*32)
         int chunks = (int)(K / 1024); chunks = chunks < 1 ? 1 : (chunks > 256 ? 256 : chunks);
+        if (chunks > cap) chunks = (int)cap;
         long long rpc = (K + chunks - 1) / chunks; rpc = (rpc + 7) / 8 * 8;
         chunks = (int)((K + rpc - 1) / rpc);
-        const int mb = (M + 31) / 32, nb = (N + 31) / 32;
         hipLaunchKernelGGL(tr_tn_partial_kernel, dim3(chunks, mb, nb), dim3(256), 0, st, A, lda, Bm, ldb, K, M, N, rpc, part);
         hipLaunchKernelGGL(tr_tn_reduce_kernel, dim3((M * N + 63) / 64), dim3(256), 0, st, part, chunks, mb * 32, nb * 32, M, N, C, ldc);
     };
@@ -1165,21 +1204,21 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         else hipLaunchKernelGGL(tr_softmax_ce_kernel, dim3(tg(RO * 64)), dim3(256), 0, st, Y, qin, B, T, ow, rf, O, 1.0f / (float)RO, row_loss, dY);
         colsum(row_loss, RO, 1, 1, 1, loss, 1);
         // ================= backward =================
-        rc |= gemm_tn_splitk(bl, st, S, O, RO, C1, S, dY, O, Gd + h->c_w2, O, nsplit, kpart);                    // dW2 = H2^T dY
+        wgrad(C1, S, dY, O, RO, S, O, Gd + h->c_w2, O);                                                           // dW2 = H2^T dY (512 x 30: the tall-skinny MFMA kernel)
         if (ub) colsum(dY, RO, O, O, 1, Gd + h->c_b2, O);
         rc |= gemm_rm(bl, false, true, (int)RO, S, O, 1.f, dY, O, P + h->c_w2, O, 0.f, dS, S);                   // dH2
-        if ((S & 3) == 0) K1(tr_relu_bwd4_kernel, RO * S / 4, (float4*)dS, (const float4*)C1, RO * S / 4);
+        if (ub) relu_bwd_colsum(dS, C1, RO, S, Gd + h->c_b1);                                                    // dC1, db1
+        else if ((S & 3) == 0) K1(tr_relu_bwd4_kernel, RO * S / 4, (float4*)dS, (const float4*)C1, RO * S / 4);
         else K1(tr_relu_bwd_kernel, RO * S, dS, C1, RO * S);
         rc |= gemm_tn_splitk(bl, st, S, S, RO, SK, S, dS, S, Gd + h->c_w1, S, nsplit, kpart);                     // dW1 = H1^T dC1
-        if (ub) colsum(dS, RO, S, S, 1, Gd + h->c_b1, S);
         rc |= gemm_rm(bl, false, true, (int)RO, S, S, 1.f, dS, S, P + h->c_w1, S, 0.f, C1, S);                   // dH1 -> C1 buffer
-        if ((S & 3) == 0) K1(tr_relu_bwd4_kernel, RO * S / 4, (float4*)C1, (const float4*)SK, RO * S / 4);        // dSK
+        if (ub) relu_bwd_colsum(C1, SK, RO, S, LG(0) + h->lo.bs);                                                 // dSK, dbs (layer 0's slot)
+        else if ((S & 3) == 0) K1(tr_relu_bwd4_kernel, RO * S / 4, (float4*)C1, (const float4*)SK, RO * S / 4);
         else K1(tr_relu_bwd_kernel, RO * S, C1, SK, RO * S);
         float* dSK = C1;
         // all skip convs at once: dWs (stacked) = ZC^T dSK ; dZC = dSK WS^T ; dbs (identical for every layer) = colsum(dSK)
         rc |= gemm_tn_splitk(bl, st, ZW, S, RO, ZC, ZW, dSK, S, GS, S, nsplit, kpart);
         if (ub) {
-            colsum(dSK, RO, S, S, 1, LG(0) + h->lo.bs, S);
             if (NL > 1) K1(tr_bcast_rows_kernel, (long long)(NL - 1) * S, LG(0) + h->lo.bs, h->c_lstride, NL, S);
         }
         rc |= gemm_rm(bl, false, true, (int)RO, ZW, S, 1.f, dSK, S, WS, S, 0.f, dZC, ZW);
