@@ -285,6 +285,41 @@ __global__ __launch_bounds__(256) void tr_tn_reduce_kernel(const float* part, in
     __syncthreads();
     if (threadIdx.x < 64 && i < M * N) C[(long long)m * ldc + n] = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
 }
+// Skinny output projection on the f32 matrix cores: Y[r][n] = sum_k X[r][k] * W[k][n] (+ bias[n]), N <= 32, K % 16 == 0 (model.py:161-165
+// conv1d_2, 512 -> 30).  rocBLAS spends 0.6 ms on this 9-GFLOP product; it is a single pass over X.  Wave = 32 rows: every lane
+// reads 32 contiguous bytes of its row per 16-wide k step (lanes l and l+32 the two halves of one 64-byte piece) and feeds eight
+// v_mfma_f32_32x32x2_f32 with the k pairs (t, 8 + t); W sits in LDS as [k][32] (zero-padded columns).
+__global__ __launch_bounds__(256) void tr_skinny_nn_kernel(const float* X, int ldx, const float* W, int ldw, const float* bias, long long rows, int K, int N,
+                                                           float* Y, int ldy)
+{
+    extern __shared__ float wl[];                       // [K][32]
+    for (int i = threadIdx.x; i < K * 32; i += 256) { const int k = i >> 5, n = i & 31; wl[i] = n < N ? W[(long long)k * ldw + n] : 0.0f; }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+    const long long ntile = (rows + 31) / 32;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
+        const long long r = tile * 32 + col;            // A operand row of this lane
+        const bool rok = r < rows;
+        const float* xp = X + (rok ? r : 0) * ldx + half * 8;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+            if (rok) { a0 = *reinterpret_cast<const float4*>(xp + k0); a1 = *reinterpret_cast<const float4*>(xp + k0 + 4); }
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int t = 0; t < 8; ++t)                  // lanes < 32 carry k = k0 + t, lanes >= 32 carry k = k0 + 8 + t
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], wl[(k0 + half * 8 + t) * 32 + col], acc, 0, 0, 0);
+        }
+        const float bv = (bias != nullptr && col < N) ? bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long long rr = tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+            if (rr < rows && col < N) Y[rr * ldy + col] = acc[i] + bv;
+        }
+    }
+}
 // training-time weight views: per layer [tap0 (32x64) = wf[0]|wg[0]] [tap1 (32x64)] [lc (L x 64) = lcf|lcg] [gc (G x 64)] and the
 // stacked skip kernel (NL*32 x S).  dir 0: canonical -> views, dir 1: views (gradients) -> canonical.
 __global__ void tr_views_kernel(float* canon, float* views, float* wsall, int NL, long long c_layer0, long long lstride, long long o_wf, long long o_wg,
@@ -1195,8 +1230,12 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         if ((rc = gemm_rm(bl, false, false, (int)RO, S, S, 1.f, SK, S, P + h->c_w1, S, 0.f, C1, S))) break;
         if ((S & 3) == 0 && (h->c_b1 & 3) == 0) K1(tr_bias_relu4_kernel, RO * S / 4, (float4*)C1, ub ? (const float4*)(P + h->c_b1) : nullptr, S / 4, RO * S / 4);
         else K1(tr_bias_relu_kernel, RO * S, C1, nullptr, 0, 0, ub ? P + h->c_b1 : nullptr, S, RO * S);
-        if ((rc = gemm_rm(bl, false, false, (int)RO, O, S, 1.f, C1, S, P + h->c_w2, O, 0.f, Y, O))) break;
-        if (ub) K1(tr_bias_add_kernel, RO * O, Y, P + h->c_b2, O, RO * O);
+        if (O <= 32 && (S & 15) == 0 && S * 32 * 4 <= 64 * 1024) {
+            hipLaunchKernelGGL(tr_skinny_nn_kernel, dim3(1024), dim3(256), (size_t)S * 32 * 4, st, C1, S, P + h->c_w2, O, ub ? P + h->c_b2 : nullptr, RO, S, O, Y, O);
+        } else {
+            if ((rc = gemm_rm(bl, false, false, (int)RO, O, S, 1.f, C1, S, P + h->c_w2, O, 0.f, Y, O))) break;
+            if (ub) K1(tr_bias_add_kernel, RO * O, Y, P + h->c_b2, O, RO * O);
+        }
         // model.py:286-290 loss
         // per-row terms, then the same two-stage column sum as the bias gradients: the loss is bit-reproducible run to run
         float* row_loss = dS;                                       // (RO) scratch: dS is not written before the backward pass
