@@ -780,18 +780,44 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
     }
 }
 // every gradient tile q of a layer: out_q[(m, n)] = sum over slabs (fixed order); rows >= mrows are dropped (lc block 2 has 16 rows)
-struct SlabDst { float* out[GQ_N]; int ldo[GQ_N]; int mrows[GQ_N]; };
-__global__ __launch_bounds__(256) void tr_slab_reduce_kernel(const float* slabs, int nslab, SlabDst dst)
+// ONE launch for all layers (blockIdx.z = layer): the layers' slabs are kept until the end of the backward pass, layer l's outputs sit
+// lstride[q] floats behind layer 0's (the per-layer reductions were ~300 five-microsecond launches per step, 8 % of it)
+struct SlabDst { float* out[GQ_N]; int ldo[GQ_N]; int mrows[GQ_N]; long long lstride[GQ_N]; };
+__global__ __launch_bounds__(256) void tr_slab_reduce_kernel(const float* slabs, long long slab_lstride, int nslab, SlabDst dst)
 {
-    const int q = blockIdx.y;
+    const int q = blockIdx.y, l = blockIdx.z;
     const int i = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    const float* sl = slabs + (long long)l * slab_lstride;
     float s = 0.0f;
-    for (int k = grp; k < nslab; k += 4) s += slabs[((long long)k * GQ_N + q) * 1024 + i];
+    for (int k = grp; k < nslab; k += 4) s += sl[((long long)k * GQ_N + q) * 1024 + i];
     __shared__ float sh[256];
     sh[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x < 64 && (i >> 5) < dst.mrows[q])
-        dst.out[q][(long long)(i >> 5) * dst.ldo[q] + (i & 31)] = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+        dst.out[q][(long long)l * dst.lstride[q] + (long long)(i >> 5) * dst.ldo[q] + (i & 31)] =
+            (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+}
+// conv biases of every layer from its 64 summed gate pre-activation gradients: bf[l] = s[l][0:32], bg[l] = s[l][32:64]
+__global__ void tr_split_bias_kernel(const float* s64, float* base, long long lstride, long long o_bf, long long o_bg, int NL)
+{
+    GRID_STRIDE(i, (long long)NL * 64) {
+        const int l = (int)(i >> 6), c = (int)(i & 63);
+        base[(long long)l * lstride + (c < 32 ? o_bf + c : o_bg + c - 32)] = s64[i];
+    }
+}
+// demb[b][g] += sum over layers l (ascending), j (ascending) of dGCP[l][b][j] * Wgc_l[g][j]   (Wgc_l = views + l*vstride, row g of (G x 64))
+__global__ void tr_demb_kernel(const float* dgcp, const float* wgc0, long long vstride, float* demb, int NL, int B, int G)
+{
+    GRID_STRIDE(i, (long long)B * G) {
+        const int b = (int)(i / G), g = (int)(i % G);
+        float s = 0.0f;
+        for (int l = 0; l < NL; ++l) {
+            const float* dg = dgcp + ((long long)l * B + b) * 64;
+            const float* w = wgc0 + (long long)l * vstride + (long long)g * 64;
+            for (int j = 0; j < 64; ++j) s += dg[j] * w[j];
+        }
+        demb[i] += s;
+    }
 }
 
 // Two waves per SIMD as in the forward kernel: the transposed weights (B operands) live in LDS, [step][lane][8] with
@@ -1086,7 +1112,7 @@ extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch,
     f += (long long)batch * 64 * (h->NL + 2) + (long long)batch * h->G * 2;
     f += 2 * ((long long)h->NL * (64LL * (64 + h->L + h->G) + 32LL * h->S));   // weight views + their gradients
     f += 512LL * 96 * 64 + 1024LL * 512;        // reduction partials
-    f += 256LL * 11 * 1024 + 1024 + 64 + (long long)batch * ((h->Tn + 31) / 32) * 96;   // fused-backward gradient slabs, per-tile column sums
+    f += (256LL * 11 * 1024 + 64 + (long long)batch * ((h->Tn + 31) / 32) * 96 + 64 + (long long)batch * 64 + 64 + 64) * h->NL + 1024 + 64;   // per layer: gradient slabs, per-tile column sums, dGCP
     f += 16LL * ((long long)h->NL * 32 > h->S ? (long long)h->NL * 32 : h->S) * h->S;   // split-K partials of the wide weight gradients
     f += 64 * 64;                               // rounding slack
     h->ws_floats = f;
@@ -1148,14 +1174,18 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
     float* WV = take(vstride * NL); float* WS = take((long long)ZW * S);       // weight views
     float* GV = take(vstride * NL); float* GS = take((long long)ZW * S);       // gradient views
     float* part = take(512LL * 96 * 64 + 1024LL * 512);
-    float* slabs = take(256LL * GQ_N * 1024);
+    const long long slab_ls = 256LL * GQ_N * 1024;
+    float* slabs = take(slab_ls * NL);                       // every layer's gradient slabs: reduced in one launch after the layer loop
     float* zpage = take(1024);
     float* kpart = take(16LL * (ZW > S ? ZW : S) * S);       // split-K partials (dW1, dW2, stacked dWs)
     int nsplit = 1;
     for (int c = 2; c <= 16 && c <= B; ++c) if (B % c == 0) nsplit = c;   // slabs of whole batch entries: RO = B * ow rows
     HIPCHK(hipMemsetAsync(zpage, 0, 4096, st));
     HIPCHK(hipFuncSetAttribute((const void*)tr_layer_bwd1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BS_FLOATS * 4));
-    float* tsum = take((long long)B * ((Tn + 31) / 32) * 96);
+    const long long tsum_ls = (long long)B * ((Tn + 31) / 32) * 96;     // layers back to back: the column sums below treat (layer, batch entry) as segments
+    float* tsum = take(tsum_ls * NL);
+    float* dGCPall = take((long long)B * 64 * NL);
+    float* bsum64 = take(64LL * NL);
     int rc = TWV_OK;
 #define K1(kern, n, ...) hipLaunchKernelGGL(kern, dim3(tg(n)), dim3(256), 0, st, __VA_ARGS__)
 #define LP(l) (P + h->c_layer0 + (long long)(l) * h->c_lstride)
@@ -1275,7 +1305,7 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             LayerBwdArgs ba;
             ba.dXn = dXn; ba.dZC = dZC + l * 32; ba.TH = TH[l]; ba.SG = SG[l]; ba.X = X[l]; ba.U = U;
             ba.W0 = Wv; ba.W1 = Wv + 32 * 64; ba.Wlc = Wv + 64 * 64; ba.Wd = Lp + h->lo.wd;
-            ba.dPRE = PRE; ba.slabs = slabs; ba.tsum = tsum; ba.dX = dXc; ba.dU = dUa;
+            ba.dPRE = PRE; ba.slabs = slabs + l * slab_ls; ba.tsum = tsum + l * tsum_ls; ba.dX = dXc; ba.dU = dUa;
             ba.B = B; ba.T = T; ba.Tn = Tn; ba.d = dl; ba.o = o; ba.ow = ow; ba.ldz = ZW; ba.tpb = (Tn + 31) / 32;
             const int ntiles = B * ba.tpb;
             int nwg = (ntiles + 3) / 4; nwg = nwg > 256 ? 256 : nwg;
@@ -1283,29 +1313,37 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             ba.zeros = zpage;
             hipLaunchKernelGGL(tr_layer_bwd1_kernel, dim3(nwg), dim3(256), 4 * BS_FLOATS * 4, st, ba);
             hipLaunchKernelGGL(tr_layer_bwd2_kernel, dim3(nwg2), dim3(512), 0, st, ba);
-            // gradient tiles -> views / canonical slots
-            {
-                SlabDst sd;
-                auto put = [&](int q, int mrows, float* out, int ldo) { sd.out[q] = out; sd.ldo[q] = ldo; sd.mrows[q] = mrows; };
-                put(GQ_W0F, 32, Gv, 64); put(GQ_W0G, 32, Gv + 32, 64);
-                put(GQ_W1F, 32, Gv + 32 * 64, 64); put(GQ_W1G, 32, Gv + 32 * 64 + 32, 64);
-                put(GQ_LCF0, 32, Gv + 64 * 64, 64); put(GQ_LCG0, 32, Gv + 64 * 64 + 32, 64);
-                put(GQ_LCF1, 32, Gv + 96 * 64, 64); put(GQ_LCG1, 32, Gv + 96 * 64 + 32, 64);
-                put(GQ_LCF2, L - 64, Gv + 128 * 64, 64); put(GQ_LCG2, L - 64, Gv + 128 * 64 + 32, 64);
-                put(GQ_WD, 32, Lg + h->lo.wd, 32);
-                hipLaunchKernelGGL(tr_slab_reduce_kernel, dim3(16, GQ_N), dim3(256), 0, st, slabs, nwg, sd);
-            }
-            // gc: dGCP[b] = sum_t dPRE[b,t] (from the per-tile sums) ; conv biases = sum_b dGCP[b] ; dWgc = emb^T dGCP ; demb += dGCP Wgc^T
-            colsum(tsum, ba.tpb, 64, 96, B, dGCP, 64);
-            if (ub) {
-                colsum(tsum + 64, ntiles, 32, 96, 1, Lg + h->lo.bd, 32);
-                colsum(dGCP, B, 64, 64, 1, part + 1024LL * 512 + 4096, 64);     // 64 sums parked behind the partials
-                HIPCHK(hipMemcpyAsync(Lg + h->lo.bf, part + 1024LL * 512 + 4096, 32 * 4, hipMemcpyDeviceToDevice, st));
-                HIPCHK(hipMemcpyAsync(Lg + h->lo.bg, part + 1024LL * 512 + 4096 + 32, 32 * 4, hipMemcpyDeviceToDevice, st));
-            }
-            rc |= gemm_rm(bl, true, false, G, 64, B, 1.f, emb, G, dGCP, 64, 0.f, Gv + (64 + L) * 64, 64);
-            rc |= gemm_rm(bl, false, true, B, G, 64, 1.f, dGCP, 64, Wv + (64 + L) * 64, 64, 1.f, demb, G);
             float* tsw = dXn; dXn = dXc; dXc = tsw;
+        }
+        if (rc) break;
+        // ---- all layers at once: gradient tiles -> views / canonical slots; gc and bias column sums; dWgc; demb
+        {
+            const int tpb = (Tn + 31) / 32, ntiles = B * tpb;
+            int nwg = (ntiles + 3) / 4; nwg = nwg > 256 ? 256 : nwg;
+            SlabDst sd;
+            auto put = [&](int q, int mrows, float* out, int ldo, long long ls) { sd.out[q] = out; sd.ldo[q] = ldo; sd.mrows[q] = mrows; sd.lstride[q] = ls; };
+            float* Gv = GV;
+            put(GQ_W0F, 32, Gv, 64, vstride); put(GQ_W0G, 32, Gv + 32, 64, vstride);
+            put(GQ_W1F, 32, Gv + 32 * 64, 64, vstride); put(GQ_W1G, 32, Gv + 32 * 64 + 32, 64, vstride);
+            put(GQ_LCF0, 32, Gv + 64 * 64, 64, vstride); put(GQ_LCG0, 32, Gv + 64 * 64 + 32, 64, vstride);
+            put(GQ_LCF1, 32, Gv + 96 * 64, 64, vstride); put(GQ_LCG1, 32, Gv + 96 * 64 + 32, 64, vstride);
+            put(GQ_LCF2, L - 64, Gv + 128 * 64, 64, vstride); put(GQ_LCG2, L - 64, Gv + 128 * 64 + 32, 64, vstride);
+            put(GQ_WD, 32, LG(0) + h->lo.wd, 32, h->c_lstride);
+            hipLaunchKernelGGL(tr_slab_reduce_kernel, dim3(16, GQ_N, NL), dim3(256), 0, st, slabs, slab_ls, nwg, sd);
+            // gc: dGCP[l][b] = sum_t dPRE[b,t] (from the per-tile sums); conv biases = sum_b dGCP[l][b]; dense bias = column sums of the tiles
+            colsum(tsum, tpb, 64, 96, NL * B, dGCPall, 64);                                   // segment = (layer, batch entry)
+            if (ub) {
+                colsum(tsum + 64, ntiles, 32, 96, NL, LG(0) + h->lo.bd, (int)h->c_lstride);   // segment = layer, outputs c_lstride apart
+                colsum(dGCPall, B, 64, 64, NL, bsum64, 64);
+                K1(tr_split_bias_kernel, 64LL * NL, bsum64, LG(0), h->c_lstride, h->lo.bf, h->lo.bg, NL);
+            }
+            // dWgc_l = emb^T dGCP_l (one strided-batched GEMM over the layers) ; demb += sum_l dGCP_l Wgc_l^T
+            {
+                const float one = 1.0f, zero = 0.0f;
+                rc |= rocblas_sgemm_strided_batched(bl, rocblas_operation_none, rocblas_operation_transpose, 64, G, B, &one, dGCPall, 64, (long long)B * 64,
+                                                    emb, G, 0, &zero, GV + (64 + L) * 64, 64, vstride, NL);
+            }
+            K1(tr_demb_kernel, (long long)B * G, dGCPall, WV + (64 + L) * 64, vstride, demb, NL, B, G);
         }
         if (rc) break;
         // causal layer, gc embedding table, upsampler, and the gradient views back into the canonical order
