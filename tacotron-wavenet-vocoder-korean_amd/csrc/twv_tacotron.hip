@@ -717,6 +717,12 @@ __device__ __forceinline__ float decg_combine(int o_part, int nchunk, int m, int
     const int b = o_part + m * nchunk * 64 + l;
     float v = lds[b];
     int ch = 1;
+    for (; ch + 7 < nchunk; ch += 8) {
+        const float c0 = lds[b + ch * 64], c1 = lds[b + (ch + 1) * 64], c2 = lds[b + (ch + 2) * 64], c3 = lds[b + (ch + 3) * 64];
+        const float c4 = lds[b + (ch + 4) * 64], c5 = lds[b + (ch + 5) * 64], c6 = lds[b + (ch + 6) * 64], c7 = lds[b + (ch + 7) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        v = v + c0; v = v + c1; v = v + c2; v = v + c3; v = v + c4; v = v + c5; v = v + c6; v = v + c7;
+    }
     for (; ch + 3 < nchunk; ch += 4) {
         const float c0 = lds[b + ch * 64], c1 = lds[b + (ch + 1) * 64], c2 = lds[b + (ch + 2) * 64], c3 = lds[b + (ch + 3) * 64];
         v = v + c0; v = v + c1; v = v + c2; v = v + c3;
