@@ -141,9 +141,11 @@ def _parse_header(b):
     return h
 
 
-def _entry_bytes(dtype, shape, offset, size, crc_masked):
+def _entry_bytes(dtype, shape, offset, size, crc_masked, shard_id=0):
     dims = b"".join(b"\x12" + _put_varint(len(d)) + d for d in (b"\x08" + _put_varint(int(n)) for n in shape))
     out = b"\x08" + _put_varint(dtype) + b"\x12" + _put_varint(len(dims)) + dims
+    if shard_id:
+        out += b"\x18" + _put_varint(shard_id)
     if offset:
         out += b"\x20" + _put_varint(offset)            # proto3: zero-valued scalars are not serialized
     if size:
@@ -345,15 +347,18 @@ def write_table(path, items, block_size=BLOCK_SIZE):
         f.write(handles + b"\x00" * (40 - len(handles)) + struct.pack("<Q", TABLE_MAGIC))
 
 
-def write_bundle(prefix, tensors):
-    """one-shard bundle of {name: array}; names are stored in sorted order like tf.train.Saver does"""
+def write_bundle(prefix, tensors, num_shards=1):
+    """bundle of {name: array}; names are stored in sorted order like tf.train.Saver does.  num_shards > 1 deals the tensors
+    round-robin over `.data-0000k-of-0000n` files (what a sharded Saver / a merged multi-device save looks like on disk)"""
     d = os.path.dirname(prefix)
     if d:
         os.makedirs(d, exist_ok=True)
-    items = [(b"", b"\x08\x01\x1a\x02\x08\x01")]          # BundleHeaderProto{num_shards 1, little endian, version{producer 1}}
-    off = 0
-    with open(prefix + ".data-00000-of-00001", "wb") as f:
-        for name in sorted(tensors, key=lambda s: s.encode("utf-8")):
+    num_shards = max(1, int(num_shards))
+    items = [(b"", b"\x08" + _put_varint(num_shards) + b"\x1a\x02\x08\x01")]   # BundleHeaderProto{num_shards, little endian, version{producer 1}}
+    files = [open("%s.data-%05d-of-%05d" % (prefix, k, num_shards), "wb") for k in range(num_shards)]
+    offs = [0] * num_shards
+    try:
+        for i, name in enumerate(sorted(tensors, key=lambda s: s.encode("utf-8"))):
             if not name:
                 raise CheckpointError("empty variable name")
             a = np.asarray(tensors[name])
@@ -361,9 +366,13 @@ def write_bundle(prefix, tensors):
             if np.dtype(dt) not in DT_OF:
                 raise CheckpointError("%s: dtype %s cannot be stored" % (name, a.dtype))
             raw = np.ascontiguousarray(a, dtype=dt).tobytes()
-            f.write(raw)
-            items.append((name.encode("utf-8"), _entry_bytes(DT_OF[np.dtype(dt)], a.shape, off, len(raw), crc_mask(crc32c(raw)))))
-            off += len(raw)
+            k = i % num_shards
+            files[k].write(raw)
+            items.append((name.encode("utf-8"), _entry_bytes(DT_OF[np.dtype(dt)], a.shape, offs[k], len(raw), crc_mask(crc32c(raw)), k)))
+            offs[k] += len(raw)
+    finally:
+        for fh in files:
+            fh.close()
     write_table(prefix + ".index", items)
 
 

@@ -222,3 +222,27 @@ def test_tacotron_variable_names_round_trip(tmp_path):
     del var["model/inference/memory_layer/kernel"]
     with pytest.raises(ck.CheckpointError, match="memory_layer"):
         ck.tacotron_tensors(var, specs)
+
+
+def test_sharded_bundle_and_unsupported_entries(tmp_path):
+    """tensors dealt over three data shards read back; partitioned (sliced) variables and missing shards are reported, not mis-read"""
+    rng = np.random.RandomState(3)
+    var = {"v%02d" % i: rng.randn(3, i + 1).astype(np.float32) for i in range(7)}
+    var["wide/shape"] = rng.randn(130, 3, 1, 2).astype(np.float32)
+    prefix = str(tmp_path / "model.ckpt-5")
+    ck.write_bundle(prefix, var, num_shards=3)
+    assert sorted(os.listdir(str(tmp_path))) == ["model.ckpt-5.data-0000%d-of-00003" % k for k in range(3)] + ["model.ckpt-5.index"]
+    got = ck.read_bundle(prefix, verify=True)
+    assert sorted(got) == sorted(var) and all(np.array_equal(got[k], var[k]) for k in var)
+    e = ck._parse_entry(ck._entry_bytes(1, (2, 2), 16, 16, 5, shard_id=2))
+    assert (e["shard_id"], e["offset"], e["size"], e["shape"]) == (2, 16, 16, [2, 2])
+    os.remove(prefix + ".data-00001-of-00003")
+    with pytest.raises(FileNotFoundError):
+        ck.read_bundle(prefix)
+    assert sorted(ck.read_bundle(prefix, names={"v00", "v03", "v06"})) == ["v00", "v03", "v06"]     # shard 0 only: still readable
+    # a partitioned variable (BundleEntryProto.slices, field 7) is refused by name
+    items = [(b"", b"\x08\x01\x1a\x02\x08\x01"), (b"part", ck._entry_bytes(1, (4,), 0, 16, 0) + b"\x3a\x00")]
+    ck.write_table(str(tmp_path / "p.index"), items)
+    open(str(tmp_path / "p.data-00000-of-00001"), "wb").write(bytes(16))
+    with pytest.raises(ck.CheckpointError, match="partitioned"):
+        ck.read_bundle(str(tmp_path / "p"))
