@@ -66,6 +66,28 @@ __global__ void tr_up_fwd_kernel(const float* K, const float* in, float* out, lo
         out[i] = K[a * 2] * x0 + K[a * 2 + 1] * x1;
     }
 }
+// the three stages composed: U[frame*hop + phase, m] = sum_j ctab[phase][j] * mel[frame, m - j] (zero for m - j < 0), phase = (a0*f1 + a1)*f2 + a2
+__global__ void tr_ctab_kernel(const float* K0, const float* K1, const float* K2, int f0, int f1, int f2, float* ctab)
+{
+    GRID_STRIDE(i, (long long)f0 * f1 * f2) {
+        const int a2 = (int)(i % f2), a1 = (int)((i / f2) % f1), a0 = (int)(i / ((long long)f1 * f2));
+        const float p0 = K0[a0 * 2], p1 = K0[a0 * 2 + 1], q0 = K1[a1 * 2], q1 = K1[a1 * 2 + 1], r0 = K2[a2 * 2], r1 = K2[a2 * 2 + 1];
+        const float s0 = p0 * q0, s1 = p0 * q1 + p1 * q0, s2 = p1 * q1;       // stage 0 then stage 1
+        ctab[i * 4 + 0] = s0 * r0;
+        ctab[i * 4 + 1] = s0 * r1 + s1 * r0;
+        ctab[i * 4 + 2] = s1 * r1 + s2 * r0;
+        ctab[i * 4 + 3] = s2 * r1;
+    }
+}
+// ms[(bf*4 + j)*Lc + m] = mel[bf*Lc + m - j] (0 for m < j): the four bin-shifted copies of every mel frame
+__global__ void tr_mel_shift_kernel(const float* mel, float* ms, long long frames, int Lc)
+{
+    GRID_STRIDE(i, frames * 4 * Lc) {
+        const int m = (int)(i % Lc), j = (int)((i / Lc) & 3);
+        const long long bf = i / (4LL * Lc);
+        ms[i] = m >= j ? mel[bf * Lc + m - j] : 0.0f;
+    }
+}
 // backward of the stage: din[b,t,m] = sum_a K[a,0] dout[tf+a,m] + K[a,1] dout[tf+a,m+1]; dK by atomics of per-thread partials
 __global__ void tr_up_bwd_in_kernel(const float* K, const float* dout, float* din, long long total_in, int f, int Lc)
 {
@@ -443,12 +465,16 @@ struct LayerFwdArgs {
     const float* bf; const float* bg; const float* bd;       // nullable
     float* TH; float* SG; float* XN; float* ZC;              // ZC already offset to this layer's 32 columns
     int B, T, Tn, d, o, ow, ldz, tpb;                        // tpb = tiles per batch entry = ceil(Tn / 32)
+    // FUSED lc projection (see tr_layer_fwd_kernel): Q[((b*F + frame)*4 + j)*64 + column] = (mel shifted by j bins) . Wlc of this layer,
+    // ctab[phase*4 + j] = the 4-tap composition of the three upsampling kernels at that phase of the hop
+    const float* Q; const float* ctab; int hop, F;
 };
 constexpr int kLcSteps = 10;                                 // 80 / 8
 
 __device__ __forceinline__ f32x4t tr_ld4(const float* p, bool ok) { f32x4t z = {0.f, 0.f, 0.f, 0.f}; return ok ? *reinterpret_cast<const f32x4t*>(p) : z; }
 
 struct LayerA { f32x4t x0[4], x1[4], u[kLcSteps]; };
+template <bool FUSED>
 __device__ __forceinline__ void tr_layer_load(LayerA& A, const LayerFwdArgs& a, int tile, int lane)
 {
     const int b = tile / a.tpb, t = (tile - b * a.tpb) * 32 + (lane & 31), hh = (lane >> 5) * 4;
@@ -460,22 +486,32 @@ __device__ __forceinline__ void tr_layer_load(LayerA& A, const LayerFwdArgs& a, 
         A.x0[i] = tr_ld4(xr - (long long)a.d * 32 + 8 * i, in && t >= a.d);
         A.x1[i] = tr_ld4(xr + 8 * i, in);
     }
+    if (!FUSED) {
 #pragma unroll
-    for (int i = 0; i < kLcSteps; ++i) A.u[i] = tr_ld4(ur + 8 * i, in && t >= a.o);
+        for (int i = 0; i < kLcSteps; ++i) A.u[i] = tr_ld4(ur + 8 * i, in && t >= a.o);
+    }
 }
 
 // Two waves per SIMD (8 per workgroup, <= 256 registers each): while one wave runs its gated-unit epilogue on the VALU the other
 // wave's MFMAs keep the matrix pipe busy -- a lone wave issues in order and never overlaps the two (SQ_VALU_MFMA_COEXEC_CYCLES = 0
 // with one wave per SIMD).  The B operands therefore live in LDS, one conflict-free ds_read_b64 (filter, gate) per MFMA pair.
 constexpr int kFwdSteps = 32 + 4 * kLcSteps;                 // tap0 16 + tap1 16 + lc 40 = 72 MFMA steps per column half
+// FUSED: the upsampled local condition is never read.  model.py:102-111's three transposed convolutions (kernel (f, 2): two
+// adjacent mel bins) compose to a 4-tap filter over mel bins whose taps depend only on the phase inside the hop, so
+//   lc projection(t) = sum_j ctab[phase(t)][j] * Q_j[frame(t)],   Q_j = (mel shifted by j bins) . Wlc      (26 frames per entry)
+// -- 8 VALU fmas per output row instead of 80 MFMA k-steps per tile, and 320 bytes per row less HBM traffic (a third of the
+// kernel's).  Same function, different float association: the training parity is tolerance-based (tests/test_train_gpu.py).
+template <bool FUSED>
 __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(LayerFwdArgs a)
 {
-    __shared__ float bt[kFwdSteps * 128];                    // [step][lane][filter, gate]
+    __shared__ float bt[(FUSED ? 32 : kFwdSteps) * 128];     // [step][lane][filter, gate]
+    __shared__ __attribute__((aligned(16))) float cts[FUSED ? 4 * 512 : 4];   // ctab (hop <= 512)
+    if (FUSED) for (int e = threadIdx.x; e < a.hop * 4; e += 512) cts[e] = a.ctab[e];
     __shared__ float bdt[16 * 64];                           // dense: [step][lane]
     __shared__ float zt[8][32 * 36];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 31, hh = lane >> 5;
-    for (int e = threadIdx.x; e < kFwdSteps * 64; e += 512) {
+    for (int e = threadIdx.x; e < (FUSED ? 32 : kFwdSteps) * 64; e += 512) {
         const int s = e >> 6, l = e & 63, nn = l & 31, h2 = l >> 5;
         const float* W; int ij;
         if (s < 16) { W = a.W0; ij = s; } else if (s < 32) { W = a.W1; ij = s - 16; } else { W = a.Wlc; ij = s - 32; }
@@ -493,7 +529,7 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(LayerFwdArgs a)
     const int ntiles = a.B * a.tpb, nwaves = gridDim.x * 8;
     for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += nwaves) {
         LayerA A;
-        tr_layer_load(A, a, tile, lane);
+        tr_layer_load<FUSED>(A, a, tile, lane);
         // residual operand and gc projection in the output (C) layout: requested now, consumed after the MFMAs
         const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
         const float gcf = a.gcp ? a.gcp[b * 64 + n] : 0.0f, gcg = a.gcp ? a.gcp[b * 64 + 32 + n] : 0.0f;
@@ -532,14 +568,39 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(LayerFwdArgs a)
                 cf = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x1[i][j], w[0], cf, 0, 0, 0);
                 cg = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x1[i][j], w[1], cg, 0, 0, 0);
             }
+        if (!FUSED) {
 #pragma unroll
-        for (int i = 0; i < kLcSteps; ++i)
+            for (int i = 0; i < kLcSteps; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x2t w = *reinterpret_cast<const f32x2t*>(&bt[((32 + 4 * i + j) * 64 + lane) * 2]);
-                cf = __builtin_amdgcn_mfma_f32_32x32x2f32(A.u[i][j], w[0], cf, 0, 0, 0);
-                cg = __builtin_amdgcn_mfma_f32_32x32x2f32(A.u[i][j], w[1], cg, 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2t w = *reinterpret_cast<const f32x2t*>(&bt[((32 + 4 * i + j) * 64 + lane) * 2]);
+                    cf = __builtin_amdgcn_mfma_f32_32x32x2f32(A.u[i][j], w[0], cf, 0, 0, 0);
+                    cg = __builtin_amdgcn_mfma_f32_32x32x2f32(A.u[i][j], w[1], cg, 0, 0, 0);
+                }
+        } else {
+            // rows of the tile: U row u = t - o; at most two frames per 32-row tile (hop >= 32)
+            int u0 = t0 - a.o; u0 = u0 < 0 ? 0 : u0;
+            const int fA = u0 / a.hop, fB = fA + 1 < a.F ? fA + 1 : fA;
+            const int edge = (fA + 1) * a.hop;                               // first U row of frame fA + 1
+            const float* qa = a.Q + (((long long)b * a.F + fA) * 4) * 64 + n;
+            const float* qb = a.Q + (((long long)b * a.F + fB) * 4) * 64 + n;
+            float qfa[4], qga[4], qfb[4], qgb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { qfa[j] = qa[j * 64]; qga[j] = qa[j * 64 + 32]; qfb[j] = qb[j * 64]; qgb[j] = qb[j * 64 + 32]; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int u = t0 - a.o + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                u = u < 0 ? 0 : u;                                            // rows below the layer's offset are discarded by the epilogue
+                const bool hi = u >= edge;
+                int ph = u - (hi ? edge : edge - a.hop);
+                ph = ph < a.hop ? ph : a.hop - 1;                             // (only rows past the utterance end, discarded as well)
+                const f32x4t c = *reinterpret_cast<const f32x4t*>(&cts[ph * 4]);
+                const float f0 = hi ? qfb[0] : qfa[0], f1 = hi ? qfb[1] : qfa[1], f2 = hi ? qfb[2] : qfa[2], f3 = hi ? qfb[3] : qfa[3];
+                const float g0 = hi ? qgb[0] : qga[0], g1 = hi ? qgb[1] : qga[1], g2 = hi ? qgb[2] : qga[2], g3 = hi ? qgb[3] : qga[3];
+                cf[r] += ((c[0] * f0 + c[1] * f1) + c[2] * f2) + c[3] * f3;
+                cg[r] += ((c[0] * g0 + c[1] * g1) + c[2] * g2) + c[3] * g3;
             }
+        }
         // ---- gated unit (C layout: lane = channel n, register r = row (r&3) + 8(r>>2) + 4hh)
         if (interior) {
             float* thp = a.TH + lrow; float* sgp = a.SG + lrow;
@@ -1114,6 +1175,7 @@ extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch,
     f += 512LL * 96 * 64 + 1024LL * 512;        // reduction partials
     f += (256LL * 11 * 1024 + 64 + (long long)batch * ((h->Tn + 31) / 32) * 96 + 64 + (long long)batch * 64 + 64 + 64) * h->NL + 1024 + 64;   // per layer: gradient slabs, per-tile column sums, dGCP
     f += 16LL * ((long long)h->NL * 32 > h->S ? (long long)h->NL * 32 : h->S) * h->S;   // split-K partials of the wide weight gradients
+    f += 4LL * 512 + 64 + RT / h->hop * 4 * h->L + 64 + (RT / h->hop * 4 * 64 + 64) * h->NL;   // fused lc projection: tap table, shifted mel, per-layer frame projections
     f += 64 * 64;                               // rounding slack
     h->ws_floats = f;
     *out = h;
@@ -1178,6 +1240,12 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
     float* slabs = take(slab_ls * NL);                       // every layer's gradient slabs: reduced in one launch after the layer loop
     float* zpage = take(1024);
     float* kpart = take(16LL * (ZW > S ? ZW : S) * S);       // split-K partials (dW1, dW2, stacked dWs)
+    const int F = T / h->hop;                                // mel frames per entry
+    const bool fused_lc = d.n_upsample == 3 && h->hop >= 32 && h->hop <= 512 && L == 80;
+    float* ctab = take(4LL * 512);
+    float* melsh = take((long long)B * F * 4 * L);
+    const long long q_ls = (long long)B * F * 4 * 64;
+    float* Qall = take((q_ls + 64) * NL);
     int nsplit = 1;
     for (int c = 2; c <= 16 && c <= B; ++c) if (B % c == 0) nsplit = c;   // slabs of whole batch entries: RO = B * ow rows
     HIPCHK(hipMemsetAsync(zpage, 0, 4096, st));
@@ -1227,6 +1295,16 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             if ((rc = twv_mu_law_encode(audio, RT, d.quantization_channels, qin, st))) break;                                         // model.py:257
             K1(tr_onehot_causal_fwd_kernel, Rr * 32, P + h->c_causal, qin, X[0], B, T, Tn, d.quantization_channels);
         }
+        if (fused_lc) {
+            // per step: the hop's tap table from the three upsampling kernels, the bin-shifted mel frames, and every layer's frame-rate
+            // lc projections Q_l = melsh (B*F*4 x 80) . Wlc_l (80 x 64) as one strided-batched GEMM
+            K1(tr_ctab_kernel, h->hop, P + h->c_up[0], P + h->c_up[1], P + h->c_up[2], d.upsample_factor[0], d.upsample_factor[1], d.upsample_factor[2], ctab);
+            K1(tr_mel_shift_kernel, (long long)B * F * 4 * L, lc, melsh, (long long)B * F, L);
+            const float one = 1.0f, zero = 0.0f;
+            rc |= rocblas_sgemm_strided_batched(bl, rocblas_operation_none, rocblas_operation_none, 64, B * F * 4, L, &one, WV + 64 * 64, 64, vstride,
+                                                melsh, L, 0, &zero, Qall, 64, q_ls + 64, NL);
+            if (rc) break;
+        }
         for (int l = 0; l < NL && !rc; ++l) {
             const int dl = d.dilations[l], o = h->off[l + 1];
             const float* Lp = LP(l);
@@ -1243,7 +1321,9 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             {
                 const int ntiles = B * fa.tpb;
                 int nwg = (ntiles + 7) / 8; nwg = nwg > 256 ? 256 : nwg;      // one workgroup (8 waves, 2 per SIMD) per CU, each wave walks its tiles
-                hipLaunchKernelGGL(tr_layer_fwd_kernel, dim3(nwg), dim3(512), 0, st, fa);
+                fa.Q = Qall + l * (q_ls + 64); fa.ctab = ctab; fa.hop = h->hop; fa.F = F;
+                if (fused_lc) hipLaunchKernelGGL(tr_layer_fwd_kernel<true>, dim3(nwg), dim3(512), 0, st, fa);
+                else hipLaunchKernelGGL(tr_layer_fwd_kernel<false>, dim3(nwg), dim3(512), 0, st, fa);
             }
         }
         if (rc) break;
