@@ -88,6 +88,43 @@ __global__ void tr_mel_shift_kernel(const float* mel, float* ms, long long frame
         ms[i] = m >= j ? mel[bf * Lc + m - j] : 0.0f;
     }
 }
+// dctab[phase][j] = sum over batch entries and frames (fixed order) of D[(b*T + frame*hop + phase)*4 + j]
+__global__ void tr_dctab_kernel(const float* D, int B, int T, int hop, float* dctab)
+{
+    GRID_STRIDE(i, (long long)hop * 4) {
+        const int ph = (int)(i >> 2), j = (int)(i & 3), F = T / hop;
+        float s = 0.0f;
+        for (int b = 0; b < B; ++b)
+            for (int f = 0; f < F; ++f) s += D[((long long)b * T + (long long)f * hop + ph) * 4 + j];
+        dctab[i] = s;
+    }
+}
+// gradients of the three upsampling kernels from dctab: ctab[phase] = K0[a0] * K1[a1] * K2[a2] (2-tap polynomials in the bin shift), so
+// dK_s[a][k] = sum over the other two stages' phases of sum_m dctab[phase][m + k] * (product of the other two binomials)[m]
+__global__ void tr_up_grad_kernel(const float* K0, const float* K1, const float* K2, int f0, int f1, int f2, const float* dctab,
+                                  float* g0, float* g1, float* g2)
+{
+    const int n0 = 2 * f0, n1 = 2 * f1, n2 = 2 * f2;
+    GRID_STRIDE(i, (long long)n0 + n1 + n2) {
+        int st, a, k;
+        if (i < n0) { st = 0; a = (int)i >> 1; k = (int)i & 1; }
+        else if (i < n0 + n1) { st = 1; a = (int)(i - n0) >> 1; k = (int)(i - n0) & 1; }
+        else { st = 2; a = (int)(i - n0 - n1) >> 1; k = (int)(i - n0 - n1) & 1; }
+        const float* KA = st == 0 ? K1 : K0; const int fa = st == 0 ? f1 : f0;       // the two other stages, in stage order
+        const float* KB = st == 2 ? K1 : K2; const int fb = st == 2 ? f1 : f2;
+        float s = 0.0f;
+        for (int x = 0; x < fa; ++x)
+            for (int y = 0; y < fb; ++y) {
+                const int a0 = st == 0 ? a : x, a1 = st == 0 ? x : (st == 1 ? a : y), a2 = st == 2 ? a : y;
+                const int ph = (a0 * f1 + a1) * f2 + a2;
+                const float u0 = KA[x * 2], u1 = KA[x * 2 + 1], v0 = KB[y * 2], v1 = KB[y * 2 + 1];
+                const float r0 = u0 * v0, r1 = u0 * v1 + u1 * v0, r2 = u1 * v1;
+                const float* dc = dctab + ph * 4 + k;
+                s += (dc[0] * r0 + dc[1] * r1) + dc[2] * r2;
+            }
+        (st == 0 ? g0 : (st == 1 ? g1 : g2))[a * 2 + k] = s;
+    }
+}
 // backward of the stage: din[b,t,m] = sum_a K[a,0] dout[tf+a,m] + K[a,1] dout[tf+a,m+1]; dK by atomics of per-thread partials
 __global__ void tr_up_bwd_in_kernel(const float* K, const float* dout, float* din, long long total_in, int f, int Lc)
 {
@@ -678,6 +715,9 @@ struct LayerBwdArgs {
     float* dX; float* dU;                                    // K2 outputs
     const float* zeros;                                      // >= 1 KB of zeros (masked LDS-DMA lanes read here)
     int B, T, Tn, d, o, ow, ldz, tpb;
+    // FUSED lc path (see tr_layer_fwd_kernel): frame-rate projections Q of this layer; D[(b*T + u)*4 + j] accumulates, over the layers,
+    // sum_columns dPRE[row of U-row u] * Q_j[frame(u)] -- all the upsampling kernels' gradients need (tr_dctab / tr_up_grad kernels)
+    const float* Q; float* D; int hop, F;
 };
 enum { GQ_W1F = 0, GQ_W1G, GQ_W0F, GQ_W0G, GQ_LCF0, GQ_LCF1, GQ_LCF2, GQ_LCG0, GQ_LCG1, GQ_LCG2, GQ_WD, GQ_N };
 
@@ -883,6 +923,7 @@ __global__ void tr_demb_kernel(const float* dgcp, const float* wgc0, long long v
 
 // Two waves per SIMD as in the forward kernel: the transposed weights (B operands) live in LDS, [step][lane][8] with
 // (W1^T, W0^T, Wlc^T block 0, 1, 2) per lane, fetched as one ds_read_b128 + one ds_read_b32 per MFMA group.
+template <bool FUSED>
 __global__ void __launch_bounds__(512) tr_layer_bwd2_kernel(LayerBwdArgs a)
 {
     __shared__ __attribute__((aligned(16))) float bt2[32 * 64 * 8];
@@ -921,7 +962,7 @@ __global__ void __launch_bounds__(512) tr_layer_bwd2_kernel(LayerBwdArgs a)
             for (int r = 0; r < 16; ++r) {
                 const int ro = (r & 3) + 8 * (r >> 2);
                 rx[r] = xp[ro * 32];
-                r0[r] = up[ro * 80]; r1[r] = up[ro * 80 + 32]; r2[r] = n < 16 ? up[ro * 80 + 64] : 0.0f;
+                if (!FUSED) { r0[r] = up[ro * 80]; r1[r] = up[ro * 80 + 32]; r2[r] = n < 16 ? up[ro * 80 + 64] : 0.0f; }
             }
         } else {
 #pragma unroll
@@ -929,8 +970,33 @@ __global__ void __launch_bounds__(512) tr_layer_bwd2_kernel(LayerBwdArgs a)
                 const int tt = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 const bool in = tt < a.Tn, v = in && tt >= a.o;
                 rx[r] = in ? a.dXn[((long long)b * a.Tn + tt) * 32 + n] : 0.0f;
-                const float* ur = a.dU + ((long long)b * a.T + (tt - a.o)) * 80;
-                r0[r] = v ? ur[n] : 0.0f; r1[r] = v ? ur[32 + n] : 0.0f; r2[r] = (v && n < 16) ? ur[64 + n] : 0.0f;
+                if (!FUSED) {
+                    const float* ur = a.dU + ((long long)b * a.T + (tt - a.o)) * 80;
+                    r0[r] = v ? ur[n] : 0.0f; r1[r] = v ? ur[32 + n] : 0.0f; r2[r] = (v && n < 16) ? ur[64 + n] : 0.0f;
+                }
+            }
+        }
+        if (FUSED) {
+            // D[u][j] += dPRE[row] . Q_j[frame(u)] over the 64 columns: this lane holds 32 of them (row = lane & 31, columns 8i + 4hh + 0..3)
+            const int u = t - a.o;
+            const bool v = t < a.Tn && u >= 0;
+            const int f = v ? u / a.hop : 0;
+            const float* qr = a.Q + (((long long)b * a.F + f) * 4) * 64 + 4 * hh;
+            float dj[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4t q4 = *reinterpret_cast<const f32x4t*>(qr + j * 64 + 8 * i);
+                    dj[j] += (qa[i][0] * q4[0] + qa[i][1] * q4[1]) + (qa[i][2] * q4[2] + qa[i][3] * q4[3]);
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dj[j] += __shfl_xor(dj[j], 32);
+            if (hh == 0 && v) {
+                f32x4t* dp = reinterpret_cast<f32x4t*>(a.D + ((long long)b * a.T + u) * 4);
+                f32x4t cur = *dp;
+                cur[0] += dj[0]; cur[1] += dj[1]; cur[2] += dj[2]; cur[3] += dj[3];
+                *dp = cur;
             }
         }
         f32x16 cx = zero, c0 = zero, c1 = zero, c2 = zero;
@@ -942,9 +1008,11 @@ __global__ void __launch_bounds__(512) tr_layer_bwd2_kernel(LayerBwdArgs a)
                 const f32x4t w4 = *reinterpret_cast<const f32x4t*>(wq);
                 const float w5 = wq[4];
                 cx = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], w4[0], cx, 0, 0, 0);
-                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], w4[2], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], w4[3], c1, 0, 0, 0);
-                c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], w5, c2, 0, 0, 0);
+                if (!FUSED) {
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], w4[2], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], w4[3], c1, 0, 0, 0);
+                    c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], w5, c2, 0, 0, 0);
+                }
                 cx = __builtin_amdgcn_mfma_f32_32x32x2f32(qb[i][j], w4[1], cx, 0, 0, 0);
             }
         if (interior) {
@@ -953,8 +1021,10 @@ __global__ void __launch_bounds__(512) tr_layer_bwd2_kernel(LayerBwdArgs a)
             for (int r = 0; r < 16; ++r) {
                 const int ro = (r & 3) + 8 * (r >> 2);
                 dxp[ro * 32] = rx[r] + cx[r];
-                up[ro * 80] = r0[r] + c0[r]; up[ro * 80 + 32] = r1[r] + c1[r];
-                if (n < 16) up[ro * 80 + 64] = r2[r] + c2[r];
+                if (!FUSED) {
+                    up[ro * 80] = r0[r] + c0[r]; up[ro * 80 + 32] = r1[r] + c1[r];
+                    if (n < 16) up[ro * 80 + 64] = r2[r] + c2[r];
+                }
             }
         } else {
 #pragma unroll
@@ -962,7 +1032,7 @@ __global__ void __launch_bounds__(512) tr_layer_bwd2_kernel(LayerBwdArgs a)
                 const int tt = t0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 if (tt < a.Tn) {
                     a.dX[((long long)b * a.Tn + tt) * 32 + n] = rx[r] + cx[r];
-                    if (tt >= a.o) {
+                    if (!FUSED && tt >= a.o) {
                         float* ur = a.dU + ((long long)b * a.T + (tt - a.o)) * 80;
                         ur[n] = r0[r] + c0[r]; ur[32 + n] = r1[r] + c1[r];
                         if (n < 16) ur[64 + n] = r2[r] + c2[r];
@@ -1175,6 +1245,7 @@ extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch,
     f += 512LL * 96 * 64 + 1024LL * 512;        // reduction partials
     f += (256LL * 11 * 1024 + 64 + (long long)batch * ((h->Tn + 31) / 32) * 96 + 64 + (long long)batch * 64 + 64 + 64) * h->NL + 1024 + 64;   // per layer: gradient slabs, per-tile column sums, dGCP
     f += 16LL * ((long long)h->NL * 32 > h->S ? (long long)h->NL * 32 : h->S) * h->S;   // split-K partials of the wide weight gradients
+    f += RT * 4 + 64 + 4LL * 512 + 64;          // fused lc backward: per-row dot products, phase-table gradient
     f += 4LL * 512 + 64 + RT / h->hop * 4 * h->L + 64 + (RT / h->hop * 4 * 64 + 64) * h->NL;   // fused lc projection: tap table, shifted mel, per-layer frame projections
     f += 64 * 64;                               // rounding slack
     h->ws_floats = f;
@@ -1246,6 +1317,8 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
     float* melsh = take((long long)B * F * 4 * L);
     const long long q_ls = (long long)B * F * 4 * 64;
     float* Qall = take((q_ls + 64) * NL);
+    float* Dbuf = take(RT * 4);                              // sum over layers of dPRE . Q_j per U row (fused lc backward)
+    float* dctab = take(4LL * 512);
     int nsplit = 1;
     for (int c = 2; c <= 16 && c <= B; ++c) if (B % c == 0) nsplit = c;   // slabs of whole batch entries: RO = B * ow rows
     HIPCHK(hipMemsetAsync(zpage, 0, 4096, st));
@@ -1374,7 +1447,8 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         if (rc) break;
         float* dXn = dXa; float* dXc = dXb;
         K1(tr_fill_kernel, Rr * 32, dXn, 0.0f, Rr * 32);
-        K1(tr_fill_kernel, RT * L, dUa, 0.0f, RT * L);
+        if (fused_lc) K1(tr_fill_kernel, RT * 4, Dbuf, 0.0f, RT * 4);
+        else K1(tr_fill_kernel, RT * L, dUa, 0.0f, RT * L);
         K1(tr_fill_kernel, (long long)B * G, demb, 0.0f, (long long)B * G);
         for (int l = NL - 1; l >= 0 && !rc; --l) {
             const int dl = d.dilations[l], o = h->off[l + 1];
@@ -1392,7 +1466,9 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             int nwg2 = (ntiles + 7) / 8; nwg2 = nwg2 > 256 ? 256 : nwg2;
             ba.zeros = zpage;
             hipLaunchKernelGGL(tr_layer_bwd1_kernel, dim3(nwg), dim3(256), 4 * BS_FLOATS * 4, st, ba);
-            hipLaunchKernelGGL(tr_layer_bwd2_kernel, dim3(nwg2), dim3(512), 0, st, ba);
+            ba.Q = Qall + l * (q_ls + 64); ba.D = Dbuf; ba.hop = h->hop; ba.F = F;
+            if (fused_lc) hipLaunchKernelGGL(tr_layer_bwd2_kernel<true>, dim3(nwg2), dim3(512), 0, st, ba);
+            else hipLaunchKernelGGL(tr_layer_bwd2_kernel<false>, dim3(nwg2), dim3(512), 0, st, ba);
             float* tsw = dXn; dXn = dXc; dXc = tsw;
         }
         if (rc) break;
@@ -1438,7 +1514,12 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         K1(tr_scatter_emb_kernel, (long long)d.gc_cardinality * G, demb, gc_ids, Gd + h->c_gcemb, B, G, d.gc_cardinality);
         K1(tr_views_kernel, (vstride + 32LL * S) * NL, Gd, GV, GS, NL, h->c_layer0, h->c_lstride, h->lo.wf, h->lo.wg, h->lo.lcf, h->lo.lcg,
            h->lo.gcf, h->lo.gcg, h->lo.ws, L, G, S, 1);
-        {
+        if (fused_lc) {
+            // upsampling kernels: D (per U row) -> dctab (per phase) -> the three (f, 2) kernels
+            K1(tr_dctab_kernel, 4LL * h->hop, Dbuf, B, T, h->hop, dctab);
+            K1(tr_up_grad_kernel, 2LL * (d.upsample_factor[0] + d.upsample_factor[1] + d.upsample_factor[2]), P + h->c_up[0], P + h->c_up[1], P + h->c_up[2],
+               d.upsample_factor[0], d.upsample_factor[1], d.upsample_factor[2], dctab, Gd + h->c_up[0], Gd + h->c_up[1], Gd + h->c_up[2]);
+        } else {
             float* dcur = dUa; float* dnxt = dUb;
             for (int i = d.n_upsample - 1; i >= 0; --i) {
                 const long long rin = (long long)B * upT[i];
