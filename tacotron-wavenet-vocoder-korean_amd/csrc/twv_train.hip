@@ -88,16 +88,30 @@ __global__ void tr_mel_shift_kernel(const float* mel, float* ms, long long frame
         ms[i] = m >= j ? mel[bf * Lc + m - j] : 0.0f;
     }
 }
-// dctab[phase][j] = sum over batch entries and frames (fixed order) of D[(b*T + frame*hop + phase)*4 + j]
-__global__ void tr_dctab_kernel(const float* D, int B, int T, int hop, float* dctab)
+// dctab[phase][j] = sum over batch entries and frames of D[(b*T + frame*hop + phase)*4 + j]: one block per phase, thread i takes the
+// (b, frame) pairs i, i+256, ... in order, then a fixed-order tree over the 256 partial sums (deterministic)
+__global__ __launch_bounds__(256) void tr_dctab_kernel(const float* D, int B, int T, int hop, float* dctab)
 {
-    GRID_STRIDE(i, (long long)hop * 4) {
-        const int ph = (int)(i >> 2), j = (int)(i & 3), F = T / hop;
-        float s = 0.0f;
-        for (int b = 0; b < B; ++b)
-            for (int f = 0; f < F; ++f) s += D[((long long)b * T + (long long)f * hop + ph) * 4 + j];
-        dctab[i] = s;
+    const int ph = blockIdx.x, F = T / hop, n = B * F;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int b = i / F, f = i - b * F;
+        const float4 v = *reinterpret_cast<const float4*>(D + ((long long)b * T + (long long)f * hop + ph) * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
+    __shared__ float4 sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            const float4 o = sh[threadIdx.x + w];
+            float4 m = sh[threadIdx.x];
+            m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+            sh[threadIdx.x] = m;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { dctab[ph * 4 + 0] = sh[0].x; dctab[ph * 4 + 1] = sh[0].y; dctab[ph * 4 + 2] = sh[0].z; dctab[ph * 4 + 3] = sh[0].w; }
 }
 // gradients of the three upsampling kernels from dctab: ctab[phase] = K0[a0] * K1[a1] * K2[a2] (2-tap polynomials in the bin shift), so
 // dK_s[a][k] = sum over the other two stages' phases of sum_m dctab[phase][m + k] * (product of the other two binomials)[m]
@@ -718,12 +732,15 @@ struct LayerBwdArgs {
     // FUSED lc path (see tr_layer_fwd_kernel): frame-rate projections Q of this layer; D[(b*T + u)*4 + j] accumulates, over the layers,
     // sum_columns dPRE[row of U-row u] * Q_j[frame(u)] -- all the upsampling kernels' gradients need (tr_dctab / tr_up_grad kernels)
     const float* Q; float* D; int hop, F;
+    // bwd1: the hop's tap table and this layer's per-tile partial sums PT[tile][2 frame slots][4 taps][64 columns] of ctab[phase][j] * dPRE
+    const float* ctab; float* PT;
 };
 enum { GQ_W1F = 0, GQ_W1G, GQ_W0F, GQ_W0G, GQ_LCF0, GQ_LCF1, GQ_LCF2, GQ_LCG0, GQ_LCG1, GQ_LCG2, GQ_WD, GQ_N };
 
 // LDS staging of one tile's operands (floats, per wave): LDS-DMA (global_load_lds b128) fills it for tile i+1 while tile i's MFMAs run
 enum { BS_TH = 0, BS_SG = 1024, BS_DXN = 2048, BS_DZC = 3072, BS_X1 = 4096, BS_X0 = 5120, BS_U = 6144, BS_FLOATS = 6144 + 2560 };
 
+template <bool FUSED>
 __device__ __forceinline__ void tr_bwd1_stage(const LayerBwdArgs& a, int tile, int lane, int base /* float offset of the wave's region in lds[] */)
 {
     const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
@@ -745,20 +762,31 @@ __device__ __forceinline__ void tr_bwd1_stage(const LayerBwdArgs& a, int tile, i
         __builtin_amdgcn_global_load_lds((gptr_t)(zok ? a.dZC + ((long long)b * a.ow + pz) * a.ldz + (lane & 7) * 4 : a.zeros + lane * 4),
                                          (lptr_t)(lds + base + BS_DZC + p * 256), 16, 0, 0);
     }
-    // U rows t0-o .. t0-o+31: 10 KB contiguous
-    const long long ubase = ((long long)b * a.T + (t0 - a.o)) * 80;
+    if (!FUSED) {
+        // U rows t0-o .. t0-o+31: 10 KB contiguous
+        const long long ubase = ((long long)b * a.T + (t0 - a.o)) * 80;
 #pragma unroll
-    for (int p = 0; p < 10; ++p) {
-        const long long off = ubase + p * 256 + lane * 4;
-        __builtin_amdgcn_global_load_lds((gptr_t)(off >= 0 ? a.U + off : a.zeros + lane * 4), (lptr_t)(lds + base + BS_U + p * 256), 16, 0, 0);
+        for (int p = 0; p < 10; ++p) {
+            const long long off = ubase + p * 256 + lane * 4;
+            __builtin_amdgcn_global_load_lds((gptr_t)(off >= 0 ? a.U + off : a.zeros + lane * 4), (lptr_t)(lds + base + BS_U + p * 256), 16, 0, 0);
+        }
     }
 }
 
+// FUSED: U is not read and W_lc's six gradient tiles are not accumulated here (96 of the 176 MFMAs per tile).  With the lc term written
+// as sum_j ctab[phase][j] * Q_j[frame], dW_lc = sum_frames shift_j(mel)^T R_j with R_j[frame] = sum over the frame's rows of
+// ctab[phase][j] * dPRE[row]: each tile leaves its share of R for the one or two frames it touches (PT), summed per frame afterwards.
+template <bool FUSED>
 __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, hh = lane >> 5;
     const int base = wave * BS_FLOATS;
+    const int cto = 4 * BS_FLOATS;                           // FUSED: ctab behind the four waves' staging areas
+    if (FUSED) {
+        for (int e = threadIdx.x; e < a.hop * 4; e += 256) lds[cto + e] = a.ctab[e];
+        __syncthreads();
+    }
     float bwd[16];                                           // Wd^T as B operand: lane (n, hh): Wd[n][k = 8i + 4hh + j]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -770,7 +798,7 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
     for (int q = 0; q < GQ_N; ++q) g[q] = zero;
     const int ntiles = a.B * a.tpb, nwaves = gridDim.x * 4;
     int tile = blockIdx.x * 4 + wave;
-    if (tile < ntiles) tr_bwd1_stage(a, tile, lane, base);
+    if (tile < ntiles) tr_bwd1_stage<FUSED>(a, tile, lane, base);
     for (; tile < ntiles; tile += nwaves) {
         const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this tile's operands are in LDS
@@ -797,7 +825,7 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
                 const int ro = (r & 3) + 8 * (r >> 2);
                 th_[r] = lds[lb + BS_TH + ro * 32]; sg_[r] = lds[lb + BS_SG + ro * 32]; dxc[r] = lds[lb + BS_DXN + ro * 32];
                 dzc[r] = lds[lb + BS_DZC + ro * 32]; x1[r] = lds[lb + BS_X1 + ro * 32]; x0[r] = lds[lb + BS_X0 + ro * 32];
-                u0[r] = lds[ub + ro * 80]; u1[r] = lds[ub + ro * 80 + 32]; u2[r] = n < 16 ? lds[ub + ro * 80 + 64] : 0.0f;
+                if (!FUSED) { u0[r] = lds[ub + ro * 80]; u1[r] = lds[ub + ro * 80 + 32]; u2[r] = n < 16 ? lds[ub + ro * 80 + 64] : 0.0f; }
             }
         } else {
 #pragma unroll
@@ -810,13 +838,15 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
                 dzc[r] = lds[base + BS_DZC + rl * 32 + n];
                 x1[r] = in ? lds[base + BS_X1 + rl * 32 + n] : 0.0f;
                 x0[r] = (in && t >= a.d) ? lds[base + BS_X0 + rl * 32 + n] : 0.0f;
-                u0[r] = valid ? lds[base + BS_U + rl * 80 + n] : 0.0f;
-                u1[r] = valid ? lds[base + BS_U + rl * 80 + 32 + n] : 0.0f;
-                u2[r] = (valid && n < 16) ? lds[base + BS_U + rl * 80 + 64 + n] : 0.0f;
+                if (!FUSED) {
+                    u0[r] = valid ? lds[base + BS_U + rl * 80 + n] : 0.0f;
+                    u1[r] = valid ? lds[base + BS_U + rl * 80 + 32 + n] : 0.0f;
+                    u2[r] = (valid && n < 16) ? lds[base + BS_U + rl * 80 + 64 + n] : 0.0f;
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read has returned: the region may be refilled
-        if (tile + nwaves < ntiles) tr_bwd1_stage(a, tile + nwaves, lane, base);
+        if (tile + nwaves < ntiles) tr_bwd1_stage<FUSED>(a, tile + nwaves, lane, base);
         float dF[16], dG[16], zc[16];
         float sf = 0.0f, sgs = 0.0f, sx = 0.0f;
         if (interior) {
@@ -850,6 +880,44 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
             const float of = __shfl_xor(sf, 32), og = __shfl_xor(sgs, 32), ox = __shfl_xor(sx, 32);
             if (hh == 0) { a.tsum[(long long)tile * 96 + n] = sf + of; a.tsum[(long long)tile * 96 + 32 + n] = sgs + og; a.tsum[(long long)tile * 96 + 64 + n] = sx + ox; }
         }
+        if (FUSED) {
+            // this tile's share of R_j[frame][column] = sum_rows ctab[phase(row)][j] * dPRE[row][column]; slot 0 = the frame of the tile's
+            // first U row, slot 1 = the next frame (only tiles that straddle a frame edge fill it)
+            const int u0 = t0 - a.o, u0c = u0 < 0 ? 0 : u0;
+            const int fA = u0c / a.hop, edge = (fA + 1) * a.hop;
+            const bool spans = u0 + 31 >= edge;
+            float raf[4] = {0.f, 0.f, 0.f, 0.f}, rag[4] = {0.f, 0.f, 0.f, 0.f}, rbf[4] = {0.f, 0.f, 0.f, 0.f}, rbg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int u = u0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                u = u < 0 ? 0 : u;                                            // rows below the layer's offset carry dF = dG = 0
+                const bool hi = u >= edge;
+                int ph = u - (hi ? edge : edge - a.hop);
+                ph = ph < a.hop ? ph : a.hop - 1;
+                const f32x4t c = *reinterpret_cast<const f32x4t*>(&lds[cto + ph * 4]);
+                const float fl = hi ? 0.0f : dF[r], gl = hi ? 0.0f : dG[r];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { raf[j] += c[j] * fl; rag[j] += c[j] * gl; }
+                if (spans) {
+                    const float fh = hi ? dF[r] : 0.0f, gh = hi ? dG[r] : 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { rbf[j] += c[j] * fh; rbg[j] += c[j] * gh; }
+                }
+            }
+            float* pt = a.PT + (long long)tile * 512 + n;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float f0_ = raf[j] + __shfl_xor(raf[j], 32), g0_ = rag[j] + __shfl_xor(rag[j], 32);
+                if (hh == 0) { pt[j * 64] = f0_; pt[j * 64 + 32] = g0_; }
+            }
+            if (spans) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float f1_ = rbf[j] + __shfl_xor(rbf[j], 32), g1_ = rbg[j] + __shfl_xor(rbg[j], 32);
+                    if (hh == 0) { pt[256 + j * 64] = f1_; pt[256 + j * 64 + 32] = g1_; }
+                }
+            }
+        }
         // ---- weight gradients: A = [row rho][channel], B = dF / dG / dXn registers
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -857,12 +925,14 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
             g[GQ_W1G] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[r], dG[r], g[GQ_W1G], 0, 0, 0);
             g[GQ_W0F] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[r], dF[r], g[GQ_W0F], 0, 0, 0);
             g[GQ_W0G] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[r], dG[r], g[GQ_W0G], 0, 0, 0);
-            g[GQ_LCF0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0[r], dF[r], g[GQ_LCF0], 0, 0, 0);
-            g[GQ_LCG0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0[r], dG[r], g[GQ_LCG0], 0, 0, 0);
-            g[GQ_LCF1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1[r], dF[r], g[GQ_LCF1], 0, 0, 0);
-            g[GQ_LCG1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1[r], dG[r], g[GQ_LCG1], 0, 0, 0);
-            g[GQ_LCF2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2[r], dF[r], g[GQ_LCF2], 0, 0, 0);
-            g[GQ_LCG2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2[r], dG[r], g[GQ_LCG2], 0, 0, 0);
+            if (!FUSED) {
+                g[GQ_LCF0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0[r], dF[r], g[GQ_LCF0], 0, 0, 0);
+                g[GQ_LCG0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u0[r], dG[r], g[GQ_LCG0], 0, 0, 0);
+                g[GQ_LCF1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1[r], dF[r], g[GQ_LCF1], 0, 0, 0);
+                g[GQ_LCG1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u1[r], dG[r], g[GQ_LCG1], 0, 0, 0);
+                g[GQ_LCF2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2[r], dF[r], g[GQ_LCF2], 0, 0, 0);
+                g[GQ_LCG2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u2[r], dG[r], g[GQ_LCG2], 0, 0, 0);
+            }
             g[GQ_WD] = __builtin_amdgcn_mfma_f32_32x32x2f32(zc[r], dxc[r], g[GQ_WD], 0, 0, 0);
         }
     }
@@ -870,6 +940,7 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
     float* slab = a.slabs + (long long)blockIdx.x * GQ_N * 1024;
 #pragma unroll
     for (int q = 0; q < GQ_N; ++q) {
+        if (FUSED && q >= GQ_LCF0 && q <= GQ_LCG2) continue;          // W_lc's gradient comes from the per-frame sums
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) lds[wave * 1056 + ((r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + n] = g[q][r];
@@ -878,6 +949,30 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
             const int rr = i >> 5, cc = i & 31, o = rr * 33 + cc;
             slab[q * 1024 + i] = (lds[o] + lds[1056 + o]) + (lds[2112 + o] + lds[3168 + o]);
         }
+    }
+}
+// R[l][(b*F + f)*4 + j][c] = sum, in tile order, of the per-tile partials that belong to frame f of batch entry b in layer l (offs[l] = the layer's
+// receptive offset o: U row u = t - o).  grid (ceil(B*F*256 / 256), 1, NL), one thread per (b, f, j, c).
+struct LayerOffs { int o[64]; };
+__global__ __launch_bounds__(256) void tr_frame_reduce_kernel(const float* PT, long long pt_lstride, LayerOffs offs, int B, int F, int hop, int tpb, int Tn,
+                                                              float* R, long long r_lstride)
+{
+    const int l = blockIdx.z, o = offs.o[l];
+    const float* pt = PT + (long long)l * pt_lstride;
+    GRID_STRIDE(i, (long long)B * F * 256) {
+        const int c = (int)(i & 63), j = (int)((i >> 6) & 3);
+        const int bf = (int)(i >> 8), b = bf / F, f = bf - b * F;
+        int ta = (f * hop + o) >> 5, tb = ((f + 1) * hop + o - 1) >> 5;
+        tb = tb < tpb ? tb : tpb - 1;
+        float s = 0.0f;
+        for (int tl = ta; tl <= tb; ++tl) {
+            const int u0 = tl * 32 - o, u0c = u0 < 0 ? 0 : u0;
+            const int fA = u0c / hop, edge = (fA + 1) * hop;
+            const float* p = pt + ((long long)b * tpb + tl) * 512 + j * 64 + c;
+            if (fA == f) s += p[0];
+            else if (fA + 1 == f && u0 + 31 >= edge) s += p[256];
+        }
+        R[(long long)l * r_lstride + i] = s;
     }
 }
 // every gradient tile q of a layer: out_q[(m, n)] = sum over slabs (fixed order); rows >= mrows are dropped (lc block 2 has 16 rows)
@@ -1246,6 +1341,7 @@ extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch,
     f += (256LL * 11 * 1024 + 64 + (long long)batch * ((h->Tn + 31) / 32) * 96 + 64 + (long long)batch * 64 + 64 + 64) * h->NL + 1024 + 64;   // per layer: gradient slabs, per-tile column sums, dGCP
     f += 16LL * ((long long)h->NL * 32 > h->S ? (long long)h->NL * 32 : h->S) * h->S;   // split-K partials of the wide weight gradients
     f += RT * 4 + 64 + 4LL * 512 + 64;          // fused lc backward: per-row dot products, phase-table gradient
+    f += ((long long)batch * ((h->Tn + 31) / 32) * 512 + 64 + RT / h->hop * 256 + 64) * h->NL;   // per-tile / per-frame sums of ctab * dPRE (dW_lc)
     f += 4LL * 512 + 64 + RT / h->hop * 4 * h->L + 64 + (RT / h->hop * 4 * 64 + 64) * h->NL;   // fused lc projection: tap table, shifted mel, per-layer frame projections
     f += 64 * 64;                               // rounding slack
     h->ws_floats = f;
@@ -1319,10 +1415,14 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
     float* Qall = take((q_ls + 64) * NL);
     float* Dbuf = take(RT * 4);                              // sum over layers of dPRE . Q_j per U row (fused lc backward)
     float* dctab = take(4LL * 512);
+    const long long pt_ls = (long long)B * ((Tn + 31) / 32) * 512;
+    float* PTall = take((pt_ls + 64) * NL);
+    float* Rall = take((q_ls + 64) * NL);
     int nsplit = 1;
     for (int c = 2; c <= 16 && c <= B; ++c) if (B % c == 0) nsplit = c;   // slabs of whole batch entries: RO = B * ow rows
     HIPCHK(hipMemsetAsync(zpage, 0, 4096, st));
-    HIPCHK(hipFuncSetAttribute((const void*)tr_layer_bwd1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BS_FLOATS * 4));
+    HIPCHK(hipFuncSetAttribute((const void*)tr_layer_bwd1_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BS_FLOATS * 4));
+    HIPCHK(hipFuncSetAttribute((const void*)tr_layer_bwd1_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (4 * BS_FLOATS + 2048) * 4));
     const long long tsum_ls = (long long)B * ((Tn + 31) / 32) * 96;     // layers back to back: the column sums below treat (layer, batch entry) as segments
     float* tsum = take(tsum_ls * NL);
     float* dGCPall = take((long long)B * 64 * NL);
@@ -1465,8 +1565,9 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             int nwg = (ntiles + 3) / 4; nwg = nwg > 256 ? 256 : nwg;
             int nwg2 = (ntiles + 7) / 8; nwg2 = nwg2 > 256 ? 256 : nwg2;
             ba.zeros = zpage;
-            hipLaunchKernelGGL(tr_layer_bwd1_kernel, dim3(nwg), dim3(256), 4 * BS_FLOATS * 4, st, ba);
-            ba.Q = Qall + l * (q_ls + 64); ba.D = Dbuf; ba.hop = h->hop; ba.F = F;
+            ba.Q = Qall + l * (q_ls + 64); ba.D = Dbuf; ba.hop = h->hop; ba.F = F; ba.ctab = ctab; ba.PT = PTall + l * (pt_ls + 64);
+            if (fused_lc) hipLaunchKernelGGL(tr_layer_bwd1_kernel<true>, dim3(nwg), dim3(256), (4 * BS_FLOATS + 2048) * 4, st, ba);
+            else hipLaunchKernelGGL(tr_layer_bwd1_kernel<false>, dim3(nwg), dim3(256), 4 * BS_FLOATS * 4, st, ba);
             if (fused_lc) hipLaunchKernelGGL(tr_layer_bwd2_kernel<true>, dim3(nwg2), dim3(512), 0, st, ba);
             else hipLaunchKernelGGL(tr_layer_bwd2_kernel<false>, dim3(nwg2), dim3(512), 0, st, ba);
             float* tsw = dXn; dXn = dXc; dXc = tsw;
@@ -1485,6 +1586,17 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             put(GQ_LCF1, 32, Gv + 96 * 64, 64, vstride); put(GQ_LCG1, 32, Gv + 96 * 64 + 32, 64, vstride);
             put(GQ_LCF2, L - 64, Gv + 128 * 64, 64, vstride); put(GQ_LCG2, L - 64, Gv + 128 * 64 + 32, 64, vstride);
             put(GQ_WD, 32, LG(0) + h->lo.wd, 32, h->c_lstride);
+            if (fused_lc) {
+                for (int q = GQ_LCF0; q <= GQ_LCG2; ++q) sd.mrows[q] = 0;       // W_lc's gradient: per-frame sums -> one strided-batched GEMM
+                LayerOffs lo_;
+                for (int l = 0; l < NL; ++l) lo_.o[l] = h->off[l + 1];
+                const long long nthr = (long long)B * F * 256;
+                hipLaunchKernelGGL(tr_frame_reduce_kernel, dim3((unsigned)((nthr + 255) / 256), 1, NL), dim3(256), 0, st, PTall, pt_ls + 64, lo_, B, F, h->hop, tpb, Tn,
+                                   Rall, q_ls + 64);
+                const float one = 1.0f, zero = 0.0f;
+                rc |= rocblas_sgemm_strided_batched(bl, rocblas_operation_none, rocblas_operation_transpose, 64, L, B * F * 4, &one, Rall, 64, q_ls + 64,
+                                                    melsh, L, 0, &zero, GV + 64 * 64, 64, vstride, NL);
+            }
             hipLaunchKernelGGL(tr_slab_reduce_kernel, dim3(16, GQ_N, NL), dim3(256), 0, st, slabs, slab_ls, nwg, sd);
             // gc: dGCP[l][b] = sum_t dPRE[b,t] (from the per-tile sums); conv biases = sum_b dGCP[l][b]; dense bias = column sums of the tiles
             colsum(tsum, tpb, 64, 96, NL * B, dGCPall, 64);                                   // segment = (layer, batch entry)
@@ -1516,7 +1628,7 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
            h->lo.gcf, h->lo.gcg, h->lo.ws, L, G, S, 1);
         if (fused_lc) {
             // upsampling kernels: D (per U row) -> dctab (per phase) -> the three (f, 2) kernels
-            K1(tr_dctab_kernel, 4LL * h->hop, Dbuf, B, T, h->hop, dctab);
+            hipLaunchKernelGGL(tr_dctab_kernel, dim3(h->hop), dim3(256), 0, st, Dbuf, B, T, h->hop, dctab);
             K1(tr_up_grad_kernel, 2LL * (d.upsample_factor[0] + d.upsample_factor[1] + d.upsample_factor[2]), P + h->c_up[0], P + h->c_up[1], P + h->c_up[2],
                d.upsample_factor[0], d.upsample_factor[1], d.upsample_factor[2], dctab, Gd + h->c_up[0], Gd + h->c_up[1], Gd + h->c_up[2]);
         } else {
