@@ -1458,7 +1458,7 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         // ================= forward =================
         K1(tr_views_kernel, (vstride + 32LL * S) * NL, const_cast<float*>(P), WV, WS, NL, h->c_layer0, h->c_lstride, h->lo.wf, h->lo.wg, h->lo.lcf, h->lo.lcg,
            h->lo.gcf, h->lo.gcg, h->lo.ws, L, G, S, 0);
-        for (int i = 0; i < d.n_upsample; ++i)     // model.py:276 create_upsample
+        for (int i = 0; i < d.n_upsample && !fused_lc; ++i)     // model.py:276 create_upsample (the fused lc path never materialises it)
             K1(tr_up_fwd_kernel, (long long)B * upT[i + 1] * L, P + h->c_up[i], ups[i], ups[i + 1], (long long)B * upT[i + 1] * L, d.upsample_factor[i], L);
         K1(tr_gather_emb_kernel, (long long)B * G, P + h->c_gcemb, gc_ids, emb, B, G);   // model.py:197-198
         if (d.scalar_input) {
