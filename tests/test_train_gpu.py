@@ -59,7 +59,7 @@ def test_loss_and_gradients_match_torch_fp32(kw):
     tr, tensors, cfg, audio, lc, gc = _case(**kw)
     loss = float(tr.loss_and_gradients(audio, lc, gc).item())
     ref_loss, ref_g = R.loss_and_grads(tensors, cfg, audio, lc, gc)
-    # tolerance: the loss is a mean of O(10) terms over B*out_w rows summed by float atomics -> 2e-5 relative
+    # tolerance: the loss is a mean of O(10) terms over B*out_w rows summed in a different (chunked, fixed) order -> 2e-5 relative
     assert abs(loss - ref_loss) <= 2e-5 * abs(ref_loss), (loss, ref_loss)
     # tolerance: every gradient tensor within 2e-3 of its own max magnitude (fp32 reductions over up to B*T rows in a
     # different order; float64 torch agrees with float32 torch to ~1e-4 on the same scale)
