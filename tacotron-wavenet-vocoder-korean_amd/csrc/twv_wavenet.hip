@@ -1667,7 +1667,14 @@ static int launch_generate2(const GenArgs& a, size_t shm, hipStream_t st)
 {
     auto kern = wn_generate_kernel<W, NTW, SCALAR, D, SPLIT1, INSTR, HELP>;
     if (shm > 32 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL(kern, dim3(a.B * a.G * (HELP ? 2 : 1)), dim3((1 + kLoaders + D + W) * 64), shm, st, a);
+    // every workgroup of the launch spins on values other workgroups produce: a COOPERATIVE launch, so that the runtime itself
+    // guarantees (or refuses) co-residency of the whole grid instead of this code inferring it from the CU count alone
+    GenArgs arg = a;
+    void* params[] = {&arg};
+    const hipError_t e = hipLaunchCooperativeKernel((const void*)kern, dim3(a.B * a.G * (HELP ? 2 : 1)), dim3((1 + kLoaders + D + W) * 64), params,
+                                                    (unsigned)shm, st);
+    if (e == hipErrorCooperativeLaunchTooLarge) return fail(TWV_E_UNSUPPORTED, "the stream (+ helper) workgroups cannot all be resident on this device");
+    HIPCHK(e);
     HIPCHK(hipGetLastError());
     return TWV_OK;
 }
