@@ -1478,14 +1478,19 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
                                                 melsh, L, 0, &zero, Qall, 64, q_ls + 64, NL);
             if (rc) break;
         }
+        {   // model.py:71-73 gc projections of every layer: GCP[l] (B x 64) = emb (B x G) . Wgc_l (G x 64)
+            const float one = 1.0f, zero = 0.0f;
+            rc |= rocblas_sgemm_strided_batched(bl, rocblas_operation_none, rocblas_operation_none, 64, B, G, &one, WV + (64 + L) * 64, 64, vstride,
+                                                emb, G, 0, &zero, GCP, 64, (long long)B * 64, NL);
+            if (rc) break;
+        }
         for (int l = 0; l < NL && !rc; ++l) {
             const int dl = d.dilations[l], o = h->off[l + 1];
             const float* Lp = LP(l);
             const float* Wv = WV + l * vstride;                 // tap0 | tap1 | lc | gc views, 64 columns = filter|gate
             // model.py:71-73 gc projection (tiny), then the fused layer: conv_filter | conv_gate taps, lc projection, gated unit,
             // dense + residual, skip input slice
-            float* gcp = GCP + (long long)l * B * 64;
-            rc |= gemm_rm(bl, false, false, B, 64, G, 1.f, emb, G, Wv + (64 + L) * 64, 64, 0.f, gcp, 64);
+            float* gcp = GCP + (long long)l * B * 64;                // all layers' projections: one strided-batched GEMM before the loop
             LayerFwdArgs fa;
             fa.X = X[l]; fa.U = U; fa.gcp = gcp; fa.W0 = Wv; fa.W1 = Wv + 32 * 64; fa.Wlc = Wv + 64 * 64; fa.Wd = Lp + h->lo.wd;
             fa.bf = ub ? Lp + h->lo.bf : nullptr; fa.bg = ub ? Lp + h->lo.bg : nullptr; fa.bd = ub ? Lp + h->lo.bd : nullptr;
