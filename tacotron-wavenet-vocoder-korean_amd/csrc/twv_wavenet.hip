@@ -1667,14 +1667,11 @@ static int launch_generate2(const GenArgs& a, size_t shm, hipStream_t st)
 {
     auto kern = wn_generate_kernel<W, NTW, SCALAR, D, SPLIT1, INSTR, HELP>;
     if (shm > 32 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    // every workgroup of the launch spins on values other workgroups produce: a COOPERATIVE launch, so that the runtime itself
-    // guarantees (or refuses) co-residency of the whole grid instead of this code inferring it from the CU count alone
-    GenArgs arg = a;
-    void* params[] = {&arg};
-    const hipError_t e = hipLaunchCooperativeKernel((const void*)kern, dim3(a.B * a.G * (HELP ? 2 : 1)), dim3((1 + kLoaders + D + W) * 64), params,
-                                                    (unsigned)shm, st);
-    if (e == hipErrorCooperativeLaunchTooLarge) return fail(TWV_E_UNSUPPORTED, "the stream (+ helper) workgroups cannot all be resident on this device");
-    HIPCHK(e);
+    // Plain launch: co-residency of the grid is checked against the CU count by the caller (one workgroup per CU: ~150 KB of LDS each).
+    // hipLaunchCooperativeKernel would let the runtime guarantee it, and was measured: same speed on four boxes, but on a fifth the
+    // step took 25.45 instead of 21.3 us (and the Tacotron decoder 5 % longer) -- consistent with a different workgroup -> XCD
+    // placement, which this kernel's L2 locality (slice g of every stream on XCD g) depends on.
+    hipLaunchKernelGGL(kern, dim3(a.B * a.G * (HELP ? 2 : 1)), dim3((1 + kLoaders + D + W) * 64), shm, st, a);
     HIPCHK(hipGetLastError());
     return TWV_OK;
 }
