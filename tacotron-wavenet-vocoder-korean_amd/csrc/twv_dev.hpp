@@ -43,6 +43,84 @@ __device__ __forceinline__ float dot_readlane(const Tile& t, float xv)
     return (s01[0] + s01[1]) + (s23[0] + s23[1]);
 }
 
+// dot_readlane with the 32 v_readlane and the 16 v_pk_fma_f32 software-pipelined by hand (same operations, same order of the fma chains:
+// bit-identical).  The compiler emits all readlanes first and then the two dependent fma chains (16 x ~6 cycles of latency-bound
+// issue, scripts/ubench/vgpr_bank.hip); interleaved, the readlanes of pair i+3 fill the latency of fma i and the chunk is issue-bound.
+// Each SGPR pair is consumed >= 6 instructions after it is written; eight pairs s[84:99] rotate.
+__device__ __forceinline__ float dot_readlane_pipe(const Tile& t, float xv)
+{
+    f32x2p a, b;
+    asm volatile(
+        "v_readlane_b32 s84, %[x], 0\n"
+        "v_readlane_b32 s85, %[x], 1\n"
+        "v_readlane_b32 s86, %[x], 2\n"
+        "v_readlane_b32 s87, %[x], 3\n"
+        "v_readlane_b32 s88, %[x], 4\n"
+        "v_readlane_b32 s89, %[x], 5\n"
+        "v_pk_fma_f32 %[a], %[p0], s[84:85], 0 op_sel_hi:[1,1,0]\n"
+        "v_readlane_b32 s90, %[x], 6\n"
+        "v_readlane_b32 s91, %[x], 7\n"
+        "v_pk_fma_f32 %[b], %[p1], s[86:87], 0 op_sel_hi:[1,1,0]\n"
+        "v_readlane_b32 s92, %[x], 8\n"
+        "v_readlane_b32 s93, %[x], 9\n"
+        "v_pk_fma_f32 %[a], %[p2], s[88:89], %[a]\n"
+        "v_readlane_b32 s94, %[x], 10\n"
+        "v_readlane_b32 s95, %[x], 11\n"
+        "v_pk_fma_f32 %[b], %[p3], s[90:91], %[b]\n"
+        "v_readlane_b32 s96, %[x], 12\n"
+        "v_readlane_b32 s97, %[x], 13\n"
+        "v_pk_fma_f32 %[a], %[p4], s[92:93], %[a]\n"
+        "v_readlane_b32 s98, %[x], 14\n"
+        "v_readlane_b32 s99, %[x], 15\n"
+        "v_pk_fma_f32 %[b], %[p5], s[94:95], %[b]\n"
+        "v_readlane_b32 s84, %[x], 16\n"
+        "v_readlane_b32 s85, %[x], 17\n"
+        "v_pk_fma_f32 %[a], %[p6], s[96:97], %[a]\n"
+        "v_readlane_b32 s86, %[x], 18\n"
+        "v_readlane_b32 s87, %[x], 19\n"
+        "v_pk_fma_f32 %[b], %[p7], s[98:99], %[b]\n"
+        "v_readlane_b32 s88, %[x], 20\n"
+        "v_readlane_b32 s89, %[x], 21\n"
+        "v_pk_fma_f32 %[a], %[p8], s[84:85], %[a]\n"
+        "v_readlane_b32 s90, %[x], 22\n"
+        "v_readlane_b32 s91, %[x], 23\n"
+        "v_pk_fma_f32 %[b], %[p9], s[86:87], %[b]\n"
+        "v_readlane_b32 s92, %[x], 24\n"
+        "v_readlane_b32 s93, %[x], 25\n"
+        "v_pk_fma_f32 %[a], %[p10], s[88:89], %[a]\n"
+        "v_readlane_b32 s94, %[x], 26\n"
+        "v_readlane_b32 s95, %[x], 27\n"
+        "v_pk_fma_f32 %[b], %[p11], s[90:91], %[b]\n"
+        "v_readlane_b32 s96, %[x], 28\n"
+        "v_readlane_b32 s97, %[x], 29\n"
+        "v_pk_fma_f32 %[a], %[p12], s[92:93], %[a]\n"
+        "v_readlane_b32 s98, %[x], 30\n"
+        "v_readlane_b32 s99, %[x], 31\n"
+        "v_pk_fma_f32 %[b], %[p13], s[94:95], %[b]\n"
+        "v_pk_fma_f32 %[a], %[p14], s[96:97], %[a]\n"
+        "v_pk_fma_f32 %[b], %[p15], s[98:99], %[b]"
+        : [a] "=&v"(a), [b] "=&v"(b)
+        : [x] "v"(xv),
+          [p0] "v"(f32x2p{t.w[0], t.w[1]}),
+          [p1] "v"(f32x2p{t.w[2], t.w[3]}),
+          [p2] "v"(f32x2p{t.w[4], t.w[5]}),
+          [p3] "v"(f32x2p{t.w[6], t.w[7]}),
+          [p4] "v"(f32x2p{t.w[8], t.w[9]}),
+          [p5] "v"(f32x2p{t.w[10], t.w[11]}),
+          [p6] "v"(f32x2p{t.w[12], t.w[13]}),
+          [p7] "v"(f32x2p{t.w[14], t.w[15]}),
+          [p8] "v"(f32x2p{t.w[16], t.w[17]}),
+          [p9] "v"(f32x2p{t.w[18], t.w[19]}),
+          [p10] "v"(f32x2p{t.w[20], t.w[21]}),
+          [p11] "v"(f32x2p{t.w[22], t.w[23]}),
+          [p12] "v"(f32x2p{t.w[24], t.w[25]}),
+          [p13] "v"(f32x2p{t.w[26], t.w[27]}),
+          [p14] "v"(f32x2p{t.w[28], t.w[29]}),
+          [p15] "v"(f32x2p{t.w[30], t.w[31]})
+        : "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+    return (a[0] + a[1]) + (b[0] + b[1]);
+}
+
 // one chunk of AC-1, operand vector already in (uniform) registers
 __device__ __forceinline__ float dot_regs(const Tile& t, const float (&x)[32])
 {

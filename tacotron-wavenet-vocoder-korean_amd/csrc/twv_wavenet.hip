@@ -391,7 +391,7 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
             const int rdy = have_next ? LDSVI(c.o_ready + slot_n) : 0x7fffffff;
 
             // model.py:68-69 conv_filter | conv_gate: chunk(tap0) [precomputed by a loader] + chunk(tap1)
-            const float acc1 = dot_readlane(w1, x);
+            const float acc1 = dot_readlane_pipe(w1, x);
             float v = pre + acc1;
             if (use_bias) v = v + bfg;
             if (has_gc) v = v + gcv;      // model.py:71-73
@@ -412,7 +412,7 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
             if (fine) pp[75] = __builtin_amdgcn_s_memtime();
 
             // model.py:89 dense 1x1, model.py:98-101 residual
-            float tr = dot_readlane(wd, z);
+            float tr = dot_readlane_pipe(wd, z);
             if (use_bias) tr = tr + bd;
             x = x + tr;
             fetch_dense(sbn);
