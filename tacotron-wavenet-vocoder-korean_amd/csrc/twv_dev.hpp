@@ -51,6 +51,7 @@ __device__ __forceinline__ float dot_readlane_pipe(const Tile& t, float xv)
 {
     f32x2p a, b;
     asm volatile(
+        "s_nop 1\n"                                    // the operand may come straight out of a VALU instruction: hazards inside inline asm are ours
         "v_readlane_b32 s84, %[x], 0\n"
         "v_readlane_b32 s85, %[x], 1\n"
         "v_readlane_b32 s86, %[x], 2\n"
@@ -96,6 +97,82 @@ __device__ __forceinline__ float dot_readlane_pipe(const Tile& t, float xv)
         "v_pk_fma_f32 %[a], %[p12], s[92:93], %[a]\n"
         "v_readlane_b32 s98, %[x], 30\n"
         "v_readlane_b32 s99, %[x], 31\n"
+        "v_pk_fma_f32 %[b], %[p13], s[94:95], %[b]\n"
+        "v_pk_fma_f32 %[a], %[p14], s[96:97], %[a]\n"
+        "v_pk_fma_f32 %[b], %[p15], s[98:99], %[b]"
+        : [a] "=&v"(a), [b] "=&v"(b)
+        : [x] "v"(xv),
+          [p0] "v"(f32x2p{t.w[0], t.w[1]}),
+          [p1] "v"(f32x2p{t.w[2], t.w[3]}),
+          [p2] "v"(f32x2p{t.w[4], t.w[5]}),
+          [p3] "v"(f32x2p{t.w[6], t.w[7]}),
+          [p4] "v"(f32x2p{t.w[8], t.w[9]}),
+          [p5] "v"(f32x2p{t.w[10], t.w[11]}),
+          [p6] "v"(f32x2p{t.w[12], t.w[13]}),
+          [p7] "v"(f32x2p{t.w[14], t.w[15]}),
+          [p8] "v"(f32x2p{t.w[16], t.w[17]}),
+          [p9] "v"(f32x2p{t.w[18], t.w[19]}),
+          [p10] "v"(f32x2p{t.w[20], t.w[21]}),
+          [p11] "v"(f32x2p{t.w[22], t.w[23]}),
+          [p12] "v"(f32x2p{t.w[24], t.w[25]}),
+          [p13] "v"(f32x2p{t.w[26], t.w[27]}),
+          [p14] "v"(f32x2p{t.w[28], t.w[29]}),
+          [p15] "v"(f32x2p{t.w[30], t.w[31]})
+        : "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+    return (a[0] + a[1]) + (b[0] + b[1]);
+}
+
+// the same with the operand vector in lanes 32..63 of `xv` (helper workgroups: second chunk of a wave)
+__device__ __forceinline__ float dot_readlane_pipe32(const Tile& t, float xv)
+{
+    f32x2p a, b;
+    asm volatile(
+        "s_nop 1\n"
+        "v_readlane_b32 s84, %[x], 32\n"
+        "v_readlane_b32 s85, %[x], 33\n"
+        "v_readlane_b32 s86, %[x], 34\n"
+        "v_readlane_b32 s87, %[x], 35\n"
+        "v_readlane_b32 s88, %[x], 36\n"
+        "v_readlane_b32 s89, %[x], 37\n"
+        "v_pk_fma_f32 %[a], %[p0], s[84:85], 0 op_sel_hi:[1,1,0]\n"
+        "v_readlane_b32 s90, %[x], 38\n"
+        "v_readlane_b32 s91, %[x], 39\n"
+        "v_pk_fma_f32 %[b], %[p1], s[86:87], 0 op_sel_hi:[1,1,0]\n"
+        "v_readlane_b32 s92, %[x], 40\n"
+        "v_readlane_b32 s93, %[x], 41\n"
+        "v_pk_fma_f32 %[a], %[p2], s[88:89], %[a]\n"
+        "v_readlane_b32 s94, %[x], 42\n"
+        "v_readlane_b32 s95, %[x], 43\n"
+        "v_pk_fma_f32 %[b], %[p3], s[90:91], %[b]\n"
+        "v_readlane_b32 s96, %[x], 44\n"
+        "v_readlane_b32 s97, %[x], 45\n"
+        "v_pk_fma_f32 %[a], %[p4], s[92:93], %[a]\n"
+        "v_readlane_b32 s98, %[x], 46\n"
+        "v_readlane_b32 s99, %[x], 47\n"
+        "v_pk_fma_f32 %[b], %[p5], s[94:95], %[b]\n"
+        "v_readlane_b32 s84, %[x], 48\n"
+        "v_readlane_b32 s85, %[x], 49\n"
+        "v_pk_fma_f32 %[a], %[p6], s[96:97], %[a]\n"
+        "v_readlane_b32 s86, %[x], 50\n"
+        "v_readlane_b32 s87, %[x], 51\n"
+        "v_pk_fma_f32 %[b], %[p7], s[98:99], %[b]\n"
+        "v_readlane_b32 s88, %[x], 52\n"
+        "v_readlane_b32 s89, %[x], 53\n"
+        "v_pk_fma_f32 %[a], %[p8], s[84:85], %[a]\n"
+        "v_readlane_b32 s90, %[x], 54\n"
+        "v_readlane_b32 s91, %[x], 55\n"
+        "v_pk_fma_f32 %[b], %[p9], s[86:87], %[b]\n"
+        "v_readlane_b32 s92, %[x], 56\n"
+        "v_readlane_b32 s93, %[x], 57\n"
+        "v_pk_fma_f32 %[a], %[p10], s[88:89], %[a]\n"
+        "v_readlane_b32 s94, %[x], 58\n"
+        "v_readlane_b32 s95, %[x], 59\n"
+        "v_pk_fma_f32 %[b], %[p11], s[90:91], %[b]\n"
+        "v_readlane_b32 s96, %[x], 60\n"
+        "v_readlane_b32 s97, %[x], 61\n"
+        "v_pk_fma_f32 %[a], %[p12], s[92:93], %[a]\n"
+        "v_readlane_b32 s98, %[x], 62\n"
+        "v_readlane_b32 s99, %[x], 63\n"
         "v_pk_fma_f32 %[b], %[p13], s[94:95], %[b]\n"
         "v_pk_fma_f32 %[a], %[p14], s[96:97], %[a]\n"
         "v_pk_fma_f32 %[b], %[p15], s[98:99], %[b]"

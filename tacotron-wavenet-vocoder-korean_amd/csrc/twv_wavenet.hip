@@ -342,7 +342,7 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
             float s_in = (t == 0) ? first_in : s_lds;
             if (a.forced != nullptr) s_in = reinterpret_cast<const float*>(a.forced)[(long long)b * T + t];
             hv = (lane == 31) ? s_in : sh;
-            x = dot_readlane(tc0, hv);
+            x = dot_readlane_pipe(tc0, hv);
         } else if (SCALAR) {
             const float s_lds = lds[ctl + C_SAMPLE];
             float s_in = (t == 0) ? first_in : s_lds;
@@ -1086,8 +1086,8 @@ __device__ __forceinline__ void helper_main(const GenArgs& a, int b, int g)
         unsigned long long* hp = a.prof + (long long)t * 80;
         if (hprof) hp[52] = __builtin_amdgcn_s_memtime();      // h1 seen
         const float x = __uint_as_float((unsigned)q);
-        lds[o_part + i0 * 64 + lane] = dot_readlane_off<0>(ta, x);
-        if (has1) lds[o_part + i1 * 64 + lane] = dot_readlane_off<32>(tb, x);
+        lds[o_part + i0 * 64 + lane] = dot_readlane_pipe(ta, x);
+        if (has1) lds[o_part + i1 * 64 + lane] = dot_readlane_pipe32(tb, x);
         arrive(o_cnt, lane);
         if (hprof) hp[53] = __builtin_amdgcn_s_memtime();      // own partials stored
         if (summer) {                                                           // owner of output block mb
@@ -1116,10 +1116,10 @@ __device__ __forceinline__ void helper_main(const GenArgs& a, int b, int g)
             if (CONV2) {
                 const unsigned ep2 = 2u * (unsigned)t + 2u;
                 if (two) {
-                    const float p = (v == 0) ? dot_readlane_off<0>(t2a, h) : dot_readlane_off<32>(t2a, h);
+                    const float p = (v == 0) ? dot_readlane_pipe(t2a, h) : dot_readlane_pipe32(t2a, h);
                     if (lane < 32) granule_store(X2 + (2 * g + v) * 32 + lane, ep2, p);
                 } else {
-                    const float p0 = dot_readlane_off<0>(t2a, h), p1 = dot_readlane_off<32>(t2b, h);
+                    const float p0 = dot_readlane_pipe(t2a, h), p1 = dot_readlane_pipe32(t2b, h);
                     if (lane < 32) {
                         granule_store(X2 + (2 * g) * 32 + lane, ep2, p0);
                         if (2 * g + 1 < NCH) granule_store(X2 + (2 * g + 1) * 32 + lane, ep2, p1);
