@@ -1,0 +1,136 @@
+// twv_dpp.hpp -- the AC-1 chunk and the residual-layer body in the ROW-BROADCAST lane layout (gfx950).
+//
+// A 32-term chunk of the arithmetic contract (four interleaved fma chains j = k mod 4, each from +0 in ascending k,
+// value (s0+s1)+(s2+s3)) needs every output lane to see operand x[k] at step k.  v_readlane + v_pk_fma_f32 spends 48 issue slots on
+// it; here the operand vector sits in the lanes of one row (16 lanes) and `v_fmac_f32_dpp ... row_newbcast:n` (DPP control 0x150+n:
+// lane n of each row to the whole row) feeds it to the fma directly: 32 instructions, no scalar registers, same fmas in the same order.
+//
+// Lane layouts (lane = 16*row + n):
+//   X  (layer input / residual, 32 values):  rows 0,1: x[n]        rows 2,3: x[16+n]
+//   XA = all rows x[n], XB = all rows x[16+n]:  ONE v_permlane32_swap of (X, X)
+//   conv output of lane (model.py:68-69 conv_filter | conv_gate):  row 0: f[a(n)]  row 1: f[b(n)]  row 2: g[a(n)]  row 3: g[b(n)]
+//        a(n) = 4*(n/2) + n%2  (k = 0,1,4,5,...: chains 0 and 1),   b(n) = a(n) + 2  (chains 2 and 3)
+//   Z  (gated output, model.py:86) after v_permlane32_swap + multiply:  rows 0,2: z[a(n)]   rows 1,3: z[b(n)]
+//   dense 1x1 (model.py:89), 32 outputs on 64 lanes: lane (row, n) owns output n + 16*(row/2) and HALF of its chunk -- even rows the
+//        chains 0,1 (k = a(i)), odd rows the chains 2,3 (k = b(i)) -- 16 fmas, then (s0+s1) | (s2+s3) meet through ONE
+//        v_permlane16_swap: exactly AC-1's (s0+s1)+(s2+s3), and the result lands in the X layout again.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "twv_math.hpp"
+
+namespace twv {
+
+__host__ __device__ inline int dpp_a(int n) { return 4 * (n >> 1) + (n & 1); }
+// conv output (0..31 filter, 32..63 gate) owned by a lane
+__host__ __device__ inline int dpp_conv_out(int lane) { const int r = lane >> 4, n = lane & 15; return ((r >> 1) ? 32 : 0) + dpp_a(n) + ((r & 1) ? 2 : 0); }
+// dense output / residual element owned by a lane
+__host__ __device__ inline int dpp_dense_out(int lane) { return (lane & 15) + 16 * (lane >> 5); }
+// reduction index of a lane's i-th dense fma
+__host__ __device__ inline int dpp_dense_k(int lane, int i) { return dpp_a(i) + (((lane >> 4) & 1) ? 2 : 0); }
+// z element held by a lane of the Z layout
+__host__ __device__ inline int dpp_z_index(int lane) { return dpp_a(lane & 15) + (((lane >> 4) & 1) ? 2 : 0); }
+
+// one layer's chain operands, register-resident for the whole launch (51 VGPRs)
+struct LayerRegs {
+    float wc[32];          // tap-1 conv kernel column of this lane's conv output
+    float wd[16];          // this lane's half of the dense kernel column
+    float bfg, gcv, bd;    // conv bias, gc projection (model.py:71-73), dense bias
+};
+
+// 32-term AC-1 chunk: acc_j += w[k] * x[k]  (k = 0..15 from XA, 16..31 from XB)
+__device__ __forceinline__ float dot32_dpp(const float (&w)[32], float xa, float xb)
+{
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+    asm volatile(
+        "s_nop 1\n"
+        "v_fmac_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %10 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %19 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %20 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+        : "v"(xa), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
+    asm volatile(
+        "s_nop 1\n"
+        "v_fmac_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %10 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %19 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %20 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+        : "v"(xb), "v"(w[16]), "v"(w[17]), "v"(w[18]), "v"(w[19]), "v"(w[20]), "v"(w[21]), "v"(w[22]), "v"(w[23]), "v"(w[24]), "v"(w[25]), "v"(w[26]), "v"(w[27]), "v"(w[28]), "v"(w[29]), "v"(w[30]), "v"(w[31]));
+    return (c0 + c1) + (c2 + c3);
+}
+
+// a lane's half of a 32-term chunk: two chains, 16 terms, operand vector in the Z layout
+__device__ __forceinline__ float dot16_dpp(const float (&w)[16], float z)
+{
+    float c0 = 0.0f, c1 = 0.0f;
+    asm volatile(
+        "s_nop 1\n"
+        "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(c0), "+v"(c1)
+        : "v"(z), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
+    return c0 + c1;
+}
+
+// model.py:66-101 for one step of one stream; X in / out in the X layout, returns z in the Z layout.
+// pre = tap-0 chunk (x[t-d], computed off the chain), lcv = lc projection (model.py:75-83); statement order of the reference:
+// ((conv + bias) + gc) + lc, conv = chunk(tap 0) + chunk(tap 1).
+__device__ __forceinline__ float layer_body_dpp(const LayerRegs& W, const ActCoef& coef, float& X, float pre, float lcv)
+{
+    const auto xs = __builtin_amdgcn_permlane32_swap(__float_as_uint(X), __float_as_uint(X), false, false);
+    const float acc1 = dot32_dpp(W.wc, __uint_as_float(xs[0]), __uint_as_float(xs[1]));
+    float v = pre + acc1;
+    v = v + W.bfg;
+    v = v + W.gcv;
+    v = v + lcv;
+    const float act = act_eval_pk(coef, v);                                  // model.py:86: lanes 0-31 tanh, 32-63 logistic
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
+    const float z = __uint_as_float(sw[0]) * __uint_as_float(sw[1]);
+    const float s = dot16_dpp(W.wd, z);                                      // model.py:89 dense 1x1
+    const auto ds = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    float tr = __uint_as_float(ds[0]) + __uint_as_float(ds[1]);
+    tr = tr + W.bd;
+    X = X + tr;                                                              // model.py:98-101 residual
+    return z;
+}
+
+}  // namespace twv
