@@ -78,6 +78,19 @@ int twv_wavenet_upsample(const twv_wavenet* h, const void* packed, const float* 
 int twv_wavenet_condition(const twv_wavenet* h, const void* packed, const float* upsampled, const int32_t* gc_ids,
                           int batch, int n_steps, void* cond, void* stream);
 
+/* Fused conditioning: when the XCD-per-stream kernel serves this (handle, batch) -- see the "xcd"
+ * option -- create_upsample (model.py:102-111) and the lc projections (model.py:75-83) run INSIDE the generation launch, row by
+ * row, ahead of the sample loop: neither the (B, T, lc) upsampled tensor nor a projection table is ever materialised.
+ *   twv_wavenet_fused_conditioning : 1 if available for this handle and batch, else 0
+ *   twv_wavenet_cond_bytes_mel     : size of `cond` for twv_wavenet_condition_mel
+ *   twv_wavenet_condition_mel      : mel (B, t_mel, lc) as generate.py:151 hands it over, gc_ids (B) -> cond; the following
+ *                                    twv_wavenet_generate call may run up to t_mel*hop steps (row t = frame pushed at step t).
+ * Results are bit-identical to twv_wavenet_upsample + twv_wavenet_condition. */
+int twv_wavenet_fused_conditioning(const twv_wavenet* h, int batch);
+size_t twv_wavenet_cond_bytes_mel(const twv_wavenet* h, int batch, int t_mel);
+int twv_wavenet_condition_mel(const twv_wavenet* h, const void* packed, const float* mel, const int32_t* gc_ids,
+                              int batch, int t_mel, void* cond, void* stream);
+
 /* predict_proba_incremental (model.py:215-245) iterated by the generate.py:202-233 host loop, as ONE persistent
  * kernel launch per call: n_steps autoregressive steps for `batch` independent streams.
  *   first_input : (B) the sample fed at step 0 (generate.py:204 waveform[:,-1:]); float32 when scalar_input,
@@ -104,7 +117,12 @@ int twv_wavenet_prime(const twv_wavenet* h, const void* packed, void* state, con
 /* synchronises `stream` and converts a non-zero status word into TWV_E_KERNEL. */
 int twv_wavenet_status(const int32_t* status, void* stream);
 
-/* launch geometry knobs (performance only, results are bit-identical): "groups" = workgroups per stream (0 auto), "workers" =
+/* launch geometry knobs (performance only, results are bit-identical): "xcd" = 1 (default): the XCD-per-stream kernel
+ * (one stream per XCD, every weight register-resident across the XCD's CUs, fused conditioning) whenever the model is the
+ * hparams-default MoL shape (scalar input, initial_filter_width 32, skip_channels 512, out_channels <= 32, <= 30 layers),
+ * batch <= 8 and the device has 256 CUs; 0 = always the generic kernel.  Set it (and "groups") BEFORE sizing / resetting the
+ * state and conditioning buffers.  "groups" = workgroups per stream of the generic kernel (0 auto; an explicit value also selects
+ * the generic kernel), "workers" =
  * worker waves per stream workgroup (4 | 3), "helpers" = 1 (default: conv1d_1 and conv1d_2's chunk partials run in one helper
  * workgroup per stream slice when twice the workgroups are co-resident) | 2 (conv1d_1 only) | 0 (none). */
 int twv_wavenet_set_option(twv_wavenet* h, const char* name, int value);

@@ -47,7 +47,7 @@ __device__ __forceinline__ float dot_readlane(const Tile& t, float xv)
 // bit-identical).  The compiler emits all readlanes first and then the two dependent fma chains (16 x ~6 cycles of latency-bound
 // issue, scripts/ubench/vgpr_bank.hip); interleaved, the readlanes of pair i+3 fill the latency of fma i and the chunk is issue-bound.
 // Each SGPR pair is consumed >= 6 instructions after it is written; eight pairs s[84:99] rotate.
-__device__ __forceinline__ float dot_readlane_pipe(const Tile& t, float xv)
+__device__ __forceinline__ float dot_readlane_pipe_a(const float (&tw)[32], float xv)
 {
     f32x2p a, b;
     asm volatile(
@@ -102,25 +102,27 @@ __device__ __forceinline__ float dot_readlane_pipe(const Tile& t, float xv)
         "v_pk_fma_f32 %[b], %[p15], s[98:99], %[b]"
         : [a] "=&v"(a), [b] "=&v"(b)
         : [x] "v"(xv),
-          [p0] "v"(f32x2p{t.w[0], t.w[1]}),
-          [p1] "v"(f32x2p{t.w[2], t.w[3]}),
-          [p2] "v"(f32x2p{t.w[4], t.w[5]}),
-          [p3] "v"(f32x2p{t.w[6], t.w[7]}),
-          [p4] "v"(f32x2p{t.w[8], t.w[9]}),
-          [p5] "v"(f32x2p{t.w[10], t.w[11]}),
-          [p6] "v"(f32x2p{t.w[12], t.w[13]}),
-          [p7] "v"(f32x2p{t.w[14], t.w[15]}),
-          [p8] "v"(f32x2p{t.w[16], t.w[17]}),
-          [p9] "v"(f32x2p{t.w[18], t.w[19]}),
-          [p10] "v"(f32x2p{t.w[20], t.w[21]}),
-          [p11] "v"(f32x2p{t.w[22], t.w[23]}),
-          [p12] "v"(f32x2p{t.w[24], t.w[25]}),
-          [p13] "v"(f32x2p{t.w[26], t.w[27]}),
-          [p14] "v"(f32x2p{t.w[28], t.w[29]}),
-          [p15] "v"(f32x2p{t.w[30], t.w[31]})
+          [p0] "v"(f32x2p{tw[0], tw[1]}),
+          [p1] "v"(f32x2p{tw[2], tw[3]}),
+          [p2] "v"(f32x2p{tw[4], tw[5]}),
+          [p3] "v"(f32x2p{tw[6], tw[7]}),
+          [p4] "v"(f32x2p{tw[8], tw[9]}),
+          [p5] "v"(f32x2p{tw[10], tw[11]}),
+          [p6] "v"(f32x2p{tw[12], tw[13]}),
+          [p7] "v"(f32x2p{tw[14], tw[15]}),
+          [p8] "v"(f32x2p{tw[16], tw[17]}),
+          [p9] "v"(f32x2p{tw[18], tw[19]}),
+          [p10] "v"(f32x2p{tw[20], tw[21]}),
+          [p11] "v"(f32x2p{tw[22], tw[23]}),
+          [p12] "v"(f32x2p{tw[24], tw[25]}),
+          [p13] "v"(f32x2p{tw[26], tw[27]}),
+          [p14] "v"(f32x2p{tw[28], tw[29]}),
+          [p15] "v"(f32x2p{tw[30], tw[31]})
         : "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
     return (a[0] + a[1]) + (b[0] + b[1]);
 }
+
+__device__ __forceinline__ float dot_readlane_pipe(const Tile& t, float xv) { return dot_readlane_pipe_a(t.w, xv); }
 
 // the same with the operand vector in lanes 32..63 of `xv` (helper workgroups: second chunk of a wave)
 __device__ __forceinline__ float dot_readlane_pipe32(const Tile& t, float xv)

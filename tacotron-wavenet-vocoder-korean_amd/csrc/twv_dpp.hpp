@@ -114,23 +114,30 @@ __device__ __forceinline__ float dot16_dpp(const float (&w)[16], float z)
 // model.py:66-101 for one step of one stream; X in / out in the X layout, returns z in the Z layout.
 // pre = tap-0 chunk (x[t-d], computed off the chain), lcv = lc projection (model.py:75-83); statement order of the reference:
 // ((conv + bias) + gc) + lc, conv = chunk(tap 0) + chunk(tap 1).
-__device__ __forceinline__ float layer_body_dpp(const LayerRegs& W, const ActCoef& coef, float& X, float pre, float lcv)
+__device__ __forceinline__ float layer_body_dpp2(const float (&wc)[32], const float (&wd)[16], float bfg, float gcv, float bd,
+                                                 const ActCoef& coef, float& X, float pre, float lcv, bool use_bias, bool has_gc,
+                                                 bool has_lc)
 {
     const auto xs = __builtin_amdgcn_permlane32_swap(__float_as_uint(X), __float_as_uint(X), false, false);
-    const float acc1 = dot32_dpp(W.wc, __uint_as_float(xs[0]), __uint_as_float(xs[1]));
+    const float acc1 = dot32_dpp(wc, __uint_as_float(xs[0]), __uint_as_float(xs[1]));
     float v = pre + acc1;
-    v = v + W.bfg;
-    v = v + W.gcv;
-    v = v + lcv;
+    if (use_bias) v = v + bfg;
+    if (has_gc) v = v + gcv;                                                 // model.py:71-73
+    if (has_lc) v = v + lcv;                                                 // model.py:75-83
     const float act = act_eval_pk(coef, v);                                  // model.py:86: lanes 0-31 tanh, 32-63 logistic
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
     const float z = __uint_as_float(sw[0]) * __uint_as_float(sw[1]);
-    const float s = dot16_dpp(W.wd, z);                                      // model.py:89 dense 1x1
+    const float s = dot16_dpp(wd, z);                                        // model.py:89 dense 1x1
     const auto ds = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
     float tr = __uint_as_float(ds[0]) + __uint_as_float(ds[1]);
-    tr = tr + W.bd;
+    if (use_bias) tr = tr + bd;
     X = X + tr;                                                              // model.py:98-101 residual
     return z;
+}
+__device__ __forceinline__ float layer_body_dpp(const LayerRegs& W, const ActCoef& coef, float& X, float pre, float lcv,
+                                                bool use_bias = true, bool has_gc = true, bool has_lc = true)
+{
+    return layer_body_dpp2(W.wc, W.wd, W.bfg, W.gcv, W.bd, coef, X, pre, lcv, use_bias, has_gc, has_lc);
 }
 
 }  // namespace twv

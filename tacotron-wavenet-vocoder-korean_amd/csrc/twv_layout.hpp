@@ -61,6 +61,7 @@ struct Layout {
     long long off_gcw, gcw_stride;   // per layer NGC tiles: gc_filter|gc_gate
     long long off_gcemb;             // [card][G]
     long long off_up[4];             // [f][2]
+    long long off_xl, off_xc;        // XCD path (twv_wavenet_xcd.hip): per layer the chain's register image; causal kernel in its lane order (0 = absent)
     long long packed_floats;
     // canonical blob offsets (floats): TF checkpoint tensors, order of DESIGN.md
     long long c_causal, c_gcemb, c_layer0, c_layer_stride;

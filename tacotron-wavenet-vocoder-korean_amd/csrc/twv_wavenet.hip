@@ -27,6 +27,7 @@
 #include "twv_layout.hpp"
 #include "twv_math.hpp"
 #include "twv_dev.hpp"
+#include "twv_xcd.hpp"
 
 using namespace twv;
 
@@ -1336,6 +1337,7 @@ struct twv_wavenet {
     int groups;    // workgroups per stream (0 = auto)
     int helpers;   // 1 = helper workgroups when the launch qualifies (conv1d_1, and conv1d_2's partials if O <= 32; default),
                    // 2 = conv1d_1 only, 0 = never
+    int xcd;       // 1 (default) = the XCD-per-stream kernel (twv_wavenet_xcd.hip) whenever model, batch and device qualify; 0 = never
     unsigned long long* prof;
     int prof_steps;
 };
@@ -1402,6 +1404,8 @@ static int build_layout(const twv_wavenet_dims& d, twv_wavenet* h)
     L.off_gcw = p; L.gcw_stride = (long long)L.NGC * kTile; p += L.gcw_stride * L.NL;
     L.off_gcemb = p; p += align_up((long long)L.gc_card * L.G, 4);
     for (int i = 0; i < L.n_up; ++i) { L.off_up[i] = p; p += align_up((long long)L.up[i] * 2, 4); }
+    L.off_xl = 0; L.off_xc = 0;
+    if (xcd_model_ok(L)) { L.off_xl = p; p += (long long)kXcdXlFloats * L.NL; L.off_xc = p; p += kXcdXcFloats; }
     L.packed_floats = p;
     // ---- canonical blob (must match DESIGN.md "canonical blob"; mirrored by the checker independently)
     long long c = 0;
@@ -1443,9 +1447,15 @@ static int device_cus()
 }
 // workgroups per stream: explicit option, else the largest of 8/4/2/1 that divides the output blocks and keeps every
 // workgroup of the launch co-resident (one workgroup per CU: the LDS slot ring takes most of the 160 KiB)
+// the XCD-per-stream kernel: one stream per XCD (8 x 32 CUs), explicit `groups` keeps the generic kernel
+static bool use_xcd(const twv_wavenet* h, int batch)
+{
+    return h->xcd != 0 && h->groups == 0 && h->lay.off_xl != 0 && batch >= 1 && batch <= kXcdStreams && device_cus() >= 256;
+}
 static int resolve_groups(const twv_wavenet* h, int batch)
 {
     const int NSJ = h->lay.NSJ;
+    if (use_xcd(h, batch)) return 1;
     if (h->groups > 0) return (NSJ % h->groups == 0) ? h->groups : -1;
     const int cus = device_cus();
     for (int g = 8; g >= 1; g >>= 1)
@@ -1477,6 +1487,7 @@ extern "C" int twv_wavenet_create(const twv_wavenet_dims* dims, twv_wavenet** ou
     h->workers = 4;
     h->helpers = 1;
     h->groups = 0;
+    h->xcd = 1;
     h->prof = nullptr; h->prof_steps = 0;
     const int rc = build_layout(*dims, h);
     if (rc != TWV_OK) { delete h; return rc; }
@@ -1505,10 +1516,12 @@ extern "C" size_t twv_wavenet_state_bytes(const twv_wavenet* h, int batch)
     // per (stream, workgroup) delay lines etc., then the all-gather granules [B][2][S] x 8 bytes
     int G = resolve_groups(h, batch);
     if (G < 1) G = 1;
-    return (size_t)h->lay.state_stride * 4 * (size_t)batch * G + (size_t)batch * 2 * h->lay.S * 8;
+    return (size_t)h->lay.state_stride * 4 * (size_t)batch * G + (size_t)batch * 2 * h->lay.S * 8 + (use_xcd(h, batch) ? xcd_exchange_bytes(batch) : 0);
 }
 extern "C" size_t twv_wavenet_cond_bytes(const twv_wavenet* h, int batch, int n_steps)
 {
+    // XCD path: header + gc projections + the rows of the (upsampled) condition; the lc projections are made inside the launch
+    if (use_xcd(h, batch)) return ((size_t)XH_WORDS + (size_t)batch * h->lay.NL * 64 + (size_t)batch * (size_t)n_steps * h->lay.L) * 4;
     return ((size_t)batch * h->lay.NL * 64 + (size_t)batch * (size_t)n_steps * h->lay.NL * 64) * 4;
 }
 extern "C" int twv_wavenet_set_profile_buffer(twv_wavenet* h, void* dev_u64, int steps)
@@ -1528,6 +1541,11 @@ extern "C" int twv_wavenet_set_option(twv_wavenet* h, const char* name, int valu
     if (!strcmp(name, "workers")) {
         if (value != 4 && value != 3) return fail(TWV_E_INVALID, "workers must be 4 or 3 (3 = idle wave beside the chain wave)");
         h->workers = value;
+        return TWV_OK;
+    }
+    if (!strcmp(name, "xcd")) {      // set BEFORE sizing / resetting the state and conditioning buffers
+        if (value != 0 && value != 1) return fail(TWV_E_INVALID, "xcd must be 0 or 1");
+        h->xcd = value;
         return TWV_OK;
     }
     if (!strcmp(name, "groups")) {   // workgroups per stream; set BEFORE sizing / resetting the state buffer
@@ -1602,6 +1620,7 @@ extern "C" int twv_wavenet_pack(const twv_wavenet* h, const float* blob, void* p
     }
     for (int i = 0; i < L.n_up; ++i)
         hipLaunchKernelGGL(wn_copy_kernel, dim3(1), dim3(256), 0, st, dst + L.off_up[i], blob + L.c_up[i], (long long)L.up[i] * 2);
+    if (L.off_xl) xcd_pack(dst, blob, L, st);
     HIPCHK(hipGetLastError());
     return TWV_OK;
 }
@@ -1636,12 +1655,54 @@ extern "C" int twv_wavenet_upsample(const twv_wavenet* h, const void* packed, co
     return TWV_OK;
 }
 
+// XCD path: cond = [header][gc projections][rows]; the rows are the upsampled condition (mode XLC_UPSAMPLED) or the mel frames
+// themselves (XLC_MEL: create_upsample runs row by row inside the generation launch)
+__global__ void wn_xcd_hdr_kernel(int* hdr, int mode, int rows)
+{
+    if (threadIdx.x < XH_WORDS) hdr[threadIdx.x] = threadIdx.x == XH_MAGIC ? kXcdCondMagic : (threadIdx.x == XH_MODE ? mode : (threadIdx.x == XH_ROWS ? rows : 0));
+}
+static int xcd_condition(const twv_wavenet* h, const void* packed, const float* rowsrc, int mode, const int32_t* gc_ids, int batch,
+                         int rows, void* cond, hipStream_t st)
+{
+    const Layout& L = h->lay;
+    const float* P = (const float*)packed;
+    float* GCv = (float*)cond + XH_WORDS;
+    if (!L.L) mode = XLC_NONE;
+    hipLaunchKernelGGL(wn_xcd_hdr_kernel, dim3(1), dim3(64), 0, st, (int*)cond, mode, rows);
+    if (L.G) {
+        if (!gc_ids) return fail(TWV_E_INVALID, "gc_ids required (generate.py:72-77)");
+        hipLaunchKernelGGL(wn_gc_kernel, dim3(batch), dim3(64), 0, st, P, L, gc_ids, GCv);
+    } else {
+        HIPCHK(hipMemsetAsync(GCv, 0, (size_t)batch * L.NL * 64 * 4, st));
+    }
+    if (mode != XLC_NONE && rows > 0) {
+        if (!rowsrc) return fail(TWV_E_INVALID, "local condition required");
+        twv_launch_copy(GCv + (size_t)batch * L.NL * 64, rowsrc, (long long)batch * rows * L.L, st);
+    }
+    HIPCHK(hipGetLastError());
+    return TWV_OK;
+}
+extern "C" int twv_wavenet_fused_conditioning(const twv_wavenet* h, int batch) { return (h && use_xcd(h, batch) && h->lay.L > 0) ? 1 : 0; }
+extern "C" size_t twv_wavenet_cond_bytes_mel(const twv_wavenet* h, int batch, int t_mel)
+{
+    return ((size_t)XH_WORDS + (size_t)batch * h->lay.NL * 64 + (size_t)batch * (size_t)t_mel * h->lay.L) * 4;
+}
+extern "C" int twv_wavenet_condition_mel(const twv_wavenet* h, const void* packed, const float* mel, const int32_t* gc_ids,
+                                         int batch, int t_mel, void* cond, void* stream)
+{
+    if (!h || !packed || !cond || !mel || batch < 1 || t_mel < 1) return fail(TWV_E_INVALID, "bad argument");
+    if (!twv_wavenet_fused_conditioning(h, batch))
+        return fail(TWV_E_UNSUPPORTED, "fused conditioning needs the XCD-per-stream kernel (see twv_wavenet_fused_conditioning); use twv_wavenet_upsample + twv_wavenet_condition");
+    return xcd_condition(h, packed, mel, XLC_MEL, gc_ids, batch, t_mel, cond, (hipStream_t)stream);
+}
+
 extern "C" int twv_wavenet_condition(const twv_wavenet* h, const void* packed, const float* upsampled, const int32_t* gc_ids,
                                      int batch, int n_steps, void* cond, void* stream)
 {
     if (!h || !packed || !cond || batch < 1 || n_steps < 0) return fail(TWV_E_INVALID, "bad argument");
     const Layout& L = h->lay;
     hipStream_t st = (hipStream_t)stream;
+    if (use_xcd(h, batch)) return xcd_condition(h, packed, upsampled, XLC_UPSAMPLED, gc_ids, batch, n_steps, cond, st);
     const float* P = (const float*)packed;
     float* GCv = (float*)cond;
     float* LC = GCv + (size_t)batch * L.NL * 64;
@@ -1700,6 +1761,18 @@ static int generate_impl(const twv_wavenet* h, const void* packed, void* state, 
     a.uniforms = uniforms; a.out = out; a.status = status; a.dbg = debug; a.dbg_steps = debug ? debug_steps : 0;
     a.prof = h->prof; a.prof_steps = h->prof ? h->prof_steps : 0;
     a.B = batch; a.T = n_steps; a.temperature = (float)temperature; a.lay = L;
+    if (use_xcd(h, batch)) {
+        // one stream per XCD, every weight register-resident across the XCD's CUs (twv_wavenet_xcd.hip)
+        XcdLaunch x;
+        x.P = a.P; x.state = a.state; x.cond = a.cond; x.first_input = first_input; x.forced = forced;
+        x.uniforms = (const float*)uniforms; x.out = (float*)out; x.status = status; x.dbg = debug; x.dbg_steps = a.dbg_steps;
+        x.B = batch; x.T = n_steps; x.lay = L;
+        unsigned char* xb = reinterpret_cast<unsigned char*>((float*)state + (size_t)L.state_stride * (size_t)batch) + (size_t)batch * 2 * L.S * 8;
+        HIPCHK(hipMemsetAsync(xb, 0, xcd_exchange_bytes(batch), st));
+        x.exch = reinterpret_cast<unsigned long long*>(xb);
+        x.roles = reinterpret_cast<int*>(xb + (size_t)batch * XcdExch::WORDS * 8);
+        return xcd_launch(x, st);
+    }
     const int G = resolve_groups(h, batch);
     if (G < 1) return fail(TWV_E_INVALID, "groups option does not divide skip_channels/64");
     if ((long long)batch * G > device_cus())

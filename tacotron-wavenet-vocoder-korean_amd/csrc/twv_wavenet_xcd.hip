@@ -1,0 +1,797 @@
+// twv_wavenet_xcd.hip -- the XCD-per-stream WaveNet generation kernel (MI355X: 8 XCDs x 32 CUs, 4 MiB L2 and 16 MB of
+// vector registers per XCD).
+//
+// Replaces, for the hparams-default MoL vocoder (wavenet/model.py:41-167,215-245, wavenet/mixture.py:84-114, generate.py:199-233;
+// scalar input, initial_filter_width 32, R = D = 32, S = 512, out_channels <= 32, up to 31 layers, batch <= 8):
+// the same per-sample chain as wn_generate_kernel (twv_wavenet.hip), but laid out for the chip instead of for one CU:
+//
+//   * ONE STREAM PER XCD.  Every workgroup reads its XCC id and takes a role ticket of that XCD, so all workgroups of a stream
+//     share one L2: a hand-off is a PLAIN 8-byte store {tag, value} (the line stays in the XCD's L2) polled with sc1 loads
+//     (bypass the reader's L1): 273 ns one way instead of the 590 ns of the agent-scope (write-through + memory-side) form
+//     (profiles/r02_xcd_chain_ubench.txt).
+//   * EVERY WEIGHT IS REGISTER-RESIDENT for the whole launch, spread over the XCD's CUs: nothing is re-streamed per step.
+//       chain workgroup   (1): 8 waves x 4 layers: tap-1 conv kernel + dense kernel of a layer = 48 VGPRs per lane
+//       service workgroup (1): tap-0 conv kernels, the delay lines (model.py:49-64 queues; in the stream's state buffer)
+//       skip workgroups   (8): slice g of the 30 skip kernels (model.py:94-96)
+//       conv1 workgroups  (8): slice g of conv1d_1 and its two chunks of conv1d_2 (model.py:158-165)
+//       lc workgroups   (2-4): create_upsample + lc_filter/lc_gate projections (model.py:102-111,75-83), running ahead of
+//                              the chain through a ring: neither the upsampled condition nor a projection table exists in HBM
+//   * THE CHAIN IS A RELAY OF EIGHT WAVES.  A layer is 32 v_fmac_f32_dpp (row_newbcast feeds x[k] to the fma: no v_readlane,
+//     no LDS operand reads) -> bias/conditioning adds -> rational tanh/sigmoid -> v_permlane32_swap -> 16 v_fmac_f32_dpp +
+//     v_permlane16_swap for the dense 1x1 (twv_dpp.hpp): 203 ns per layer against 654 ns in wn_generate_kernel.  A wave hands
+//     the residual vector to the next one through a tagged LDS granule.  What is not on the sample-to-sample dependency chain
+//     (tap-0 chunks, which only need x[t-d]; lc projections; delay-line traffic) never touches the chain workgroup.
+//
+// Arithmetic: the contract of DESIGN.md (AC-1..AC-4); every dot product is the same fma chains in the same order as in
+// wn_generate_kernel and the CPU checker, so the two kernels produce identical bits and share the state layout (G = 1).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/twv_amd.h"
+#include "twv_layout.hpp"
+#include "twv_math.hpp"
+#include "twv_dev.hpp"
+#include "twv_dpp.hpp"
+#include "twv_xcd.hpp"
+
+using namespace twv;
+
+namespace {
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+#define LDSU64(i) (((__attribute__((address_space(3))) volatile unsigned long long*)lds)[(i)])
+
+// Granule traffic goes through ONE buffer descriptor over the stream's exchange area: per access one 32-bit lane offset (VGPR) and
+// one uniform offset (SGPR / immediate) -- 64-bit flat addresses of every granule array would not fit next to the weights.
+//   load : sc1 (aux bit 4): misses the CU's L1, served by the XCD's L2 (MI355X_MICROARCH: "sc1 loads bypass L1 only")
+//   store: plain: write-through the L1, the line STAYS in the XCD's L2 (an sc1 store would drop it to the memory side)
+// aux bit 31 = volatile for the compiler (a poll must not be hoisted out of its loop; it also sets sc0, which changes nothing for a
+// load).  Stores are NOT volatile (that would make them sc0 sc1 = write-through to the memory side); a compiler barrier pins them.
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+constexpr int kAuxLoad = (int)(16u | 0x80000000u), kAuxStore = 0;
+__device__ __forceinline__ unsigned long long xb_load(rsrc_t rs, int uword, int lword)
+{
+    const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rs, lword * 8, uword * 8, kAuxLoad);
+    return ((unsigned long long)v.y << 32) | (unsigned long long)v.x;
+}
+__device__ __forceinline__ void xb_store(rsrc_t rs, int uword, int lword, unsigned tag, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2v{__float_as_uint(v), tag}, rs, lword * 8, uword * 8, kAuxStore);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ unsigned g_tag(unsigned long long q) { return (unsigned)(q >> 32); }
+__device__ __forceinline__ float g_val(unsigned long long q) { return __uint_as_float((unsigned)q); }
+
+// bounded polling with a stream-wide abort word: a wait that runs out raises a watchdog code instead of hanging
+struct Poll {
+    rsrc_t rs;
+    int* status;
+    int it;
+    bool dead;
+};
+__device__ __forceinline__ bool poll_tick(Poll& p, int code)
+{
+    if (((++p.it) & 63) == 0) {
+        if (xb_load(p.rs, (int)XcdExch::CTRL + 1, 0) != 0ull) { p.dead = true; return false; }
+        if (p.it > (1 << 21)) {
+            atomicMax(p.status, code);
+            xb_store(p.rs, (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);
+            p.dead = true;
+            return false;
+        }
+    }
+    return true;
+}
+__device__ __forceinline__ void nap_until(unsigned long long target)
+{
+#pragma nounroll
+    for (int i = 0; i < 4096 && __builtin_amdgcn_s_memtime() < target; ++i) __builtin_amdgcn_s_sleep(8);
+}
+
+// chain lane that holds z[k] / x[j] in the granule arrays (twv_dpp.hpp layouts)
+__device__ __forceinline__ int lane_of_z(int k) { return ((k & 2) ? 16 : 0) + 2 * (k >> 2) + (k & 1); }
+__device__ __forceinline__ int lane_of_x(int j) { return j < 16 ? j : 16 + j; }
+
+// a chain wave's per-layer registers (the dense kernel lives in LDS)
+struct ChainRegs { float wc[32]; float bfg, gcv, bd; };
+
+enum { ROLE_CHAIN = 0, ROLE_SERVICE = 1, ROLE_SKIP0 = 2, ROLE_CONV0 = 10, ROLE_LC0 = 18 };
+
+struct XArgs {
+    XcdLaunch p;
+    int n_lc_wg, lc_lpw;      // lc workgroups per stream, layers per lc wave
+};
+
+// =====================================================================================================================
+//  CHAIN workgroup: model.py:41-46 causal layer (wave 0), model.py:66-101 residual layers (relay over the waves),
+//  mixture.py:84-114 sampler (wave 7)
+// =====================================================================================================================
+template <bool INSTR>
+__device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
+{
+    const XcdLaunch& a = xa.p;
+    const Layout& L = a.lay;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int NL = L.NL, T = a.T;
+    const bool use_bias = L.use_bias != 0, has_gc = L.G > 0, has_lc = L.L > 0, forced = a.forced != nullptr;
+    // waves 0..5 hold four layers each, waves 6 and 7 three: wave 7 also runs the sampler and the causal layer (it HAS the new sample)
+    const int l0 = w < 6 ? 4 * w : 24 + 3 * (w - 6);
+    const int cap = w < 6 ? 4 : 3;
+    int nl = NL - l0;
+    nl = nl < 0 ? 0 : (nl > cap ? cap : nl);
+    const bool next_has = (l0 + nl < NL);                      // a later wave continues the stack
+    const bool head = (w == 7);                                // sampler + causal layer
+    if (nl == 0 && !head) return;
+    const int oc = dpp_conv_out(lane), od = dpp_dense_out(lane);
+    const ActCoef coef = act_coef(lane >= 32);
+    float* stb = a.state + (long long)b * L.state_stride;
+    Poll pl{rs, a.status, 0, false};
+    constexpr int O_ABORT = 9 * 64;                            // LDS, in 8-byte words: input boxes of waves 0..7, abort word
+    constexpr int O_WD = 2048;                                 // LDS floats: dense kernels [layer][4][64 lanes][4]
+
+    // ---- the wave's layers: tap-1 conv kernel register-resident for the whole launch, dense kernel LDS-resident
+    ChainRegs W[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < nl) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.P + L.off_xl + (long long)(l0 + i) * kXcdXlFloats) + lane;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const f32x4 v = src[q * 64]; W[i].wc[4 * q] = v.x; W[i].wc[4 * q + 1] = v.y; W[i].wc[4 * q + 2] = v.z; W[i].wc[4 * q + 3] = v.w; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) LDS4((O_WD >> 2) + ((l0 + i) * 4 + q) * 64 + lane) = src[(8 + q) * 64];
+            const f32x4 v = src[12 * 64];
+            W[i].bfg = v.x; W[i].bd = v.y;
+            W[i].gcv = has_gc ? a.cond[XH_WORDS + ((long long)b * NL + l0 + i) * 64 + oc] : 0.0f;     // model.py:71-73, hoisted
+        }
+    }
+    // wave 7: causal kernel (model.py:41-46), every lane the 32 taps of ITS residual channel (X layout), in the registers of the
+    // fourth layer slot (wave 7 holds three layers); causal queue (model.py:52)
+    float hv = 0.0f, first_in = 0.0f;
+    if (head) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.P + L.off_xc) + lane;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const f32x4 v = src[q * 64]; W[3].wc[4 * q] = v.x; W[3].wc[4 * q + 1] = v.y; W[3].wc[4 * q + 2] = v.z; W[3].wc[4 * q + 3] = v.w; }
+        hv = stb[L.st_hist + lane];
+        if (!forced) first_in = reinterpret_cast<const float*>(a.first_input)[b];
+    }
+    // wave 7: the sampler's constants and the noise terms of step 0
+    const bool sampler = head && !forced;
+    float b2v = 0.0f, s_lnl = 0.0f, s_tq = 0.0f, samp = 0.0f;
+    auto noise = [&](int t) {
+        // mixture.py:103 -log(-log u) per mixture lane; mixture.py:110-111 log u - log(1 - u) of the last draw
+        const float* up = a.uniforms + ((long long)b * T + t) * (L.nr_mix + 1);
+        const float u = lane <= L.nr_mix ? up[lane] : 0.5f;
+        s_lnl = log_e(-log_e(u));
+        const float uu = __shfl(u, L.nr_mix);
+        s_tq = log_e(uu) - log_e(1.0f - uu);
+    };
+    if (sampler) {
+        if (use_bias && lane < L.O) b2v = a.P[L.off_b2 + lane];
+        noise(0);
+    }
+    __builtin_amdgcn_s_waitcnt(0);        // every register image and LDS copy has landed before the relay starts
+
+    float X = 0.0f;
+    for (int t = 0; t < T && !pl.dead; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+        // ---- wave 7, head of the step: new input sample -> causal queue -> causal layer -> wave 0
+        if (head) {
+            const float sh = __shfl_down(hv, 1);                       // model.py:122 queue shift
+            const float s_in = forced ? reinterpret_cast<const float*>(a.forced)[(long long)b * T + t] : (t == 0 ? first_in : samp);
+            if (lane == 0) xb_store(rs, (int)XcdExch::CTRL, 0, tag, 0.0f);     // progress: step t has started (the lc workgroups throttle on it)
+            hv = (lane == 31) ? s_in : sh;
+            const float x0 = dot_readlane_pipe_a(W[3].wc, hv);          // model.py:41-46: one AC-1 chunk, no bias; X layout
+            LDSU64(0 * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(x0);
+        }
+        // ---- (A) this step's tap-0 chunks and lc projections of the wave's layers (service workgroup; long since published)
+        float pre[4] = {0.0f, 0.0f, 0.0f, 0.0f}, lcv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (nl > 0) {
+            pl.it = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < nl) {
+                        const unsigned long long qp = xb_load(rs, (int)XcdExch::PG + (l0 + i) * 64, oc);
+                        const unsigned long long ql = xb_load(rs, (int)XcdExch::LG + (l0 + i) * 64, oc);
+                        ok = ok && g_tag(qp) == tag && g_tag(ql) == tag;
+                        pre[i] = g_val(qp); lcv[i] = g_val(ql);
+                    }
+                }
+                if (__all(ok)) break;
+                if (!poll_tick(pl, 31)) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (pl.dead) break;
+            // ---- (B) the wave's input: the previous wave's residual vector (wave 0: the causal layer's output)
+            unsigned long long q;
+            pl.it = 0;
+            for (;;) {
+                q = LDSU64(w * 64 + lane);
+                if (__all(g_tag(q) == tag)) break;
+                if (!poll_tick(pl, 33)) break;
+            }
+            if (pl.dead) break;
+            X = g_val(q);
+        }
+        // ---- the wave's layers
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < nl) {
+                float wd[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = LDS4((O_WD >> 2) + ((l0 + i) * 4 + q) * 64 + lane);
+                    wd[4 * q] = v.x; wd[4 * q + 1] = v.y; wd[4 * q + 2] = v.z; wd[4 * q + 3] = v.w;
+                }
+                const float x_in = X;
+                const float z = layer_body_dpp2(W[i].wc, wd, W[i].bfg, W[i].gcv, W[i].bd, coef, X, pre[i], lcv[i], use_bias, has_gc, has_lc);
+                xb_store(rs, (int)XcdExch::ZG + (l0 + i) * 64, lane, tag, z);        // -> skip workgroups
+                xb_store(rs, (int)XcdExch::XG + (l0 + i) * 64, lane, tag, x_in);     // -> service workgroup (model.py:145: the queue takes the layer INPUT)
+                if (INSTR && a.dbg != nullptr && t < a.dbg_steps) {
+                    float* dp = a.dbg + ((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)(l0 + i) * 64;
+                    if (lane < 32) dp[dpp_z_index(lane)] = z;
+                    if ((lane & 16) == 0) dp[32 + od] = X;
+                }
+            }
+        }
+        if (next_has && nl > 0) LDSU64((w + 1) * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(X);
+        // ---- sampler: conv1d_2's [16 chunks][32 lanes] partial table from the conv1 workgroups -> mixture.py:84-114
+        if (sampler) {
+            const int half = lane >> 5;
+            unsigned long long q[8];
+            pl.it = 0;
+            for (;;) {
+                bool good = true;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    q[k] = xb_load(rs, (int)XcdExch::PT + k * 32, half * 256 + (lane & 31));
+                    good = good && g_tag(q[k]) == tag;
+                }
+                if (__all(good)) break;
+                if (!poll_tick(pl, 34)) break;
+            }
+            if (pl.dead) break;
+            float acc = g_val(q[0]);                                   // chunk partials added in chunk order (AC-1)
+#pragma unroll
+            for (int k = 1; k < 8; ++k) acc = acc + g_val(q[k]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)q[k], (unsigned)q[k], false, false);
+                acc = acc + __uint_as_float(sw[1]);                    // chunk 8 + k of the same output (upper half-wave's granule)
+            }
+            float y = acc;
+            if (use_bias && lane < L.O) y = y + b2v;
+            if (INSTR && a.dbg != nullptr && t < a.dbg_steps)
+                a.dbg[((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)NL * 64 + lane] = y;
+            const int nr = L.nr_mix;
+            const float gmb = y - s_lnl;                               // mixture.py:103
+            int k = 0;
+            float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gmb), 0));
+            for (int i = 1; i < nr; ++i) {
+                const float gi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gmb), i));
+                if (gi > best) { best = gi; k = i; }                   // argmax, first maximum
+            }
+            k = __builtin_amdgcn_readfirstlane(k);
+            const float mean = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), nr + k));        // mixture.py:105
+            float ls = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), 2 * nr + k));             // mixture.py:107
+            const float lsmin = (float)-32.23619130191664;
+            ls = ls > lsmin ? ls : lsmin;
+            const float e = exp_e(ls);
+            const float prod = e * s_tq;                               // mixture.py:110-111
+            float xs = mean + prod;
+            xs = xs > -1.0f ? xs : -1.0f;                              // mixture.py:113
+            xs = xs < 1.0f ? xs : 1.0f;
+            samp = xs;                                                 // uniform: the next step's input, straight into the causal queue
+            if (lane == 0) a.out[(long long)b * T + t] = xs;
+            if (t + 1 < T) noise(t + 1);                               // off the critical path: the next step's noise terms
+        }
+        if (LDSU64(O_ABORT) != 0ull) break;
+    }
+    if (pl.dead) LDSU64(O_ABORT) = 1ull;
+    // ---- persist (model.py:49-64 causal queue)
+    if (head) {
+        stb[L.st_hist + lane] = hv;
+        if (lane == 0) {
+            int* meta = reinterpret_cast<int*>(stb + L.st_meta);
+            meta[M_TABS] = meta[M_TABS] + T;
+        }
+    }
+}
+
+// =====================================================================================================================
+//  SERVICE workgroup: the delay lines (model.py:49-64, 116-126, 144-146) and the tap-0 chunk of conv_filter|conv_gate
+//  (model.py:68-69: the tap that reads x[t-d]), one step ahead of the chain; forwards the lc projections.
+//  Wave s owns layers s, s+8, s+16, s+24.
+// =====================================================================================================================
+__device__ __forceinline__ unsigned ring_slot(unsigned pos0, unsigned t, unsigned d)
+{
+    const unsigned v = pos0 + t;
+    return (d & (d - 1)) == 0 ? (v & (d - 1)) : v % d;
+}
+__device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
+{
+    const XcdLaunch& a = xa.p;
+    const Layout& L = a.lay;
+    const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int NL = L.NL, T = a.T;
+    const bool has_lc = L.L > 0;
+    float* stb = a.state + (long long)b * L.state_stride;
+    float* ring = stb + L.st_ring;
+    const int* pmeta = reinterpret_cast<const int*>(a.P + L.off_meta);
+    int* ringpos = reinterpret_cast<int*>(stb + L.st_ringpos);
+    Poll pl{rs, a.status, 0, false};
+    int nown = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (s + 8 * i < NL) nown = i + 1;
+    if (nown == 0) return;
+    Tile t0[4];
+    unsigned dil[4], roff[4], pos0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        dil[i] = 1; roff[i] = 0; pos0[i] = 0;
+        if (i < nown) {
+            const int l = s + 8 * i;
+            load_tile(t0[i], a.P + L.off_layer0 + (long long)l * L.layer_stride + LayerOff::T0, lane);
+            dil[i] = (unsigned)pmeta[l]; roff[i] = (unsigned)pmeta[64 + l]; pos0[i] = (unsigned)ringpos[l];
+        }
+    }
+    const int n16 = lane & 15;
+    // operand of the tap-0 chunk of step t: x[t-d] = the slot the delay line overwrites at step t
+    auto tap0 = [&](int i, unsigned t, float& xa_, float& xb_) {
+        const unsigned slot = ring_slot(pos0[i], t, dil[i]);
+        const unsigned long long* p = reinterpret_cast<const unsigned long long*>(ring + roff[i] + slot * 32);
+        // 8-byte sc1 loads of float pairs: lanes n and n+1 of a pair read the same word
+        const unsigned long long qa = __hip_atomic_load((gu64*)(p + (n16 >> 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long qb = __hip_atomic_load((gu64*)(p + 8 + (n16 >> 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        xa_ = __uint_as_float((n16 & 1) ? (unsigned)(qa >> 32) : (unsigned)qa);
+        xb_ = __uint_as_float((n16 & 1) ? (unsigned)(qb >> 32) : (unsigned)qb);
+    };
+    // ---- step 0: from the persisted state
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < nown) {
+            const int l = s + 8 * i;
+            float xa_, xb_;
+            tap0(i, 0u, xa_, xb_);
+            const float pre = dot32_dpp(t0[i].w, xa_, xb_);
+            const float lcv = has_lc ? stb[L.st_lcprev + l * 64 + lane] : 0.0f;     // frame pushed by the previous call (zeros after reset)
+            xb_store(rs, (int)XcdExch::PG + l * 64, lane, 1u, pre);
+            xb_store(rs, (int)XcdExch::LG + l * 64, lane, 1u, lcv);
+        }
+    }
+    for (int t = 0; t < T && !pl.dead; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < nown && !pl.dead) {
+                const int l = s + 8 * i;
+                const bool more = t + 1 < T;
+                // next step's operand when it is already in the delay line (d >= 2): requested before the wait
+                float oa = 0.0f, ob = 0.0f;
+                if (more && dil[i] > 1) tap0(i, (unsigned)t + 1u, oa, ob);
+                // the layer input x_l[t] from the chain
+                unsigned long long qa, qb;
+                pl.it = 0;
+                for (;;) {
+                    qa = xb_load(rs, (int)XcdExch::XG + l * 64, n16);
+                    qb = xb_load(rs, (int)XcdExch::XG + l * 64 + 32, n16);
+                    if (__all(g_tag(qa) == tag && g_tag(qb) == tag)) break;
+                    if (!poll_tick(pl, 41)) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (pl.dead) break;
+                const float xa_ = g_val(qa), xb_ = g_val(qb);
+                // model.py:145 dilation queue <- layer input
+                const unsigned slot = ring_slot(pos0[i], (unsigned)t, dil[i]);
+                if (lane < 32) ring[roff[i] + slot * 32 + lane] = lane < 16 ? xa_ : xb_;
+                if (more) {
+                    if (dil[i] == 1) { oa = xa_; ob = xb_; }
+                    const float pre = dot32_dpp(t0[i].w, oa, ob);
+                    float lcv = 0.0f;
+                    if (has_lc) {
+                        // lc frame used at step t+1 = frame pushed at step t (model.py:79-80: slice from the FRONT of the queue)
+                        const int lw = (int)XcdExch::LCR + (((t + 1) % kXcdLcRing) * 32 + l) * 64;
+                        unsigned long long ql;
+                        pl.it = 0;
+                        for (;;) {
+                            ql = xb_load(rs, lw, lane);
+                            if (__all(g_tag(ql) == tag + 1u)) break;
+                            if (!poll_tick(pl, 42)) break;
+                            __builtin_amdgcn_s_sleep(8);
+                        }
+                        if (pl.dead) break;
+                        lcv = g_val(ql);
+                    }
+                    xb_store(rs, (int)XcdExch::PG + l * 64, lane, tag + 1u, pre);
+                    xb_store(rs, (int)XcdExch::LG + l * 64, lane, tag + 1u, lcv);
+                }
+            }
+        }
+    }
+    if (lane == 0 && !pl.dead) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nown) ringpos[s + 8 * i] = (int)((pos0[i] + (unsigned)T) % dil[i]);
+    }
+}
+
+// =====================================================================================================================
+//  SKIP workgroup g: model.py:94-96 skip 1x1 of every layer for output block g, model.py:154 sum over the layers in layer
+//  order, model.py:157 relu.  Wave v owns layers v, v+8, ...; the wave that owns the last layer adds the values up as they appear.
+// =====================================================================================================================
+__device__ __forceinline__ void skip_role(const XArgs& xa, int b, int g, rsrc_t rs)
+{
+    const XcdLaunch& a = xa.p;
+    const Layout& L = a.lay;
+    const int v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int NL = L.NL, T = a.T;
+    const bool use_bias = L.use_bias != 0;
+    Poll pl{rs, a.status, 0, false};
+    int nown = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (v + 8 * i < NL) nown = i + 1;
+    if (nown == 0) return;
+    Tile ws[4];
+    float bs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bs[i] = 0.0f;
+        if (i < nown) {
+            const long long lb = L.off_layer0 + (long long)(v + 8 * i) * L.layer_stride;
+            load_tile(ws[i], a.P + lb + LayerOff::SK + (long long)g * kTile, lane);
+            if (use_bias) bs[i] = a.P[lb + LayerOff::SK + (long long)L.NSJ * kTile + g * 64 + lane];
+        }
+    }
+    const bool summer = v == ((NL - 1) & 7);
+    const int n16 = lane & 15;
+    const int za_lane = lane_of_z(n16), zb_lane = lane_of_z(16 + n16);
+    unsigned long long seen[4] = {0, 0, 0, 0}, period = 0;       // arrival times of the own layers in the previous step
+    for (int t = 0; t < T && !pl.dead; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+        int nextl = 0;
+        float tot = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < nown && !pl.dead) {
+                const int l = v + 8 * i;
+                if (period) nap_until(seen[i] + period - (period >> 3));
+                unsigned long long qa, qb;
+                pl.it = 0;
+                for (;;) {
+                    qa = xb_load(rs, (int)XcdExch::ZG + l * 64, za_lane);
+                    qb = xb_load(rs, (int)XcdExch::ZG + l * 64, zb_lane);
+                    if (__all(g_tag(qa) == tag && g_tag(qb) == tag)) break;
+                    if (!poll_tick(pl, 51)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (pl.dead) break;
+                {
+                    const unsigned long long now = __builtin_amdgcn_s_memtime();
+                    if (i == 0) { const unsigned long long d = now - seen[0]; period = (seen[0] != 0 && d < (1ull << 18)) ? d : 0; }
+                    seen[i] = now;
+                }
+                float val = dot32_dpp(ws[i].w, g_val(qa), g_val(qb));                 // model.py:96
+                if (use_bias) val = val + bs[i];
+                if (!summer) {
+                    LDSU64(l * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(val);
+                } else {
+                    // model.py:154 sum(outputs): layers nextl .. l-1 come from the other waves, in layer order
+                    for (; nextl < l && !pl.dead; ++nextl) {
+                        unsigned long long q;
+                        pl.it = 0;
+                        for (;;) {
+                            q = LDSU64(nextl * 64 + lane);
+                            if (__all(g_tag(q) == tag)) break;
+                            if (!poll_tick(pl, 52)) break;
+                        }
+                        tot = (nextl == 0) ? g_val(q) : tot + g_val(q);
+                    }
+                    tot = (l == 0) ? val : tot + val;
+                    nextl = l + 1;
+                }
+            }
+        }
+        if (summer && !pl.dead) {
+            const float h = tot > 0.0f ? tot : 0.0f;                                   // model.py:157
+            xb_store(rs, (int)XcdExch::H1 + g * 64, lane, tag, h);
+        }
+    }
+}
+
+// =====================================================================================================================
+//  CONV1 workgroup g: model.py:158-160 conv1d_1 + relu for output block g (16 chunk tiles over the 8 waves), then the two
+//  chunks (2g, 2g+1) of model.py:161-165 conv1d_2 that read this block: what travels on is conv1d_2's partial table.
+// =====================================================================================================================
+__device__ __forceinline__ void conv1_role(const XArgs& xa, int b, int g, rsrc_t rs)
+{
+    const XcdLaunch& a = xa.p;
+    const Layout& L = a.lay;
+    const int v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int T = a.T, NCH = L.NCH;
+    const bool use_bias = L.use_bias != 0;
+    Poll pl{rs, a.status, 0, false};
+    constexpr int O_PART = 0, O_CNT = 16 * 64, O_ABORT = O_CNT + 1;      // LDS floats: chunk partials | arrival counter | abort
+    if (threadIdx.x == 0) { LDSI(O_CNT) = 0; LDSI(O_ABORT) = 0; }
+    __syncthreads();
+    const int c0 = 2 * v, c1 = 2 * v + 1;                                 // this wave's chunks
+    Tile ta, tb;
+    load_tile(ta, a.P + L.off_w1 + ((long long)g * NCH + c0) * kTile, lane);
+    load_tile(tb, a.P + L.off_w1 + ((long long)g * NCH + c1) * kTile, lane);
+    const bool summer = v < 2;
+    float b1v = 0.0f;
+    Tile t2;
+    if (summer) {
+        if (use_bias) b1v = a.P[L.off_b1 + g * 64 + lane];
+        load_tile(t2, a.P + L.off_w2 + (long long)(2 * g + v) * kTile, lane);
+    }
+    const int n16 = lane & 15;
+    unsigned long long t_arr = 0, period = 0;
+    for (int t = 0; t < T && !pl.dead; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+        if (period) nap_until(t_arr + period - (period >> 3));
+        unsigned long long q0, q1, q2, q3;
+        pl.it = 0;
+        for (;;) {
+            q0 = xb_load(rs, (int)XcdExch::H1 + c0 * 32, n16);
+            q1 = xb_load(rs, (int)XcdExch::H1 + c0 * 32 + 16, n16);
+            q2 = xb_load(rs, (int)XcdExch::H1 + c1 * 32, n16);
+            q3 = xb_load(rs, (int)XcdExch::H1 + c1 * 32 + 16, n16);
+            if (__all(g_tag(q0) == tag && g_tag(q1) == tag && g_tag(q2) == tag && g_tag(q3) == tag)) break;
+            if (!poll_tick(pl, 61)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (pl.dead) break;
+        {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            const unsigned long long d = now - t_arr;
+            period = (t_arr != 0 && d < (1ull << 18)) ? d : 0;
+            t_arr = now;
+        }
+        lds[O_PART + c0 * 64 + lane] = dot32_dpp(ta.w, g_val(q0), g_val(q1));
+        lds[O_PART + c1 * 64 + lane] = dot32_dpp(tb.w, g_val(q2), g_val(q3));
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(&LDSI(O_CNT), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (summer) {
+            pl.it = 0;
+            while (LDSVI(O_CNT) < 8 * (t + 1)) { if (!poll_tick(pl, 62)) break; }
+            if (pl.dead) break;
+            asm volatile("" ::: "memory");
+            float cp[16];
+#pragma unroll
+            for (int ch = 0; ch < 16; ++ch) cp[ch] = lds[O_PART + ch * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
+            float r = cp[0];                                            // AC-1: chunk values added in chunk order
+#pragma unroll
+            for (int ch = 1; ch < 16; ++ch) r = r + cp[ch];
+            if (use_bias) r = r + b1v;
+            const float h = r > 0.0f ? r : 0.0f;                         // model.py:160
+            // conv1d_2 chunk 2g+v reads h[32v .. 32v+31] of this block
+            const float p = (v == 0) ? dot_readlane_pipe(t2, h) : dot_readlane_pipe32(t2, h);
+            if (lane < 32) xb_store(rs, (int)XcdExch::PT + (2 * g + v) * 32, lane, tag, p);
+        }
+    }
+    if (pl.dead && lane == 0) LDSI(O_ABORT) = 1;
+}
+
+// =====================================================================================================================
+//  LC workgroups: model.py:102-111 create_upsample (row by row) and model.py:75-83 lc_filter|lc_gate of every layer,
+//  ahead of the chain through the ring XcdExch::LCR.  Wave gw owns layers gw*lpw .. gw*lpw+lpw-1 (NLC tiles each).
+// =====================================================================================================================
+__device__ __forceinline__ void lc_role(const XArgs& xa, int b, int wg, rsrc_t rs)
+{
+    const XcdLaunch& a = xa.p;
+    const Layout& L = a.lay;
+    const int v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int NL = L.NL, T = a.T, NLC = L.NLC, Lc = L.L, lpw = xa.lc_lpw;
+    const int gw = wg * 8 + v;
+    const int lfirst = gw * lpw;
+    int nown = NL - lfirst;
+    nown = nown < 0 ? 0 : (nown > lpw ? lpw : nown);
+    if (nown == 0) return;
+    Poll pl{rs, a.status, 0, false};
+    float* stb = a.state + (long long)b * L.state_stride;
+    const int* hdr = reinterpret_cast<const int*>(a.cond);
+    const int mode = hdr[XH_MODE], rows = hdr[XH_ROWS];
+    const float* payload = a.cond + XH_WORDS + (long long)a.B * NL * 64;
+    Tile lt[4];
+#pragma unroll
+    for (int idx = 0; idx < 4; ++idx) {
+        if (idx < nown * NLC) {
+            const int j = idx / NLC, c = idx - j * NLC;
+            load_tile(lt[idx], a.P + L.off_lcw + (long long)(lfirst + j) * L.lcw_stride + (long long)c * kTile, lane);
+        }
+    }
+    // wave-private LDS: two rows of 128 floats (ping-pong of the transposed-conv stages; the final row feeds the dots)
+    const int o_row = v * 256;
+    const int n16 = lane & 15;
+    // upsampling kernels (f_i, 2) and the mixed-radix phase counter of the output row index
+    int ph[4] = {0, 0, 0, 0}, frame = 0;
+    const int n_up = L.n_up;
+    int hop = 1;
+    for (int i = 0; i < n_up; ++i) hop *= L.up[i];
+    const long long need_rows = (mode == XLC_MEL) ? ((long long)T + hop - 1) / hop : T;
+    if (rows < need_rows) {
+        if (lane == 0) { atomicMax(a.status, 71); xb_store(rs, (int)XcdExch::CTRL + 1, 0, 1u, 0.0f); }
+        return;
+    }
+    for (int u = 0; u < T && !pl.dead; ++u) {
+        // ---- throttle: slot (u+1) % ring is free once the chain has started step u + 2 - ring
+        if (u + 3 - kXcdLcRing > 0) {
+            pl.it = 0;
+            for (;;) {
+                const unsigned long long q = xb_load(rs, (int)XcdExch::CTRL, 0);
+                if ((int)g_tag(q) >= u + 3 - kXcdLcRing) break;
+                if (!poll_tick(pl, 72)) break;
+                __builtin_amdgcn_s_sleep(16);
+            }
+            if (pl.dead) break;
+        }
+        // ---- row u of the upsampled condition into LDS (zero padded to NLC*32)
+        int o_cur = o_row;
+        if (mode == XLC_UPSAMPLED) {
+            const float* src = payload + ((long long)b * rows + u) * Lc;
+            lds[o_cur + lane] = lane < Lc ? src[lane] : 0.0f;
+            lds[o_cur + 64 + lane] = 64 + lane < Lc ? src[64 + lane] : 0.0f;
+        } else {
+            const float* src = payload + ((long long)b * rows + frame) * Lc;
+            lds[o_cur + lane] = lane < Lc ? src[lane] : 0.0f;
+            lds[o_cur + 64 + lane] = 64 + lane < Lc ? src[64 + lane] : 0.0f;
+            for (int i = 0; i < n_up; ++i) {
+                // out[m] = K[a][0]*in[m] + K[a][1]*in[m-1]   as a two-term AC-1 chunk   (model.py:102-111, 'same' transposed conv)
+                const float k0 = a.P[L.off_up[i] + ph[i] * 2 + 0], k1 = a.P[L.off_up[i] + ph[i] * 2 + 1];
+                const int o_nxt = (o_cur == o_row) ? o_row + 128 : o_row;
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf) {
+                    const int m = hlf * 64 + lane;
+                    const float x0 = lds[o_cur + m];
+                    const float x1 = m > 0 ? lds[o_cur + m - 1] : 0.0f;
+                    const float s0 = fma_(k0, x0, 0.0f);
+                    const float s1 = fma_(k1, x1, 0.0f);
+                    const float r = (s0 + s1) + (0.0f + 0.0f);
+                    lds[o_nxt + m] = m < Lc ? r : 0.0f;
+                }
+                o_cur = o_nxt;
+            }
+            // advance the phase counter (last stage fastest)
+            int carry = 1;
+            for (int i = n_up - 1; i >= 0; --i) {
+                if (carry) { ph[i] += 1; carry = 0; if (ph[i] == L.up[i]) { ph[i] = 0; carry = 1; } }
+            }
+            frame += carry;
+        }
+        // ---- projections: AC-1 chunks of 32 over the lc channels, chunk values added in order
+        float resx[4];
+#pragma unroll
+        for (int idx = 0; idx < 4; ++idx) {
+            resx[idx] = 0.0f;
+            if (idx < nown * NLC) {
+                const int j = idx / NLC, c = idx - j * NLC;
+                const float xa_ = lds[o_cur + c * 32 + n16], xb_ = lds[o_cur + c * 32 + 16 + n16];
+                resx[idx] = dot32_dpp(lt[idx].w, xa_, xb_);
+                (void)j;
+            }
+        }
+        // combine per layer in chunk order (indices are compile-time; j, c are uniform)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < nown) {
+                float r = 0.0f;
+#pragma unroll
+                for (int idx = 0; idx < 4; ++idx) {
+                    if (idx >= j * NLC && idx < (j + 1) * NLC) r = (idx == j * NLC) ? resx[idx] : r + resx[idx];
+                }
+                const int l = lfirst + j;
+                if (u + 1 < T) xb_store(rs, (int)XcdExch::LCR + (((u + 1) % kXcdLcRing) * 32 + l) * 64, lane, (unsigned)u + 2u, r);
+                else stb[L.st_lcprev + l * 64 + lane] = r;             // the frame the NEXT call uses at its step 0
+            }
+        }
+    }
+}
+
+template <bool INSTR>
+__global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
+{
+    const XcdLaunch& a = xa.p;
+    // ---- role ticket of this workgroup's XCD (HIP promises nothing about workgroup -> XCD placement: ask the hardware)
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 15u;
+    int ticket = 0;
+    if (threadIdx.x == 0) ticket = (xcc < (unsigned)a.B && xcc < 8u) ? atomicAdd(a.roles + xcc, 1) : 1 << 20;
+    ticket = __shfl(ticket, 0);
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = ticket;
+    // LDS hand-off words start at zero
+    for (int i = threadIdx.x; i < 32 * 64 * 2 + 64; i += blockDim.x) lds[i] = 0.0f;
+    __syncthreads();
+    ticket = s_ticket;
+    const int b = (int)xcc;
+    if (ticket >= ROLE_LC0 + xa.n_lc_wg) return;                 // surplus workgroup (or an XCD without a stream)
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.exch + (long long)b * XcdExch::WORDS, 0, (int)(XcdExch::WORDS * 8), 0x00020000);
+    const bool forced = a.forced != nullptr;
+    if (ticket == ROLE_CHAIN) chain_role<INSTR>(xa, b, rs);
+    else if (ticket == ROLE_SERVICE) service_role(xa, b, rs);
+    else if (ticket < ROLE_CONV0) { if (!forced) skip_role(xa, b, ticket - ROLE_SKIP0, rs); }
+    else if (ticket < ROLE_LC0) { if (!forced) conv1_role(xa, b, ticket - ROLE_CONV0, rs); }
+    else lc_role(xa, b, ticket - ROLE_LC0, rs);
+}
+
+// ---- pack: the chain's register images from the canonical blob (generate.py:157-161 Saver.restore) -------------------------
+__global__ void wn_xcd_pack_kernel(float* dst, const float* blob, Layout L)
+{
+    const long long per_layer = kXcdXlFloats;
+    const long long total = per_layer * L.NL + kXcdXcFloats;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        if (i < per_layer * L.NL) {
+            const int l = (int)(i / per_layer);
+            const int e = (int)(i - (long long)l * per_layer);
+            const int q = e >> 8, lane = (e >> 2) & 63, c = e & 3;          // [q][lane][4]
+            const long long lb = L.c_layer0 + (long long)l * L.c_layer_stride;
+            const int oc = dpp_conv_out(lane), od = dpp_dense_out(lane);
+            if (q < 8) {                                                    // conv_filter|conv_gate kernel (2,R,D), tap 1
+                const int k = 4 * q + c;
+                v = blob[lb + (oc < 32 ? L.c_wf : L.c_wg) + 32 * 32 + k * 32 + (oc & 31)];
+            } else if (q < 12) {                                            // dense kernel (1,D,R): this lane's half of the chunk
+                const int i16 = 4 * (q - 8) + c;
+                v = blob[lb + L.c_wd + dpp_dense_k(lane, i16) * 32 + od];
+            } else if (L.use_bias) {
+                if (c == 0) v = blob[lb + (oc < 32 ? L.c_bf : L.c_bg) + (oc & 31)];
+                else if (c == 1) v = blob[lb + L.c_bd + od];
+            }
+            dst[L.off_xl + i] = v;
+        } else {
+            const int e = (int)(i - per_layer * L.NL);
+            const int q = e >> 8, lane = (e >> 2) & 63, c = e & 3;
+            const int k = 4 * q + c;                                        // wavenet/conv1d/kernel (ifw,1,R)
+            if (k < L.ifw) v = blob[L.c_causal + k * 32 + dpp_dense_out(lane)];
+            dst[L.off_xc + e] = v;
+        }
+    }
+}
+
+}  // namespace
+
+namespace twv {
+
+bool xcd_model_ok(const Layout& L)
+{
+    return L.scalar && L.ifw == 32 && L.S == 512 && L.O <= 32 && L.NOJ == 1 && L.NL >= 1 && L.NL <= kXcdMaxLayers && L.NLC <= 4;
+}
+static int lc_layers_per_wave(const Layout& L) { const int n = L.NLC > 0 ? 4 / L.NLC : 1; return n < 1 ? 1 : n; }
+int xcd_lc_workgroups(const Layout& L)
+{
+    if (L.L == 0) return 0;
+    const int lpw = lc_layers_per_wave(L);
+    const int waves = (L.NL + lpw - 1) / lpw;
+    return (waves + 7) / 8;
+}
+int xcd_workgroups_per_stream(const Layout& L) { return ROLE_LC0 + xcd_lc_workgroups(L); }
+size_t xcd_exchange_bytes(int batch) { return (size_t)batch * XcdExch::WORDS * 8 + 64; }
+void xcd_pack(float* packed, const float* blob, const Layout& L, hipStream_t st)
+{
+    hipLaunchKernelGGL(wn_xcd_pack_kernel, dim3(512), dim3(256), 0, st, packed, blob, L);
+}
+int xcd_launch(const XcdLaunch& p, hipStream_t st)
+{
+    XArgs xa;
+    xa.p = p;
+    xa.n_lc_wg = xcd_lc_workgroups(p.lay);
+    xa.lc_lpw = lc_layers_per_wave(p.lay);
+    const size_t shm = (size_t)(2048 + 32 * 1024) * 4;            // chain workgroup: hand-off boxes + the dense kernels of every layer (130 KiB)
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    else (void)hipGetLastError();
+    // twice the CUs: a workgroup takes a whole CU (512 threads x ~250 VGPRs); surplus workgroups leave at once, so every XCD's role
+    // table fills whatever order the dispatcher uses
+    const int grid = 2 * cus;
+    if (p.dbg != nullptr) hipLaunchKernelGGL(wn_xcd_generate_kernel<true>, dim3(grid), dim3(512), shm, st, xa);
+    else hipLaunchKernelGGL(wn_xcd_generate_kernel<false>, dim3(grid), dim3(512), shm, st, xa);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return twv_fail(TWV_E_HIP, std::string("xcd launch: ") + hipGetErrorString(e));
+    return TWV_OK;
+}
+
+}  // namespace twv

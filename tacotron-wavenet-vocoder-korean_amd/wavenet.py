@@ -20,6 +20,27 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class Upsampled(object):
+    """What WaveNetModel.create_upsample returns under fused conditioning: the mel frames plus the shape of the upsampled tensor
+    they stand for.  generate() takes it as `upsampled_local_condition`; tensor() materialises it (model.py:102-111)."""
+
+    def __init__(self, model, mel):
+        self.model, self.mel = model, mel
+        self.shape = (mel.shape[0], mel.shape[1] * model.hop_size, mel.shape[2])
+        self._t = None
+
+    def tensor(self):
+        if self._t is None:
+            self._t = self.model._upsample_now(self.mel)
+        return self._t
+
+    def cpu(self):
+        return self.tensor().cpu()
+
+    def __getitem__(self, idx):
+        return self.tensor()[idx]
+
+
 class WaveNetModel(object):
     def __init__(self, batch_size, dilations, filter_width, residual_channels, dilation_channels, skip_channels,
                  quantization_channels=2 ** 8, out_channels=30, use_biases=False, scalar_input=False,
@@ -113,10 +134,24 @@ class WaveNetModel(object):
             _lib.check(self._L.twv_wavenet_reset_state(self._h, _ptr(self._state), self.batch_size, _stream()))
 
     # ---- model.py:102-111 ----
-    def create_upsample(self, local_condition_batch):
+    def fused_conditioning(self):
+        """True when create_upsample + the lc projections run inside the generation launch (XCD-per-stream kernel)."""
+        return bool(self._L.twv_wavenet_fused_conditioning(self._h, self.batch_size))
+
+    def create_upsample(self, local_condition_batch, materialize=None):
+        """net.create_upsample(mel) (generate.py:200).  With fused conditioning the returned `Upsampled` only holds the mel frames:
+        `generate` upsamples row by row inside its launch; `.tensor()` (or materialize=True) builds the (B, T_mel*hop, lc) tensor
+        with the stand-alone kernel -- same bits either way."""
         mel = torch.as_tensor(local_condition_batch, dtype=torch.float32, device=self.device).contiguous()
         B, Tm, Lc = mel.shape
         assert Lc == self.local_condition_channels
+        up = Upsampled(self, mel)
+        if materialize is None:
+            materialize = not self.fused_conditioning()
+        return up.tensor() if materialize else up
+
+    def _upsample_now(self, mel):
+        B, Tm, Lc = mel.shape
         with torch.cuda.device(self.device):
             out = torch.empty((B, Tm * self.hop_size, Lc), dtype=torch.float32, device=self.device)
             scratch = torch.empty_like(out)
@@ -126,10 +161,18 @@ class WaveNetModel(object):
     def _condition(self, upsampled, gc_ids, n_steps):
         B = self.batch_size
         with torch.cuda.device(self.device):
-            cond = torch.empty(self._L.twv_wavenet_cond_bytes(self._h, B, n_steps) // 4, dtype=torch.float32, device=self.device)
             gc = None
             if self.global_condition_channels:
                 gc = torch.as_tensor(np.asarray(gc_ids, dtype=np.int32), device=self.device).contiguous()
+            if isinstance(upsampled, Upsampled) and self.fused_conditioning() and n_steps <= upsampled.shape[1]:
+                mel = upsampled.mel
+                cond = torch.empty(self._L.twv_wavenet_cond_bytes_mel(self._h, B, mel.shape[1]) // 4, dtype=torch.float32, device=self.device)
+                _lib.check(self._L.twv_wavenet_condition_mel(self._h, _ptr(self._packed), _ptr(mel), _ptr(gc), B, mel.shape[1], _ptr(cond), _stream()))
+                self._keep = (gc, mel)
+                return cond
+            if isinstance(upsampled, Upsampled):
+                upsampled = upsampled.tensor()[:, :n_steps]
+            cond = torch.empty(self._L.twv_wavenet_cond_bytes(self._h, B, n_steps) // 4, dtype=torch.float32, device=self.device)
             up = None
             if self.local_condition_channels:
                 up = torch.as_tensor(upsampled, dtype=torch.float32, device=self.device).contiguous()
