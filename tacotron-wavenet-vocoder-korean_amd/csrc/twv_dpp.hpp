@@ -111,33 +111,101 @@ __device__ __forceinline__ float dot16_dpp(const float (&w)[16], float z)
     return c0 + c1;
 }
 
-// model.py:66-101 for one step of one stream; X in / out in the X layout, returns z in the Z layout.
-// pre = tap-0 chunk (x[t-d], computed off the chain), lcv = lc projection (model.py:75-83); statement order of the reference:
-// ((conv + bias) + gc) + lc, conv = chunk(tap 0) + chunk(tap 1).
-__device__ __forceinline__ float layer_body_dpp2(const float (&wc)[32], const float (&wd)[16], float bfg, float gcv, float bd,
-                                                 const ActCoef& coef, float& X, float pre, float lcv, bool use_bias, bool has_gc,
-                                                 bool has_lc)
+// model.py:66-101 for one step of one stream, in two halves so that the caller can publish z between them.
+// front: X (X layout) -> z (Z layout).  pre = tap-0 chunk (x[t-d], computed off the chain), lcv = lc projection (model.py:75-83);
+// statement order of the reference: ((conv + bias) + gc) + lc, conv = chunk(tap 0) + chunk(tap 1).
+// ALL = biases, gc and lc all present (hparams default): no selects on the dependency chain.
+template <bool ALL>
+__device__ __forceinline__ float layer_front_dpp(const float (&wc)[32], float bfg, float gcv, const ActCoef& coef, float X, float pre,
+                                                 float lcv, bool use_bias, bool has_gc, bool has_lc)
 {
     const auto xs = __builtin_amdgcn_permlane32_swap(__float_as_uint(X), __float_as_uint(X), false, false);
     const float acc1 = dot32_dpp(wc, __uint_as_float(xs[0]), __uint_as_float(xs[1]));
     float v = pre + acc1;
-    if (use_bias) v = v + bfg;
-    if (has_gc) v = v + gcv;                                                 // model.py:71-73
-    if (has_lc) v = v + lcv;                                                 // model.py:75-83
+    if (ALL) {
+        v = v + bfg;
+        v = v + gcv;
+        v = v + lcv;
+    } else {
+        if (use_bias) v = v + bfg;
+        if (has_gc) v = v + gcv;                                             // model.py:71-73
+        if (has_lc) v = v + lcv;                                             // model.py:75-83
+    }
     const float act = act_eval_pk(coef, v);                                  // model.py:86: lanes 0-31 tanh, 32-63 logistic
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
-    const float z = __uint_as_float(sw[0]) * __uint_as_float(sw[1]);
-    const float s = dot16_dpp(wd, z);                                        // model.py:89 dense 1x1
+    return __uint_as_float(sw[0]) * __uint_as_float(sw[1]);
+}
+// back: model.py:89 dense 1x1 of z, model.py:98-101 residual; X in / out in the X layout
+template <bool ALL>
+__device__ __forceinline__ void layer_back_dpp(const float (&wd)[16], float bd, float z, float& X, bool use_bias)
+{
+    const float s = dot16_dpp(wd, z);
     const auto ds = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
     float tr = __uint_as_float(ds[0]) + __uint_as_float(ds[1]);
-    if (use_bias) tr = tr + bd;
-    X = X + tr;                                                              // model.py:98-101 residual
+    if (ALL || use_bias) tr = tr + bd;
+    X = X + tr;
+}
+__device__ __forceinline__ float layer_body_dpp2(const float (&wc)[32], const float (&wd)[16], float bfg, float gcv, float bd,
+                                                 const ActCoef& coef, float& X, float pre, float lcv, bool use_bias, bool has_gc,
+                                                 bool has_lc)
+{
+    const float z = layer_front_dpp<false>(wc, bfg, gcv, coef, X, pre, lcv, use_bias, has_gc, has_lc);
+    layer_back_dpp<false>(wd, bd, z, X, use_bias);
     return z;
 }
 __device__ __forceinline__ float layer_body_dpp(const LayerRegs& W, const ActCoef& coef, float& X, float pre, float lcv,
                                                 bool use_bias = true, bool has_gc = true, bool has_lc = true)
 {
     return layer_body_dpp2(W.wc, W.wd, W.bfg, W.gcv, W.bd, coef, X, pre, lcv, use_bias, has_gc, has_lc);
+}
+
+// The causal layer's chunk (model.py:41-46) with the newest sample split off: the queue holds the last 32 inputs, k = 31 the newest.
+// Chain j of AC-1 takes k = j, j+4, ..; k = 31 is the LAST term of chain 3, so the other 31 terms are summed before the sample
+// exists; what is left on the sample-to-sample path is one fma and the three adds.  ha / hb: all rows hist[n] / hist[16+n]
+// (lane 15 of hb is not read).
+__device__ __forceinline__ void causal_partial_dpp(const float (&w)[32], float ha, float hb, float (&c)[4])
+{
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+    asm volatile(
+        "s_nop 1\n"
+        "v_fmac_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %10 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %19 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %20 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+        : "v"(ha), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
+    asm volatile(
+        "s_nop 1\n"
+        "v_fmac_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %10 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %19 row_newbcast:14 row_mask:0xf bank_mask:0xf"
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+        : "v"(hb), "v"(w[16]), "v"(w[17]), "v"(w[18]), "v"(w[19]), "v"(w[20]), "v"(w[21]), "v"(w[22]), "v"(w[23]), "v"(w[24]), "v"(w[25]), "v"(w[26]), "v"(w[27]), "v"(w[28]), "v"(w[29]), "v"(w[30]));
+    c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
 }
 
 }  // namespace twv

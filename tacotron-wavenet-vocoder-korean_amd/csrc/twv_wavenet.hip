@@ -1766,6 +1766,7 @@ static int generate_impl(const twv_wavenet* h, const void* packed, void* state, 
         XcdLaunch x;
         x.P = a.P; x.state = a.state; x.cond = a.cond; x.first_input = first_input; x.forced = forced;
         x.uniforms = (const float*)uniforms; x.out = (float*)out; x.status = status; x.dbg = debug; x.dbg_steps = a.dbg_steps;
+        x.prof = a.prof; x.prof_steps = a.prof_steps;
         x.B = batch; x.T = n_steps; x.lay = L;
         unsigned char* xb = reinterpret_cast<unsigned char*>((float*)state + (size_t)L.state_stride * (size_t)batch) + (size_t)batch * 2 * L.S * 8;
         HIPCHK(hipMemsetAsync(xb, 0, xcd_exchange_bytes(batch), st));

@@ -59,6 +59,18 @@ __device__ __forceinline__ void xb_store(rsrc_t rs, int uword, int lword, unsign
     __builtin_amdgcn_raw_buffer_store_b64(u32x2v{__float_as_uint(v), tag}, rs, lword * 8, uword * 8, kAuxStore);
     asm volatile("" ::: "memory");
 }
+// two self-tagged 8-byte granules {a, tag}, {b, tag} with ONE 16-byte store (readers load the halves separately)
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void xb_store2(rsrc_t rs, int uword, int lane, unsigned tag, float va, float vb)
+{
+    const u32x4s d = {__float_as_uint(va), tag, __float_as_uint(vb), tag};
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, lane * 16, uword * 8, kAuxStore);
+    // Store-data hazard: a VMEM store of more than 64 bits reads its data registers over the following cycles, and the compiler's
+    // hazard recogniser exempts buffer stores whose soffset is an SGPR -- on gfx950 the very next v_mov into the tuple still tore the
+    // granule (lanes 12-15 of every row stored the NEW register contents: tags went missing once in ~10^4 stores).  Keeping the
+    // tuple alive as an operand of the wait states makes the window safe whatever the scheduler does.
+    asm volatile("s_nop 1" ::"v"(d) : "memory");
+}
 __device__ __forceinline__ unsigned g_tag(unsigned long long q) { return (unsigned)(q >> 32); }
 __device__ __forceinline__ float g_val(unsigned long long q) { return __uint_as_float((unsigned)q); }
 
@@ -95,6 +107,13 @@ __device__ __forceinline__ int lane_of_x(int j) { return j < 16 ? j : 16 + j; }
 // a chain wave's per-layer registers (the dense kernel lives in LDS)
 struct ChainRegs { float wc[32]; float bfg, gcv, bd; };
 
+// phase stamps (instrumented build only): lane 0 of stream 0's workgroups; s_memrealtime (100 MHz, ONE clock for the chip --
+// s_memtime counters of different CUs are offset against each other by milliseconds)
+#define XSTAMP(cond_, slot_) do { if (INSTR && a.prof != nullptr && b == 0 && t < a.prof_steps && lane == 0 && (cond_)) a.prof[(long long)t * 64 + (slot_)] = wall_clock64(); } while (0)
+
+// where a wave is (instrumented build only): read back from the exchange area after a watchdog abort
+#define XMARK(role_, stage_) do { if (INSTR && lane == 0) xb_store(rs, (int)XcdExch::MARK + (role_) * 8 + (int)(threadIdx.x >> 6), 0, (unsigned)t + 1u, (float)(stage_)); } while (0)
+
 enum { ROLE_CHAIN = 0, ROLE_SERVICE = 1, ROLE_SKIP0 = 2, ROLE_CONV0 = 10, ROLE_LC0 = 18 };
 
 struct XArgs {
@@ -106,7 +125,7 @@ struct XArgs {
 //  CHAIN workgroup: model.py:41-46 causal layer (wave 0), model.py:66-101 residual layers (relay over the waves),
 //  mixture.py:84-114 sampler (wave 7)
 // =====================================================================================================================
-template <bool INSTR>
+template <bool INSTR, bool ALL>
 __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
 {
     const XcdLaunch& a = xa.p;
@@ -145,18 +164,20 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
         }
     }
     // wave 7: causal kernel (model.py:41-46), every lane the 32 taps of ITS residual channel (X layout), in the registers of the
-    // fourth layer slot (wave 7 holds three layers); causal queue (model.py:52)
-    float hv = 0.0f, first_in = 0.0f;
-    if (head) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.P + L.off_xc) + lane;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { const f32x4 v = src[q * 64]; W[3].wc[4 * q] = v.x; W[3].wc[4 * q + 1] = v.y; W[3].wc[4 * q + 2] = v.z; W[3].wc[4 * q + 3] = v.w; }
-        hv = stb[L.st_hist + lane];
-        if (!forced) first_in = reinterpret_cast<const float*>(a.first_input)[b];
-    }
-    // wave 7: the sampler's constants and the noise terms of step 0
+    // fourth layer slot (wave 7 holds three layers); causal queue (model.py:52) as two row-broadcast registers:
+    // ha: every row hist[n], hb: every row hist[16+n]  (hist[31] = newest input)
+    float ha = 0.0f, hb = 0.0f, first_in = 0.0f, b2v = 0.0f, s_lnl = 0.0f, s_tq = 0.0f, samp = 0.0f;
+    float cp[4] = {0.0f, 0.0f, 0.0f, 0.0f};                   // the causal chunk without its newest term
     const bool sampler = head && !forced;
-    float b2v = 0.0f, s_lnl = 0.0f, s_tq = 0.0f, samp = 0.0f;
+    const bool is15 = (lane & 15) == 15;
+    // model.py:122 queue shift (the slot of the newest sample stays open) + the 31 terms that do not need it
+    auto causal_prepare = [&]() {
+        const float t1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ha), 0x101, 0xf, 0xf, true));   // row_shl:1
+        const float b0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(hb), 0x150, 0xf, 0xf, true));   // row_newbcast:0
+        ha = is15 ? b0 : t1;
+        hb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(hb), 0x101, 0xf, 0xf, true));
+        causal_partial_dpp(W[3].wc, ha, hb, cp);
+    };
     auto noise = [&](int t) {
         // mixture.py:103 -log(-log u) per mixture lane; mixture.py:110-111 log u - log(1 - u) of the last draw
         const float* up = a.uniforms + ((long long)b * T + t) * (L.nr_mix + 1);
@@ -165,24 +186,39 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
         const float uu = __shfl(u, L.nr_mix);
         s_tq = log_e(uu) - log_e(1.0f - uu);
     };
-    if (sampler) {
-        if (use_bias && lane < L.O) b2v = a.P[L.off_b2 + lane];
-        noise(0);
+    if (head) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.P + L.off_xc) + lane;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const f32x4 v = src[q * 64]; W[3].wc[4 * q] = v.x; W[3].wc[4 * q + 1] = v.y; W[3].wc[4 * q + 2] = v.z; W[3].wc[4 * q + 3] = v.w; }
+        ha = stb[L.st_hist + (lane & 15)];
+        hb = stb[L.st_hist + 16 + (lane & 15)];
+        if (!forced) first_in = reinterpret_cast<const float*>(a.first_input)[b];
+        if (sampler && use_bias && lane < L.O) b2v = a.P[L.off_b2 + lane];
+        causal_prepare();
     }
     __builtin_amdgcn_s_waitcnt(0);        // every register image and LDS copy has landed before the relay starts
 
     float X = 0.0f;
     for (int t = 0; t < T && !pl.dead; ++t) {
         const unsigned tag = (unsigned)t + 1u;
-        // ---- wave 7, head of the step: new input sample -> causal queue -> causal layer -> wave 0
+        // ---- wave 7, head of the step: new input sample -> causal layer -> wave 0.  On the sample-to-sample path: one fma, three adds.
         if (head) {
-            const float sh = __shfl_down(hv, 1);                       // model.py:122 queue shift
+            XSTAMP(true, 0);
             const float s_in = forced ? reinterpret_cast<const float*>(a.forced)[(long long)b * T + t] : (t == 0 ? first_in : samp);
-            if (lane == 0) xb_store(rs, (int)XcdExch::CTRL, 0, tag, 0.0f);     // progress: step t has started (the lc workgroups throttle on it)
-            hv = (lane == 31) ? s_in : sh;
-            const float x0 = dot_readlane_pipe_a(W[3].wc, hv);          // model.py:41-46: one AC-1 chunk, no bias; X layout
+            const float c3 = fma_(W[3].wc[31], s_in, cp[3]);            // k = 31, the last term of chain 3
+            const float x0 = (cp[0] + cp[1]) + (cp[2] + c3);            // model.py:41-46: one AC-1 chunk, no bias; X layout
             LDSU64(0 * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(x0);
+            XSTAMP(true, 1);
+            // off the path: results out, progress, the queue takes the sample, next step's partial chunk and noise terms
+            if (lane == 0) {
+                if (sampler && t > 0) a.out[(long long)b * T + t - 1] = samp;
+                xb_store(rs, (int)XcdExch::CTRL, 0, tag, 0.0f);        // step t has started (the lc workgroups throttle on it)
+            }
+            hb = is15 ? s_in : hb;                                      // (ha, hb) = the queue after step t
+            if (t + 1 < T) causal_prepare();
+            if (sampler) noise(t);
         }
+        XMARK(ROLE_CHAIN, 1);
         // ---- (A) this step's tap-0 chunks and lc projections of the wave's layers (service workgroup; long since published)
         float pre[4] = {0.0f, 0.0f, 0.0f, 0.0f}, lcv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (nl > 0) {
@@ -203,6 +239,8 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                 __builtin_amdgcn_s_sleep(4);
             }
             if (pl.dead) break;
+            XSTAMP(true, 26 + w);
+            XMARK(ROLE_CHAIN, 2);
             // ---- (B) the wave's input: the previous wave's residual vector (wave 0: the causal layer's output)
             unsigned long long q;
             pl.it = 0;
@@ -213,6 +251,8 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
             }
             if (pl.dead) break;
             X = g_val(q);
+            XSTAMP(true, 2 + w);
+            XMARK(ROLE_CHAIN, 3);
         }
         // ---- the wave's layers
 #pragma unroll
@@ -224,10 +264,11 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                     const f32x4 v = LDS4((O_WD >> 2) + ((l0 + i) * 4 + q) * 64 + lane);
                     wd[4 * q] = v.x; wd[4 * q + 1] = v.y; wd[4 * q + 2] = v.z; wd[4 * q + 3] = v.w;
                 }
-                const float x_in = X;
-                const float z = layer_body_dpp2(W[i].wc, wd, W[i].bfg, W[i].gcv, W[i].bd, coef, X, pre[i], lcv[i], use_bias, has_gc, has_lc);
-                xb_store(rs, (int)XcdExch::ZG + (l0 + i) * 64, lane, tag, z);        // -> skip workgroups
-                xb_store(rs, (int)XcdExch::XG + (l0 + i) * 64, lane, tag, x_in);     // -> service workgroup (model.py:145: the queue takes the layer INPUT)
+                const float z = layer_front_dpp<ALL>(W[i].wc, W[i].bfg, W[i].gcv, coef, X, pre[i], lcv[i], use_bias, has_gc, has_lc);
+                // one 16-byte store, two self-tagged halves: {z, tag} -> skip workgroups, {layer input, tag} -> service workgroup
+                // (model.py:145: the queue takes the layer INPUT)
+                xb_store2(rs, (int)XcdExch::ZX + (l0 + i) * 128, lane, tag, z, X);
+                layer_back_dpp<ALL>(wd, W[i].bd, z, X, use_bias);
                 if (INSTR && a.dbg != nullptr && t < a.dbg_steps) {
                     float* dp = a.dbg + ((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)(l0 + i) * 64;
                     if (lane < 32) dp[dpp_z_index(lane)] = z;
@@ -236,6 +277,8 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
             }
         }
         if (next_has && nl > 0) LDSU64((w + 1) * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(X);
+        XSTAMP(nl > 0, 10 + w);
+        XMARK(ROLE_CHAIN, 4);
         // ---- sampler: conv1d_2's [16 chunks][32 lanes] partial table from the conv1 workgroups -> mixture.py:84-114
         if (sampler) {
             const int half = lane >> 5;
@@ -252,6 +295,8 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                 if (!poll_tick(pl, 34)) break;
             }
             if (pl.dead) break;
+            XSTAMP(true, 18);
+            XMARK(ROLE_CHAIN, 5);
             float acc = g_val(q[0]);                                   // chunk partials added in chunk order (AC-1)
 #pragma unroll
             for (int k = 1; k < 8; ++k) acc = acc + g_val(q[k]);
@@ -282,16 +327,17 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
             float xs = mean + prod;
             xs = xs > -1.0f ? xs : -1.0f;                              // mixture.py:113
             xs = xs < 1.0f ? xs : 1.0f;
-            samp = xs;                                                 // uniform: the next step's input, straight into the causal queue
-            if (lane == 0) a.out[(long long)b * T + t] = xs;
-            if (t + 1 < T) noise(t + 1);                               // off the critical path: the next step's noise terms
+            samp = xs;                                                 // uniform: the next step's input, straight into the causal layer
+            XSTAMP(true, 19);
         }
         if (LDSU64(O_ABORT) != 0ull) break;
     }
     if (pl.dead) LDSU64(O_ABORT) = 1ull;
-    // ---- persist (model.py:49-64 causal queue)
+    // ---- persist (model.py:49-64 causal queue): canonical order, element k = k-th oldest input
     if (head) {
-        stb[L.st_hist + lane] = hv;
+        if (sampler && !pl.dead && T > 0 && lane == 0) a.out[(long long)b * T + T - 1] = samp;
+        if (lane < 16) stb[L.st_hist + lane] = ha;
+        else if (lane < 32) stb[L.st_hist + lane] = hb;
         if (lane == 0) {
             int* meta = reinterpret_cast<int*>(stb + L.st_meta);
             meta[M_TABS] = meta[M_TABS] + T;
@@ -309,6 +355,7 @@ __device__ __forceinline__ unsigned ring_slot(unsigned pos0, unsigned t, unsigne
     const unsigned v = pos0 + t;
     return (d & (d - 1)) == 0 ? (v & (d - 1)) : v % d;
 }
+template <bool INSTR>
 __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
 {
     const XcdLaunch& a = xa.p;
@@ -370,12 +417,13 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
                 // next step's operand when it is already in the delay line (d >= 2): requested before the wait
                 float oa = 0.0f, ob = 0.0f;
                 if (more && dil[i] > 1) tap0(i, (unsigned)t + 1u, oa, ob);
+                XMARK(ROLE_SERVICE, 10 + i);
                 // the layer input x_l[t] from the chain
                 unsigned long long qa, qb;
                 pl.it = 0;
                 for (;;) {
-                    qa = xb_load(rs, (int)XcdExch::XG + l * 64, n16);
-                    qb = xb_load(rs, (int)XcdExch::XG + l * 64 + 32, n16);
+                    qa = xb_load(rs, (int)XcdExch::ZX + l * 128 + 1, n16 * 2);
+                    qb = xb_load(rs, (int)XcdExch::ZX + l * 128 + 65, n16 * 2);
                     if (__all(g_tag(qa) == tag && g_tag(qb) == tag)) break;
                     if (!poll_tick(pl, 41)) break;
                     __builtin_amdgcn_s_sleep(8);
@@ -389,6 +437,7 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
                     if (dil[i] == 1) { oa = xa_; ob = xb_; }
                     const float pre = dot32_dpp(t0[i].w, oa, ob);
                     float lcv = 0.0f;
+                    XMARK(ROLE_SERVICE, 20 + i);
                     if (has_lc) {
                         // lc frame used at step t+1 = frame pushed at step t (model.py:79-80: slice from the FRONT of the queue)
                         const int lw = (int)XcdExch::LCR + (((t + 1) % kXcdLcRing) * 32 + l) * 64;
@@ -420,6 +469,7 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
 //  SKIP workgroup g: model.py:94-96 skip 1x1 of every layer for output block g, model.py:154 sum over the layers in layer
 //  order, model.py:157 relu.  Wave v owns layers v, v+8, ...; the wave that owns the last layer adds the values up as they appear.
 // =====================================================================================================================
+template <bool INSTR>
 __device__ __forceinline__ void skip_role(const XArgs& xa, int b, int g, rsrc_t rs)
 {
     const XcdLaunch& a = xa.p;
@@ -455,28 +505,10 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, int b, int g, rsrc_t 
         for (int i = 0; i < 4; ++i) {
             if (i < nown && !pl.dead) {
                 const int l = v + 8 * i;
-                if (period) nap_until(seen[i] + period - (period >> 3));
-                unsigned long long qa, qb;
-                pl.it = 0;
-                for (;;) {
-                    qa = xb_load(rs, (int)XcdExch::ZG + l * 64, za_lane);
-                    qb = xb_load(rs, (int)XcdExch::ZG + l * 64, zb_lane);
-                    if (__all(g_tag(qa) == tag && g_tag(qb) == tag)) break;
-                    if (!poll_tick(pl, 51)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (pl.dead) break;
-                {
-                    const unsigned long long now = __builtin_amdgcn_s_memtime();
-                    if (i == 0) { const unsigned long long d = now - seen[0]; period = (seen[0] != 0 && d < (1ull << 18)) ? d : 0; }
-                    seen[i] = now;
-                }
-                float val = dot32_dpp(ws[i].w, g_val(qa), g_val(qb));                 // model.py:96
-                if (use_bias) val = val + bs[i];
-                if (!summer) {
-                    LDSU64(l * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(val);
-                } else {
-                    // model.py:154 sum(outputs): layers nextl .. l-1 come from the other waves, in layer order
+                XMARK(ROLE_SKIP0 + g, 20 + i);
+                if (summer) {
+                    // model.py:154 sum(outputs): the values of layers nextl .. l-1 come from the other waves; they are added, in layer
+                    // order, WHILE this wave's own layer is still on its way, so that after the last layer one add is left
                     for (; nextl < l && !pl.dead; ++nextl) {
                         unsigned long long q;
                         pl.it = 0;
@@ -487,6 +519,37 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, int b, int g, rsrc_t 
                         }
                         tot = (nextl == 0) ? g_val(q) : tot + g_val(q);
                     }
+                    if (pl.dead) break;
+                } else if (period) {
+                    nap_until(seen[i] + period - (period >> 3));
+                }
+                XMARK(ROLE_SKIP0 + g, 10 + i);
+                unsigned long long qa, qb;
+                pl.it = 0;
+                for (;;) {
+                    qa = xb_load(rs, (int)XcdExch::ZX + l * 128, za_lane * 2);
+                    qb = xb_load(rs, (int)XcdExch::ZX + l * 128, zb_lane * 2);
+                    if (__all(g_tag(qa) == tag && g_tag(qb) == tag)) break;
+                    if (!poll_tick(pl, 51)) break;
+                    if (!summer) __builtin_amdgcn_s_sleep(1);
+                }
+                if (INSTR && pl.dead && g == 0 && lane == 0) {   // bring-up: what the abandoned poll last saw
+                    xb_store(rs, (int)XcdExch::MARK + 176 + v * 4, 0, g_tag(qa), __uint_as_float(g_tag(qb)));
+                    xb_store(rs, (int)XcdExch::MARK + 177 + v * 4, 0, (unsigned)l, __uint_as_float((unsigned)pl.it));
+                    xb_store(rs, (int)XcdExch::MARK + 178 + v * 4, 0, tag, __uint_as_float((unsigned)i));
+                }
+                if (pl.dead) break;
+                if (!summer) {
+                    const unsigned long long now = __builtin_amdgcn_s_memtime();
+                    if (i == 0) { const unsigned long long d = now - seen[0]; period = (seen[0] != 0 && d < (1ull << 18)) ? d : 0; }
+                    seen[i] = now;
+                }
+                XSTAMP(g == 0 && summer && l == NL - 1, 20);
+                float val = dot32_dpp(ws[i].w, g_val(qa), g_val(qb));                 // model.py:96
+                if (use_bias) val = val + bs[i];
+                if (!summer) {
+                    LDSU64(l * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(val);
+                } else {
                     tot = (l == 0) ? val : tot + val;
                     nextl = l + 1;
                 }
@@ -495,6 +558,7 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, int b, int g, rsrc_t 
         if (summer && !pl.dead) {
             const float h = tot > 0.0f ? tot : 0.0f;                                   // model.py:157
             xb_store(rs, (int)XcdExch::H1 + g * 64, lane, tag, h);
+            XSTAMP(g == 0, 21);
         }
     }
 }
@@ -503,6 +567,7 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, int b, int g, rsrc_t 
 //  CONV1 workgroup g: model.py:158-160 conv1d_1 + relu for output block g (16 chunk tiles over the 8 waves), then the two
 //  chunks (2g, 2g+1) of model.py:161-165 conv1d_2 that read this block: what travels on is conv1d_2's partial table.
 // =====================================================================================================================
+template <bool INSTR>
 __device__ __forceinline__ void conv1_role(const XArgs& xa, int b, int g, rsrc_t rs)
 {
     const XcdLaunch& a = xa.p;
@@ -525,19 +590,17 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, int b, int g, rsrc_t
         if (use_bias) b1v = a.P[L.off_b1 + g * 64 + lane];
         load_tile(t2, a.P + L.off_w2 + (long long)(2 * g + v) * kTile, lane);
     }
-    const int n16 = lane & 15;
     unsigned long long t_arr = 0, period = 0;
     for (int t = 0; t < T && !pl.dead; ++t) {
         const unsigned tag = (unsigned)t + 1u;
         if (period) nap_until(t_arr + period - (period >> 3));
-        unsigned long long q0, q1, q2, q3;
+        XMARK(ROLE_CONV0 + g, 1);
+        // this wave's two chunks are exactly the 64 values skip workgroup v publishes: ONE granule per lane
+        unsigned long long q;
         pl.it = 0;
         for (;;) {
-            q0 = xb_load(rs, (int)XcdExch::H1 + c0 * 32, n16);
-            q1 = xb_load(rs, (int)XcdExch::H1 + c0 * 32 + 16, n16);
-            q2 = xb_load(rs, (int)XcdExch::H1 + c1 * 32, n16);
-            q3 = xb_load(rs, (int)XcdExch::H1 + c1 * 32 + 16, n16);
-            if (__all(g_tag(q0) == tag && g_tag(q1) == tag && g_tag(q2) == tag && g_tag(q3) == tag)) break;
+            q = xb_load(rs, (int)XcdExch::H1 + v * 64, lane);
+            if (__all(g_tag(q) == tag)) break;
             if (!poll_tick(pl, 61)) break;
             __builtin_amdgcn_s_sleep(1);
         }
@@ -548,15 +611,24 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, int b, int g, rsrc_t
             period = (t_arr != 0 && d < (1ull << 18)) ? d : 0;
             t_arr = now;
         }
-        lds[O_PART + c0 * 64 + lane] = dot32_dpp(ta.w, g_val(q0), g_val(q1));
-        lds[O_PART + c1 * 64 + lane] = dot32_dpp(tb.w, g_val(q2), g_val(q3));
+        XSTAMP(g == 0 && v == 0, 22);
+        // rows r0..r3 of the wave = h1[64v + 16r ..]; the dots want "every row r0" / "every row r1" (chunk c0) and r2 / r3 (chunk c1)
+        const unsigned hq = (unsigned)q;
+        const auto p16 = __builtin_amdgcn_permlane16_swap(hq, hq, false, false);        // [r0,r0,r2,r2], [r1,r1,r3,r3]
+        const auto pa = __builtin_amdgcn_permlane32_swap(p16[0], p16[0], false, false);  // [r0 x4], [r2 x4]
+        const auto pb = __builtin_amdgcn_permlane32_swap(p16[1], p16[1], false, false);  // [r1 x4], [r3 x4]
+        lds[O_PART + c0 * 64 + lane] = dot32_dpp(ta.w, __uint_as_float(pa[0]), __uint_as_float(pb[0]));
+        lds[O_PART + c1 * 64 + lane] = dot32_dpp(tb.w, __uint_as_float(pa[1]), __uint_as_float(pb[1]));
         asm volatile("" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(&LDSI(O_CNT), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        XSTAMP(g == 0 && v == 0, 23);
+        XMARK(ROLE_CONV0 + g, 2);
         if (summer) {
             pl.it = 0;
             while (LDSVI(O_CNT) < 8 * (t + 1)) { if (!poll_tick(pl, 62)) break; }
             if (pl.dead) break;
             asm volatile("" ::: "memory");
+            XSTAMP(g == 0 && v == 0, 24);
             float cp[16];
 #pragma unroll
             for (int ch = 0; ch < 16; ++ch) cp[ch] = lds[O_PART + ch * 64 + lane];
@@ -569,6 +641,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, int b, int g, rsrc_t
             // conv1d_2 chunk 2g+v reads h[32v .. 32v+31] of this block
             const float p = (v == 0) ? dot_readlane_pipe(t2, h) : dot_readlane_pipe32(t2, h);
             if (lane < 32) xb_store(rs, (int)XcdExch::PT + (2 * g + v) * 32, lane, tag, p);
+            XSTAMP(g == 0 && v == 0, 25);
         }
     }
     if (pl.dead && lane == 0) LDSI(O_ABORT) = 1;
@@ -578,6 +651,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, int b, int g, rsrc_t
 //  LC workgroups: model.py:102-111 create_upsample (row by row) and model.py:75-83 lc_filter|lc_gate of every layer,
 //  ahead of the chain through the ring XcdExch::LCR.  Wave gw owns layers gw*lpw .. gw*lpw+lpw-1 (NLC tiles each).
 // =====================================================================================================================
+template <bool INSTR>
 __device__ __forceinline__ void lc_role(const XArgs& xa, int b, int wg, rsrc_t rs)
 {
     const XcdLaunch& a = xa.p;
@@ -616,6 +690,8 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, int b, int wg, rsrc_t r
         return;
     }
     for (int u = 0; u < T && !pl.dead; ++u) {
+        const int t = u;
+        XMARK(ROLE_LC0 + wg, 1);
         // ---- throttle: slot (u+1) % ring is free once the chain has started step u + 2 - ring
         if (u + 3 - kXcdLcRing > 0) {
             pl.it = 0;
@@ -710,11 +786,15 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
     if (ticket >= ROLE_LC0 + xa.n_lc_wg) return;                 // surplus workgroup (or an XCD without a stream)
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.exch + (long long)b * XcdExch::WORDS, 0, (int)(XcdExch::WORDS * 8), 0x00020000);
     const bool forced = a.forced != nullptr;
-    if (ticket == ROLE_CHAIN) chain_role<INSTR>(xa, b, rs);
-    else if (ticket == ROLE_SERVICE) service_role(xa, b, rs);
-    else if (ticket < ROLE_CONV0) { if (!forced) skip_role(xa, b, ticket - ROLE_SKIP0, rs); }
-    else if (ticket < ROLE_LC0) { if (!forced) conv1_role(xa, b, ticket - ROLE_CONV0, rs); }
-    else lc_role(xa, b, ticket - ROLE_LC0, rs);
+    if (ticket == ROLE_CHAIN) {
+        // hparams default (biases, gc, lc all present): no selects on the dependency chain
+        if (a.lay.use_bias && a.lay.G > 0 && a.lay.L > 0) chain_role<INSTR, true>(xa, b, rs);
+        else chain_role<INSTR, false>(xa, b, rs);
+    }
+    else if (ticket == ROLE_SERVICE) service_role<INSTR>(xa, b, rs);
+    else if (ticket < ROLE_CONV0) { if (!forced) skip_role<INSTR>(xa, b, ticket - ROLE_SKIP0, rs); }
+    else if (ticket < ROLE_LC0) { if (!forced) conv1_role<INSTR>(xa, b, ticket - ROLE_CONV0, rs); }
+    else lc_role<INSTR>(xa, b, ticket - ROLE_LC0, rs);
 }
 
 // ---- pack: the chain's register images from the canonical blob (generate.py:157-161 Saver.restore) -------------------------
@@ -787,7 +867,7 @@ int xcd_launch(const XcdLaunch& p, hipStream_t st)
     // twice the CUs: a workgroup takes a whole CU (512 threads x ~250 VGPRs); surplus workgroups leave at once, so every XCD's role
     // table fills whatever order the dispatcher uses
     const int grid = 2 * cus;
-    if (p.dbg != nullptr) hipLaunchKernelGGL(wn_xcd_generate_kernel<true>, dim3(grid), dim3(512), shm, st, xa);
+    if (p.dbg != nullptr || p.prof != nullptr) hipLaunchKernelGGL(wn_xcd_generate_kernel<true>, dim3(grid), dim3(512), shm, st, xa);
     else hipLaunchKernelGGL(wn_xcd_generate_kernel<false>, dim3(grid), dim3(512), shm, st, xa);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return twv_fail(TWV_E_HIP, std::string("xcd launch: ") + hipGetErrorString(e));

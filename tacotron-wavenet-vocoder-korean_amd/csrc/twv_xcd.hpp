@@ -20,15 +20,15 @@ enum { XLC_NONE = 0, XLC_UPSAMPLED = 1, XLC_MEL = 2 };
 
 // exchange area of one stream, in 8-byte granules {tag, value}
 struct XcdExch {
-    static constexpr long long ZG = 0;                                  // [32][64] z of layer l, step tag-1    chain -> skip
-    static constexpr long long XG = ZG + 32 * 64;                       // [32][64] layer input                 chain -> service
-    static constexpr long long PG = XG + 32 * 64;                       // [32][64] tap-0 chunk                 service -> chain
+    static constexpr long long ZX = 0;                                  // [32][64] x {z, tag | layer input, tag}: chain -> skip | service
+    static constexpr long long PG = ZX + 32 * 128;                      // [32][64] tap-0 chunk                 service -> chain
     static constexpr long long LG = PG + 32 * 64;                       // [32][64] lc projection               service -> chain
     static constexpr long long H1 = LG + 32 * 64;                       // [512] relu(skip sum)                 skip -> conv1
     static constexpr long long PT = H1 + 512;                           // [16][32] conv1d_2 chunk partials     conv1 -> sampler
     static constexpr long long LCR = PT + 512;                          // [ring][32][64] lc projections        lc -> service
     static constexpr long long CTRL = LCR + (long long)kXcdLcRing * 32 * 64;   // [64] progress, abort
-    static constexpr long long WORDS = CTRL + 64;
+    static constexpr long long MARK = CTRL + 64;                        // [32 roles][8 waves] {step, stage} markers (instrumented build)
+    static constexpr long long WORDS = MARK + 256;
 };
 
 struct XcdLaunch {
@@ -42,6 +42,8 @@ struct XcdLaunch {
     int* status;
     float* dbg;
     int dbg_steps;
+    unsigned long long* prof;      // optional [prof_steps][64] s_memtime stamps of stream 0 (tuning aid; see scripts/xcd_phase_profile.py)
+    int prof_steps;
     int B, T;
     unsigned long long* exch;      // [B][XcdExch::WORDS]
     int* roles;                    // [8] role tickets per XCD (zeroed before the launch)
