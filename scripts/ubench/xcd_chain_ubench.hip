@@ -129,6 +129,74 @@ __global__ void __launch_bounds__(64) layer_dpp_kernel(const LayerCanon* Lc, con
     if ((lane & 16) == 0) xout[od] = X;
 }
 
+
+// ---------------------------------------------------------------- 3b. what each piece of the product's layer loop costs
+// MODE bit0: dense kernel from LDS (4 ds_read_b128 per layer); bit1: one 16-byte granule store + wait states per layer;
+// bit2: run-time layer count (uniform branch per layer); bit3: two 8-byte granule stores instead of bit1's one
+typedef unsigned u32x4t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2t __attribute__((ext_vector_type(2)));
+typedef float f32x4t __attribute__((ext_vector_type(4)));
+extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+#define ULDS4(o) (((__attribute__((address_space(3))) f32x4t*)dyn_lds)[(o)])
+template <int MODE>
+__global__ void __launch_bounds__(64) layer_var_kernel(const LayerCanon* Lc, const float* x0, float* xout, int steps, unsigned long long* cyc, unsigned long long* gran, int nl_rt)
+{
+    const int lane = threadIdx.x;
+    const ActCoef coef = act_coef(lane >= 32);
+    LayerRegs W[NLU];
+    float pre[NLU], lcv[NLU];
+    const int oc = dpp_conv_out(lane), od = dpp_dense_out(lane);
+#pragma unroll
+    for (int l = 0; l < NLU; ++l) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) W[l].wc[k] = Lc[l].Wc[k][oc];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { W[l].wd[i] = Lc[l].Wd[dpp_dense_k(lane, i)][od]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ULDS4((l * 4 + q) * 64 + lane) = f32x4t{W[l].wd[4 * q], W[l].wd[4 * q + 1], W[l].wd[4 * q + 2], W[l].wd[4 * q + 3]};
+        W[l].bfg = Lc[l].bfg[oc]; W[l].gcv = Lc[l].gcv[oc]; W[l].bd = Lc[l].bd[od];
+        pre[l] = Lc[l].pre[oc]; lcv[l] = Lc[l].lcv[oc];
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gran, 0, 1 << 20, 0x00020000);
+    float X = x0[od];
+    const int nl = (MODE & 4) ? nl_rt : NLU;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long w0 = wall_clock64();
+    for (int t = 0; t < steps; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+#pragma unroll
+        for (int l = 0; l < NLU; ++l) {
+            if (l < nl) {
+                float wd[16];
+                if (MODE & 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const f32x4t v = ULDS4((l * 4 + q) * 64 + lane); wd[4 * q] = v.x; wd[4 * q + 1] = v.y; wd[4 * q + 2] = v.z; wd[4 * q + 3] = v.w; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) wd[i] = W[l].wd[i];
+                }
+                const float z = layer_front_dpp<true>(W[l].wc, W[l].bfg, W[l].gcv, coef, X, pre[l], lcv[l], true, true, true);
+                if (MODE & 2) {
+                    const u32x4t d = {__float_as_uint(z), tag, __float_as_uint(X), tag};
+                    __builtin_amdgcn_raw_buffer_store_b128(d, rs, lane * 16, l * 1024, 0);
+                    asm volatile("s_nop 1" ::"v"(d) : "memory");
+                }
+                if (MODE & 8) {
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2t{__float_as_uint(z), tag}, rs, lane * 8, l * 1024, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2t{__float_as_uint(X), tag}, rs, lane * 8, l * 1024 + 512, 0);
+                    asm volatile("" ::: "memory");
+                }
+                layer_back_dpp<true>(wd, W[l].bd, z, X, true);
+            }
+        }
+        X = X * 0.25f;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long w1 = wall_clock64();
+    if (lane == 0) { cyc[0] = t1 - t0; cyc[1] = w1 - w0; }
+    if ((lane & 16) == 0) xout[od] = X;
+}
+
 // ---------------------------------------------------------------- 4. same-XCD hop
 // MODE bit0: sc1 store (else plain), bit1: "sc0 sc1" load (else sc1), bit2: 16-byte granules
 template <int MODE>
@@ -285,6 +353,24 @@ int main()
                badx, badz, NLU * 32, steps, NLU, xb[0]);
         printf("    %.1f memtime ticks = %.1f ns per layer\n", (double)c[0] / steps / NLU, (double)c[1] * 10.0 / steps / NLU);
         fflush(stdout);
+
+        {
+            unsigned long long* gran; CHECK(hipMalloc(&gran, 1 << 20));
+            const char* nm[16] = {"registers only", "+ dense kernel from LDS", "+ 16-B store + s_nop", "+ LDS + 16-B store", "+ run-time layer count", "+ LDS + count", "+ store + count", "+ LDS + store + count (product shape)",
+                                  "+ two 8-B stores", "+ LDS + two 8-B stores", "", "", "+ two 8-B stores + count", "+ LDS + two 8-B stores + count", "", ""};
+            for (int m = 0; m < 14; ++m) {
+                if (m == 10 || m == 11) continue;
+#define LV(M) hipLaunchKernelGGL(layer_var_kernel<M>, dim3(1), dim3(64), 32768, 0, dL, dx0, dxb, steps, dc, gran, NLU)
+                switch (m) { case 0: LV(0); break; case 1: LV(1); break; case 2: LV(2); break; case 3: LV(3); break; case 4: LV(4); break; case 5: LV(5); break; case 6: LV(6); break; case 7: LV(7); break;
+                             case 8: LV(8); break; case 9: LV(9); break; case 12: LV(12); break; default: LV(13); break; }
+#undef LV
+                CHECK(hipDeviceSynchronize());
+                CHECK(hipMemcpy(c, dc, 16, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(xb, dxb, 128, hipMemcpyDeviceToHost));
+                int bad = 0; for (int i = 0; i < 32; ++i) bad += memcmp(&xa[i], &xb[i], 4) != 0;
+                printf("    [3b] %-40s %6.1f ticks = %6.1f ns per layer (x mismatches %d)\n", nm[m], (double)c[0] / steps / NLU, (double)c[1] * 10.0 / steps / NLU, bad);
+            }
+            fflush(stdout);
+        }
     }
     // ---- 4
     {

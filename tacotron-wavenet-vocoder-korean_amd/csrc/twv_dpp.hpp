@@ -84,6 +84,96 @@ __device__ __forceinline__ float dot32_dpp(const float (&w)[32], float xa, float
     return (c0 + c1) + (c2 + c3);
 }
 
+// two independent 32-term chunks (different tiles, different operands) interleaved instruction by instruction: eight fma chains in
+// flight instead of four, so neither dot waits on its own chains (conv1 workgroups: 2 chunk tiles per wave)
+__device__ __forceinline__ void dot32_dpp_x2(const float (&wa)[32], float xa0, float xb0, const float (&wb)[32], float xa1, float xb1,
+                                             float& ra, float& rb)
+{
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
+    asm volatile(
+        "s_nop 1\n"
+        "v_fmac_f32_dpp %0, %8, %10 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %4, %9, %18 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %8, %11 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %5, %9, %19 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %8, %12 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %6, %9, %20 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %8, %13 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %7, %9, %21 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %8, %14 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %4, %9, %22 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %8, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %5, %9, %23 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %8, %16 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %6, %9, %24 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %8, %17 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %7, %9, %25 row_newbcast:7 row_mask:0xf bank_mask:0xf"
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+        : "v"(xa0), "v"(xa1), "v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "v"(wa[4]), "v"(wa[5]), "v"(wa[6]), "v"(wa[7]), "v"(wb[0]), "v"(wb[1]), "v"(wb[2]), "v"(wb[3]), "v"(wb[4]), "v"(wb[5]), "v"(wb[6]), "v"(wb[7]));
+    asm volatile(
+        "s_nop 1\n"
+        "v_fmac_f32_dpp %0, %8, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %4, %9, %18 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %8, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %5, %9, %19 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %8, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %6, %9, %20 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %8, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %7, %9, %21 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %8, %14 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %4, %9, %22 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %8, %15 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %5, %9, %23 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %8, %16 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %6, %9, %24 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %8, %17 row_newbcast:15 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %7, %9, %25 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+        : "v"(xa0), "v"(xa1), "v"(wa[8]), "v"(wa[9]), "v"(wa[10]), "v"(wa[11]), "v"(wa[12]), "v"(wa[13]), "v"(wa[14]), "v"(wa[15]), "v"(wb[8]), "v"(wb[9]), "v"(wb[10]), "v"(wb[11]), "v"(wb[12]), "v"(wb[13]), "v"(wb[14]), "v"(wb[15]));
+    asm volatile(
+        "s_nop 1\n"
+        "v_fmac_f32_dpp %0, %8, %10 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %4, %9, %18 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %8, %11 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %5, %9, %19 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %8, %12 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %6, %9, %20 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %8, %13 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %7, %9, %21 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %8, %14 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %4, %9, %22 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %8, %15 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %5, %9, %23 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %8, %16 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %6, %9, %24 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %8, %17 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %7, %9, %25 row_newbcast:7 row_mask:0xf bank_mask:0xf"
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+        : "v"(xb0), "v"(xb1), "v"(wa[16]), "v"(wa[17]), "v"(wa[18]), "v"(wa[19]), "v"(wa[20]), "v"(wa[21]), "v"(wa[22]), "v"(wa[23]), "v"(wb[16]), "v"(wb[17]), "v"(wb[18]), "v"(wb[19]), "v"(wb[20]), "v"(wb[21]), "v"(wb[22]), "v"(wb[23]));
+    asm volatile(
+        "s_nop 1\n"
+        "v_fmac_f32_dpp %0, %8, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %4, %9, %18 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %8, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %5, %9, %19 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %8, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %6, %9, %20 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %8, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %7, %9, %21 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %8, %14 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %4, %9, %22 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %8, %15 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %5, %9, %23 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %8, %16 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %6, %9, %24 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %8, %17 row_newbcast:15 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %7, %9, %25 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+        : "v"(xb0), "v"(xb1), "v"(wa[24]), "v"(wa[25]), "v"(wa[26]), "v"(wa[27]), "v"(wa[28]), "v"(wa[29]), "v"(wa[30]), "v"(wa[31]), "v"(wb[24]), "v"(wb[25]), "v"(wb[26]), "v"(wb[27]), "v"(wb[28]), "v"(wb[29]), "v"(wb[30]), "v"(wb[31]));
+    ra = (c0 + c1) + (c2 + c3);
+    rb = (d0 + d1) + (d2 + d3);
+}
+
 // a lane's half of a 32-term chunk: two chains, 16 terms, operand vector in the Z layout
 __device__ __forceinline__ float dot16_dpp(const float (&w)[16], float z)
 {
@@ -131,7 +221,7 @@ __device__ __forceinline__ float layer_front_dpp(const float (&wc)[32], float bf
         if (has_gc) v = v + gcv;                                             // model.py:71-73
         if (has_lc) v = v + lcv;                                             // model.py:75-83
     }
-    const float act = act_eval_pk(coef, v);                                  // model.py:86: lanes 0-31 tanh, 32-63 logistic
+    const float act = act_eval_pk_med3(coef, v);                             // model.py:86: lanes 0-31 tanh, 32-63 logistic
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
     return __uint_as_float(sw[0]) * __uint_as_float(sw[1]);
 }

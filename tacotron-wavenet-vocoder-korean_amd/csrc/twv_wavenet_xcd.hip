@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <type_traits>
 #include "../../include/twv_amd.h"
 #include "twv_layout.hpp"
 #include "twv_math.hpp"
@@ -145,7 +146,6 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
     const ActCoef coef = act_coef(lane >= 32);
     float* stb = a.state + (long long)b * L.state_stride;
     Poll pl{rs, a.status, 0, false};
-    constexpr int O_ABORT = 9 * 64;                            // LDS, in 8-byte words: input boxes of waves 0..7, abort word
     constexpr int O_WD = 2048;                                 // LDS floats: dense kernels [layer][4][64 lanes][4]
 
     // ---- the wave's layers: tap-1 conv kernel register-resident for the whole launch, dense kernel LDS-resident
@@ -199,6 +199,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
     __builtin_amdgcn_s_waitcnt(0);        // every register image and LDS copy has landed before the relay starts
 
     float X = 0.0f;
+    unsigned long long t_in = 0, in_period = 0;          // when this wave's input arrived in the previous step, and the step period
     for (int t = 0; t < T && !pl.dead; ++t) {
         const unsigned tag = (unsigned)t + 1u;
         // ---- wave 7, head of the step: new input sample -> causal layer -> wave 0.  On the sample-to-sample path: one fma, three adds.
@@ -217,6 +218,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
             hb = is15 ? s_in : hb;                                      // (ha, hb) = the queue after step t
             if (t + 1 < T) causal_prepare();
             if (sampler) noise(t);
+            __builtin_amdgcn_s_setprio(0);
         }
         XMARK(ROLE_CHAIN, 1);
         // ---- (A) this step's tap-0 chunks and lc projections of the wave's layers (service workgroup; long since published)
@@ -241,7 +243,10 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
             if (pl.dead) break;
             XSTAMP(true, 26 + w);
             XMARK(ROLE_CHAIN, 2);
-            // ---- (B) the wave's input: the previous wave's residual vector (wave 0: the causal layer's output)
+            // ---- (B) the wave's input: the previous wave's residual vector (wave 0: the causal layer's output).  The wave sleeps
+            // through most of the step and polls only when its turn is near: a spinning wave takes issue slots from the wave that
+            // shares its SIMD (waves w and w+4), and that one may be the wave carrying the chain right now.
+            if (in_period) nap_until(t_in + in_period - (in_period >> 4));
             unsigned long long q;
             pl.it = 0;
             for (;;) {
@@ -250,14 +255,22 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                 if (!poll_tick(pl, 33)) break;
             }
             if (pl.dead) break;
+            __builtin_amdgcn_s_setprio(3);
             X = g_val(q);
+            {
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                const unsigned long long d = now - t_in;
+                in_period = (t_in != 0 && d < (1ull << 18)) ? d : 0;
+                t_in = now;
+            }
             XSTAMP(true, 2 + w);
             XMARK(ROLE_CHAIN, 3);
         }
-        // ---- the wave's layers
+        // ---- the wave's layers (the loop is compiled once per layer count: a run-time count costs a branch pair per layer)
+        auto run_layers = [&](auto nc) {
+            constexpr int N = decltype(nc)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i < nl) {
+            for (int i = 0; i < N; ++i) {
                 float wd[16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -275,12 +288,20 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                     if ((lane & 16) == 0) dp[32 + od] = X;
                 }
             }
-        }
+        };
+        if (nl == 4) run_layers(std::integral_constant<int, 4>{});
+        else if (nl == 3) run_layers(std::integral_constant<int, 3>{});
+        else if (nl == 2) run_layers(std::integral_constant<int, 2>{});
+        else if (nl == 1) run_layers(std::integral_constant<int, 1>{});
         if (next_has && nl > 0) LDSU64((w + 1) * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(X);
+        if (!sampler) __builtin_amdgcn_s_setprio(0);
         XSTAMP(nl > 0, 10 + w);
         XMARK(ROLE_CHAIN, 4);
         // ---- sampler: conv1d_2's [16 chunks][32 lanes] partial table from the conv1 workgroups -> mixture.py:84-114
         if (sampler) {
+            __builtin_amdgcn_s_setprio(3);
+            // the [16 chunks][32 lanes] partial table, each granule once: lanes 0-31 chunks 0-7 of output (lane & 31), lanes 32-63
+            // chunks 8-15 (a poll of 16 granules per lane was measured: +0.2 us on the hop)
             const int half = lane >> 5;
             unsigned long long q[8];
             pl.it = 0;
@@ -297,32 +318,35 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
             if (pl.dead) break;
             XSTAMP(true, 18);
             XMARK(ROLE_CHAIN, 5);
-            float acc = g_val(q[0]);                                   // chunk partials added in chunk order (AC-1)
+            float y = g_val(q[0]);                                     // chunk partials added in chunk order (AC-1)
 #pragma unroll
-            for (int k = 1; k < 8; ++k) acc = acc + g_val(q[k]);
+            for (int k = 1; k < 8; ++k) y = y + g_val(q[k]);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)q[k], (unsigned)q[k], false, false);
-                acc = acc + __uint_as_float(sw[1]);                    // chunk 8 + k of the same output (upper half-wave's granule)
+                y = y + __uint_as_float(sw[1]);                        // chunk 8 + k of the same output (upper half-wave's granule)
             }
-            float y = acc;
             if (use_bias && lane < L.O) y = y + b2v;
             if (INSTR && a.dbg != nullptr && t < a.dbg_steps)
                 a.dbg[((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)NL * 64 + lane] = y;
             const int nr = L.nr_mix;
-            const float gmb = y - s_lnl;                               // mixture.py:103
-            int k = 0;
-            float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gmb), 0));
-            for (int i = 1; i < nr; ++i) {
-                const float gi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gmb), i));
-                if (gi > best) { best = gi; k = i; }                   // argmax, first maximum
-            }
-            k = __builtin_amdgcn_readfirstlane(k);
-            const float mean = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), nr + k));        // mixture.py:105
-            float ls = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), 2 * nr + k));             // mixture.py:107
+            // mixture.py:107 exp(max(log_scale, log 1e-14)) on EVERY lane (lane 2nr+i holds log_scale_i), next to the argmax chain
             const float lsmin = (float)-32.23619130191664;
-            ls = ls > lsmin ? ls : lsmin;
-            const float e = exp_e(ls);
+            const float e_all = exp_e(y > lsmin ? y : lsmin);
+            // mixture.py:103 argmax_i(logit_i - log(-log u_i)), first maximum: running maximum over lanes 0..15 with four
+            // v_max_f32 row_shr steps, then the lowest lane that equals it
+            const float ninf = __uint_as_float(0xff800000u);
+            const float gmb = (lane < nr) ? y - s_lnl : ninf;
+            float mx = gmb;
+            mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ninf), __float_as_int(mx), 0x111, 0xf, 0xf, false)));
+            mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ninf), __float_as_int(mx), 0x112, 0xf, 0xf, false)));
+            mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ninf), __float_as_int(mx), 0x114, 0xf, 0xf, false)));
+            mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ninf), __float_as_int(mx), 0x118, 0xf, 0xf, false)));
+            const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx), 15));
+            const unsigned long long hit = __ballot(lane < nr && gmb == best);
+            const int k = hit ? (int)__ffsll((long long)hit) - 1 : 0;
+            const float mean = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), nr + k));        // mixture.py:105
+            const float e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_all), 2 * nr + k));    // mixture.py:107
             const float prod = e * s_tq;                               // mixture.py:110-111
             float xs = mean + prod;
             xs = xs > -1.0f ? xs : -1.0f;                              // mixture.py:113
@@ -330,9 +354,8 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
             samp = xs;                                                 // uniform: the next step's input, straight into the causal layer
             XSTAMP(true, 19);
         }
-        if (LDSU64(O_ABORT) != 0ull) break;
     }
-    if (pl.dead) LDSU64(O_ABORT) = 1ull;
+
     // ---- persist (model.py:49-64 causal queue): canonical order, element k = k-th oldest input
     if (head) {
         if (sampler && !pl.dead && T > 0 && lane == 0) a.out[(long long)b * T + T - 1] = samp;
@@ -505,30 +528,28 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, int b, int g, rsrc_t 
         for (int i = 0; i < 4; ++i) {
             if (i < nown && !pl.dead) {
                 const int l = v + 8 * i;
-                XMARK(ROLE_SKIP0 + g, 20 + i);
-                if (summer) {
-                    // model.py:154 sum(outputs): the values of layers nextl .. l-1 come from the other waves; they are added, in layer
-                    // order, WHILE this wave's own layer is still on its way, so that after the last layer one add is left
+                // model.py:154 sum(outputs), in layer order: the values of layers nextl .. l-1 come from the other waves through LDS
+                auto drain = [&](bool blocking) {
                     for (; nextl < l && !pl.dead; ++nextl) {
                         unsigned long long q;
                         pl.it = 0;
                         for (;;) {
                             q = LDSU64(nextl * 64 + lane);
                             if (__all(g_tag(q) == tag)) break;
-                            if (!poll_tick(pl, 52)) break;
+                            if (!blocking) return;
+                            if (!poll_tick(pl, 52)) return;
                         }
                         tot = (nextl == 0) ? g_val(q) : tot + g_val(q);
                     }
-                    if (pl.dead) break;
-                } else if (period) {
-                    nap_until(seen[i] + period - (period >> 3));
-                }
+                };
+                if (!summer && period) nap_until(seen[i] + period - (period >> 3));
                 XMARK(ROLE_SKIP0 + g, 10 + i);
                 unsigned long long qa, qb;
                 pl.it = 0;
                 for (;;) {
                     qa = xb_load(rs, (int)XcdExch::ZX + l * 128, za_lane * 2);
                     qb = xb_load(rs, (int)XcdExch::ZX + l * 128, zb_lane * 2);
+                    if (summer) drain(false);                          // while the loads are in flight: add what has arrived
                     if (__all(g_tag(qa) == tag && g_tag(qb) == tag)) break;
                     if (!poll_tick(pl, 51)) break;
                     if (!summer) __builtin_amdgcn_s_sleep(1);
@@ -550,6 +571,7 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, int b, int g, rsrc_t 
                 if (!summer) {
                     LDSU64(l * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(val);
                 } else {
+                    drain(true);                                       // whatever is still missing below this layer
                     tot = (l == 0) ? val : tot + val;
                     nextl = l + 1;
                 }
@@ -617,8 +639,10 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, int b, int g, rsrc_t
         const auto p16 = __builtin_amdgcn_permlane16_swap(hq, hq, false, false);        // [r0,r0,r2,r2], [r1,r1,r3,r3]
         const auto pa = __builtin_amdgcn_permlane32_swap(p16[0], p16[0], false, false);  // [r0 x4], [r2 x4]
         const auto pb = __builtin_amdgcn_permlane32_swap(p16[1], p16[1], false, false);  // [r1 x4], [r3 x4]
-        lds[O_PART + c0 * 64 + lane] = dot32_dpp(ta.w, __uint_as_float(pa[0]), __uint_as_float(pb[0]));
-        lds[O_PART + c1 * 64 + lane] = dot32_dpp(tb.w, __uint_as_float(pa[1]), __uint_as_float(pb[1]));
+        float r0, r1;
+        dot32_dpp_x2(ta.w, __uint_as_float(pa[0]), __uint_as_float(pb[0]), tb.w, __uint_as_float(pa[1]), __uint_as_float(pb[1]), r0, r1);
+        lds[O_PART + c0 * 64 + lane] = r0;
+        lds[O_PART + c1 * 64 + lane] = r1;
         asm volatile("" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(&LDSI(O_CNT), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         XSTAMP(g == 0 && v == 0, 23);
