@@ -2,12 +2,18 @@
 """bench.py -- WaveNet autoregressive synthesis throughput on MI355X (BASELINE.json metric).
 
 One "step" = one pass of the hot path over one batch of synthetic input: B=8 utterances x `--seconds` s of 24 kHz
-audio (default 8 s = 192 000 samples each; BASELINE.json configs[1]), mel -> upsample -> hoisted conditioning ->
-persistent generation kernel -> samples, inputs resident in HBM.  Prints ONE JSON line (rank 0).
+audio (default 8 s = 192 000 samples each; BASELINE.json configs[1]): mel -> conditioning -> ONE persistent generation
+launch (create_upsample, lc projections and the 192 000-step sample loop inside it) -> samples; inputs resident in HBM.
+Prints ONE JSON line (rank 0).
+
+`python bench.py --gpus N` starts its own N ranks (torch.distributed.run, 127.0.0.1) when it was not launched under one;
+every rank drives one GPU with its own batch of utterances (weak scaling, no collective on the data path).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -16,31 +22,95 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=8.0, help="audio seconds per utterance (8.0 = the BASELINE config)")
-    ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--workers", type=int, default=0)
-    ap.add_argument("--groups", type=int, default=-1, help="workgroups per stream (-1 = auto)")
+    ap.add_argument("--batch", type=int, default=8, help="utterances per GPU (8 = the BASELINE config; 1 = configs[4]'s one utterance per GPU)")
+    ap.add_argument("--xcd", type=int, default=-1, help="0 = force the generic generation kernel (default: XCD-per-stream kernel where it qualifies)")
+    ap.add_argument("--groups", type=int, default=-1, help="generic kernel: workgroups per stream (-1 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the secondary streams sweep (B = 8, 16, 32 on one GPU)")
     ap.add_argument("--no-tacotron", action="store_true", help="skip the secondary Tacotron mel-frames/s measurement")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement (configs[3], RCCL all-reduce at N>1)")
-    ap.add_argument("--cpu-steps", type=int, default=0, help="oracle sample size in generation steps (0 = auto, about 15 s)")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="host time per CPU-baseline leg")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise the launch / rendezvous / max-over-ranks path (gloo)")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` outside a launcher: become N ranks (one per GPU) and hand back their exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def traffic_per_step(kernel, key):
+    """HBM bytes per generation step from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    scripts/pmc_to_traffic.py), valid only for the library build it was measured on (source hash)."""
+    try:
+        import twvk_amd
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            t = json.load(fh)
+        e = t.get(twvk_amd._lib.source_hash(), {}).get(kernel, {}).get(key)
+        return None if e is None else float(e["fetch_bytes_per_step"]) + float(e["write_bytes_per_step"])
+    except Exception:
+        return None
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
+    assert world == args.gpus, "launched with WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     import numpy as np
     import torch
+
+    if args.dry_run:
+        # the multi-rank skeleton without a GPU: rendezvous on 127.0.0.1, barrier-bracketed timed region, MAX over ranks, rank-0 report
+        dist = None
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+            dist.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.05 * (rank + 1))
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        produced = torch.tensor([1.0, dt], dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(produced[:1], op=dist.ReduceOp.SUM)
+            dist.all_reduce(produced[1:], op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": int(produced[0].item()), "world": world, "max_seconds": float(produced[1].item())}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    import ctypes as C
     import twvk_amd
+    from twvk_amd import _lib
     from twvk_amd.wavenet import WaveNetModel
     from twvk_amd import weights as W
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    assert torch.cuda.device_count() > local_rank, "rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     dist = None
@@ -50,47 +120,50 @@ def main():
 
     hp = twvk_amd.default_hparams()
     dil = [2 ** i for i in range(10)] * 3            # BASELINE configs[1]: 30 dilated residual layers
-    B = args.batch
     Tm = int(round(args.seconds * hp.sample_rate / hp.hop_size))
     T = Tm * hp.hop_size
-    m = WaveNetModel(B, dil, hp.filter_width, hp.residual_channels, hp.dilation_channels, hp.skip_channels,
-                     quantization_channels=hp.quantization_channels, out_channels=hp.out_channels, use_biases=hp.use_biases,
-                     scalar_input=True, initial_filter_width=hp.initial_filter_width,
-                     global_condition_channels=hp.gc_channels, global_condition_cardinality=2,
-                     local_condition_channels=hp.num_mels, upsample_factor=hp.upsample_factor, train_mode=False, device=dev)
-    if args.workers:
-        m.set_option("workers", args.workers)
-    if args.groups >= 0:
-        m.set_option("groups", args.groups)
-    tensors = W.random_tensors(m.specs, seed=0, scale=0.05)
-    m.load_weights(tensors)
-    rng = np.random.RandomState(1 + rank)
-    mel = torch.from_numpy(rng.uniform(-4, 4, (B, Tm, hp.num_mels)).astype(np.float32)).to(dev)
-    gc = (np.arange(B) % 2).astype(np.int32)
-    seed_in = (2 * rng.rand(B) - 1).astype(np.float32)
-    lo, hi = np.float32(1e-5), np.float32(1 - 1e-5)
-    u = torch.from_numpy((rng.random_sample((B, T, 11)).astype(np.float32) * (hi - lo) + lo)).to(dev)
+    tensors = None
 
-    gen_ms = []
+    def make_vocoder(B):
+        nonlocal tensors
+        m = WaveNetModel(B, dil, hp.filter_width, hp.residual_channels, hp.dilation_channels, hp.skip_channels,
+                         quantization_channels=hp.quantization_channels, out_channels=hp.out_channels, use_biases=hp.use_biases,
+                         scalar_input=True, initial_filter_width=hp.initial_filter_width,
+                         global_condition_channels=hp.gc_channels, global_condition_cardinality=2,
+                         local_condition_channels=hp.num_mels, upsample_factor=hp.upsample_factor, train_mode=False, device=dev)
+        if args.xcd >= 0:
+            m.set_option("xcd", args.xcd)
+        if args.groups >= 0:
+            m.set_option("groups", args.groups)
+        if tensors is None:
+            tensors = W.random_tensors(m.specs, seed=0, scale=0.05)
+        m.load_weights(tensors)
+        return m
 
-    def one_pass(timed):
+    def make_inputs(B, T_, seed):
+        rng = np.random.RandomState(seed)
+        mel = torch.from_numpy(rng.uniform(-4, 4, (B, (T_ + hp.hop_size - 1) // hp.hop_size, hp.num_mels)).astype(np.float32)).to(dev)
+        gc = (np.arange(B) % 2).astype(np.int32)
+        seed_in = (2 * rng.rand(B) - 1).astype(np.float32)
+        lo, hi = np.float32(1e-5), np.float32(1 - 1e-5)
+        u = torch.from_numpy((rng.random_sample((B, T_, 11)).astype(np.float32) * (hi - lo) + lo)).to(dev)
+        return mel, gc, seed_in, u
+
+    def one_pass(m, B, T_, mel, gc, seed_in, u):
+        """the whole hot path for one batch; the events bracket the generation kernel on ITS stream"""
         m.queue_initializer()
-        U = m.create_upsample(mel)
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        # generate() = condition (hoisted projections) + the persistent kernel; events bracket the kernel on ITS stream
-        B_, T_ = B, T
+        U = m.create_upsample(mel)                   # fused path: only wraps the mel; generic path: the stand-alone upsampling kernel
         cond = m._condition(U, gc, T_)
-        import ctypes as C
-        from twvk_amd import _lib
         fi = torch.as_tensor(seed_in, device=dev)
-        out = torch.empty((B_, T_), dtype=torch.float32, device=dev)
+        out = torch.empty((B, T_), dtype=torch.float32, device=dev)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         _lib.check(m._L.twv_wavenet_generate(m._h, C.c_void_p(m._packed.data_ptr()), C.c_void_p(m._state.data_ptr()),
                                              C.c_void_p(cond.data_ptr()), C.c_void_p(fi.data_ptr()), C.c_void_p(u.data_ptr()), 1.0,
-                                             B_, T_, C.c_void_p(out.data_ptr()), C.c_void_p(m._status.data_ptr()), None, 0,
+                                             B, T_, C.c_void_p(out.data_ptr()), C.c_void_p(m._status.data_ptr()), None, 0,
                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         e1.record()
-        return out, (e0, e1)
+        return out, (e0, e1), cond
 
     def sync_all():
         torch.cuda.synchronize()
@@ -98,27 +171,30 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    B = args.batch
+    m = make_vocoder(B)
+    fused = m.fused_conditioning()
+    mel, gc, seed_in, u = make_inputs(B, T, 1 + rank)
     for _ in range(args.warmup):
-        out, _ev = one_pass(False)
+        out, _ev, _c = one_pass(m, B, T, mel, gc, seed_in, u)
     sync_all()
     t0 = time.perf_counter()
     evs = []
     for _ in range(args.steps):
-        out, ev = one_pass(True)
+        out, ev, _c = one_pass(m, B, T, mel, gc, seed_in, u)
         evs.append(ev)
     sync_all()
     dt = time.perf_counter() - t0
-    _lib_status = m._L.twv_wavenet_status
-    from twvk_amd import _lib
-    import ctypes as C
-    _lib.check(_lib_status(C.c_void_p(m._status.data_ptr()), None))
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    gen_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
+    _lib.check(m._L.twv_wavenet_status(C.c_void_p(m._status.data_ptr()), None))
     samples = out.cpu().numpy()
-    assert np.isfinite(samples).all() and np.abs(samples).max() <= 1.0
+    ok = bool(np.isfinite(samples).all() and np.abs(samples).max() <= 1.0)
+    produced = torch.tensor([1.0 if ok else 0.0, dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(produced[:1], op=dist.ReduceOp.SUM)       # ranks that produced samples: what n_gpus reports
+        dist.all_reduce(produced[1:], op=dist.ReduceOp.MAX)
+    n_ok, dt = int(produced[0].item()), float(produced[1].item())
+    assert ok, "rank %d: samples are not finite / not in [-1, 1]" % rank
+    gen_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
 
     # secondary: configs[3] teacher-forced training step, per-GPU batch 64 x 8000 (cropped to 7800) samples, data-parallel with a
     # gradient all-reduce over RCCL when N > 1 -- every rank takes part, so it runs before the rank-0 report is assembled
@@ -160,7 +236,7 @@ def main():
             train_res = {"error": repr(e)}
 
     if rank == 0:
-        total_samples = world * B * T * args.steps
+        total_samples = n_ok * B * T * args.steps
         value = total_samples / dt
         # roofline: algorithmic HBM bytes per generation step for all B streams, weights streamed every step
         NL = len(dil)
@@ -169,47 +245,102 @@ def main():
         bytes_per_step = wfloats * 4 + B * (80 + 1 + 1) * 4
         k_ms = float(np.mean(gen_ms))
         achieved = bytes_per_step * T / (k_ms * 1e-3) / 1e9
+        kernel = "wn_xcd_generate_kernel" if fused else "wn_generate_kernel"
+        tps = traffic_per_step(kernel, "B%d_NL%d" % (B, NL))
         res = {
             "metric": "WaveNet autoregressive audio samples/sec at 24 kHz, batch=8",
-            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "samples/s", "n_gpus": n_ok, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: WaveNet autoregressive synth, 30 dilated residual layers (3x[1..512]), R=D=32, S=512, "
                                    "MoL-30 output, gc+lc conditioning, 24 kHz, batch=%d x %.2f s (%d samples each) per GPU, random-init weights, "
                                    "injected uniforms" % (B, T / hp.sample_rate, T),
-                       "batch_per_gpu": B, "samples_per_utterance": T, "sharding": "utterances, one batch of %d per GPU, no collective" % B},
+                       "batch_per_gpu": B, "samples_per_utterance": T, "sharding": "utterances, one batch of %d per GPU, no collective" % B,
+                       "kernel": kernel + (" (one stream per XCD, weights register-resident, create_upsample + lc projections fused into the launch)" if fused else "")},
             "realtime_factor_aggregate": value / hp.sample_rate,
-            "roofline": {"bound": "hbm", "kernel": "wn_generate_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "realtime_factor_per_stream": value / hp.sample_rate / (n_ok * B),
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0,
-                         # HBM bytes per launch from rocprofv3 PMC (separate --pmc passes, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
-                         # measured per generated step on this kernel (profiles/r01_rocprofv3_pmc_fetch_write_generate_0.5s_v3.csv)
-                         "traffic": (1.135e6 + 0.214e6) * T if (B == 8 and NL == 30) else None, "algorithmic_bytes_per_launch": bytes_per_step * T,
-                         "kernel_ms": k_ms, "us_per_generation_step": k_ms * 1e3 / T},
+                         # HBM bytes per launch from rocprofv3 PMC (separate --pmc passes; FETCH_SIZE / WRITE_SIZE with the guide's gfx950
+                         # corrections), per generated step, for THIS build of the library (profiles/traffic.json is keyed by source hash)
+                         "traffic": None if tps is None else tps * T, "algorithmic_bytes_per_launch": bytes_per_step * T,
+                         "kernel_ms": k_ms, "us_per_generation_step": k_ms * 1e3 / T,
+                         "note": "weights are register-/L2-resident: the sample loop is a dependent chain (latency), not a bandwidth stream; "
+                                 "algorithmic bytes assume the weights were re-read from HBM every step (SURVEY.md 8d)"},
         }
+        if not args.no_sweep and world == 1:
+            # what more streams on the same GPU are worth: 1 s of audio per stream at B = 8 (XCD-per-stream kernel), 16 and 32 (generic kernel)
+            sweep = []
+            T1 = hp.sample_rate // hp.hop_size * hp.hop_size
+            for Bs in (8, 16, 32):
+                try:
+                    ms = m if Bs == B else make_vocoder(Bs)
+                    inp = make_inputs(Bs, T1, 50 + Bs)
+                    one_pass(ms, Bs, T1, *inp)
+                    torch.cuda.synchronize()
+                    _o, (s0, s1), _c2 = one_pass(ms, Bs, T1, *inp)
+                    torch.cuda.synchronize()
+                    kms = s0.elapsed_time(s1)
+                    _lib.check(ms._L.twv_wavenet_status(C.c_void_p(ms._status.data_ptr()), None))
+                    sweep.append({"streams": Bs, "samples_per_s": Bs * T1 / (kms * 1e-3), "us_per_generation_step": kms * 1e3 / T1,
+                                  "realtime_factor_per_stream": T1 / (kms * 1e-3) / hp.sample_rate,
+                                  "kernel": "wn_xcd_generate_kernel" if ms.fused_conditioning() else "wn_generate_kernel"})
+                    if ms is not m:
+                        del ms
+                except Exception as e:
+                    sweep.append({"streams": Bs, "error": repr(e)})
+            res["streams_sweep"] = sweep
         if not args.no_cpu_baseline and world == 1:
-            from helpers import make_case
             from oracle import oracle as O
             d = O.make_dims(dil)
             blob = O.blob_from_tensors(d, tensors)
-            st = O.State(d, B)
-            n = args.cpu_steps
-            if not n:   # size the sample for about 15 s of CPU work
-                probe = 200
-                Up = rng.uniform(-1, 1, (B, probe, 80)).astype(np.float32)
+            mel_h = mel.cpu().numpy()
+            # (a) the checker on the timed output: the first 600 samples of every stream, bit for bit
+            ncheck = min(T, 600)
+            Uo = O.upsample(d, blob, mel_h[:, :(ncheck + hp.hop_size - 1) // hp.hop_size])[:, :ncheck]
+            want = O.generate_mol(d, blob, O.State(d, B), Uo, gc, seed_in, u[:, :ncheck].cpu().numpy())
+            assert np.array_equal(samples[:, :ncheck], want), "timed output differs from the CPU checker in the first %d samples" % ncheck
+            res["checked_against_oracle"] = "first %d samples of all %d streams of the last timed pass: bit-identical" % (ncheck, B)
+
+            # (b) the same workload on the host: 1 thread, then one stream per core on every core
+            def cpu_leg(nstreams, threads):
+                rng = np.random.RandomState(77)
+                probe = 100
+                gcs = (np.arange(nstreams) % 2).astype(np.int32)
+                sd = rng.uniform(-1, 1, nstreams).astype(np.float32)
+                uu = rng.uniform(1e-5, 1 - 1e-5, (nstreams, probe, 11)).astype(np.float32)
+                Up = rng.uniform(-1, 1, (nstreams, probe, 80)).astype(np.float32)
+                O.set_threads(threads)
+                st = O.State(d, nstreams)
                 c0 = time.perf_counter()
-                O.generate_mol(d, blob, st, Up, gc, seed_in, u[:, :probe].cpu().numpy())
+                O.generate_mol(d, blob, st, Up, gcs, sd, uu)
                 per = (time.perf_counter() - c0) / probe
-                n = int(max(probe, min(T, 15.0 / max(per, 1e-9))))
-                st.reset()
-            Uc = rng.uniform(-1, 1, (B, n, 80)).astype(np.float32)
-            uc = u[:, :n].cpu().numpy()
-            c0 = time.perf_counter()
-            O.generate_mol(d, blob, st, Uc, gc, seed_in, uc)
-            cdt = time.perf_counter() - c0
-            res["cpu_baseline"] = {"value": B * n / cdt, "unit": "samples/s", "cores": 1, "kind": "port",
+                n = int(max(probe, min(T, args.cpu_seconds / max(per, 1e-9))))
+                uu = rng.uniform(1e-5, 1 - 1e-5, (nstreams, n, 11)).astype(np.float32)
+                Up = rng.uniform(-1, 1, (nstreams, n, 80)).astype(np.float32)
+                st = O.State(d, nstreams)
+                c0 = time.perf_counter()
+                O.generate_mol(d, blob, st, Up, gcs, sd, uu)
+                cdt = time.perf_counter() - c0
+                O.set_threads(1)
+                return nstreams * n / cdt, n, cdt
+            cores = O.set_threads(1)
+            v1, n1, t1 = cpu_leg(B, 1)
+            res["cpu_baseline"] = {"value": v1, "unit": "samples/s", "cores": 1, "kind": "port",
                                    "sample": "build's CPU restatement (oracle/, plain C, 1 thread) of the same model on the GPU box's host: "
                                              "B=%d x %d generation steps = %.1f s of CPU work; NOT the reference generate.py "
-                                             "(TensorFlow is absent; parity unpinned)" % (B, n, cdt)}
+                                             "(TensorFlow is absent; parity unpinned)" % (B, n1, t1)}
+            if cores > 1:
+                vc, nc, tc = cpu_leg(cores, cores)
+                quota = ""
+                try:
+                    with open("/sys/fs/cgroup/cpu.max") as fh:
+                        quota = "; cgroup cpu.max = " + fh.read().strip()
+                except Exception:
+                    pass
+                res["cpu_baseline"]["all_cores"] = {"value": vc, "unit": "samples/s", "cores": cores, "kind": "port",
+                                                    "sample": "the same restatement, one stream per core (OpenMP, %d threads), %d streams x %d steps = %.1f s%s"
+                                                              % (cores, cores, nc, tc, quota)}
         if not args.no_tacotron and world == 1:
             # secondary half of BASELINE.json's metric: Tacotron mel frames/sec at configs[2] (B=32, 100 tokens + EOS, 200 decoder steps)
             try:

@@ -79,6 +79,8 @@ def lib():
         L.twvo_state_free.argtypes = [C.c_void_p]
         L.twvo_step.argtypes = [P, fp, C.c_void_p, fp, ip, fp, ip, fp, fp, fp]
         L.twvo_sample_mol.restype = C.c_float; L.twvo_sample_mol.argtypes = [fp, C.c_int, fp]
+        L.twvo_set_threads.argtypes = [C.c_int]; L.twvo_set_threads.restype = None
+        L.twvo_max_threads.restype = C.c_int
         L.twvo_generate_mol.argtypes = [P, fp, C.c_void_p, fp, ip, fp, fp, C.c_int, C.c_int, fp]
         L.twvo_sample_categorical.restype = C.c_int
         L.twvo_sample_categorical.argtypes = [fp, C.c_int, C.c_double, C.c_double, fp]
@@ -237,6 +239,12 @@ def step(d, blob, st, inp, lc=None, gc_ids=None, debug=False):
 def sample_mol(y, u):
     y = _c32(y); u = _c32(u)
     return float(lib().twvo_sample_mol(_f(y), y.size // 3, _f(u)))
+
+
+def set_threads(n):
+    """threads for generate_mol (one stream per thread); returns the host core count"""
+    lib().twvo_set_threads(int(n))
+    return int(lib().twvo_max_threads())
 
 
 def generate_mol(d, blob, st, U, gc_ids, seed, u):

@@ -82,6 +82,9 @@ float twvo_sample_mol(const float* y, int nr_mix, const float* u);
 
 /* generate.py:199-233 host loop, scalar_input (MoL).  U (B,T,L) upsampled lc; seed (B) = waveform[:,-1] before the loop;
  * u (B,T,nr_mix+1) injected uniforms in [1e-5,1-1e-5]; out (B,T). */
+/* threads for twvo_generate_mol (one stream per thread); twvo_max_threads = host cores */
+void twvo_set_threads(int n);
+int twvo_max_threads(void);
 void twvo_generate_mol(const twvo_dims* d, const float* blob, twvo_state* s, const float* U, const int32_t* gc_ids,
                        const float* seed, const float* u, int B, int T, float* out);
 

@@ -10,6 +10,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "twv_oracle.h"
 
 typedef struct {
@@ -226,24 +229,25 @@ static void postprocess_at(const twvo_dims* d, const float* blob, const blob_off
 }
 
 /* model.py:215-245 predict_proba_incremental up to raw_output, via _create_network's train_mode==False branch */
-void twvo_step(const twvo_dims* d, const float* blob, twvo_state* s,
-               const float* in_scalar, const int32_t* in_q, const float* lc, const int32_t* gc_ids,
-               float* raw_out, float* dbg_z, float* dbg_x)
+/* one stream of twvo_step (private scratch: streams are independent, so callers may run them on different threads) */
+static void step_one(const twvo_dims* d, const float* blob, const blob_offs* op, twvo_state* s, int b,
+                     const float* in_scalar, const int32_t* in_q, const float* lc, const int32_t* gc_ids,
+                     float* raw_out, float* dbg_z, float* dbg_x)
 {
-    blob_offs o; offsets(d, &o);
+    const blob_offs o = *op;
     const int R = d->R, D = d->D, S = d->S, L = d->L;
     float* total = (float*)malloc(sizeof(float) * S), *skip = (float*)malloc(sizeof(float) * S);
-    float* onehot = (float*)calloc(d->Q > 0 ? d->Q : 1, sizeof(float));
     float x[512], z[512], tr[512];
-    for (int b = 0; b < s->B; ++b) {
+    {
         /* model.py:122 causal queue shift+append */
         float* cq = s->causal_q + (size_t)b * s->cq_rows * s->cq_cols;
         if (d->scalar_input) {
             push(cq, s->cq_rows, 1, &in_scalar[b]);
         } else { /* model.py:226 one_hot */
-            memset(onehot, 0, sizeof(float) * d->Q);
+            float* onehot = (float*)calloc(d->Q > 0 ? d->Q : 1, sizeof(float));
             if (in_q[b] >= 0 && in_q[b] < d->Q) onehot[in_q[b]] = 1.0f;
             push(cq, 2, d->Q, onehot);
+            free(onehot);
         }
         /* model.py:125-126 lc queue */
         float* lq = s->lc_q + (size_t)b * 2 * (L ? L : 1);
@@ -265,7 +269,29 @@ void twvo_step(const twvo_dims* d, const float* blob, twvo_state* s,
         }
         postprocess_at(d, blob, &o, total, raw_out + (size_t)b * d->O);
     }
-    free(total); free(skip); free(onehot);
+    free(total); free(skip);
+}
+
+/* model.py:215-245 predict_proba_incremental up to raw_output, via _create_network's train_mode==False branch */
+void twvo_step(const twvo_dims* d, const float* blob, twvo_state* s,
+               const float* in_scalar, const int32_t* in_q, const float* lc, const int32_t* gc_ids,
+               float* raw_out, float* dbg_z, float* dbg_x)
+{
+    blob_offs o; offsets(d, &o);
+    for (int b = 0; b < s->B; ++b) step_one(d, blob, &o, s, b, in_scalar, in_q, lc, gc_ids, raw_out, dbg_z, dbg_x);
+}
+
+/* threads used by twvo_generate_mol (streams are independent: one stream per thread, no barrier inside the sample loop).
+ * 1 = the scalar port; the arithmetic of a stream does not depend on the thread count. */
+static int g_threads = 1;
+void twvo_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int twvo_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_num_procs();
+#else
+    return 1;
+#endif
 }
 
 /* mixture.py:84-114 sample_from_discretized_mix_logistic, uniforms injected */
@@ -289,19 +315,22 @@ float twvo_sample_mol(const float* y, int nr, const float* u)
     return xs;
 }
 
-/* generate.py:199-233 (scalar_input branch) */
+/* generate.py:199-233 (scalar_input branch); the batch lanes of the reference's sess.run are independent streams */
 void twvo_generate_mol(const twvo_dims* d, const float* blob, twvo_state* s, const float* U, const int32_t* gc_ids,
                        const float* seed, const float* u, int B, int T, float* out)
 {
     const int nr = d->O / 3, nu = nr + 1, L = d->L;
+    blob_offs o; offsets(d, &o);
     float* in = (float*)malloc(sizeof(float) * B), *raw = (float*)malloc(sizeof(float) * (size_t)B * d->O);
     float* lc = (float*)malloc(sizeof(float) * (size_t)B * (L ? L : 1));
-    for (int b = 0; b < B; ++b) in[b] = seed[b];
-    for (int t = 0; t < T; ++t) {
-        for (int b = 0; b < B; ++b)
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+#endif
+    for (int b = 0; b < B; ++b) {
+        in[b] = seed[b];
+        for (int t = 0; t < T; ++t) {
             if (L) memcpy(lc + (size_t)b * L, U + ((size_t)b * T + t) * L, sizeof(float) * L); /* generate.py:211 upsampled[:,step,:] */
-        twvo_step(d, blob, s, in, NULL, L ? lc : NULL, gc_ids, raw, NULL, NULL);
-        for (int b = 0; b < B; ++b) {
+            step_one(d, blob, &o, s, b, in, NULL, L ? lc : NULL, gc_ids, raw, NULL, NULL);
             const float smp = twvo_sample_mol(raw + (size_t)b * d->O, nr, u + ((size_t)b * T + t) * nu);
             out[(size_t)b * T + t] = smp;
             in[b] = smp; /* generate.py:204,233: the next window is the sample just appended */

@@ -23,16 +23,35 @@ class Dims(C.Structure):
                 ("lc_channels", C.c_int32), ("n_upsample", C.c_int32), ("upsample_factor", C.c_int32 * 4)]
 
 
+def source_hash():
+    """sha256 over the library's sources (csrc/, include/twv_amd.h) and the compile flags: what the binary is stamped with
+    (twv_version() ends in it) and what decides whether a build is stale."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h"))]
+    files.append(os.path.join(_HERE, "..", "include", "twv_amd.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False):
-    """hipcc cross-compiles the gfx950 library in-tree (works without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "twv_amd.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+    """hipcc cross-compiles the gfx950 library in-tree (works without a GPU).  The source hash is compiled into the binary and kept
+    in a sidecar file: a library whose stamp differs from the tree's hash is rebuilt (file times say nothing after a checkout)."""
+    want = source_hash()
+    stamp = LIB_PATH + ".srchash"
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return LIB_PATH
     hip = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
-    cmd = ["hipcc"] + HIPCC_FLAGS + hip + ["-o", LIB_PATH, "-L/opt/rocm/lib", "-lrocblas", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"]
+    cmd = ["hipcc"] + HIPCC_FLAGS + ['-DTWV_SRC_HASH="%s"' % want] + hip + ["-o", LIB_PATH, "-L/opt/rocm/lib", "-lrocblas", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(stamp, "w") as fh:
+        fh.write(want + "\n")
     return LIB_PATH
 
 

@@ -110,10 +110,10 @@ struct ChainRegs { float wc[32]; float bfg, gcv, bd; };
 
 // phase stamps (instrumented build only): lane 0 of stream 0's workgroups; s_memrealtime (100 MHz, ONE clock for the chip --
 // s_memtime counters of different CUs are offset against each other by milliseconds)
-#define XSTAMP(cond_, slot_) do { if (INSTR && a.prof != nullptr && b == 0 && t < a.prof_steps && lane == 0 && (cond_)) a.prof[(long long)t * 64 + (slot_)] = wall_clock64(); } while (0)
+#define XSTAMP(cond_, slot_) do { if ((INSTR & 1) && a.prof != nullptr && b == 0 && t < a.prof_steps && lane == 0 && (cond_)) a.prof[(long long)t * 64 + (slot_)] = wall_clock64(); } while (0)
 
 // where a wave is (instrumented build only): read back from the exchange area after a watchdog abort
-#define XMARK(role_, stage_) do { if (INSTR && lane == 0) xb_store(rs, (int)XcdExch::MARK + (role_) * 8 + (int)(threadIdx.x >> 6), 0, (unsigned)t + 1u, (float)(stage_)); } while (0)
+#define XMARK(role_, stage_) do { if ((INSTR & 1) && lane == 0) xb_store(rs, (int)XcdExch::MARK + (role_) * 8 + (int)(threadIdx.x >> 6), 0, (unsigned)t + 1u, (float)(stage_)); } while (0)
 
 enum { ROLE_CHAIN = 0, ROLE_SERVICE = 1, ROLE_SKIP0 = 2, ROLE_CONV0 = 10, ROLE_LC0 = 18 };
 
@@ -126,7 +126,7 @@ struct XArgs {
 //  CHAIN workgroup: model.py:41-46 causal layer (wave 0), model.py:66-101 residual layers (relay over the waves),
 //  mixture.py:84-114 sampler (wave 7)
 // =====================================================================================================================
-template <bool INSTR, bool ALL>
+template <int INSTR, bool ALL>
 __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
 {
     const XcdLaunch& a = xa.p;
@@ -282,7 +282,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                 // (model.py:145: the queue takes the layer INPUT)
                 xb_store2(rs, (int)XcdExch::ZX + (l0 + i) * 128, lane, tag, z, X);
                 layer_back_dpp<ALL>(wd, W[i].bd, z, X, use_bias);
-                if (INSTR && a.dbg != nullptr && t < a.dbg_steps) {
+                if ((INSTR & 2) && a.dbg != nullptr && t < a.dbg_steps) {
                     float* dp = a.dbg + ((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)(l0 + i) * 64;
                     if (lane < 32) dp[dpp_z_index(lane)] = z;
                     if ((lane & 16) == 0) dp[32 + od] = X;
@@ -327,7 +327,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                 y = y + __uint_as_float(sw[1]);                        // chunk 8 + k of the same output (upper half-wave's granule)
             }
             if (use_bias && lane < L.O) y = y + b2v;
-            if (INSTR && a.dbg != nullptr && t < a.dbg_steps)
+            if ((INSTR & 2) && a.dbg != nullptr && t < a.dbg_steps)
                 a.dbg[((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)NL * 64 + lane] = y;
             const int nr = L.nr_mix;
             // mixture.py:107 exp(max(log_scale, log 1e-14)) on EVERY lane (lane 2nr+i holds log_scale_i), next to the argmax chain
@@ -378,7 +378,7 @@ __device__ __forceinline__ unsigned ring_slot(unsigned pos0, unsigned t, unsigne
     const unsigned v = pos0 + t;
     return (d & (d - 1)) == 0 ? (v & (d - 1)) : v % d;
 }
-template <bool INSTR>
+template <int INSTR>
 __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
 {
     const XcdLaunch& a = xa.p;
@@ -492,7 +492,7 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
 //  SKIP workgroup g: model.py:94-96 skip 1x1 of every layer for output block g, model.py:154 sum over the layers in layer
 //  order, model.py:157 relu.  Wave v owns layers v, v+8, ...; the wave that owns the last layer adds the values up as they appear.
 // =====================================================================================================================
-template <bool INSTR>
+template <int INSTR>
 __device__ __forceinline__ void skip_role(const XArgs& xa, int b, int g, rsrc_t rs)
 {
     const XcdLaunch& a = xa.p;
@@ -554,7 +554,7 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, int b, int g, rsrc_t 
                     if (!poll_tick(pl, 51)) break;
                     if (!summer) __builtin_amdgcn_s_sleep(1);
                 }
-                if (INSTR && pl.dead && g == 0 && lane == 0) {   // bring-up: what the abandoned poll last saw
+                if ((INSTR & 1) && pl.dead && g == 0 && lane == 0) {   // bring-up: what the abandoned poll last saw
                     xb_store(rs, (int)XcdExch::MARK + 176 + v * 4, 0, g_tag(qa), __uint_as_float(g_tag(qb)));
                     xb_store(rs, (int)XcdExch::MARK + 177 + v * 4, 0, (unsigned)l, __uint_as_float((unsigned)pl.it));
                     xb_store(rs, (int)XcdExch::MARK + 178 + v * 4, 0, tag, __uint_as_float((unsigned)i));
@@ -589,7 +589,7 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, int b, int g, rsrc_t 
 //  CONV1 workgroup g: model.py:158-160 conv1d_1 + relu for output block g (16 chunk tiles over the 8 waves), then the two
 //  chunks (2g, 2g+1) of model.py:161-165 conv1d_2 that read this block: what travels on is conv1d_2's partial table.
 // =====================================================================================================================
-template <bool INSTR>
+template <int INSTR>
 __device__ __forceinline__ void conv1_role(const XArgs& xa, int b, int g, rsrc_t rs)
 {
     const XcdLaunch& a = xa.p;
@@ -675,7 +675,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, int b, int g, rsrc_t
 //  LC workgroups: model.py:102-111 create_upsample (row by row) and model.py:75-83 lc_filter|lc_gate of every layer,
 //  ahead of the chain through the ring XcdExch::LCR.  Wave gw owns layers gw*lpw .. gw*lpw+lpw-1 (NLC tiles each).
 // =====================================================================================================================
-template <bool INSTR>
+template <int INSTR>
 __device__ __forceinline__ void lc_role(const XArgs& xa, int b, int wg, rsrc_t rs)
 {
     const XcdLaunch& a = xa.p;
@@ -789,7 +789,7 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, int b, int wg, rsrc_t r
     }
 }
 
-template <bool INSTR>
+template <int INSTR>
 __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
 {
     const XcdLaunch& a = xa.p;
@@ -891,8 +891,12 @@ int xcd_launch(const XcdLaunch& p, hipStream_t st)
     // twice the CUs: a workgroup takes a whole CU (512 threads x ~250 VGPRs); surplus workgroups leave at once, so every XCD's role
     // table fills whatever order the dispatcher uses
     const int grid = 2 * cus;
-    if (p.dbg != nullptr || p.prof != nullptr) hipLaunchKernelGGL(wn_xcd_generate_kernel<true>, dim3(grid), dim3(512), shm, st, xa);
-    else hipLaunchKernelGGL(wn_xcd_generate_kernel<false>, dim3(grid), dim3(512), shm, st, xa);
+    // instrumented builds are separate instantiations: 1 = phase stamps / stage markers, 2 = per-layer dumps
+    const int instr = (p.prof != nullptr ? 1 : 0) | (p.dbg != nullptr ? 2 : 0);
+    if (instr == 3) hipLaunchKernelGGL(wn_xcd_generate_kernel<3>, dim3(grid), dim3(512), shm, st, xa);
+    else if (instr == 2) hipLaunchKernelGGL(wn_xcd_generate_kernel<2>, dim3(grid), dim3(512), shm, st, xa);
+    else if (instr == 1) hipLaunchKernelGGL(wn_xcd_generate_kernel<1>, dim3(grid), dim3(512), shm, st, xa);
+    else hipLaunchKernelGGL(wn_xcd_generate_kernel<0>, dim3(grid), dim3(512), shm, st, xa);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return twv_fail(TWV_E_HIP, std::string("xcd launch: ") + hipGetErrorString(e));
     return TWV_OK;

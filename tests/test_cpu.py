@@ -486,3 +486,54 @@ def test_tacotron_blob_layout_agrees(oracle):
     assert np.array_equal(TP.flatten(specs, tensors), oracle.taco_blob(d, tensors))
     m = TP.Tacotron(hp, num_speakers=2, device="cpu")                   # host-only: create touches no device
     assert _lib.lib().twv_tacotron_blob_floats(m._h) == oracle.taco_blob(d, tensors).size
+
+
+def test_oracle_streams_on_threads_give_the_same_bits(oracle):
+    """the checker's generate loop runs one stream per host thread when asked (bench.py's all-cores baseline, the full-size GPU
+    parity tests); a stream's arithmetic does not depend on the thread count"""
+    from helpers import make_case, mol_uniforms
+    dil = [1, 2, 4, 8, 16, 32]
+    d, tensors, blob = make_case(oracle, dil)
+    B, T = 5, 40
+    rng = np.random.RandomState(0)
+    U = rng.uniform(-1, 1, (B, T, 80)).astype(np.float32)
+    gc = (np.arange(B) % 2).astype(np.int32)
+    seed = rng.uniform(-1, 1, B).astype(np.float32)
+    u = mol_uniforms(B, T, 10)
+    cores = oracle.set_threads(1)
+    assert cores >= 1
+    a = oracle.generate_mol(d, blob, oracle.State(d, B), U, gc, seed, u)
+    oracle.set_threads(4)
+    try:
+        b = oracle.generate_mol(d, blob, oracle.State(d, B), U, gc, seed, u)
+    finally:
+        oracle.set_threads(1)
+    assert np.array_equal(a, b)
+
+
+def test_library_is_stamped_with_the_source_hash():
+    """_lib.build() compiles the hash of csrc/ + include/ + flags into twv_version(): a stale binary cannot pass for the tree"""
+    import twvk_amd
+    twvk_amd._lib.build()
+    L = twvk_amd._lib.lib()
+    assert L.twv_version().decode().endswith("src:" + twvk_amd._lib.source_hash())
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` outside a launcher becomes two ranks (torch.distributed.run on 127.0.0.1); --dry-run drives that
+    path without a GPU: gloo rendezvous, barrier-bracketed region, MAX over ranks, n_gpus = ranks that reported, ONE JSON line"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["dry_run"] is True and res["n_gpus"] == 2 and res["world"] == 2
+    assert res["max_seconds"] >= 0.1            # the slower rank (0.05 s x 2) bounds the timed region
+    # --gpus 1 needs no launcher
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry-run"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode == 0 and json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1

@@ -142,3 +142,19 @@ def test_tacotron_gemm_kernels_agree(torch_cuda, oracle):
     assert first_mismatch(lin_a.cpu().numpy(), lin_b.cpu().numpy()) is None
     mel_o, lin_o, _ = oracle.taco_infer(d, blob, tok, ln, spk)
     assert first_mismatch(mel_a.cpu().numpy(), mel_o) is None and first_mismatch(lin_a.cpu().numpy(), lin_o) is None
+
+
+@pytest.mark.parametrize("steps", [25, 200])
+def test_tacotron_at_bench_geometry(torch_cuda, oracle, steps):
+    """BASELINE configs[2] as bench.py launches it: default dims, B = 32 utterances of 101 tokens, decoder split over 8 workgroups
+    per utterance (all 256 workgroups resident), 25 decoder steps and the full 200 (= 1000 mel frames); bit for bit"""
+    hp = _hp(max_iters=steps)
+    N, T = 32, 101
+    d, blob, tok, ln, spk, m = _case(oracle, hp, N, T, [T] * N, seed=21)
+    m.set_option("decoder_groups", 8)
+    mel_o, lin_o, al_o = oracle.taco_infer(d, blob, tok, ln, spk)
+    mel, lin, al = m.infer(tok, ln, spk)
+    assert mel.shape == (N, steps * 5, 80)
+    assert first_mismatch(al.cpu().numpy(), al_o) is None, ("alignments", first_mismatch(al.cpu().numpy(), al_o))
+    assert first_mismatch(mel.cpu().numpy(), mel_o) is None, ("mel", first_mismatch(mel.cpu().numpy(), mel_o))
+    assert first_mismatch(lin.cpu().numpy(), lin_o) is None, ("linear", first_mismatch(lin.cpu().numpy(), lin_o))

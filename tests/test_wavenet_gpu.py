@@ -19,6 +19,8 @@ def test_native_library_is_loaded(torch_cuda):
     import twvk_amd
     L = twvk_amd._lib.lib()
     assert b"gfx950" in L.twv_version()
+    # the binary is stamped with the hash of the sources it was built from: what runs here IS this tree (not a stale shipped build)
+    assert L.twv_version().decode().endswith("src:" + twvk_amd._lib.source_hash()), (L.twv_version(), twvk_amd._lib.source_hash())
     with open("/proc/self/maps") as f:
         assert "libtwv_amd.so" in f.read(), "the in-tree HIP library must be the thing that runs"
 
@@ -385,3 +387,97 @@ def test_wav_to_int16_matches_numpy_save_wav(torch_cuda):
             ref = wav[i].copy()
             ref *= 32767 / max(0.01, np.max(np.abs(ref)))
             assert np.array_equal(got[i], ref.astype(np.int16)), (scale, i)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+#  parity AT THE BENCHMARKED LAUNCH GEOMETRY (BASELINE configs[1]: B = 8 streams, 30 layers): every workgroup role, every XCD,
+#  epoch counters far past the short tests.  The checker runs one stream per host thread (same arithmetic per stream).
+# ---------------------------------------------------------------------------------------------------------------------
+def _bench_case(oracle, B, T, xcd=None, groups=None):
+    dil = [2 ** i for i in range(10)] * 3
+    d, tensors, blob = make_case(oracle, dil)
+    m = make_model(B, dil, tensors, xcd=xcd, groups=groups)
+    rng = np.random.RandomState(1)
+    Tm = (T + 299) // 300
+    mel = rng.uniform(-4, 4, (B, Tm, 80)).astype(np.float32)
+    gc = (np.arange(B) % 2).astype(np.int32)
+    seed_in = (2 * rng.rand(B) - 1).astype(np.float32)
+    u = mol_uniforms(B, T, 10)
+    oracle.set_threads(min(B, oracle.set_threads(1)))
+    try:
+        want = oracle.generate_mol(d, blob, oracle.State(d, B), oracle.upsample(d, blob, mel)[:, :T], gc, seed_in, u)
+    finally:
+        oracle.set_threads(1)
+    return m, mel, gc, seed_in, u, want
+
+
+def test_xcd_kernel_at_bench_geometry(torch_cuda, oracle):
+    """the XCD-per-stream kernel as bench.py launches it: B = 8 (one stream per XCD, 22 workgroups each), fused conditioning
+    (create_upsample + lc projections inside the launch), 24 000 steps = 1 s of audio per stream; bit for bit"""
+    B, T = 8, 24000
+    m, mel, gc, seed_in, u, want = _bench_case(oracle, B, T)
+    assert m.fused_conditioning(), "this configuration must be served by the XCD-per-stream kernel on an MI355X"
+    got = m.generate(m.create_upsample(mel), gc, seed_in, u).cpu().numpy()
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+
+
+def test_generic_kernel_at_bench_geometry(torch_cuda, oracle):
+    """the generic kernel at B = 8: 8 workgroups per stream + helper workgroups (64 + 64 co-resident), 24 000 steps; bit for bit"""
+    B, T = 8, 24000
+    m, mel, gc, seed_in, u, want = _bench_case(oracle, B, T, xcd=0)
+    assert not m.fused_conditioning()
+    got = m.generate(m.create_upsample(mel)[:, :T].contiguous(), gc, seed_in, u).cpu().numpy()
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+
+
+def test_xcd_kernel_full_length_utterances(torch_cuda, oracle):
+    """BASELINE configs[1] in full: 8 utterances x 8 s = 192 000 steps each, against the checker (a minute or two of host time)"""
+    B, T = 8, 192000
+    m, mel, gc, seed_in, u, want = _bench_case(oracle, B, T)
+    got = m.generate(m.create_upsample(mel), gc, seed_in, u).cpu().numpy()
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+
+
+@pytest.mark.parametrize("B", [1, 3, 8])
+def test_xcd_kernel_matches_generic_kernel(torch_cuda, oracle, B):
+    """both kernels, same inputs, several stream counts (B < 8 leaves XCDs idle), chunked calls with state carried over"""
+    dil = [2 ** i for i in range(10)] * 3
+    d, tensors, blob = make_case(oracle, dil, seed=5)
+    rng = np.random.RandomState(9)
+    T = 900
+    mel = rng.uniform(-4, 4, (B, 3, 80)).astype(np.float32)
+    gc = (np.arange(B) % 2).astype(np.int32)
+    seed_in = (2 * rng.rand(B) - 1).astype(np.float32)
+    u = mol_uniforms(B, T, 10)
+    outs = []
+    for xcd in (1, 0):
+        m = make_model(B, dil, tensors, xcd=xcd)
+        U = m.create_upsample(mel)
+        a = m.generate(U[:, :500].contiguous(), gc, seed_in, u[:, :500]).cpu().numpy()
+        b = m.generate(U[:, 500:].contiguous(), gc, a[:, -1], u[:, 500:]).cpu().numpy()
+        outs.append(np.concatenate([a, b], axis=1))
+    assert first_mismatch(outs[0], outs[1]) is None, first_mismatch(outs[0], outs[1])
+    want = oracle.generate_mol(d, blob, oracle.State(d, B), oracle.upsample(d, blob, mel), gc, seed_in, u)
+    assert first_mismatch(outs[0], want) is None, first_mismatch(outs[0], want)
+
+
+def test_fused_conditioning_equals_materialised_upsample(torch_cuda, oracle):
+    """create_upsample inside the launch (mel rows) == the stand-alone upsampling kernel + rows handed over, same kernel otherwise"""
+    dil = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512]
+    d, tensors, blob = make_case(oracle, dil, seed=2)
+    B, T = 2, 1200
+    rng = np.random.RandomState(3)
+    mel = rng.uniform(-4, 4, (B, 4, 80)).astype(np.float32)
+    gc = np.array([1, 0], np.int32)
+    seed_in = (2 * rng.rand(B) - 1).astype(np.float32)
+    u = mol_uniforms(B, T, 10)
+    m = make_model(B, dil, tensors)
+    if not m.fused_conditioning():
+        pytest.skip("needs the XCD-per-stream kernel")
+    lazy = m.create_upsample(mel)
+    a = m.generate(lazy, gc, seed_in, u).cpu().numpy()
+    m.queue_initializer()
+    b = m.generate(lazy.tensor(), gc, seed_in, u).cpu().numpy()
+    assert first_mismatch(a, b) is None
+    want = oracle.generate_mol(d, blob, oracle.State(d, B), oracle.upsample(d, blob, mel), gc, seed_in, u)
+    assert first_mismatch(a, want) is None
