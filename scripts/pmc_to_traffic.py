@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Condense the rocprofv3 passes of scripts/profile_generation.sh: per-kernel stats, FETCH_SIZE / WRITE_SIZE / SQ counters of the
+generation kernel -> gpurun_out/prof_<tag>/summary_<tag>.txt, and HBM bytes per generation step -> profiles/traffic.json (keyed by
+the library's source hash: bench.py reports `roofline.traffic` only for the build it was measured on).
+
+FETCH_SIZE / WRITE_SIZE are in KiB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 counts 64 B per 128-B request of a
+wide coalesced read -> doubled; WRITE_SIZE is taken as reported (uncalibrated)."""
+import csv, glob, json, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+out, tag = sys.argv[1], sys.argv[2]
+lines = []
+
+
+def rows(pattern):
+    for f in glob.glob(os.path.join(out, pattern), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                yield r
+
+
+stats = sorted(rows("stats/**/*kernel_stats.csv"), key=lambda r: -float(r["TotalDurationNs"]))
+lines.append("rocprofv3 --kernel-trace --stats, bench.py --seconds 1.0 --steps 3 --warmup 1 (24 000 generation steps per launch)")
+for r in stats[:8]:
+    lines.append("  %-90s calls %3s  avg %12.1f us  %6s %%" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+gen = [r for r in stats if "generate_kernel" in r["Name"]]
+if gen:
+    lines.append("  => %s: %.3f us per generation step" % (re.search(r"wn_\w+", gen[0]["Name"]).group(0), float(gen[0]["AverageNs"]) / 1e3 / 24000))
+steps = 12000
+vals = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
+    for r in rows("pmc_%s/**/*counter_collection.csv" % c):
+        if "generate_kernel" in r["Kernel_Name"]:
+            vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            vals["_name"] = re.search(r"wn_\w+", r["Kernel_Name"]).group(0)
+            vals["_vgpr"] = r.get("VGPR_Count"); vals["_scratch"] = r.get("Scratch_Size"); vals["_lds"] = r.get("LDS_Block_Size")
+lines.append("")
+lines.append("PMC passes (separate runs, --kernel-trace only), bench.py --seconds 0.5 --steps 1 --warmup 0 (12 000 generation steps), kernel %s" % vals.get("_name"))
+lines.append("  VGPRs %s, scratch %s B/lane, LDS %s B" % (vals.get("_vgpr"), vals.get("_scratch"), vals.get("_lds")))
+for k, v in sorted(vals.items()):
+    if not k.startswith("_"):
+        lines.append("  %-22s %18.1f" % (k, sum(v) / len(v)))
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    fetch = 2.0 * 1024.0 * sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"]) / steps
+    write = 1024.0 * sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"]) / steps
+    lines.append("  => HBM traffic per generation step (all 8 streams): %.0f B read (FETCH_SIZE KiB x 2, gfx950 correction) + %.0f B written" % (fetch, write))
+    import twvk_amd
+    h = twvk_amd._lib.source_hash()
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    t = json.load(open(p)) if os.path.exists(p) else {}
+    kname = "wn_xcd_generate_kernel" if "xcd" in vals["_name"] else "wn_generate_kernel"
+    t.setdefault(h, {}).setdefault(kname, {})["B8_NL30"] = {"fetch_bytes_per_step": fetch, "write_bytes_per_step": write, "profile": "profiles/%s_rocprofv3_generation_summary.txt" % tag}
+    json.dump(t, open(p, "w"), indent=1, sort_keys=True)
+    lines.append("  (profiles/traffic.json updated for library source hash %s)" % h)
+if "SQ_WAVE_CYCLES" in vals:
+    wc = sum(vals["SQ_WAVE_CYCLES"]) / len(vals["SQ_WAVE_CYCLES"])
+    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
+        if k in vals:
+            lines.append("  %-22s / SQ_WAVE_CYCLES = %.3f" % (k, sum(vals[k]) / len(vals[k]) / wc))
+txt = "\n".join(lines)
+print(txt)
+open(os.path.join(out, "summary_%s.txt" % tag), "w").write(txt + "\n")

@@ -1,0 +1,18 @@
+#!/bin/bash
+# rocprofv3 evidence for the generation kernel (run on the GPU box: `gpurun -- bash scripts/profile_generation.sh <tag>`).
+# Counters are collected in their own passes with --kernel-trace only (FETCH_SIZE and WRITE_SIZE do not fit one pass).
+# Outputs land in gpurun_out/prof_<tag>/; scripts/pmc_to_traffic.py turns the two TCC passes into profiles/traffic.json.
+set -u
+TAG=${1:-r02}
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p $OUT
+REPO=$PWD
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-sweep --no-tacotron --no-train"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH --seconds 1.0 --steps 3 --warmup 1 > $OUT/stats.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- $BENCH --seconds 0.5 --steps 1 --warmup 0 > $OUT/pmc_$C.log 2>&1
+done
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_SQ -- $BENCH --seconds 0.5 --steps 1 --warmup 0 > $OUT/pmc_SQ.log 2>&1
+cd $REPO
+python scripts/pmc_to_traffic.py $OUT $TAG
