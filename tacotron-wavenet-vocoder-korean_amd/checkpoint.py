@@ -469,6 +469,36 @@ def tacotron_tensors(variables, specs, scope="model/inference/"):
     return out
 
 
+def tacotron_variable_names(spec_names, scope="model/inference/"):
+    """the bundle variables `tacotron_tensors` reads for these specs (for read_bundle(names=...): Adam slots etc. are not loaded)"""
+    out = set()
+    for name in spec_names:
+        if name.endswith("batch_normalization"):
+            out.update(scope + name + "/" + p for p in BN_PARTS)
+        else:
+            out.add(scope + name)
+    return out
+
+
+def all_checkpoint_paths(logdir):
+    """all_model_checkpoint_paths of the `checkpoint` state file, oldest first (tf.train.Saver's max_to_keep bookkeeping)"""
+    state = os.path.join(logdir, "checkpoint")
+    out = []
+    if os.path.exists(state):
+        with open(state) as f:
+            for line in f:
+                if line.startswith("all_model_checkpoint_paths:"):
+                    q = line.split(":", 1)[1].strip().strip('"')
+                    out.append(q if os.path.isabs(q) else os.path.join(logdir, q))
+    return out
+
+
+def delete_bundle(prefix):
+    for f in [prefix + ".index"] + [q for q in __import__("glob").glob(prefix + ".data-*")]:
+        if os.path.exists(f):
+            os.remove(f)
+
+
 def tacotron_variables(tensors, scope="model/inference/"):
     """inverse of tacotron_tensors (for writing a bundle)"""
     out = {}

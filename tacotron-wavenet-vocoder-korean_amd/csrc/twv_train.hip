@@ -1698,7 +1698,7 @@ extern "C" int twv_adam_ema_step(float* params, const float* grads, float* m, fl
     if (!params || !grads || !m || !v || !ema || n < 0 || t < 1) return twv_fail(TWV_E_INVALID, "bad argument");
     // tf.train.AdamOptimizer: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
     double b1t = 1.0, b2t = 1.0;
-    for (int64_t i = 0; i < t && (b1t > 1e-300 || b2t > 1e-300); ++i) { b1t *= beta1; b2t *= beta2; }
+    b1t = pow(beta1, (double)t); b2t = pow(beta2, (double)t);      // beta^t in double (TF keeps running float products; the difference is below fp32 round-off of lr_t)
     const float lr_t = (float)(lr * sqrt(1.0 - b2t) / (1.0 - b1t));
     if (n) hipLaunchKernelGGL(tr_adam_ema_kernel, dim3(tg(n)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, ema, (long long)n, lr_t,
                               (float)beta1, (float)beta2, (float)eps, (float)ema_decay, (float)grad_scale);

@@ -36,7 +36,7 @@ def text_to_wave(synthesizer, vocoder, tokens, speaker_ids, uniforms, n_frames=N
     Tacotron speaker ids and as the vocoder's global-condition ids (generate.py --gc_id).  n_frames: mel frames handed to the
     vocoder (default: all max_iters*r frames; the reference trims on the host, see attention_trim_frames).
     uniforms: (B, n_frames*hop, nr_mix+1) draws for the MoL sampler.  Returns dict(mel, alignments, audio)."""
-    out = synthesizer.synthesize(tokens=tokens, speaker_ids=speaker_ids, want_linear=False)
+    out = synthesizer.infer(tokens, speaker_ids=speaker_ids, want_linear=False)
     mel = out["mel"]                                             # (B, max_iters*r, num_mels) device tensor
     B = mel.shape[0]
     if B != vocoder.batch_size:

@@ -177,31 +177,9 @@ class Tacotron(object):
         return mel, lin, al
 
 
-class Synthesizer(object):
-    """synthesizer.py:30-200 for token input: load(checkpoint, num_speakers), synthesize(tokens=..., speaker_ids=...)."""
-
-    def load(self, checkpoint, num_speakers=2, hparams=None, device="cuda:0"):
-        from .hparams import hparams as default_hp
-        self.num_speakers = num_speakers
-        self.model = Tacotron(hparams or default_hp, num_speakers, device=device)
-        if isinstance(checkpoint, str) and not checkpoint.endswith(".npz"):
-            # synthesizer.py:37-41,69-70: a logdir (most recent model.ckpt-N) or one bundle prefix, restored by variable name
-            from . import checkpoint as ckpt
-            prefix = ckpt.most_recent_checkpoint(checkpoint) if os.path.isdir(checkpoint) else ckpt.resolve(checkpoint)
-            tensors = ckpt.tacotron_tensors(ckpt.read_bundle(prefix), self.model.specs)
-        else:
-            tensors = dict(np.load(checkpoint)) if isinstance(checkpoint, str) else checkpoint
-        self.model.load_weights(tensors)
-
-    def synthesize(self, tokens, speaker_ids=None, want_linear=True):
-        seqs = [np.asarray(s, np.int32) for s in tokens]
-        max_len = max(len(s) for s in seqs)
-        sequences = np.stack([np.pad(s, (0, max_len - len(s))) for s in seqs])          # datafeeder_tacotron.py:288-290
-        input_lengths = [int(np.argmax(a == 1)) + 1 for a in sequences]                  # synthesizer.py:126
-        if speaker_ids is None:
-            speaker_ids = np.zeros(len(seqs), np.int32)                                  # synthesizer.py:49-50 default
-        mel, lin, al = self.model.infer(sequences, input_lengths, speaker_ids, want_linear=want_linear)
-        return {"mel": mel, "linear": lin, "alignments": al, "input_lengths": input_lengths}
-
-    def close(self):
-        self.model = None
+def __getattr__(name):
+    # the reference's Synthesizer (synthesizer.py) has its own module here too; kept importable from this one
+    if name == "Synthesizer":
+        from .synthesizer import Synthesizer
+        return Synthesizer
+    raise AttributeError(name)

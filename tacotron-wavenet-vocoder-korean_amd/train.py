@@ -51,6 +51,7 @@ class WaveNetTrainer(object):
             l2_regularization_strength = getattr(hparams, "l2_regularization_strength", l2_regularization_strength) or 0.0
             if sample_size is None:
                 sample_size = hparams.sample_size
+            self.max_checkpoints = getattr(hparams, "max_checkpoints", 3)
         self.lr0, self.decay_steps, self.decay_rate = learning_rate, decay_steps, decay_rate
         self.ema_decay, self.beta1, self.beta2, self.epsilon = ema_decay, beta1, beta2, epsilon
         self.group = group
@@ -111,7 +112,7 @@ class WaveNetTrainer(object):
         return self._named(self.ema)
 
     # ---- saver.save / load (utils/__init__.py:62-90; train_vocoder.py:133-152,175-176) ----
-    def save(self, logdir, step=None, include_optimizer=True):
+    def save(self, logdir, step=None, include_optimizer=True, max_to_keep=None):
         """writes `logdir/model.ckpt-<step>` as a TensorFlow V2 bundle + the `checkpoint` state file (checkpoint.py).
         Variables carry the reference graph's names: the weights under their own names, their EMA shadows under
         `<name>/ExponentialMovingAverage`, `global_step`; with include_optimizer the Adam moments under
@@ -132,7 +133,14 @@ class WaveNetTrainer(object):
             var["optimizer/beta2_power"] = np.asarray(self.beta2 ** (self.global_step + 1), np.float32)
         prefix = os.path.join(logdir, "model.ckpt-%d" % step)
         ckpt.write_bundle(prefix, var)
-        ckpt.write_checkpoint_state(logdir, prefix)
+        # tf.train.Saver(max_to_keep=hparams.max_checkpoints) (train_vocoder.py:133): the state file lists every kept bundle, the
+        # oldest ones beyond the limit are deleted
+        if max_to_keep is None:
+            max_to_keep = getattr(self, "max_checkpoints", 3)
+        kept = [q for q in ckpt.all_checkpoint_paths(logdir) if q != prefix and os.path.exists(q + ".index")] + [prefix]
+        while max_to_keep and len(kept) > max_to_keep:
+            ckpt.delete_bundle(kept.pop(0))
+        ckpt.write_checkpoint_state(logdir, prefix, kept)
         return prefix
 
     def restore(self, path, verify=False):

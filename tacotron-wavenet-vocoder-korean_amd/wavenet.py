@@ -238,3 +238,44 @@ class WaveNetModel(object):
         u = np.asarray(uniforms)
         u = u.reshape(B, 1, -1) if self.scalar_input else u.reshape(B, 1)
         return self.generate(lc, global_condition, np.asarray(waveform).reshape(B), u, temperature)
+
+    # ---- model.py:247-346: the training-graph builders, eagerly (the reference builds graph nodes `net.loss` / `net.optimize` that
+    # train_vocoder.py:163 runs once per step; here the calls ARE the step) ----
+    def _trainer_for(self, sample_size, hparams=None):
+        from .train import WaveNetTrainer, crop_length
+        tr = getattr(self, "_trainer", None)
+        if tr is None or tr.sample_size != crop_length(sample_size, self.hop_size):
+            old = tr
+            tr = WaveNetTrainer(self, hparams, sample_size=sample_size)
+            if old is not None and old.params is not None:
+                tr.params, tr.m, tr.v, tr.ema, tr.global_step = old.params, old.m, old.v, old.ema, old.global_step
+            self._trainer = tr
+        return tr
+
+    def add_loss(self, input_batch, local_condition=None, global_condition_batch=None, l2_regularization_strength=None, name='wavenet'):
+        """model.py:247-312: teacher-forced loss of one batch (B, T[, 1]) -> `self.loss` (device scalar); the gradients stay in the
+        trainer for add_optimizer.  Weights: `net._trainer.load_weights(...)` / `init_weights()` once before the first call."""
+        audio = torch.as_tensor(input_batch, dtype=torch.float32)
+        if audio.dim() == 3:
+            audio = audio[:, :, 0]
+        tr = self._trainer_for(audio.shape[1])
+        tr.l2 = float(l2_regularization_strength or 0.0)              # train_vocoder.py:118-119: 0 -> None
+        if tr.params is None:
+            tr.init_weights(seed=0)
+        self.loss = tr.loss_and_gradients(audio, local_condition, global_condition_batch)
+        return self.loss
+
+    def add_optimizer(self, hparams, global_step=None):
+        """model.py:314-346: exponential-decay learning rate, Adam, optional clip_by_global_norm, EMA of the variables; applies the
+        gradients add_loss left (all-reduced over the process group when there is one).  Returns the learning rate used."""
+        from .train import allreduce_sum_
+        tr = self._trainer
+        tr.lr0 = getattr(hparams, "wavenet_learning_rate", tr.lr0)
+        tr.decay_steps = getattr(hparams, "wavenet_decay_steps", tr.decay_steps)
+        tr.decay_rate = getattr(hparams, "wavenet_decay_rate", tr.decay_rate)
+        tr.clip_gradients = bool(getattr(hparams, "wavenet_clip_gradients", tr.clip_gradients))
+        if global_step is not None:
+            tr.global_step = int(global_step)
+        world = allreduce_sum_(tr.grads, tr.group)
+        self.optimize = tr.apply_gradients(world)
+        return self.optimize

@@ -58,7 +58,7 @@ def test_synthesizer_linear_to_wave_and_save(tmp_path):
     hp = _hp(max_iters=4, griffin_lim_iters=2)
     td = O.taco_dims(max_iters=4, num_freq=hp.num_freq)
     syn = Synthesizer(); syn.load(O.taco_random_tensors(td, seed=5), num_speakers=2, hparams=hp)
-    out = syn.synthesize(tokens=[[5, 9, 33, 12, 1]], speaker_ids=[1])
+    out = syn.infer([[5, 9, 33, 12, 1]], speaker_ids=[1])
     wav = inv_linear_spectrogram(out["linear"], hp, seed=3)
     assert wav.shape == (1, hp.hop_size * (4 * hp.reduction_factor - 1)) and np.isfinite(wav.cpu().numpy()).all()
     path = str(tmp_path / "a.wav")

@@ -102,8 +102,8 @@ def test_synthesizer_loads_a_bundle(torch_cuda, oracle, tmp_path):
                         ck.tacotron_variables(tensors if step == 3000 else {k: v * 0 + 1 for k, v in tensors.items()}))
     toks = [[5, 9, 33, 12, 1], [7, 7, 1]]
     ref = Synthesizer(); ref.load(tensors, num_speakers=2, hparams=hp)
-    want = ref.synthesize(tokens=toks, speaker_ids=[1, 0])["mel"].cpu().numpy()
+    want = ref.infer(toks, speaker_ids=[1, 0])["mel"].cpu().numpy()
     syn = Synthesizer(); syn.load(str(tmp_path), num_speakers=2, hparams=hp)               # directory -> most recent step
-    assert first_mismatch(syn.synthesize(tokens=toks, speaker_ids=[1, 0])["mel"].cpu().numpy(), want) is None
+    assert first_mismatch(syn.infer(toks, speaker_ids=[1, 0])["mel"].cpu().numpy(), want) is None
     syn = Synthesizer(); syn.load(str(tmp_path / "model.ckpt-3000"), num_speakers=2, hparams=hp)   # one bundle prefix
-    assert first_mismatch(syn.synthesize(tokens=toks, speaker_ids=[1, 0])["mel"].cpu().numpy(), want) is None
+    assert first_mismatch(syn.infer(toks, speaker_ids=[1, 0])["mel"].cpu().numpy(), want) is None

@@ -512,11 +512,13 @@ def test_oracle_streams_on_threads_give_the_same_bits(oracle):
 
 
 def test_library_is_stamped_with_the_source_hash():
-    """_lib.build() compiles the hash of csrc/ + include/ + flags into twv_version(): a stale binary cannot pass for the tree"""
-    import twvk_amd
-    twvk_amd._lib.build()
-    L = twvk_amd._lib.lib()
-    assert L.twv_version().decode().endswith("src:" + twvk_amd._lib.source_hash())
+    """_lib.build() compiles the hash of csrc/ + include/ + flags into twv_version(): a stale binary cannot pass for the tree
+    (own process: this one may have loaded the library before a rebuild)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import twvk_amd; twvk_amd._lib.build(); L = twvk_amd._lib.lib(); "
+            "assert L.twv_version().decode().endswith('src:' + twvk_amd._lib.source_hash()), L.twv_version()")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-2000:]
 
 
 def test_bench_starts_its_own_ranks():
@@ -537,3 +539,70 @@ def test_bench_starts_its_own_ranks():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry-run"], capture_output=True, text=True,
                          timeout=300, env=env)
     assert out.returncode == 0 and json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_crop_rule_of_the_wavenet_feeder():
+    """datafeeder_wavenet.py:153-156: a random FRAME offset; audio and mel cut in step (hop multiples); global np.random"""
+    import twvk_amd
+    from twvk_amd.train_vocoder import crop_example, ensure_divisible
+    hop, frames, max_frames = 300, 40, 26
+    assert ensure_divisible(8000, hop, True) == 7800 and ensure_divisible(7800, hop, True) == 7800     # datafeeder_wavenet.py:41-47
+    audio = np.arange(frames * hop, dtype=np.float32)
+    mel = np.repeat(np.arange(frames, dtype=np.float32)[:, None], 80, axis=1)
+    np.random.seed(7)
+    want_s = np.random.randint(0, frames - max_frames + 1)
+    np.random.seed(7)
+    a, m = crop_example(audio.reshape(-1, 1), mel, max_frames, hop)
+    assert a.shape == (max_frames * hop,) and m.shape == (max_frames, 80)
+    assert a[0] == want_s * hop and m[0, 0] == want_s                      # same offset for both, in units of frames
+    seen = set()
+    for _ in range(200):
+        a, m = crop_example(audio, mel, max_frames, hop)
+        assert a[0] == m[0, 0] * hop and a[-1] == (m[-1, 0] + 1) * hop - 1
+        seen.add(int(m[0, 0]))
+    assert seen == set(range(frames - max_frames + 1))                      # every offset incl. both ends (randint's high is exclusive)
+    with pytest.raises(AssertionError):
+        crop_example(audio[:-1], mel, max_frames, hop)                      # assert_ready_for_upsampling
+
+
+def test_wavenet_feeder_batches(tmp_path):
+    """the feeder's batch rule (datafeeder_wavenet.py:104-118) on two speaker directories of npz examples"""
+    import twvk_amd
+    from twvk_amd.train_vocoder import DataFeederWavenet
+    hp = twvk_amd.default_hparams()
+    hp.sample_size = 1500
+    dirs = []
+    rng = np.random.RandomState(0)
+    for spk in range(2):
+        d = tmp_path / ("spk%d" % spk); d.mkdir(); dirs.append(str(d))
+        for i in range(3):
+            frames = 9 + i
+            np.savez(str(d / ("ex%d.npz" % i)), audio=rng.uniform(-1, 1, frames * 300).astype(np.float32), mel=rng.randn(frames, 80).astype(np.float32))
+    f = DataFeederWavenet(dirs, batch_size=4, receptive_field=1000, gc_enable=True, hp=hp)
+    assert f.sample_size == 1500 and f.max_frames == 5
+    ids = []
+    for _ in range(8):
+        a, m, g = f.next_batch()
+        assert a.shape == (4, 1500) and m.shape == (4, 5, 80) and g.shape == (4,) and g.dtype == np.int32
+        ids += g.tolist()
+    assert set(ids) == {0, 1}
+
+
+def test_train_vocoder_directory_rules(tmp_path):
+    """utils/__init__.py:100-142 validate_directories as train_vocoder.py uses it"""
+    import argparse
+    import twvk_amd
+    from twvk_amd.train_vocoder import validate_directories
+    hp = twvk_amd.default_hparams()
+    ns = argparse.Namespace(logdir=str(tmp_path / "a"), logdir_root=str(tmp_path), restore_from=None)
+    with pytest.raises(ValueError):
+        validate_directories(ns, hp)
+    ns = argparse.Namespace(logdir=str(tmp_path / "a"), logdir_root=None, restore_from=str(tmp_path / "b"))
+    with pytest.raises(ValueError):
+        validate_directories(ns, hp)
+    ns = argparse.Namespace(logdir=None, logdir_root=str(tmp_path / "root"), restore_from=str(tmp_path / "b"))
+    d = validate_directories(ns, hp)
+    assert d["restore_from"] == str(tmp_path / "b") and d["logdir"].startswith(str(tmp_path / "root")) and os.path.exists(os.path.join(d["logdir"], "params.json"))
+    ns = argparse.Namespace(logdir=str(tmp_path / "c"), logdir_root=None, restore_from=None)
+    d = validate_directories(ns, hp)
+    assert d["logdir"] == d["restore_from"] == str(tmp_path / "c")

@@ -94,7 +94,7 @@ def test_synthesizer_surface(torch_cuda, oracle):
     tensors = oracle.taco_random_tensors(d, seed=5)
     syn = Synthesizer()
     syn.load(tensors, num_speakers=2, hparams=hp)
-    out = syn.synthesize(tokens=[[5, 9, 33, 12, 1], [7, 7, 1]], speaker_ids=[1, 0])
+    out = syn.infer([[5, 9, 33, 12, 1], [7, 7, 1]], speaker_ids=[1, 0])
     assert out["input_lengths"] == [5, 3]                               # synthesizer.py:126 argmax(seq == 1) + 1
     tok = np.array([[5, 9, 33, 12, 1], [7, 7, 1, 0, 0]], np.int32)
     mel_o, _, _ = oracle.taco_infer(d, oracle.taco_blob(d, tensors), tok, np.array([5, 3], np.int32), np.array([1, 0], np.int32))
@@ -158,3 +158,61 @@ def test_tacotron_at_bench_geometry(torch_cuda, oracle, steps):
     assert first_mismatch(al.cpu().numpy(), al_o) is None, ("alignments", first_mismatch(al.cpu().numpy(), al_o))
     assert first_mismatch(mel.cpu().numpy(), mel_o) is None, ("mel", first_mismatch(mel.cpu().numpy(), mel_o))
     assert first_mismatch(lin.cpu().numpy(), lin_o) is None, ("linear", first_mismatch(lin.cpu().numpy(), lin_o))
+
+
+def test_synthesize_writes_the_reference_outputs(torch_cuda, oracle, tmp_path):
+    """Synthesizer.synthesize with the reference's signature (synthesizer.py:72-83): per utterance the attention-trimmed wav
+    (Griffin-Lim on the GPU) and the mel .npy that generate.py --mel reads; without base_path the wav bytes come back"""
+    import io
+    from scipy.io import wavfile
+    from twvk_amd.synthesizer import Synthesizer, plot_graph_and_save_audio, main as synth_main
+    from twvk_amd.audio import inv_linear_spectrogram
+    from twvk_amd.e2e import attention_trim_frames
+    from twvk_amd.ops import wav_to_int16
+    hp = _hp(max_iters=6, griffin_lim_iters=3)
+    d = oracle.taco_dims(max_iters=6, num_freq=hp.num_freq)
+    tensors = oracle.taco_random_tensors(d, seed=5)
+    syn = Synthesizer()
+    syn.load(tensors, num_speakers=2, hparams=hp)
+    toks = [[5, 9, 33, 12, 1], [7, 7, 1]]
+    res = syn.synthesize(tokens=toks, base_path=str(tmp_path), speaker_ids=[1, 0], attention_trim=True, seed=11)
+    assert res == [True, True]
+    wavs = sorted(str(p) for p in tmp_path.glob("*.wav")); mels = sorted(str(p) for p in tmp_path.glob("*.npy"))
+    assert len(wavs) == 2 and [w.replace(".wav", ".npy") for w in wavs] == mels
+    out = syn.infer(toks, speaker_ids=[1, 0])
+    for i in range(2):
+        al = out["alignments"][i].cpu().numpy()
+        n = attention_trim_frames(al, len(out["sequences"][i]), hp.reduction_factor)       # synthesizer.py:232-256
+        mel = np.load(mels[i])
+        assert first_mismatch(mel, out["mel"][i, :n].cpu().numpy()) is None               # the vocoder's --mel input
+        want = inv_linear_spectrogram(out["linear"][i:i + 1, :n], hp, seed=11)
+        sr, data = wavfile.read(wavs[i])
+        assert sr == hp.sample_rate and np.array_equal(data, wav_to_int16(want).cpu().numpy().reshape(-1))
+    blob = syn.synthesize(tokens=toks[:1], speaker_ids=[1], seed=11)[0]                    # no path: wav bytes (synthesizer.py:283-287)
+    sr, data = wavfile.read(io.BytesIO(blob))
+    assert sr == hp.sample_rate and np.array_equal(data, wavfile.read(wavs[0])[1])
+    with pytest.raises(ValueError):
+        syn.synthesize(texts="text needs the frontend")
+    with pytest.raises(ValueError):
+        syn.synthesize(tokens=toks, manual_attention_mode=1)
+
+
+def test_synthesizer_cli(torch_cuda, oracle, tmp_path):
+    """synthesizer.py:371-388 flags; the checkpoint is a TF-V2 bundle directory (most recent step, or --checkpoint_step)"""
+    import twvk_amd
+    from twvk_amd import checkpoint as ckpt
+    from twvk_amd.hparams import save_hparams
+    from twvk_amd.synthesizer import main as synth_main, get_most_recent_checkpoint
+    hp = _hp(max_iters=4, griffin_lim_iters=2)
+    d = oracle.taco_dims(max_iters=4, num_freq=hp.num_freq)
+    tensors = oracle.taco_random_tensors(d, seed=5)
+    logdir = tmp_path / "logdir"; logdir.mkdir()
+    save_hparams(str(logdir), hp)
+    for step in (1000, 3000):
+        ckpt.write_bundle(str(logdir / ("model.ckpt-%d" % step)), ckpt.tacotron_variables(tensors))
+    assert get_most_recent_checkpoint(str(logdir)).endswith("model.ckpt-3000")
+    assert get_most_recent_checkpoint(str(logdir), 1000).endswith("model.ckpt-1000")
+    out = tmp_path / "samples"
+    assert synth_main(["--load_path", str(logdir), "--sample_path", str(out), "--tokens", "5,9,33,12,1", "--num_speakers", "2",
+                       "--speaker_id", "1", "--seed", "3"]) is True
+    assert len(list(out.glob("*.wav"))) == 1 and len(list(out.glob("*.npy"))) == 1

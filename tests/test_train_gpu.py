@@ -2,6 +2,8 @@
 
 Floating-point work -> tolerance parity (written at each assert).  The GPU path sums in a different order (rocBLAS
 GEMMs over all rows, chunked column sums), so agreement is to fp32 round-off of the reductions, not bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -200,3 +202,46 @@ def test_l2_and_gradient_clipping_options():
     p1, _, _, _ = R.adam_ema(p0, gc_, np.zeros_like(p0), np.zeros_like(p0), p0.copy(), 1, lr)
     np.testing.assert_allclose(tr.params.cpu().numpy(), p1, rtol=0, atol=2e-6)     # tolerance: one fp32 Adam update of size lr
     np.testing.assert_allclose(np.sqrt((tr.grads.cpu().numpy().astype(np.float64) ** 2).sum()), 1.0, rtol=1e-5)
+
+
+def test_train_vocoder_cli_trains_checkpoints_and_resumes(tmp_path):
+    """train_vocoder.py's loop on synthetic data: steps, a bundle every --checkpoint_every steps, at most hparams.max_checkpoints
+    kept, and --logdir alone resumes from the last one (train_vocoder.py:133-152,175-176)"""
+    import json
+    import twvk_amd
+    from twvk_amd import checkpoint as ckpt
+    from twvk_amd.hparams import hparams
+    from twvk_amd.train_vocoder import main as tv_main
+    saved = {k: getattr(hparams, k) for k in ("dilations", "wavenet_batch_size", "sample_size", "skip_channels", "max_checkpoints")}
+    try:
+        hparams.dilations = [1, 2, 4, 8, 1, 2, 4, 8]; hparams.wavenet_batch_size = 2; hparams.sample_size = 1300
+        hparams.skip_channels = 64; hparams.max_checkpoints = 2
+        logdir = str(tmp_path / "run")
+        lines = []
+        r = tv_main(["--data_dir", "a,b", "--logdir", logdir, "--checkpoint_every", "2", "--num_steps", "6", "--synthetic"], log=lines.append)
+        assert r["step"] == 6 and np.isfinite(r["loss"])
+        assert sum(1 for l in lines if l.startswith("step ")) == 6
+        kept = sorted(os.path.basename(p) for p in ckpt.all_checkpoint_paths(logdir))
+        assert kept == ["model.ckpt-4", "model.ckpt-6"]                              # Saver(max_to_keep=2)
+        assert not os.path.exists(os.path.join(logdir, "model.ckpt-2.index"))
+        assert json.load(open(os.path.join(logdir, "params.json")))["wavenet_batch_size"] == 2
+        lines = []
+        r2 = tv_main(["--data_dir", "a,b", "--logdir", logdir, "--checkpoint_every", "100", "--num_steps", "8", "--synthetic"], log=lines.append)
+        assert r2["step"] == 8 and any("Global step was: 6" in l for l in lines)    # resumed, two more steps
+    finally:
+        for k, v in saved.items():
+            setattr(hparams, k, v)
+
+
+def test_add_loss_and_add_optimizer_surface():
+    """net.add_loss(...) / net.add_optimizer(hparams, global_step) (model.py:247,314) == WaveNetTrainer.step"""
+    import twvk_amd
+    tr, tensors, cfg, audio, lc, gc = _case(dil=[1, 2, 4, 1, 2], B=2, Tm=3)
+    l_ref = float(tr.step(audio, lc, gc).item())
+    p_ref = tr.params.cpu().numpy()
+    net = make_model(2, [1, 2, 4, 1, 2], tensors, S=64)
+    net._trainer_for(audio.shape[1]).load_weights(tensors)
+    loss = net.add_loss(audio[:, :, None], lc, gc, l2_regularization_strength=0)
+    lr = net.add_optimizer(twvk_amd.default_hparams(), 0)
+    assert float(loss.item()) == l_ref and lr == pytest.approx(1e-3)
+    assert np.array_equal(net._trainer.params.cpu().numpy(), p_ref)
