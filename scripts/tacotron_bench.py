@@ -22,10 +22,11 @@ def random_tensors(specs, seed=0):
     return t
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--steps", type=int, default=3)
-ap.add_argument("--no-linear", action="store_true"); args = ap.parse_args()
+ap.add_argument("--no-linear", action="store_true"); ap.add_argument("--decoder-groups", type=int, default=0); args = ap.parse_args()
 hp = twvk_amd.default_hparams()
 m = Tacotron(hp, num_speakers=2)
 m.load_weights(random_tensors(m.specs))
+if args.decoder_groups: m.set_option("decoder_groups", args.decoder_groups)
 rng = np.random.RandomState(1)
 N, T = args.batch, 101
 tok = rng.randint(2, 80, (N, T)).astype(np.int32); tok[:, -1] = 1

@@ -20,6 +20,7 @@
 #include <vector>
 #include "../../include/twv_amd.h"
 #include "twv_dev.hpp"
+#include "twv_dpp.hpp"
 
 static int g_gemm_valu = 0;            // "gemm_valu" option: 1 = the VALU kernel (cross-check of the MFMA one)
 enum { TACT_NONE = 0, TACT_RELU = 1, TACT_TANH = 2, TACT_SIGMOID = 3, TACT_SOFTSIGN = 4 };
@@ -693,6 +694,7 @@ __global__ void __launch_bounds__(512) tc_decoder_kernel(DecArgs a)
 // Arithmetic is unchanged: every output column's chunks are still summed in order inside one workgroup.
 constexpr int kExN = 1024;          // granules per exchange buffer
 typedef __attribute__((address_space(1))) unsigned long long tgu64;
+typedef unsigned u32x2d __attribute__((ext_vector_type(2)));
 
 struct DecGArgs {
     DecArgs d;
@@ -1166,6 +1168,416 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
 #undef DECG_PREFETCH
 }
 
+// -----------------------------------------------------------------------------------------------------
+//  decoder, XCD-local: the utterances of one XCD share 32 workgroups that hold the decoder REGISTER-RESIDENT
+// -----------------------------------------------------------------------------------------------------
+// The split kernel above puts the 8 workgroups of an utterance on 8 XCDs (slice g of the weights stays in XCD g's L2), so every one
+// of its 10+ exchanges per step is a memory-side hop (~0.65 us) and every stage re-streams its tiles from L2.  An XCD has 16 MB of
+// vector registers: the whole decoder (6.4 MB) fits.  Here workgroup (x, g) -- XCD x by HW_REG_XCC_ID, slice g = role ticket 0..31 --
+// keeps columns [16g, 16g+16) of EVERY decoder matrix in registers for the whole launch and applies them to all (up to 4) utterances
+// of its XCD; activations travel as plain-store / sc1-load granules inside the XCD's L2 (~0.27 us, twv_wavenet_xcd.hip).
+// A wave task = 16 output columns x 4 chunks of 32 terms (one chunk per 16-lane row), an AC-1 chunk = 32 v_fmac_f32_dpp with the
+// operand fed by row_newbcast (twv_dpp.hpp); chunk values are added in chunk order by one wave.  Same arithmetic, same order:
+// bit-identical to the other two decoder kernels.
+constexpr int kXU = 4;              // utterances per XCD
+constexpr int kXSlots = 5;          // register-resident tasks per wave
+constexpr int kXStages = 16;
+struct XStageTab {
+    int nst;
+    int K[kXStages], N[kXStages], act[kXStages], post[kXStages], xsel[kXStages], dsel[kXStages], p0[kXStages], p1[kXStages], p2[kXStages];
+    long long w[kXStages], b[kXStages];          // packed offsets (floats): standard tiles, bias (-1 = none)
+};
+struct DecXArgs {
+    DecArgs d;
+    XStageTab tab;
+    unsigned long long* exch;       // [8][2][kXU*512] granules
+    int* tickets;                   // [8], zeroed before the launch
+    long long xt_off;               // packed offset (floats) of the row tiles [32][8][kXSlots][2048]
+    int upx;                        // utterances per XCD (N <= 8*upx)
+};
+// the tasks of slice g, in (stage, chunk group) order: task i belongs to wave i % 8, register slot i / 8
+__host__ __device__ inline int xdec_tasks(const XStageTab& t, int g, int wave, int (&st_of)[kXSlots], int (&grp_of)[kXSlots])
+{
+    for (int j = 0; j < kXSlots; ++j) { st_of[j] = -1; grp_of[j] = 0; }
+    int id = 0, worst = 0;
+    for (int st = 0; st < t.nst; ++st) {
+        if (16 * g >= t.N[st]) continue;
+        const int ngrp = (((t.K[st] + 31) >> 5) + 3) >> 2;
+        for (int q = 0; q < ngrp; ++q, ++id) {
+            const int slot = id >> 3;
+            if (slot > worst) worst = slot;
+            if ((id & 7) == wave && slot < kXSlots) { st_of[slot] = st; grp_of[slot] = q; }
+        }
+    }
+    return worst + 1;       // slots needed
+}
+// row tiles from the standard tiles: lane (row r, n) of task (st, group q) holds W[32*(4q+r) + k][16g + n], k = 0..31
+__global__ void tc_xdec_pack_kernel(float* P, XStageTab t, long long xt_off)
+{
+    const int g = blockIdx.x >> 3, wave = blockIdx.x & 7;
+    int st_of[kXSlots], grp_of[kXSlots];
+    xdec_tasks(t, g, wave, st_of, grp_of);
+    for (int j = 0; j < kXSlots; ++j) {
+        float* dst = P + xt_off + (((long long)g * 8 + wave) * kXSlots + j) * kTile;
+        const int st = st_of[j];
+        for (int e = threadIdx.x; e < kTile; e += blockDim.x) {
+            float v = 0.0f;
+            if (st >= 0) {
+                const int kq = e >> 8, lane = (e >> 2) & 63, c4 = e & 3;
+                const int k = 4 * kq + c4, r = lane >> 4, n = lane & 15;
+                const int nchunk = (t.K[st] + 31) >> 5, c = 4 * grp_of[j] + r, col = 16 * g + n;
+                if (c < nchunk && col < t.N[st])
+                    v = P[t.w[st] + ((long long)(col >> 6) * nchunk + c) * kTile + (((k >> 2) * 64 + (col & 63)) << 2) + (k & 3)];
+            }
+            dst[e] = v;
+        }
+    }
+}
+// LDS vectors of an utterance (stage inputs / gather destinations).  The concatenations the cells read are separate buffers, so that a
+// gathered value is written straight to every place that reads it (no copy phase between the stages):
+//   CATA = [prenet out | context | attention-rnn state]   (rnn_wrappers.py:310-312)        CATB = [attention-rnn state | context] (:463)
+//   CATR+l = [y | state of residual GRU l]                (tacotron.py:167)
+enum { XV_FRAME = 0, XV_VEC, XV_CATA, XV_CATB, XV_PQ, XV_Y, XV_CATR };
+// what the gathering thread does with the value of column `col` (gather kinds)
+enum { XG_PLAIN = 0, XG_GATES, XG_CAND_ATT, XG_CAND_RES, XG_OUT, XG_P, XG_CTX };
+
+template <bool PROF>
+__global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
+{
+#define XSTAMPT(k) if (PROF && a.prof && xcc == 0 && g == 0 && tid == 0 && it == 3) a.prof[st * 16 + (k)] = __builtin_amdgcn_s_memtime();
+    const DecArgs& a = xa.d;
+    const XStageTab& tb = xa.tab;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, M = a.M, R = a.R, A = a.A, AS = a.AS, ENC = a.ENC, DR = a.DR, D1 = a.D1;
+    // ---- which XCD, which slice
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 15u;
+    __shared__ int s_ticket;
+    const int UPX = xa.upx;
+    const int n0 = (int)xcc * UPX;
+    int nu = a.N - n0;
+    nu = nu < 0 ? 0 : (nu > UPX ? UPX : nu);
+    if (tid == 0) s_ticket = (xcc < 8u && nu > 0) ? atomicAdd(xa.tickets + xcc, 1) : 1 << 20;
+    __syncthreads();
+    const int g = s_ticket;
+    if (g >= 32) return;
+    const float* P = a.P;
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xa.exch + (long long)xcc * 2 * kXU * 512, 0, 2 * kXU * 512 * 8, 0x00020000);
+    // ---- LDS carve: per utterance a block of UST floats, then shared areas
+    const int Tp = ((T + 3) / 4) * 4;
+    const int Fp = ((M + 31) / 32) * 32;
+    int o = 0;
+    const int u_frame = o; o += Fp;
+    const int u_vec = o; o += 1024;                        // prenet hidden; gates r | u
+    const int u_cata = o; o += D1 + ENC + AS;
+    const int u_catb = o; o += AS + ENC;
+    const int u_catr = o; o += a.layers * 2 * DR;
+    const int u_keep = o; o += 512;                        // h before the update
+    const int u_y = o; o += DR;
+    const int u_pq = o; o += A;
+    const int u_al = o; o += Tp;
+    const int u_p = o; o += Tp;
+    const int UST = o;
+    o = UST * nu;
+    const int nAch = A / 32;
+    const int ntmax = (T + 31) >> 5;                       // time steps of this slice: t = g, g+32, ...
+    const int nt = T > g ? (T - g + 31) >> 5 : 0;
+    const int ncol = ENC >> 5, c0 = g * ncol;              // context columns of this slice
+    const int nch_t = (T + 31) >> 5;
+    const int o_nv = o; o += A;
+    const int o_ab = o; o += A;
+    const int o_bias = o; o += 16 * tb.nst;                // this slice's 16 bias values per stage
+    const int o_scp = o; o += nu * ntmax * 8;
+    const int o_keys = o; o += nu * ntmax * A;
+    const int o_memo = o; o += nu * T * ncol;
+    const int o_part = o; o += nu * 16 * 24 > nu * nch_t * ncol ? nu * 16 * 24 : nu * nch_t * ncol;
+    const int o_abort = o; o += 4;
+    const int o_tab = o; o += kXStages * 12;              // the stage table (kernel arguments are slow to index per stage)
+
+    int len[kXU];
+#pragma unroll
+    for (int u = 0; u < kXU; ++u) len[u] = u < nu ? a.lengths[n0 + u] : 0;
+    for (int u = 0; u < nu; ++u) {
+        const int ub = u * UST;
+        const float* init = a.init + (long long)(n0 + u) * (AS + a.layers * DR);
+        for (int i = tid; i < UST; i += 512) lds[ub + i] = 0.0f;
+        __syncthreads();
+        // initial state (tacotron.py:184-195, AttentionWrapper.zero_state, helpers.py:90-92): go-frame, context and y zero
+        for (int i = tid; i < AS; i += 512) { lds[ub + u_cata + D1 + ENC + i] = init[i]; lds[ub + u_catb + i] = init[i]; }
+        for (int i = tid; i < a.layers * DR; i += 512) { const int l = i / DR, k = i - l * DR; lds[ub + u_catr + l * 2 * DR + DR + k] = init[AS + i]; }
+        if (tid == 0) lds[ub + u_al] = 1.0f;                // one-hot at 0 [RECALLED-TF initial_alignments]
+        const float* keys = a.keys + (long long)(n0 + u) * T * A;
+        const float* memo = a.memo + (long long)(n0 + u) * T * ENC;
+        for (int i = tid; i < nt * A; i += 512) { const int tl = i / A, j = i - tl * A; lds[o_keys + (u * ntmax + tl) * A + j] = keys[(long long)((tl << 5) + g) * A + j]; }
+        for (int i = tid; i < T * ncol; i += 512) { const int t = i / ncol, cl = i - t * ncol; lds[o_memo + (u * T + t) * ncol + cl] = memo[(long long)t * ENC + c0 + cl]; }
+    }
+    for (int i = tid; i < A; i += 512) { lds[o_nv + i] = P[a.w.nv + i]; lds[o_ab + i] = P[a.w.ab + i]; }
+    for (int i = tid; i < 16 * tb.nst; i += 512) {
+        const int st = i >> 4, col = 16 * g + (i & 15);
+        lds[o_bias + i] = (tb.b[st] >= 0 && col < tb.N[st]) ? P[tb.b[st] + col] : 0.0f;
+    }
+    if (tid < 4) LDSI(o_abort + tid) = 0;
+    if (tid < tb.nst) {
+        const int q = o_tab + tid * 12;
+        LDSI(q + 0) = tb.K[tid]; LDSI(q + 1) = tb.N[tid]; LDSI(q + 2) = tb.act[tid]; LDSI(q + 3) = tb.post[tid];
+        LDSI(q + 4) = tb.xsel[tid]; LDSI(q + 5) = tb.dsel[tid]; LDSI(q + 6) = tb.p0[tid]; LDSI(q + 7) = tb.p1[tid]; LDSI(q + 8) = tb.p2[tid];
+        LDSI(q + 9) = tb.b[tid] >= 0 ? 1 : 0;
+    }
+    const int nst = tb.nst;
+    const float asb = P[a.w.asb];
+    // ---- this wave's tasks and their register-resident row tiles
+    int st_of[kXSlots], grp_of[kXSlots];
+    xdec_tasks(tb, g, wave, st_of, grp_of);
+    Tile wt[kXSlots];
+#pragma unroll
+    for (int j = 0; j < kXSlots; ++j)
+        load_tile(wt[j], P + xa.xt_off + (((long long)g * 8 + wave) * kXSlots + j) * kTile, lane);
+    __syncthreads();
+
+    unsigned ep = 0;
+    bool ok = true;
+    int it = 0, st = 0;
+    auto vsel = [&](int v) { return v == XV_FRAME ? u_frame : v == XV_VEC ? u_vec : v == XV_CATA ? u_cata : v == XV_CATB ? u_catb : v == XV_PQ ? u_pq : v == XV_Y ? u_y : u_catr + (v - XV_CATR) * 2 * DR; };
+    // Exchange `ep`: thread i collects element i (< cnt <= 512) of every utterance (granule u*512 + i) and puts it where its readers
+    // want it -- `kind` says what a value means (GRU gates / candidates update the cell state on the spot).
+    auto gather = [&](int cnt, int kind, int dst, int g0, int g1, int g2) {
+        const int boff = (int)(ep & 1u) * (kXU * 512);
+        bool done[kXU];
+#pragma unroll
+        for (int u = 0; u < kXU; ++u) done[u] = !(u < nu && tid < cnt);
+        for (int itp = 0; itp < (1 << 20); ++itp) {
+#pragma unroll
+            for (int u = 0; u < kXU; ++u) {
+                if (!done[u]) {
+                    const u32x2d q = __builtin_amdgcn_raw_buffer_load_b64(rs, (boff + u * 512 + tid) * 8, 0, (int)(16u | 0x80000000u));
+                    if (q.y == ep) {
+                        done[u] = true;
+                        const float v = __uint_as_float(q.x);
+                        const int ub = u * UST, col = tid;
+                        if (kind == XG_PLAIN) lds[ub + dst + col] = v;
+                        else if (kind == XG_GATES) {          // tf.contrib.rnn.GRUCell, gate order r | u: keep h, cell input <- [x, r*h]
+                            const int nin = g0, U = g1;        // dst = the cell's concatenated input
+                            if (col < U) { const float h = lds[ub + dst + nin + col]; lds[ub + u_keep + col] = h; lds[ub + dst + nin + col] = v * h; }
+                            else lds[ub + u_vec + col] = v;
+                        } else if (kind == XG_CAND_ATT || kind == XG_CAND_RES) {       // h <- u*h + (1-u)*c
+                            const int U = g0;
+                            const float uu = lds[ub + u_vec + U + col], h = lds[ub + u_keep + col];
+                            const float t1 = uu * h, t2 = 1.0f - uu, t3 = t2 * v;
+                            const float hn = t1 + t3;
+                            if (kind == XG_CAND_ATT) {         // the attention rnn's state: next step's cell input, this step's query / projection input
+                                lds[ub + u_cata + D1 + ENC + col] = hn;
+                                lds[ub + u_catb + col] = hn;
+                            } else {                           // residual layer l = g1: y <- y + h (tacotron.py:167); next layer's input or the output projection's
+                                const int cr = u_catr + g1 * 2 * DR;
+                                lds[ub + cr + DR + col] = hn;
+                                const float yn = lds[ub + cr + col] + hn;
+                                if (g2 > 0) lds[ub + u_catr + g2 * 2 * DR + col] = yn; else lds[ub + u_y + col] = yn;
+                            }
+                        } else if (kind == XG_OUT) {           // tacotron.py:204 reshape; helpers.py:40 last frame fed back
+                            if (g == 0) a.mel[((long long)(n0 + u) * a.iters + it) * M * R + col] = v;
+                            if (col >= M * (R - 1)) lds[ub + u_frame + col - M * (R - 1)] = v;
+                        } else if (kind == XG_P) lds[ub + u_p + col] = v;
+                        else { lds[ub + u_cata + D1 + col] = v; lds[ub + u_catb + AS + col] = v; }       // XG_CTX
+                    }
+                }
+            }
+            if (__all(done[0] && done[1] && done[2] && done[3])) return;
+            if ((itp & 63) == 63 && LDSVI(o_abort)) return;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        LDSVI(o_abort) = 1;
+    };
+    auto publish = [&](int u, int i, float v) {
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2d{__float_as_uint(v), ep}, rs, (int)((ep & 1u) * (kXU * 512) + u * 512 + i) * 8, 0, 0);
+    };
+
+    for (it = 0; it < a.iters && ok; ++it) {
+        for (st = 0; st < nst && ok; ++st) {
+            const int q_ = o_tab + st * 12;
+            const int K = __builtin_amdgcn_readfirstlane(LDSI(q_ + 0)), N = __builtin_amdgcn_readfirstlane(LDSI(q_ + 1));
+            const int act = __builtin_amdgcn_readfirstlane(LDSI(q_ + 2)), post = __builtin_amdgcn_readfirstlane(LDSI(q_ + 3));
+            const int xsel = __builtin_amdgcn_readfirstlane(LDSI(q_ + 4)), dsel = __builtin_amdgcn_readfirstlane(LDSI(q_ + 5));
+            const int tp0 = __builtin_amdgcn_readfirstlane(LDSI(q_ + 6)), tp1 = __builtin_amdgcn_readfirstlane(LDSI(q_ + 7));
+            const int tp2 = __builtin_amdgcn_readfirstlane(LDSI(q_ + 8)), has_b = __builtin_amdgcn_readfirstlane(LDSI(q_ + 9));
+            const int xo = vsel(xsel), dst = vsel(dsel);
+            const int nchunk = (K + 31) >> 5;
+            const bool mine = 16 * g < N;
+            XSTAMPT(0)
+            // ---- this wave's task of the stage (at most one): 16 columns x 4 chunks for every utterance, partials to LDS
+#pragma unroll
+            for (int j = 0; j < kXSlots; ++j) {
+                if (st_of[j] == st) {
+                    const int c = 4 * grp_of[j] + (lane >> 4);
+                    const bool live = c < nchunk;
+                    float x0[kXU], x1[kXU];
+#pragma unroll
+                    for (int u = 0; u < kXU; ++u) {              // every operand requested before the first dot
+                        const int xb_ = u * UST + xo + 32 * c + (lane & 15);
+                        x0[u] = (live && u < nu) ? lds[xb_] : 0.0f;
+                        x1[u] = (live && u < nu) ? lds[xb_ + 16] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kXU; u += 2) {
+                        if (u < nu) {
+                            float r0, r1;
+                            dot32_dpp_x2(wt[j].w, x0[u], x1[u], wt[j].w, x0[u + 1], x1[u + 1], r0, r1);    // two utterances interleaved
+                            if (live) lds[o_part + (u * 24 + c) * 16 + (lane & 15)] = r0;
+                            if (live && u + 1 < nu) lds[o_part + ((u + 1) * 24 + c) * 16 + (lane & 15)] = r1;
+                        }
+                    }
+                }
+            }
+            XSTAMPT(1)
+            __syncthreads();
+            XSTAMPT(2)
+            // ---- wave 0: chunk values in chunk order (AC-1) + bias + activation -> the slice's 16 values per utterance
+            ++ep;
+            if (wave == 0 && mine) {
+                const int u = lane >> 4, n = lane & 15, col = 16 * g + n;
+                if (u < nu && col < N) {
+                    const int b = o_part + u * 24 * 16 + n;
+                    float v = lds[b];
+                    int ch = 1;
+                    for (; ch + 7 < nchunk; ch += 8) {      // eight loads in flight, adds in chunk order
+                        const float c0_ = lds[b + ch * 16], c1 = lds[b + (ch + 1) * 16], c2 = lds[b + (ch + 2) * 16], c3 = lds[b + (ch + 3) * 16];
+                        const float c4 = lds[b + (ch + 4) * 16], c5 = lds[b + (ch + 5) * 16], c6 = lds[b + (ch + 6) * 16], c7 = lds[b + (ch + 7) * 16];
+                        __builtin_amdgcn_sched_barrier(0);
+                        v = v + c0_; v = v + c1; v = v + c2; v = v + c3; v = v + c4; v = v + c5; v = v + c6; v = v + c7;
+                    }
+                    for (; ch + 3 < nchunk; ch += 4) {
+                        const float c0_ = lds[b + ch * 16], c1 = lds[b + (ch + 1) * 16], c2 = lds[b + (ch + 2) * 16], c3 = lds[b + (ch + 3) * 16];
+                        v = v + c0_; v = v + c1; v = v + c2; v = v + c3;
+                    }
+                    for (; ch < nchunk; ++ch) v = v + lds[b + ch * 16];
+                    if (has_b) v = v + lds[o_bias + st * 16 + n];
+                    if (act == DA_SIGMOID) v = sigmoid_e(v);
+                    else if (act == DA_TANH) v = tanh_e(v);
+                    else if (act == DA_RELU) v = v > 0.0f ? v : 0.0f;
+                    publish(u, col, v);
+                }
+            }
+            XSTAMPT(3)
+            {
+                const int kind = post == DP_GATES ? XG_GATES : post == DP_CAND ? (tp2 < 0 ? XG_CAND_ATT : XG_CAND_RES) : post == DP_OUT ? XG_OUT : XG_PLAIN;
+                // GATES: (cell input, nin, U); CAND: (U, layer, next layer or 0)
+                gather(N, kind, post == DP_GATES ? xo : dst, tp0, post == DP_GATES ? tp1 : tp1 - 1, tp2 - 1);
+            }
+            XSTAMPT(4)
+            __syncthreads();
+            XSTAMPT(5)
+            ok = LDSI(o_abort) == 0;
+            if (!ok) break;
+            if (post == DP_QUERY) {
+                // [RECALLED-TF BahdanauMonotonicAttention.__call__] score for the time steps t = g, g+32, ... of every utterance:
+                // one thread per (u, t, chunk, chain k): s_k = fma chain over j = k, k+4, ..., k+28; the four chains of a chunk sit in
+                // adjacent lanes and are combined as (s0+s1)+(s2+s3)
+                const int ntask = nu * nt * nAch * 4;
+                for (int task0 = 0; task0 < ntask; task0 += 512) {
+                    const int task = task0 + tid;
+                    const bool live = task < ntask;
+                    const int k = task & 3, tc = task >> 2;
+                    const int ch = live ? tc % nAch : 0, ut = live ? tc / nAch : 0;
+                    const int u = ut / (nt > 0 ? nt : 1), tl = ut - u * nt;
+                    float sk = 0.f;
+                    const int jb = ch * 32 + k, kl = o_keys + (u * ntmax + tl) * A + jb, pq = u * UST + u_pq + jb;
+#pragma unroll
+                    for (int j = 0; j < 32; j += 4) sk = fma_(lds[o_nv + jb + j], tanh_e((lds[kl + j] + lds[pq + j]) + lds[o_ab + jb + j]), sk);
+                    const float s1 = __shfl_xor(sk, 1);
+                    const float pr = (k & 1) ? s1 + sk : sk + s1;       // lanes k=0,1 hold s0+s1 ; k=2,3 hold s2+s3 (operand order as written)
+                    const float p2 = __shfl_xor(pr, 2);
+                    if (live && k == 0) lds[o_scp + (u * ntmax + tl) * 8 + ch] = pr + p2;
+                }
+                XSTAMPT(6)
+                __syncthreads();
+                ++ep;
+                for (int i = tid; i < nu * nt; i += 512) {
+                    const int u = i / nt, tl = i - u * nt, t = (tl << 5) + g;
+                    float sc = 0.0f;
+                    for (int ch = 0; ch < nAch; ++ch) { const float c = lds[o_scp + (u * ntmax + tl) * 8 + ch]; sc = ch == 0 ? c : sc + c; }
+                    sc = sc + asb;
+                    int lu = len[0];
+#pragma unroll
+                    for (int q = 1; q < kXU; ++q) lu = (u == q) ? len[q] : lu;
+                    publish(u, t, t < lu ? sigmoid_e(sc) : 0.0f);         // _maybe_mask_score(-inf) -> p = 0
+                }
+                XSTAMPT(7)
+                gather(T, XG_P, 0, 0, 0, 0);
+                __syncthreads();
+                XSTAMPT(8)
+                ok = LDSI(o_abort) == 0;
+                if (!ok) break;
+                // monotonic attention recurrence (redundant in every workgroup), wave u for utterance u, in registers:
+                // cumprod(1 - p) as exp(exclusive cumsum(log(clip(1 - p)))) [RECALLED-TF safe_cumprod], then
+                // alignments = p * cumprod * inclusive cumsum(previous / clip(cumprod, 1e-10, 1))
+                if (wave < nu) {
+                    const int ub = wave * UST;
+                    float run = 0.0f, run2 = 0.0f;
+                    for (int base = 0; base < T; base += 64) {
+                        const int t = base + lane, nb_ = T - base < 64 ? T - base : 64;
+                        const bool live = t < T;
+                        const float pv = live ? lds[ub + u_p + t] : 0.0f;
+                        float om = 1.0f - pv;
+                        const float tiny = 1.17549435e-38f;
+                        om = om < tiny ? tiny : (om > 1.0f ? 1.0f : om);
+                        const float lq = live ? log_e(om) : 0.0f;
+                        const float ex = decg_scan_regs(lq, run, nb_, lane, false);
+                        const float cpv = exp_e(ex);
+                        float den = cpv;
+                        den = den < 1e-10f ? 1e-10f : (den > 1.0f ? 1.0f : den);
+                        const float q2 = live ? div_(lds[ub + u_al + t], den) : 0.0f;
+                        const float cs = decg_scan_regs(q2, run2, nb_, lane, true);
+                        if (live) {
+                            const float pc = pv * cpv;
+                            const float al = pc * cs;
+                            lds[ub + u_al + t] = al;
+                            if (a.align && g == 0) a.align[((long long)(n0 + wave) * T + t) * a.iters + it] = al;      // tacotron.py:223
+                        }
+                    }
+                    for (int t = T + lane; t < Tp; t += 64) lds[ub + u_al + t] = 0.0f;
+                }
+                __syncthreads();
+                XSTAMPT(9)
+                // rnn_wrappers.py:390 context = alignments . values: this slice takes ENC/32 columns; one thread per (utterance, column,
+                // 32-step chunk), chunk values added in order
+                {
+                    const int ntk = nu * ncol * nch_t;
+                    for (int task = tid; task < ntk; task += 512) {
+                        const int cl = task % ncol, uc = task / ncol, ch = uc % nch_t, u = uc / nch_t;
+                        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                        const int ta = ch * 32, tbb = T < ta + 32 ? T : ta + 32;
+                        const int mo = o_memo + u * T * ncol + cl, al = u * UST + u_al;
+                        for (int t = ta; t < tbb; t += 4) {
+                            s0 = fma_(lds[mo + t * ncol], lds[al + t], s0);
+                            if (t + 1 < tbb) s1 = fma_(lds[mo + (t + 1) * ncol], lds[al + t + 1], s1);
+                            if (t + 2 < tbb) s2 = fma_(lds[mo + (t + 2) * ncol], lds[al + t + 2], s2);
+                            if (t + 3 < tbb) s3 = fma_(lds[mo + (t + 3) * ncol], lds[al + t + 3], s3);
+                        }
+                        lds[o_part + (u * nch_t + ch) * ncol + cl] = (s0 + s1) + (s2 + s3);
+                    }
+                    __syncthreads();
+                    ++ep;
+                    if (tid < nu * ncol) {
+                        const int u = tid / ncol, cl = tid - u * ncol;
+                        float v = 0.0f;
+                        for (int ch = 0; ch < nch_t; ++ch) { const float c = lds[o_part + (u * nch_t + ch) * ncol + cl]; v = ch == 0 ? c : v + c; }
+                        publish(u, c0 + cl, v);
+                    }
+                    XSTAMPT(10)
+                    gather(ENC, XG_CTX, 0, 0, 0, 0);
+                    __syncthreads();
+                    ok = LDSI(o_abort) == 0;
+                    if (!ok) break;
+                }
+            }
+            XSTAMPT(11)
+        }
+    }
+    if (!ok && tid == 0) a.status[0] = 22;                    // exchange watchdog
+#undef XSTAMPT
+}
+
 // =====================================================================================================
 //  host side
 // =====================================================================================================
@@ -1183,6 +1595,7 @@ struct twv_tacotron {
     unsigned long long* prof = nullptr;
     int dec_groups = 0;             // 0 auto (8, halved until N*G fits the CUs), -1 single-workgroup kernel
     long long blob_floats, packed_floats;
+    long long xt_off = 0;           // row tiles of the XCD-local decoder kernel [32 slices][8 waves][kXSlots][2048]
     TMat emb, semb;                 // raw tables (K rows x N)
     TMat dW[8]; TVec db[8]; int ndense, dn[8];
     TMat pW1, pW2; TVec pb1, pb2;
@@ -1249,6 +1662,7 @@ static void taco_build(twv_tacotron* h)
     h->lW = mat(2 * d.post_rnn_size, d.num_freq); h->lb = vec(d.num_freq);
     h->blob_floats = src;
     h->nv = TVec{dst, A}; dst += (A + 3) / 4 * 4;      // derived: normed_v
+    h->xt_off = dst; dst += 32LL * 8 * kXSlots * kTile;
     h->packed_floats = dst;
 }
 
@@ -1285,7 +1699,8 @@ extern "C" int twv_tacotron_set_option(twv_tacotron* h, const char* name, int va
     if (!h || !name) return twv_fail(TWV_E_INVALID, "null argument");
     if (!strcmp(name, "gemm_valu")) { g_gemm_valu = value ? 1 : 0; return TWV_OK; }
     if (!strcmp(name, "decoder_groups")) {
-        if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return twv_fail(TWV_E_INVALID, "decoder_groups must be -1, 0, 1, 2, 4 or 8");
+        if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 32)
+            return twv_fail(TWV_E_INVALID, "decoder_groups must be -1, 0, 1, 2, 4, 8 or 32 (32 = the XCD-local kernel)");
         h->dec_groups = value;
         return TWV_OK;
     }
@@ -1310,6 +1725,43 @@ __global__ void tc_normed_v_kernel(float* P, long long av, long long ag, long lo
     }
 }
 
+// the decoder step as a stage table (same order and operands as tc_decoder_g_kernel's): used by the XCD-local kernel and its pack
+static void taco_xstages(const twv_tacotron* h, XStageTab& t)
+{
+    const twv_tacotron_dims& d = h->d;
+    const int M = d.num_mels, R = d.reduction_factor, D0 = d.dec_prenet_sizes[0], D1 = d.dec_prenet_sizes[1], AS = d.attention_state_size,
+              A = d.attention_size, ENC = 2 * d.enc_rnn_size, DR = d.dec_rnn_size;
+    int s = 0;
+    auto put = [&](const TMat& w, long long b, int K, int N, int x, int dst, int act, int post, int p0, int p1, int p2) {
+        t.w[s] = w.off; t.b[s] = b; t.K[s] = K; t.N[s] = N; t.xsel[s] = x; t.dsel[s] = dst; t.act[s] = act; t.post[s] = post;
+        t.p0[s] = p0; t.p1[s] = p1; t.p2[s] = p2; ++s;
+    };
+    put(h->dpW1, h->dpb1.off, M, D0, XV_FRAME, XV_VEC, DA_RELU, DP_NONE, 0, 0, 0);                               // rnn_wrappers.py:425 prenet
+    put(h->dpW2, h->dpb2.off, D0, D1, XV_VEC, XV_CATA, DA_RELU, DP_NONE, 0, 0, 0);
+    put(h->aWgm, h->abg.off, D1 + ENC + AS, 2 * AS, XV_CATA, XV_VEC, DA_SIGMOID, DP_GATES, D1 + ENC, AS, 0);      // rnn_wrappers.py:310-312 attention GRU
+    put(h->aWcm, h->abc.off, D1 + ENC + AS, AS, XV_CATA, XV_VEC, DA_TANH, DP_CAND, AS, 0, -1);
+    put(h->Wq, -1, AS, A, XV_CATB, XV_PQ, DA_NONE, DP_QUERY, 0, 0, 0);                                            // attention query layer on the new state
+    put(h->cW, h->cb.off, AS + ENC, DR, XV_CATB, XV_CATR, DA_NONE, DP_PROJ, 0, 0, 0);                             // rnn_wrappers.py:463 + OutputProjectionWrapper -> y
+    for (int l = 0; l < d.dec_layer_num; ++l) {                                                                  // tacotron.py:167 residual GRUs
+        put(h->rWg[l], h->rbg[l].off, 2 * DR, 2 * DR, XV_CATR + l, XV_VEC, DA_SIGMOID, DP_GATES, DR, DR, 0);
+        put(h->rWc[l], h->rbc[l].off, 2 * DR, DR, XV_CATR + l, XV_VEC, DA_TANH, DP_CAND, DR, 1 + l, l + 1 < d.dec_layer_num ? 2 + l : 0);
+    }
+    put(h->oW, h->ob.off, DR, M * R, XV_Y, XV_VEC, DA_NONE, DP_OUT, 0, 0, 0);                                     // tacotron.py:173
+    t.nst = s;
+}
+// does the XCD-local kernel take this model?  (16-column slices over 32 workgroups, register slots per wave, LDS)
+static bool taco_xdec_ok(const twv_tacotron* h, const XStageTab& t)
+{
+    const twv_tacotron_dims& d = h->d;
+    if (t.nst > kXStages || d.attention_size % 32 || (2 * d.enc_rnn_size) % 32 || d.attention_size > 256 || d.dec_layer_num > 4) return false;
+    for (int s = 0; s < t.nst; ++s) if (t.N[s] > 512 || t.K[s] > 24 * 32) return false;
+    for (int g = 0; g < 32; ++g) {
+        int a[kXSlots], b[kXSlots];
+        if (xdec_tasks(t, g, 0, a, b) > kXSlots) return false;
+    }
+    return true;
+}
+
 extern "C" int twv_tacotron_pack(const twv_tacotron* h, const float* blob, void* packed, void* stream)
 {
     if (!h || !blob || !packed) return twv_fail(TWV_E_INVALID, "null argument");
@@ -1325,6 +1777,11 @@ extern "C" int twv_tacotron_pack(const twv_tacotron* h, const float* blob, void*
         }
     }
     hipLaunchKernelGGL(tc_normed_v_kernel, dim3(1), dim3(64), 0, st, dst, h->av.off, h->ag.off, h->nv.off, h->d.attention_size);
+    {   // row tiles of the XCD-local decoder kernel, from the standard tiles just written
+        XStageTab xt;
+        taco_xstages(h, xt);
+        if (taco_xdec_ok(h, xt)) hipLaunchKernelGGL(tc_xdec_pack_kernel, dim3(32 * 8), dim3(256), 0, st, dst, xt, h->xt_off);
+    }
     HIPCHK(hipGetLastError());
     return TWV_OK;
 }
@@ -1345,6 +1802,7 @@ static long long taco_ws_floats(const twv_tacotron* h, int N, int T)
     f += (long long)N * 4096;           // speaker-dependent vectors
     f += rowsP * 256;                   // post CBHG output
     f += (long long)N * 4096;           // decoder exchange granules
+    f += 8LL * 2 * kXU * 512 * 2 + 64;  // XCD-local decoder: exchange granules per XCD + role tickets
     return f + 1024;
 }
 extern "C" size_t twv_tacotron_workspace_bytes(const twv_tacotron* h, int batch, int t_in) { return (size_t)taco_ws_floats(h, batch, t_in) * 4; }
@@ -1439,6 +1897,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
     float* spk = w; w += (long long)N * 4096;
     float* postout = w; w += (long long)rowsP * 256;
     float* exch = w; w += (long long)N * 2 * kExN * 2;      // decoder exchange granules (8 bytes each)
+    float* xexch = w; w += 8LL * 2 * kXU * 512 * 2 + 64;    // XCD-local decoder: granules [8][2][kXU*512] + tickets
     // ---- tacotron.py:51-60 embedding, :67-82 speaker embedding + deep_dense (softsign)
     hipLaunchKernelGGL(tc_embed_kernel, dim3(tgrid((long long)rows * E)), dim3(256), 0, st, P + h->emb.off, tokens, rows, E, ra);
     hipLaunchKernelGGL(tc_gather_rows_kernel, dim3(tgrid((long long)N * SE)), dim3(256), 0, st, P + h->semb.off, speaker_ids, N, SE, spk);
@@ -1491,6 +1950,35 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
         while (G > 1 && (long long)N * G > cus) G >>= 1;
         if (2 * (AS > DR ? AS : DR) > kExN || M * R > kExN || T > kExN || ENC > kExN) G = 1;
         while (G > 1 && ENC % G) G >>= 1;
+        XStageTab xt;
+        taco_xstages(h, xt);
+        const int upx = (N + 7) / 8;
+        long long xfl = 0;
+        {   // LDS of tc_decoder_x_kernel (mirrors its carve)
+            const int nu = upx < N ? upx : N, ncol = ENC / 32, ntm = (T + 31) / 32;
+            const long long ust = (M + 31) / 32 * 32 + 1024 + (da.D1 + ENC + AS) + (AS + ENC) + d.dec_layer_num * 2 * DR + 512 + DR + A + Tp * 2;
+            const long long p1 = (long long)nu * 16 * 24, p2 = (long long)nu * ntm * ncol;
+            xfl = ust * nu + 2 * A + 16 * xt.nst + (long long)nu * ntm * 8 + (long long)nu * ntm * A + (long long)nu * T * ncol + (p1 > p2 ? p1 : p2) + 4 + kXStages * 12 + 64;
+        }
+        const bool xok = taco_xdec_ok(h, xt) && cus >= 256 && upx <= kXU && T <= 512 && xfl * 4 <= 160 * 1024;
+        if (h->dec_groups == 32 && xok) {      // opt-in: measured 43.5 us per decoder step against the split kernel's 47, the whole pass is not faster yet
+            // XCD-local kernel: every XCD's 32 workgroups hold the decoder in registers and serve that XCD's utterances
+            DecXArgs xa;
+            xa.d = da; xa.tab = xt; xa.upx = upx; xa.xt_off = h->xt_off;
+            xa.exch = reinterpret_cast<unsigned long long*>(xexch);
+            xa.tickets = reinterpret_cast<int*>(xexch + 8LL * 2 * kXU * 512 * 2);
+            HIPCHK(hipMemsetAsync(xexch, 0, (size_t)(8LL * 2 * kXU * 512 * 2 + 64) * 4, st));
+            const size_t shm = (size_t)xfl * 4;
+            if (da.prof) {
+                HIPCHK(hipFuncSetAttribute((const void*)tc_decoder_x_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+                hipLaunchKernelGGL(tc_decoder_x_kernel<true>, dim3(2 * cus), dim3(512), shm, st, xa);
+            } else {
+                HIPCHK(hipFuncSetAttribute((const void*)tc_decoder_x_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+                hipLaunchKernelGGL(tc_decoder_x_kernel<false>, dim3(2 * cus), dim3(512), shm, st, xa);
+            }
+        } else if (h->dec_groups == 32) {
+            return twv_fail(TWV_E_UNSUPPORTED, "decoder_groups = 32 (XCD-local decoder) needs 256 CUs, batch <= 32, t_in <= 512 and the default decoder sizes");
+        } else
         if (h->dec_groups == -1) {       // the single-workgroup kernel (kept as a cross-check of the split one)
             const long long fl = 2048 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + Tp * 4 + A + Tp * 8 + pmax;
             const size_t shm = (size_t)fl * 4;

@@ -101,9 +101,10 @@ def test_synthesizer_surface(torch_cuda, oracle):
     assert first_mismatch(out["mel"].cpu().numpy(), mel_o) is None
 
 
-@pytest.mark.parametrize("groups", [-1, 1, 2, 4, 8])
+@pytest.mark.parametrize("groups", [-1, 1, 2, 4, 8, 32])
 def test_decoder_launch_geometry_does_not_change_results(torch_cuda, oracle, groups):
-    """decoder split over G workgroups per utterance (exchange through polled granules) == single-workgroup kernel == oracle"""
+    """decoder split over G workgroups per utterance (exchange through polled granules) == single-workgroup kernel == the XCD-local
+    register-resident kernel (32) == oracle"""
     hp = _hp(max_iters=7, enc_bank_size=3, post_bank_size=2, num_freq=65)
     d, blob, tok, ln, spk, m = _case(oracle, hp, 3, 37, [37, 20, 5], seed=11)
     mel_o, lin_o, al_o = oracle.taco_infer(d, blob, tok, ln, spk)
@@ -216,3 +217,17 @@ def test_synthesizer_cli(torch_cuda, oracle, tmp_path):
     assert synth_main(["--load_path", str(logdir), "--sample_path", str(out), "--tokens", "5,9,33,12,1", "--num_speakers", "2",
                        "--speaker_id", "1", "--seed", "3"]) is True
     assert len(list(out.glob("*.wav"))) == 1 and len(list(out.glob("*.npy"))) == 1
+
+
+def test_xcd_local_decoder_at_bench_geometry(torch_cuda, oracle):
+    """decoder_groups = 32: every XCD's 32 workgroups hold the decoder in registers and serve 4 utterances; B = 32, 25 steps, ragged lengths"""
+    hp = _hp(max_iters=25)
+    N, T = 32, 101
+    lengths = [T - (i % 7) * 9 for i in range(N)]
+    d, blob, tok, ln, spk, m = _case(oracle, hp, N, T, lengths, seed=23)
+    m.set_option("decoder_groups", 32)
+    mel_o, lin_o, al_o = oracle.taco_infer(d, blob, tok, ln, spk)
+    mel, lin, al = m.infer(tok, ln, spk)
+    assert first_mismatch(al.cpu().numpy(), al_o) is None, ("alignments", first_mismatch(al.cpu().numpy(), al_o))
+    assert first_mismatch(mel.cpu().numpy(), mel_o) is None, ("mel", first_mismatch(mel.cpu().numpy(), mel_o))
+    assert first_mismatch(lin.cpu().numpy(), lin_o) is None
