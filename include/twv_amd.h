@@ -35,7 +35,8 @@ typedef struct {
     int32_t initial_filter_width;        /* <= 64 */
     int32_t use_biases;
     int32_t gc_channels;                 /* 0 = no global conditioning, else <= 64 */
-    int32_t gc_cardinality;
+    int32_t gc_cardinality;              /* 0 with gc_channels > 0: no gc_embedding table; every `gc_ids` argument then points at (B, gc_channels)
+                                            float embeddings instead of int32 ids (_embed_gc's second branch, model.py:199-207) */
     int32_t lc_channels;                 /* num_mels; 0 = no local conditioning, else <= 128 */
     int32_t n_upsample;                  /* len(upsample_factor) <= 4 */
     int32_t upsample_factor[4];

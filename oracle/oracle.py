@@ -34,7 +34,7 @@ def make_dims(dilations, R=32, D=32, S=512, Q=256, out_channels=30, scalar_input
     d.ifw = ifw if scalar_input else 2
     d.use_bias = 1 if use_bias else 0
     d.G = G or 0
-    d.gc_card = gc_card if G else 0
+    d.gc_card = (gc_card or 0) if G else 0          # 0 with G > 0: the caller supplies the embedding (model.py:199-207)
     d.L = L or 0
     d.n_up = len(up) if L else 0
     for i, v in enumerate(up if L else ()):
@@ -106,6 +106,8 @@ def _c32(a):
 
 
 def _ci(a):
+    if a is not None and np.asarray(a).dtype.kind == 'f':      # a (B, G) embedding instead of ids: same pointer, float payload
+        return np.ascontiguousarray(a, dtype=np.float32).view(np.int32)
     return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
 
 
@@ -124,7 +126,7 @@ def tensor_specs(d):
         specs.append(("wavenet/conv1d/kernel", (d.ifw, 1, d.R)))
     else:
         specs.append(("wavenet/conv1d/kernel", (2, d.Q, d.R)))
-    if d.G:
+    if d.G and d.gc_card:
         specs.append(("wavenet/gc_embedding", (d.gc_card, d.G)))
     for i in range(d.n_layers):
         p = "wavenet/dilated_stack/layer%d/dilation_layer/" % i

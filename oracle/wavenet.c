@@ -253,7 +253,10 @@ static void step_one(const twvo_dims* d, const float* blob, const blob_offs* op,
         float* lq = s->lc_q + (size_t)b * 2 * (L ? L : 1);
         if (L && lc) push(lq, 2, L, lc + (size_t)b * L);
         const float* lc_used = (L && lc) ? lq : NULL; /* model.py:79-80: slice from the FRONT -> queue[0] = previous step's frame */
-        const float* emb = (d->G && gc_ids) ? blob + o.gc_emb + (size_t)gc_ids[b] * d->G : NULL; /* model.py:197-198 */
+        /* model.py:191-207: ids looked up in gc_embedding, or (global_condition_cardinality is None) the embedding itself, passed
+         * through the same pointer as (B, G) floats */
+        const float* emb = !(d->G && gc_ids) ? NULL : d->gc_card > 0 ? blob + o.gc_emb + (size_t)gc_ids[b] * d->G
+                                                                      : (const float*)gc_ids + (size_t)b * d->G;
         /* model.py:131 / 41-46 causal layer: conv1d valid, no bias, over the whole queue */
         for (int j = 0; j < R; ++j)
             x[j] = twvo_cdot(blob + o.causal + j, R, cq, s->cq_rows * s->cq_cols);
@@ -426,7 +429,7 @@ void twvo_forward_full(const twvo_dims* d, const float* blob, int B, int Tin, co
         for (int p = 0; p < Tc; ++p)
             for (int j = 0; j < R; ++j)
                 cur[(size_t)p * R + j] = twvo_cdot(blob + o.causal + j, R, inp + (size_t)p * cin, kc * cin); /* model.py:131 */
-        const float* emb = (d->G && gc_ids) ? blob + o.gc_emb + (size_t)gc_ids[b] * d->G : NULL;
+        const float* emb = !(d->G && gc_ids) ? NULL : d->gc_card > 0 ? blob + o.gc_emb + (size_t)gc_ids[b] * d->G : (const float*)gc_ids + (size_t)b * d->G;
         for (int i = 0; i < d->n_layers; ++i) {
             const int dil = d->dilations[i];
             const int Tn = Tc - dil;

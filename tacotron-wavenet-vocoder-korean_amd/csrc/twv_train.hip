@@ -1285,6 +1285,8 @@ static rocblas_status gemm_tn_splitk(rocblas_handle h, hipStream_t st, int M, in
 
 extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch, int n_samples, twv_wavenet_trainer** out)
 {
+    if (dims && dims->gc_channels > 0 && dims->gc_cardinality < 1)
+        return twv_fail(TWV_E_UNSUPPORTED, "training needs global_condition_cardinality (the gc_embedding table is a trained variable; model.py:191-195)");
     if (!dims || !out || batch < 1) return twv_fail(TWV_E_INVALID, "bad argument");
     const twv_wavenet_dims& d = *dims;
     if (d.residual_channels != 32 || d.dilation_channels != 32) return twv_fail(TWV_E_UNSUPPORTED, "residual/dilation channels must be 32");

@@ -110,8 +110,13 @@ __global__ void __launch_bounds__(64) wn_gc_kernel(const float* P, Layout L, con
 {
     __shared__ __attribute__((aligned(16))) float emb[64];
     const int b = blockIdx.x, lane = threadIdx.x;
-    const int id = gc_ids[b];
-    emb[lane] = lane < L.G ? P[L.off_gcemb + (long long)id * L.G + lane] : 0.0f;
+    // model.py:191-207: ids looked up in gc_embedding, or (no cardinality) the embedding itself as (B, G) floats through the same pointer
+    if (L.gc_card > 0) {
+        const int id = gc_ids[b];
+        emb[lane] = lane < L.G ? P[L.off_gcemb + (long long)id * L.G + lane] : 0.0f;
+    } else {
+        emb[lane] = lane < L.G ? reinterpret_cast<const float*>(gc_ids)[(long long)b * L.G + lane] : 0.0f;
+    }
     __syncthreads();
     for (int l = 0; l < L.NL; ++l) {
         float res = 0.0f;
@@ -1369,7 +1374,7 @@ static int build_layout(const twv_wavenet_dims& d, twv_wavenet* h)
     if (d.skip_channels < 64 || d.skip_channels > 1024 || d.skip_channels % 64)
         return fail(TWV_E_UNSUPPORTED, "skip_channels must be a multiple of 64 in [64,1024]");
     if (d.gc_channels < 0 || d.gc_channels > 64) return fail(TWV_E_UNSUPPORTED, "gc_channels must be <= 64");
-    if (d.gc_channels > 0 && d.gc_cardinality < 1) return fail(TWV_E_INVALID, "gc_cardinality required with gc_channels");
+    if (d.gc_channels > 0 && d.gc_cardinality < 0) return fail(TWV_E_INVALID, "gc_cardinality must be >= 0 (0 = the caller passes the embedding, model.py:199-207)");
     if (d.lc_channels < 0 || d.lc_channels > 128 || d.lc_channels % 4) return fail(TWV_E_UNSUPPORTED, "lc_channels must be a multiple of 4, <= 128");
     if (d.lc_channels > 0 && (d.n_upsample < 1 || d.n_upsample > 4)) return fail(TWV_E_INVALID, "1..4 upsample factors required with lc_channels");
     L.NL = d.n_layers; L.S = d.skip_channels; L.Q = d.quantization_channels; L.scalar = d.scalar_input ? 1 : 0;

@@ -163,7 +163,12 @@ class WaveNetModel(object):
         with torch.cuda.device(self.device):
             gc = None
             if self.global_condition_channels:
-                gc = torch.as_tensor(np.asarray(gc_ids, dtype=np.int32), device=self.device).contiguous()
+                if self.global_condition_cardinality:
+                    gc = torch.as_tensor(np.asarray(gc_ids, dtype=np.int32), device=self.device).contiguous()
+                else:      # model.py:199-207: the global condition IS the embedding (B, gc_channels)
+                    gc = torch.as_tensor(np.asarray(gc_ids, dtype=np.float32), device=self.device).reshape(B, -1).contiguous()
+                    if gc.shape[1] != self.global_condition_channels:
+                        raise ValueError('Shape of global_condition {} does not match global_condition_channels {}.'.format(tuple(gc.shape), self.global_condition_channels))
             if isinstance(upsampled, Upsampled) and self.fused_conditioning() and n_steps <= upsampled.shape[1]:
                 mel = upsampled.mel
                 cond = torch.empty(self._L.twv_wavenet_cond_bytes_mel(self._h, B, mel.shape[1]) // 4, dtype=torch.float32, device=self.device)

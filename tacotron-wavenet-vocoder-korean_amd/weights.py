@@ -9,7 +9,7 @@ def tensor_specs(n_layers, R=32, D=32, S=512, Q=256, out_channels=30, scalar_inp
                  use_biases=True, gc_channels=32, gc_cardinality=2, lc_channels=80, upsample_factor=(5, 5, 12)):
     O = out_channels if scalar_input else Q
     specs = [("wavenet/conv1d/kernel", (initial_filter_width, 1, R) if scalar_input else (2, Q, R))]
-    if gc_channels:
+    if gc_channels and gc_cardinality:      # cardinality None / 0: the caller passes the embedding itself (model.py:199-207)
         specs.append(("wavenet/gc_embedding", (gc_cardinality, gc_channels)))
     for i in range(n_layers):
         p = "wavenet/dilated_stack/layer%d/dilation_layer/" % i

@@ -17,7 +17,7 @@ def make_model(batch, dilations, tensors, scalar_input=True, S=512, Q=256, out_c
     from twvk_amd.wavenet import WaveNetModel
     m = WaveNetModel(batch, dilations, 2, 32, 32, S, quantization_channels=Q, out_channels=out_channels,
                      use_biases=use_bias, scalar_input=scalar_input, initial_filter_width=ifw,
-                     global_condition_channels=G or None, global_condition_cardinality=gc_card if G else None,
+                     global_condition_channels=G or None, global_condition_cardinality=(gc_card or None) if G else None,
                      local_condition_channels=L or None, upsample_factor=list(up) if L else None, train_mode=False)
     if workers:
         m.set_option("workers", workers)

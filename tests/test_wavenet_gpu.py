@@ -481,3 +481,32 @@ def test_fused_conditioning_equals_materialised_upsample(torch_cuda, oracle):
     assert first_mismatch(a, b) is None
     want = oracle.generate_mol(d, blob, oracle.State(d, B), oracle.upsample(d, blob, mel), gc, seed_in, u)
     assert first_mismatch(a, want) is None
+
+
+@pytest.mark.parametrize("xcd", [1, 0])
+def test_global_condition_passed_as_embedding(torch_cuda, oracle, xcd):
+    """_embed_gc's second branch (model.py:199-207): no cardinality, the caller passes the (B, gc_channels) embedding itself.
+    Feeding the rows a gc_embedding table would have produced gives the id-path's samples bit for bit; both kernels."""
+    dil = [1, 2, 4, 8, 16, 32]
+    B, T = 2, 300
+    d_id, tensors_id, blob_id = make_case(oracle, dil, gc_card=3, seed=4)
+    table = tensors_id["wavenet/gc_embedding"]
+    ids = np.array([2, 0], np.int32)
+    rng = np.random.RandomState(6)
+    mel = rng.uniform(-4, 4, (B, 1, 80)).astype(np.float32)
+    seed_in = (2 * rng.rand(B) - 1).astype(np.float32)
+    u = mol_uniforms(B, T, 10)
+    want = oracle.generate_mol(d_id, blob_id, oracle.State(d_id, B), oracle.upsample(d_id, blob_id, mel), ids, seed_in, u)
+    # the same weights without the table
+    d_e = oracle.make_dims(dil, gc_card=0)
+    tensors_e = {k: v for k, v in tensors_id.items() if k != "wavenet/gc_embedding"}
+    blob_e = oracle.blob_from_tensors(d_e, tensors_e)
+    emb = table[ids]
+    assert "wavenet/gc_embedding" not in dict(oracle.tensor_specs(d_e))
+    want_e = oracle.generate_mol(d_e, blob_e, oracle.State(d_e, B), oracle.upsample(d_e, blob_e, mel), emb, seed_in, u)
+    assert first_mismatch(want_e, want) is None                      # the checker's two branches agree
+    m = make_model(B, dil, tensors_e, gc_card=0, xcd=xcd)
+    got = m.generate(m.create_upsample(mel), emb, seed_in, u).cpu().numpy()
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+    with pytest.raises(ValueError):
+        m.generate(m.create_upsample(mel), emb[:, :5], seed_in, u)   # wrong embedding width (model.py:203-206)
