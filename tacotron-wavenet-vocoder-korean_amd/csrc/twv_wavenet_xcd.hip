@@ -49,11 +49,17 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 // aux bit 31 = volatile for the compiler (a poll must not be hoisted out of its loop; it also sets sc0, which changes nothing for a
 // load).  Stores are NOT volatile (that would make them sc0 sc1 = write-through to the memory side); a compiler barrier pins them.
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 constexpr int kAuxLoad = (int)(16u | 0x80000000u), kAuxStore = 0;
 __device__ __forceinline__ unsigned long long xb_load(rsrc_t rs, int uword, int lword)
 {
     const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rs, lword * 8, uword * 8, kAuxLoad);
     return ((unsigned long long)v.y << 32) | (unsigned long long)v.x;
+}
+// two adjacent granules with one load (each half carries its own tag: the halves may come from different stores)
+__device__ __forceinline__ u32x4s xb_load2(rsrc_t rs, int uword, int lpair)
+{
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, lpair * 16, uword * 8, kAuxLoad);
 }
 __device__ __forceinline__ void xb_store(rsrc_t rs, int uword, int lword, unsigned tag, float v)
 {
@@ -61,7 +67,6 @@ __device__ __forceinline__ void xb_store(rsrc_t rs, int uword, int lword, unsign
     asm volatile("" ::: "memory");
 }
 // two self-tagged 8-byte granules {a, tag}, {b, tag} with ONE 16-byte store (readers load the halves separately)
-typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void xb_store2(rsrc_t rs, int uword, int lane, unsigned tag, float va, float vb)
 {
     const u32x4s d = {__float_as_uint(va), tag, __float_as_uint(vb), tag};
@@ -300,17 +305,20 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
         // ---- sampler: conv1d_2's [16 chunks][32 lanes] partial table from the conv1 workgroups -> mixture.py:84-114
         if (sampler) {
             __builtin_amdgcn_s_setprio(3);
-            // the [16 chunks][32 lanes] partial table, each granule once: lanes 0-31 chunks 0-7 of output (lane & 31), lanes 32-63
-            // chunks 8-15 (a poll of 16 granules per lane was measured: +0.2 us on the hop)
+            // the [8 chunk pairs][32 outputs][2] partial table, each granule once, FOUR 16-byte loads per round (every load in a polling
+            // round adds to its round trip: 16 8-byte loads per lane were measured at +0.2 us on the hop over 8): lanes 0-31 chunks 0-7
+            // of output (lane & 31), lanes 32-63 chunks 8-15
             const int half = lane >> 5;
             unsigned long long q[8];
             pl.it = 0;
             for (;;) {
                 bool good = true;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    q[k] = xb_load(rs, (int)XcdExch::PT + k * 32, half * 256 + (lane & 31));
-                    good = good && g_tag(q[k]) == tag;
+                for (int k = 0; k < 4; ++k) {
+                    const u32x4s d = xb_load2(rs, (int)XcdExch::PT, (half * 4 + k) * 32 + (lane & 31));
+                    q[2 * k] = ((unsigned long long)d.y << 32) | d.x;
+                    q[2 * k + 1] = ((unsigned long long)d.w << 32) | d.z;
+                    good = good && d.y == tag && d.w == tag;
                 }
                 if (__all(good)) break;
                 if (!poll_tick(pl, 34)) break;
@@ -518,7 +526,7 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, int b, int g, rsrc_t 
     }
     const bool summer = v == ((NL - 1) & 7);
     const int n16 = lane & 15;
-    const int za_lane = lane_of_z(n16), zb_lane = lane_of_z(16 + n16);
+    const int zc_lane = lane_of_z((lane < 32 ? 0 : 16) + n16);
     unsigned long long seen[4] = {0, 0, 0, 0}, period = 0;       // arrival times of the own layers in the previous step
     for (int t = 0; t < T && !pl.dead; ++t) {
         const unsigned tag = (unsigned)t + 1u;
@@ -544,18 +552,19 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, int b, int g, rsrc_t 
                 };
                 if (!summer && period) nap_until(seen[i] + period - (period >> 3));
                 XMARK(ROLE_SKIP0 + g, 10 + i);
-                unsigned long long qa, qb;
+                // ONE load per round (every load of a polling round adds to its round trip): lanes 0-31 fetch z[0..15] twice, lanes
+                // 32-63 z[16..31] twice; v_permlane32_swap makes the two dot operands of it
+                unsigned long long qz;
                 pl.it = 0;
                 for (;;) {
-                    qa = xb_load(rs, (int)XcdExch::ZX + l * 128, za_lane * 2);
-                    qb = xb_load(rs, (int)XcdExch::ZX + l * 128, zb_lane * 2);
-                    if (summer) drain(false);                          // while the loads are in flight: add what has arrived
-                    if (__all(g_tag(qa) == tag && g_tag(qb) == tag)) break;
+                    qz = xb_load(rs, (int)XcdExch::ZX + l * 128, zc_lane * 2);
+                    if (summer) drain(false);                          // while the load is in flight: add what has arrived
+                    if (__all(g_tag(qz) == tag)) break;
                     if (!poll_tick(pl, 51)) break;
                     if (!summer) __builtin_amdgcn_s_sleep(1);
                 }
                 if ((INSTR & 1) && pl.dead && g == 0 && lane == 0) {   // bring-up: what the abandoned poll last saw
-                    xb_store(rs, (int)XcdExch::MARK + 176 + v * 4, 0, g_tag(qa), __uint_as_float(g_tag(qb)));
+                    xb_store(rs, (int)XcdExch::MARK + 176 + v * 4, 0, g_tag(qz), __uint_as_float(g_tag(qz)));
                     xb_store(rs, (int)XcdExch::MARK + 177 + v * 4, 0, (unsigned)l, __uint_as_float((unsigned)pl.it));
                     xb_store(rs, (int)XcdExch::MARK + 178 + v * 4, 0, tag, __uint_as_float((unsigned)i));
                 }
@@ -566,7 +575,8 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, int b, int g, rsrc_t 
                     seen[i] = now;
                 }
                 XSTAMP(g == 0 && summer && l == NL - 1, 20);
-                float val = dot32_dpp(ws[i].w, g_val(qa), g_val(qb));                 // model.py:96
+                const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)qz, (unsigned)qz, false, false);   // [lo, lo], [hi, hi]
+                float val = dot32_dpp(ws[i].w, __uint_as_float(sw[0]), __uint_as_float(sw[1]));              // model.py:96
                 if (use_bias) val = val + bs[i];
                 if (!summer) {
                     LDSU64(l * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(val);
@@ -664,7 +674,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, int b, int g, rsrc_t
             const float h = r > 0.0f ? r : 0.0f;                         // model.py:160
             // conv1d_2 chunk 2g+v reads h[32v .. 32v+31] of this block
             const float p = (v == 0) ? dot_readlane_pipe(t2, h) : dot_readlane_pipe32(t2, h);
-            if (lane < 32) xb_store(rs, (int)XcdExch::PT + (2 * g + v) * 32, lane, tag, p);
+            if (lane < 32) xb_store(rs, (int)XcdExch::PT, (g * 32 + lane) * 2 + v, tag, p);     // chunk 2g+v of output `lane`, next to its pair
             XSTAMP(g == 0 && v == 0, 25);
         }
     }
