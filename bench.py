@@ -59,12 +59,12 @@ def respawn_under_torchrun(args):
 
 def traffic_per_step(kernel, key):
     """HBM bytes per generation step from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
-    scripts/pmc_to_traffic.py), valid only for the library build it was measured on (source hash)."""
+    scripts/pmc_to_traffic.py), valid only for the generation-kernel sources it was measured on (_lib.generation_hash())."""
     try:
         import twvk_amd
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             t = json.load(fh)
-        e = t.get(twvk_amd._lib.source_hash(), {}).get(kernel, {}).get(key)
+        e = t.get(twvk_amd._lib.generation_hash(), {}).get(kernel, {}).get(key)
         return None if e is None else float(e["fetch_bytes_per_step"]) + float(e["write_bytes_per_step"])
     except Exception:
         return None
@@ -262,7 +262,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0,
                          # HBM bytes per launch from rocprofv3 PMC (separate --pmc passes; FETCH_SIZE / WRITE_SIZE with the guide's gfx950
-                         # corrections), per generated step, for THIS build of the library (profiles/traffic.json is keyed by source hash)
+                         # corrections), per generated step, for THESE generation-kernel sources (profiles/traffic.json is keyed by _lib.generation_hash())
                          "traffic": None if tps is None else tps * T, "algorithmic_bytes_per_launch": bytes_per_step * T,
                          "kernel_ms": k_ms, "us_per_generation_step": k_ms * 1e3 / T,
                          "note": "weights are register-/L2-resident: the sample loop is a dependent chain (latency), not a bandwidth stream; "

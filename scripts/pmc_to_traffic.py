@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Condense the rocprofv3 passes of scripts/profile_generation.sh: per-kernel stats, FETCH_SIZE / WRITE_SIZE / SQ counters of the
 generation kernel -> gpurun_out/prof_<tag>/summary_<tag>.txt, and HBM bytes per generation step -> profiles/traffic.json (keyed by
-the library's source hash: bench.py reports `roofline.traffic` only for the build it was measured on).
+the hash of the generation kernels' sources: bench.py reports `roofline.traffic` only for the code it was measured on).
 
 FETCH_SIZE / WRITE_SIZE are in KiB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 counts 64 B per 128-B request of a
 wide coalesced read -> doubled; WRITE_SIZE is taken as reported (uncalibrated)."""
@@ -45,13 +45,13 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     write = 1024.0 * sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"]) / steps
     lines.append("  => HBM traffic per generation step (all 8 streams): %.0f B read (FETCH_SIZE KiB x 2, gfx950 correction) + %.0f B written" % (fetch, write))
     import twvk_amd
-    h = twvk_amd._lib.source_hash()
+    h = twvk_amd._lib.generation_hash()
     p = os.path.join(ROOT, "profiles", "traffic.json")
     t = json.load(open(p)) if os.path.exists(p) else {}
     kname = "wn_xcd_generate_kernel" if "xcd" in vals["_name"] else "wn_generate_kernel"
-    t.setdefault(h, {}).setdefault(kname, {})["B8_NL30"] = {"fetch_bytes_per_step": fetch, "write_bytes_per_step": write, "profile": "profiles/%s_rocprofv3_generation_summary.txt" % tag}
+    t.setdefault(h, {}).setdefault(kname, {})["B8_NL30"] = {"fetch_bytes_per_step": fetch, "write_bytes_per_step": write, "profile": "profiles/r02_rocprofv3_generation_summary_%s.txt" % tag}
     json.dump(t, open(p, "w"), indent=1, sort_keys=True)
-    lines.append("  (profiles/traffic.json updated for library source hash %s)" % h)
+    lines.append("  (profiles/traffic.json updated for generation-kernel source hash %s)" % h)
 if "SQ_WAVE_CYCLES" in vals:
     wc = sum(vals["SQ_WAVE_CYCLES"]) / len(vals["SQ_WAVE_CYCLES"])
     for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):

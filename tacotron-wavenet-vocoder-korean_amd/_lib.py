@@ -23,19 +23,32 @@ class Dims(C.Structure):
                 ("lc_channels", C.c_int32), ("n_upsample", C.c_int32), ("upsample_factor", C.c_int32 * 4)]
 
 
-def source_hash():
-    """sha256 over the library's sources (csrc/, include/twv_amd.h) and the compile flags: what the binary is stamped with
-    (twv_version() ends in it) and what decides whether a build is stale."""
+GENERATION_SOURCES = ("twv_wavenet.hip", "twv_wavenet_xcd.hip", "twv_xcd.hpp", "twv_dpp.hpp", "twv_dev.hpp", "twv_math.hpp", "twv_layout.hpp")
+
+
+def _hash_files(files):
     import hashlib
     h = hashlib.sha256()
-    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h"))]
-    files.append(os.path.join(_HERE, "..", "include", "twv_amd.h"))
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(HIPCC_FLAGS).encode())
     return h.hexdigest()[:16]
+
+
+def source_hash():
+    """sha256 over the library's sources (csrc/, include/twv_amd.h) and the compile flags: what the binary is stamped with
+    (twv_version() ends in it) and what decides whether a build is stale."""
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h"))]
+    files.append(os.path.join(_HERE, "..", "include", "twv_amd.h"))
+    return _hash_files(files)
+
+
+def generation_hash():
+    """sha256 over the sources the two generation kernels are compiled from (and the flags): the key of profiles/traffic.json --
+    counter measurements of the generation kernel stay valid while only the Tacotron / training sources change."""
+    return _hash_files([os.path.join(CSRC, f) for f in GENERATION_SOURCES])
 
 
 def build(force=False, verbose=False):
