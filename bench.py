@@ -256,7 +256,7 @@ def main():
                                    "MoL-30 output, gc+lc conditioning, 24 kHz, batch=%d x %.2f s (%d samples each) per GPU, random-init weights, "
                                    "injected uniforms" % (B, T / hp.sample_rate, T),
                        "batch_per_gpu": B, "samples_per_utterance": T, "sharding": "utterances, one batch of %d per GPU, no collective" % B,
-                       "kernel": kernel + (" (one stream per XCD, weights register-resident, create_upsample + lc projections fused into the launch)" if fused else "")},
+                       "kernel": kernel + (" (stream b on XCD b % 8, weights register-resident, create_upsample + lc projections fused into the launch)" if fused else "")},
             "realtime_factor_aggregate": value / hp.sample_rate,
             "realtime_factor_per_stream": value / hp.sample_rate / (n_ok * B),
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

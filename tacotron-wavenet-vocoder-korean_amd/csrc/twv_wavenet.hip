@@ -1456,7 +1456,7 @@ static int device_cus()
 }
 // workgroups per stream: explicit option, else the largest of 8/4/2/1 that divides the output blocks and keeps every
 // workgroup of the launch co-resident (one workgroup per CU: the LDS slot ring takes most of the 160 KiB)
-// the XCD-per-stream kernel: one stream per XCD (8 x 32 CUs), explicit `groups` keeps the generic kernel
+// the XCD-per-stream kernel: stream b on XCD b % 8 (8 x 32 CUs; up to four streams per XCD), explicit `groups` keeps the generic kernel
 static bool use_xcd(const twv_wavenet* h, int batch)
 {
     return h->xcd != 0 && h->groups == 0 && h->lay.off_xl != 0 && batch >= 1 && batch <= kXcdStreams && device_cus() >= 256;
@@ -1771,7 +1771,7 @@ static int generate_impl(const twv_wavenet* h, const void* packed, void* state, 
     a.prof = h->prof; a.prof_steps = h->prof ? h->prof_steps : 0;
     a.B = batch; a.T = n_steps; a.temperature = (float)temperature; a.lay = L;
     if (use_xcd(h, batch)) {
-        // one stream per XCD, every weight register-resident across the XCD's CUs (twv_wavenet_xcd.hip)
+        // stream b on XCD b % 8, every weight register-resident across the XCD's CUs (twv_wavenet_xcd.hip)
         XcdLaunch x;
         x.P = a.P; x.state = a.state; x.cond = a.cond; x.first_input = first_input; x.forced = forced;
         x.uniforms = (const float*)uniforms; x.out = (float*)out; x.status = status; x.dbg = debug; x.dbg_steps = a.dbg_steps;

@@ -2,20 +2,23 @@
 // vector registers per XCD).
 //
 // Replaces, for the hparams-default MoL vocoder (wavenet/model.py:41-167,215-245, wavenet/mixture.py:84-114, generate.py:199-233;
-// scalar input, initial_filter_width 32, R = D = 32, S = 512, out_channels <= 32, up to 31 layers, batch <= 8):
+// scalar input, initial_filter_width 32, R = D = 32, S = 512, out_channels <= 32, up to 30 layers, batch <= 32):
 // the same per-sample chain as wn_generate_kernel (twv_wavenet.hip), but laid out for the chip instead of for one CU:
 //
-//   * ONE STREAM PER XCD.  Every workgroup reads its XCC id and takes a role ticket of that XCD, so all workgroups of a stream
+//   * A STREAM LIVES ON ONE XCD (stream b on XCD b % 8).  Every workgroup reads its XCC id and takes a role ticket of that XCD, so all workgroups of a stream
 //     share one L2: a hand-off is a PLAIN 8-byte store {tag, value} (the line stays in the XCD's L2) polled with sc1 loads
 //     (bypass the reader's L1): 273 ns one way instead of the 590 ns of the agent-scope (write-through + memory-side) form
 //     (profiles/r02_xcd_chain_ubench.txt).
 //   * EVERY WEIGHT IS REGISTER-RESIDENT for the whole launch, spread over the XCD's CUs: nothing is re-streamed per step.
-//       chain workgroup   (1): 8 waves x 4 layers: tap-1 conv kernel + dense kernel of a layer = 48 VGPRs per lane
-//       service workgroup (1): tap-0 conv kernels, the delay lines (model.py:49-64 queues; in the stream's state buffer)
-//       skip workgroups   (8): slice g of the 30 skip kernels (model.py:94-96)
-//       conv1 workgroups  (8): slice g of conv1d_1 and its two chunks of conv1d_2 (model.py:158-165)
-//       lc workgroups   (2-4): create_upsample + lc_filter/lc_gate projections (model.py:102-111,75-83), running ahead of
+//       chain workgroup   (1 per stream): 8 waves x 4 layers: tap-1 conv kernel + dense kernel of a layer = 48 VGPRs per lane
+//       service workgroup (1 per stream): tap-0 conv kernels, the delay lines (model.py:49-64 queues; in the stream's state buffer)
+//       skip workgroups   (8 per XCD): slice g of the 30 skip kernels (model.py:94-96)
+//       conv1 workgroups  (8 per XCD): slice g of conv1d_1 and its two chunks of conv1d_2 (model.py:158-165)
+//       lc workgroups   (2-4 per XCD): create_upsample + lc_filter/lc_gate projections (model.py:102-111,75-83), running ahead of
 //                              the chain through a ring: neither the upsampled condition nor a projection table exists in HBM
+//     The skip / conv1 / lc workgroups hold weights only, so with more than 8 streams ONE set per XCD serves the XCD's streams in
+//     turn (2 ns + 16 + n_lc <= 28 of the 32 CUs for ns = 4): the streams settle a fraction of a microsecond apart, B = 16 keeps
+//     the single-stream step time (10.6 us), B = 32 runs at 12.9 us (2.5 M samples/s).
 //   * THE CHAIN IS A RELAY OF EIGHT WAVES.  A layer is 32 v_fmac_f32_dpp (row_newbcast feeds x[k] to the fma: no v_readlane,
 //     no LDS operand reads) -> bias/conditioning adds -> rational tanh/sigmoid -> v_permlane32_swap -> 16 v_fmac_f32_dpp +
 //     v_permlane16_swap for the dense 1x1 (twv_dpp.hpp): 203 ns per layer against 654 ns in wn_generate_kernel.  A wave hands
@@ -120,12 +123,20 @@ struct ChainRegs { float wc[32]; float bfg, gcv, bd; };
 // where a wave is (instrumented build only): read back from the exchange area after a watchdog abort
 #define XMARK(role_, stage_) do { if ((INSTR & 1) && lane == 0) xb_store(rs, (int)XcdExch::MARK + (role_) * 8 + (int)(threadIdx.x >> 6), 0, (unsigned)t + 1u, (float)(stage_)); } while (0)
 
-enum { ROLE_CHAIN = 0, ROLE_SERVICE = 1, ROLE_SKIP0 = 2, ROLE_CONV0 = 10, ROLE_LC0 = 18 };
+enum { ROLE_CHAIN = 0, ROLE_SERVICE = 1, ROLE_SKIP0 = 2, ROLE_CONV0 = 10, ROLE_LC0 = 18 };     // slots of the stage markers (XMARK)
+constexpr int kXcdStreamsPerXcd = kXcdStreams / 8;
 
 struct XArgs {
     XcdLaunch p;
-    int n_lc_wg, lc_lpw;      // lc workgroups per stream, layers per lc wave
+    int n_lc_wg, lc_lpw;      // lc workgroups per XCD, layers per lc wave
 };
+
+// the streams of one XCD (stream b runs on XCD b % 8): each has its own chain and service workgroup; the skip, conv1 and lc
+// workgroups hold weights only, so ONE set per XCD serves them all, stream after stream in a fixed order -- the streams settle a
+// fraction of a microsecond apart and every one keeps the single-stream step time
+template <int NS> struct XStreams { rsrc_t rs[NS]; int b[NS]; };
+constexpr int kSkipLdsWords = 32 * 64;       // 8-byte LDS words per stream in a skip workgroup
+constexpr int kConvLdsFloats = 16 * 64 + 64; // LDS floats per stream in a conv1 workgroup
 
 // =====================================================================================================================
 //  CHAIN workgroup: model.py:41-46 causal layer (wave 0), model.py:66-101 residual layers (relay over the waves),
@@ -500,15 +511,15 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
 //  SKIP workgroup g: model.py:94-96 skip 1x1 of every layer for output block g, model.py:154 sum over the layers in layer
 //  order, model.py:157 relu.  Wave v owns layers v, v+8, ...; the wave that owns the last layer adds the values up as they appear.
 // =====================================================================================================================
-template <int INSTR>
-__device__ __forceinline__ void skip_role(const XArgs& xa, int b, int g, rsrc_t rs)
+template <int INSTR, int NS>
+__device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& sx, int g)
 {
     const XcdLaunch& a = xa.p;
     const Layout& L = a.lay;
     const int v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int NL = L.NL, T = a.T;
     const bool use_bias = L.use_bias != 0;
-    Poll pl{rs, a.status, 0, false};
+    Poll pl{sx.rs[0], a.status, 0, false};
     int nown = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) if (v + 8 * i < NL) nown = i + 1;
@@ -527,71 +538,88 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, int b, int g, rsrc_t 
     const bool summer = v == ((NL - 1) & 7);
     const int n16 = lane & 15;
     const int zc_lane = lane_of_z((lane < 32 ? 0 : 16) + n16);
-    unsigned long long seen[4] = {0, 0, 0, 0}, period = 0;       // arrival times of the own layers in the previous step
+    unsigned long long seen[4] = {0, 0, 0, 0}, period = 0;       // arrival times of the own layers (first stream) in the previous step
     for (int t = 0; t < T && !pl.dead; ++t) {
         const unsigned tag = (unsigned)t + 1u;
-        int nextl = 0;
-        float tot = 0.0f;
+        int nextl[NS];
+        float tot[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { nextl[k] = 0; tot[k] = 0.0f; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < nown && !pl.dead) {
                 const int l = v + 8 * i;
-                // model.py:154 sum(outputs), in layer order: the values of layers nextl .. l-1 come from the other waves through LDS
-                auto drain = [&](bool blocking) {
-                    for (; nextl < l && !pl.dead; ++nextl) {
-                        unsigned long long q;
-                        pl.it = 0;
-                        for (;;) {
-                            q = LDSU64(nextl * 64 + lane);
-                            if (__all(g_tag(q) == tag)) break;
-                            if (!blocking) return;
-                            if (!poll_tick(pl, 52)) return;
-                        }
-                        tot = (nextl == 0) ? g_val(q) : tot + g_val(q);
-                    }
-                };
                 if (!summer && period) nap_until(seen[i] + period - (period >> 3));
-                XMARK(ROLE_SKIP0 + g, 10 + i);
-                // ONE load per round (every load of a polling round adds to its round trip): lanes 0-31 fetch z[0..15] twice, lanes
-                // 32-63 z[16..31] twice; v_permlane32_swap makes the two dot operands of it
-                unsigned long long qz;
-                pl.it = 0;
-                for (;;) {
-                    qz = xb_load(rs, (int)XcdExch::ZX + l * 128, zc_lane * 2);
-                    if (summer) drain(false);                          // while the load is in flight: add what has arrived
-                    if (__all(g_tag(qz) == tag)) break;
-                    if (!poll_tick(pl, 51)) break;
-                    if (!summer) __builtin_amdgcn_s_sleep(1);
-                }
-                if ((INSTR & 1) && pl.dead && g == 0 && lane == 0) {   // bring-up: what the abandoned poll last saw
-                    xb_store(rs, (int)XcdExch::MARK + 176 + v * 4, 0, g_tag(qz), __uint_as_float(g_tag(qz)));
-                    xb_store(rs, (int)XcdExch::MARK + 177 + v * 4, 0, (unsigned)l, __uint_as_float((unsigned)pl.it));
-                    xb_store(rs, (int)XcdExch::MARK + 178 + v * 4, 0, tag, __uint_as_float((unsigned)i));
-                }
-                if (pl.dead) break;
-                if (!summer) {
-                    const unsigned long long now = __builtin_amdgcn_s_memtime();
-                    if (i == 0) { const unsigned long long d = now - seen[0]; period = (seen[0] != 0 && d < (1ull << 18)) ? d : 0; }
-                    seen[i] = now;
-                }
-                XSTAMP(g == 0 && summer && l == NL - 1, 20);
-                const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)qz, (unsigned)qz, false, false);   // [lo, lo], [hi, hi]
-                float val = dot32_dpp(ws[i].w, __uint_as_float(sw[0]), __uint_as_float(sw[1]));              // model.py:96
-                if (use_bias) val = val + bs[i];
-                if (!summer) {
-                    LDSU64(l * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(val);
-                } else {
-                    drain(true);                                       // whatever is still missing below this layer
-                    tot = (l == 0) ? val : tot + val;
-                    nextl = l + 1;
+                // the XCD's streams in a fixed order (they settle a fraction of a microsecond apart).  Measured alternatives: polling all
+                // the streams still missing in one round and serving whichever arrived (every extra load of a polling round adds to
+                // its round trip: B = 32 ran at 16.5 instead of 13 us/step); requesting the next stream's granules while this stream's
+                // dot runs (17 us/step).
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    if (pl.dead) break;
+                    const rsrc_t rs = sx.rs[k];
+                    const int b = sx.b[k];
+                    pl.rs = rs;
+                    // model.py:154 sum(outputs), in layer order: the values of layers nextl .. l-1 come from the other waves through LDS
+                    auto drain = [&](bool blocking) {
+                        for (; nextl[k] < l && !pl.dead; ++nextl[k]) {
+                            unsigned long long q;
+                            pl.it = 0;
+                            for (;;) {
+                                q = LDSU64(k * kSkipLdsWords + nextl[k] * 64 + lane);
+                                if (__all(g_tag(q) == tag)) break;
+                                if (!blocking) return;
+                                if (!poll_tick(pl, 52)) return;
+                            }
+                            tot[k] = (nextl[k] == 0) ? g_val(q) : tot[k] + g_val(q);
+                        }
+                    };
+                    XMARK(ROLE_SKIP0 + g, 10 + i);
+                    // ONE load per round (every load of a polling round adds to its round trip): lanes 0-31 fetch z[0..15] twice, lanes
+                    // 32-63 z[16..31] twice; v_permlane32_swap makes the two dot operands of it
+                    unsigned long long qz;
+                    pl.it = 0;
+                    for (;;) {
+                        qz = xb_load(rs, (int)XcdExch::ZX + l * 128, zc_lane * 2);
+                        if (summer) drain(false);                          // while the load is in flight: add what has arrived
+                        if (__all(g_tag(qz) == tag)) break;
+                        if (!poll_tick(pl, 51)) break;
+                        if (!summer) __builtin_amdgcn_s_sleep(1);
+                    }
+                    if ((INSTR & 1) && pl.dead && g == 0 && lane == 0) {   // bring-up: what the abandoned poll last saw
+                        xb_store(rs, (int)XcdExch::MARK + 176 + v * 4, 0, g_tag(qz), __uint_as_float(g_tag(qz)));
+                        xb_store(rs, (int)XcdExch::MARK + 177 + v * 4, 0, (unsigned)l, __uint_as_float((unsigned)pl.it));
+                        xb_store(rs, (int)XcdExch::MARK + 178 + v * 4, 0, tag, __uint_as_float((unsigned)i));
+                    }
+                    if (pl.dead) break;
+                    if (!summer && k == 0) {
+                        const unsigned long long now = __builtin_amdgcn_s_memtime();
+                        if (i == 0) { const unsigned long long d = now - seen[0]; period = (seen[0] != 0 && d < (1ull << 18)) ? d : 0; }
+                        seen[i] = now;
+                    }
+                    XSTAMP(g == 0 && summer && l == NL - 1, 20);
+                    const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)qz, (unsigned)qz, false, false);   // [lo, lo], [hi, hi]
+                    float val = dot32_dpp(ws[i].w, __uint_as_float(sw[0]), __uint_as_float(sw[1]));              // model.py:96
+                    if (use_bias) val = val + bs[i];
+                    if (!summer) {
+                        LDSU64(k * kSkipLdsWords + l * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(val);
+                    } else {
+                        drain(true);                                       // whatever is still missing below this layer
+                        tot[k] = (l == 0) ? val : tot[k] + val;
+                        nextl[k] = l + 1;
+                        if (l == NL - 1 && !pl.dead) {                     // this stream's sum is complete: out it goes before the next stream's turn
+                            const float h = tot[k] > 0.0f ? tot[k] : 0.0f;                       // model.py:157
+                            xb_store(rs, (int)XcdExch::H1 + g * 64, lane, tag, h);
+                            XSTAMP(g == 0, 21);
+                        }
+                    }
                 }
             }
         }
-        if (summer && !pl.dead) {
-            const float h = tot > 0.0f ? tot : 0.0f;                                   // model.py:157
-            xb_store(rs, (int)XcdExch::H1 + g * 64, lane, tag, h);
-            XSTAMP(g == 0, 21);
-        }
+    }
+    if (pl.dead && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) xb_store(sx.rs[k], (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);      // a watchdog on one stream stops them all
     }
 }
 
@@ -599,17 +627,17 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, int b, int g, rsrc_t 
 //  CONV1 workgroup g: model.py:158-160 conv1d_1 + relu for output block g (16 chunk tiles over the 8 waves), then the two
 //  chunks (2g, 2g+1) of model.py:161-165 conv1d_2 that read this block: what travels on is conv1d_2's partial table.
 // =====================================================================================================================
-template <int INSTR>
-__device__ __forceinline__ void conv1_role(const XArgs& xa, int b, int g, rsrc_t rs)
+template <int INSTR, int NS>
+__device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& sx, int g)
 {
     const XcdLaunch& a = xa.p;
     const Layout& L = a.lay;
     const int v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int T = a.T, NCH = L.NCH;
     const bool use_bias = L.use_bias != 0;
-    Poll pl{rs, a.status, 0, false};
-    constexpr int O_PART = 0, O_CNT = 16 * 64, O_ABORT = O_CNT + 1;      // LDS floats: chunk partials | arrival counter | abort
-    if (threadIdx.x == 0) { LDSI(O_CNT) = 0; LDSI(O_ABORT) = 0; }
+    Poll pl{sx.rs[0], a.status, 0, false};
+    constexpr int O_PART = 0, O_CNT = 16 * 64, O_ABORT = O_CNT + 1;      // LDS floats per stream: chunk partials | arrival counter | abort
+    if (threadIdx.x < NS) { LDSI(threadIdx.x * kConvLdsFloats + O_CNT) = 0; LDSI(threadIdx.x * kConvLdsFloats + O_ABORT) = 0; }
     __syncthreads();
     const int c0 = 2 * v, c1 = 2 * v + 1;                                 // this wave's chunks
     Tile ta, tb;
@@ -626,67 +654,78 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, int b, int g, rsrc_t
     for (int t = 0; t < T && !pl.dead; ++t) {
         const unsigned tag = (unsigned)t + 1u;
         if (period) nap_until(t_arr + period - (period >> 3));
-        XMARK(ROLE_CONV0 + g, 1);
-        // this wave's two chunks are exactly the 64 values skip workgroup v publishes: ONE granule per lane
-        unsigned long long q;
-        pl.it = 0;
-        for (;;) {
-            q = xb_load(rs, (int)XcdExch::H1 + v * 64, lane);
-            if (__all(g_tag(q) == tag)) break;
-            if (!poll_tick(pl, 61)) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (pl.dead) break;
-        {
-            const unsigned long long now = __builtin_amdgcn_s_memtime();
-            const unsigned long long d = now - t_arr;
-            period = (t_arr != 0 && d < (1ull << 18)) ? d : 0;
-            t_arr = now;
-        }
-        XSTAMP(g == 0 && v == 0, 22);
-        // rows r0..r3 of the wave = h1[64v + 16r ..]; the dots want "every row r0" / "every row r1" (chunk c0) and r2 / r3 (chunk c1)
-        const unsigned hq = (unsigned)q;
-        const auto p16 = __builtin_amdgcn_permlane16_swap(hq, hq, false, false);        // [r0,r0,r2,r2], [r1,r1,r3,r3]
-        const auto pa = __builtin_amdgcn_permlane32_swap(p16[0], p16[0], false, false);  // [r0 x4], [r2 x4]
-        const auto pb = __builtin_amdgcn_permlane32_swap(p16[1], p16[1], false, false);  // [r1 x4], [r3 x4]
-        float r0, r1;
-        dot32_dpp_x2(ta.w, __uint_as_float(pa[0]), __uint_as_float(pb[0]), tb.w, __uint_as_float(pa[1]), __uint_as_float(pb[1]), r0, r1);
-        lds[O_PART + c0 * 64 + lane] = r0;
-        lds[O_PART + c1 * 64 + lane] = r1;
-        asm volatile("" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(&LDSI(O_CNT), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        XSTAMP(g == 0 && v == 0, 23);
-        XMARK(ROLE_CONV0 + g, 2);
-        if (summer) {
-            pl.it = 0;
-            while (LDSVI(O_CNT) < 8 * (t + 1)) { if (!poll_tick(pl, 62)) break; }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
             if (pl.dead) break;
+            const rsrc_t rs = sx.rs[k];
+            const int b = sx.b[k];
+            const int ob = k * kConvLdsFloats;
+            pl.rs = rs;
+            XMARK(ROLE_CONV0 + g, 1);
+            // this wave's two chunks are exactly the 64 values skip workgroup v publishes: ONE granule per lane
+            unsigned long long q;
+            pl.it = 0;
+            for (;;) {
+                q = xb_load(rs, (int)XcdExch::H1 + v * 64, lane);
+                if (__all(g_tag(q) == tag)) break;
+                if (!poll_tick(pl, 61)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (pl.dead) break;
+            if (k == 0) {
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                const unsigned long long d = now - t_arr;
+                period = (t_arr != 0 && d < (1ull << 18)) ? d : 0;
+                t_arr = now;
+            }
+            XSTAMP(g == 0 && v == 0, 22);
+            // rows r0..r3 of the wave = h1[64v + 16r ..]; the dots want "every row r0" / "every row r1" (chunk c0) and r2 / r3 (chunk c1)
+            const unsigned hq = (unsigned)q;
+            const auto p16 = __builtin_amdgcn_permlane16_swap(hq, hq, false, false);        // [r0,r0,r2,r2], [r1,r1,r3,r3]
+            const auto pa = __builtin_amdgcn_permlane32_swap(p16[0], p16[0], false, false);  // [r0 x4], [r2 x4]
+            const auto pb = __builtin_amdgcn_permlane32_swap(p16[1], p16[1], false, false);  // [r1 x4], [r3 x4]
+            float r0, r1;
+            dot32_dpp_x2(ta.w, __uint_as_float(pa[0]), __uint_as_float(pb[0]), tb.w, __uint_as_float(pa[1]), __uint_as_float(pb[1]), r0, r1);
+            lds[ob + O_PART + c0 * 64 + lane] = r0;
+            lds[ob + O_PART + c1 * 64 + lane] = r1;
             asm volatile("" ::: "memory");
-            XSTAMP(g == 0 && v == 0, 24);
-            float cp[16];
+            if (lane == 0) __hip_atomic_fetch_add(&LDSI(ob + O_CNT), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            XSTAMP(g == 0 && v == 0, 23);
+            XMARK(ROLE_CONV0 + g, 2);
+            if (summer) {
+                pl.it = 0;
+                while (LDSVI(ob + O_CNT) < 8 * (t + 1)) { if (!poll_tick(pl, 62)) break; }
+                if (pl.dead) break;
+                asm volatile("" ::: "memory");
+                XSTAMP(g == 0 && v == 0, 24);
+                float cp[16];
 #pragma unroll
-            for (int ch = 0; ch < 16; ++ch) cp[ch] = lds[O_PART + ch * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);
-            float r = cp[0];                                            // AC-1: chunk values added in chunk order
+                for (int ch = 0; ch < 16; ++ch) cp[ch] = lds[ob + O_PART + ch * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+                float r = cp[0];                                            // AC-1: chunk values added in chunk order
 #pragma unroll
-            for (int ch = 1; ch < 16; ++ch) r = r + cp[ch];
-            if (use_bias) r = r + b1v;
-            const float h = r > 0.0f ? r : 0.0f;                         // model.py:160
-            // conv1d_2 chunk 2g+v reads h[32v .. 32v+31] of this block
-            const float p = (v == 0) ? dot_readlane_pipe(t2, h) : dot_readlane_pipe32(t2, h);
-            if (lane < 32) xb_store(rs, (int)XcdExch::PT, (g * 32 + lane) * 2 + v, tag, p);     // chunk 2g+v of output `lane`, next to its pair
-            XSTAMP(g == 0 && v == 0, 25);
+                for (int ch = 1; ch < 16; ++ch) r = r + cp[ch];
+                if (use_bias) r = r + b1v;
+                const float h = r > 0.0f ? r : 0.0f;                         // model.py:160
+                // conv1d_2 chunk 2g+v reads h[32v .. 32v+31] of this block
+                const float p = (v == 0) ? dot_readlane_pipe(t2, h) : dot_readlane_pipe32(t2, h);
+                if (lane < 32) xb_store(rs, (int)XcdExch::PT, (g * 32 + lane) * 2 + v, tag, p);     // chunk 2g+v of output `lane`, next to its pair
+                XSTAMP(g == 0 && v == 0, 25);
+            }
         }
     }
-    if (pl.dead && lane == 0) LDSI(O_ABORT) = 1;
+    if (pl.dead && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { LDSI(k * kConvLdsFloats + O_ABORT) = 1; xb_store(sx.rs[k], (int)XcdExch::CTRL + 1, 0, 1u, 0.0f); }
+    }
 }
 
 // =====================================================================================================================
 //  LC workgroups: model.py:102-111 create_upsample (row by row) and model.py:75-83 lc_filter|lc_gate of every layer,
 //  ahead of the chain through the ring XcdExch::LCR.  Wave gw owns layers gw*lpw .. gw*lpw+lpw-1 (NLC tiles each).
 // =====================================================================================================================
-template <int INSTR>
-__device__ __forceinline__ void lc_role(const XArgs& xa, int b, int wg, rsrc_t rs)
+template <int INSTR, int NS>
+__device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx, int wg)
 {
     const XcdLaunch& a = xa.p;
     const Layout& L = a.lay;
@@ -697,8 +736,7 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, int b, int wg, rsrc_t r
     int nown = NL - lfirst;
     nown = nown < 0 ? 0 : (nown > lpw ? lpw : nown);
     if (nown == 0) return;
-    Poll pl{rs, a.status, 0, false};
-    float* stb = a.state + (long long)b * L.state_stride;
+    Poll pl{sx.rs[0], a.status, 0, false};
     const int* hdr = reinterpret_cast<const int*>(a.cond);
     const int mode = hdr[XH_MODE], rows = hdr[XH_ROWS];
     const float* payload = a.cond + XH_WORDS + (long long)a.B * NL * 64;
@@ -720,49 +758,104 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, int b, int wg, rsrc_t r
     for (int i = 0; i < n_up; ++i) hop *= L.up[i];
     const long long need_rows = (mode == XLC_MEL) ? ((long long)T + hop - 1) / hop : T;
     if (rows < need_rows) {
-        if (lane == 0) { atomicMax(a.status, 71); xb_store(rs, (int)XcdExch::CTRL + 1, 0, 1u, 0.0f); }
+        if (lane == 0) {
+            atomicMax(a.status, 71);
+#pragma unroll
+            for (int k = 0; k < NS; ++k) xb_store(sx.rs[k], (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);
+        }
         return;
     }
     for (int u = 0; u < T && !pl.dead; ++u) {
         const int t = u;
-        XMARK(ROLE_LC0 + wg, 1);
-        // ---- throttle: slot (u+1) % ring is free once the chain has started step u + 2 - ring
+        // ---- what does not depend on the stream: the taps of this row's phase (model.py:102-111)
+        float k0[4] = {0.f, 0.f, 0.f, 0.f}, k1[4] = {0.f, 0.f, 0.f, 0.f};
+        if (mode != XLC_UPSAMPLED) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < n_up) { k0[i] = a.P[L.off_up[i] + ph[i] * 2 + 0]; k1[i] = a.P[L.off_up[i] + ph[i] * 2 + 1]; }
+        }
+        // ---- throttle: slot (u+1) % ring is free once the chain has started step u + 2 - ring (every stream of the XCD)
         if (u + 3 - kXcdLcRing > 0) {
-            pl.it = 0;
-            for (;;) {
-                const unsigned long long q = xb_load(rs, (int)XcdExch::CTRL, 0);
-                if ((int)g_tag(q) >= u + 3 - kXcdLcRing) break;
-                if (!poll_tick(pl, 72)) break;
-                __builtin_amdgcn_s_sleep(16);
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                if (pl.dead) break;
+                const rsrc_t rs = sx.rs[k];
+                pl.rs = rs;
+                XMARK(ROLE_LC0 + wg, 1);
+                pl.it = 0;
+                for (;;) {
+                    const unsigned long long q = xb_load(rs, (int)XcdExch::CTRL, 0);
+                    if ((int)g_tag(q) >= u + 3 - kXcdLcRing) break;
+                    if (!poll_tick(pl, 72)) break;
+                    __builtin_amdgcn_s_sleep(16);
+                }
             }
             if (pl.dead) break;
         }
-        // ---- row u of the upsampled condition into LDS (zero padded to NLC*32)
-        int o_cur = o_row;
-        if (mode == XLC_UPSAMPLED) {
-            const float* src = payload + ((long long)b * rows + u) * Lc;
-            lds[o_cur + lane] = lane < Lc ? src[lane] : 0.0f;
-            lds[o_cur + 64 + lane] = 64 + lane < Lc ? src[64 + lane] : 0.0f;
-        } else {
-            const float* src = payload + ((long long)b * rows + frame) * Lc;
-            lds[o_cur + lane] = lane < Lc ? src[lane] : 0.0f;
-            lds[o_cur + 64 + lane] = 64 + lane < Lc ? src[64 + lane] : 0.0f;
-            for (int i = 0; i < n_up; ++i) {
-                // out[m] = K[a][0]*in[m] + K[a][1]*in[m-1]   as a two-term AC-1 chunk   (model.py:102-111, 'same' transposed conv)
-                const float k0 = a.P[L.off_up[i] + ph[i] * 2 + 0], k1 = a.P[L.off_up[i] + ph[i] * 2 + 1];
-                const int o_nxt = (o_cur == o_row) ? o_row + 128 : o_row;
+        // ---- the streams' input rows, all requested before the first is used
+        float rowa[NS], rowb[NS];
 #pragma unroll
-                for (int hlf = 0; hlf < 2; ++hlf) {
-                    const int m = hlf * 64 + lane;
-                    const float x0 = lds[o_cur + m];
-                    const float x1 = m > 0 ? lds[o_cur + m - 1] : 0.0f;
-                    const float s0 = fma_(k0, x0, 0.0f);
-                    const float s1 = fma_(k1, x1, 0.0f);
-                    const float r = (s0 + s1) + (0.0f + 0.0f);
-                    lds[o_nxt + m] = m < Lc ? r : 0.0f;
+        for (int k = 0; k < NS; ++k) {
+            const float* src = payload + ((long long)sx.b[k] * rows + (mode == XLC_UPSAMPLED ? u : frame)) * Lc;
+            rowa[k] = lane < Lc ? src[lane] : 0.0f;
+            rowb[k] = 64 + lane < Lc ? src[64 + lane] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const rsrc_t rs = sx.rs[k];
+            const int b = sx.b[k];
+            // ---- row u of the upsampled condition into LDS (zero padded to NLC*32)
+            int o_cur = o_row;
+            lds[o_cur + lane] = rowa[k];
+            lds[o_cur + 64 + lane] = rowb[k];
+            if (mode != XLC_UPSAMPLED) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < n_up) {
+                        // out[m] = K[a][0]*in[m] + K[a][1]*in[m-1]   as a two-term AC-1 chunk   (model.py:102-111, 'same' transposed conv)
+                        const int o_nxt = (o_cur == o_row) ? o_row + 128 : o_row;
+#pragma unroll
+                        for (int hlf = 0; hlf < 2; ++hlf) {
+                            const int m = hlf * 64 + lane;
+                            const float x0 = lds[o_cur + m];
+                            const float x1 = m > 0 ? lds[o_cur + m - 1] : 0.0f;
+                            const float s0 = fma_(k0[i], x0, 0.0f);
+                            const float s1 = fma_(k1[i], x1, 0.0f);
+                            const float r = (s0 + s1) + (0.0f + 0.0f);
+                            lds[o_nxt + m] = m < Lc ? r : 0.0f;
+                        }
+                        o_cur = o_nxt;
+                    }
                 }
-                o_cur = o_nxt;
             }
+            // ---- projections: AC-1 chunks of 32 over the lc channels, chunk values added in order
+            float resx[4];
+#pragma unroll
+            for (int idx = 0; idx < 4; ++idx) {
+                resx[idx] = 0.0f;
+                if (idx < nown * NLC) {
+                    const int j = idx / NLC, c = idx - j * NLC;
+                    const float xa_ = lds[o_cur + c * 32 + n16], xb_ = lds[o_cur + c * 32 + 16 + n16];
+                    resx[idx] = dot32_dpp(lt[idx].w, xa_, xb_);
+                    (void)j;
+                }
+            }
+            // combine per layer in chunk order (indices are compile-time; j, c are uniform)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < nown) {
+                    float r = 0.0f;
+#pragma unroll
+                    for (int idx = 0; idx < 4; ++idx) {
+                        if (idx >= j * NLC && idx < (j + 1) * NLC) r = (idx == j * NLC) ? resx[idx] : r + resx[idx];
+                    }
+                    const int l = lfirst + j;
+                    if (u + 1 < T) xb_store(rs, (int)XcdExch::LCR + (((u + 1) % kXcdLcRing) * 32 + l) * 64, lane, (unsigned)u + 2u, r);
+                    else (a.state + (long long)b * L.state_stride)[L.st_lcprev + l * 64 + lane] = r;    // the frame the NEXT call uses at its step 0
+                }
+            }
+        }
+        if (mode != XLC_UPSAMPLED) {
             // advance the phase counter (last stage fastest)
             int carry = 1;
             for (int i = n_up - 1; i >= 0; --i) {
@@ -770,32 +863,10 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, int b, int wg, rsrc_t r
             }
             frame += carry;
         }
-        // ---- projections: AC-1 chunks of 32 over the lc channels, chunk values added in order
-        float resx[4];
+    }
+    if (pl.dead && lane == 0) {
 #pragma unroll
-        for (int idx = 0; idx < 4; ++idx) {
-            resx[idx] = 0.0f;
-            if (idx < nown * NLC) {
-                const int j = idx / NLC, c = idx - j * NLC;
-                const float xa_ = lds[o_cur + c * 32 + n16], xb_ = lds[o_cur + c * 32 + 16 + n16];
-                resx[idx] = dot32_dpp(lt[idx].w, xa_, xb_);
-                (void)j;
-            }
-        }
-        // combine per layer in chunk order (indices are compile-time; j, c are uniform)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (j < nown) {
-                float r = 0.0f;
-#pragma unroll
-                for (int idx = 0; idx < 4; ++idx) {
-                    if (idx >= j * NLC && idx < (j + 1) * NLC) r = (idx == j * NLC) ? resx[idx] : r + resx[idx];
-                }
-                const int l = lfirst + j;
-                if (u + 1 < T) xb_store(rs, (int)XcdExch::LCR + (((u + 1) % kXcdLcRing) * 32 + l) * 64, lane, (unsigned)u + 2u, r);
-                else stb[L.st_lcprev + l * 64 + lane] = r;             // the frame the NEXT call uses at its step 0
-            }
-        }
+        for (int k = 0; k < NS; ++k) xb_store(sx.rs[k], (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);
     }
 }
 
@@ -813,22 +884,39 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
     __shared__ int s_ticket;
     if (threadIdx.x == 0) s_ticket = ticket;
     // LDS hand-off words start at zero
-    for (int i = threadIdx.x; i < 32 * 64 * 2 + 64; i += blockDim.x) lds[i] = 0.0f;
+    for (int i = threadIdx.x; i < kXcdStreamsPerXcd * kSkipLdsWords * 2 + 64; i += blockDim.x) lds[i] = 0.0f;
     __syncthreads();
     ticket = s_ticket;
-    const int b = (int)xcc;
-    if (ticket >= ROLE_LC0 + xa.n_lc_wg) return;                 // surplus workgroup (or an XCD without a stream)
-    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.exch + (long long)b * XcdExch::WORDS, 0, (int)(XcdExch::WORDS * 8), 0x00020000);
+    // roles of an XCD with ns streams: ns chains, ns service workgroups, then ONE set of 8 skip + 8 conv1 + n_lc workgroups
+    const int ns = xcc < (unsigned)a.B && xcc < 8u ? (a.B - (int)xcc + 7) / 8 : 0;
+    if (ticket >= 2 * ns + 16 + xa.n_lc_wg) return;             // surplus workgroup (or an XCD without a stream)
     const bool forced = a.forced != nullptr;
-    if (ticket == ROLE_CHAIN) {
-        // hparams default (biases, gc, lc all present): no selects on the dependency chain
-        if (a.lay.use_bias && a.lay.G > 0 && a.lay.L > 0) chain_role<INSTR, true>(xa, b, rs);
-        else chain_role<INSTR, false>(xa, b, rs);
+    auto exch_of = [&](int b) { return __builtin_amdgcn_make_buffer_rsrc(a.exch + (long long)b * XcdExch::WORDS, 0, (int)(XcdExch::WORDS * 8), 0x00020000); };
+    if (ticket < 2 * ns) {
+        const int b = (int)xcc + 8 * (ticket < ns ? ticket : ticket - ns);
+        const rsrc_t rs = exch_of(b);
+        if (ticket < ns) {
+            // hparams default (biases, gc, lc all present): no selects on the dependency chain
+            if (a.lay.use_bias && a.lay.G > 0 && a.lay.L > 0) chain_role<INSTR, true>(xa, b, rs);
+            else chain_role<INSTR, false>(xa, b, rs);
+        }
+        else service_role<INSTR>(xa, b, rs);
+        return;
     }
-    else if (ticket == ROLE_SERVICE) service_role<INSTR>(xa, b, rs);
-    else if (ticket < ROLE_CONV0) { if (!forced) skip_role<INSTR>(xa, b, ticket - ROLE_SKIP0, rs); }
-    else if (ticket < ROLE_LC0) { if (!forced) conv1_role<INSTR>(xa, b, ticket - ROLE_CONV0, rs); }
-    else lc_role<INSTR>(xa, b, ticket - ROLE_LC0, rs);
+    const int role = ticket - 2 * ns;                            // 0-7 skip, 8-15 conv1, 16.. lc
+    auto shared_roles = [&](auto nsc) {
+        constexpr int NS = decltype(nsc)::value;
+        XStreams<NS> sx;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) { sx.b[k] = (int)xcc + 8 * k; sx.rs[k] = exch_of(sx.b[k]); }
+        if (role < 8) { if (!forced) skip_role<INSTR, NS>(xa, sx, role); }
+        else if (role < 16) { if (!forced) conv1_role<INSTR, NS>(xa, sx, role - 8); }
+        else lc_role<INSTR, NS>(xa, sx, role - 16);
+    };
+    if (ns == 1) shared_roles(std::integral_constant<int, 1>{});
+    else if (ns == 2) shared_roles(std::integral_constant<int, 2>{});
+    else if (ns == 3) shared_roles(std::integral_constant<int, 3>{});
+    else shared_roles(std::integral_constant<int, 4>{});
 }
 
 // ---- pack: the chain's register images from the canonical blob (generate.py:157-161 Saver.restore) -------------------------

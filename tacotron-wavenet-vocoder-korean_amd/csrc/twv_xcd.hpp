@@ -8,7 +8,7 @@
 namespace twv {
 
 constexpr int kXcdMaxLayers = 31;      // chain workgroup: wave 0 holds the causal layer + 3 layers, waves 1..7 four layers each
-constexpr int kXcdStreams = 8;         // one stream per XCD
+constexpr int kXcdStreams = 32;        // up to four streams per XCD (stream b runs on XCD b % 8)
 constexpr int kXcdLcRing = 16;         // steps of lc projections the lc workgroups may run ahead of the chain
 constexpr int kXcdXlFloats = 13 * 64 * 4;   // per layer: the chain's register image [13 float4][64 lanes]
 constexpr int kXcdXcFloats = 8 * 64 * 4;    // causal kernel in the chain's lane order

@@ -421,6 +421,17 @@ def test_xcd_kernel_at_bench_geometry(torch_cuda, oracle):
     assert first_mismatch(got, want) is None, first_mismatch(got, want)
 
 
+@pytest.mark.parametrize("B", [16, 32])
+def test_xcd_kernel_with_several_streams_per_xcd(torch_cuda, oracle, B):
+    """the stream sweep of bench.py: 2 and 4 streams per XCD (own chain + service workgroup each, ONE set of skip / conv1 / lc
+    workgroups per XCD serving them in turn), 12 000 steps; bit for bit"""
+    T = 12000
+    m, mel, gc, seed_in, u, want = _bench_case(oracle, B, T)
+    assert m.fused_conditioning(), "up to 32 streams are served by the XCD kernel on an MI355X"
+    got = m.generate(m.create_upsample(mel), gc, seed_in, u).cpu().numpy()
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+
+
 def test_generic_kernel_at_bench_geometry(torch_cuda, oracle):
     """the generic kernel at B = 8: 8 workgroups per stream + helper workgroups (64 + 64 co-resident), 24 000 steps; bit for bit"""
     B, T = 8, 24000
@@ -438,9 +449,10 @@ def test_xcd_kernel_full_length_utterances(torch_cuda, oracle):
     assert first_mismatch(got, want) is None, first_mismatch(got, want)
 
 
-@pytest.mark.parametrize("B", [1, 3, 8])
+@pytest.mark.parametrize("B", [1, 3, 8, 9, 19, 32])
 def test_xcd_kernel_matches_generic_kernel(torch_cuda, oracle, B):
-    """both kernels, same inputs, several stream counts (B < 8 leaves XCDs idle), chunked calls with state carried over"""
+    """both kernels, same inputs, several stream counts (B < 8 leaves XCDs idle; B = 9 and 19 give the XCDs different numbers of
+    streams), chunked calls with state carried over"""
     dil = [2 ** i for i in range(10)] * 3
     d, tensors, blob = make_case(oracle, dil, seed=5)
     rng = np.random.RandomState(9)
