@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include "../../include/twv_amd.h"
@@ -1776,6 +1777,7 @@ static int generate_impl(const twv_wavenet* h, const void* packed, void* state, 
         x.P = a.P; x.state = a.state; x.cond = a.cond; x.first_input = first_input; x.forced = forced;
         x.uniforms = (const float*)uniforms; x.out = (float*)out; x.status = status; x.dbg = debug; x.dbg_steps = a.dbg_steps;
         x.prof = a.prof; x.prof_steps = a.prof_steps;
+        { const char* e = getenv("TWV_XCD_PROF_STREAM"); x.prof_stream = e ? atoi(e) : 0; if (x.prof_stream < 0 || x.prof_stream >= batch) x.prof_stream = 0; }
         x.B = batch; x.T = n_steps; x.lay = L;
         unsigned char* xb = reinterpret_cast<unsigned char*>((float*)state + (size_t)L.state_stride * (size_t)batch) + (size_t)batch * 2 * L.S * 8;
         HIPCHK(hipMemsetAsync(xb, 0, xcd_exchange_bytes(batch), st));

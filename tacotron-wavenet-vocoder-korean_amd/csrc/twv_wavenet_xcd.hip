@@ -118,7 +118,7 @@ struct ChainRegs { float wc[32]; float bfg, gcv, bd; };
 
 // phase stamps (instrumented build only): lane 0 of stream 0's workgroups; s_memrealtime (100 MHz, ONE clock for the chip --
 // s_memtime counters of different CUs are offset against each other by milliseconds)
-#define XSTAMP(cond_, slot_) do { if ((INSTR & 1) && a.prof != nullptr && b == 0 && t < a.prof_steps && lane == 0 && (cond_)) a.prof[(long long)t * 64 + (slot_)] = wall_clock64(); } while (0)
+#define XSTAMP(cond_, slot_) do { if ((INSTR & 1) && a.prof != nullptr && b == a.prof_stream && t < a.prof_steps && lane == 0 && (cond_)) a.prof[(long long)t * 64 + (slot_)] = wall_clock64(); } while (0)
 
 // where a wave is (instrumented build only): read back from the exchange area after a watchdog abort
 #define XMARK(role_, stage_) do { if ((INSTR & 1) && lane == 0) xb_store(rs, (int)XcdExch::MARK + (role_) * 8 + (int)(threadIdx.x >> 6), 0, (unsigned)t + 1u, (float)(stage_)); } while (0)
@@ -553,7 +553,7 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
                 // the XCD's streams in a fixed order (they settle a fraction of a microsecond apart).  Measured alternatives: polling all
                 // the streams still missing in one round and serving whichever arrived (every extra load of a polling round adds to
                 // its round trip: B = 32 ran at 16.5 instead of 13 us/step); requesting the next stream's granules while this stream's
-                // dot runs (17 us/step).
+                // dot runs (no gain: 12.0 against 12.1 us/step at B = 32, slower at B = 16).
 #pragma unroll
                 for (int k = 0; k < NS; ++k) {
                     if (pl.dead) break;
@@ -561,17 +561,30 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
                     const int b = sx.b[k];
                     pl.rs = rs;
                     // model.py:154 sum(outputs), in layer order: the values of layers nextl .. l-1 come from the other waves through LDS
+                    // eight slots per LDS round trip (one at a time, the 30 reads of a step cost the wave 1.5 us per stream: with four
+                    // streams per XCD that was the step time); consumed strictly in layer order, up to the first one not yet there.
+                    // Inside the z poll (non-blocking) the wide form lengthens the polling round: measured on one box, one slot per
+                    // round is better up to two streams per XCD (10.47 against 10.67 us/step at B = 8), eight from three on (11.96
+                    // against 13.5 us/step at B = 32)
+                    constexpr int kNb = NS >= 3 ? 8 : 1;
                     auto drain = [&](bool blocking) {
-                        for (; nextl[k] < l && !pl.dead; ++nextl[k]) {
-                            unsigned long long q;
-                            pl.it = 0;
-                            for (;;) {
-                                q = LDSU64(k * kSkipLdsWords + nextl[k] * 64 + lane);
-                                if (__all(g_tag(q) == tag)) break;
+                        pl.it = 0;
+                        while (nextl[k] < l && !pl.dead) {
+                            const int base = nextl[k];
+                            unsigned long long q[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) if (blocking || j < kNb) q[j] = LDSU64(k * kSkipLdsWords + ((base + j) & 31) * 64 + lane);
+                            bool go = true;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                if (!blocking && j >= kNb) break;
+                                go = go && (base + j < l) && __all(g_tag(q[j]) == tag);
+                                if (go) { tot[k] = (base + j == 0) ? g_val(q[j]) : tot[k] + g_val(q[j]); nextl[k] = base + j + 1; }
+                            }
+                            if (nextl[k] == base) {
                                 if (!blocking) return;
                                 if (!poll_tick(pl, 52)) return;
                             }
-                            tot[k] = (nextl[k] == 0) ? g_val(q) : tot[k] + g_val(q);
                         }
                     };
                     XMARK(ROLE_SKIP0 + g, 10 + i);

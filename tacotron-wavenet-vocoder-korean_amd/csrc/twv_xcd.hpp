@@ -44,6 +44,7 @@ struct XcdLaunch {
     int dbg_steps;
     unsigned long long* prof;      // optional [prof_steps][64] s_memtime stamps of stream 0 (tuning aid; see scripts/xcd_phase_profile.py)
     int prof_steps;
+    int prof_stream;               // the stream whose workgroups stamp (0; TWV_XCD_PROF_STREAM picks another one: tuning aid)
     int B, T;
     unsigned long long* exch;      // [B][XcdExch::WORDS]
     int* roles;                    // [8] role tickets per XCD (zeroed before the launch)
