@@ -142,14 +142,15 @@ constexpr int kConvLdsFloats = 16 * 64 + 64; // LDS floats per stream in a conv1
 //  CHAIN workgroup: model.py:41-46 causal layer (wave 0), model.py:66-101 residual layers (relay over the waves),
 //  mixture.py:84-114 sampler (wave 7)
 // =====================================================================================================================
-template <int INSTR, bool ALL>
+template <int INSTR, bool ALL, bool FORCED>
 __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
 {
     const XcdLaunch& a = xa.p;
     const Layout& L = a.lay;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int NL = L.NL, T = a.T;
-    const bool use_bias = L.use_bias != 0, has_gc = L.G > 0, has_lc = L.L > 0, forced = a.forced != nullptr;
+    const bool use_bias = L.use_bias != 0, has_gc = L.G > 0, has_lc = L.L > 0;
+    constexpr bool forced = FORCED;                           // teacher-forced steps (twv_wavenet_prime): its own instantiation, the sampling loop carries none of it
     // waves 0..5 hold four layers each, waves 6 and 7 three: wave 7 also runs the sampler and the causal layer (it HAS the new sample)
     const int l0 = w < 6 ? 4 * w : 24 + 3 * (w - 6);
     const int cap = w < 6 ? 4 : 3;
@@ -220,6 +221,16 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
         const unsigned tag = (unsigned)t + 1u;
         // ---- wave 7, head of the step: new input sample -> causal layer -> wave 0.  On the sample-to-sample path: one fma, three adds.
         if (head) {
+            if (forced && t > 0) {
+                pl.it = 0;
+                for (;;) {
+                    const unsigned long long q = LDSU64(8 * 64 + lane);
+                    if (__all(g_tag(q) == (unsigned)t)) break;             // the tag of step t-1
+                    if (!poll_tick(pl, 35)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (pl.dead) break;
+            }
             XSTAMP(true, 0);
             const float s_in = forced ? reinterpret_cast<const float*>(a.forced)[(long long)b * T + t] : (t == 0 ? first_in : samp);
             const float c3 = fma_(W[3].wc[31], s_in, cp[3]);            // k = 31, the last term of chain 3
@@ -310,6 +321,9 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
         else if (nl == 2) run_layers(std::integral_constant<int, 2>{});
         else if (nl == 1) run_layers(std::integral_constant<int, 1>{});
         if (next_has && nl > 0) LDSU64((w + 1) * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(X);
+        // teacher-forced steps (twv_wavenet_prime): nothing makes the head wait for the stack (there is no sample to wait for), so
+        // the wave that runs the last layer reports the end of the step in box 8 and the head starts the next one after that
+        if (forced && nl > 0 && !next_has) LDSU64(8 * 64 + lane) = (unsigned long long)tag << 32;
         if (!sampler) __builtin_amdgcn_s_setprio(0);
         XSTAMP(nl > 0, 10 + w);
         XMARK(ROLE_CHAIN, 4);
@@ -910,8 +924,9 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
         const rsrc_t rs = exch_of(b);
         if (ticket < ns) {
             // hparams default (biases, gc, lc all present): no selects on the dependency chain
-            if (a.lay.use_bias && a.lay.G > 0 && a.lay.L > 0) chain_role<INSTR, true>(xa, b, rs);
-            else chain_role<INSTR, false>(xa, b, rs);
+            if (forced) chain_role<INSTR, false, true>(xa, b, rs);
+            else if (a.lay.use_bias && a.lay.G > 0 && a.lay.L > 0) chain_role<INSTR, true, false>(xa, b, rs);
+            else chain_role<INSTR, false, false>(xa, b, rs);
         }
         else service_role<INSTR>(xa, b, rs);
         return;

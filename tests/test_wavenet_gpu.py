@@ -321,6 +321,51 @@ def test_priming_then_generation(torch_cuda, oracle, scalar):
     assert first_mismatch(got, want) is None
 
 
+@pytest.mark.parametrize("B", [3, 11])
+def test_xcd_kernel_priming_then_generation(torch_cuda, oracle, B):
+    """generate.py:168-180 on the XCD kernel (B = 11: XCDs 0-2 carry two streams, the others one): prime with RF-1 seed samples
+    (zero lc, predictions discarded; the skip / conv1 workgroups idle), then generate from mel frames"""
+    dil = [1, 2, 4, 8, 16, 32]
+    T = 600
+    d, tensors, blob = make_case(oracle, dil, scale=0.1)
+    m = make_model(B, dil, tensors)
+    assert m.fused_conditioning()
+    rf = oracle.receptive_field(d)
+    rng = np.random.RandomState(9)
+    seedwave = rng.uniform(-1, 1, (B, rf)).astype(np.float32)
+    mel = rng.uniform(-4, 4, (B, 2, 80)).astype(np.float32)
+    gc = (np.arange(B) % 2).astype(np.int32)
+    st = oracle.State(d, B)
+    zeros = np.zeros((B, 80), np.float32)
+    for i in range(rf - 1):                                   # generate.py:177-180
+        oracle.step(d, blob, st, seedwave[:, i], zeros, gc)
+    u = mol_uniforms(B, T, 10)
+    want = oracle.generate_mol(d, blob, st, oracle.upsample(d, blob, mel), gc, seedwave[:, -1], u)
+    m.prime(seedwave[:, :rf - 1], None, gc)
+    got = m.generate(m.create_upsample(mel), gc, seedwave[:, -1], u).cpu().numpy()
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+
+
+@pytest.mark.parametrize("nl,use_bias,G,L,O", [(1, True, 32, 80, 30), (5, True, 32, 80, 30), (9, False, 32, 80, 30), (24, True, 0, 80, 30),
+                                             (25, True, 32, 0, 30), (28, False, 0, 0, 3), (30, True, 32, 80, 6)])
+def test_xcd_kernel_shapes(torch_cuda, oracle, nl, use_bias, G, L, O):
+    """the XCD kernel away from the bench shape: layer counts that end inside / at the edge of a chain wave, no biases, no global /
+    local conditioning (the chain's general instantiation), other mixture sizes; B = 3 leaves five XCDs idle"""
+    dil = ([1, 2, 4, 8, 16, 32, 64] * 5)[:nl]
+    B, T = 3, 450
+    d, tensors, blob = make_case(oracle, dil, use_bias=use_bias, G=G, L=L, out_channels=O, scale=0.1)
+    m = make_model(B, dil, tensors, use_bias=use_bias, G=G, L=L, out_channels=O)
+    assert m.fused_conditioning() == bool(L)
+    rng = np.random.RandomState(nl)
+    mel = rng.uniform(-4, 4, (B, 2, 80)).astype(np.float32) if L else None
+    gc = (np.arange(B) % 2).astype(np.int32) if G else None
+    seed_in = (2 * rng.rand(B) - 1).astype(np.float32)
+    u = mol_uniforms(B, T, O // 3)
+    want = oracle.generate_mol(d, blob, oracle.State(d, B), oracle.upsample(d, blob, mel)[:, :T] if L else None, gc, seed_in, u)
+    got = m.generate(m.create_upsample(mel) if L else None, gc, seed_in, u).cpu().numpy()
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+
+
 def test_generate_cli(torch_cuda, tmp_path):
     """generate.py surface: flags, params.json override, output files (generate.py:52-69,109,261)"""
     import json
