@@ -187,12 +187,14 @@ def test_generate_variants(torch_cuda, oracle, kw):
     assert first_mismatch(got.cpu().numpy(), want) is None, kw
 
 
-def test_state_carries_over_between_calls(torch_cuda, oracle):
-    """generate(T1) then generate(T2) == generate(T1+T2); n_steps=1 calls == one sess.run each (generate.py:211)"""
+@pytest.mark.parametrize("S", [128, 512])
+def test_state_carries_over_between_calls(torch_cuda, oracle, S):
+    """generate(T1) then generate(T2) == generate(T1+T2); n_steps=1 calls == one sess.run each (generate.py:211).
+    S = 128: the generic kernel; S = 512: the XCD kernel fed with materialised upsampled rows"""
     dil = [1, 2, 4, 8] * 2
     B, T = 2, 40
-    d, tensors, blob = make_case(oracle, dil, S=128, scale=0.1)
-    m = make_model(B, dil, tensors, S=128)
+    d, tensors, blob = make_case(oracle, dil, S=S, scale=0.1)
+    m = make_model(B, dil, tensors, S=S)
     rng = np.random.RandomState(3)
     U = rng.uniform(-1, 1, (B, T, 80)).astype(np.float32)
     gc = np.array([1, 0], np.int32)
