@@ -121,7 +121,8 @@ int twv_wavenet_status(const int32_t* status, void* stream);
 /* launch geometry knobs (performance only, results are bit-identical): "xcd" = 1 (default): the XCD-per-stream kernel
  * (stream b on XCD b % 8, up to four streams per XCD; every weight register-resident across the XCD's CUs, fused conditioning)
  * whenever the model is the hparams-default MoL shape (scalar input, initial_filter_width 32, skip_channels 512,
- * out_channels <= 32, <= 30 layers), batch <= 32 and the device has 256 CUs; 0 = always the generic kernel.  Set it (and "groups") BEFORE sizing / resetting the
+ * out_channels <= 32, <= 50 layers: hparams.py's default stack), batch <= 32 (<= 16 with more than 30 layers) and the device has
+ * 256 CUs; 0 = always the generic kernel.  Set it (and "groups") BEFORE sizing / resetting the
  * state and conditioning buffers.  "groups" = workgroups per stream of the generic kernel (0 auto; an explicit value also selects
  * the generic kernel), "workers" =
  * worker waves per stream workgroup (4 | 3), "helpers" = 1 (default: conv1d_1 and conv1d_2's chunk partials run in one helper

@@ -1460,7 +1460,7 @@ static int device_cus()
 // the XCD-per-stream kernel: stream b on XCD b % 8 (8 x 32 CUs; up to four streams per XCD), explicit `groups` keeps the generic kernel
 static bool use_xcd(const twv_wavenet* h, int batch)
 {
-    return h->xcd != 0 && h->groups == 0 && h->lay.off_xl != 0 && batch >= 1 && batch <= kXcdStreams && device_cus() >= 256;
+    return h->xcd != 0 && h->groups == 0 && h->lay.off_xl != 0 && batch >= 1 && batch <= (h->lay.NL > kXcdSeg0Layers ? kXcdStreams / 2 : kXcdStreams) && device_cus() >= 256;
 }
 static int resolve_groups(const twv_wavenet* h, int batch)
 {

@@ -2,7 +2,7 @@
 // vector registers per XCD).
 //
 // Replaces, for the hparams-default MoL vocoder (wavenet/model.py:41-167,215-245, wavenet/mixture.py:84-114, generate.py:199-233;
-// scalar input, initial_filter_width 32, R = D = 32, S = 512, out_channels <= 32, up to 30 layers, batch <= 32):
+// scalar input, initial_filter_width 32, R = D = 32, S = 512, out_channels <= 32, up to 50 layers, batch <= 32 (16 above 30 layers)):
 // the same per-sample chain as wn_generate_kernel (twv_wavenet.hip), but laid out for the chip instead of for one CU:
 //
 //   * A STREAM LIVES ON ONE XCD (stream b on XCD b % 8).  Every workgroup reads its XCC id and takes a role ticket of that XCD, so all workgroups of a stream
@@ -16,6 +16,10 @@
 //       conv1 workgroups  (8 per XCD): slice g of conv1d_1 and its two chunks of conv1d_2 (model.py:158-165)
 //       lc workgroups   (2-4 per XCD): create_upsample + lc_filter/lc_gate projections (model.py:102-111,75-83), running ahead of
 //                              the chain through a ring: neither the upsampled condition nor a projection table exists in HBM
+//     More than 30 layers (hparams.py's default stack has 50): a SECOND chain workgroup takes layers 30.. (one L2 hop away), the
+//     service / skip waves keep the tiles of the early layers in LDS (their values are needed last) and the lc waves hold two layers;
+//     this is a kernel instantiation of its own (BIGK), the 30-layer kernel's code is untouched by it: 16.2 us/step at 50 layers
+//     against 32.9 on the generic kernel.
 //     The skip / conv1 / lc workgroups hold weights only, so with more than 8 streams ONE set per XCD serves the XCD's streams in
 //     turn (2 ns + 16 + n_lc <= 28 of the 32 CUs for ns = 4): the streams settle a fraction of a microsecond apart, B = 16 keeps
 //     the single-stream step time (10.6 us), B = 32 runs at 12.9 us (2.5 M samples/s).
@@ -142,7 +146,7 @@ constexpr int kConvLdsFloats = 16 * 64 + 64; // LDS floats per stream in a conv1
 //  CHAIN workgroup: model.py:41-46 causal layer (wave 0), model.py:66-101 residual layers (relay over the waves),
 //  mixture.py:84-114 sampler (wave 7)
 // =====================================================================================================================
-template <int INSTR, bool ALL, bool FORCED>
+template <int INSTR, bool ALL, bool FORCED, bool SEG1, bool TWOSEG>
 __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
 {
     const XcdLaunch& a = xa.p;
@@ -151,13 +155,18 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
     const int NL = L.NL, T = a.T;
     const bool use_bias = L.use_bias != 0, has_gc = L.G > 0, has_lc = L.L > 0;
     constexpr bool forced = FORCED;                           // teacher-forced steps (twv_wavenet_prime): its own instantiation, the sampling loop carries none of it
-    // waves 0..5 hold four layers each, waves 6 and 7 three: wave 7 also runs the sampler and the causal layer (it HAS the new sample)
-    const int l0 = w < 6 ? 4 * w : 24 + 3 * (w - 6);
-    const int cap = w < 6 ? 4 : 3;
+    // first chain workgroup: waves 0..5 hold four layers each, waves 6 and 7 three: wave 7 also runs the sampler and the causal
+    // layer (it HAS the new sample).  A model with more than 30 layers (hparams.py's default has 50) continues in a second chain
+    // workgroup (SEG1: four layers per wave from layer 30 on), one L2 hop away.
+    const int l0 = SEG1 ? kXcdSeg0Layers + 4 * w : (w < 6 ? 4 * w : 24 + 3 * (w - 6));
+    const int lw0 = SEG1 ? 4 * w : l0;                         // the wave's first layer, counted inside this workgroup (LDS copies)
+    const int cap = SEG1 ? 4 : (w < 6 ? 4 : 3);
     int nl = NL - l0;
     nl = nl < 0 ? 0 : (nl > cap ? cap : nl);
     const bool next_has = (l0 + nl < NL);                      // a later wave continues the stack
-    const bool head = (w == 7);                                // sampler + causal layer
+    const bool head = !SEG1 && (w == 7);                       // sampler + causal layer
+    const bool to_seg1 = TWOSEG && !SEG1 && w == 7 && next_has;     // the stack goes on in the second chain workgroup
+    constexpr bool two_seg = TWOSEG;
     if (nl == 0 && !head) return;
     const int oc = dpp_conv_out(lane), od = dpp_dense_out(lane);
     const ActCoef coef = act_coef(lane >= 32);
@@ -174,7 +183,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
 #pragma unroll
             for (int q = 0; q < 8; ++q) { const f32x4 v = src[q * 64]; W[i].wc[4 * q] = v.x; W[i].wc[4 * q + 1] = v.y; W[i].wc[4 * q + 2] = v.z; W[i].wc[4 * q + 3] = v.w; }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) LDS4((O_WD >> 2) + ((l0 + i) * 4 + q) * 64 + lane) = src[(8 + q) * 64];
+            for (int q = 0; q < 4; ++q) LDS4((O_WD >> 2) + ((lw0 + i) * 4 + q) * 64 + lane) = src[(8 + q) * 64];
             const f32x4 v = src[12 * 64];
             W[i].bfg = v.x; W[i].bd = v.y;
             W[i].gcv = has_gc ? a.cond[XH_WORDS + ((long long)b * NL + l0 + i) * 64 + oc] : 0.0f;     // model.py:71-73, hoisted
@@ -224,7 +233,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
             if (forced && t > 0) {
                 pl.it = 0;
                 for (;;) {
-                    const unsigned long long q = LDSU64(8 * 64 + lane);
+                    const unsigned long long q = two_seg ? xb_load(rs, (int)XcdExch::DONE, lane) : LDSU64(8 * 64 + lane);
                     if (__all(g_tag(q) == (unsigned)t)) break;             // the tag of step t-1
                     if (!poll_tick(pl, 35)) break;
                     __builtin_amdgcn_s_sleep(2);
@@ -247,7 +256,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
             if (sampler) noise(t);
             __builtin_amdgcn_s_setprio(0);
         }
-        XMARK(ROLE_CHAIN, 1);
+        XMARK(SEG1 ? 30 : ROLE_CHAIN, 1);
         // ---- (A) this step's tap-0 chunks and lc projections of the wave's layers (service workgroup; long since published)
         float pre[4] = {0.0f, 0.0f, 0.0f, 0.0f}, lcv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (nl > 0) {
@@ -268,18 +277,26 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                 __builtin_amdgcn_s_sleep(4);
             }
             if (pl.dead) break;
-            XSTAMP(true, 26 + w);
-            XMARK(ROLE_CHAIN, 2);
+            XSTAMP(!SEG1, 26 + w);
+            XMARK(SEG1 ? 30 : ROLE_CHAIN, 2);
             // ---- (B) the wave's input: the previous wave's residual vector (wave 0: the causal layer's output).  The wave sleeps
             // through most of the step and polls only when its turn is near: a spinning wave takes issue slots from the wave that
             // shares its SIMD (waves w and w+4), and that one may be the wave carrying the chain right now.
             if (in_period) nap_until(t_in + in_period - (in_period >> 4));
             unsigned long long q;
             pl.it = 0;
-            for (;;) {
-                q = LDSU64(w * 64 + lane);
-                if (__all(g_tag(q) == tag)) break;
-                if (!poll_tick(pl, 33)) break;
+            if (SEG1 && w == 0) {
+                for (;;) {                                               // from wave 7 of the first chain workgroup: one L2 hop
+                    q = xb_load(rs, (int)XcdExch::SEG, lane);
+                    if (__all(g_tag(q) == tag)) break;
+                    if (!poll_tick(pl, 36)) break;
+                }
+            } else {
+                for (;;) {
+                    q = LDSU64(w * 64 + lane);
+                    if (__all(g_tag(q) == tag)) break;
+                    if (!poll_tick(pl, 33)) break;
+                }
             }
             if (pl.dead) break;
             __builtin_amdgcn_s_setprio(3);
@@ -290,8 +307,8 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                 in_period = (t_in != 0 && d < (1ull << 18)) ? d : 0;
                 t_in = now;
             }
-            XSTAMP(true, 2 + w);
-            XMARK(ROLE_CHAIN, 3);
+            XSTAMP(true, (SEG1 ? 40 : 2) + w);
+            XMARK(SEG1 ? 30 : ROLE_CHAIN, 3);
         }
         // ---- the wave's layers (the loop is compiled once per layer count: a run-time count costs a branch pair per layer)
         auto run_layers = [&](auto nc) {
@@ -301,7 +318,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                 float wd[16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = LDS4((O_WD >> 2) + ((l0 + i) * 4 + q) * 64 + lane);
+                    const f32x4 v = LDS4((O_WD >> 2) + ((lw0 + i) * 4 + q) * 64 + lane);
                     wd[4 * q] = v.x; wd[4 * q + 1] = v.y; wd[4 * q + 2] = v.z; wd[4 * q + 3] = v.w;
                 }
                 const float z = layer_front_dpp<ALL>(W[i].wc, W[i].bfg, W[i].gcv, coef, X, pre[i], lcv[i], use_bias, has_gc, has_lc);
@@ -320,13 +337,17 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
         else if (nl == 3) run_layers(std::integral_constant<int, 3>{});
         else if (nl == 2) run_layers(std::integral_constant<int, 2>{});
         else if (nl == 1) run_layers(std::integral_constant<int, 1>{});
-        if (next_has && nl > 0) LDSU64((w + 1) * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(X);
+        if (to_seg1) xb_store(rs, (int)XcdExch::SEG, lane, tag, X);
+        else if (next_has && nl > 0) LDSU64((w + 1) * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(X);
         // teacher-forced steps (twv_wavenet_prime): nothing makes the head wait for the stack (there is no sample to wait for), so
         // the wave that runs the last layer reports the end of the step in box 8 and the head starts the next one after that
-        if (forced && nl > 0 && !next_has) LDSU64(8 * 64 + lane) = (unsigned long long)tag << 32;
+        if (forced && nl > 0 && !next_has) {
+            if (SEG1) xb_store(rs, (int)XcdExch::DONE, lane, tag, 0.0f);
+            else LDSU64(8 * 64 + lane) = (unsigned long long)tag << 32;
+        }
         if (!sampler) __builtin_amdgcn_s_setprio(0);
-        XSTAMP(nl > 0, 10 + w);
-        XMARK(ROLE_CHAIN, 4);
+        XSTAMP(nl > 0, (SEG1 ? 48 : 10) + w);
+        XMARK(SEG1 ? 30 : ROLE_CHAIN, 4);
         // ---- sampler: conv1d_2's [16 chunks][32 lanes] partial table from the conv1 workgroups -> mixture.py:84-114
         if (sampler) {
             __builtin_amdgcn_s_setprio(3);
@@ -350,7 +371,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
             }
             if (pl.dead) break;
             XSTAMP(true, 18);
-            XMARK(ROLE_CHAIN, 5);
+            XMARK(SEG1 ? 30 : ROLE_CHAIN, 5);
             float y = g_val(q[0]);                                     // chunk partials added in chunk order (AC-1)
 #pragma unroll
             for (int k = 1; k < 8; ++k) y = y + g_val(q[k]);
@@ -406,12 +427,59 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
 //  (model.py:68-69: the tap that reads x[t-d]), one step ahead of the chain; forwards the lc projections.
 //  Wave s owns layers s, s+8, s+16, s+24.
 // =====================================================================================================================
+// a weight tile kept in LDS (layers beyond the register slots of a helper wave): same [8 float4][64 lanes] image; the dot takes it
+// in two halves of 16 registers (the same two blocks of 16 v_fmac_f32_dpp as dot32_dpp, twv_dpp.hpp)
+#define TWV_FMAC16_DPP(c0, c1, c2, c3, x, w)                                                          \
+    asm volatile(                                                                                      \
+        "s_nop 1\n"                                                                                    \
+        "v_fmac_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"                        \
+        "v_fmac_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"                        \
+        "v_fmac_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"                        \
+        "v_fmac_f32_dpp %3, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"                        \
+        "v_fmac_f32_dpp %0, %4, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"                        \
+        "v_fmac_f32_dpp %1, %4, %10 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"                       \
+        "v_fmac_f32_dpp %2, %4, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"                       \
+        "v_fmac_f32_dpp %3, %4, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"                       \
+        "v_fmac_f32_dpp %0, %4, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"                       \
+        "v_fmac_f32_dpp %1, %4, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"                       \
+        "v_fmac_f32_dpp %2, %4, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"                      \
+        "v_fmac_f32_dpp %3, %4, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"                      \
+        "v_fmac_f32_dpp %0, %4, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"                      \
+        "v_fmac_f32_dpp %1, %4, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"                      \
+        "v_fmac_f32_dpp %2, %4, %19 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"                      \
+        "v_fmac_f32_dpp %3, %4, %20 row_newbcast:15 row_mask:0xf bank_mask:0xf"                        \
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)                                                       \
+        : "v"(x), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), \
+          "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]))
+__device__ __forceinline__ float dot32_dpp_lds(int off4, int lane, float xa, float xb)
+{
+    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float w[16];
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            const f32x4 q = LDS4(off4 + (4 * h + kq) * 64 + lane);
+            w[4 * kq + 0] = q.x; w[4 * kq + 1] = q.y; w[4 * kq + 2] = q.z; w[4 * kq + 3] = q.w;
+        }
+        if (h == 0) { TWV_FMAC16_DPP(c0, c1, c2, c3, xa, w); }
+        else { TWV_FMAC16_DPP(c0, c1, c2, c3, xb, w); }
+    }
+    return (c0 + c1) + (c2 + c3);
+}
+__device__ __forceinline__ void copy_tile_to_lds(int off4, const float* base, int lane)
+{
+    const f32x4* p = reinterpret_cast<const f32x4*>(base) + lane;
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) LDS4(off4 + kq * 64 + lane) = p[kq * 64];
+}
+
 __device__ __forceinline__ unsigned ring_slot(unsigned pos0, unsigned t, unsigned d)
 {
     const unsigned v = pos0 + t;
     return (d & (d - 1)) == 0 ? (v & (d - 1)) : v % d;
 }
-template <int INSTR>
+template <int INSTR, bool BIG>
 __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
 {
     const XcdLaunch& a = xa.p;
@@ -424,24 +492,36 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
     const int* pmeta = reinterpret_cast<const int*>(a.P + L.off_meta);
     int* ringpos = reinterpret_cast<int*>(stb + L.st_ringpos);
     Poll pl{rs, a.status, 0, false};
-    int nown = 0;
+    // BIG (more than 32 layers): four tiles in registers (layers NLDS + s + 8i), the first NLDS = NL - 32 layers' tiles in LDS (this
+    // workgroup has no other use for it: 18 tiles = 144 KiB at 50 layers)
+    constexpr int kReg = 4, kLds = BIG ? 3 : 0, kSlots = kReg + kLds;
+    const int NLDS = BIG ? (NL > 8 * kReg ? NL - 8 * kReg : 0) : 0;
+    int nown = 0, nlds = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) if (s + 8 * i < NL) nown = i + 1;
-    if (nown == 0) return;
-    Tile t0[4];
-    unsigned dil[4], roff[4], pos0[4];
+    for (int i = 0; i < kReg; ++i) if (NLDS + s + 8 * i < NL) nown = i + 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < kLds; ++j) if (s + 8 * j < NLDS) nlds = j + 1;
+    if (nown == 0 && nlds == 0) return;
+    Tile t0[kReg];
+    unsigned dil[kSlots], roff[kSlots], pos0[kSlots];
+    int lay_of[kSlots];
+#pragma unroll
+    for (int i = 0; i < kSlots; ++i) {
         dil[i] = 1; roff[i] = 0; pos0[i] = 0;
-        if (i < nown) {
-            const int l = s + 8 * i;
-            load_tile(t0[i], a.P + L.off_layer0 + (long long)l * L.layer_stride + LayerOff::T0, lane);
+        const bool is_lds = i < kLds;
+        const int l = is_lds ? s + 8 * i : NLDS + s + 8 * (i - kLds);
+        const bool have = is_lds ? i < nlds : (i - kLds) < nown;
+        lay_of[i] = have ? l : -1;
+        if (have) {
+            const float* src = a.P + L.off_layer0 + (long long)l * L.layer_stride + LayerOff::T0;
+            if (is_lds) copy_tile_to_lds(l * (kTile / 4), src, lane);     // own layers only: written and read by this wave alone
+            else load_tile(t0[i - kLds < 0 ? 0 : i - kLds], src, lane);
             dil[i] = (unsigned)pmeta[l]; roff[i] = (unsigned)pmeta[64 + l]; pos0[i] = (unsigned)ringpos[l];
         }
     }
     const int n16 = lane & 15;
     // operand of the tap-0 chunk of step t: x[t-d] = the slot the delay line overwrites at step t
-    auto tap0 = [&](int i, unsigned t, float& xa_, float& xb_) {
+    auto tap0 = [&](int i, unsigned t, float& xa_, float& xb_) __attribute__((always_inline)) {
         const unsigned slot = ring_slot(pos0[i], t, dil[i]);
         const unsigned long long* p = reinterpret_cast<const unsigned long long*>(ring + roff[i] + slot * 32);
         // 8-byte sc1 loads of float pairs: lanes n and n+1 of a pair read the same word
@@ -450,14 +530,19 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
         xa_ = __uint_as_float((n16 & 1) ? (unsigned)(qa >> 32) : (unsigned)qa);
         xb_ = __uint_as_float((n16 & 1) ? (unsigned)(qb >> 32) : (unsigned)qb);
     };
+    // the tile of slot i: a register tile, or (BIG, early layers) fetched from LDS
+    auto dot_slot = [&](int i, float oa, float ob) __attribute__((always_inline)) -> float {
+        if (i < kLds) return dot32_dpp_lds(lay_of[i] * (kTile / 4), lane, oa, ob);
+        return dot32_dpp(t0[i - kLds < 0 ? 0 : i - kLds].w, oa, ob);
+    };
     // ---- step 0: from the persisted state
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (i < nown) {
-            const int l = s + 8 * i;
+    for (int i = 0; i < kSlots; ++i) {
+        if (lay_of[i] >= 0) {
+            const int l = lay_of[i];
             float xa_, xb_;
             tap0(i, 0u, xa_, xb_);
-            const float pre = dot32_dpp(t0[i].w, xa_, xb_);
+            const float pre = dot_slot(i, xa_, xb_);
             const float lcv = has_lc ? stb[L.st_lcprev + l * 64 + lane] : 0.0f;     // frame pushed by the previous call (zeros after reset)
             xb_store(rs, (int)XcdExch::PG + l * 64, lane, 1u, pre);
             xb_store(rs, (int)XcdExch::LG + l * 64, lane, 1u, lcv);
@@ -466,9 +551,9 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
     for (int t = 0; t < T && !pl.dead; ++t) {
         const unsigned tag = (unsigned)t + 1u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i < nown && !pl.dead) {
-                const int l = s + 8 * i;
+        for (int i = 0; i < kSlots; ++i) {
+            if (lay_of[i] >= 0 && !pl.dead) {
+                const int l = lay_of[i];
                 const bool more = t + 1 < T;
                 // next step's operand when it is already in the delay line (d >= 2): requested before the wait
                 float oa = 0.0f, ob = 0.0f;
@@ -491,12 +576,12 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
                 if (lane < 32) ring[roff[i] + slot * 32 + lane] = lane < 16 ? xa_ : xb_;
                 if (more) {
                     if (dil[i] == 1) { oa = xa_; ob = xb_; }
-                    const float pre = dot32_dpp(t0[i].w, oa, ob);
+                    const float pre = dot_slot(i, oa, ob);
                     float lcv = 0.0f;
                     XMARK(ROLE_SERVICE, 20 + i);
                     if (has_lc) {
                         // lc frame used at step t+1 = frame pushed at step t (model.py:79-80: slice from the FRONT of the queue)
-                        const int lw = (int)XcdExch::LCR + (((t + 1) % kXcdLcRing) * 32 + l) * 64;
+                        const int lw = (int)XcdExch::LCR + (((t + 1) % kXcdLcRing) * kXcdLs + l) * 64;
                         unsigned long long ql;
                         pl.it = 0;
                         for (;;) {
@@ -516,8 +601,8 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
     }
     if (lane == 0 && !pl.dead) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i < nown) ringpos[s + 8 * i] = (int)((pos0[i] + (unsigned)T) % dil[i]);
+        for (int i = 0; i < kSlots; ++i)
+            if (lay_of[i] >= 0) ringpos[lay_of[i]] = (int)((pos0[i] + (unsigned)T) % dil[i]);
     }
 }
 
@@ -525,7 +610,10 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
 //  SKIP workgroup g: model.py:94-96 skip 1x1 of every layer for output block g, model.py:154 sum over the layers in layer
 //  order, model.py:157 relu.  Wave v owns layers v, v+8, ...; the wave that owns the last layer adds the values up as they appear.
 // =====================================================================================================================
-template <int INSTR, int NS>
+// BIG (more than 32 layers; hparams.py's default has 50): a wave holds FIVE tiles in registers -- the layers NLDS + v + 8i, the late
+// ones, whose values are needed soonest after they appear -- and the tiles of the first NLDS = NL - 40 layers (v, v + 8) sit in LDS
+// and pass through a sixth register tile when their turn comes.
+template <int INSTR, int NS, bool BIG>
 __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& sx, int g)
 {
     const XcdLaunch& a = xa.p;
@@ -534,36 +622,52 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
     const int NL = L.NL, T = a.T;
     const bool use_bias = L.use_bias != 0;
     Poll pl{sx.rs[0], a.status, 0, false};
-    int nown = 0;
+    constexpr int kReg = BIG ? 5 : 4, kLds = BIG ? 2 : 0, kSlots = kReg + kLds;
+    const int NLDS = BIG ? (NL > 8 * kReg ? NL - 8 * kReg : 0) : 0;      // layers whose tiles live in LDS
+    const int SW = BIG ? NL * 64 : kSkipLdsWords;                        // 8-byte value slots per stream
+    const int o_tile4 = (NS * SW * 2 + 3) >> 2;                          // LDS tiles behind the value slots (float4 units)
+    int nown = 0, nlds = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) if (v + 8 * i < NL) nown = i + 1;
-    if (nown == 0) return;
-    Tile ws[4];
-    float bs[4];
+    for (int i = 0; i < kReg; ++i) if (NLDS + v + 8 * i < NL) nown = i + 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        bs[i] = 0.0f;
+    for (int j = 0; j < kLds; ++j) if (v + 8 * j < NLDS) nlds = j + 1;
+    if (nown == 0 && nlds == 0) return;
+    Tile ws[kReg];
+    float bs[kSlots];
+#pragma unroll
+    for (int i = 0; i < kSlots; ++i) bs[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kReg; ++i) {
         if (i < nown) {
-            const long long lb = L.off_layer0 + (long long)(v + 8 * i) * L.layer_stride;
+            const long long lb = L.off_layer0 + (long long)(NLDS + v + 8 * i) * L.layer_stride;
             load_tile(ws[i], a.P + lb + LayerOff::SK + (long long)g * kTile, lane);
-            if (use_bias) bs[i] = a.P[lb + LayerOff::SK + (long long)L.NSJ * kTile + g * 64 + lane];
+            if (use_bias) bs[kLds + i] = a.P[lb + LayerOff::SK + (long long)L.NSJ * kTile + g * 64 + lane];
         }
     }
-    const bool summer = v == ((NL - 1) & 7);
+#pragma unroll
+    for (int j = 0; j < kLds; ++j) {
+        if (j < nlds) {                                                   // own layers only: written and read by this wave alone
+            const long long lb = L.off_layer0 + (long long)(v + 8 * j) * L.layer_stride;
+            copy_tile_to_lds(o_tile4 + (v + 8 * j) * (kTile / 4), a.P + lb + LayerOff::SK + (long long)g * kTile, lane);
+            if (use_bias) bs[j] = a.P[lb + LayerOff::SK + (long long)L.NSJ * kTile + g * 64 + lane];
+        }
+    }
+    const bool summer = v == ((NL - 1 - NLDS) & 7);
     const int n16 = lane & 15;
     const int zc_lane = lane_of_z((lane < 32 ? 0 : 16) + n16);
-    unsigned long long seen[4] = {0, 0, 0, 0}, period = 0;       // arrival times of the own layers (first stream) in the previous step
+    unsigned long long seen[kSlots], period = 0;                  // arrival times of the own layers (first stream) in the previous step
+#pragma unroll
+    for (int i = 0; i < kSlots; ++i) seen[i] = 0;
     for (int t = 0; t < T && !pl.dead; ++t) {
         const unsigned tag = (unsigned)t + 1u;
         int nextl[NS];
         float tot[NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k) { nextl[k] = 0; tot[k] = 0.0f; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (i < nown && !pl.dead) {
-                const int l = v + 8 * i;
-                if (!summer && period) nap_until(seen[i] + period - (period >> 3));
+        // one own layer: `dot` multiplies by a register tile or (BIG, early layers) by a tile in LDS
+        auto own_layer = [&](auto&& dot, const float bias, const int l, const int si) __attribute__((always_inline)) {
+            {
+                if (!summer && period) nap_until(seen[si] + period - (period >> 3));
                 // the XCD's streams in a fixed order (they settle a fraction of a microsecond apart).  Measured alternatives: polling all
                 // the streams still missing in one round and serving whichever arrived (every extra load of a polling round adds to
                 // its round trip: B = 32 ran at 16.5 instead of 13 us/step); requesting the next stream's granules while this stream's
@@ -574,20 +678,21 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
                     const rsrc_t rs = sx.rs[k];
                     const int b = sx.b[k];
                     pl.rs = rs;
-                    // model.py:154 sum(outputs), in layer order: the values of layers nextl .. l-1 come from the other waves through LDS
+                    // model.py:154 sum(outputs), in layer order: the values of layers nextl .. l-1 come from the other waves through LDS;
                     // eight slots per LDS round trip (one at a time, the 30 reads of a step cost the wave 1.5 us per stream: with four
                     // streams per XCD that was the step time); consumed strictly in layer order, up to the first one not yet there.
                     // Inside the z poll (non-blocking) the wide form lengthens the polling round: measured on one box, one slot per
                     // round is better up to two streams per XCD (10.47 against 10.67 us/step at B = 8), eight from three on (11.96
                     // against 13.5 us/step at B = 32)
                     constexpr int kNb = NS >= 3 ? 8 : 1;
-                    auto drain = [&](bool blocking) {
+                    auto drain = [&](bool blocking) __attribute__((always_inline)) {
                         pl.it = 0;
                         while (nextl[k] < l && !pl.dead) {
                             const int base = nextl[k];
                             unsigned long long q[8];
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) if (blocking || j < kNb) q[j] = LDSU64(k * kSkipLdsWords + ((base + j) & 31) * 64 + lane);
+                            for (int j = 0; j < 8; ++j)
+                                if (blocking || j < kNb) q[j] = LDSU64(k * SW + (base + j < NL ? base + j : NL - 1) * 64 + lane);
                             bool go = true;
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
@@ -601,7 +706,7 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
                             }
                         }
                     };
-                    XMARK(ROLE_SKIP0 + g, 10 + i);
+                    XMARK(ROLE_SKIP0 + g, 10 + si);
                     // ONE load per round (every load of a polling round adds to its round trip): lanes 0-31 fetch z[0..15] twice, lanes
                     // 32-63 z[16..31] twice; v_permlane32_swap makes the two dot operands of it
                     unsigned long long qz;
@@ -616,20 +721,20 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
                     if ((INSTR & 1) && pl.dead && g == 0 && lane == 0) {   // bring-up: what the abandoned poll last saw
                         xb_store(rs, (int)XcdExch::MARK + 176 + v * 4, 0, g_tag(qz), __uint_as_float(g_tag(qz)));
                         xb_store(rs, (int)XcdExch::MARK + 177 + v * 4, 0, (unsigned)l, __uint_as_float((unsigned)pl.it));
-                        xb_store(rs, (int)XcdExch::MARK + 178 + v * 4, 0, tag, __uint_as_float((unsigned)i));
+                        xb_store(rs, (int)XcdExch::MARK + 178 + v * 4, 0, tag, __uint_as_float((unsigned)si));
                     }
                     if (pl.dead) break;
                     if (!summer && k == 0) {
                         const unsigned long long now = __builtin_amdgcn_s_memtime();
-                        if (i == 0) { const unsigned long long d = now - seen[0]; period = (seen[0] != 0 && d < (1ull << 18)) ? d : 0; }
-                        seen[i] = now;
+                        if (si == 0) { const unsigned long long d = now - seen[0]; period = (seen[0] != 0 && d < (1ull << 18)) ? d : 0; }
+                        seen[si] = now;
                     }
                     XSTAMP(g == 0 && summer && l == NL - 1, 20);
                     const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)qz, (unsigned)qz, false, false);   // [lo, lo], [hi, hi]
-                    float val = dot32_dpp(ws[i].w, __uint_as_float(sw[0]), __uint_as_float(sw[1]));              // model.py:96
-                    if (use_bias) val = val + bs[i];
+                    float val = dot(__uint_as_float(sw[0]), __uint_as_float(sw[1]));                             // model.py:96
+                    if (use_bias) val = val + bias;
                     if (!summer) {
-                        LDSU64(k * kSkipLdsWords + l * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(val);
+                        LDSU64(k * SW + l * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(val);
                     } else {
                         drain(true);                                       // whatever is still missing below this layer
                         tot[k] = (l == 0) ? val : tot[k] + val;
@@ -642,6 +747,15 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
                     }
                 }
             }
+        };
+#pragma unroll
+        for (int j = 0; j < kLds; ++j) {
+            if (j < nlds && !pl.dead)
+                own_layer([&](float xa_, float xb_) __attribute__((always_inline)) { return dot32_dpp_lds(o_tile4 + (v + 8 * j) * (kTile / 4), lane, xa_, xb_); }, bs[j], v + 8 * j, j);
+        }
+#pragma unroll
+        for (int i = 0; i < kReg; ++i) {
+            if (i < nown && !pl.dead) own_layer([&](float xa_, float xb_) __attribute__((always_inline)) { return dot32_dpp(ws[i].w, xa_, xb_); }, bs[kLds + i], NLDS + v + 8 * i, kLds + i);
         }
     }
     if (pl.dead && lane == 0) {
@@ -751,7 +865,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
 //  LC workgroups: model.py:102-111 create_upsample (row by row) and model.py:75-83 lc_filter|lc_gate of every layer,
 //  ahead of the chain through the ring XcdExch::LCR.  Wave gw owns layers gw*lpw .. gw*lpw+lpw-1 (NLC tiles each).
 // =====================================================================================================================
-template <int INSTR, int NS>
+template <int INSTR, int NS, bool BIG>
 __device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx, int wg)
 {
     const XcdLaunch& a = xa.p;
@@ -767,9 +881,10 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx,
     const int* hdr = reinterpret_cast<const int*>(a.cond);
     const int mode = hdr[XH_MODE], rows = hdr[XH_ROWS];
     const float* payload = a.cond + XH_WORDS + (long long)a.B * NL * 64;
-    Tile lt[4];
+    constexpr int kLt = BIG ? 6 : 4;                                      // register tiles per wave (BIG: two layers of three chunks)
+    Tile lt[kLt];
 #pragma unroll
-    for (int idx = 0; idx < 4; ++idx) {
+    for (int idx = 0; idx < kLt; ++idx) {
         if (idx < nown * NLC) {
             const int j = idx / NLC, c = idx - j * NLC;
             load_tile(lt[idx], a.P + L.off_lcw + (long long)(lfirst + j) * L.lcw_stride + (long long)c * kTile, lane);
@@ -856,9 +971,9 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx,
                 }
             }
             // ---- projections: AC-1 chunks of 32 over the lc channels, chunk values added in order
-            float resx[4];
+            float resx[kLt];
 #pragma unroll
-            for (int idx = 0; idx < 4; ++idx) {
+            for (int idx = 0; idx < kLt; ++idx) {
                 resx[idx] = 0.0f;
                 if (idx < nown * NLC) {
                     const int j = idx / NLC, c = idx - j * NLC;
@@ -869,15 +984,15 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx,
             }
             // combine per layer in chunk order (indices are compile-time; j, c are uniform)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < kLt; ++j) {
                 if (j < nown) {
                     float r = 0.0f;
 #pragma unroll
-                    for (int idx = 0; idx < 4; ++idx) {
+                    for (int idx = 0; idx < kLt; ++idx) {
                         if (idx >= j * NLC && idx < (j + 1) * NLC) r = (idx == j * NLC) ? resx[idx] : r + resx[idx];
                     }
                     const int l = lfirst + j;
-                    if (u + 1 < T) xb_store(rs, (int)XcdExch::LCR + (((u + 1) % kXcdLcRing) * 32 + l) * 64, lane, (unsigned)u + 2u, r);
+                    if (u + 1 < T) xb_store(rs, (int)XcdExch::LCR + (((u + 1) % kXcdLcRing) * kXcdLs + l) * 64, lane, (unsigned)u + 2u, r);
                     else (a.state + (long long)b * L.state_stride)[L.st_lcprev + l * 64 + lane] = r;    // the frame the NEXT call uses at its step 0
                 }
             }
@@ -897,7 +1012,10 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx,
     }
 }
 
-template <int INSTR>
+// BIGK: the instantiation for 31-50 layers (second chain workgroup, helper waves with LDS-resident early tiles).  It is a kernel of
+// its own so that the register allocation of the 30-layer kernel is not touched by it (as ONE kernel the sampling loop of the bench
+// configuration ran at 13.3 instead of 10.4 us per step).
+template <int INSTR, bool BIGK>
 __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
 {
     const XcdLaunch& a = xa.p;
@@ -914,37 +1032,52 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
     for (int i = threadIdx.x; i < kXcdStreamsPerXcd * kSkipLdsWords * 2 + 64; i += blockDim.x) lds[i] = 0.0f;
     __syncthreads();
     ticket = s_ticket;
-    // roles of an XCD with ns streams: ns chains, ns service workgroups, then ONE set of 8 skip + 8 conv1 + n_lc workgroups
+    // roles of an XCD with ns streams: ns chains (of one or two workgroups), ns service workgroups, then ONE set of 8 skip + 8 conv1 +
+    // n_lc workgroups
     const int ns = xcc < (unsigned)a.B && xcc < 8u ? (a.B - (int)xcc + 7) / 8 : 0;
-    if (ticket >= 2 * ns + 16 + xa.n_lc_wg) return;             // surplus workgroup (or an XCD without a stream)
+    constexpr int nseg = BIGK ? 2 : 1;
+    const int nchain = ns * nseg;
+    if (ticket >= nchain + ns + 16 + xa.n_lc_wg) return;        // surplus workgroup (or an XCD without a stream)
     const bool forced = a.forced != nullptr;
     auto exch_of = [&](int b) { return __builtin_amdgcn_make_buffer_rsrc(a.exch + (long long)b * XcdExch::WORDS, 0, (int)(XcdExch::WORDS * 8), 0x00020000); };
-    if (ticket < 2 * ns) {
-        const int b = (int)xcc + 8 * (ticket < ns ? ticket : ticket - ns);
+    if (ticket < nchain + ns) {
+        const int k = ticket < nchain ? ticket / nseg : ticket - nchain;
+        const int b = (int)xcc + 8 * k;
         const rsrc_t rs = exch_of(b);
-        if (ticket < ns) {
-            // hparams default (biases, gc, lc all present): no selects on the dependency chain
-            if (forced) chain_role<INSTR, false, true>(xa, b, rs);
-            else if (a.lay.use_bias && a.lay.G > 0 && a.lay.L > 0) chain_role<INSTR, true, false>(xa, b, rs);
-            else chain_role<INSTR, false, false>(xa, b, rs);
+        if (ticket < nchain) {
+            const bool all = a.lay.use_bias && a.lay.G > 0 && a.lay.L > 0;       // hparams default: no selects on the dependency chain
+            if (ticket % nseg == 0) {
+                if (forced) chain_role<INSTR, false, true, false, BIGK>(xa, b, rs);
+                else if (all) chain_role<INSTR, true, false, false, BIGK>(xa, b, rs);
+                else chain_role<INSTR, false, false, false, BIGK>(xa, b, rs);
+            } else if constexpr (BIGK) {
+                if (forced) chain_role<INSTR, false, true, true, true>(xa, b, rs);
+                else if (all) chain_role<INSTR, true, false, true, true>(xa, b, rs);
+                else chain_role<INSTR, false, false, true, true>(xa, b, rs);
+            }
         }
-        else service_role<INSTR>(xa, b, rs);
+        else service_role<INSTR, BIGK>(xa, b, rs);
         return;
     }
-    const int role = ticket - 2 * ns;                            // 0-7 skip, 8-15 conv1, 16.. lc
+    const int role = ticket - nchain - ns;                       // 0-7 skip, 8-15 conv1, 16.. lc
     auto shared_roles = [&](auto nsc) {
         constexpr int NS = decltype(nsc)::value;
         XStreams<NS> sx;
 #pragma unroll
         for (int k = 0; k < NS; ++k) { sx.b[k] = (int)xcc + 8 * k; sx.rs[k] = exch_of(sx.b[k]); }
-        if (role < 8) { if (!forced) skip_role<INSTR, NS>(xa, sx, role); }
+        if (role < 8) { if (!forced) skip_role<INSTR, NS, BIGK>(xa, sx, role); }
         else if (role < 16) { if (!forced) conv1_role<INSTR, NS>(xa, sx, role - 8); }
-        else lc_role<INSTR, NS>(xa, sx, role - 16);
+        else lc_role<INSTR, NS, BIGK>(xa, sx, role - 16);
     };
-    if (ns == 1) shared_roles(std::integral_constant<int, 1>{});
-    else if (ns == 2) shared_roles(std::integral_constant<int, 2>{});
-    else if (ns == 3) shared_roles(std::integral_constant<int, 3>{});
-    else shared_roles(std::integral_constant<int, 4>{});
+    if constexpr (BIGK) {                                         // at most two streams per XCD (LDS of the skip workgroups)
+        if (ns == 1) shared_roles(std::integral_constant<int, 1>{});
+        else shared_roles(std::integral_constant<int, 2>{});
+    } else {
+        if (ns == 1) shared_roles(std::integral_constant<int, 1>{});
+        else if (ns == 2) shared_roles(std::integral_constant<int, 2>{});
+        else if (ns == 3) shared_roles(std::integral_constant<int, 3>{});
+        else shared_roles(std::integral_constant<int, 4>{});
+    }
 }
 
 // ---- pack: the chain's register images from the canonical blob (generate.py:157-161 Saver.restore) -------------------------
@@ -989,7 +1122,7 @@ bool xcd_model_ok(const Layout& L)
 {
     return L.scalar && L.ifw == 32 && L.S == 512 && L.O <= 32 && L.NOJ == 1 && L.NL >= 1 && L.NL <= kXcdMaxLayers && L.NLC <= 4;
 }
-static int lc_layers_per_wave(const Layout& L) { const int n = L.NLC > 0 ? 4 / L.NLC : 1; return n < 1 ? 1 : n; }
+static int lc_layers_per_wave(const Layout& L) { const int n = L.NLC > 0 ? (L.NL > kXcdSeg0Layers ? 6 : 4) / L.NLC : 1; return n < 1 ? 1 : (n > 4 ? 4 : n); }
 int xcd_lc_workgroups(const Layout& L)
 {
     if (L.L == 0) return 0;
@@ -1009,7 +1142,9 @@ int xcd_launch(const XcdLaunch& p, hipStream_t st)
     xa.p = p;
     xa.n_lc_wg = xcd_lc_workgroups(p.lay);
     xa.lc_lpw = lc_layers_per_wave(p.lay);
-    const size_t shm = (size_t)(2048 + 32 * 1024) * 4;            // chain workgroup: hand-off boxes + the dense kernels of every layer (130 KiB)
+    // chain workgroup: hand-off boxes + the dense kernels of its layers (136 KiB); more than 32 layers: the skip / service workgroups
+    // keep the tiles of layers 0 .. NL-41 in LDS next to their value slots (159 KiB of the CU's 160)
+    const size_t shm = p.lay.NL > kXcdSeg0Layers ? (size_t)159 * 1024 : (size_t)(2048 + 32 * 1024) * 4;
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
@@ -1019,10 +1154,14 @@ int xcd_launch(const XcdLaunch& p, hipStream_t st)
     const int grid = 2 * cus;
     // instrumented builds are separate instantiations: 1 = phase stamps / stage markers, 2 = per-layer dumps
     const int instr = (p.prof != nullptr ? 1 : 0) | (p.dbg != nullptr ? 2 : 0);
-    if (instr == 3) hipLaunchKernelGGL(wn_xcd_generate_kernel<3>, dim3(grid), dim3(512), shm, st, xa);
-    else if (instr == 2) hipLaunchKernelGGL(wn_xcd_generate_kernel<2>, dim3(grid), dim3(512), shm, st, xa);
-    else if (instr == 1) hipLaunchKernelGGL(wn_xcd_generate_kernel<1>, dim3(grid), dim3(512), shm, st, xa);
-    else hipLaunchKernelGGL(wn_xcd_generate_kernel<0>, dim3(grid), dim3(512), shm, st, xa);
+    if (p.lay.NL > kXcdSeg0Layers) {
+        if (instr != 0) return twv_fail(TWV_E_UNSUPPORTED, "layer dumps / phase stamps exist for the 30-layer XCD kernel only (set option \"xcd\" = 0 for the generic kernel)");
+        hipLaunchKernelGGL((wn_xcd_generate_kernel<0, true>), dim3(grid), dim3(512), shm, st, xa);
+    }
+    else if (instr == 3) hipLaunchKernelGGL((wn_xcd_generate_kernel<3, false>), dim3(grid), dim3(512), shm, st, xa);
+    else if (instr == 2) hipLaunchKernelGGL((wn_xcd_generate_kernel<2, false>), dim3(grid), dim3(512), shm, st, xa);
+    else if (instr == 1) hipLaunchKernelGGL((wn_xcd_generate_kernel<1, false>), dim3(grid), dim3(512), shm, st, xa);
+    else hipLaunchKernelGGL((wn_xcd_generate_kernel<0, false>), dim3(grid), dim3(512), shm, st, xa);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return twv_fail(TWV_E_HIP, std::string("xcd launch: ") + hipGetErrorString(e));
     return TWV_OK;

@@ -7,7 +7,9 @@
 
 namespace twv {
 
-constexpr int kXcdMaxLayers = 31;      // chain workgroup: wave 0 holds the causal layer + 3 layers, waves 1..7 four layers each
+constexpr int kXcdSeg0Layers = 30;     // first chain workgroup: waves 0..5 four layers each, waves 6 and 7 three (wave 7 also runs the causal layer + sampler)
+constexpr int kXcdMaxLayers = 50;      // a second chain workgroup takes layers 30.. (hparams.py has 50); limit: LDS of the service workgroup (tiles of layers 0 .. NL-33) and of the skip workgroups (value slots of two streams + tiles of layers 0 .. NL-41)
+constexpr int kXcdLs = 64;             // layer slots of the per-layer exchange arrays
 constexpr int kXcdStreams = 32;        // up to four streams per XCD (stream b runs on XCD b % 8)
 constexpr int kXcdLcRing = 16;         // steps of lc projections the lc workgroups may run ahead of the chain
 constexpr int kXcdXlFloats = 13 * 64 * 4;   // per layer: the chain's register image [13 float4][64 lanes]
@@ -20,15 +22,18 @@ enum { XLC_NONE = 0, XLC_UPSAMPLED = 1, XLC_MEL = 2 };
 
 // exchange area of one stream, in 8-byte granules {tag, value}
 struct XcdExch {
-    static constexpr long long ZX = 0;                                  // [32][64] x {z, tag | layer input, tag}: chain -> skip | service
-    static constexpr long long PG = ZX + 32 * 128;                      // [32][64] tap-0 chunk                 service -> chain
-    static constexpr long long LG = PG + 32 * 64;                       // [32][64] lc projection               service -> chain
-    static constexpr long long H1 = LG + 32 * 64;                       // [512] relu(skip sum)                 skip -> conv1
+    static constexpr long long ZX = 0;                                  // [Ls][64] x {z, tag | layer input, tag}: chain -> skip | service
+    static constexpr long long PG = ZX + kXcdLs * 128;                  // [Ls][64] tap-0 chunk                 service -> chain
+    static constexpr long long LG = PG + kXcdLs * 64;                   // [Ls][64] lc projection               service -> chain
+    static constexpr long long H1 = LG + kXcdLs * 64;                   // [512] relu(skip sum)                 skip -> conv1
     static constexpr long long PT = H1 + 512;                           // [16][32] conv1d_2 chunk partials     conv1 -> sampler
-    static constexpr long long LCR = PT + 512;                          // [ring][32][64] lc projections        lc -> service
-    static constexpr long long CTRL = LCR + (long long)kXcdLcRing * 32 * 64;   // [64] progress, abort
+    static constexpr long long LCR = PT + 512;                          // [ring][Ls][64] lc projections        lc -> service
+    static constexpr long long CTRL = LCR + (long long)kXcdLcRing * kXcdLs * 64;   // [64] progress, abort
     static constexpr long long MARK = CTRL + 64;                        // [32 roles][8 waves] {step, stage} markers (instrumented build)
-    static constexpr long long WORDS = MARK + 256;
+    static constexpr long long SEG = MARK + 256;                        // [64] residual vector, first -> second chain workgroup (more than 30 layers)
+    static constexpr long long DONE = SEG + 64;                         // [64] end of a teacher-forced step, second chain workgroup -> head
+    static constexpr long long WORDS = DONE + 64;
+    // (slots of layers a model does not have are never touched: they cost address space, not cache)
 };
 
 struct XcdLaunch {

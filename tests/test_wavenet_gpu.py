@@ -368,6 +368,55 @@ def test_xcd_kernel_shapes(torch_cuda, oracle, nl, use_bias, G, L, O):
     assert first_mismatch(got, want) is None, first_mismatch(got, want)
 
 
+@pytest.mark.parametrize("nl,B", [(31, 3), (33, 2), (41, 9), (50, 2), (50, 16)])
+def test_xcd_kernel_more_than_30_layers(torch_cuda, oracle, nl, B):
+    """hparams.py's default stack has 50 layers: a second chain workgroup takes layers 30.., the service / skip waves keep the tiles
+    of the early layers in LDS, two lc layers per wave; B = 9 and 16 put two streams on an XCD.  Chunked calls, bit for bit."""
+    dil = ([2 ** i for i in range(10)] * 5)[:nl]
+    d, tensors, blob = make_case(oracle, dil, seed=nl)
+    m = make_model(B, dil, tensors)
+    assert m.fused_conditioning(), "up to 50 layers are served by the XCD kernel on an MI355X"
+    rng = np.random.RandomState(nl + B)
+    T = 900
+    mel = rng.uniform(-4, 4, (B, 3, 80)).astype(np.float32)
+    gc = (np.arange(B) % 2).astype(np.int32)
+    seed_in = (2 * rng.rand(B) - 1).astype(np.float32)
+    u = mol_uniforms(B, T, 10)
+    oracle.set_threads(min(B, oracle.set_threads(1)))
+    try:
+        want = oracle.generate_mol(d, blob, oracle.State(d, B), oracle.upsample(d, blob, mel), gc, seed_in, u)
+    finally:
+        oracle.set_threads(1)
+    U = m.create_upsample(mel)
+    a = m.generate(U[:, :600].contiguous(), gc, seed_in, u[:, :600]).cpu().numpy()
+    b = m.generate(U[:, 600:].contiguous(), gc, a[:, -1], u[:, 600:]).cpu().numpy()
+    got = np.concatenate([a, b], axis=1)
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+
+
+def test_xcd_kernel_priming_50_layers(torch_cuda, oracle):
+    """teacher-forced steps through both chain workgroups (the end of a step travels back to the head through L2)"""
+    dil = [2 ** i for i in range(6)] * 8 + [1, 2]
+    B, T = 2, 300
+    d, tensors, blob = make_case(oracle, dil, scale=0.1)
+    m = make_model(B, dil, tensors)
+    assert len(dil) == 50 and m.fused_conditioning()
+    rf = oracle.receptive_field(d)
+    rng = np.random.RandomState(4)
+    seedwave = rng.uniform(-1, 1, (B, rf)).astype(np.float32)
+    mel = rng.uniform(-4, 4, (B, 1, 80)).astype(np.float32)
+    gc = np.array([1, 0], np.int32)
+    st = oracle.State(d, B)
+    zeros = np.zeros((B, 80), np.float32)
+    for i in range(rf - 1):
+        oracle.step(d, blob, st, seedwave[:, i], zeros, gc)
+    u = mol_uniforms(B, T, 10)
+    want = oracle.generate_mol(d, blob, st, oracle.upsample(d, blob, mel), gc, seedwave[:, -1], u)
+    m.prime(seedwave[:, :rf - 1], None, gc)
+    got = m.generate(m.create_upsample(mel), gc, seedwave[:, -1], u).cpu().numpy()
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+
+
 def test_generate_cli(torch_cuda, tmp_path):
     """generate.py surface: flags, params.json override, output files (generate.py:52-69,109,261)"""
     import json
