@@ -124,7 +124,7 @@ def main():
     T = Tm * hp.hop_size
     tensors = None
 
-    def make_vocoder(B):
+    def make_vocoder(B, dil=dil, own_weights=False):
         nonlocal tensors
         m = WaveNetModel(B, dil, hp.filter_width, hp.residual_channels, hp.dilation_channels, hp.skip_channels,
                          quantization_channels=hp.quantization_channels, out_channels=hp.out_channels, use_biases=hp.use_biases,
@@ -135,6 +135,9 @@ def main():
             m.set_option("xcd", args.xcd)
         if args.groups >= 0:
             m.set_option("groups", args.groups)
+        if own_weights:
+            m.load_weights(W.random_tensors(m.specs, seed=0, scale=0.05))
+            return m
         if tensors is None:
             tensors = W.random_tensors(m.specs, seed=0, scale=0.05)
         m.load_weights(tensors)
@@ -290,6 +293,22 @@ def main():
                 except Exception as e:
                     sweep.append({"streams": Bs, "error": repr(e)})
             res["streams_sweep"] = sweep
+            # hparams.py's own default stack is 5 x [1..512] = 50 layers (BASELINE configs[1] quotes 30): the same pass at B = 8 x 1 s
+            try:
+                m50 = make_vocoder(B, dil=[2 ** i for i in range(10)] * 5, own_weights=True)
+                inp = make_inputs(B, T1, 77)
+                one_pass(m50, B, T1, *inp)
+                torch.cuda.synchronize()
+                _o, (s0, s1), _c2 = one_pass(m50, B, T1, *inp)
+                torch.cuda.synchronize()
+                kms = s0.elapsed_time(s1)
+                _lib.check(m50._L.twv_wavenet_status(C.c_void_p(m50._status.data_ptr()), None))
+                res["hparams_default_50_layers"] = {"streams": B, "samples_per_s": B * T1 / (kms * 1e-3), "us_per_generation_step": kms * 1e3 / T1,
+                                                    "realtime_factor_per_stream": T1 / (kms * 1e-3) / hp.sample_rate,
+                                                    "kernel": "wn_xcd_generate_kernel" if m50.fused_conditioning() else "wn_generate_kernel"}
+                del m50
+            except Exception as e:
+                res["hparams_default_50_layers"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle as O
             d = O.make_dims(dil)

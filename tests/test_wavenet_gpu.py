@@ -349,7 +349,8 @@ def test_xcd_kernel_priming_then_generation(torch_cuda, oracle, B):
 
 
 @pytest.mark.parametrize("nl,use_bias,G,L,O", [(1, True, 32, 80, 30), (5, True, 32, 80, 30), (9, False, 32, 80, 30), (24, True, 0, 80, 30),
-                                             (25, True, 32, 0, 30), (28, False, 0, 0, 3), (30, True, 32, 80, 6)])
+                                             (25, True, 32, 0, 30), (28, False, 0, 0, 3), (30, True, 32, 80, 6), (35, False, 0, 0, 3),
+                                             (44, True, 0, 80, 30), (47, True, 32, 0, 9)])
 def test_xcd_kernel_shapes(torch_cuda, oracle, nl, use_bias, G, L, O):
     """the XCD kernel away from the bench shape: layer counts that end inside / at the edge of a chain wave, no biases, no global /
     local conditioning (the chain's general instantiation), other mixture sizes; B = 3 leaves five XCDs idle"""
@@ -394,13 +395,14 @@ def test_xcd_kernel_more_than_30_layers(torch_cuda, oracle, nl, B):
     assert first_mismatch(got, want) is None, first_mismatch(got, want)
 
 
-def test_xcd_kernel_priming_50_layers(torch_cuda, oracle):
+@pytest.mark.parametrize("nl", [31, 50])
+def test_xcd_kernel_priming_two_chain_workgroups(torch_cuda, oracle, nl):
     """teacher-forced steps through both chain workgroups (the end of a step travels back to the head through L2)"""
-    dil = [2 ** i for i in range(6)] * 8 + [1, 2]
+    dil = ([2 ** i for i in range(6)] * 9)[:nl]
     B, T = 2, 300
     d, tensors, blob = make_case(oracle, dil, scale=0.1)
     m = make_model(B, dil, tensors)
-    assert len(dil) == 50 and m.fused_conditioning()
+    assert m.fused_conditioning()
     rf = oracle.receptive_field(d)
     rng = np.random.RandomState(4)
     seedwave = rng.uniform(-1, 1, (B, rf)).astype(np.float32)
