@@ -1012,10 +1012,10 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx,
     }
 }
 
-// BIGK: the instantiation for 31-50 layers (second chain workgroup, helper waves with LDS-resident early tiles).  It is a kernel of
+// ONE: see xcd_launch.  BIGK: the instantiation for 31-50 layers (second chain workgroup, helper waves with LDS-resident early tiles).  It is a kernel of
 // its own so that the register allocation of the 30-layer kernel is not touched by it (as ONE kernel the sampling loop of the bench
 // configuration ran at 13.3 instead of 10.4 us per step).
-template <int INSTR, bool BIGK>
+template <int INSTR, bool BIGK, bool ONE>
 __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
 {
     const XcdLaunch& a = xa.p;
@@ -1072,6 +1072,8 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
     if constexpr (BIGK) {                                         // at most two streams per XCD (LDS of the skip workgroups)
         if (ns == 1) shared_roles(std::integral_constant<int, 1>{});
         else shared_roles(std::integral_constant<int, 2>{});
+    } else if constexpr (ONE) {                                   // batch <= 8 (see xcd_launch)
+        shared_roles(std::integral_constant<int, 1>{});
     } else {
         if (ns == 1) shared_roles(std::integral_constant<int, 1>{});
         else if (ns == 2) shared_roles(std::integral_constant<int, 2>{});
@@ -1156,12 +1158,16 @@ int xcd_launch(const XcdLaunch& p, hipStream_t st)
     const int instr = (p.prof != nullptr ? 1 : 0) | (p.dbg != nullptr ? 2 : 0);
     if (p.lay.NL > kXcdSeg0Layers) {
         if (instr != 0) return twv_fail(TWV_E_UNSUPPORTED, "layer dumps / phase stamps exist for the 30-layer XCD kernel only (set option \"xcd\" = 0 for the generic kernel)");
-        hipLaunchKernelGGL((wn_xcd_generate_kernel<0, true>), dim3(grid), dim3(512), shm, st, xa);
+        hipLaunchKernelGGL((wn_xcd_generate_kernel<0, true, false>), dim3(grid), dim3(512), shm, st, xa);
     }
-    else if (instr == 3) hipLaunchKernelGGL((wn_xcd_generate_kernel<3, false>), dim3(grid), dim3(512), shm, st, xa);
-    else if (instr == 2) hipLaunchKernelGGL((wn_xcd_generate_kernel<2, false>), dim3(grid), dim3(512), shm, st, xa);
-    else if (instr == 1) hipLaunchKernelGGL((wn_xcd_generate_kernel<1, false>), dim3(grid), dim3(512), shm, st, xa);
-    else hipLaunchKernelGGL((wn_xcd_generate_kernel<0, false>), dim3(grid), dim3(512), shm, st, xa);
+    else if (instr == 3) hipLaunchKernelGGL((wn_xcd_generate_kernel<3, false, false>), dim3(grid), dim3(512), shm, st, xa);
+    else if (instr == 2) hipLaunchKernelGGL((wn_xcd_generate_kernel<2, false, false>), dim3(grid), dim3(512), shm, st, xa);
+    else if (instr == 1) hipLaunchKernelGGL((wn_xcd_generate_kernel<1, false, false>), dim3(grid), dim3(512), shm, st, xa);
+    // ONE: batch <= 8 (one stream per XCD) without the multi-stream roles compiled into the kernel: the register allocation of the
+    // sampling loop depends on what shares the kernel (measured on one box, interleaved: 10.42 against 10.59 us/step; specialising
+    // further -- only the hparams-default sampling chain in the kernel -- gave 10.61 again: it is allocation luck, not a trend)
+    else if (p.B <= 8) hipLaunchKernelGGL((wn_xcd_generate_kernel<0, false, true>), dim3(grid), dim3(512), shm, st, xa);
+    else hipLaunchKernelGGL((wn_xcd_generate_kernel<0, false, false>), dim3(grid), dim3(512), shm, st, xa);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return twv_fail(TWV_E_HIP, std::string("xcd launch: ") + hipGetErrorString(e));
     return TWV_OK;
