@@ -18,6 +18,12 @@
 #include <hip/hip_runtime.h>
 #include "twv_math.hpp"
 
+// 8-byte instructions (v_fmac_f32_dpp is VOP2 + a DPP dword) issue measurably slower when they sit at an address of 4 mod 8: the same
+// chain loop ran at 10.42 or 10.60 us per generation step depending on whether unrelated code had shifted it by an odd number of
+// dwords (scan over 16 paddings: every even one fast, every odd one slow; profiles/r02_chain_alignment_scan.txt).  Every block of
+// DPP fmacs therefore starts 8-byte aligned (the assembler pads with one s_nop where needed).
+#define TWV_ALIGN8 "\t.p2align 3\n"
+
 namespace twv {
 
 __host__ __device__ inline int dpp_a(int n) { return 4 * (n >> 1) + (n & 1); }
@@ -42,7 +48,7 @@ __device__ __forceinline__ float dot32_dpp(const float (&w)[32], float xa, float
 {
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
     asm volatile(
-        "s_nop 1\n"
+        "s_nop 1\n" TWV_ALIGN8
         "v_fmac_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
@@ -62,7 +68,7 @@ __device__ __forceinline__ float dot32_dpp(const float (&w)[32], float xa, float
         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
         : "v"(xa), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
     asm volatile(
-        "s_nop 1\n"
+        "s_nop 1\n" TWV_ALIGN8
         "v_fmac_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
@@ -91,7 +97,7 @@ __device__ __forceinline__ void dot32_dpp_x2(const float (&wa)[32], float xa0, f
 {
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
     asm volatile(
-        "s_nop 1\n"
+        "s_nop 1\n" TWV_ALIGN8
         "v_fmac_f32_dpp %0, %8, %10 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %4, %9, %18 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %1, %8, %11 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
@@ -111,7 +117,7 @@ __device__ __forceinline__ void dot32_dpp_x2(const float (&wa)[32], float xa0, f
         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
         : "v"(xa0), "v"(xa1), "v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "v"(wa[4]), "v"(wa[5]), "v"(wa[6]), "v"(wa[7]), "v"(wb[0]), "v"(wb[1]), "v"(wb[2]), "v"(wb[3]), "v"(wb[4]), "v"(wb[5]), "v"(wb[6]), "v"(wb[7]));
     asm volatile(
-        "s_nop 1\n"
+        "s_nop 1\n" TWV_ALIGN8
         "v_fmac_f32_dpp %0, %8, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %4, %9, %18 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %1, %8, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
@@ -131,7 +137,7 @@ __device__ __forceinline__ void dot32_dpp_x2(const float (&wa)[32], float xa0, f
         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
         : "v"(xa0), "v"(xa1), "v"(wa[8]), "v"(wa[9]), "v"(wa[10]), "v"(wa[11]), "v"(wa[12]), "v"(wa[13]), "v"(wa[14]), "v"(wa[15]), "v"(wb[8]), "v"(wb[9]), "v"(wb[10]), "v"(wb[11]), "v"(wb[12]), "v"(wb[13]), "v"(wb[14]), "v"(wb[15]));
     asm volatile(
-        "s_nop 1\n"
+        "s_nop 1\n" TWV_ALIGN8
         "v_fmac_f32_dpp %0, %8, %10 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %4, %9, %18 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %1, %8, %11 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
@@ -151,7 +157,7 @@ __device__ __forceinline__ void dot32_dpp_x2(const float (&wa)[32], float xa0, f
         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
         : "v"(xb0), "v"(xb1), "v"(wa[16]), "v"(wa[17]), "v"(wa[18]), "v"(wa[19]), "v"(wa[20]), "v"(wa[21]), "v"(wa[22]), "v"(wa[23]), "v"(wb[16]), "v"(wb[17]), "v"(wb[18]), "v"(wb[19]), "v"(wb[20]), "v"(wb[21]), "v"(wb[22]), "v"(wb[23]));
     asm volatile(
-        "s_nop 1\n"
+        "s_nop 1\n" TWV_ALIGN8
         "v_fmac_f32_dpp %0, %8, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %4, %9, %18 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %1, %8, %11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
@@ -179,7 +185,7 @@ __device__ __forceinline__ float dot16_dpp(const float (&w)[16], float z)
 {
     float c0 = 0.0f, c1 = 0.0f;
     asm volatile(
-        "s_nop 1\n"
+        "s_nop 1\n" TWV_ALIGN8
         "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
@@ -257,7 +263,7 @@ __device__ __forceinline__ void causal_partial_dpp(const float (&w)[32], float h
 {
     float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
     asm volatile(
-        "s_nop 1\n"
+        "s_nop 1\n" TWV_ALIGN8
         "v_fmac_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
@@ -277,7 +283,7 @@ __device__ __forceinline__ void causal_partial_dpp(const float (&w)[32], float h
         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
         : "v"(ha), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
     asm volatile(
-        "s_nop 1\n"
+        "s_nop 1\n" TWV_ALIGN8
         "v_fmac_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
         "v_fmac_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"

@@ -44,6 +44,11 @@
 
 using namespace twv;
 
+#ifndef TWV_CHAIN_PAD
+#define TWV_CHAIN_PAD 0
+#endif
+#define TWV_STR2(x) #x
+#define TWV_STR(x) TWV_STR2(x)
 namespace {
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
@@ -223,6 +228,10 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
         causal_prepare();
     }
     __builtin_amdgcn_s_waitcnt(0);        // every register image and LDS copy has landed before the relay starts
+    // The step loop starts at a fixed offset inside a 64-byte fetch window: the same instructions with the same registers ran at
+    // 10.42 or 10.60 us/step depending on where unrelated code had pushed them (no instruction-cache misses either way; aligning
+    // every loop head gives the slow figure).  TWV_CHAIN_PAD nops after the alignment: scanned, see DESIGN.md section 4.
+    asm volatile(".p2align 6\n\t.rept " TWV_STR(TWV_CHAIN_PAD) "\n\ts_nop 0\n\t.endr" ::: "memory");
 
     float X = 0.0f;
     unsigned long long t_in = 0, in_period = 0;          // when this wave's input arrived in the previous step, and the step period
@@ -431,7 +440,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
 // in two halves of 16 registers (the same two blocks of 16 v_fmac_f32_dpp as dot32_dpp, twv_dpp.hpp)
 #define TWV_FMAC16_DPP(c0, c1, c2, c3, x, w)                                                          \
     asm volatile(                                                                                      \
-        "s_nop 1\n"                                                                                    \
+        "s_nop 1\n" TWV_ALIGN8                                                                         \
         "v_fmac_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"                        \
         "v_fmac_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"                        \
         "v_fmac_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"                        \
@@ -920,12 +929,11 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx,
         if (u + 3 - kXcdLcRing > 0) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                if (pl.dead) break;
                 const rsrc_t rs = sx.rs[k];
                 pl.rs = rs;
                 XMARK(ROLE_LC0 + wg, 1);
                 pl.it = 0;
-                for (;;) {
+                while (!pl.dead) {
                     const unsigned long long q = xb_load(rs, (int)XcdExch::CTRL, 0);
                     if ((int)g_tag(q) >= u + 3 - kXcdLcRing) break;
                     if (!poll_tick(pl, 72)) break;
