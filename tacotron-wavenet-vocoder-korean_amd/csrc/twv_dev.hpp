@@ -52,6 +52,7 @@ __device__ __forceinline__ float dot_readlane_pipe_a(const float (&tw)[32], floa
     f32x2p a, b;
     asm volatile(
         "s_nop 1\n"                                    // the operand may come straight out of a VALU instruction: hazards inside inline asm are ours
+        "\t.p2align 3\n"                              // 8-byte instructions at 8-byte addresses (see TWV_ALIGN8, twv_dpp.hpp)
         "v_readlane_b32 s84, %[x], 0\n"
         "v_readlane_b32 s85, %[x], 1\n"
         "v_readlane_b32 s86, %[x], 2\n"
@@ -130,6 +131,7 @@ __device__ __forceinline__ float dot_readlane_pipe32(const Tile& t, float xv)
     f32x2p a, b;
     asm volatile(
         "s_nop 1\n"
+        "\t.p2align 3\n"
         "v_readlane_b32 s84, %[x], 32\n"
         "v_readlane_b32 s85, %[x], 33\n"
         "v_readlane_b32 s86, %[x], 34\n"
