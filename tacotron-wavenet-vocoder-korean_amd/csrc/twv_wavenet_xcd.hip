@@ -661,12 +661,24 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
             if (use_bias) bs[j] = a.P[lb + LayerOff::SK + (long long)L.NSJ * kTile + g * 64 + lane];
         }
     }
-    const bool summer = v == ((NL - 1 - NLDS) & 7);
+    // the wave that owns the last layer adds a stream's values up.  With three or four streams per XCD that wave was the busiest of the
+    // kernel (it set the step time at B = 32), so the streams from the third on are summed by a SECOND wave, the owner of layer NL-2,
+    // which keeps a copy of the last layer's tile for them.
+    constexpr bool SPLIT = NS >= 3 && !BIG;
+    const int vA = (NL - 1 - NLDS) & 7, vB = (SPLIT && NL >= 2) ? ((NL - 2) & 7) : -1;
+    const bool sumA = v == vA, sumB = v == vB, anysum = sumA || sumB;
+    Tile wx;                                                      // wave B: the last layer's tile
+    float bx = 0.0f;
+    if (SPLIT && sumB) {
+        const long long lb = L.off_layer0 + (long long)(NL - 1) * L.layer_stride;
+        load_tile(wx, a.P + lb + LayerOff::SK + (long long)g * kTile, lane);
+        if (use_bias) bx = a.P[lb + LayerOff::SK + (long long)L.NSJ * kTile + g * 64 + lane];
+    }
     const int n16 = lane & 15;
     const int zc_lane = lane_of_z((lane < 32 ? 0 : 16) + n16);
-    unsigned long long seen[kSlots], period = 0;                  // arrival times of the own layers (first stream) in the previous step
+    unsigned long long seen[kSlots + 1], period = 0;              // arrival times of the own layers (first stream served) in the previous step
 #pragma unroll
-    for (int i = 0; i < kSlots; ++i) seen[i] = 0;
+    for (int i = 0; i < kSlots + 1; ++i) seen[i] = 0;
     for (int t = 0; t < T && !pl.dead; ++t) {
         const unsigned tag = (unsigned)t + 1u;
         int nextl[NS];
@@ -674,9 +686,9 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
 #pragma unroll
         for (int k = 0; k < NS; ++k) { nextl[k] = 0; tot[k] = 0.0f; }
         // one own layer: `dot` multiplies by a register tile or (BIG, early layers) by a tile in LDS
-        auto own_layer = [&](auto&& dot, const float bias, const int l, const int si) __attribute__((always_inline)) {
+        auto own_layer = [&](auto&& dot, const float bias, const int l, const int si, const int k0, const int k1) __attribute__((always_inline)) {
             {
-                if (!summer && period) nap_until(seen[si] + period - (period >> 3));
+                if (!anysum && period) nap_until(seen[si] + period - (period >> 3));
                 // the XCD's streams in a fixed order (they settle a fraction of a microsecond apart).  Measured alternatives: polling all
                 // the streams still missing in one round and serving whichever arrived (every extra load of a polling round adds to
                 // its round trip: B = 32 ran at 16.5 instead of 13 us/step); requesting the next stream's granules while this stream's
@@ -684,6 +696,8 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
 #pragma unroll
                 for (int k = 0; k < NS; ++k) {
                     if (pl.dead) break;
+                    if (k < k0 || k >= k1) continue;                       // the last layer is served by two waves (see SPLIT)
+                    const bool summer = (SPLIT && vB >= 0) ? (k < 2 ? sumA : sumB) : sumA;     // of stream k
                     const rsrc_t rs = sx.rs[k];
                     const int b = sx.b[k];
                     pl.rs = rs;
@@ -733,7 +747,7 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
                         xb_store(rs, (int)XcdExch::MARK + 178 + v * 4, 0, tag, __uint_as_float((unsigned)si));
                     }
                     if (pl.dead) break;
-                    if (!summer && k == 0) {
+                    if (!anysum && k == 0) {
                         const unsigned long long now = __builtin_amdgcn_s_memtime();
                         if (si == 0) { const unsigned long long d = now - seen[0]; period = (seen[0] != 0 && d < (1ull << 18)) ? d : 0; }
                         seen[si] = now;
@@ -760,12 +774,18 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
 #pragma unroll
         for (int j = 0; j < kLds; ++j) {
             if (j < nlds && !pl.dead)
-                own_layer([&](float xa_, float xb_) __attribute__((always_inline)) { return dot32_dpp_lds(o_tile4 + (v + 8 * j) * (kTile / 4), lane, xa_, xb_); }, bs[j], v + 8 * j, j);
+                own_layer([&](float xa_, float xb_) __attribute__((always_inline)) { return dot32_dpp_lds(o_tile4 + (v + 8 * j) * (kTile / 4), lane, xa_, xb_); }, bs[j], v + 8 * j, j, 0, NS);
         }
 #pragma unroll
         for (int i = 0; i < kReg; ++i) {
-            if (i < nown && !pl.dead) own_layer([&](float xa_, float xb_) __attribute__((always_inline)) { return dot32_dpp(ws[i].w, xa_, xb_); }, bs[kLds + i], NLDS + v + 8 * i, kLds + i);
+            if (i < nown && !pl.dead) {
+                const int l = NLDS + v + 8 * i;
+                own_layer([&](float xa_, float xb_) __attribute__((always_inline)) { return dot32_dpp(ws[i].w, xa_, xb_); }, bs[kLds + i], l, kLds + i, 0,
+                          (SPLIT && vB >= 0 && l == NL - 1) ? 2 : NS);
+            }
         }
+        if (SPLIT && sumB && !pl.dead)
+            own_layer([&](float xa_, float xb_) __attribute__((always_inline)) { return dot32_dpp(wx.w, xa_, xb_); }, bx, NL - 1, kSlots, 2, NS);
     }
     if (pl.dead && lane == 0) {
 #pragma unroll
