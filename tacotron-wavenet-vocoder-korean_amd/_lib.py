@@ -59,10 +59,24 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return LIB_PATH
     hip = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
-    cmd = ["hipcc"] + HIPCC_FLAGS + ['-DTWV_SRC_HASH="%s"' % want] + hip + ["-o", LIB_PATH, "-L/opt/rocm/lib", "-lrocblas", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # one hipcc per source file, side by side (the generation kernels alone take a minute), then one link
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + ['-DTWV_SRC_HASH="%s"' % want]
+    with tempfile.TemporaryDirectory(prefix="twv_build_") as tmp:
+        def compile_one(src):
+            obj = os.path.join(tmp, os.path.basename(src) + ".o")
+            cmd = ["hipcc"] + cflags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            return obj
+        with ThreadPoolExecutor(max_workers=min(len(hip), os.cpu_count() or 1)) as pool:
+            objs = list(pool.map(compile_one, hip))
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH, "-L/opt/rocm/lib", "-lrocblas", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     with open(stamp, "w") as fh:
         fh.write(want + "\n")
     return LIB_PATH
