@@ -419,6 +419,20 @@ def test_xcd_kernel_priming_two_chain_workgroups(torch_cuda, oracle, nl):
     assert first_mismatch(got, want) is None, first_mismatch(got, want)
 
 
+def test_xcd_kernel_layer_dumps_need_the_30_layer_kernel(torch_cuda, oracle):
+    """the 31-50 layer instantiation has no instrumented build: asking for layer dumps fails loudly instead of returning nothing"""
+    import twvk_amd
+    dil = [1, 2, 4, 8] * 8
+    d, tensors, blob = make_case(oracle, dil)
+    m = make_model(1, dil, tensors)
+    mel = np.zeros((1, 1, 80), np.float32)
+    with pytest.raises(twvk_amd._lib.TwvError, match="30-layer"):
+        m.generate(m.create_upsample(mel), np.zeros(1, np.int32), np.zeros(1, np.float32), mol_uniforms(1, 8, 10), debug_steps=2)
+    m0 = make_model(1, dil, tensors, xcd=0)                       # the generic kernel serves the request
+    out, dump = m0.generate(m0.create_upsample(mel)[:, :8].contiguous(), np.zeros(1, np.int32), np.zeros(1, np.float32), mol_uniforms(1, 8, 10), debug_steps=2)
+    assert np.isfinite(dump.cpu().numpy()).all()
+
+
 def test_generate_cli(torch_cuda, tmp_path):
     """generate.py surface: flags, params.json override, output files (generate.py:52-69,109,261)"""
     import json
