@@ -806,8 +806,8 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
     const int T = a.T, NCH = L.NCH;
     const bool use_bias = L.use_bias != 0;
     Poll pl{sx.rs[0], a.status, 0, false};
-    constexpr int O_PART = 0, O_CNT = 16 * 64, O_ABORT = O_CNT + 1;      // LDS floats per stream: chunk partials | arrival counter | abort
-    if (threadIdx.x < NS) { LDSI(threadIdx.x * kConvLdsFloats + O_CNT) = 0; LDSI(threadIdx.x * kConvLdsFloats + O_ABORT) = 0; }
+    constexpr int O_PART = 0, O_CNT = 16 * 64;                            // LDS floats per stream: chunk partials | arrival counter
+    if (threadIdx.x < NS) LDSI(threadIdx.x * kConvLdsFloats + O_CNT) = 0;
     __syncthreads();
     const int c0 = 2 * v, c1 = 2 * v + 1;                                 // this wave's chunks
     Tile ta, tb;
@@ -886,7 +886,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
     }
     if (pl.dead && lane == 0) {
 #pragma unroll
-        for (int k = 0; k < NS; ++k) { LDSI(k * kConvLdsFloats + O_ABORT) = 1; xb_store(sx.rs[k], (int)XcdExch::CTRL + 1, 0, 1u, 0.0f); }
+        for (int k = 0; k < NS; ++k) xb_store(sx.rs[k], (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);       // the waves waiting on the LDS counter see it in poll_tick
     }
 }
 
