@@ -843,12 +843,8 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
                 __builtin_amdgcn_s_sleep(1);
             }
             if (pl.dead) break;
-            if (k == 0) {
-                const unsigned long long now = __builtin_amdgcn_s_memtime();
-                const unsigned long long d = now - t_arr;
-                period = (t_arr != 0 && d < (1ull << 18)) ? d : 0;
-                t_arr = now;
-            }
+            unsigned long long now_arr = 0;
+            if (k == 0) now_arr = __builtin_amdgcn_s_memtime();       // read only: the arithmetic follows the dots (as in the chain)
             XSTAMP(g == 0 && v == 0, 22);
             // rows r0..r3 of the wave = h1[64v + 16r ..]; the dots want "every row r0" / "every row r1" (chunk c0) and r2 / r3 (chunk c1)
             const unsigned hq = (unsigned)q;
@@ -861,6 +857,11 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
             lds[ob + O_PART + c1 * 64 + lane] = r1;
             asm volatile("" ::: "memory");
             if (lane == 0) __hip_atomic_fetch_add(&LDSI(ob + O_CNT), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (k == 0) {
+                const unsigned long long d = now_arr - t_arr;
+                period = (t_arr != 0 && d < (1ull << 18)) ? d : 0;
+                t_arr = now_arr;
+            }
             XSTAMP(g == 0 && v == 0, 23);
             XMARK(ROLE_CONV0 + g, 2);
             if (summer) {
