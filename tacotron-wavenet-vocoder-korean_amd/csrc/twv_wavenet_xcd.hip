@@ -101,6 +101,7 @@ struct Poll {
 };
 __device__ __forceinline__ bool poll_tick(Poll& p, int code)
 {
+    if (p.dead) return false;
     if (((++p.it) & 63) == 0) {
         if (xb_load(p.rs, (int)XcdExch::CTRL + 1, 0) != 0ull) { p.dead = true; return false; }
         if (p.it > (1 << 21)) {
@@ -151,7 +152,7 @@ constexpr int kConvLdsFloats = 16 * 64 + 64; // LDS floats per stream in a conv1
 //  CHAIN workgroup: model.py:41-46 causal layer (wave 0), model.py:66-101 residual layers (relay over the waves),
 //  mixture.py:84-114 sampler (wave 7)
 // =====================================================================================================================
-template <int INSTR, bool ALL, bool FORCED, bool SEG1, bool TWOSEG>
+template <int INSTR, bool ALL, bool FORCED, bool SEG1, bool TWOSEG, int NC>
 __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
 {
     const XcdLaunch& a = xa.p;
@@ -168,6 +169,9 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
     const int cap = SEG1 ? 4 : (w < 6 ? 4 : 3);
     int nl = NL - l0;
     nl = nl < 0 ? 0 : (nl > cap ? cap : nl);
+    // NC: the wave's layer count as a compile-time constant (4 or 3; -1: the run-time value) -- the step loop then carries no dispatch
+    // on the count (three compare-and-branch pairs on the wave-to-wave hand-off path)
+    const int nlc = NC >= 0 ? NC : nl;
     const bool next_has = (l0 + nl < NL);                      // a later wave continues the stack
     const bool head = !SEG1 && (w == 7);                       // sampler + causal layer
     const bool to_seg1 = TWOSEG && !SEG1 && w == 7 && next_has;     // the stack goes on in the second chain workgroup
@@ -268,13 +272,13 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
         XMARK(SEG1 ? 30 : ROLE_CHAIN, 1);
         // ---- (A) this step's tap-0 chunks and lc projections of the wave's layers (service workgroup; long since published)
         float pre[4] = {0.0f, 0.0f, 0.0f, 0.0f}, lcv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (nl > 0) {
+        if (nlc > 0) {
             pl.it = 0;
             for (;;) {
                 bool ok = true;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if (i < nl) {
+                    if (i < nlc) {
                         const unsigned long long qp = xb_load(rs, (int)XcdExch::PG + (l0 + i) * 64, oc);
                         const unsigned long long ql = xb_load(rs, (int)XcdExch::LG + (l0 + i) * 64, oc);
                         ok = ok && g_tag(qp) == tag && g_tag(ql) == tag;
@@ -285,7 +289,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                 if (!poll_tick(pl, 31)) break;
                 __builtin_amdgcn_s_sleep(4);
             }
-            if (pl.dead) break;
+            // (a watchdog abort ends the loop at its head: an exit here would make the compiler thread state flags through the hand-off path)
             XSTAMP(!SEG1, 26 + w);
             XMARK(SEG1 ? 30 : ROLE_CHAIN, 2);
             // ---- (B) the wave's input: the previous wave's residual vector (wave 0: the causal layer's output).  The wave sleeps
@@ -307,7 +311,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                     if (!poll_tick(pl, 33)) break;
                 }
             }
-            if (pl.dead) break;
+            // (a watchdog abort ends the loop at its head: an exit here would make the compiler thread state flags through the hand-off path)
             __builtin_amdgcn_s_setprio(3);
             X = g_val(q);
             now_in = __builtin_amdgcn_s_memtime();             // only READ here: the arithmetic on it waits until the layers are out (the
@@ -338,19 +342,22 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                 }
             }
         };
-        if (nl == 4) run_layers(std::integral_constant<int, 4>{});
-        else if (nl == 3) run_layers(std::integral_constant<int, 3>{});
-        else if (nl == 2) run_layers(std::integral_constant<int, 2>{});
-        else if (nl == 1) run_layers(std::integral_constant<int, 1>{});
+        if constexpr (NC > 0) run_layers(std::integral_constant<int, NC>{});
+        else {
+            if (nl == 4) run_layers(std::integral_constant<int, 4>{});
+            else if (nl == 3) run_layers(std::integral_constant<int, 3>{});
+            else if (nl == 2) run_layers(std::integral_constant<int, 2>{});
+            else if (nl == 1) run_layers(std::integral_constant<int, 1>{});
+        }
         if (to_seg1) xb_store(rs, (int)XcdExch::SEG, lane, tag, X);
-        else if (next_has && nl > 0) LDSU64((w + 1) * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(X);
+        else if (nlc > 0) LDSU64((next_has ? w + 1 : 9) * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(X);   // nobody reads box 9: no branch on the hand-off
         // teacher-forced steps (twv_wavenet_prime): nothing makes the head wait for the stack (there is no sample to wait for), so
         // the wave that runs the last layer reports the end of the step in box 8 and the head starts the next one after that
         if (forced && nl > 0 && !next_has) {
             if (SEG1) xb_store(rs, (int)XcdExch::DONE, lane, tag, 0.0f);
             else LDSU64(8 * 64 + lane) = (unsigned long long)tag << 32;
         }
-        if (nl > 0) {                                          // the wave's clock for its next nap (off the hand-off path)
+        if (nlc > 0) {                                         // the wave's clock for its next nap (off the hand-off path)
             const unsigned long long d = now_in - t_in;
             in_period = (t_in != 0 && d < (1ull << 18)) ? d : 0;
             t_in = now_in;
@@ -379,7 +386,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                 if (__all(good)) break;
                 if (!poll_tick(pl, 34)) break;
             }
-            if (pl.dead) break;
+            // (a watchdog abort ends the loop at its head: an exit here would make the compiler thread state flags through the hand-off path)
             XSTAMP(true, 18);
             XMARK(SEG1 ? 30 : ROLE_CHAIN, 5);
             float y = g_val(q[0]);                                     // chunk partials added in chunk order (AC-1)
@@ -747,7 +754,7 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
                         xb_store(rs, (int)XcdExch::MARK + 177 + v * 4, 0, (unsigned)l, __uint_as_float((unsigned)pl.it));
                         xb_store(rs, (int)XcdExch::MARK + 178 + v * 4, 0, tag, __uint_as_float((unsigned)si));
                     }
-                    if (pl.dead) break;
+                    // (no exit here on a watchdog abort: see the chain role; the loops end at their heads)
                     if (!anysum && k == 0) {
                         const unsigned long long now = __builtin_amdgcn_s_memtime();
                         if (si == 0) { const unsigned long long d = now - seen[0]; period = (seen[0] != 0 && d < (1ull << 18)) ? d : 0; }
@@ -842,7 +849,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
                 if (!poll_tick(pl, 61)) break;
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (pl.dead) break;
+            // (no exit here on a watchdog abort: see the chain role; the loops end at their heads)
             unsigned long long now_arr = 0;
             if (k == 0) now_arr = __builtin_amdgcn_s_memtime();       // read only: the arithmetic follows the dots (as in the chain)
             XSTAMP(g == 0 && v == 0, 22);
@@ -867,7 +874,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
             if (summer) {
                 pl.it = 0;
                 while (LDSVI(ob + O_CNT) < 8 * (t + 1)) { if (!poll_tick(pl, 62)) break; }
-                if (pl.dead) break;
+                // (no exit here on a watchdog abort: see the chain role; the loops end at their heads)
                 asm volatile("" ::: "memory");
                 XSTAMP(g == 0 && v == 0, 24);
                 float cp[16];
@@ -1077,13 +1084,18 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
         if (ticket < nchain) {
             const bool all = a.lay.use_bias && a.lay.G > 0 && a.lay.L > 0;       // hparams default: no selects on the dependency chain
             if (ticket % nseg == 0) {
-                if (forced) chain_role<INSTR, false, true, false, BIGK>(xa, b, rs);
-                else if (all) chain_role<INSTR, true, false, false, BIGK>(xa, b, rs);
-                else chain_role<INSTR, false, false, false, BIGK>(xa, b, rs);
+                // the sampling chain of the hparams-default model once per layer count of a wave (first chain workgroup: 4 or 3)
+                const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+                const int nlw = a.lay.NL - (wv < 6 ? 4 * wv : 24 + 3 * (wv - 6));
+                if (forced) chain_role<INSTR, false, true, false, BIGK, -1>(xa, b, rs);
+                else if (all && nlw >= 4 && wv < 6) chain_role<INSTR, true, false, false, BIGK, 4>(xa, b, rs);
+                else if (all && nlw >= 3 && wv >= 6) chain_role<INSTR, true, false, false, BIGK, 3>(xa, b, rs);
+                else if (all) chain_role<INSTR, true, false, false, BIGK, -1>(xa, b, rs);
+                else chain_role<INSTR, false, false, false, BIGK, -1>(xa, b, rs);
             } else if constexpr (BIGK) {
-                if (forced) chain_role<INSTR, false, true, true, true>(xa, b, rs);
-                else if (all) chain_role<INSTR, true, false, true, true>(xa, b, rs);
-                else chain_role<INSTR, false, false, true, true>(xa, b, rs);
+                if (forced) chain_role<INSTR, false, true, true, true, -1>(xa, b, rs);
+                else if (all) chain_role<INSTR, true, false, true, true, -1>(xa, b, rs);
+                else chain_role<INSTR, false, false, true, true, -1>(xa, b, rs);
             }
         }
         else service_role<INSTR, BIGK>(xa, b, rs);
