@@ -1093,7 +1093,9 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
                 else if (all) chain_role<INSTR, true, false, false, BIGK, -1>(xa, b, rs);
                 else chain_role<INSTR, false, false, false, BIGK, -1>(xa, b, rs);
             } else if constexpr (BIGK) {
+                const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
                 if (forced) chain_role<INSTR, false, true, true, true, -1>(xa, b, rs);
+                else if (all && a.lay.NL - kXcdSeg0Layers - 4 * wv >= 4) chain_role<INSTR, true, false, true, true, 4>(xa, b, rs);
                 else if (all) chain_role<INSTR, true, false, true, true, -1>(xa, b, rs);
                 else chain_role<INSTR, false, false, true, true, -1>(xa, b, rs);
             }
