@@ -18,15 +18,16 @@
 //                              the chain through a ring: neither the upsampled condition nor a projection table exists in HBM
 //     More than 30 layers (hparams.py's default stack has 50): a SECOND chain workgroup takes layers 30.. (one L2 hop away), the
 //     service / skip waves keep the tiles of the early layers in LDS (their values are needed last) and the lc waves hold two layers;
-//     this is a kernel instantiation of its own (BIGK), the 30-layer kernel's code is untouched by it: 16.2 us/step at 50 layers
+//     this is a kernel instantiation of its own (BIGK), the 30-layer kernel's code is untouched by it: 14.7 us/step at 50 layers
 //     against 32.9 on the generic kernel.
 //     The skip / conv1 / lc workgroups hold weights only, so with more than 8 streams ONE set per XCD serves the XCD's streams in
 //     turn (2 ns + 16 + n_lc <= 28 of the 32 CUs for ns = 4): the streams settle a fraction of a microsecond apart, B = 16 keeps
-//     the single-stream step time (10.6 us), B = 32 runs at 12.9 us (2.5 M samples/s).
+//     the single-stream step time (9.7 us), B = 32 runs at 10.8 us (2.97 M samples/s).
 //   * THE CHAIN IS A RELAY OF EIGHT WAVES.  A layer is 32 v_fmac_f32_dpp (row_newbcast feeds x[k] to the fma: no v_readlane,
 //     no LDS operand reads) -> bias/conditioning adds -> rational tanh/sigmoid -> v_permlane32_swap -> 16 v_fmac_f32_dpp +
-//     v_permlane16_swap for the dense 1x1 (twv_dpp.hpp): 203 ns per layer against 654 ns in wn_generate_kernel.  A wave hands
-//     the residual vector to the next one through a tagged LDS granule.  What is not on the sample-to-sample dependency chain
+//     v_permlane16_swap for the dense 1x1 (twv_dpp.hpp): 243 ns per layer in the product (200 for the arithmetic alone) against 654 ns
+//     in wn_generate_kernel.  A wave hands the residual vector to the next one through a tagged LDS granule (90 ns); nothing but
+//     the poll's exit sits between its arrival and the first layer (every branch there costs ~60 cycles: DESIGN.md section 4).  What is not on the sample-to-sample dependency chain
 //     (tap-0 chunks, which only need x[t-d]; lc projections; delay-line traffic) never touches the chain workgroup.
 //
 // Arithmetic: the contract of DESIGN.md (AC-1..AC-4); every dot product is the same fma chains in the same order as in
