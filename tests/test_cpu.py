@@ -606,3 +606,18 @@ def test_train_vocoder_directory_rules(tmp_path):
     ns = argparse.Namespace(logdir=str(tmp_path / "c"), logdir_root=None, restore_from=None)
     d = validate_directories(ns, hp)
     assert d["logdir"] == d["restore_from"] == str(tmp_path / "c")
+
+
+def test_bench_reports_counter_traffic_only_for_the_measured_sources(monkeypatch):
+    """roofline.traffic comes from profiles/traffic.json, keyed by the hash of the generation kernels' sources: the committed entry
+    belongs to THIS tree (a stale file would silently turn the field into null), any other code gets null"""
+    import importlib
+    import twvk_amd
+    bench = importlib.import_module("bench")
+    h = twvk_amd._lib.generation_hash()
+    assert h != twvk_amd._lib.source_hash() and len(h) == 16
+    got = bench.traffic_per_step("wn_xcd_generate_kernel", "B8_NL30")
+    assert got is not None and 3000.0 < got < 10000.0, "profiles/traffic.json is not keyed to the generation sources of this tree (re-run scripts/profile_generation.sh)"
+    assert bench.traffic_per_step("wn_xcd_generate_kernel", "B8_NL50") is None
+    monkeypatch.setattr(twvk_amd._lib, "generation_hash", lambda: "0" * 16)
+    assert bench.traffic_per_step("wn_xcd_generate_kernel", "B8_NL30") is None
