@@ -387,15 +387,19 @@ void twvo_generate_mulaw(const twvo_dims* d, const float* blob, twvo_state* s, c
                          const int32_t* seed, const double* u, double temperature, int B, int T, int32_t* out)
 {
     const int L = d->L;
+    blob_offs o; offsets(d, &o);
     int32_t* in = (int32_t*)malloc(sizeof(int32_t) * B);
     float* raw = (float*)malloc(sizeof(float) * (size_t)B * d->O);
     float* lc = (float*)malloc(sizeof(float) * (size_t)B * (L ? L : 1));
-    for (int b = 0; b < B; ++b) in[b] = seed[b];
-    for (int t = 0; t < T; ++t) {
-        for (int b = 0; b < B; ++b)
+    /* the batch lanes are independent streams: one stream per thread (twvo_set_threads), same arithmetic per stream */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+#endif
+    for (int b = 0; b < B; ++b) {
+        in[b] = seed[b];
+        for (int t = 0; t < T; ++t) {
             if (L) memcpy(lc + (size_t)b * L, U + ((size_t)b * T + t) * L, sizeof(float) * L);
-        twvo_step(d, blob, s, NULL, in, L ? lc : NULL, gc_ids, raw, NULL, NULL);
-        for (int b = 0; b < B; ++b) {
+            step_one(d, blob, &o, s, b, NULL, in, L ? lc : NULL, gc_ids, raw, NULL, NULL);
             const int q = twvo_sample_categorical(raw + (size_t)b * d->O, d->O, temperature, u[(size_t)b * T + t], NULL);
             out[(size_t)b * T + t] = q;
             in[b] = q;

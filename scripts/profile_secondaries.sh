@@ -1,0 +1,21 @@
+#!/bin/bash
+# rocprofv3 evidence for the MFMA kernels of the two secondary rows (run on the GPU box: `gpurun -- bash scripts/profile_secondaries.sh <tag>`):
+#   configs[2] Tacotron text->mel  (scripts/tacotron_bench.py: tc_gemm_mfma_kernel, tc_gemm_mfma_ck_kernel, tc_decoder_*)
+#   configs[3] WaveNet training    (scripts/train_bench.py:    tr_layer_{fwd,bwd1,bwd2}_kernel + the wide GEMMs)
+# Kernel stats in one run; counters in their own runs with --kernel-trace only (MI355X_MICROARCH.md: 8 SQ slots per pass).
+# Outputs land in gpurun_out/prof_<tag>/; scripts/pmc_to_mfma.py condenses them into summary_mfma_<tag>.txt.
+set -u
+TAG=${1:-r03}
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p $OUT
+REPO=$PWD
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 -L > $OUT/counters_available.txt 2>&1
+for W in tacotron train; do
+  if [ $W = tacotron ]; then CMD="python $REPO/scripts/tacotron_bench.py --steps 3"; else CMD="python $REPO/scripts/train_bench.py --steps 3 --warmup 1"; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -- $CMD > $OUT/stats_$W.log 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma_$W -- $CMD > $OUT/pmc_mfma_$W.log 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_mops_$W -- $CMD > $OUT/pmc_mops_$W.log 2>&1
+done
+cd $REPO
+python scripts/pmc_to_mfma.py $OUT $TAG

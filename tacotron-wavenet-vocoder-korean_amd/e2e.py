@@ -11,23 +11,19 @@ from .shard import shard_range
 
 
 def attention_trim_frames(alignment, sequence_length, reduction_factor):
-    """synthesizer.py:232-256 (`attention_trim and end_of_sentence`): number of spectrogram frames to keep.
-    alignment (T_in, T_dec) numpy; returns spec_end_idx = r * jdx + 3."""
-    attention_argmax = alignment.argmax(0)
-    end_idx = min(sequence_length - 1, int(attention_argmax.max()))
-    max_counter = min(int((attention_argmax == end_idx).sum()), 5)
-    end_idx_counter = 0
-    jdx = 0
-    for jdx, attend_idx in enumerate(attention_argmax):
-        if len(attention_argmax) > jdx + 1:
-            if attend_idx == end_idx:
-                end_idx_counter += 1
-            if attend_idx == end_idx and attention_argmax[jdx + 1] > end_idx:
-                break
-            if end_idx_counter >= max_counter:
-                break
-        else:
-            break
+    """Number of spectrogram frames synthesizer.py:232-256 keeps when `attention_trim and end_of_sentence` (= r * jdx + 3).
+    alignment (T_in, T_dec) numpy.  The rule, stated on arrays: `focus[j]` is the input position decoder step j attends to; the
+    decode is cut at the first step j (not the last one) where either the focus sits on the final position `end` and moves past
+    it at j + 1, or `end` has been in focus `quota` times (quota = how often it is in focus overall, at most 5)."""
+    focus = np.asarray(alignment).argmax(axis=0)
+    n = focus.size
+    end = min(int(sequence_length) - 1, int(focus.max()))
+    on_end = focus == end
+    quota = min(int(on_end.sum()), 5)
+    leaves_end = on_end[:-1] & (focus[1:] > end)
+    quota_met = np.cumsum(on_end)[:-1] >= quota
+    cut = np.flatnonzero(leaves_end | quota_met)
+    jdx = int(cut[0]) if cut.size else n - 1
     return reduction_factor * jdx + 3
 
 

@@ -38,18 +38,20 @@ def str2bool(v):
 
 
 def get_most_recent_checkpoint(checkpoint_dir, checkpoint_step=None):
-    """synthesizer.py:289-299: the bundle prefix `model.ckpt-<largest step>` of a directory (or of the step asked for)"""
-    if checkpoint_step is None:
-        checkpoint_paths = [path for path in glob("{}/*.ckpt-*.data-*".format(checkpoint_dir))]
-        idxes = [int(os.path.basename(path).split('-')[1].split('.')[0]) for path in checkpoint_paths]
-        if not idxes:
+    """synthesizer.py:289-299: the bundle prefix `model.ckpt-<N>` of a directory -- the step asked for, else the largest N that has
+    a data shard on disk"""
+    step = checkpoint_step
+    if step is None:
+        steps = []
+        for shard in glob(os.path.join(checkpoint_dir, "*.ckpt-*.data-*")):
+            tail = os.path.basename(shard).split(".ckpt-", 1)[1]           # "<N>.data-00000-of-00001"
+            steps.append(int(tail.split(".", 1)[0]))
+        if not steps:
             raise FileNotFoundError("no model.ckpt-* bundle in %s" % checkpoint_dir)
-        max_idx = max(idxes)
-    else:
-        max_idx = checkpoint_step
-    lastest_checkpoint = os.path.join(checkpoint_dir, "model.ckpt-{}".format(max_idx))
-    print(" [*] Found lastest checkpoint: {}".format(lastest_checkpoint))
-    return lastest_checkpoint
+        step = max(steps)
+    prefix = os.path.join(checkpoint_dir, "model.ckpt-%d" % int(step))
+    print(" [*] Found latest checkpoint: %s" % prefix)
+    return prefix
 
 
 def _prepare_inputs(inputs):

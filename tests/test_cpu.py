@@ -411,6 +411,31 @@ def test_torch_training_reference_agrees_with_the_c_restatement(oracle):
     assert y.shape == raw.shape and np.abs(y - raw).max() < 1e-5     # tolerance: fp32 sums in a different order
 
 
+def test_torch_training_reference_matmul_form_equals_conv_form():
+    """tests/torch_train_ref.py: `network_mm` (what the full-size configs[3] GPU test runs in float64 on the device) is the same
+    graph as the conv1d form -- loss and every gradient agree to float64 round-off, scalar-input and one-hot model"""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch_train_ref as R
+    import twvk_amd  # noqa: F401
+    from twvk_amd import weights as W
+    for scalar in (True, False):
+        dil = [1, 2, 4, 8, 1, 2]
+        tensors = W.random_tensors(W.tensor_specs(len(dil), S=64, scalar_input=scalar, Q=256), seed=0, scale=0.1)
+        rng = np.random.RandomState(1)
+        B, Tm = 2, 2
+        audio = ((rng.rand(B, Tm * 300) - 0.5) * 1.6).astype(np.float32)
+        lc = (rng.randn(B, Tm, 80) * 0.5).astype(np.float32)
+        gc = np.array([1, 0], np.int32)
+        cfg = dict(dilations=dil, initial_filter_width=32, use_biases=True, upsample_factor=(5, 5, 12), scalar_input=scalar, Q=256)
+        q = None if scalar else rng.randint(256, size=(B, Tm * 300))
+        l1, g1 = R.loss_and_grads(tensors, cfg, audio, lc, gc, dtype=torch.float64, quantized=q)
+        l2, g2 = R.loss_and_grads(tensors, cfg, audio, lc, gc, dtype=torch.float64, quantized=q, matmul_form=True)
+        assert abs(l1 - l2) <= 1e-12 * abs(l1)
+        for k in g1:
+            assert np.abs(g1[k] - g2[k]).max() <= 1e-12 * max(np.abs(g1[k]).max(), 1e-30), k
+
+
 def test_attention_trim_rule():
     """synthesizer.py:232-256: stop at the decoder step where attention has sat on the last token (<= 5 steps) or moves past it"""
     import twvk_amd

@@ -88,6 +88,38 @@ def test_loss_and_gradients_at_bench_geometry():
         assert e_hip <= max(10 * e_t32, 2e-3), "%s: HIP %.3g vs torch-f32 %.3g (relative to the tensor's max, against float64)" % (k, e_hip, e_t32)
 
 
+def test_one_step_at_the_full_configs3_batch():
+    """BASELINE configs[3] at its own size: ONE teacher-forced step of B = 64 crops x 7800 samples (8000 floored to a hop multiple,
+    datafeeder_wavenet.py:41-47), 30 layers, S = 512, MoL loss -- the batch bench.py times.  The checker is the torch restatement
+    in float64, run on the GPU in its matmul form (tests/torch_train_ref.py:network_mm; ~0.5 M rows per matmul); the float32
+    torch model beside it gives the scale of plain round-off.  Bar (as for the 16 x 3600 case): loss within 10x the f32 model's own
+    distance from float64 (floor 2e-5 relative); every gradient tensor at most 10x further from float64 than the f32 model is
+    (floor 2e-3 of the tensor's largest element)."""
+    dil = [2 ** i for i in range(10)] * 3
+    tr, tensors, cfg, audio, lc, gc = _case(dil=dil, B=64, Tm=26, S=512)
+    assert audio.shape == (64, 7800)
+    loss = float(tr.loss_and_gradients(audio, lc, gc).item())
+    got = tr.gradients()
+    l64, g64 = R.loss_and_grads(tensors, cfg, audio, lc, gc, dtype=torch.float64, device="cuda:0", matmul_form=True)
+    torch.cuda.empty_cache()
+    l32, g32 = R.loss_and_grads(tensors, cfg, audio, lc, gc, dtype=torch.float32, device="cuda:0", matmul_form=True)
+    torch.cuda.empty_cache()
+    assert abs(loss - l64) <= max(10 * abs(l32 - l64), 2e-5 * abs(l64)), (loss, l32, l64)
+    sampled = ["wavenet/conv1d_2/kernel", "wavenet/dilated_stack/layer29/dilation_layer/skip/kernel",
+               "wavenet/dilated_stack/layer0/dilation_layer/conv_filter/kernel", "wavenet/upsample0/kernel"]
+    assert all(k in g64 for k in sampled)
+    worst = ("", 0.0)
+    for k in g64:
+        scale = max(float(np.abs(g64[k]).max()), 1e-30)
+        e_hip = float(np.abs(got[k] - g64[k]).max()) / scale
+        e_t32 = float(np.abs(g32[k] - g64[k]).max()) / scale
+        assert np.isfinite(got[k]).all(), k
+        assert e_hip <= max(10 * e_t32, 2e-3), "%s: HIP %.3g vs torch-f32 %.3g (relative to the tensor's max, against float64)" % (k, e_hip, e_t32)
+        if e_hip > worst[1]:
+            worst = (k, e_hip)
+    print("full-size step: loss %.6f (f64 %.6f, f32 %.6f); worst gradient tensor %s at %.2e of its max" % (loss, l64, l32, worst[0], worst[1]))
+
+
 def test_gradients_against_float64_reference_are_closer_than_float32_noise():
     """the fp32 torch model itself deviates from float64 by round-off; the HIP path must be in the same league"""
     tr, tensors, cfg, audio, lc, gc = _case(dil=[1, 2, 4, 1, 2], B=2, Tm=3)

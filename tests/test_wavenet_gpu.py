@@ -290,6 +290,22 @@ def test_generate_c1_config(torch_cuda, oracle):
     assert got.min() >= 0 and got.max() <= 255
 
 
+def test_generate_c2_mulaw_variant_at_batch_8(torch_cuda, oracle):
+    """the mu-law-256 variant of BASELINE configs[1] (30 layers = 3 x [1..512], S = 512, gc + lc, B = 8) -- the model
+    north_star's integer-parity bar is stated on.  12 000 steps per stream (0.5 s at 24 kHz): int32 category ids equal to the
+    checker's, element for element (model.py:223-227,243 float64 softmax, generate.py:219-231 temperature + legacy choice)"""
+    dil = [2 ** i for i in range(10)] * 3
+    oracle.set_threads(min(8, oracle.set_threads(1)))
+    try:
+        d, blob, want, got, _ = _run_onehot(oracle, dil, 8, 12000)
+    finally:
+        oracle.set_threads(1)
+    got = got.cpu().numpy()
+    assert got.dtype == np.int32 and got.shape == (8, 12000)
+    assert np.array_equal(got, want), first_mismatch(got, want)
+    assert len(np.unique(got)) > 200                     # the streams really walk the whole alphabet
+
+
 @pytest.mark.parametrize("kw", [dict(groups=1), dict(groups=2, Q=64), dict(L=0, G=0, Q=16)])
 def test_generate_onehot_variants(torch_cuda, oracle, kw):
     d, blob, want, got, _ = _run_onehot(oracle, [1, 2, 4, 8, 16], 3, 50, S=128, scale=0.3, **kw)

@@ -92,10 +92,49 @@ def network(P, cfg, net_in, U, gc_ids):
     return conv(F.relu(c1), "wavenet/conv1d_2").transpose(1, 2)             # (B, out_w, 3*nr)
 
 
-def loss_fn(P, cfg, audio, lc, gc_ids, quantized=None):
+def network_mm(P, cfg, net_in, U, gc_ids):
+    """`network` written with matmuls only (a width-2 dilated 'valid' conv is two matmuls on row-shifted slices, a 1x1 conv is one;
+    the skip outputs are added up as they appear): device-agnostic and float64-capable on the GPU, where conv1d in float64 is not a
+    library path.  Same graph, same result up to the summation order inside a matmul (checked against `network` on the CPU)."""
+    dil, ifw, ub = cfg["dilations"], cfg["initial_filter_width"], cfg["use_biases"]
+    rf = receptive_field(cfg)
+    scalar = cfg.get("scalar_input", True)
+    if scalar:
+        cur = net_in[:, 0, :].unfold(1, ifw, 1) @ P["wavenet/conv1d/kernel"][:, 0, :]             # (B, Tc, R)
+    else:
+        x = net_in.transpose(1, 2)                                                                # (B, Tn, Q)
+        k = P["wavenet/conv1d/kernel"]
+        cur = x[:, :-1] @ k[0] + x[:, 1:] @ k[1]
+    out_w = net_in.shape[2] - rf + 1
+    gc = P["wavenet/gc_embedding"][gc_ids.long()]                                                 # (B, G)
+
+    def b(name):
+        return P[name + "/bias"] if (ub and (name + "/bias") in P) else 0.0
+
+    total = None
+    for i, d in enumerate(dil):
+        p = "wavenet/dilated_stack/layer%d/dilation_layer/" % i
+        n = cur.shape[1] - d
+        pre = []
+        for nm in ("filter", "gate"):
+            w = P[p + "conv_" + nm + "/kernel"]
+            v = cur[:, :n] @ w[0] + cur[:, d:] @ w[1] + b(p + "conv_" + nm)
+            v = v + (gc @ P[p + "gc_" + nm + "/kernel"][0])[:, None, :]
+            v = v + U[:, :n] @ P[p + "lc_" + nm + "/kernel"][0]                                   # model.py:79-80 slice from the front
+            pre.append(v)
+        z = torch.tanh(pre[0]) * torch.sigmoid(pre[1])
+        sk = z[:, n - out_w:] @ P[p + "skip/kernel"][0] + b(p + "skip")
+        total = sk if total is None else total + sk
+        cur = cur[:, d:] + (z @ P[p + "dense/kernel"][0] + b(p + "dense"))
+    c1 = F.relu(total) @ P["wavenet/conv1d_1/kernel"][0] + b("wavenet/conv1d_1")
+    return F.relu(c1) @ P["wavenet/conv1d_2/kernel"][0] + b("wavenet/conv1d_2")                  # (B, out_w, O)
+
+
+def loss_fn(P, cfg, audio, lc, gc_ids, quantized=None, net=None):
     """P: dict TF-name -> torch tensor (TF layouts); audio (B,T); lc (B,T/hop,L); gc_ids (B) -> scalar loss.
     one-hot model (scalar_input False): `quantized` = mu_law_encode(audio) ints (B,T), model.py:257-260"""
     rf = receptive_field(cfg)
+    network = net or globals()["network"]
     U = upsample(lc, [P["wavenet/upsample%d/kernel" % i] for i in range(len(cfg["upsample_factor"]))], cfg["upsample_factor"])
     if cfg.get("scalar_input", True):
         net_in = audio[:, None, :-1]                           # model.py:267-269 (B,1,T-1)
@@ -108,12 +147,16 @@ def loss_fn(P, cfg, audio, lc, gc_ids, quantized=None):
     return F.cross_entropy(y.reshape(-1, cfg["Q"]), tgt.reshape(-1), reduction="mean")
 
 
-def loss_and_grads(tensors, cfg, audio, lc, gc_ids, dtype=torch.float32, quantized=None):
-    P = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in tensors.items()}
-    loss = loss_fn(P, cfg, torch.tensor(audio, dtype=dtype), torch.tensor(lc, dtype=dtype), torch.tensor(np.asarray(gc_ids)),
-                   None if quantized is None else torch.tensor(np.asarray(quantized)))
+def loss_and_grads(tensors, cfg, audio, lc, gc_ids, dtype=torch.float32, quantized=None, device="cpu", matmul_form=False):
+    """device / matmul_form: the full-size configs[3] batch is checked with the matmul form in float64 ON the GPU (torch as the
+    checker of a floating-point kernel; conv1d in float64 has no GPU library path)"""
+    P = {k: torch.tensor(np.asarray(v), dtype=dtype, device=device, requires_grad=True) for k, v in tensors.items()}
+    loss = loss_fn(P, cfg, torch.tensor(audio, dtype=dtype, device=device), torch.tensor(lc, dtype=dtype, device=device),
+                   torch.tensor(np.asarray(gc_ids), device=device),
+                   None if quantized is None else torch.tensor(np.asarray(quantized), device=device),
+                   net=network_mm if matmul_form else None)
     loss.backward()
-    return float(loss.item()), {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape, np.float32)) for k, v in P.items()}
+    return float(loss.item()), {k: (v.grad.cpu().numpy() if v.grad is not None else np.zeros(v.shape, np.float32)) for k, v in P.items()}
 
 
 def adam_ema(p, g, m, v, ema, t, lr, b1=0.9, b2=0.999, eps=1e-8, decay=0.9999):
