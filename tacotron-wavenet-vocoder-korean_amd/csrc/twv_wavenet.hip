@@ -1344,6 +1344,7 @@ struct twv_wavenet {
     int helpers;   // 1 = helper workgroups when the launch qualifies (conv1d_1, and conv1d_2's partials if O <= 32; default),
                    // 2 = conv1d_1 only, 0 = never
     int xcd;       // 1 (default) = the XCD-per-stream kernel (twv_wavenet_xcd.hip) whenever model, batch and device qualify; 0 = never
+    int xcd_many;  // 1 = its many-streams form (two streams per chain workgroup; what batch 33..64 runs) also at batch <= 32
     unsigned long long* prof;
     int prof_steps;
 };
@@ -1460,7 +1461,7 @@ static int device_cus()
 // the XCD-per-stream kernel: stream b on XCD b % 8 (8 x 32 CUs; up to four streams per XCD), explicit `groups` keeps the generic kernel
 static bool use_xcd(const twv_wavenet* h, int batch)
 {
-    return h->xcd != 0 && h->groups == 0 && h->lay.off_xl != 0 && batch >= 1 && batch <= (h->lay.NL > kXcdSeg0Layers ? kXcdStreams / 2 : kXcdStreams) && device_cus() >= 256;
+    return h->xcd != 0 && h->groups == 0 && h->lay.off_xl != 0 && batch >= 1 && batch <= xcd_max_streams(h->lay) && device_cus() >= 256;
 }
 static int resolve_groups(const twv_wavenet* h, int batch)
 {
@@ -1498,6 +1499,7 @@ extern "C" int twv_wavenet_create(const twv_wavenet_dims* dims, twv_wavenet** ou
     h->helpers = 1;
     h->groups = 0;
     h->xcd = 1;
+    h->xcd_many = 0;
     h->prof = nullptr; h->prof_steps = 0;
     const int rc = build_layout(*dims, h);
     if (rc != TWV_OK) { delete h; return rc; }
@@ -1556,6 +1558,11 @@ extern "C" int twv_wavenet_set_option(twv_wavenet* h, const char* name, int valu
     if (!strcmp(name, "xcd")) {      // set BEFORE sizing / resetting the state and conditioning buffers
         if (value != 0 && value != 1) return fail(TWV_E_INVALID, "xcd must be 0 or 1");
         h->xcd = value;
+        return TWV_OK;
+    }
+    if (!strcmp(name, "xcd_many")) { // 1: the many-streams XCD kernel (two streams per chain workgroup) also at batch <= 32 (it is what batch 33..64 runs)
+        if (value != 0 && value != 1) return fail(TWV_E_INVALID, "xcd_many must be 0 or 1");
+        h->xcd_many = value;
         return TWV_OK;
     }
     if (!strcmp(name, "groups")) {   // workgroups per stream; set BEFORE sizing / resetting the state buffer
@@ -1778,7 +1785,7 @@ static int generate_impl(const twv_wavenet* h, const void* packed, void* state, 
         x.uniforms = (const float*)uniforms; x.out = (float*)out; x.status = status; x.dbg = debug; x.dbg_steps = a.dbg_steps;
         x.prof = a.prof; x.prof_steps = a.prof_steps;
         { const char* e = getenv("TWV_XCD_PROF_STREAM"); x.prof_stream = e ? atoi(e) : 0; if (x.prof_stream < 0 || x.prof_stream >= batch) x.prof_stream = 0; }
-        x.B = batch; x.T = n_steps; x.lay = L;
+        x.B = batch; x.T = n_steps; x.lay = L; x.many = h->xcd_many;
         unsigned char* xb = reinterpret_cast<unsigned char*>((float*)state + (size_t)L.state_stride * (size_t)batch) + (size_t)batch * 2 * L.S * 8;
         HIPCHK(hipMemsetAsync(xb, 0, xcd_exchange_bytes(batch), st));
         x.exch = reinterpret_cast<unsigned long long*>(xb);

@@ -74,6 +74,21 @@ __device__ __forceinline__ u32x4s xb_load2(rsrc_t rs, int uword, int lpair)
 {
     return __builtin_amdgcn_raw_buffer_load_b128(rs, lpair * 16, uword * 8, kAuxLoad);
 }
+// The same loads behind a compiler barrier (the many-streams kernel's roles).  Aux bit 31 marks the MACHINE instruction volatile, but
+// the IR call is a read-only intrinsic: in wn_xcd_many_kernel loop-invariant code motion hoisted the sampler's four table loads out of
+// their polling loop, which then spun on registers until the watchdog.  A load cannot move across the barrier; it costs no
+// instruction.  (wn_xcd_generate_kernel keeps the plain form: its polls compile as written, and the barrier shifts its schedule.)
+template <bool BAR> __device__ __forceinline__ unsigned long long xb_load_t(rsrc_t rs, int uword, int lword)
+{
+    if (BAR) asm volatile("" ::: "memory");
+    return xb_load(rs, uword, lword);
+}
+__device__ __forceinline__ unsigned long long xbm_load(rsrc_t rs, int uword, int lword) { return xb_load_t<true>(rs, uword, lword); }
+__device__ __forceinline__ u32x4s xbm_load2(rsrc_t rs, int uword, int lpair)
+{
+    asm volatile("" ::: "memory");
+    return xb_load2(rs, uword, lpair);
+}
 __device__ __forceinline__ void xb_store(rsrc_t rs, int uword, int lword, unsigned tag, float v)
 {
     __builtin_amdgcn_raw_buffer_store_b64(u32x2v{__float_as_uint(v), tag}, rs, lword * 8, uword * 8, kAuxStore);
@@ -100,11 +115,12 @@ struct Poll {
     int it;
     bool dead;
 };
+template <bool BAR = false>
 __device__ __forceinline__ bool poll_tick(Poll& p, int code)
 {
     if (p.dead) return false;
     if (((++p.it) & 63) == 0) {
-        if (xb_load(p.rs, (int)XcdExch::CTRL + 1, 0) != 0ull) { p.dead = true; return false; }
+        if (xb_load_t<BAR>(p.rs, (int)XcdExch::CTRL + 1, 0) != 0ull) { p.dead = true; return false; }
         if (p.it > (1 << 21)) {
             atomicMax(p.status, code);
             xb_store(p.rs, (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);
@@ -806,8 +822,8 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
 //  CONV1 workgroup g: model.py:158-160 conv1d_1 + relu for output block g (16 chunk tiles over the 8 waves), then the two
 //  chunks (2g, 2g+1) of model.py:161-165 conv1d_2 that read this block: what travels on is conv1d_2's partial table.
 // =====================================================================================================================
-template <int INSTR, int NS>
-__device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& sx, int g)
+template <int INSTR, int NS, bool BAR = false>
+__device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& sx, int g, const int ns_rt = NS)
 {
     const XcdLaunch& a = xa.p;
     const Layout& L = a.lay;
@@ -836,6 +852,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             if (pl.dead) break;
+            if (k >= ns_rt) break;                                     // (many-streams kernel: NS = 8 slots, ns_rt streams on this XCD)
             const rsrc_t rs = sx.rs[k];
             const int b = sx.b[k];
             const int ob = k * kConvLdsFloats;
@@ -845,9 +862,9 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
             unsigned long long q;
             pl.it = 0;
             for (;;) {
-                q = xb_load(rs, (int)XcdExch::H1 + v * 64, lane);
+                q = xb_load_t<BAR>(rs, (int)XcdExch::H1 + v * 64, lane);
                 if (__all(g_tag(q) == tag)) break;
-                if (!poll_tick(pl, 61)) break;
+                if (!poll_tick<BAR>(pl, 61)) break;
                 __builtin_amdgcn_s_sleep(1);
             }
             // (no exit here on a watchdog abort: see the chain role; the loops end at their heads)
@@ -874,7 +891,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
             XMARK(ROLE_CONV0 + g, 2);
             if (summer) {
                 pl.it = 0;
-                while (LDSVI(ob + O_CNT) < 8 * (t + 1)) { if (!poll_tick(pl, 62)) break; }
+                while (LDSVI(ob + O_CNT) < 8 * (t + 1)) { if (!poll_tick<BAR>(pl, 62)) break; }
                 // (no exit here on a watchdog abort: see the chain role; the loops end at their heads)
                 asm volatile("" ::: "memory");
                 XSTAMP(g == 0 && v == 0, 24);
@@ -904,8 +921,8 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
 //  LC workgroups: model.py:102-111 create_upsample (row by row) and model.py:75-83 lc_filter|lc_gate of every layer,
 //  ahead of the chain through the ring XcdExch::LCR.  Wave gw owns layers gw*lpw .. gw*lpw+lpw-1 (NLC tiles each).
 // =====================================================================================================================
-template <int INSTR, int NS, bool BIG>
-__device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx, int wg)
+template <int INSTR, int NS, bool BIG, bool BAR = false>
+__device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx, int wg, const int ns_rt = NS)
 {
     const XcdLaunch& a = xa.p;
     const Layout& L = a.lay;
@@ -959,14 +976,15 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx,
         if (u + 3 - kXcdLcRing > 0) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
+                if (k >= ns_rt) break;
                 const rsrc_t rs = sx.rs[k];
                 pl.rs = rs;
                 XMARK(ROLE_LC0 + wg, 1);
                 pl.it = 0;
                 while (!pl.dead) {
-                    const unsigned long long q = xb_load(rs, (int)XcdExch::CTRL, 0);
+                    const unsigned long long q = xb_load_t<BAR>(rs, (int)XcdExch::CTRL, 0);
                     if ((int)g_tag(q) >= u + 3 - kXcdLcRing) break;
-                    if (!poll_tick(pl, 72)) break;
+                    if (!poll_tick<BAR>(pl, 72)) break;
                     __builtin_amdgcn_s_sleep(16);
                 }
             }
@@ -976,12 +994,15 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx,
         float rowa[NS], rowb[NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
+            rowa[k] = 0.0f; rowb[k] = 0.0f;
+            if (k >= ns_rt) continue;
             const float* src = payload + ((long long)sx.b[k] * rows + (mode == XLC_UPSAMPLED ? u : frame)) * Lc;
             rowa[k] = lane < Lc ? src[lane] : 0.0f;
             rowb[k] = 64 + lane < Lc ? src[64 + lane] : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
+            if (k >= ns_rt) break;
             const rsrc_t rs = sx.rs[k];
             const int b = sx.b[k];
             // ---- row u of the upsampled condition into LDS (zero padded to NLC*32)
@@ -1031,7 +1052,22 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx,
                     }
                     const int l = lfirst + j;
                     if (u + 1 < T) xb_store(rs, (int)XcdExch::LCR + (((u + 1) % kXcdLcRing) * kXcdLs + l) * 64, lane, (unsigned)u + 2u, r);
-                    else (a.state + (long long)b * L.state_stride)[L.st_lcprev + l * 64 + lane] = r;    // the frame the NEXT call uses at its step 0
+                    else {
+                        // the frame the NEXT call uses at its step 0.  In a short call nothing has throttled this wave yet, and the service
+                        // workgroup may not have read the PREVIOUS call's frame from the same slot: it publishes that frame as LG tag 1 right
+                        // after reading it (found by a one-step call at batch 64: the many-streams service reads its second slot later)
+                        if (T <= kXcdLcRing + 1) {
+                            pl.rs = rs;
+                            pl.it = 0;
+                            for (;;) {
+                                const unsigned long long ql = xb_load_t<BAR>(rs, (int)XcdExch::LG + l * 64, lane);
+                                if (__all(g_tag(ql) >= 1u)) break;
+                                if (!poll_tick<BAR>(pl, 73)) break;
+                                __builtin_amdgcn_s_sleep(8);
+                            }
+                        }
+                        (a.state + (long long)b * L.state_stride)[L.st_lcprev + l * 64 + lane] = r;
+                    }
                 }
             }
         }
@@ -1127,6 +1163,627 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
     }
 }
 
+// =====================================================================================================================
+//  THE MANY-STREAMS KERNEL (batch 33 .. 64: five to eight streams per XCD).
+//
+//  The chain workgroup's weights serve a stream ~1 us of every ~9.5 us step per wave (SQ_WAIT_ANY 0.83 at batch 8), so TWO streams
+//  rotate through one chain workgroup here (slot 0 = stream k, slot 1 = stream k + 4 of the XCD): wave w runs slot 0's layers, hands
+//  the residual vector on, runs slot 1's layers; register-resident kernels shared, per-slot state = the hand-off boxes, the gc
+//  projections (LDS) and, on wave 7, the causal queue and the sampler's noise terms.  Wave 7 draws a slot's sample and feeds its
+//  causal layer in one go (sampler(t-1) -> head(t) per slot, then the slots' layers): neither stream waits for the other's post phase.
+//  The service workgroup carries the same two streams (tap-0 kernels shared, delay lines per stream).  4 chain + 4 service + 8 skip
+//  + 8 conv1 + 4 lc workgroups = 28 of the XCD's 32 CUs serve eight streams.
+//
+//  The skip role is laid out differently: with eight streams the 32 (layer, stream) polls per wave and step of skip_role (a wave
+//  owns slice g of FOUR layers) are an L2 round trip each -- more than the step.  Here a wave owns FOUR SLICES of ONE layer: one
+//  poll per stream and step, four dots.  Workgroup (q, hh) = layer group q (eight consecutive layers, the first group short so that
+//  the last one is full) x output half hh (256 columns); model.py:154's sum over the layers IN LAYER ORDER runs as a relay through
+//  the group's waves (tagged LDS words, like the chain's hand-off) and on to the next group through one L2 granule hop, which is
+//  off the sample path: the total of layers 0..l-1 is waiting when layer l's value appears.  Same adds in the same order: same bits.
+// =====================================================================================================================
+// where a wave is (layer-dump build only): {stage, step + 1} in the MARK area of the stream it is working for -- read back by
+// scripts/many_check.py after a watchdog abort.  Slots: 0-7 chain waves, 8-15 service waves, 16 + 8 r + m skip, 80 + 8 g + v conv1
+#define MMARK(rs_, slot_, stage_) do { if ((INSTR & 2) && lane == 0) xb_store(rs_, (int)XcdExch::MARK + (slot_), 0, (unsigned)t + 1u, (float)(stage_)); } while (0)
+constexpr int kMS = 2;                                   // stream slots of a chain / service workgroup
+constexpr int kManyChains = 4;                           // chain (and service) workgroups per XCD
+constexpr int kManyPerXcd = kMS * kManyChains;           // streams per XCD
+constexpr int kM_BOX = 10;                               // hand-off boxes per slot: 0..7 the waves' inputs, 8 end of a forced step, 9 sink
+constexpr int kM_OWD = 4096;                             // LDS floats: dense kernels [30 layers][4][64 lanes][4] behind the boxes
+constexpr int kM_OGC = kM_OWD + kXcdSeg0Layers * 1024;   // gc projections [slot][30][64]
+constexpr int kM_OHS = kM_OGC + kMS * kXcdSeg0Layers * 64;                 // wave 7's per-slot state [slot][9][64]: causal queue (2), partial chunk (4), noise terms (2), first input
+constexpr int kManyChainLds = kM_OHS + kMS * 9 * 64;                       // floats (155.5 KiB)
+constexpr int kManySkipLds = kManyPerXcd * 8 * 4 * 64 * 2;                 // floats: [stream][wave][4 slices][64] 8-byte words (128 KiB)
+constexpr int kManyLds = kManyChainLds > kManySkipLds ? kManyChainLds : kManySkipLds;
+
+__device__ __forceinline__ rsrc_t exch_rsrc(const XcdLaunch& a, int b)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(a.exch + (long long)b * XcdExch::WORDS, 0, (int)(XcdExch::WORDS * 8), 0x00020000);
+}
+
+// mixture.py:84-114 from conv1d_2's [16 chunks][32 outputs] partial table of ONE stream (the sampler half of chain_role, as a function:
+// the many-streams chain draws for two slots).  Returns the sample; `tag` = step + 1 of the step the table belongs to.
+template <int INSTR>
+__device__ __forceinline__ float many_sample(const XcdLaunch& a, const Layout& L, Poll& pl, rsrc_t rs, int lane, unsigned tag, float b2v,
+                                             float s_lnl, float s_tq, bool use_bias, int b, int NL)
+{
+    const int half = lane >> 5;
+    unsigned long long q[8];
+    pl.it = 0;
+    for (;;) {
+        bool good = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u32x4s d = xbm_load2(rs, (int)XcdExch::PT, (half * 4 + k) * 32 + (lane & 31));
+            q[2 * k] = ((unsigned long long)d.y << 32) | d.x;
+            q[2 * k + 1] = ((unsigned long long)d.w << 32) | d.z;
+            good = good && d.y == tag && d.w == tag;
+        }
+        if (__all(good)) break;
+        if (!poll_tick<true>(pl, 34)) break;
+    }
+    if ((INSTR & 2) && pl.dead) {                              // bring-up: what the abandoned poll last saw (lanes 0 and 32)
+        if ((lane & 31) == 0) {
+            xb_store(rs, (int)XcdExch::MARK + 240 + (lane >> 5) * 4, 0, tag, __uint_as_float(g_tag(q[0])));
+            xb_store(rs, (int)XcdExch::MARK + 241 + (lane >> 5) * 4, 0, (unsigned)pl.it, __uint_as_float(g_tag(q[7])));
+        }
+    }
+    float y = g_val(q[0]);                                     // chunk partials added in chunk order (AC-1)
+#pragma unroll
+    for (int k = 1; k < 8; ++k) y = y + g_val(q[k]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)q[k], (unsigned)q[k], false, false);
+        y = y + __uint_as_float(sw[1]);                        // chunk 8 + k of the same output (upper half-wave's granule)
+    }
+    if (use_bias && lane < L.O) y = y + b2v;
+    if ((INSTR & 2) && a.dbg != nullptr && (int)tag - 1 < a.dbg_steps)
+        a.dbg[((long long)b * a.dbg_steps + ((int)tag - 1)) * ((long long)NL * 64 + L.Opad) + (long long)NL * 64 + lane] = y;
+    const int nr = L.nr_mix;
+    const float lsmin = (float)-32.23619130191664;             // mixture.py:107 exp(max(log_scale, log 1e-14)) on every lane
+    const float e_all = exp_e(y > lsmin ? y : lsmin);
+    const float ninf = __uint_as_float(0xff800000u);           // mixture.py:103 argmax_i(logit_i - log(-log u_i)), first maximum
+    const float gmb = (lane < nr) ? y - s_lnl : ninf;
+    float mx = gmb;
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ninf), __float_as_int(mx), 0x111, 0xf, 0xf, false)));
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ninf), __float_as_int(mx), 0x112, 0xf, 0xf, false)));
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ninf), __float_as_int(mx), 0x114, 0xf, 0xf, false)));
+    mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ninf), __float_as_int(mx), 0x118, 0xf, 0xf, false)));
+    const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx), 15));
+    const unsigned long long hit = __ballot(lane < nr && gmb == best);
+    const int k = hit ? (int)__ffsll((long long)hit) - 1 : 0;
+    const float mean = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), nr + k));        // mixture.py:105
+    const float e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_all), 2 * nr + k));    // mixture.py:107
+    const float prod = e * s_tq;                               // mixture.py:110-111
+    float xs = mean + prod;
+    xs = xs > -1.0f ? xs : -1.0f;                              // mixture.py:113
+    xs = xs < 1.0f ? xs : 1.0f;
+    return xs;
+}
+
+// ---- CHAIN workgroup c of an XCD, two stream slots (model.py:41-46, 66-101; mixture.py:84-114 on wave 7) ----------------------
+// The slot loop is a real loop (one copy of the layer code, as in chain_role): per-slot values are derived from the slot number
+// (stream, buffer descriptor) or live in LDS rows between a slot's turns (wave 7's causal queue / noise terms, the gc projections).
+template <int INSTR, bool ALL, bool FORCED, int NC>
+__device__ __forceinline__ void chain_many_role(const XArgs& xa, int xcc, int ns, int c)
+{
+    const XcdLaunch& a = xa.p;
+    const Layout& L = a.lay;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int NL = L.NL, T = a.T;
+    const bool use_bias = L.use_bias != 0, has_gc = L.G > 0, has_lc = L.L > 0;
+    constexpr bool forced = FORCED;
+    const int l0 = w < 6 ? 4 * w : 24 + 3 * (w - 6);
+    const int cap = w < 6 ? 4 : 3;
+    int nl = NL - l0;
+    nl = nl < 0 ? 0 : (nl > cap ? cap : nl);
+    const int nlc = NC >= 0 ? NC : nl;
+    const bool next_has = (l0 + nl < NL);
+    const bool head = (w == 7);                                // sampler + causal layer
+    if (nl == 0 && !head) return;
+    const int oc = dpp_conv_out(lane), od = dpp_dense_out(lane);
+    const ActCoef coef = act_coef(lane >= 32);
+    const int nslot = (c + kManyChains < ns) ? 2 : 1;          // slot s carries stream k = c + 4 s of this XCD
+    auto stream_of = [&](int s) { return xcc + 8 * (c + kManyChains * s); };
+    Poll pl{exch_rsrc(a, stream_of(0)), a.status, 0, false};
+
+    // ---- the wave's layers: tap-1 conv kernel register-resident for the whole launch, dense kernel and gc projections in LDS
+    ChainRegs W[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < nl) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.P + L.off_xl + (long long)(l0 + i) * kXcdXlFloats) + lane;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const f32x4 v = src[q * 64]; W[i].wc[4 * q] = v.x; W[i].wc[4 * q + 1] = v.y; W[i].wc[4 * q + 2] = v.z; W[i].wc[4 * q + 3] = v.w; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) LDS4((kM_OWD >> 2) + ((l0 + i) * 4 + q) * 64 + lane) = src[(8 + q) * 64];
+            const f32x4 v = src[12 * 64];
+            W[i].bfg = v.x; W[i].bd = v.y; W[i].gcv = 0.0f;
+            for (int s = 0; s < nslot; ++s)                      // model.py:71-73, hoisted: per stream
+                lds[kM_OGC + (s * kXcdSeg0Layers + l0 + i) * 64 + lane] = has_gc ? a.cond[XH_WORDS + ((long long)stream_of(s) * NL + l0 + i) * 64 + oc] : 0.0f;
+        }
+    }
+    // wave 7's per-slot state lives in LDS rows (kM_OHS) between a slot's turns: rows 0 ha, 1 hb (the causal queue, model.py:52, as two
+    // row-broadcast registers), 2-5 the causal chunk without its newest term, 6 / 7 the sampler's noise terms, 8 the first input
+    auto hs = [&](int s, int row) -> float& { return lds[kM_OHS + (s * 9 + row) * 64 + lane]; };
+    float b2v = 0.0f;
+    const bool sampler = head && !forced;
+    const bool is15 = (lane & 15) == 15;
+    auto causal_prepare = [&](float& ha_, float& hb_, float (&cp_)[4]) __attribute__((always_inline)) {
+        const float t1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ha_), 0x101, 0xf, 0xf, true));   // row_shl:1
+        const float b0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(hb_), 0x150, 0xf, 0xf, true));   // row_newbcast:0
+        ha_ = is15 ? b0 : t1;
+        hb_ = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(hb_), 0x101, 0xf, 0xf, true));
+        causal_partial_dpp(W[3].wc, ha_, hb_, cp_);
+    };
+    if (head) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.P + L.off_xc) + lane;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const f32x4 v = src[q * 64]; W[3].wc[4 * q] = v.x; W[3].wc[4 * q + 1] = v.y; W[3].wc[4 * q + 2] = v.z; W[3].wc[4 * q + 3] = v.w; }
+        if (sampler && use_bias && lane < L.O) b2v = a.P[L.off_b2 + lane];
+        for (int s = 0; s < nslot; ++s) {
+            const float* stb = a.state + (long long)stream_of(s) * L.state_stride;
+            float ha_ = stb[L.st_hist + (lane & 15)];
+            float hb_ = stb[L.st_hist + 16 + (lane & 15)];
+            float cp_[4];
+            causal_prepare(ha_, hb_, cp_);
+            hs(s, 0) = ha_; hs(s, 1) = hb_; hs(s, 2) = cp_[0]; hs(s, 3) = cp_[1]; hs(s, 4) = cp_[2]; hs(s, 5) = cp_[3];
+            hs(s, 6) = 0.0f; hs(s, 7) = 0.0f;
+            hs(s, 8) = forced ? 0.0f : reinterpret_cast<const float*>(a.first_input)[stream_of(s)];
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    asm volatile(".p2align 6" ::: "memory");
+
+    unsigned long long tin0 = 0, tin1 = 0, per0 = 0, per1 = 0;  // per slot: when the wave's input arrived in the previous step, the step period
+    for (int t = 0; t < T && !pl.dead; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+        // ---- wave 7: per slot, the sample of step t-1 straight into the causal layer of step t (one fma and three adds on the
+        // sample-to-sample path), result to wave 0.  Slot after slot: neither stream waits for the other's post phase.
+        if (head) {
+#pragma nounroll
+            for (int s = 0; s < nslot && !pl.dead; ++s) {
+                const int b = stream_of(s);
+                const rsrc_t rs = exch_rsrc(a, b);
+                pl.rs = rs;
+                float ha_ = hs(s, 0), hb_ = hs(s, 1), cp_[4] = {hs(s, 2), hs(s, 3), hs(s, 4), hs(s, 5)};      // requested before the wait below
+                const float lnl_ = hs(s, 6), tq_ = hs(s, 7);
+                float s_in = hs(s, 8);
+                MMARK(rs, w, 1);
+                if (forced) {
+                    if (t > 0) {                                    // teacher-forced: the end of step t-1 (box 8) releases step t
+                        pl.it = 0;
+                        for (;;) {
+                            const unsigned long long q = LDSU64((s * kM_BOX + 8) * 64 + lane);
+                            if (__all(g_tag(q) == (unsigned)t)) break;
+                            if (!poll_tick<true>(pl, 35)) break;
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                    }
+                    s_in = reinterpret_cast<const float*>(a.forced)[(long long)b * T + t];
+                } else if (t > 0) {
+                    __builtin_amdgcn_s_setprio(3);
+                    s_in = many_sample<INSTR>(a, L, pl, rs, lane, (unsigned)t, b2v, lnl_, tq_, use_bias, b, NL);
+                }
+                // (a watchdog abort ends the loops at their heads)
+                MMARK(rs, w, 2);
+                const float c3 = fma_(W[3].wc[31], s_in, cp_[3]);            // k = 31, the last term of chain 3
+                const float x0 = (cp_[0] + cp_[1]) + (cp_[2] + c3);          // model.py:41-46: one AC-1 chunk, no bias; X layout
+                LDSU64((s * kM_BOX + 0) * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(x0);
+                if (lane == 0) {
+                    if (sampler && t > 0) a.out[(long long)b * T + t - 1] = s_in;
+                    xb_store(rs, (int)XcdExch::CTRL, 0, tag, 0.0f);          // step t has started (the lc workgroups throttle on it)
+                }
+                hb_ = is15 ? s_in : hb_;                                     // (ha, hb) = the queue after step t
+                if (t + 1 < T) causal_prepare(ha_, hb_, cp_);
+                hs(s, 0) = ha_; hs(s, 1) = hb_; hs(s, 2) = cp_[0]; hs(s, 3) = cp_[1]; hs(s, 4) = cp_[2]; hs(s, 5) = cp_[3];
+                if (sampler) {
+                    // mixture.py:103 -log(-log u) per mixture lane; mixture.py:110-111 log u - log(1 - u) of the last draw
+                    const float* up = a.uniforms + ((long long)b * T + t) * (L.nr_mix + 1);
+                    const float u = lane <= L.nr_mix ? up[lane] : 0.5f;
+                    hs(s, 6) = log_e(-log_e(u));
+                    const float uu = __shfl(u, L.nr_mix);
+                    hs(s, 7) = log_e(uu) - log_e(1.0f - uu);
+                }
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        // ---- the wave's layers, slot after slot
+        if (nlc > 0) {
+#pragma nounroll
+            for (int s = 0; s < nslot && !pl.dead; ++s) {
+                const int b = stream_of(s);
+                const rsrc_t rs = exch_rsrc(a, b);
+                pl.rs = rs;
+                float pre[4] = {0.0f, 0.0f, 0.0f, 0.0f}, lcv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                MMARK(rs, w, 3);
+                // (A) this step's tap-0 chunks and lc projections of the wave's layers (service workgroup; long since published)
+                pl.it = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (i < nlc) {
+                            const unsigned long long qp = xbm_load(rs, (int)XcdExch::PG + (l0 + i) * 64, oc);
+                            const unsigned long long ql = xbm_load(rs, (int)XcdExch::LG + (l0 + i) * 64, oc);
+                            ok = ok && g_tag(qp) == tag && g_tag(ql) == tag;
+                            pre[i] = g_val(qp); lcv[i] = g_val(ql);
+                        }
+                    }
+                    if (__all(ok)) break;
+                    if (!poll_tick<true>(pl, 31)) break;
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                MMARK(rs, w, 4);
+                // (B) the wave's input: the previous wave's residual vector (wave 0: the causal layer's output); sleep until its turn is near
+                const unsigned long long t_in = s ? tin1 : tin0, in_period = s ? per1 : per0;
+                if (in_period) nap_until(t_in + in_period - (in_period >> 4));
+                unsigned long long q;
+                pl.it = 0;
+                for (;;) {
+                    q = LDSU64((s * kM_BOX + w) * 64 + lane);
+                    if (__all(g_tag(q) == tag)) break;
+                    if (!poll_tick<true>(pl, 33)) break;
+                }
+                __builtin_amdgcn_s_setprio(3);
+                float X = g_val(q);
+                const unsigned long long now_in = __builtin_amdgcn_s_memtime();
+                auto run_layers = [&](auto nc) __attribute__((always_inline)) {
+                    constexpr int N = decltype(nc)::value;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        float wd[16];
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) {
+                            const f32x4 v = LDS4((kM_OWD >> 2) + ((l0 + i) * 4 + qq) * 64 + lane);
+                            wd[4 * qq] = v.x; wd[4 * qq + 1] = v.y; wd[4 * qq + 2] = v.z; wd[4 * qq + 3] = v.w;
+                        }
+                        const float gcv = lds[kM_OGC + (s * kXcdSeg0Layers + l0 + i) * 64 + lane];
+                        const float z = layer_front_dpp<ALL>(W[i].wc, W[i].bfg, gcv, coef, X, pre[i], lcv[i], use_bias, has_gc, has_lc);
+                        xb_store2(rs, (int)XcdExch::ZX + (l0 + i) * 128, lane, tag, z, X);     // {z, tag} -> skip, {layer input, tag} -> service
+                        layer_back_dpp<ALL>(wd, W[i].bd, z, X, use_bias);
+                        if ((INSTR & 2) && a.dbg != nullptr && t < a.dbg_steps) {
+                            float* dp = a.dbg + ((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)(l0 + i) * 64;
+                            if (lane < 32) dp[dpp_z_index(lane)] = z;
+                            if ((lane & 16) == 0) dp[32 + od] = X;
+                        }
+                    }
+                };
+                if constexpr (NC > 0) run_layers(std::integral_constant<int, NC>{});
+                else {
+                    if (nl == 4) run_layers(std::integral_constant<int, 4>{});
+                    else if (nl == 3) run_layers(std::integral_constant<int, 3>{});
+                    else if (nl == 2) run_layers(std::integral_constant<int, 2>{});
+                    else if (nl == 1) run_layers(std::integral_constant<int, 1>{});
+                }
+                LDSU64((s * kM_BOX + (next_has ? w + 1 : 9)) * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(X);
+                if (forced && !next_has) LDSU64((s * kM_BOX + 8) * 64 + lane) = (unsigned long long)tag << 32;    // the stack is through with step t
+                const unsigned long long d = now_in - t_in;
+                const unsigned long long np = (t_in != 0 && d < (1ull << 18)) ? d : 0;
+                if (s) { per1 = np; tin1 = now_in; } else { per0 = np; tin0 = now_in; }
+                __builtin_amdgcn_s_setprio(0);
+                MMARK(rs, w, 5);
+            }
+        }
+    }
+    // ---- the last sample; persist the causal queue (model.py:49-64), canonical order
+    if (head) {
+        for (int s = 0; s < nslot; ++s) {
+            const int b = stream_of(s);
+            float* stb = a.state + (long long)b * L.state_stride;
+            if (sampler && !pl.dead && T > 0) {
+                const rsrc_t rs = exch_rsrc(a, b);
+                pl.rs = rs;
+                const float last = many_sample<INSTR>(a, L, pl, rs, lane, (unsigned)T, b2v, hs(s, 6), hs(s, 7), use_bias, b, NL);
+                if (lane == 0 && !pl.dead) a.out[(long long)b * T + T - 1] = last;
+            }
+            if (lane < 16) stb[L.st_hist + lane] = hs(s, 0);
+            else if (lane < 32) stb[L.st_hist + lane] = hs(s, 1);
+            if (lane == 0) {
+                int* meta = reinterpret_cast<int*>(stb + L.st_meta);
+                meta[M_TABS] = meta[M_TABS] + T;
+            }
+        }
+    }
+    if (pl.dead && lane == 0)
+        for (int s = 0; s < nslot; ++s) xb_store(exch_rsrc(a, stream_of(s)), (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);
+}
+
+// ---- SERVICE workgroup c of an XCD, two stream slots: delay lines + tap-0 chunks one step ahead (service_role for two streams) ---
+template <int INSTR>
+__device__ __forceinline__ void service_many_role(const XArgs& xa, int xcc, int ns, int c)
+{
+    const XcdLaunch& a = xa.p;
+    const Layout& L = a.lay;
+    const int sv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int NL = L.NL, T = a.T;
+    const bool has_lc = L.L > 0;
+    const int* pmeta = reinterpret_cast<const int*>(a.P + L.off_meta);
+    constexpr int kReg = 4;
+    int nown = 0;
+#pragma unroll
+    for (int i = 0; i < kReg; ++i) if (sv + 8 * i < NL) nown = i + 1;
+    if (nown == 0) return;
+    bool ex[kMS];
+    rsrc_t rsv[kMS];
+    float* stb[kMS];
+#pragma unroll
+    for (int j = 0; j < kMS; ++j) {
+        const int k = c + kManyChains * j;
+        ex[j] = k < ns;
+        const int b = ex[j] ? xcc + 8 * k : xcc + 8 * c;
+        rsv[j] = exch_rsrc(a, b);
+        stb[j] = a.state + (long long)b * L.state_stride;
+    }
+    Poll pl{rsv[0], a.status, 0, false};
+    Tile t0[kReg];
+    unsigned dil[kReg], roff[kReg], pos0[kReg][kMS];
+#pragma unroll
+    for (int i = 0; i < kReg; ++i) {
+        dil[i] = 1; roff[i] = 0;
+#pragma unroll
+        for (int j = 0; j < kMS; ++j) pos0[i][j] = 0;
+        if (i < nown) {
+            const int l = sv + 8 * i;
+            load_tile(t0[i], a.P + L.off_layer0 + (long long)l * L.layer_stride + LayerOff::T0, lane);
+            dil[i] = (unsigned)pmeta[l]; roff[i] = (unsigned)pmeta[64 + l];
+#pragma unroll
+            for (int j = 0; j < kMS; ++j) if (ex[j]) pos0[i][j] = (unsigned)reinterpret_cast<const int*>(stb[j] + L.st_ringpos)[l];
+        }
+    }
+    const int n16 = lane & 15;
+    auto tap0 = [&](const float* ring, unsigned pos0_, unsigned d_, unsigned roff_, unsigned t, float& xa_, float& xb_) __attribute__((always_inline)) {
+        const unsigned slot = ring_slot(pos0_, t, d_);
+        const unsigned long long* p = reinterpret_cast<const unsigned long long*>(ring + roff_ + slot * 32);
+        const unsigned long long qa = __hip_atomic_load((gu64*)(p + (n16 >> 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long qb = __hip_atomic_load((gu64*)(p + 8 + (n16 >> 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        xa_ = __uint_as_float((n16 & 1) ? (unsigned)(qa >> 32) : (unsigned)qa);
+        xb_ = __uint_as_float((n16 & 1) ? (unsigned)(qb >> 32) : (unsigned)qb);
+    };
+    // ---- step 0: from the persisted state
+#pragma unroll
+    for (int i = 0; i < kReg; ++i) {
+        if (i < nown) {
+            const int l = sv + 8 * i;
+#pragma unroll
+            for (int j = 0; j < kMS; ++j) {
+                if (!ex[j]) continue;
+                float xa_, xb_;
+                tap0(stb[j] + L.st_ring, pos0[i][j], dil[i], roff[i], 0u, xa_, xb_);
+                const float pre = dot32_dpp(t0[i].w, xa_, xb_);
+                const float lcv = has_lc ? stb[j][L.st_lcprev + l * 64 + lane] : 0.0f;
+                xb_store(rsv[j], (int)XcdExch::PG + l * 64, lane, 1u, pre);
+                xb_store(rsv[j], (int)XcdExch::LG + l * 64, lane, 1u, lcv);
+            }
+        }
+    }
+    for (int t = 0; t < T && !pl.dead; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+        const bool more = t + 1 < T;
+#pragma unroll
+        for (int i = 0; i < kReg; ++i) {
+            if (i >= nown) continue;
+            const int l = sv + 8 * i;
+#pragma unroll
+            for (int j = 0; j < kMS; ++j) {
+                if (!ex[j] || pl.dead) continue;
+                const rsrc_t rs = rsv[j];
+                float* ring = stb[j] + L.st_ring;
+                pl.rs = rs;
+                float oa = 0.0f, ob = 0.0f;
+                if (more && dil[i] > 1) tap0(ring, pos0[i][j], dil[i], roff[i], (unsigned)t + 1u, oa, ob);     // already in the delay line
+                unsigned long long qa, qb;
+                pl.it = 0;
+                for (;;) {                                             // the layer input x_l[t] from the chain
+                    qa = xbm_load(rs, (int)XcdExch::ZX + l * 128 + 1, n16 * 2);
+                    qb = xbm_load(rs, (int)XcdExch::ZX + l * 128 + 65, n16 * 2);
+                    if (__all(g_tag(qa) == tag && g_tag(qb) == tag)) break;
+                    if (!poll_tick<true>(pl, 41)) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (pl.dead) continue;
+                const float xa_ = g_val(qa), xb_ = g_val(qb);
+                const unsigned slot = ring_slot(pos0[i][j], (unsigned)t, dil[i]);      // model.py:145 dilation queue <- layer input
+                if (lane < 32) ring[roff[i] + slot * 32 + lane] = lane < 16 ? xa_ : xb_;
+                if (more) {
+                    if (dil[i] == 1) { oa = xa_; ob = xb_; }
+                    const float pre = dot32_dpp(t0[i].w, oa, ob);
+                    float lcv = 0.0f;
+                    if (has_lc) {                                      // frame pushed at step t is used at step t+1 (model.py:79-80)
+                        const int lw = (int)XcdExch::LCR + (((t + 1) % kXcdLcRing) * kXcdLs + l) * 64;
+                        unsigned long long ql;
+                        pl.it = 0;
+                        for (;;) {
+                            ql = xbm_load(rs, lw, lane);
+                            if (__all(g_tag(ql) == tag + 1u)) break;
+                            if (!poll_tick<true>(pl, 42)) break;
+                            __builtin_amdgcn_s_sleep(8);
+                        }
+                        if (pl.dead) continue;
+                        lcv = g_val(ql);
+                    }
+                    xb_store(rs, (int)XcdExch::PG + l * 64, lane, tag + 1u, pre);
+                    xb_store(rs, (int)XcdExch::LG + l * 64, lane, tag + 1u, lcv);
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        if (!pl.dead) {
+#pragma unroll
+            for (int i = 0; i < kReg; ++i)
+                if (i < nown)
+#pragma unroll
+                    for (int j = 0; j < kMS; ++j)
+                        if (ex[j]) reinterpret_cast<int*>(stb[j] + L.st_ringpos)[sv + 8 * i] = (int)((pos0[i][j] + (unsigned)T) % dil[i]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kMS; ++j) xb_store(rsv[j], (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);
+        }
+    }
+}
+
+// ---- SKIP workgroup r = (layer group q, output half hh): model.py:94-96 skip 1x1 of ONE layer per wave for four 64-column slices,
+//      model.py:154 sum in layer order as a relay (LDS inside the group, one L2 hop between groups), model.py:157 relu at the end ---
+template <int INSTR>
+__device__ __forceinline__ void skip_many_role(const XArgs& xa, int xcc, int ns, int r)
+{
+    const XcdLaunch& a = xa.p;
+    const Layout& L = a.lay;
+    const int m = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int NL = L.NL, T = a.T;
+    const bool use_bias = L.use_bias != 0;
+    const int q = r >> 1, hh = r & 1;
+    const int ngroups = (NL + 7) >> 3;
+    if (q >= ngroups) return;
+    const int first = NL - 8 * (ngroups - 1);                   // size of group 0 (the LAST group is always full: its relay has caught up)
+    const int base = q == 0 ? 0 : first + 8 * (q - 1);
+    const int size = q == 0 ? first : 8;
+    if (m >= size) return;
+    const int l = base + m;
+    const bool from_lds = m > 0, from_l2 = (m == 0 && q > 0);
+    const bool last = (l == NL - 1), to_l2 = (!last && m == size - 1);
+    Tile ws[4];
+    float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    {
+        const long long lb = L.off_layer0 + (long long)l * L.layer_stride;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            load_tile(ws[j], a.P + lb + LayerOff::SK + (long long)(4 * hh + j) * kTile, lane);
+            if (use_bias) bs[j] = a.P[lb + LayerOff::SK + (long long)L.NSJ * kTile + (4 * hh + j) * 64 + lane];
+        }
+    }
+    Poll pl{exch_rsrc(a, xcc), a.status, 0, false};
+    const int n16 = lane & 15;
+    const int zc_lane = lane_of_z((lane < 32 ? 0 : 16) + n16);
+    unsigned long long seen = 0, period = 0;
+    for (int t = 0; t < T && !pl.dead; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+        if (period) nap_until(seen + period - (period >> 3));
+#pragma nounroll
+        for (int k = 0; k < ns; ++k) {
+            if (pl.dead) break;
+            const rsrc_t rs = exch_rsrc(a, xcc + 8 * k);
+            pl.rs = rs;
+            // the layer's 32 z values with ONE load per round (lanes 0-31 z[0..15] twice, lanes 32-63 z[16..31] twice)
+            unsigned long long qz;
+            MMARK(rs, 16 + 8 * r + m, 1);
+            pl.it = 0;
+            for (;;) {
+                qz = xbm_load(rs, (int)XcdExch::ZX + l * 128, zc_lane * 2);
+                if (__all(g_tag(qz) == tag)) break;
+                if (!poll_tick<true>(pl, 51)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            MMARK(rs, 16 + 8 * r + m, 2);
+            if (k == 0) {
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                const unsigned long long d = now - seen;
+                period = (seen != 0 && d < (1ull << 18)) ? d : 0;
+                seen = now;
+            }
+            const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)qz, (unsigned)qz, false, false);   // [lo, lo], [hi, hi]
+            const float xa_ = __uint_as_float(sw[0]), xb_ = __uint_as_float(sw[1]);
+            float val[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                val[j] = dot32_dpp(ws[j].w, xa_, xb_);                                              // model.py:96
+                if (use_bias) val[j] = val[j] + bs[j];
+            }
+            // model.py:154: the running total of layers 0 .. l-1 comes from the previous wave (LDS) or the previous group (L2)
+            float tot[4];
+            if (from_lds) {
+                unsigned long long qi[4];
+                const int o = ((k * 8 + m) * 4) * 64 + lane;
+                pl.it = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { qi[j] = LDSU64(o + j * 64); ok = ok && g_tag(qi[j]) == tag; }
+                    if (__all(ok)) break;
+                    if (!poll_tick<true>(pl, 52)) break;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tot[j] = g_val(qi[j]) + val[j];
+            } else if (from_l2) {
+                u32x4s d0, d1;
+                const int uw = (int)XcdExch::SKT + ((q - 1) * 2 + hh) * 256;
+                pl.it = 0;
+                for (;;) {
+                    d0 = xbm_load2(rs, uw, lane);
+                    d1 = xbm_load2(rs, uw + 128, lane);
+                    if (__all(d0.y == tag && d0.w == tag && d1.y == tag && d1.w == tag)) break;
+                    if (!poll_tick<true>(pl, 53)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                tot[0] = __uint_as_float(d0.x) + val[0]; tot[1] = __uint_as_float(d0.z) + val[1];
+                tot[2] = __uint_as_float(d1.x) + val[2]; tot[3] = __uint_as_float(d1.z) + val[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tot[j] = val[j];
+            }
+            if (pl.dead) break;
+            MMARK(rs, 16 + 8 * r + m, 3);
+            if (last) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float h = tot[j] > 0.0f ? tot[j] : 0.0f;                                  // model.py:157
+                    xb_store(rs, (int)XcdExch::H1 + (4 * hh + j) * 64, lane, tag, h);
+                }
+            } else if (to_l2) {
+                const int uw = (int)XcdExch::SKT + (q * 2 + hh) * 256;
+                xb_store2(rs, uw, lane, tag, tot[0], tot[1]);
+                xb_store2(rs, uw + 128, lane, tag, tot[2], tot[3]);
+            } else {
+                const int o = ((k * 8 + m + 1) * 4) * 64 + lane;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) LDSU64(o + j * 64) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(tot[j]);
+            }
+        }
+    }
+    if (pl.dead && lane == 0) {
+        for (int k = 0; k < ns; ++k) xb_store(exch_rsrc(a, xcc + 8 * k), (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);
+    }
+}
+
+template <int INSTR>
+__global__ void __launch_bounds__(512) wn_xcd_many_kernel(XArgs xa)
+{
+    const XcdLaunch& a = xa.p;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 15u;
+    int ticket = 0;
+    if (threadIdx.x == 0) ticket = (xcc < (unsigned)a.B && xcc < 8u) ? atomicAdd(a.roles + xcc, 1) : 1 << 20;
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = ticket;
+    for (int i = threadIdx.x; i < kManyLds; i += blockDim.x) lds[i] = 0.0f;      // LDS hand-off words start at zero
+    __syncthreads();
+    ticket = s_ticket;
+    const int ns = xcc < (unsigned)a.B && xcc < 8u ? (a.B - (int)xcc + 7) / 8 : 0;     // streams on this XCD (<= 8)
+    const int nch = ns < kManyChains ? ns : kManyChains;
+    if (ticket >= 2 * nch + 16 + xa.n_lc_wg) return;            // surplus workgroup (or an XCD without a stream)
+    const bool forced = a.forced != nullptr;
+    if (ticket < nch) {
+        const bool all = a.lay.use_bias && a.lay.G > 0 && a.lay.L > 0;
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int nlw = a.lay.NL - (wv < 6 ? 4 * wv : 24 + 3 * (wv - 6));
+        if (forced) chain_many_role<INSTR, false, true, -1>(xa, (int)xcc, ns, ticket);
+        else if (all && nlw >= 4 && wv < 6) chain_many_role<INSTR, true, false, 4>(xa, (int)xcc, ns, ticket);
+        else if (all && nlw >= 3 && wv >= 6) chain_many_role<INSTR, true, false, 3>(xa, (int)xcc, ns, ticket);
+        else if (all) chain_many_role<INSTR, true, false, -1>(xa, (int)xcc, ns, ticket);
+        else chain_many_role<INSTR, false, false, -1>(xa, (int)xcc, ns, ticket);
+        return;
+    }
+    if (ticket < 2 * nch) { service_many_role<INSTR>(xa, (int)xcc, ns, ticket - nch); return; }
+    const int role = ticket - 2 * nch;                           // 0-7 skip, 8-15 conv1, 16.. lc
+    if (role < 8) { if (!forced) skip_many_role<INSTR>(xa, (int)xcc, ns, role); return; }
+    XStreams<kManyPerXcd> sx;
+#pragma unroll
+    for (int k = 0; k < kManyPerXcd; ++k) { sx.b[k] = (int)xcc + 8 * (k < ns ? k : 0); sx.rs[k] = exch_rsrc(a, sx.b[k]); }
+    if (role < 16) { if (!forced) conv1_role<0, kManyPerXcd, true>(xa, sx, role - 8, ns); }
+    else lc_role<0, kManyPerXcd, false, true>(xa, sx, role - 16, ns);
+}
+
 // ---- pack: the chain's register images from the canonical blob (generate.py:157-161 Saver.restore) -------------------------
 __global__ void wn_xcd_pack_kernel(float* dst, const float* blob, Layout L)
 {
@@ -1169,6 +1826,7 @@ bool xcd_model_ok(const Layout& L)
 {
     return L.scalar && L.ifw == 32 && L.S == 512 && L.O <= 32 && L.NOJ == 1 && L.NL >= 1 && L.NL <= kXcdMaxLayers && L.NLC <= 4;
 }
+int xcd_max_streams(const Layout& L) { return L.NL > kXcdSeg0Layers ? kXcdStreams / 2 : kXcdManyStreams; }
 static int lc_layers_per_wave(const Layout& L) { const int n = L.NLC > 0 ? (L.NL > kXcdSeg0Layers ? 6 : 4) / L.NLC : 1; return n < 1 ? 1 : (n > 4 ? 4 : n); }
 int xcd_lc_workgroups(const Layout& L)
 {
@@ -1191,7 +1849,8 @@ int xcd_launch(const XcdLaunch& p, hipStream_t st)
     xa.lc_lpw = lc_layers_per_wave(p.lay);
     // chain workgroup: hand-off boxes + the dense kernels of its layers (136 KiB); more than 32 layers: the skip / service workgroups
     // keep the tiles of layers 0 .. NL-41 in LDS next to their value slots (159 KiB of the CU's 160)
-    const size_t shm = p.lay.NL > kXcdSeg0Layers ? (size_t)159 * 1024 : (size_t)(2048 + 32 * 1024) * 4;
+    const bool many = (p.B > kXcdStreams || p.many != 0) && p.lay.NL <= kXcdSeg0Layers;
+    const size_t shm = many ? (size_t)kManyLds * 4 : p.lay.NL > kXcdSeg0Layers ? (size_t)159 * 1024 : (size_t)(2048 + 32 * 1024) * 4;
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
@@ -1201,18 +1860,30 @@ int xcd_launch(const XcdLaunch& p, hipStream_t st)
     const int grid = 2 * cus;
     // instrumented builds are separate instantiations: 1 = phase stamps / stage markers, 2 = per-layer dumps
     const int instr = (p.prof != nullptr ? 1 : 0) | (p.dbg != nullptr ? 2 : 0);
-    if (p.lay.NL > kXcdSeg0Layers) {
-        if (instr != 0) return twv_fail(TWV_E_UNSUPPORTED, "layer dumps / phase stamps exist for the 30-layer XCD kernel only (set option \"xcd\" = 0 for the generic kernel)");
-        hipLaunchKernelGGL((wn_xcd_generate_kernel<0, true, false>), dim3(grid), dim3(512), shm, st, xa);
+    auto go = [&](auto kern) {
+        // more than 64 KiB of dynamic LDS: say so (the runtime has accepted the launch without it; the attribute is the documented way)
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shm, st, xa);
+    };
+    if (many) {
+        if (p.B > kXcdManyStreams) return twv_fail(TWV_E_UNSUPPORTED, "the many-streams XCD kernel takes at most 64 streams");
+        if (instr & 1) return twv_fail(TWV_E_UNSUPPORTED, "phase stamps exist for the one-chain-per-stream XCD kernel only (batch <= 32)");
+        if (instr == 2) go(wn_xcd_many_kernel<2>);
+        else go(wn_xcd_many_kernel<0>);
     }
-    else if (instr == 3) hipLaunchKernelGGL((wn_xcd_generate_kernel<3, false, false>), dim3(grid), dim3(512), shm, st, xa);
-    else if (instr == 2) hipLaunchKernelGGL((wn_xcd_generate_kernel<2, false, false>), dim3(grid), dim3(512), shm, st, xa);
-    else if (instr == 1) hipLaunchKernelGGL((wn_xcd_generate_kernel<1, false, false>), dim3(grid), dim3(512), shm, st, xa);
+    else if (p.lay.NL > kXcdSeg0Layers) {
+        if (instr != 0) return twv_fail(TWV_E_UNSUPPORTED, "layer dumps / phase stamps exist for the 30-layer XCD kernel only (set option \"xcd\" = 0 for the generic kernel)");
+        go(wn_xcd_generate_kernel<0, true, false>);
+    }
+    else if (instr == 3) go(wn_xcd_generate_kernel<3, false, false>);
+    else if (instr == 2) go(wn_xcd_generate_kernel<2, false, false>);
+    else if (instr == 1) go(wn_xcd_generate_kernel<1, false, false>);
     // ONE: batch <= 8 (one stream per XCD) without the multi-stream roles compiled into the kernel: the register allocation of the
     // sampling loop depends on what shares the kernel (measured on one box, interleaved: 10.42 against 10.59 us/step; specialising
     // further -- only the hparams-default sampling chain in the kernel -- gave 10.61 again: it is allocation luck, not a trend)
-    else if (p.B <= 8) hipLaunchKernelGGL((wn_xcd_generate_kernel<0, false, true>), dim3(grid), dim3(512), shm, st, xa);
-    else hipLaunchKernelGGL((wn_xcd_generate_kernel<0, false, false>), dim3(grid), dim3(512), shm, st, xa);
+    else if (p.B <= 8) go(wn_xcd_generate_kernel<0, false, true>);
+    else go(wn_xcd_generate_kernel<0, false, false>);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return twv_fail(TWV_E_HIP, std::string("xcd launch: ") + hipGetErrorString(e));
     return TWV_OK;

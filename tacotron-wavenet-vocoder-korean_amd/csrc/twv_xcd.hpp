@@ -10,7 +10,8 @@ namespace twv {
 constexpr int kXcdSeg0Layers = 30;     // first chain workgroup: waves 0..5 four layers each, waves 6 and 7 three (wave 7 also runs the causal layer + sampler)
 constexpr int kXcdMaxLayers = 50;      // a second chain workgroup takes layers 30.. (hparams.py has 50); limit: LDS of the service workgroup (tiles of layers 0 .. NL-33) and of the skip workgroups (value slots of two streams + tiles of layers 0 .. NL-41)
 constexpr int kXcdLs = 64;             // layer slots of the per-layer exchange arrays
-constexpr int kXcdStreams = 32;        // up to four streams per XCD (stream b runs on XCD b % 8)
+constexpr int kXcdStreams = 32;        // up to four streams per XCD (stream b runs on XCD b % 8), each with its own chain workgroup
+constexpr int kXcdManyStreams = 64;    // the many-streams kernel (30 layers or fewer): up to eight per XCD, two per chain workgroup
 constexpr int kXcdLcRing = 16;         // steps of lc projections the lc workgroups may run ahead of the chain
 constexpr int kXcdXlFloats = 13 * 64 * 4;   // per layer: the chain's register image [13 float4][64 lanes]
 constexpr int kXcdXcFloats = 8 * 64 * 4;    // causal kernel in the chain's lane order
@@ -32,7 +33,8 @@ struct XcdExch {
     static constexpr long long MARK = CTRL + 64;                        // [32 roles][8 waves] {step, stage} markers (instrumented build)
     static constexpr long long SEG = MARK + 256;                        // [64] residual vector, first -> second chain workgroup (more than 30 layers)
     static constexpr long long DONE = SEG + 64;                         // [64] end of a teacher-forced step, second chain workgroup -> head
-    static constexpr long long WORDS = DONE + 64;
+    static constexpr long long SKT = DONE + 64;                         // [3 hops][2 halves][2 pairs][64 lanes][2] running skip total, layer group -> next group (many-streams kernel)
+    static constexpr long long WORDS = SKT + 3 * 2 * 256;
     // (slots of layers a model does not have are never touched: they cost address space, not cache)
 };
 
@@ -51,12 +53,14 @@ struct XcdLaunch {
     int prof_steps;
     int prof_stream;               // the stream whose workgroups stamp (0; TWV_XCD_PROF_STREAM picks another one: tuning aid)
     int B, T;
+    int many;                      // 1: the many-streams kernel even where batch <= 32 (option "xcd_many": tests, A/B runs)
     unsigned long long* exch;      // [B][XcdExch::WORDS]
     int* roles;                    // [8] role tickets per XCD (zeroed before the launch)
     Layout lay;
 };
 
 bool xcd_model_ok(const Layout& L);                       // shape the kernel is written for
+int xcd_max_streams(const Layout& L);                     // 64 (30 layers or fewer), 16 above
 int xcd_lc_workgroups(const Layout& L);                   // lc workgroups per stream
 int xcd_workgroups_per_stream(const Layout& L);
 size_t xcd_exchange_bytes(int batch);                     // exchange area + role tickets

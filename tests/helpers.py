@@ -12,7 +12,7 @@ def make_case(O, dilations, scalar_input=True, S=512, Q=256, out_channels=30, if
 
 
 def make_model(batch, dilations, tensors, scalar_input=True, S=512, Q=256, out_channels=30, ifw=32, use_bias=True, G=32,
-               gc_card=2, L=80, up=(5, 5, 12), workers=None, groups=None, xcd=None):
+               gc_card=2, L=80, up=(5, 5, 12), workers=None, groups=None, xcd=None, xcd_many=None):
     import twvk_amd  # noqa: F401
     from twvk_amd.wavenet import WaveNetModel
     m = WaveNetModel(batch, dilations, 2, 32, 32, S, quantization_channels=Q, out_channels=out_channels,
@@ -25,6 +25,8 @@ def make_model(batch, dilations, tensors, scalar_input=True, S=512, Q=256, out_c
         m.set_option("groups", groups)
     if xcd is not None:
         m.set_option("xcd", xcd)          # 0: the generic kernel even where the XCD-per-stream kernel qualifies
+    if xcd_many is not None:
+        m.set_option("xcd_many", xcd_many)  # 1: the many-streams XCD kernel (two streams per chain workgroup) also at batch <= 32
     m.load_weights(tensors)
     return m
 

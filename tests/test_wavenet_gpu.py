@@ -560,6 +560,106 @@ def test_xcd_kernel_with_several_streams_per_xcd(torch_cuda, oracle, B):
     assert first_mismatch(got, want) is None, first_mismatch(got, want)
 
 
+@pytest.mark.parametrize("B", [48, 64])
+def test_xcd_many_streams_kernel_at_bench_geometry(torch_cuda, oracle, B):
+    """more than 32 streams: the many-streams kernel (five to eight streams per XCD: two per chain / service workgroup, skip
+    workgroups laid out as layer groups x output halves with the layer-ordered sum as a relay), BASELINE configs[1]'s model,
+    12 000 steps per stream with fused conditioning; every sample of every stream bit for bit"""
+    T = 12000
+    m, mel, gc, seed_in, u, want = _bench_case(oracle, B, T)
+    assert m.fused_conditioning(), "up to 64 streams are served by the XCD kernels on an MI355X"
+    got = m.generate(m.create_upsample(mel), gc, seed_in, u).cpu().numpy()
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+
+
+@pytest.mark.parametrize("B", [1, 9, 33, 43, 64])
+def test_xcd_many_streams_kernel_chunked_calls(torch_cuda, oracle, B):
+    """the many-streams kernel (forced with the `xcd_many` option where the batch alone would not select it) against the checker:
+    stream counts that leave chain workgroups with one slot, XCDs with different numbers of streams, chunked calls including
+    single-step launches (the state -- delay lines, causal queue, last lc frame -- carries over), materialised upsampled rows"""
+    dil = [2 ** i for i in range(10)] * 3
+    d, tensors, blob = make_case(oracle, dil, seed=5)
+    rng = np.random.RandomState(9 + B)
+    T = 640
+    mel = rng.uniform(-4, 4, (B, 3, 80)).astype(np.float32)
+    gc = (np.arange(B) % 2).astype(np.int32)
+    seed_in = (2 * rng.rand(B) - 1).astype(np.float32)
+    u = mol_uniforms(B, T, 10)
+    oracle.set_threads(min(B, oracle.set_threads(1)))
+    try:
+        want = oracle.generate_mol(d, blob, oracle.State(d, B), oracle.upsample(d, blob, mel)[:, :T], gc, seed_in, u)
+    finally:
+        oracle.set_threads(1)
+    m = make_model(B, dil, tensors, xcd_many=1)
+    U = m.create_upsample(mel).tensor()
+    outs, fi, p = [], seed_in, 0
+    for n in (300, 1, 1, 2, 336):
+        o = m.generate(U[:, p:p + n].contiguous(), gc, fi, u[:, p:p + n]).cpu().numpy()
+        outs.append(o); fi = o[:, -1]; p += n
+    got = np.concatenate(outs, axis=1)
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+
+
+@pytest.mark.parametrize("nl,use_bias,G,L,O", [(1, True, 32, 80, 30), (7, True, 32, 80, 30), (9, False, 32, 80, 30), (17, True, 0, 80, 30),
+                                             (25, True, 32, 0, 30), (28, False, 0, 0, 3), (30, True, 32, 80, 6)])
+def test_xcd_many_streams_kernel_shapes(torch_cuda, oracle, nl, use_bias, G, L, O):
+    """the many-streams kernel away from the bench shape: layer counts that end inside a chain wave / inside a skip layer group
+    (one group, a short first group), no biases, no global / local conditioning, other mixture sizes; B = 43 gives the XCDs five
+    and six streams; with layer dumps for the first steps"""
+    dil = ([1, 2, 4, 8, 16, 32, 64] * 5)[:nl]
+    B, T, dbg = 43, 450, 2
+    d, tensors, blob = make_case(oracle, dil, use_bias=use_bias, G=G, L=L, out_channels=O, scale=0.1)
+    m = make_model(B, dil, tensors, use_bias=use_bias, G=G, L=L, out_channels=O)
+    assert m.fused_conditioning() == bool(L)
+    rng = np.random.RandomState(nl)
+    mel = rng.uniform(-4, 4, (B, 2, 80)).astype(np.float32) if L else None
+    gc = (np.arange(B) % 2).astype(np.int32) if G else None
+    seed_in = (2 * rng.rand(B) - 1).astype(np.float32)
+    u = mol_uniforms(B, T, O // 3)
+    U_o = oracle.upsample(d, blob, mel)[:, :T] if L else None
+    oracle.set_threads(min(B, oracle.set_threads(1)))
+    try:
+        want = oracle.generate_mol(d, blob, oracle.State(d, B), U_o, gc, seed_in, u)
+    finally:
+        oracle.set_threads(1)
+    got, dump = m.generate(m.create_upsample(mel) if L else None, gc, seed_in, u, debug_steps=dbg)
+    dump = dump.cpu().numpy()
+    st = oracle.State(d, B)
+    inp = seed_in.copy()
+    for t in range(dbg):
+        raw, dz, dx = oracle.step(d, blob, st, inp, U_o[:, t] if L else None, gc, debug=True)
+        gz = dump[:, t, :nl * 64].reshape(B, nl, 2, 32)
+        assert first_mismatch(gz[:, :, 0], dz) is None, ("z", t, first_mismatch(gz[:, :, 0], dz))
+        assert first_mismatch(gz[:, :, 1], dx) is None, ("x", t, first_mismatch(gz[:, :, 1], dx))
+        assert first_mismatch(dump[:, t, nl * 64:nl * 64 + d.O], raw) is None, ("raw", t)
+        inp = want[:, t]
+    assert first_mismatch(got.cpu().numpy(), want) is None, first_mismatch(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("B", [11, 40])
+def test_xcd_many_streams_kernel_priming_then_generation(torch_cuda, oracle, B):
+    """generate.py:168-180 on the many-streams kernel: RF-1 teacher-forced steps through chain workgroups that carry two slots (the
+    skip / conv1 workgroups idle, the end of a slot's step releases its next one), then generation from mel frames"""
+    dil = [1, 2, 4, 8, 16, 32]
+    T = 600
+    d, tensors, blob = make_case(oracle, dil, scale=0.1)
+    m = make_model(B, dil, tensors, xcd_many=1)
+    rf = oracle.receptive_field(d)
+    rng = np.random.RandomState(9)
+    seedwave = rng.uniform(-1, 1, (B, rf)).astype(np.float32)
+    mel = rng.uniform(-4, 4, (B, 2, 80)).astype(np.float32)
+    gc = (np.arange(B) % 2).astype(np.int32)
+    st = oracle.State(d, B)
+    zeros = np.zeros((B, 80), np.float32)
+    for i in range(rf - 1):
+        oracle.step(d, blob, st, seedwave[:, i], zeros, gc)
+    u = mol_uniforms(B, T, 10)
+    want = oracle.generate_mol(d, blob, st, oracle.upsample(d, blob, mel), gc, seedwave[:, -1], u)
+    m.prime(seedwave[:, :rf - 1], None, gc)
+    got = m.generate(m.create_upsample(mel), gc, seedwave[:, -1], u).cpu().numpy()
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+
+
 def test_generic_kernel_at_bench_geometry(torch_cuda, oracle):
     """the generic kernel at B = 8: 8 workgroups per stream + helper workgroups (64 + 64 co-resident), 24 000 steps; bit for bit"""
     B, T = 8, 24000
