@@ -147,6 +147,15 @@ struct ChainRegs { float wc[32]; float bfg, gcv, bd; };
 // s_memtime counters of different CUs are offset against each other by milliseconds)
 #define XSTAMP(cond_, slot_) do { if ((INSTR & 1) && a.prof != nullptr && b == a.prof_stream && t < a.prof_steps && lane == 0 && (cond_)) a.prof[(long long)t * 64 + (slot_)] = wall_clock64(); } while (0)
 
+// wait accounting (INSTR & 4, the many-streams kernel's tuning build, scripts/many_profile.py): every wave adds up the s_memtime ticks it
+// spends inside its polls, by kind; at the end lane 0 of XCD 0's waves writes {total, waits...} to prof[(role * 8 + wave) * 8 ..]
+#define WACC_DECL() unsigned long long wacc_[6] = {0, 0, 0, 0, 0, 0}, w0_ = 0, wt0_ = 0; if (INSTR & 4) wt0_ = __builtin_amdgcn_s_memtime()
+#define WACC_T0() do { if (INSTR & 4) w0_ = __builtin_amdgcn_s_memtime(); } while (0)
+#define WACC_T1(i_) do { if (INSTR & 4) wacc_[i_] += __builtin_amdgcn_s_memtime() - w0_; } while (0)
+#define WACC_OUT(prof_, slot_, wave_) do { if ((INSTR & 4) && (prof_) != nullptr && (slot_) >= 0 && lane == 0) {                 \
+        unsigned long long* o_ = (prof_) + (((slot_) * 8 + (wave_)) * 8);                                                        \
+        o_[0] = __builtin_amdgcn_s_memtime() - wt0_;                                                                             \
+        o_[1] = wacc_[0]; o_[2] = wacc_[1]; o_[3] = wacc_[2]; o_[4] = wacc_[3]; o_[5] = wacc_[4]; o_[6] = wacc_[5]; } } while (0)
 // where a wave is (instrumented build only): read back from the exchange area after a watchdog abort
 #define XMARK(role_, stage_) do { if ((INSTR & 1) && lane == 0) xb_store(rs, (int)XcdExch::MARK + (role_) * 8 + (int)(threadIdx.x >> 6), 0, (unsigned)t + 1u, (float)(stage_)); } while (0)
 
@@ -823,7 +832,7 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
 //  chunks (2g, 2g+1) of model.py:161-165 conv1d_2 that read this block: what travels on is conv1d_2's partial table.
 // =====================================================================================================================
 template <int INSTR, int NS, bool BAR = false>
-__device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& sx, int g, const int ns_rt = NS)
+__device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& sx, int g, const int ns_rt = NS, const int prof_slot = -1)
 {
     const XcdLaunch& a = xa.p;
     const Layout& L = a.lay;
@@ -846,9 +855,12 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
         load_tile(t2, a.P + L.off_w2 + (long long)(2 * g + v) * kTile, lane);
     }
     unsigned long long t_arr = 0, period = 0;
+    WACC_DECL();
     for (int t = 0; t < T && !pl.dead; ++t) {
         const unsigned tag = (unsigned)t + 1u;
+        WACC_T0();
         if (period) nap_until(t_arr + period - (period >> 3));
+        WACC_T1(0);
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             if (pl.dead) break;
@@ -860,6 +872,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
             XMARK(ROLE_CONV0 + g, 1);
             // this wave's two chunks are exactly the 64 values skip workgroup v publishes: ONE granule per lane
             unsigned long long q;
+            WACC_T0();
             pl.it = 0;
             for (;;) {
                 q = xb_load_t<BAR>(rs, (int)XcdExch::H1 + v * 64, lane);
@@ -867,6 +880,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
                 if (!poll_tick<BAR>(pl, 61)) break;
                 __builtin_amdgcn_s_sleep(1);
             }
+            WACC_T1(1);
             // (no exit here on a watchdog abort: see the chain role; the loops end at their heads)
             unsigned long long now_arr = 0;
             if (k == 0) now_arr = __builtin_amdgcn_s_memtime();       // read only: the arithmetic follows the dots (as in the chain)
@@ -890,8 +904,10 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
             XSTAMP(g == 0 && v == 0, 23);
             XMARK(ROLE_CONV0 + g, 2);
             if (summer) {
+                WACC_T0();
                 pl.it = 0;
                 while (LDSVI(ob + O_CNT) < 8 * (t + 1)) { if (!poll_tick<BAR>(pl, 62)) break; }
+                WACC_T1(2);
                 // (no exit here on a watchdog abort: see the chain role; the loops end at their heads)
                 asm volatile("" ::: "memory");
                 XSTAMP(g == 0 && v == 0, 24);
@@ -915,6 +931,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
 #pragma unroll
         for (int k = 0; k < NS; ++k) xb_store(sx.rs[k], (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);       // the waves waiting on the LDS counter see it in poll_tick
     }
+    WACC_OUT(a.prof, prof_slot, v);
 }
 
 // =====================================================================================================================
@@ -922,7 +939,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
 //  ahead of the chain through the ring XcdExch::LCR.  Wave gw owns layers gw*lpw .. gw*lpw+lpw-1 (NLC tiles each).
 // =====================================================================================================================
 template <int INSTR, int NS, bool BIG, bool BAR = false>
-__device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx, int wg, const int ns_rt = NS)
+__device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx, int wg, const int ns_rt = NS, const int prof_slot = -1)
 {
     const XcdLaunch& a = xa.p;
     const Layout& L = a.lay;
@@ -963,6 +980,7 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx,
         }
         return;
     }
+    WACC_DECL();
     for (int u = 0; u < T && !pl.dead; ++u) {
         const int t = u;
         // ---- what does not depend on the stream: the taps of this row's phase (model.py:102-111)
@@ -973,6 +991,7 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx,
                 if (i < n_up) { k0[i] = a.P[L.off_up[i] + ph[i] * 2 + 0]; k1[i] = a.P[L.off_up[i] + ph[i] * 2 + 1]; }
         }
         // ---- throttle: slot (u+1) % ring is free once the chain has started step u + 2 - ring (every stream of the XCD)
+        WACC_T0();
         if (u + 3 - kXcdLcRing > 0) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
@@ -990,6 +1009,7 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx,
             }
             if (pl.dead) break;
         }
+        WACC_T1(0);
         // ---- the streams' input rows, all requested before the first is used
         float rowa[NS], rowb[NS];
 #pragma unroll
@@ -1084,6 +1104,7 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx,
 #pragma unroll
         for (int k = 0; k < NS; ++k) xb_store(sx.rs[k], (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);
     }
+    WACC_OUT(a.prof, prof_slot, v);
 }
 
 // ONE: see xcd_launch.  BIGK: the instantiation for 31-50 layers (second chain workgroup, helper waves with LDS-resident early tiles).  It is a kernel of
@@ -1167,7 +1188,7 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
 //  THE MANY-STREAMS KERNEL (batch 33 .. 64: five to eight streams per XCD).
 //
 //  The chain workgroup's weights serve a stream ~1 us of every ~9.5 us step per wave (SQ_WAIT_ANY 0.83 at batch 8), so TWO streams
-//  rotate through one chain workgroup here (slot 0 = stream k, slot 1 = stream k + 4 of the XCD): wave w runs slot 0's layers, hands
+//  rotate through one chain workgroup here (slots 0 / 1 = streams 2c / 2c + 1 of the XCD): wave w runs slot 0's layers, hands
 //  the residual vector on, runs slot 1's layers; register-resident kernels shared, per-slot state = the hand-off boxes, the gc
 //  projections (LDS) and, on wave 7, the causal queue and the sampler's noise terms.  Wave 7 draws a slot's sample and feeds its
 //  causal layer in one go (sampler(t-1) -> head(t) per slot, then the slots' layers): neither stream waits for the other's post phase.
@@ -1282,8 +1303,12 @@ __device__ __forceinline__ void chain_many_role(const XArgs& xa, int xcc, int ns
     if (nl == 0 && !head) return;
     const int oc = dpp_conv_out(lane), od = dpp_dense_out(lane);
     const ActCoef coef = act_coef(lane >= 32);
-    const int nslot = (c + kManyChains < ns) ? 2 : 1;          // slot s carries stream k = c + 4 s of this XCD
-    auto stream_of = [&](int s) { return xcc + 8 * (c + kManyChains * s); };
+    // slot s carries stream k = 2 c + s of this XCD: chain-mates are NEIGHBOURS in the order the shared workgroups serve the XCD's streams
+    // (k = 0, 1, ..): slot 1 follows slot 0 through the waves about one wave-time (1 us) later, which is also the spacing that order
+    // settles into.  (With k = c and c + 4 in one workgroup the shared roles held the mates >= 4 service times apart, wave 7 was still
+    // busy with slot 1's layers when slot 0's next sample was due, and one extra stream cost every stream of the XCD 0.9 us per step.)
+    const int nslot = (2 * c + 1 < ns) ? 2 : 1;
+    auto stream_of = [&](int s) { return xcc + 8 * (2 * c + s); };
     Poll pl{exch_rsrc(a, stream_of(0)), a.status, 0, false};
 
     // ---- the wave's layers: tap-1 conv kernel register-resident for the whole launch, dense kernel and gc projections in LDS
@@ -1335,6 +1360,7 @@ __device__ __forceinline__ void chain_many_role(const XArgs& xa, int xcc, int ns
     asm volatile(".p2align 6" ::: "memory");
 
     unsigned long long tin0 = 0, tin1 = 0, per0 = 0, per1 = 0;  // per slot: when the wave's input arrived in the previous step, the step period
+    WACC_DECL();
     for (int t = 0; t < T && !pl.dead; ++t) {
         const unsigned tag = (unsigned)t + 1u;
         // ---- wave 7: per slot, the sample of step t-1 straight into the causal layer of step t (one fma and three adds on the
@@ -1362,7 +1388,9 @@ __device__ __forceinline__ void chain_many_role(const XArgs& xa, int xcc, int ns
                     s_in = reinterpret_cast<const float*>(a.forced)[(long long)b * T + t];
                 } else if (t > 0) {
                     __builtin_amdgcn_s_setprio(3);
+                    WACC_T0();
                     s_in = many_sample<INSTR>(a, L, pl, rs, lane, (unsigned)t, b2v, lnl_, tq_, use_bias, b, NL);
+                    WACC_T1(2);                                  // (poll + the sampler's arithmetic)
                 }
                 // (a watchdog abort ends the loops at their heads)
                 MMARK(rs, w, 2);
@@ -1396,6 +1424,7 @@ __device__ __forceinline__ void chain_many_role(const XArgs& xa, int xcc, int ns
                 pl.rs = rs;
                 float pre[4] = {0.0f, 0.0f, 0.0f, 0.0f}, lcv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 MMARK(rs, w, 3);
+                WACC_T0();
                 // (A) this step's tap-0 chunks and lc projections of the wave's layers (service workgroup; long since published)
                 pl.it = 0;
                 for (;;) {
@@ -1414,6 +1443,8 @@ __device__ __forceinline__ void chain_many_role(const XArgs& xa, int xcc, int ns
                     __builtin_amdgcn_s_sleep(4);
                 }
                 MMARK(rs, w, 4);
+                WACC_T1(0);
+                WACC_T0();
                 // (B) the wave's input: the previous wave's residual vector (wave 0: the causal layer's output); sleep until its turn is near
                 const unsigned long long t_in = s ? tin1 : tin0, in_period = s ? per1 : per0;
                 if (in_period) nap_until(t_in + in_period - (in_period >> 4));
@@ -1427,6 +1458,7 @@ __device__ __forceinline__ void chain_many_role(const XArgs& xa, int xcc, int ns
                 __builtin_amdgcn_s_setprio(3);
                 float X = g_val(q);
                 const unsigned long long now_in = __builtin_amdgcn_s_memtime();
+                WACC_T1(1);
                 auto run_layers = [&](auto nc) __attribute__((always_inline)) {
                     constexpr int N = decltype(nc)::value;
 #pragma unroll
@@ -1486,6 +1518,7 @@ __device__ __forceinline__ void chain_many_role(const XArgs& xa, int xcc, int ns
     }
     if (pl.dead && lane == 0)
         for (int s = 0; s < nslot; ++s) xb_store(exch_rsrc(a, stream_of(s)), (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);
+    WACC_OUT(a.prof, xcc == 0 ? c : -1, w);
 }
 
 // ---- SERVICE workgroup c of an XCD, two stream slots: delay lines + tap-0 chunks one step ahead (service_role for two streams) ---
@@ -1508,13 +1541,14 @@ __device__ __forceinline__ void service_many_role(const XArgs& xa, int xcc, int 
     float* stb[kMS];
 #pragma unroll
     for (int j = 0; j < kMS; ++j) {
-        const int k = c + kManyChains * j;
+        const int k = 2 * c + j;                               // the chain workgroup's two streams
         ex[j] = k < ns;
-        const int b = ex[j] ? xcc + 8 * k : xcc + 8 * c;
+        const int b = ex[j] ? xcc + 8 * k : xcc + 8 * 2 * c;
         rsv[j] = exch_rsrc(a, b);
         stb[j] = a.state + (long long)b * L.state_stride;
     }
     Poll pl{rsv[0], a.status, 0, false};
+    WACC_DECL();
     Tile t0[kReg];
     unsigned dil[kReg], roff[kReg], pos0[kReg][kMS];
 #pragma unroll
@@ -1572,6 +1606,7 @@ __device__ __forceinline__ void service_many_role(const XArgs& xa, int xcc, int 
                 float oa = 0.0f, ob = 0.0f;
                 if (more && dil[i] > 1) tap0(ring, pos0[i][j], dil[i], roff[i], (unsigned)t + 1u, oa, ob);     // already in the delay line
                 unsigned long long qa, qb;
+                WACC_T0();
                 pl.it = 0;
                 for (;;) {                                             // the layer input x_l[t] from the chain
                     qa = xbm_load(rs, (int)XcdExch::ZX + l * 128 + 1, n16 * 2);
@@ -1580,6 +1615,7 @@ __device__ __forceinline__ void service_many_role(const XArgs& xa, int xcc, int 
                     if (!poll_tick<true>(pl, 41)) break;
                     __builtin_amdgcn_s_sleep(8);
                 }
+                WACC_T1(0);
                 if (pl.dead) continue;
                 const float xa_ = g_val(qa), xb_ = g_val(qb);
                 const unsigned slot = ring_slot(pos0[i][j], (unsigned)t, dil[i]);      // model.py:145 dilation queue <- layer input
@@ -1591,6 +1627,7 @@ __device__ __forceinline__ void service_many_role(const XArgs& xa, int xcc, int 
                     if (has_lc) {                                      // frame pushed at step t is used at step t+1 (model.py:79-80)
                         const int lw = (int)XcdExch::LCR + (((t + 1) % kXcdLcRing) * kXcdLs + l) * 64;
                         unsigned long long ql;
+                        WACC_T0();
                         pl.it = 0;
                         for (;;) {
                             ql = xbm_load(rs, lw, lane);
@@ -1598,6 +1635,7 @@ __device__ __forceinline__ void service_many_role(const XArgs& xa, int xcc, int 
                             if (!poll_tick<true>(pl, 42)) break;
                             __builtin_amdgcn_s_sleep(8);
                         }
+                        WACC_T1(1);
                         if (pl.dead) continue;
                         lcv = g_val(ql);
                     }
@@ -1620,6 +1658,7 @@ __device__ __forceinline__ void service_many_role(const XArgs& xa, int xcc, int 
             for (int j = 0; j < kMS; ++j) xb_store(rsv[j], (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);
         }
     }
+    WACC_OUT(a.prof, xcc == 0 ? 4 + c : -1, sv);
 }
 
 // ---- SKIP workgroup r = (layer group q, output half hh): model.py:94-96 skip 1x1 of ONE layer per wave for four 64-column slices,
@@ -1656,9 +1695,12 @@ __device__ __forceinline__ void skip_many_role(const XArgs& xa, int xcc, int ns,
     const int n16 = lane & 15;
     const int zc_lane = lane_of_z((lane < 32 ? 0 : 16) + n16);
     unsigned long long seen = 0, period = 0;
+    WACC_DECL();
     for (int t = 0; t < T && !pl.dead; ++t) {
         const unsigned tag = (unsigned)t + 1u;
+        WACC_T0();
         if (period) nap_until(seen + period - (period >> 3));
+        WACC_T1(0);
 #pragma nounroll
         for (int k = 0; k < ns; ++k) {
             if (pl.dead) break;
@@ -1667,6 +1709,7 @@ __device__ __forceinline__ void skip_many_role(const XArgs& xa, int xcc, int ns,
             // the layer's 32 z values with ONE load per round (lanes 0-31 z[0..15] twice, lanes 32-63 z[16..31] twice)
             unsigned long long qz;
             MMARK(rs, 16 + 8 * r + m, 1);
+            WACC_T0();
             pl.it = 0;
             for (;;) {
                 qz = xbm_load(rs, (int)XcdExch::ZX + l * 128, zc_lane * 2);
@@ -1674,6 +1717,7 @@ __device__ __forceinline__ void skip_many_role(const XArgs& xa, int xcc, int ns,
                 if (!poll_tick<true>(pl, 51)) break;
                 __builtin_amdgcn_s_sleep(1);
             }
+            WACC_T1(1);
             MMARK(rs, 16 + 8 * r + m, 2);
             if (k == 0) {
                 const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -1691,6 +1735,7 @@ __device__ __forceinline__ void skip_many_role(const XArgs& xa, int xcc, int ns,
             }
             // model.py:154: the running total of layers 0 .. l-1 comes from the previous wave (LDS) or the previous group (L2)
             float tot[4];
+            WACC_T0();
             if (from_lds) {
                 unsigned long long qi[4];
                 const int o = ((k * 8 + m) * 4) * 64 + lane;
@@ -1721,6 +1766,7 @@ __device__ __forceinline__ void skip_many_role(const XArgs& xa, int xcc, int ns,
 #pragma unroll
                 for (int j = 0; j < 4; ++j) tot[j] = val[j];
             }
+            WACC_T1(2);
             if (pl.dead) break;
             MMARK(rs, 16 + 8 * r + m, 3);
             if (last) {
@@ -1743,6 +1789,177 @@ __device__ __forceinline__ void skip_many_role(const XArgs& xa, int xcc, int ns,
     if (pl.dead && lane == 0) {
         for (int k = 0; k < ns; ++k) xb_store(exch_rsrc(a, xcc + 8 * k), (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);
     }
+    WACC_OUT(a.prof, xcc == 0 ? 8 + r : -1, m);
+}
+
+// ---- LC workgroups of the many-streams kernel: lc_role's arithmetic (model.py:102-111 create_upsample row by row, model.py:75-83
+//      lc_filter|lc_gate of the wave's layer) with the two things that made it the busiest role at eight streams per XCD removed
+//      (scripts/many_profile.py: 88 % busy, everything else waiting on it):
+//      * a transposed-conv stage's output only changes when ITS phase digit (or an earlier one, or the mel frame) changes -- with
+//        upsample_factor [5, 5, 12] stage 0 every 60 rows, stage 1 every 12, only the last stage every row.  Each stage's input row is
+//        kept per stream in wave-private LDS and a stage is re-run only when its input changed: same fmas on the same values, so the
+//        same bits, a third of the LDS round trips; the mel frame is re-read every 300 rows instead of every row;
+//      * the throttle on the chain's progress is checked every fourth row, for all streams in ONE polling round.
+template <int INSTR>
+__device__ __forceinline__ void lc_many_role(const XArgs& xa, int xcc, int ns, int wg, const int prof_slot)
+{
+    const XcdLaunch& a = xa.p;
+    const Layout& L = a.lay;
+    const int v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int NL = L.NL, T = a.T, NLC = L.NLC, Lc = L.L, lpw = xa.lc_lpw;
+    const int gw = wg * 8 + v;
+    const int lfirst = gw * lpw;
+    int nown = NL - lfirst;
+    nown = nown < 0 ? 0 : (nown > lpw ? lpw : nown);
+    if (nown == 0) return;
+    Poll pl{exch_rsrc(a, xcc), a.status, 0, false};
+    const int* hdr = reinterpret_cast<const int*>(a.cond);
+    const int mode = hdr[XH_MODE], rows = hdr[XH_ROWS];
+    const float* payload = a.cond + XH_WORDS + (long long)a.B * NL * 64;
+    constexpr int kLt = 4;
+    Tile lt[kLt];
+#pragma unroll
+    for (int idx = 0; idx < kLt; ++idx) {
+        if (idx < nown * NLC) {
+            const int j = idx / NLC, c = idx - j * NLC;
+            load_tile(lt[idx], a.P + L.off_lcw + (long long)(lfirst + j) * L.lcw_stride + (long long)c * kTile, lane);
+        }
+    }
+    const int n16 = lane & 15;
+    const int n_up = (mode == XLC_UPSAMPLED) ? 0 : L.n_up;          // rows handed over already upsampled: no stage
+    int hop = 1;
+    for (int i = 0; i < L.n_up; ++i) hop *= L.up[i];
+    const long long need_rows = (mode == XLC_MEL) ? ((long long)T + hop - 1) / hop : T;
+    if (rows < need_rows) {
+        if (lane == 0) {
+            atomicMax(a.status, 71);
+            for (int k = 0; k < ns; ++k) xb_store(exch_rsrc(a, xcc + 8 * k), (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);
+        }
+        return;
+    }
+    // wave-private LDS: per stream n_up + 1 rows of kRow floats: row 0 the input frame, row i the output of stage i - 1
+    const int kRow = NLC * 32;
+    const int o_wave = v * (kManyLds / 8);                          // an eighth of the workgroup's LDS per wave (see xcd_many_lc_fits)
+    auto rowoff = [&](int k, int i) { return o_wave + (k * (n_up + 1) + i) * kRow; };
+    int ph[4] = {0, 0, 0, 0}, frame = 0;
+    WACC_DECL();
+    for (int u = 0; u < T && !pl.dead; ++u) {
+        const int t = u;
+        (void)t;
+        // ---- throttle, every fourth row for the next four: slot (u'+1) % ring is free once the chain has started step u' + 2 - ring
+        WACC_T0();
+        if ((u & 3) == 0 && u + 6 - kXcdLcRing > 0) {
+            pl.it = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < kManyPerXcd; ++k) {
+                    if (k < ns) {
+                        const unsigned long long q = xbm_load(exch_rsrc(a, xcc + 8 * k), (int)XcdExch::CTRL, 0);
+                        ok = ok && (int)g_tag(q) >= u + 6 - kXcdLcRing;
+                    }
+                }
+                if (ok) break;
+                if (!poll_tick<true>(pl, 72)) break;
+                __builtin_amdgcn_s_sleep(16);
+            }
+            if (pl.dead) break;
+        }
+        WACC_T1(0);
+        // ---- which stages see a new input at this row: stage j iff the phase digits after j are all zero (the counter's carry
+        // reached digit j); the input frame itself iff every digit is zero
+        int first = n_up > 0 ? n_up - 1 : 0;
+#pragma unroll
+        for (int j = 3; j >= 1; --j)
+            if (first == j && ph[j] == 0) first = j - 1;
+        const bool reload = (n_up == 0) || (first == 0 && ph[0] == 0);
+        float k0[4] = {0.f, 0.f, 0.f, 0.f}, k1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n_up && i >= first) { k0[i] = a.P[L.off_up[i] + ph[i] * 2 + 0]; k1[i] = a.P[L.off_up[i] + ph[i] * 2 + 1]; }
+#pragma nounroll
+        for (int k = 0; k < ns; ++k) {
+            const int b = xcc + 8 * k;
+            const rsrc_t rs = exch_rsrc(a, b);
+            if (reload) {                                               // row `frame` (mel) / row u (upsampled), zero padded to kRow
+                const float* src = payload + ((long long)b * rows + (mode == XLC_UPSAMPLED ? u : frame)) * Lc;
+                const float ra = lane < Lc ? src[lane] : 0.0f;
+                const float rb = 64 + lane < Lc ? src[64 + lane] : 0.0f;
+                const int o = rowoff(k, 0);
+                if (lane < kRow) lds[o + lane] = ra;
+                if (64 + lane < kRow) lds[o + 64 + lane] = rb;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < n_up && i >= first) {
+                    // out[m] = K[a][0]*in[m] + K[a][1]*in[m-1]   as a two-term AC-1 chunk   (model.py:102-111, 'same' transposed conv)
+                    const int o_in = rowoff(k, i), o_out = rowoff(k, i + 1);
+#pragma unroll
+                    for (int hlf = 0; hlf < 2; ++hlf) {
+                        const int m = hlf * 64 + lane;
+                        if (m < kRow) {
+                            const float x0 = lds[o_in + m];
+                            const float x1 = m > 0 ? lds[o_in + m - 1] : 0.0f;
+                            const float s0 = fma_(k0[i], x0, 0.0f);
+                            const float s1 = fma_(k1[i], x1, 0.0f);
+                            const float r = (s0 + s1) + (0.0f + 0.0f);
+                            lds[o_out + m] = m < Lc ? r : 0.0f;
+                        }
+                    }
+                }
+            }
+            const int o_cur = rowoff(k, n_up);
+            // ---- projections: AC-1 chunks of 32 over the lc channels, chunk values added in order
+            float resx[kLt];
+#pragma unroll
+            for (int idx = 0; idx < kLt; ++idx) {
+                resx[idx] = 0.0f;
+                if (idx < nown * NLC) {
+                    const int c = idx % NLC;
+                    const float xa_ = lds[o_cur + c * 32 + n16], xb_ = lds[o_cur + c * 32 + 16 + n16];
+                    resx[idx] = dot32_dpp(lt[idx].w, xa_, xb_);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kLt; ++j) {
+                if (j < nown) {
+                    float r = 0.0f;
+#pragma unroll
+                    for (int idx = 0; idx < kLt; ++idx) {
+                        if (idx >= j * NLC && idx < (j + 1) * NLC) r = (idx == j * NLC) ? resx[idx] : r + resx[idx];
+                    }
+                    const int l = lfirst + j;
+                    if (u + 1 < T) xb_store(rs, (int)XcdExch::LCR + (((u + 1) % kXcdLcRing) * kXcdLs + l) * 64, lane, (unsigned)u + 2u, r);
+                    else {
+                        // the frame the NEXT call uses at its step 0; in a short call wait until the service workgroup has read the
+                        // previous call's frame from the same slot (it publishes it as LG tag 1 right after reading it; see lc_role)
+                        if (T <= kXcdLcRing + 1) {
+                            pl.rs = rs;
+                            pl.it = 0;
+                            for (;;) {
+                                const unsigned long long ql = xbm_load(rs, (int)XcdExch::LG + l * 64, lane);
+                                if (__all(g_tag(ql) >= 1u)) break;
+                                if (!poll_tick<true>(pl, 73)) break;
+                                __builtin_amdgcn_s_sleep(8);
+                            }
+                        }
+                        (a.state + (long long)b * L.state_stride)[L.st_lcprev + l * 64 + lane] = r;
+                    }
+                }
+            }
+        }
+        if (n_up > 0) {                                             // advance the phase counter (last stage fastest)
+            int carry = 1;
+#pragma unroll
+            for (int i = 3; i >= 0; --i) {
+                if (i < n_up && carry) { ph[i] += 1; carry = 0; if (ph[i] == L.up[i]) { ph[i] = 0; carry = 1; } }
+            }
+            frame += carry;
+        }
+    }
+    if (pl.dead && lane == 0)
+        for (int k = 0; k < ns; ++k) xb_store(exch_rsrc(a, xcc + 8 * k), (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);
+    WACC_OUT(a.prof, prof_slot, v);
 }
 
 template <int INSTR>
@@ -1760,7 +1977,7 @@ __global__ void __launch_bounds__(512) wn_xcd_many_kernel(XArgs xa)
     __syncthreads();
     ticket = s_ticket;
     const int ns = xcc < (unsigned)a.B && xcc < 8u ? (a.B - (int)xcc + 7) / 8 : 0;     // streams on this XCD (<= 8)
-    const int nch = ns < kManyChains ? ns : kManyChains;
+    const int nch = (ns + kMS - 1) / kMS;                         // chain (and service) workgroups: two streams each
     if (ticket >= 2 * nch + 16 + xa.n_lc_wg) return;            // surplus workgroup (or an XCD without a stream)
     const bool forced = a.forced != nullptr;
     if (ticket < nch) {
@@ -1780,8 +1997,8 @@ __global__ void __launch_bounds__(512) wn_xcd_many_kernel(XArgs xa)
     XStreams<kManyPerXcd> sx;
 #pragma unroll
     for (int k = 0; k < kManyPerXcd; ++k) { sx.b[k] = (int)xcc + 8 * (k < ns ? k : 0); sx.rs[k] = exch_rsrc(a, sx.b[k]); }
-    if (role < 16) { if (!forced) conv1_role<0, kManyPerXcd, true>(xa, sx, role - 8, ns); }
-    else lc_role<0, kManyPerXcd, false, true>(xa, sx, role - 16, ns);
+    if (role < 16) { if (!forced) conv1_role<(INSTR & 4), kManyPerXcd, true>(xa, sx, role - 8, ns, xcc == 0 ? 16 + role - 8 : -1); }
+    else lc_many_role<INSTR>(xa, (int)xcc, ns, role - 16, xcc == 0 ? 24 + role - 16 : -1);
 }
 
 // ---- pack: the chain's register images from the canonical blob (generate.py:157-161 Saver.restore) -------------------------
@@ -1826,7 +2043,9 @@ bool xcd_model_ok(const Layout& L)
 {
     return L.scalar && L.ifw == 32 && L.S == 512 && L.O <= 32 && L.NOJ == 1 && L.NL >= 1 && L.NL <= kXcdMaxLayers && L.NLC <= 4;
 }
-int xcd_max_streams(const Layout& L) { return L.NL > kXcdSeg0Layers ? kXcdStreams / 2 : kXcdManyStreams; }
+// many-streams kernel: every lc wave caches (n_up + 1) rows of NLC*32 floats for each of the XCD's eight streams in its eighth of the LDS
+static bool xcd_many_lc_fits(const Layout& L) { return (long long)kManyPerXcd * (L.n_up + 1) * L.NLC * 32 <= kManyLds / 8; }
+int xcd_max_streams(const Layout& L) { return L.NL > kXcdSeg0Layers ? kXcdStreams / 2 : (xcd_many_lc_fits(L) ? kXcdManyStreams : kXcdStreams); }
 static int lc_layers_per_wave(const Layout& L) { const int n = L.NLC > 0 ? (L.NL > kXcdSeg0Layers ? 6 : 4) / L.NLC : 1; return n < 1 ? 1 : (n > 4 ? 4 : n); }
 int xcd_lc_workgroups(const Layout& L)
 {
@@ -1849,7 +2068,7 @@ int xcd_launch(const XcdLaunch& p, hipStream_t st)
     xa.lc_lpw = lc_layers_per_wave(p.lay);
     // chain workgroup: hand-off boxes + the dense kernels of its layers (136 KiB); more than 32 layers: the skip / service workgroups
     // keep the tiles of layers 0 .. NL-41 in LDS next to their value slots (159 KiB of the CU's 160)
-    const bool many = (p.B > kXcdStreams || p.many != 0) && p.lay.NL <= kXcdSeg0Layers;
+    const bool many = (p.B > kXcdStreams || p.many != 0) && p.lay.NL <= kXcdSeg0Layers && xcd_many_lc_fits(p.lay);
     const size_t shm = many ? (size_t)kManyLds * 4 : p.lay.NL > kXcdSeg0Layers ? (size_t)159 * 1024 : (size_t)(2048 + 32 * 1024) * 4;
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
@@ -1868,8 +2087,10 @@ int xcd_launch(const XcdLaunch& p, hipStream_t st)
     };
     if (many) {
         if (p.B > kXcdManyStreams) return twv_fail(TWV_E_UNSUPPORTED, "the many-streams XCD kernel takes at most 64 streams");
-        if (instr & 1) return twv_fail(TWV_E_UNSUPPORTED, "phase stamps exist for the one-chain-per-stream XCD kernel only (batch <= 32)");
-        if (instr == 2) go(wn_xcd_many_kernel<2>);
+        // a profile buffer selects the wait-accounting build here (scripts/many_profile.py), not the phase stamps of the batch <= 32 kernel
+        if (instr == 3) return twv_fail(TWV_E_UNSUPPORTED, "layer dumps and wait accounting are separate builds of the many-streams kernel");
+        if (instr == 1) go(wn_xcd_many_kernel<4>);
+        else if (instr == 2) go(wn_xcd_many_kernel<2>);
         else go(wn_xcd_many_kernel<0>);
     }
     else if (p.lay.NL > kXcdSeg0Layers) {
