@@ -37,6 +37,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step measurement (configs[3], RCCL all-reduce at N>1)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="host time per CPU-baseline leg")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise the launch / rendezvous / max-over-ranks path (gloo)")
+    ap.add_argument("--e2e", action="store_true", help="configs[4] instead: end-to-end text -> mel -> wave, 8 utterances sharded over the GPUs (scripts/e2e_bench.py)")
+    ap.add_argument("--e2e-frames", type=int, default=1000, help="mel frames per utterance handed to the vocoder with --e2e (1000 = the full 200-step decode)")
     return ap.parse_args(argv)
 
 
@@ -81,6 +83,13 @@ def main():
 
     import numpy as np
     import torch
+
+    if args.e2e:
+        # BASELINE configs[4] (one line of its own): the same launcher path, scripts/e2e_bench.py as the rank program
+        import runpy
+        sys.argv = [os.path.join(ROOT, "scripts", "e2e_bench.py"), "--frames", str(args.e2e_frames)]
+        runpy.run_path(sys.argv[0], run_name="__main__")
+        return
 
     if args.dry_run:
         # the multi-rank skeleton without a GPU: rendezvous on 127.0.0.1, barrier-bracketed timed region, MAX over ranks, rank-0 report
@@ -191,12 +200,26 @@ def main():
     _lib.check(m._L.twv_wavenet_status(C.c_void_p(m._status.data_ptr()), None))
     samples = out.cpu().numpy()
     ok = bool(np.isfinite(samples).all() and np.abs(samples).max() <= 1.0)
-    produced = torch.tensor([1.0 if ok else 0.0, dt], dtype=torch.float64, device=dev)
+    # the checker on THIS rank's timed output (after the timed region): the first 600 samples of every stream, bit for bit
+    ncheck = min(T, 600)
+    matched = 0.0
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        d_chk = O.make_dims(dil)
+        blob_chk = O.blob_from_tensors(d_chk, tensors)
+        Uo = O.upsample(d_chk, blob_chk, mel.cpu().numpy()[:, :(ncheck + hp.hop_size - 1) // hp.hop_size])[:, :ncheck]
+        O.set_threads(min(B, O.set_threads(1)))
+        want = O.generate_mol(d_chk, blob_chk, O.State(d_chk, B), Uo, gc, seed_in, u[:, :ncheck].cpu().numpy())
+        O.set_threads(1)
+        matched = 1.0 if np.array_equal(samples[:, :ncheck], want) else 0.0
+    produced = torch.tensor([1.0 if ok else 0.0, dt, matched], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(produced[:1], op=dist.ReduceOp.SUM)       # ranks that produced samples: what n_gpus reports
-        dist.all_reduce(produced[1:], op=dist.ReduceOp.MAX)
-    n_ok, dt = int(produced[0].item()), float(produced[1].item())
+        dist.all_reduce(produced[1:2], op=dist.ReduceOp.MAX)
+        dist.all_reduce(produced[2:], op=dist.ReduceOp.SUM)       # ranks whose output matched the checker
+    n_ok, dt, n_matched = int(produced[0].item()), float(produced[1].item()), int(produced[2].item())
     assert ok, "rank %d: samples are not finite / not in [-1, 1]" % rank
+    assert args.no_cpu_baseline or matched == 1.0, "rank %d: timed output differs from the CPU checker in the first %d samples" % (rank, ncheck)
     gen_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
 
     # secondary: configs[3] teacher-forced training step, per-GPU batch 64 x 8000 (cropped to 7800) samples, data-parallel with a
@@ -228,7 +251,18 @@ def main():
                 tq = torch.tensor([qdt], dtype=torch.float64, device=dev)
                 dist.all_reduce(tq, op=dist.ReduceOp.MAX)
                 qdt = float(tq.item())
+            # executed matrix-core work of one step (forward + two backward contractions per GEMM; the lc projection is NOT in it: it
+            # runs at frame rate as 8 VALU fmas per row): per layer (2 taps x 32x64 + dense 32x32) MACs on all B*(T-1) rows
+            # and the skip 1x1 (32x512) on the B*out_w output rows; conv1d_1 512x512 and conv1d_2 512x30 on the output rows
+            rows_all = 64 * (TT_ - 1); rows_ow = 64 * trn.output_width
+            mac_fwd = len(dil) * (rows_all * (2 * 32 * 64 + 32 * 32) + rows_ow * 32 * 512) + rows_ow * (512 * 512 + 512 * 30)
+            flop_step = 2.0 * 3.0 * mac_fwd
             train_res = {"metric": "WaveNet training audio samples/sec (teacher-forced step: MoL loss, backward, all-reduce, Adam, EMA)",
+                         "roofline": {"bound": "mfma", "kernel": "whole step: tr_layer_{fwd,bwd1,bwd2}_kernel + the wide f32 GEMMs (rocBLAS MI16x16x4)",
+                                      "achieved": flop_step / qdt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flop_step / qdt / 1e12 / 157.3,
+                                      "flop_per_step": flop_step, "traffic": None,
+                                      "note": "executed f32 matrix-core FLOPs only (2 x 3 x forward MACs of the dense contractions; per-kernel durations and "
+                                              "SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F32 counters: profiles/r03_rocprofv3_*train*)"},
                          "value": world * 64 * TT_ / qdt, "unit": "audio samples/s", "steps_per_s": 1.0 / qdt, "ms_per_step": qdt * 1e3,
                          "n_gpus": world, "scaling": "weak", "dtype": "f32",
                          "collective": "all-reduce(sum) of one flat f32 gradient buffer, %d elements, RCCL" % trn.n_params if world > 1 else "none (1 GPU)",
@@ -248,7 +282,13 @@ def main():
         bytes_per_step = wfloats * 4 + B * (80 + 1 + 1) * 4
         k_ms = float(np.mean(gen_ms))
         achieved = bytes_per_step * T / (k_ms * 1e-3) / 1e9
-        kernel = "wn_xcd_generate_kernel" if fused else "wn_generate_kernel"
+        kernel = ("wn_xcd_many_kernel" if B > 32 else "wn_xcd_generate_kernel") if fused else "wn_generate_kernel"
+        us_step = k_ms * 1e3 / T
+        # what binds this kernel is the sample-to-sample dependency chain, not HBM: the floor of that chain from the micro-benchmarks
+        # (scripts/ubench/xcd_chain_ubench.hip -> profiles/r02_xcd_chain_ubench*.txt, profiles/r02_xcd_phase_profile_v6.txt)
+        floor_us = NL * 0.200 + 8 * 0.075 + 0.15 + (3 * 0.26 + 1.08)
+        macs_stream = NL * (2 * 32 * 64 + 32 * 32 + 32 * 512 + 80 * 64) + 32 * 32 + 512 * 512 + 512 * 30   # executed per stream and step (gc hoisted)
+        flop_step = 2.0 * macs_stream * B
         tps = traffic_per_step(kernel, "B%d_NL%d" % (B, NL))
         res = {
             "metric": "WaveNet autoregressive audio samples/sec at 24 kHz, batch=8",
@@ -267,7 +307,14 @@ def main():
                          # HBM bytes per launch from rocprofv3 PMC (separate --pmc passes; FETCH_SIZE / WRITE_SIZE with the guide's gfx950
                          # corrections), per generated step, for THESE generation-kernel sources (profiles/traffic.json is keyed by _lib.generation_hash())
                          "traffic": None if tps is None else tps * T, "algorithmic_bytes_per_launch": bytes_per_step * T,
-                         "kernel_ms": k_ms, "us_per_generation_step": k_ms * 1e3 / T,
+                         "kernel_ms": k_ms, "us_per_generation_step": us_step,
+                         "latency_floor_us": floor_us, "frac_of_floor": floor_us / us_step,
+                         "latency_floor_formula": "%d layers x 0.200 us (a layer's dependent arithmetic alone: 32+16 dependent fmas, 6 adds, 21-deep rational "
+                                                  "activation) + 8 wave hand-offs x 0.075 + causal layer 0.15 + post phase (3 L2 hops x 0.26 + skip 0.22 + "
+                                                  "chunk dots 0.28 + ordered sum/conv1d_2 0.27 + sampler 0.31); measured pieces, "
+                                                  "profiles/r02_xcd_chain_ubench_3b.txt and profiles/r02_xcd_phase_profile_v6.txt" % NL,
+                         "fp32_flop_per_step": flop_step, "fp32_tflops": flop_step / (us_step * 1e-6) / 1e12,
+                         "fp32_frac": flop_step / (us_step * 1e-6) / 1e12 / 157.3,
                          "note": "weights are register-/L2-resident: the sample loop is a dependent chain (latency), not a bandwidth stream; "
                                  "algorithmic bytes assume the weights were re-read from HBM every step (SURVEY.md 8d)"},
         }
@@ -275,7 +322,7 @@ def main():
             # what more streams on the same GPU are worth: 1 s of audio per stream at B = 8 (XCD-per-stream kernel), 16 and 32 (generic kernel)
             sweep = []
             T1 = hp.sample_rate // hp.hop_size * hp.hop_size
-            for Bs in (8, 16, 32):
+            for Bs in (8, 16, 32, 48, 64):
                 try:
                     ms = m if Bs == B else make_vocoder(Bs)
                     inp = make_inputs(Bs, T1, 50 + Bs)
@@ -286,8 +333,10 @@ def main():
                     kms = s0.elapsed_time(s1)
                     _lib.check(ms._L.twv_wavenet_status(C.c_void_p(ms._status.data_ptr()), None))
                     sweep.append({"streams": Bs, "samples_per_s": Bs * T1 / (kms * 1e-3), "us_per_generation_step": kms * 1e3 / T1,
+                                  "realtime_factor_aggregate": Bs * T1 / (kms * 1e-3) / hp.sample_rate,
                                   "realtime_factor_per_stream": T1 / (kms * 1e-3) / hp.sample_rate,
-                                  "kernel": "wn_xcd_generate_kernel" if ms.fused_conditioning() else "wn_generate_kernel"})
+                                  "fp32_frac": 2.0 * macs_stream * Bs / (kms * 1e-3 / T1) / 1e12 / 157.3,
+                                  "kernel": ("wn_xcd_many_kernel" if Bs > 32 else "wn_xcd_generate_kernel") if ms.fused_conditioning() else "wn_generate_kernel"})
                     if ms is not m:
                         del ms
                 except Exception as e:
@@ -309,19 +358,13 @@ def main():
                 del m50
             except Exception as e:
                 res["hparams_default_50_layers"] = {"error": repr(e)}
+        if not args.no_cpu_baseline:
+            res["checked_against_oracle"] = "first %d samples of all %d streams of the last timed pass: bit-identical on %d of %d ranks" % (ncheck, B, n_matched, world)
+            res["checked_ranks"] = n_matched
         if not args.no_cpu_baseline and world == 1:
-            from oracle import oracle as O
-            d = O.make_dims(dil)
-            blob = O.blob_from_tensors(d, tensors)
-            mel_h = mel.cpu().numpy()
-            # (a) the checker on the timed output: the first 600 samples of every stream, bit for bit
-            ncheck = min(T, 600)
-            Uo = O.upsample(d, blob, mel_h[:, :(ncheck + hp.hop_size - 1) // hp.hop_size])[:, :ncheck]
-            want = O.generate_mol(d, blob, O.State(d, B), Uo, gc, seed_in, u[:, :ncheck].cpu().numpy())
-            assert np.array_equal(samples[:, :ncheck], want), "timed output differs from the CPU checker in the first %d samples" % ncheck
-            res["checked_against_oracle"] = "first %d samples of all %d streams of the last timed pass: bit-identical" % (ncheck, B)
+            d, blob = d_chk, blob_chk
 
-            # (b) the same workload on the host: 1 thread, then one stream per core on every core
+            # the same workload on the host (rank 0, N = 1 only): 1 thread, then one stream per core on every core
             def cpu_leg(nstreams, threads):
                 rng = np.random.RandomState(77)
                 probe = 100
@@ -351,15 +394,18 @@ def main():
                                              "(TensorFlow is absent; parity unpinned)" % (B, n1, t1)}
             if cores > 1:
                 vc, nc, tc = cpu_leg(cores, cores)
-                quota = ""
+                quota, eff = "", cores
                 try:
                     with open("/sys/fs/cgroup/cpu.max") as fh:
-                        quota = "; cgroup cpu.max = " + fh.read().strip()
+                        q = fh.read().split()
+                    quota = "; cgroup cpu.max = " + " ".join(q)
+                    if q[0] != "max":
+                        eff = max(1, min(cores, int(float(q[0]) / float(q[1]))))      # the cores the cgroup actually grants
                 except Exception:
                     pass
-                res["cpu_baseline"]["all_cores"] = {"value": vc, "unit": "samples/s", "cores": cores, "kind": "port",
-                                                    "sample": "the same restatement, one stream per core (OpenMP, %d threads), %d streams x %d steps = %.1f s%s"
-                                                              % (cores, cores, nc, tc, quota)}
+                res["cpu_baseline"]["all_cores"] = {"value": vc, "unit": "samples/s", "cores": eff, "threads": cores, "kind": "port",
+                                                    "sample": "the same restatement, one stream per thread (OpenMP, %d threads on %d granted cores), %d streams x %d steps = %.1f s%s"
+                                                              % (cores, eff, cores, nc, tc, quota)}
         if not args.no_tacotron and world == 1:
             # secondary half of BASELINE.json's metric: Tacotron mel frames/sec at configs[2] (B=32, 100 tokens + EOS, 200 decoder steps)
             try:
@@ -386,8 +432,20 @@ def main():
                 for _ in range(3): tmel, _, _ = tm.infer(tok, tln, tsp)
                 torch.cuda.synchronize()
                 qdt = (time.perf_counter() - q0) / 3
+                # the matrix-core kernels of the pass, timed live: HIP events around every dense contraction of one more pass
+                tm.set_option("gemm_timing", 1)
+                tm.infer(tok, tln, tsp); torch.cuda.synchronize()
+                gflop, gms, gn = tm.gemm_stats()
+                tm.set_option("gemm_timing", 0)
                 res["tacotron"] = {"metric": "Tacotron mel frames/sec", "value": TN * hp.max_iters * hp.reduction_factor / qdt,
                                    "unit": "mel frames/s", "ms_per_pass": qdt * 1e3, "dtype": "f32",
+                                   "roofline": {"bound": "mfma", "kernel": "tc_gemm_mfma_kernel + tc_gemm_mfma_ck_kernel (%d launches per pass: CBHG conv banks, projections, "
+                                                                        "highways, GRU input halves, attention keys, linear)" % gn,
+                                                "achieved": gflop / (gms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": gflop / (gms * 1e-3) / 1e12 / 157.3,
+                                                "flop_per_pass": gflop, "kernel_ms_per_pass": gms, "traffic": None,
+                                                "note": "useful FLOPs (2*rows*K*N, unpadded) of the dense contractions / their summed HIP-event time; "
+                                                        "the rest of the pass is the decoder's latency chain (tc_decoder_g_kernel) and the GRU sequences; "
+                                                        "counters: profiles/r03_rocprofv3_*tacotron*"},
                                    "config": {"workload": "configs[2]: Tacotron text->mel (CBHG encoder, monotonic Bahdanau attention decoder, post-CBHG, "
                                                           "linear), batch=32, 101 tokens, 200 decoder steps = 1000 mel frames/utterance, random-init weights"},
                                    "finite": bool(torch.isfinite(tmel).all().item())}

@@ -181,6 +181,11 @@ int twv_tacotron_set_option(twv_tacotron* h, const char* name, int value);
  * phase boundaries of every decoder step (prenet, attention GRU, query, score, recurrence, context, projection, residual GRUs,
  * output).  NULL disables. */
 int twv_tacotron_set_profile_buffer(twv_tacotron* h, void* dev_u64);
+/* measurement aid for bench.py's `tacotron.roofline` (no reference counterpart): after twv_tacotron_set_option(h, "gemm_timing", 1)
+ * every dense contraction of the pass (CBHG conv banks / projections / highways of tacotron/modules.py:25-74, the attention keys and the
+ * linear projection) is bracketed by HIP events on its stream; this returns the useful FLOPs (2*rows*K*N), the summed kernel time
+ * and the launch count since then. */
+int twv_tacotron_gemm_stats(twv_tacotron* h, double* flop, double* ms, int64_t* launches);
 
 /* ======================================= WaveNet teacher-forced training step =======================================
  * Replaces one `sess.run([net.loss, net.optimize])` of train_vocoder.py:155-181 for the scalar-input (MoL) model:

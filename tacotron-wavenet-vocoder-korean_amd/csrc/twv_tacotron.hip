@@ -23,6 +23,16 @@
 #include "twv_dpp.hpp"
 
 static int g_gemm_valu = 0;            // "gemm_valu" option: 1 = the VALU kernel (cross-check of the MFMA one)
+// "gemm_timing" option (measurement aid, bench.py's `tacotron.roofline`): every GEMM launch is bracketed by a pair of HIP events on
+// its stream and its useful FLOPs (2 * rows * K * N, unpadded) are counted; twv_tacotron_gemm_stats sums both since the option was set.
+struct GemmStat {
+    bool on = false;
+    double flop = 0.0;
+    long long launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+};
+static GemmStat g_gemm_stat;
 enum { TACT_NONE = 0, TACT_RELU = 1, TACT_TANH = 2, TACT_SIGMOID = 3, TACT_SOFTSIGN = 4 };
 __device__ __forceinline__ float tc_act(float v, int act)
 {
@@ -1698,6 +1708,11 @@ extern "C" int twv_tacotron_set_option(twv_tacotron* h, const char* name, int va
 {
     if (!h || !name) return twv_fail(TWV_E_INVALID, "null argument");
     if (!strcmp(name, "gemm_valu")) { g_gemm_valu = value ? 1 : 0; return TWV_OK; }
+    if (!strcmp(name, "gemm_timing")) {   // 1: start counting (resets the sums), 0: stop
+        g_gemm_stat.on = value != 0;
+        g_gemm_stat.flop = 0.0; g_gemm_stat.launches = 0; g_gemm_stat.used = 0;
+        return TWV_OK;
+    }
     if (!strcmp(name, "decoder_groups")) {
         if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 32)
             return twv_fail(TWV_E_INVALID, "decoder_groups must be -1, 0, 1, 2, 4, 8 or 32 (32 = the XCD-local kernel)");
@@ -1707,6 +1722,19 @@ extern "C" int twv_tacotron_set_option(twv_tacotron* h, const char* name, int va
     return twv_fail(TWV_E_INVALID, "unknown option");
 }
 extern "C" int twv_tacotron_set_profile_buffer(twv_tacotron* h, void* dev_u64) { if (!h) return 1; h->prof = (unsigned long long*)dev_u64; return 0; }
+extern "C" int twv_tacotron_gemm_stats(twv_tacotron* h, double* flop, double* ms, int64_t* launches)
+{
+    if (!h || !flop || !ms || !launches) return twv_fail(TWV_E_INVALID, "null argument");
+    double total = 0.0;
+    for (size_t i = 0; i < g_gemm_stat.used; ++i) {
+        if (hipEventSynchronize(g_gemm_stat.ev[i].second) != hipSuccess) return twv_fail(TWV_E_HIP, "hipEventSynchronize");
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, g_gemm_stat.ev[i].first, g_gemm_stat.ev[i].second) != hipSuccess) return twv_fail(TWV_E_HIP, "hipEventElapsedTime");
+        total += t;
+    }
+    *flop = g_gemm_stat.flop; *ms = total; *launches = g_gemm_stat.launches;
+    return TWV_OK;
+}
 extern "C" size_t twv_tacotron_packed_bytes(const twv_tacotron* h) { return (size_t)h->packed_floats * 4; }
 
 __global__ void tc_normed_v_kernel(float* P, long long av, long long ag, long long nv, int A)
@@ -1819,6 +1847,20 @@ static void launch_gemm(hipStream_t st, const float* P, const float* X, int ldx,
     a.bias = bias ? P + bias->off : nullptr; a.act = act;
     a.bn_inv = inv ? P + inv->off : nullptr; a.bn_shift = shift ? P + shift->off : nullptr;
     a.add1 = add1; a.ld1 = ld1; a.add2 = add2; a.ld2 = ld2; a.Y = Y; a.ldy = ldy; a.col0 = col0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g_gemm_stat.on) {
+        if (g_gemm_stat.used == g_gemm_stat.ev.size()) {
+            hipEvent_t x0, x1;
+            if (hipEventCreate(&x0) == hipSuccess && hipEventCreate(&x1) == hipSuccess) g_gemm_stat.ev.push_back({x0, x1});
+        }
+        if (g_gemm_stat.used < g_gemm_stat.ev.size()) {
+            e0 = g_gemm_stat.ev[g_gemm_stat.used].first; e1 = g_gemm_stat.ev[g_gemm_stat.used].second;
+            ++g_gemm_stat.used;
+            (void)hipEventRecord(e0, st);
+        }
+        g_gemm_stat.flop += 2.0 * (double)rows * (double)W.K * (double)W.N;
+        ++g_gemm_stat.launches;
+    }
     if (g_gemm_valu)
         hipLaunchKernelGGL(tc_gemm_kernel, dim3((rows + kGemmRows - 1) / kGemmRows), dim3(256), kGemmRows * kGemmKS * 4, st, a);
     else {
@@ -1829,6 +1871,7 @@ static void launch_gemm(hipStream_t st, const float* P, const float* X, int ldx,
         else
             hipLaunchKernelGGL(tc_gemm_mfma_kernel, dim3((rows + kMmRows - 1) / kMmRows, (W.N + 127) / 128), dim3(256), 0, st, a);
     }
+    if (e1) (void)hipEventRecord(e1, st);
 }
 
 // modules.py:25-74 for `rows` = N*T rows

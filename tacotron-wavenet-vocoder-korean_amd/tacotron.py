@@ -138,6 +138,12 @@ class Tacotron(object):
         """launch geometry (performance only): "decoder_groups" = workgroups per utterance in the decoder (0 auto, 1/2/4/8, -1 old kernel)"""
         _lib.check(self._L.twv_tacotron_set_option(self._h, name.encode(), int(value)))
 
+    def gemm_stats(self):
+        """after set_option("gemm_timing", 1): (useful FLOPs, summed kernel milliseconds, launches) of the dense contractions since then"""
+        f, ms, n = C.c_double(), C.c_double(), C.c_int64()
+        _lib.check(self._L.twv_tacotron_gemm_stats(self._h, C.byref(f), C.byref(ms), C.byref(n)))
+        return f.value, ms.value, n.value
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):
