@@ -20,7 +20,8 @@ extern "C" {
 
 #define TWV_MAX_LAYERS 64
 
-enum { TWV_OK = 0, TWV_E_INVALID = 1, TWV_E_UNSUPPORTED = 2, TWV_E_HIP = 3, TWV_E_KERNEL = 4 };
+enum { TWV_OK = 0, TWV_E_INVALID = 1, TWV_E_UNSUPPORTED = 2, TWV_E_HIP = 3, TWV_E_KERNEL = 4,
+       TWV_E_BUSY = 5 /* a persistent kernel found the device occupied by other work: nothing was done, retry later */ };
 
 /* WaveNetModel constructor arguments (wavenet/model.py:8-10) + hparams.upsample_factor (hparams.py:79) */
 typedef struct {
@@ -115,7 +116,9 @@ int twv_wavenet_generate(const twv_wavenet* h, const void* packed, void* state, 
 int twv_wavenet_prime(const twv_wavenet* h, const void* packed, void* state, const void* cond, const void* inputs,
                       int batch, int n_steps, int32_t* status, void* stream);
 
-/* synchronises `stream` and converts a non-zero status word into TWV_E_KERNEL. */
+/* synchronises `stream` and converts a non-zero status word into an error: TWV_E_BUSY (the generation kernel's role workgroups could
+ * not all become resident because other kernels hold CUs -- the launch did nothing, the state is unchanged, retry), TWV_E_INVALID (the
+ * conditioning buffer was built for another kernel selection) or TWV_E_KERNEL (a wait inside the kernel ran out: watchdog code). */
 int twv_wavenet_status(const int32_t* status, void* stream);
 
 /* launch geometry knobs (performance only, results are bit-identical): "xcd" = 1 (default): the XCD-per-stream kernel
@@ -232,6 +235,9 @@ int twv_inv_linear_spectrogram(twv_griffin_lim* h, const float* lin, const float
 
 /* cross-lane primitive self-test (device float[256]); used by the gpu tests to pin v_permlane32_swap / v_readlane semantics */
 int twv_selftest(float* out256, void* stream);
+/* test aid: `blocks` workgroups that each hold `lds_bytes` of LDS and spin for `milliseconds` on `stream` -- stands in for "another
+ * kernel is using the device" in the co-residency test of the persistent generation kernel (TWV_E_BUSY). */
+int twv_debug_occupy(int blocks, int lds_bytes, double milliseconds, void* stream);
 
 /* ---- checkpoint helper (host only) ----
  * CRC-32C of `n` bytes, continuing from `crc` (0 to start): the per-tensor / per-block checksum of the TensorFlow

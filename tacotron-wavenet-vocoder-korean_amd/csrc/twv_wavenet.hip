@@ -1848,6 +1848,13 @@ extern "C" int twv_wavenet_status(const int32_t* status, void* stream)
     int32_t hst[4] = {0, 0, 0, 0};
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     HIPCHK(hipMemcpy(hst, status, sizeof(hst), hipMemcpyDeviceToHost));
+    if (hst[0] == 90)
+        return fail(TWV_E_BUSY, "the generation kernel's role workgroups did not all become resident within ~50 ms: the device is busy "
+                                "(a persistent kernel needs the device to itself, INTEGRATION.md section 3); nothing was generated, the "
+                                "state is unchanged -- retry when the other work has drained (status code 90)");
+    if (hst[0] == 74)
+        return fail(TWV_E_INVALID, "the conditioning buffer was not built for the XCD-per-stream kernel (options changed between "
+                                   "twv_wavenet_condition and twv_wavenet_generate?); nothing was generated (status code 74)");
     if (hst[0] != 0) return fail(TWV_E_KERNEL, "generation kernel watchdog code " + std::to_string(hst[0]));
     return TWV_OK;
 }
@@ -1883,6 +1890,22 @@ extern "C" int twv_wav_to_int16(const float* wav, int rows, int64_t n, int16_t* 
     HIPCHK(hipGetLastError());
     return TWV_OK;
 }
+__global__ void wn_occupy_kernel(unsigned long long ticks)
+{
+    extern __shared__ float hold[];
+    if (threadIdx.x == 0) hold[0] = 0.0f;
+    const unsigned long long t0 = wall_clock64();                      // 100 MHz chip-wide clock
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+extern "C" int twv_debug_occupy(int blocks, int lds_bytes, double milliseconds, void* stream)
+{
+    if (blocks < 1 || lds_bytes < 0 || lds_bytes > 160 * 1024 || milliseconds < 0) return fail(TWV_E_INVALID, "bad argument");
+    if (lds_bytes > 32 * 1024) HIPCHK(hipFuncSetAttribute((const void*)wn_occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(wn_occupy_kernel, dim3(blocks), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, (unsigned long long)(milliseconds * 1e5));
+    HIPCHK(hipGetLastError());
+    return TWV_OK;
+}
+
 extern "C" int twv_selftest(float* out256, void* stream)
 {
     if (!out256) return fail(TWV_E_INVALID, "null argument");

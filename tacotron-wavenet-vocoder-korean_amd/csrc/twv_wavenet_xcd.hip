@@ -165,6 +165,7 @@ constexpr int kXcdStreamsPerXcd = kXcdStreams / 8;
 struct XArgs {
     XcdLaunch p;
     int n_lc_wg, lc_lpw;      // lc workgroups per XCD, layers per lc wave
+    int total_roles;          // role workgroups of the whole launch (all XCDs): what roles_resident counts up to
 };
 
 // the streams of one XCD (stream b runs on XCD b % 8): each has its own chain and service workgroup; the skip, conv1 and lc
@@ -1107,6 +1108,45 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx,
     WACC_OUT(a.prof, prof_slot, v);
 }
 
+// ---- co-residency check.  The roles of a launch spin on each other, so ALL of them must be running: with another kernel holding CUs
+// (a second model, a Tacotron pass on another stream) some role workgroups stay queued and the rest would poll until the watchdog --
+// after having consumed inputs and touched the state.  Every role workgroup therefore counts itself in first and waits, bounded
+// (~50 ms), for the rest; the last one to arrive raises GO, the first one to run out of patience raises ABORT (one compare-and-swap
+// decides for the whole launch).  On ABORT every workgroup leaves before it has written anything but its ticket: status code 90, the
+// state and the outputs are untouched and the caller may simply retry.  Thread 0 also checks that the conditioning buffer carries
+// the header twv_wavenet_condition[_mel] writes for THIS kernel (code 74: a buffer built while the generic kernel was selected).
+// roles[0..7] per-XCD tickets, roles[8] arrivals, roles[9] decision (0 undecided, 1 go, 2 abort).
+__device__ __forceinline__ bool roles_resident(const XArgs& xa)
+{
+    const XcdLaunch& a = xa.p;
+    __shared__ int s_go;
+    if (threadIdx.x == 0) {
+        int* arrived = a.roles + 8;
+        int* decision = a.roles + 9;
+        const int* hdr = reinterpret_cast<const int*>(a.cond);
+        if (hdr[XH_MAGIC] != kXcdCondMagic || (unsigned)hdr[XH_MODE] > (unsigned)XLC_MEL) {
+            atomicMax(a.status, 74);
+            atomicCAS(decision, 0, 2);
+        }
+        if (atomicAdd(arrived, 1) + 1 == xa.total_roles) atomicCAS(decision, 0, 1);
+        int f = 0;
+#pragma nounroll
+        for (int i = 0; i < (1 << 15); ++i) {
+            f = atomicAdd(decision, 0);
+            if (f != 0) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+        if (f == 0) {
+            const int old = atomicCAS(decision, 0, 2);
+            f = old == 0 ? 2 : old;
+            if (old == 0) atomicMax(a.status, 90);
+        }
+        s_go = (f == 1) ? 1 : 0;
+    }
+    __syncthreads();
+    return s_go != 0;
+}
+
 // ONE: see xcd_launch.  BIGK: the instantiation for 31-50 layers (second chain workgroup, helper waves with LDS-resident early tiles).  It is a kernel of
 // its own so that the register allocation of the 30-layer kernel is not touched by it (as ONE kernel the sampling loop of the bench
 // configuration ran at 13.3 instead of 10.4 us per step).
@@ -1133,6 +1173,7 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
     constexpr int nseg = BIGK ? 2 : 1;
     const int nchain = ns * nseg;
     if (ticket >= nchain + ns + 16 + xa.n_lc_wg) return;        // surplus workgroup (or an XCD without a stream)
+    if (!roles_resident(xa)) return;                            // the device is busy: nobody starts (status 90)
     const bool forced = a.forced != nullptr;
     auto exch_of = [&](int b) { return __builtin_amdgcn_make_buffer_rsrc(a.exch + (long long)b * XcdExch::WORDS, 0, (int)(XcdExch::WORDS * 8), 0x00020000); };
     if (ticket < nchain + ns) {
@@ -1979,6 +2020,7 @@ __global__ void __launch_bounds__(512) wn_xcd_many_kernel(XArgs xa)
     const int ns = xcc < (unsigned)a.B && xcc < 8u ? (a.B - (int)xcc + 7) / 8 : 0;     // streams on this XCD (<= 8)
     const int nch = (ns + kMS - 1) / kMS;                         // chain (and service) workgroups: two streams each
     if (ticket >= 2 * nch + 16 + xa.n_lc_wg) return;            // surplus workgroup (or an XCD without a stream)
+    if (!roles_resident(xa)) return;                            // the device is busy: nobody starts (status 90)
     const bool forced = a.forced != nullptr;
     if (ticket < nch) {
         const bool all = a.lay.use_bias && a.lay.G > 0 && a.lay.L > 0;
@@ -2069,6 +2111,12 @@ int xcd_launch(const XcdLaunch& p, hipStream_t st)
     // chain workgroup: hand-off boxes + the dense kernels of its layers (136 KiB); more than 32 layers: the skip / service workgroups
     // keep the tiles of layers 0 .. NL-41 in LDS next to their value slots (159 KiB of the CU's 160)
     const bool many = (p.B > kXcdStreams || p.many != 0) && p.lay.NL <= kXcdSeg0Layers && xcd_many_lc_fits(p.lay);
+    xa.total_roles = 0;
+    for (int x = 0; x < 8 && x < p.B; ++x) {
+        const int ns = (p.B - x + 7) / 8;
+        if (many) xa.total_roles += 2 * ((ns + kMS - 1) / kMS) + 16 + xa.n_lc_wg;
+        else xa.total_roles += ns * (p.lay.NL > kXcdSeg0Layers ? 2 : 1) + ns + 16 + xa.n_lc_wg;
+    }
     const size_t shm = many ? (size_t)kManyLds * 4 : p.lay.NL > kXcdSeg0Layers ? (size_t)159 * 1024 : (size_t)(2048 + 32 * 1024) * 4;
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;

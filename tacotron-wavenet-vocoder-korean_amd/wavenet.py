@@ -22,7 +22,10 @@ def _stream():
 
 class Upsampled(object):
     """What WaveNetModel.create_upsample returns under fused conditioning: the mel frames plus the shape of the upsampled tensor
-    they stand for.  generate() takes it as `upsampled_local_condition`; tensor() materialises it (model.py:102-111)."""
+    they stand for.  generate() takes it as `upsampled_local_condition` and upsamples inside its launch, ALWAYS FROM ROW 0: for
+    chunked generation hand over `rows_from(start)` (or slices of `tensor()`), not the same object twice.  Anything else that is
+    done to it -- indexing, `.to()`, `.float()`, `.cpu()`, `np.asarray`, `torch.cat`, arithmetic -- works on the materialised
+    (B, T_mel*hop, lc) tensor of model.py:102-111, built on first use by the stand-alone upsampling kernel (same bits)."""
 
     def __init__(self, model, mel):
         self.model, self.mel = model, mel
@@ -34,11 +37,50 @@ class Upsampled(object):
             self._t = self.model._upsample_now(self.mel)
         return self._t
 
-    def cpu(self):
-        return self.tensor().cpu()
+    def rows_from(self, start):
+        """the condition from upsampled row `start` on: still lazy (fused) when `start` is a whole number of hops, else the
+        materialised rows"""
+        hop = self.model.hop_size
+        if start % hop == 0:
+            return Upsampled(self.model, self.mel[:, start // hop:].contiguous())
+        return self.tensor()[:, start:]
 
     def __getitem__(self, idx):
         return self.tensor()[idx]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.tensor().cpu().numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def __getattr__(self, name):                 # everything a tensor has that this handle does not: on the materialised tensor
+        if name.startswith("__") or name in ("model", "mel", "shape", "_t"):
+            raise AttributeError(name)
+        return getattr(self.tensor(), name)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        def conv(x):
+            if isinstance(x, Upsampled):
+                return x.tensor()
+            if isinstance(x, (list, tuple)):
+                return type(x)(conv(v) for v in x)
+            return x
+        return func(*conv(args), **{k: conv(v) for k, v in (kwargs or {}).items()})
+
+
+def _forward_operators():
+    import operator
+    for name in ("add", "sub", "mul", "truediv", "matmul", "pow"):
+        op = getattr(operator, name)
+        setattr(Upsampled, "__%s__" % name, lambda self, other, op=op: op(self.tensor(), other.tensor() if isinstance(other, Upsampled) else other))
+        setattr(Upsampled, "__r%s__" % name, lambda self, other, op=op: op(other, self.tensor()))
+    Upsampled.__neg__ = lambda self: -self.tensor()
+
+
+_forward_operators()
 
 
 class WaveNetModel(object):
@@ -110,7 +152,12 @@ class WaveNetModel(object):
         return receptive_field
 
     def set_option(self, name, value):
+        """launch-geometry options of the C-ABI (twv_wavenet_set_option).  "xcd" / "xcd_many" / "groups" select the kernel and with it
+        the SIZE and layout of the state buffer (the XCD kernels append their exchange area): the queues are re-created, i.e. reset as by
+        queue_initializer (generate.py:163) -- set such options before priming / generating, not between chunks of one utterance."""
         _lib.check(self._L.twv_wavenet_set_option(self._h, name.encode(), int(value)))
+        if name in ("xcd", "xcd_many", "groups") and self._state is not None:
+            self.queue_initializer()
 
     # ---- weights (tf.train.Saver.restore of generate.py:157-161) ----
     def load_weights(self, tensors):
@@ -128,7 +175,7 @@ class WaveNetModel(object):
     def queue_initializer(self):
         with torch.cuda.device(self.device):
             n = self._L.twv_wavenet_state_bytes(self._h, self.batch_size) // 4
-            if self._state is None:
+            if self._state is None or self._state.numel() != n:          # (the size depends on the kernel selection: see set_option)
                 self._state = torch.empty(n, dtype=torch.float32, device=self.device)
                 self._status = torch.zeros(4, dtype=torch.int32, device=self.device)
             _lib.check(self._L.twv_wavenet_reset_state(self._h, _ptr(self._state), self.batch_size, _stream()))
@@ -136,7 +183,8 @@ class WaveNetModel(object):
     # ---- model.py:102-111 ----
     def fused_conditioning(self):
         """True when create_upsample + the lc projections run inside the generation launch (XCD-per-stream kernel)."""
-        return bool(self._L.twv_wavenet_fused_conditioning(self._h, self.batch_size))
+        with torch.cuda.device(self.device):             # the answer depends on THIS model's device (its CU count)
+            return bool(self._L.twv_wavenet_fused_conditioning(self._h, self.batch_size))
 
     def create_upsample(self, local_condition_batch, materialize=None):
         """net.create_upsample(mel) (generate.py:200).  With fused conditioning the returned `Upsampled` only holds the mel frames:

@@ -660,6 +660,80 @@ def test_xcd_many_streams_kernel_priming_then_generation(torch_cuda, oracle, B):
     assert first_mismatch(got, want) is None, first_mismatch(got, want)
 
 
+def test_busy_device_is_a_clean_error_not_a_hang(torch_cuda, oracle):
+    """a persistent kernel's roles spin on each other, so all of them must be resident.  With another kernel holding half of every
+    XCD's CUs (twv_debug_occupy on a second stream) the role workgroups cannot all start: the launch must come back quickly with
+    TWV_E_BUSY -- no hang, no samples written, the state untouched -- and the same call succeeds bit for bit once the device is free"""
+    import ctypes as C
+    import time
+    import twvk_amd
+    from twvk_amd._lib import TwvError
+    torch = torch_cuda
+    B, T = 8, 600
+    m, mel, gc, seed_in, u, want = _bench_case(oracle, B, T)
+    side = torch.cuda.Stream()
+    # 128 one-wave workgroups x 100 KB of LDS for 400 ms: one per CU on half of the chip (the generation kernel's workgroups need a whole CU's LDS)
+    twvk_amd._lib.check(m._L.twv_debug_occupy(128, 100 * 1024, 400.0, C.c_void_p(side.cuda_stream)))
+    time.sleep(0.02)
+    t0 = time.perf_counter()
+    with pytest.raises(TwvError, match="busy"):
+        m.generate(m.create_upsample(mel), gc, seed_in, u)
+    assert time.perf_counter() - t0 < 0.35, "the refusal must come from the start-up check (~50 ms), not from a watchdog"
+    torch.cuda.synchronize()
+    got = m.generate(m.create_upsample(mel), gc, seed_in, u).cpu().numpy()           # no queue_initializer in between: the state was not touched
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+
+
+def test_kernel_options_resize_the_state_buffer(torch_cuda, oracle):
+    """the XCD kernels append their exchange area to the state buffer, so switching the kernel selection after
+    load_weights() must re-create the buffer (it used to be kept: out-of-bounds device writes); either order gives the same samples"""
+    dil = [1, 2, 4, 8, 16, 32]
+    d, tensors, blob = make_case(oracle, dil, scale=0.1)
+    B, T = 3, 300
+    rng = np.random.RandomState(2)
+    mel = rng.uniform(-4, 4, (B, 1, 80)).astype(np.float32)
+    gc = (np.arange(B) % 2).astype(np.int32)
+    seed_in = (2 * rng.rand(B) - 1).astype(np.float32)
+    u = mol_uniforms(B, T, 10)
+    want = oracle.generate_mol(d, blob, oracle.State(d, B), oracle.upsample(d, blob, mel), gc, seed_in, u)
+    m = make_model(B, dil, tensors, xcd=0)                     # sized for the generic kernel ...
+    n0 = m._state.numel()
+    m.set_option("xcd", 1)                                     # ... then the XCD kernel is selected
+    assert m._state.numel() > n0 and m.fused_conditioning()
+    assert first_mismatch(m.generate(m.create_upsample(mel), gc, seed_in, u).cpu().numpy(), want) is None
+    m.set_option("xcd_many", 1)
+    assert first_mismatch(m.generate(m.create_upsample(mel), gc, seed_in, u).cpu().numpy(), want) is None
+    m.set_option("xcd", 0)
+    assert m._state.numel() == n0 and not m.fused_conditioning()
+    up = m.create_upsample(mel)
+    assert first_mismatch(m.generate(up, gc, seed_in, u).cpu().numpy(), want) is None
+
+
+def test_lazy_upsampled_handle_behaves_like_the_tensor(torch_cuda, oracle):
+    """create_upsample under fused conditioning returns a handle; everything but generate() sees the (B, T*hop, lc) tensor"""
+    dil = [1, 2, 4, 8]
+    d, tensors, blob = make_case(oracle, dil, scale=0.1)
+    m = make_model(2, dil, tensors)
+    mel = np.random.RandomState(1).uniform(-4, 4, (2, 3, 80)).astype(np.float32)
+    up = m.create_upsample(mel)
+    want = oracle.upsample(d, blob, mel)
+    if not m.fused_conditioning():
+        pytest.skip("needs the XCD-per-stream kernel")
+    assert up.shape == (2, 900, 80) and len(up) == 2
+    assert first_mismatch(np.asarray(up), want) is None
+    assert first_mismatch(up.float().cpu().numpy(), want) is None
+    assert first_mismatch(torch_cuda.cat([up, up], dim=1)[:, 900:].cpu().numpy(), want) is None
+    assert first_mismatch((up * 1.0)[:, :5].cpu().numpy(), want[:, :5]) is None
+    # chunked generation: rows_from() keeps the fused path at hop boundaries
+    gc = np.array([0, 1], np.int32)
+    seed_in = np.zeros(2, np.float32)
+    u = mol_uniforms(2, 900, 10)
+    ref = oracle.generate_mol(d, blob, oracle.State(d, 2), want, gc, seed_in, u)
+    a = m.generate(up, gc, seed_in, u[:, :600]).cpu().numpy()
+    b = m.generate(up.rows_from(600), gc, a[:, -1], u[:, 600:]).cpu().numpy()
+    assert first_mismatch(np.concatenate([a, b], axis=1), ref) is None
+
+
 def test_generic_kernel_at_bench_geometry(torch_cuda, oracle):
     """the generic kernel at B = 8: 8 workgroups per stream + helper workgroups (64 + 64 co-resident), 24 000 steps; bit for bit"""
     B, T = 8, 24000
