@@ -49,7 +49,7 @@ class DataFeederWavenet(object):
     speaker ids (B)).  Same bookkeeping: per-directory offsets starting at 2, reshuffle on wrap-around, 32 batches' worth of
     examples drawn evenly from the directories, shuffled, cut into batches."""
 
-    def __init__(self, data_dirs, batch_size, receptive_field, gc_enable=False, hp=hparams):
+    def __init__(self, data_dirs, batch_size, receptive_field, gc_enable=False, hp=hparams, rank=0, world=1):
         self.data_dirs = list(data_dirs)
         self.batch_size = batch_size
         self.receptive_field = receptive_field
@@ -57,13 +57,17 @@ class DataFeederWavenet(object):
         self.sample_size = ensure_divisible(hp.sample_size, self.hop_size, True)
         self.max_frames = self.sample_size // self.hop_size
         self.gc_enable = gc_enable
-        self.rng = np.random.RandomState(123)
+        self.rng = np.random.RandomState(123 + rank)                # (the reference has one feeder: RandomState(123))
         self._offset = defaultdict(lambda: 2)
         self.data_dir_to_id = {d: i for i, d in enumerate(self.data_dirs)}
         self.path_dict = {d: sorted(os.path.basename(p) for p in glob("{}/*.npz".format(d))) for d in self.data_dirs}
         for d, paths in self.path_dict.items():
             if not paths:
                 raise ValueError("no .npz examples in %s" % d)
+            # data-parallel ranks read DISJOINT examples (every world-th file of a directory), so that the all-reduced gradient is the
+            # gradient of world x batch_size different crops; a directory with fewer files than ranks is shared whole
+            if world > 1 and len(paths) >= world:
+                self.path_dict[d] = paths[rank::world]
         self._batches = []
 
     def _get_next_example(self, data_dir):
@@ -160,29 +164,42 @@ def main(argv=None, log=print):
     from . import checkpoint as ckpt
     config = get_arguments(argv)
     config.data_dir = config.data_dir.split(",")
-    try:
-        directories = validate_directories(config, hparams)
-    except ValueError as e:
-        print("Some arguments are wrong:")
-        print(str(e))
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:                                                   # one process per GPU; gradients meet in WaveNetTrainer.step
+        import torch.distributed as dist
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=torch.device("cuda:%d" % local_rank))
+    # rank 0 decides the directories (a default logdir carries a timestamp: every rank computing its own would give N directories)
+    # and creates them / writes params.json; the others take its answer
+    directories = None
+    if rank == 0:
+        try:
+            directories = validate_directories(config, hparams)
+        except ValueError as e:
+            print("Some arguments are wrong:")
+            print(str(e))
+    if dist is not None:
+        box = [directories]
+        dist.broadcast_object_list(box, src=0)
+        directories = box[0]
+        if directories is not None and rank != 0 and os.path.exists(os.path.join(directories['logdir'], "params.json")):
+            load_hparams(hparams, directories['logdir'])
+    if directories is None:
         return None
     logdir, restore_from = directories['logdir'], directories['restore_from']
     is_overwritten_training = logdir != restore_from
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:                                                   # one process per GPU; gradients meet in WaveNetTrainer.step
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if not dist.is_initialized():
-            dist.init_process_group("nccl", device_id=torch.device("cuda:%d" % local_rank))
     num_speakers = len(config.data_dir)
     gc_enable = num_speakers > 1
     rf = WaveNetModel.calculate_receptive_field(hparams.filter_width, hparams.dilations, hparams.scalar_input, hparams.initial_filter_width)
     if config.synthetic:
         reader = SyntheticFeeder(hparams.wavenet_batch_size, max(num_speakers, 1), hparams, seed=rank)
     else:
-        reader = DataFeederWavenet(config.data_dir, hparams.wavenet_batch_size, rf, gc_enable=gc_enable, hp=hparams)
-        np.random.seed(1234 + rank)                                 # ranks must not draw the same crops
+        reader = DataFeederWavenet(config.data_dir, hparams.wavenet_batch_size, rf, gc_enable=gc_enable, hp=hparams, rank=rank, world=world)
+        np.random.seed(1234 + rank)                                 # ranks must not draw the same crop offsets
     net = WaveNetModel(batch_size=hparams.wavenet_batch_size, dilations=hparams.dilations, filter_width=hparams.filter_width,
                        residual_channels=hparams.residual_channels, dilation_channels=hparams.dilation_channels,
                        quantization_channels=hparams.quantization_channels, out_channels=hparams.out_channels,
@@ -202,7 +219,18 @@ def main(argv=None, log=print):
     step, loss_value = trainer.global_step, float("nan")
     while step < num_steps:
         start_time = time.time()
-        audio, lc, gc = reader.next_batch()
+        failure = None
+        try:
+            audio, lc, gc = reader.next_batch()
+        except Exception as e:                                      # a rank that cannot feed must not leave the others in the all-reduce
+            failure = e
+        if dist is not None:
+            flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device="cuda:%d" % local_rank if torch.cuda.is_available() else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()) and failure is None:
+                failure = RuntimeError("another rank's feeder failed at step %d" % (step + 1))
+        if failure is not None:
+            raise failure
         loss = trainer.step(audio, lc, gc)
         step = trainer.global_step
         loss_value = float(loss.item())

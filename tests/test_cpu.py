@@ -611,6 +611,14 @@ def test_wavenet_feeder_batches(tmp_path):
         assert a.shape == (4, 1500) and m.shape == (4, 5, 80) and g.shape == (4,) and g.dtype == np.int32
         ids += g.tolist()
     assert set(ids) == {0, 1}
+    # data-parallel ranks read disjoint examples of every speaker directory (the all-reduced gradient then covers world x batch crops)
+    r0 = DataFeederWavenet(dirs, batch_size=4, receptive_field=1000, gc_enable=True, hp=hp, rank=0, world=2)
+    r1 = DataFeederWavenet(dirs, batch_size=4, receptive_field=1000, gc_enable=True, hp=hp, rank=1, world=2)
+    for d in dirs:
+        assert r0.path_dict[d] and r1.path_dict[d] and not set(r0.path_dict[d]) & set(r1.path_dict[d])
+        assert sorted(r0.path_dict[d] + r1.path_dict[d]) == sorted(f.path_dict[d])
+    a0, _, _ = r0.next_batch(); a1, _, _ = r1.next_batch()
+    assert a0.shape == a1.shape == (4, 1500) and not np.array_equal(a0, a1)
 
 
 def test_train_vocoder_directory_rules(tmp_path):
