@@ -234,12 +234,51 @@ class WaveNetModel(object):
             self._keep = (gc, up)
         return cond
 
+    # ---- the generic kernel's hoisted conditioning, bounded ----
+    MAX_COND_BYTES = 1 << 30
+
+    def _steps_per_call(self, n_steps):
+        """The generic kernel reads a hoisted projection table cond[B][T][layers][64] (4 * B * T * layers * 64 bytes: 11.8 GB at BASELINE
+        configs[1], linear in B*T).  Longer requests are cut into calls of at most MAX_COND_BYTES of it -- a whole number of hops, so the
+        upsampled rows of a chunk come from whole mel frames; the state carries over between calls (as between the sess.run calls of
+        generate.py:211), so the samples do not change.  The fused (XCD) path has no such table: one call."""
+        if self.fused_conditioning() or not self.local_condition_channels:
+            return n_steps
+        per_step = 4 * self.batch_size * len(self.dilations) * 64
+        hop = max(1, self.hop_size)
+        steps = max(hop, (self.MAX_COND_BYTES // per_step) // hop * hop)
+        return min(n_steps, steps)
+
+    def _lc_rows(self, upsampled, p, n):
+        """rows [p, p+n) of the upsampled local condition; a lazy handle is upsampled chunk by chunk (a transposed conv with
+        stride == kernel size in time: every output row depends on one mel frame only, model.py:102-111)"""
+        if upsampled is None:
+            return None
+        if isinstance(upsampled, Upsampled):
+            hop = self.hop_size
+            f0, f1 = p // hop, (p + n + hop - 1) // hop
+            rows = self._upsample_now(upsampled.mel[:, f0:f1].contiguous())
+            return rows[:, p - f0 * hop:p - f0 * hop + n].contiguous()
+        return upsampled[:, p:p + n]
+
     # ---- generate.py:199-233 as one persistent launch ----
     def generate(self, upsampled_local_condition, global_condition, first_input, uniforms, temperature=1.0,
                  debug_steps=0, check=True):
         """upsampled_local_condition (B,T,lc) | None; global_condition: (B) ids | None; first_input (B); uniforms
         (B,T,nr_mix+1) float32 (scalar_input) or (B,T) float64.  Returns (B,T) samples (and the debug dump)."""
         B = self.batch_size
+        T_all = np.shape(uniforms)[1] if not torch.is_tensor(uniforms) else uniforms.shape[1]
+        per_call = self._steps_per_call(T_all)
+        if per_call < T_all and not debug_steps:
+            outs, fi, p = [], first_input, 0
+            while p < T_all:
+                n = min(per_call, T_all - p)
+                o = self.generate(self._lc_rows(upsampled_local_condition, p, n), global_condition, fi, uniforms[:, p:p + n],
+                                  temperature=temperature, check=check)
+                outs.append(o)
+                fi = o[:, -1].cpu().numpy()                  # generate.py:204: the next window is the sample just appended
+                p += n
+            return torch.cat(outs, dim=1)
         with torch.cuda.device(self.device):
             if self.scalar_input:
                 u = torch.as_tensor(uniforms, dtype=torch.float32, device=self.device).contiguous()
@@ -269,8 +308,14 @@ class WaveNetModel(object):
         B = self.batch_size
         with torch.cuda.device(self.device):
             dt = torch.float32 if self.scalar_input else torch.int32
-            x = torch.as_tensor(np.asarray(inputs), dtype=dt, device=self.device).reshape(B, -1).contiguous()
+            x = torch.as_tensor(inputs if torch.is_tensor(inputs) else np.asarray(inputs), dtype=dt, device=self.device).reshape(B, -1).contiguous()
             n = x.shape[1]
+            per_call = self._steps_per_call(n)
+            if per_call < n:                                 # bounded conditioning table (see _steps_per_call)
+                for p in range(0, n, per_call):
+                    m_ = min(per_call, n - p)
+                    self.prime(x[:, p:p + m_], self._lc_rows(upsampled_local_condition, p, m_), global_condition, check=check)
+                return
             if upsampled_local_condition is None and self.local_condition_channels:
                 upsampled_local_condition = torch.zeros((B, n, self.local_condition_channels), dtype=torch.float32, device=self.device)
             cond = self._condition(upsampled_local_condition, global_condition, n)
@@ -282,10 +327,22 @@ class WaveNetModel(object):
     # ---- model.py:215-245: one step (a single sess.run of generate.py:211) ----
     def predict_proba_incremental(self, waveform, upsampled_local_condition=None, global_condition=None, uniforms=None,
                                   temperature=1.0):
+        """One step of the incremental network (the queues advance by one sample, like one sess.run of generate.py:211).
+        scalar_input (model.py:229-231): returns the sample drawn by sample_from_discretized_mix_logistic, (B, 1) float -- the two
+        uniform draws must be injected.  One-hot model (model.py:241-243): returns tf.cast(softmax(float64(logits)), float32), (B, Q)
+        probabilities, as the reference does (sampling is the caller's, generate.py:219-231); with `uniforms` given it returns the
+        category drawn by that host rule instead (an extension: generate()'s one-step form)."""
         B = self.batch_size
         lc = None
         if upsampled_local_condition is not None:
             lc = torch.as_tensor(upsampled_local_condition, dtype=torch.float32, device=self.device).reshape(B, 1, -1)
+        if uniforms is None and not self.scalar_input:
+            from .ops import eval_elementwise
+            Q = self.quantization_channels
+            _ids, dump = self.generate(lc, global_condition, np.asarray(waveform).reshape(B), np.full((B, 1), 0.5), debug_steps=1)
+            logits = dump[:, 0, len(self.dilations) * 64:len(self.dilations) * 64 + Q].to(torch.float64)
+            e = eval_elementwise("exp64", logits - logits.max(dim=1, keepdim=True)[0], device=self.device)      # the kernel's own float64 exp
+            return (e / e.sum(dim=1, keepdim=True)).to(torch.float32)
         if uniforms is None:
             raise ValueError("uniforms must be injected (the reference draws unseeded tf.random_uniform / np.random)")
         u = np.asarray(uniforms)

@@ -280,6 +280,63 @@ def test_generate_onehot_small_with_dumps(torch_cuda, oracle, temperature):
     assert np.array_equal(got.cpu().numpy(), want), first_mismatch(got.cpu().numpy(), want)
 
 
+def test_predict_proba_incremental_returns_probabilities_for_the_onehot_model(torch_cuda, oracle):
+    """model.py:241-243: the one-hot model's predict_proba_incremental returns tf.cast(softmax(float64(logits)), float32), (B, Q);
+    the queues advance by one step per call.  Tolerance 1e-6 on probabilities (float output; north_star's float bar is 1e-4)."""
+    dil = [1, 2, 4, 8, 1, 2]
+    B, Q = 2, 256
+    d, tensors, blob = make_case(oracle, dil, scalar_input=False, S=128, Q=Q, scale=0.3)
+    m = make_model(B, dil, tensors, scalar_input=False, S=128, Q=Q)
+    rng = np.random.RandomState(5)
+    U = rng.uniform(-4, 4, (B, 3, 80)).astype(np.float32)
+    gc = np.array([1, 0], np.int32)
+    st = oracle.State(d, B)
+    inp = rng.randint(Q, size=B).astype(np.int32)
+    for t in range(3):
+        raw, _, _ = oracle.step(d, blob, st, inp, U[:, t], gc, debug=True)
+        x = raw.astype(np.float64)
+        e = np.exp(x - x.max(axis=1, keepdims=True))
+        want = (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+        got = m.predict_proba_incremental(inp, U[:, t], gc).cpu().numpy()
+        assert got.shape == (B, Q) and got.dtype == np.float32
+        assert np.abs(got - want).max() <= 1e-6, (t, np.abs(got - want).max())
+        assert abs(float(got.sum(axis=1).max()) - 1.0) < 1e-5
+        inp = want.argmax(axis=1).astype(np.int32)
+
+
+def test_generic_kernel_conditioning_is_bounded(torch_cuda, oracle):
+    """the generic kernel's hoisted projection table grows with B*T (11.8 GB at configs[1]): generate() / prime() cut long requests
+    into calls of bounded table size with the state carried over -- same samples as one call.  Forced here with a tiny bound."""
+    dil = [1, 2, 4, 8, 16]
+    B, T = 2, 1500
+    d, tensors, blob = make_case(oracle, dil, S=128, scale=0.2)
+    rng = np.random.RandomState(2)
+    mel = rng.uniform(-4, 4, (B, 5, 80)).astype(np.float32)
+    gc = np.array([0, 1], np.int32)
+    seed_in = (2 * rng.rand(B) - 1).astype(np.float32)
+    u = mol_uniforms(B, T, 10)
+    want = oracle.generate_mol(d, blob, oracle.State(d, B), oracle.upsample(d, blob, mel), gc, seed_in, u)
+    m = make_model(B, dil, tensors, S=128)
+    assert not m.fused_conditioning()
+    m.MAX_COND_BYTES = 4 * B * len(dil) * 64 * 450            # room for 450 steps -> one hop (300 steps) per call
+    assert m._steps_per_call(T) == 300
+    got = m.generate(m.create_upsample(mel), gc, seed_in, u).cpu().numpy()
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+    # priming through the same bound, then generation
+    rf = oracle.receptive_field(d)
+    seedwave = rng.uniform(-1, 1, (B, 700)).astype(np.float32)
+    st = oracle.State(d, B)
+    zeros = np.zeros((B, 80), np.float32)
+    for i in range(699):
+        oracle.step(d, blob, st, seedwave[:, i], zeros, gc)
+    want2 = oracle.generate_mol(d, blob, st, oracle.upsample(d, blob, mel)[:, :300], gc, seedwave[:, -1], u[:, :300])
+    m.queue_initializer()
+    m.prime(seedwave[:, :699], None, gc)
+    got2 = m.generate(m.create_upsample(mel)[:, :300].contiguous(), gc, seedwave[:, -1], u[:, :300]).cpu().numpy()
+    assert first_mismatch(got2, want2) is None, first_mismatch(got2, want2)
+    assert rf < 700
+
+
 def test_generate_c1_config(torch_cuda, oracle):
     """BASELINE configs[0]: mu-law-256, default 50 layers, 54 mel frames x 300 = 16 200 samples (about 1 s at 16 kHz), B=1"""
     dil = [2 ** i for i in range(10)] * 5
