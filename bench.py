@@ -358,6 +358,39 @@ def main():
                 del m50
             except Exception as e:
                 res["hparams_default_50_layers"] = {"error": repr(e)}
+        if not args.no_sweep and world == 1:
+            # the mu-law-256 variant of configs[1] (one-hot input, 256-way softmax output) -- the model north_star's integer
+            # parity bar is stated on.  It runs on the generic kernel: its sampler is generate.py:219-231 taken literally (float64
+            # softmax, then a LEFT-TO-RIGHT float32 np.logaddexp.reduce over the 256 classes and a sequential float64 cumsum), a chain of
+            # 255 dependent exp+log1p evaluations per sample that no kernel layout shortens without changing the drawn indices.
+            try:
+                Tq = hp.sample_rate // 4 // hp.hop_size * hp.hop_size
+                mq = WaveNetModel(B, dil, hp.filter_width, hp.residual_channels, hp.dilation_channels, hp.skip_channels,
+                                  quantization_channels=256, out_channels=hp.out_channels, use_biases=hp.use_biases, scalar_input=False,
+                                  initial_filter_width=hp.initial_filter_width, global_condition_channels=hp.gc_channels,
+                                  global_condition_cardinality=2, local_condition_channels=hp.num_mels, upsample_factor=hp.upsample_factor,
+                                  train_mode=False, device=dev)
+                mq.load_weights(W.random_tensors(mq.specs, seed=0, scale=0.05))
+                rq = np.random.RandomState(91)
+                melq = torch.from_numpy(rq.uniform(-4, 4, (B, Tq // hp.hop_size, hp.num_mels)).astype(np.float32)).to(dev)
+                uq = torch.from_numpy(rq.random_sample((B, Tq))).to(dev)
+                fq = rq.randint(256, size=B).astype(np.int32)
+                Uq = mq.create_upsample(melq)
+                mq.generate(Uq, gc, fq, uq[:, :600])
+                mq.queue_initializer()
+                torch.cuda.synchronize()
+                q0 = time.perf_counter()
+                oq = mq.generate(Uq, gc, fq, uq)
+                torch.cuda.synchronize()
+                qdt = time.perf_counter() - q0
+                res["mulaw_256"] = {"streams": B, "samples_per_s": B * Tq / qdt, "us_per_generation_step": qdt / Tq * 1e6,
+                                    "realtime_factor_per_stream": Tq / qdt / hp.sample_rate, "kernel": "wn_generate_kernel",
+                                    "classes_drawn": int(torch.unique(oq).numel()),
+                                    "config": {"workload": "configs[1]'s stack with one-hot mu-law-256 input and a 256-way softmax output, batch=%d x %d steps; "
+                                                           "bit-exact int32 indices vs the checker in tests/test_wavenet_gpu.py::test_generate_c2_mulaw_variant_at_batch_8" % (B, Tq)}}
+                del mq, Uq
+            except Exception as e:
+                res["mulaw_256"] = {"error": repr(e)}
         if not args.no_cpu_baseline:
             res["checked_against_oracle"] = "first %d samples of all %d streams of the last timed pass: bit-identical on %d of %d ranks" % (ncheck, B, n_matched, world)
             res["checked_ranks"] = n_matched
