@@ -41,3 +41,19 @@ for role in range(28):
         rows.append("w%d %5.0f t/step busy %4.1f%% [%s]" % (w, tot / T, 100 * busy / tot, " ".join("%s %4.1f%%" % (cats[i], 100 * waits[i] / tot) for i in range(4) if cats[i] != "-")))
     if rows:
         print("%-8s %2d: " % (nm, role - base) + " | ".join(rows[:8]))
+
+tr = prof.cpu().numpy()[2048:2048 + 512].astype(np.int64)
+t0 = tr[0]
+if t0 > 0:
+    print("timeline of step 2000, stream 0 of XCD 0 (us after the head pushed the causal layer's output; 10 ns clock):")
+    print("  z stored, layers 0..29:", " ".join("%.2f" % ((tr[64 + l] - t0) / 100.0) for l in range(30)))
+    print("  next step's push (= step period): %.2f" % ((tr[1] - t0) / 100.0))
+    print("  conv1 h1 seen (g x wave):", " ".join("%.2f" % ((tr[400 + i] - t0) / 100.0) for i in range(64) if tr[400 + i] > 0))
+    print("  conv1d_2 partials stored (g x summer):", " ".join("%.2f" % ((tr[480 + i] - t0) / 100.0) for i in range(16) if tr[480 + i] > 0))
+    for r in range(8):
+        rows = []
+        for m in range(8):
+            e = tr[128 + (r * 8 + m) * 4: 128 + (r * 8 + m) * 4 + 4]
+            if e[1] > 0:
+                rows.append("w%d %.2f/%.2f/%.2f" % (m, (e[0] - t0) / 100.0, (e[1] - t0) / 100.0, (e[3] - t0) / 100.0))
+        print("  skip %d (group %d half %d) wake/z-seen/total-out: " % (r, r >> 1, r & 1) + " | ".join(rows))

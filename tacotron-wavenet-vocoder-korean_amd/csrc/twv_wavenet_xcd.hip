@@ -152,6 +152,9 @@ struct ChainRegs { float wc[32]; float bfg, gcv, bd; };
 #define WACC_DECL() unsigned long long wacc_[6] = {0, 0, 0, 0, 0, 0}, w0_ = 0, wt0_ = 0; if (INSTR & 4) wt0_ = __builtin_amdgcn_s_memtime()
 #define WACC_T0() do { if (INSTR & 4) w0_ = __builtin_amdgcn_s_memtime(); } while (0)
 #define WACC_T1(i_) do { if (INSTR & 4) wacc_[i_] += __builtin_amdgcn_s_memtime() - w0_; } while (0)
+// one step's timeline (the same build): chip-wide 100 MHz clock of a few events of XCD 0 / stream 0 at step kTraceStep -> prof[2048 + slot]
+constexpr int kTraceStep = 2000;
+#define WTRACE(cond_, slot_) do { if ((INSTR & 4) && a.prof != nullptr && t == kTraceStep && (cond_) && lane == 0) a.prof[2048 + (slot_)] = wall_clock64(); } while (0)
 #define WACC_OUT(prof_, slot_, wave_) do { if ((INSTR & 4) && (prof_) != nullptr && (slot_) >= 0 && lane == 0) {                 \
         unsigned long long* o_ = (prof_) + (((slot_) * 8 + (wave_)) * 8);                                                        \
         o_[0] = __builtin_amdgcn_s_memtime() - wt0_;                                                                             \
@@ -882,6 +885,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
                 __builtin_amdgcn_s_sleep(1);
             }
             WACC_T1(1);
+            WTRACE(prof_slot >= 0 && k == 0, 400 + g * 8 + v);
             // (no exit here on a watchdog abort: see the chain role; the loops end at their heads)
             unsigned long long now_arr = 0;
             if (k == 0) now_arr = __builtin_amdgcn_s_memtime();       // read only: the arithmetic follows the dots (as in the chain)
@@ -924,6 +928,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& 
                 // conv1d_2 chunk 2g+v reads h[32v .. 32v+31] of this block
                 const float p = (v == 0) ? dot_readlane_pipe(t2, h) : dot_readlane_pipe32(t2, h);
                 if (lane < 32) xb_store(rs, (int)XcdExch::PT, (g * 32 + lane) * 2 + v, tag, p);     // chunk 2g+v of output `lane`, next to its pair
+                WTRACE(prof_slot >= 0 && k == 0, 480 + g * 2 + v);
                 XSTAMP(g == 0 && v == 0, 25);
             }
         }
@@ -1438,6 +1443,8 @@ __device__ __forceinline__ void chain_many_role(const XArgs& xa, int xcc, int ns
                 const float c3 = fma_(W[3].wc[31], s_in, cp_[3]);            // k = 31, the last term of chain 3
                 const float x0 = (cp_[0] + cp_[1]) + (cp_[2] + c3);          // model.py:41-46: one AC-1 chunk, no bias; X layout
                 LDSU64((s * kM_BOX + 0) * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(x0);
+                WTRACE(xcc == 0 && c == 0 && s == 0, 0);
+                if ((INSTR & 4) && a.prof != nullptr && t == kTraceStep + 1 && xcc == 0 && c == 0 && s == 0 && lane == 0) a.prof[2048 + 1] = wall_clock64();   // the next step's push
                 if (lane == 0) {
                     if (sampler && t > 0) a.out[(long long)b * T + t - 1] = s_in;
                     xb_store(rs, (int)XcdExch::CTRL, 0, tag, 0.0f);          // step t has started (the lc workgroups throttle on it)
@@ -1513,6 +1520,7 @@ __device__ __forceinline__ void chain_many_role(const XArgs& xa, int xcc, int ns
                         const float gcv = lds[kM_OGC + (s * kXcdSeg0Layers + l0 + i) * 64 + lane];
                         const float z = layer_front_dpp<ALL>(W[i].wc, W[i].bfg, gcv, coef, X, pre[i], lcv[i], use_bias, has_gc, has_lc);
                         xb_store2(rs, (int)XcdExch::ZX + (l0 + i) * 128, lane, tag, z, X);     // {z, tag} -> skip, {layer input, tag} -> service
+                        WTRACE(xcc == 0 && c == 0 && s == 0, 64 + l0 + i);
                         layer_back_dpp<ALL>(wd, W[i].bd, z, X, use_bias);
                         if ((INSTR & 2) && a.dbg != nullptr && t < a.dbg_steps) {
                             float* dp = a.dbg + ((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)(l0 + i) * 64;
@@ -1704,6 +1712,10 @@ __device__ __forceinline__ void service_many_role(const XArgs& xa, int xcc, int 
 
 // ---- SKIP workgroup r = (layer group q, output half hh): model.py:94-96 skip 1x1 of ONE layer per wave for four 64-column slices,
 //      model.py:154 sum in layer order as a relay (LDS inside the group, one L2 hop between groups), model.py:157 relu at the end ---
+//      (Measured alternative, round 3: FEEDER waves that only publish their four values and one or two CLOSER waves per group that add
+//      them up in order while waiting for the group's last layer -- no wave ever waits for a running total.  Bit-exact, but slower:
+//      B = 8 11.3 instead of 10.5 us/step, and from six streams per XCD on the closers saturate (B = 64: 16.7 us): the adds that are
+//      left when the last layer arrives sit on ONE wave's sample path instead of being spread over the relay.)
 template <int INSTR>
 __device__ __forceinline__ void skip_many_role(const XArgs& xa, int xcc, int ns, int r)
 {
@@ -1742,6 +1754,7 @@ __device__ __forceinline__ void skip_many_role(const XArgs& xa, int xcc, int ns,
         WACC_T0();
         if (period) nap_until(seen + period - (period >> 3));
         WACC_T1(0);
+        WTRACE(xcc == 0, 128 + (r * 8 + m) * 4 + 0);
 #pragma nounroll
         for (int k = 0; k < ns; ++k) {
             if (pl.dead) break;
@@ -1760,6 +1773,7 @@ __device__ __forceinline__ void skip_many_role(const XArgs& xa, int xcc, int ns,
             }
             WACC_T1(1);
             MMARK(rs, 16 + 8 * r + m, 2);
+            WTRACE(xcc == 0 && k == 0, 128 + (r * 8 + m) * 4 + 1);
             if (k == 0) {
                 const unsigned long long now = __builtin_amdgcn_s_memtime();
                 const unsigned long long d = now - seen;
@@ -1810,6 +1824,7 @@ __device__ __forceinline__ void skip_many_role(const XArgs& xa, int xcc, int ns,
             WACC_T1(2);
             if (pl.dead) break;
             MMARK(rs, 16 + 8 * r + m, 3);
+            WTRACE(xcc == 0 && k == 0, 128 + (r * 8 + m) * 4 + 3);
             if (last) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -2026,6 +2041,15 @@ __global__ void __launch_bounds__(512) wn_xcd_many_kernel(XArgs xa)
         const bool all = a.lay.use_bias && a.lay.G > 0 && a.lay.L > 0;
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const int nlw = a.lay.NL - (wv < 6 ? 4 * wv : 24 + 3 * (wv - 6));
+#ifdef TWV_EXPERIMENT_OLD_CHAIN
+        if (ns == 1 && !forced && all) {
+            const rsrc_t rs1 = exch_rsrc(a, (int)xcc);
+            if (nlw >= 4 && wv < 6) chain_role<0, true, false, false, false, 4>(xa, (int)xcc, rs1);
+            else if (nlw >= 3 && wv >= 6) chain_role<0, true, false, false, false, 3>(xa, (int)xcc, rs1);
+            else chain_role<0, true, false, false, false, -1>(xa, (int)xcc, rs1);
+            return;
+        }
+#endif
         if (forced) chain_many_role<INSTR, false, true, -1>(xa, (int)xcc, ns, ticket);
         else if (all && nlw >= 4 && wv < 6) chain_many_role<INSTR, true, false, 4>(xa, (int)xcc, ns, ticket);
         else if (all && nlw >= 3 && wv >= 6) chain_many_role<INSTR, true, false, 3>(xa, (int)xcc, ns, ticket);
@@ -2033,9 +2057,20 @@ __global__ void __launch_bounds__(512) wn_xcd_many_kernel(XArgs xa)
         else chain_many_role<INSTR, false, false, -1>(xa, (int)xcc, ns, ticket);
         return;
     }
+#ifdef TWV_EXPERIMENT_OLD_CHAIN
+    if (ticket < 2 * nch && ns == 1) { service_role<0, false>(xa, (int)xcc, exch_rsrc(a, (int)xcc)); return; }
+#endif
     if (ticket < 2 * nch) { service_many_role<INSTR>(xa, (int)xcc, ns, ticket - nch); return; }
     const int role = ticket - 2 * nch;                           // 0-7 skip, 8-15 conv1, 16.. lc
-    if (role < 8) { if (!forced) skip_many_role<INSTR>(xa, (int)xcc, ns, role); return; }
+    if (role < 8) {
+        if (!forced) {
+#ifdef TWV_EXPERIMENT_OLD_SKIP
+            if (ns == 1) { XStreams<1> s1; s1.b[0] = (int)xcc; s1.rs[0] = exch_rsrc(a, (int)xcc); skip_role<0, 1, false>(xa, s1, role); return; }
+#endif
+            skip_many_role<INSTR>(xa, (int)xcc, ns, role);
+        }
+        return;
+    }
     XStreams<kManyPerXcd> sx;
 #pragma unroll
     for (int k = 0; k < kManyPerXcd; ++k) { sx.b[k] = (int)xcc + 8 * (k < ns ? k : 0); sx.rs[k] = exch_rsrc(a, sx.b[k]); }
