@@ -1715,7 +1715,9 @@ __device__ __forceinline__ void service_many_role(const XArgs& xa, int xcc, int 
 //      (Measured alternative, round 3: FEEDER waves that only publish their four values and one or two CLOSER waves per group that add
 //      them up in order while waiting for the group's last layer -- no wave ever waits for a running total.  Bit-exact, but slower:
 //      B = 8 11.3 instead of 10.5 us/step, and from six streams per XCD on the closers saturate (B = 64: 16.7 us): the adds that are
-//      left when the last layer arrives sit on ONE wave's sample path instead of being spread over the relay.)
+//      left when the last layer arrives sit on ONE wave's sample path instead of being spread over the relay.  Also measured: the relay
+//      through every second wave (an adder takes the feeder's value before its own: one hop per two layers) -- bit-exact, 10.57 / 11.02
+//      instead of 10.44 / 10.77 us/step at B = 8 / 64.)
 template <int INSTR>
 __device__ __forceinline__ void skip_many_role(const XArgs& xa, int xcc, int ns, int r)
 {
