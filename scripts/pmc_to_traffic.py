@@ -49,9 +49,33 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     p = os.path.join(ROOT, "profiles", "traffic.json")
     t = json.load(open(p)) if os.path.exists(p) else {}
     kname = "wn_xcd_generate_kernel" if "xcd" in vals["_name"] else "wn_generate_kernel"
-    t.setdefault(h, {}).setdefault(kname, {})["B8_NL30"] = {"fetch_bytes_per_step": fetch, "write_bytes_per_step": write, "profile": "profiles/r02_rocprofv3_generation_summary_%s.txt" % tag}
+    t.setdefault(h, {}).setdefault(kname, {})["B8_NL30"] = {"fetch_bytes_per_step": fetch, "write_bytes_per_step": write, "profile": "profiles/%s_rocprofv3_generation_summary.txt" % tag}
     json.dump(t, open(p, "w"), indent=1, sort_keys=True)
     lines.append("  (profiles/traffic.json updated for generation-kernel source hash %s)" % h)
+# ---- the many-streams kernel at batch 64
+mstats = sorted(rows("stats_many/**/*kernel_stats.csv"), key=lambda r: -float(r["TotalDurationNs"]))
+mg = [r for r in mstats if "many_kernel" in r["Name"]]
+if mg:
+    lines.append("")
+    lines.append("many-streams kernel, scripts/many_bench.py --batch 64 --seconds 1.0 --steps 3 --warmup 1 (24 000 generation steps per launch, 64 streams):")
+    lines.append("  %-60s calls %3s  avg %12.1f us  => %.3f us per generation step, %.3f M samples/s" % (
+        "wn_xcd_many_kernel", mg[0]["Calls"], float(mg[0]["AverageNs"]) / 1e3, float(mg[0]["AverageNs"]) / 1e3 / 24000, 64 * 24000 / (float(mg[0]["AverageNs"]) / 1e9) / 1e6))
+mv = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for r in rows("pmc_many_%s/**/*counter_collection.csv" % c):
+        if "many_kernel" in r["Kernel_Name"]:
+            mv.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+if "FETCH_SIZE" in mv and "WRITE_SIZE" in mv:
+    fetch = 2.0 * 1024.0 * sum(mv["FETCH_SIZE"]) / len(mv["FETCH_SIZE"]) / steps
+    write = 1024.0 * sum(mv["WRITE_SIZE"]) / len(mv["WRITE_SIZE"]) / steps
+    lines.append("  PMC (12 000-step launch): FETCH_SIZE %.1f KiB, WRITE_SIZE %.1f KiB => %.0f B read (x2 gfx950 correction) + %.0f B written per generation step (all 64 streams)" % (
+        sum(mv["FETCH_SIZE"]) / len(mv["FETCH_SIZE"]), sum(mv["WRITE_SIZE"]) / len(mv["WRITE_SIZE"]), fetch, write))
+    import twvk_amd
+    h = twvk_amd._lib.generation_hash()
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    t = json.load(open(p)) if os.path.exists(p) else {}
+    t.setdefault(h, {}).setdefault("wn_xcd_many_kernel", {})["B64_NL30"] = {"fetch_bytes_per_step": fetch, "write_bytes_per_step": write, "profile": "profiles/%s_rocprofv3_generation_summary.txt" % tag}
+    json.dump(t, open(p, "w"), indent=1, sort_keys=True)
 if "SQ_WAVE_CYCLES" in vals:
     wc = sum(vals["SQ_WAVE_CYCLES"]) / len(vals["SQ_WAVE_CYCLES"])
     for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
