@@ -322,7 +322,7 @@ def main():
             # what more streams on the same GPU are worth: 1 s of audio per stream at B = 8 (XCD-per-stream kernel), 16 and 32 (generic kernel)
             sweep = []
             T1 = hp.sample_rate // hp.hop_size * hp.hop_size
-            for Bs in (8, 16, 32, 48, 64):
+            for Bs in (8, 16, 32, 48, 64, 72, 96):
                 try:
                     ms = m if Bs == B else make_vocoder(Bs)
                     inp = make_inputs(Bs, T1, 50 + Bs)

@@ -137,6 +137,8 @@ if "b64" in stages:
     run("b8s", [1, 2, 4, 8, 16, 32], 8, 40, 0, chunks=[15, 1, 1, 2, 21], scale=0.1)
     run("b32s", [1, 2, 4, 8, 16, 32], 32, 40, 0, chunks=[15, 1, 1, 2, 21], scale=0.1)
     run("b48", [2 ** i for i in range(10)] * 3, 48, 900, 0, chunks=[500, 400], seed=5)     # default selection: batch > 32 -> many
+    run("b96", [2 ** i for i in range(10)] * 3, 96, 900, 0, chunks=[500, 1, 399], seed=5)
+    run("b75", [2 ** i for i in range(10)] * 3, 75, 600, 0, seed=6)
 if "prime" in stages:
     dil = [1, 2, 4, 8, 16, 32]
     for B in (11, 40):
@@ -161,7 +163,7 @@ if "time" in stages:
     from twvk_amd import weights as W
     dil = [2 ** i for i in range(10)] * 3
     T = 12000
-    for B, many in ((8, 0), (8, 1), (32, 0), (32, 1), (40, 1), (48, 1), (56, 1), (64, 1)):
+    for B, many in ((8, 0), (8, 1), (32, 0), (32, 1), (48, 1), (64, 1), (72, 1), (80, 1), (88, 1), (96, 1)):
         try:
             d, tensors, blob = make_case(O, dil)
             m = make_model(B, dil, tensors); m.set_option("xcd_many", many)

@@ -175,6 +175,15 @@ struct XArgs {
 // workgroups hold weights only, so ONE set per XCD serves them all, stream after stream in a fixed order -- the streams settle a
 // fraction of a microsecond apart and every one keeps the single-stream step time
 template <int NS> struct XStreams { rsrc_t rs[NS]; int b[NS]; };
+__device__ __forceinline__ rsrc_t exch_rsrc(const XcdLaunch& a, int b)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(a.exch + (long long)b * XcdExch::WORDS, 0, (int)(XcdExch::WORDS * 8), 0x00020000);
+}
+// the same view with the descriptors made on demand (many-streams kernel: twelve descriptors held in scalar registers for the whole
+// launch spilled); slots of streams the XCD does not have alias stream 0
+struct XLazyRs { const XcdLaunch* a; int xcc, ns; __device__ __forceinline__ rsrc_t operator[](int k) const { return exch_rsrc(*a, xcc + 8 * (k < ns ? k : 0)); } };
+struct XLazyB { int xcc, ns; __device__ __forceinline__ int operator[](int k) const { return xcc + 8 * (k < ns ? k : 0); } };
+template <int NS> struct XStreamsLazy { XLazyRs rs; XLazyB b; };
 constexpr int kSkipLdsWords = 32 * 64;       // 8-byte LDS words per stream in a skip workgroup
 constexpr int kConvLdsFloats = 16 * 64 + 64; // LDS floats per stream in a conv1 workgroup
 
@@ -835,8 +844,8 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
 //  CONV1 workgroup g: model.py:158-160 conv1d_1 + relu for output block g (16 chunk tiles over the 8 waves), then the two
 //  chunks (2g, 2g+1) of model.py:161-165 conv1d_2 that read this block: what travels on is conv1d_2's partial table.
 // =====================================================================================================================
-template <int INSTR, int NS, bool BAR = false>
-__device__ __forceinline__ void conv1_role(const XArgs& xa, const XStreams<NS>& sx, int g, const int ns_rt = NS, const int prof_slot = -1)
+template <int INSTR, int NS, bool BAR = false, class SX = XStreams<NS>>
+__device__ __forceinline__ void conv1_role(const XArgs& xa, const SX& sx, int g, const int ns_rt = NS, const int prof_slot = -1)
 {
     const XcdLaunch& a = xa.p;
     const Layout& L = a.lay;
@@ -1252,20 +1261,19 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
 // scripts/many_check.py after a watchdog abort.  Slots: 0-7 chain waves, 8-15 service waves, 16 + 8 r + m skip, 80 + 8 g + v conv1
 #define MMARK(rs_, slot_, stage_) do { if ((INSTR & 2) && lane == 0) xb_store(rs_, (int)XcdExch::MARK + (slot_), 0, (unsigned)t + 1u, (float)(stage_)); } while (0)
 constexpr int kMS = 2;                                   // stream slots of a chain / service workgroup
-constexpr int kManyChains = 4;                           // chain (and service) workgroups per XCD
+constexpr int kManyChains = 6;                           // chain (and service) workgroups per XCD: 6 + 6 + 8 skip + 8 conv1 + 4 lc = all 32 CUs at twelve streams
 constexpr int kManyPerXcd = kMS * kManyChains;           // streams per XCD
 constexpr int kM_BOX = 10;                               // hand-off boxes per slot: 0..7 the waves' inputs, 8 end of a forced step, 9 sink
 constexpr int kM_OWD = 4096;                             // LDS floats: dense kernels [30 layers][4][64 lanes][4] behind the boxes
 constexpr int kM_OGC = kM_OWD + kXcdSeg0Layers * 1024;   // gc projections [slot][30][64]
 constexpr int kM_OHS = kM_OGC + kMS * kXcdSeg0Layers * 64;                 // wave 7's per-slot state [slot][9][64]: causal queue (2), partial chunk (4), noise terms (2), first input
 constexpr int kManyChainLds = kM_OHS + kMS * 9 * 64;                       // floats (155.5 KiB)
-constexpr int kManySkipLds = kManyPerXcd * 8 * 4 * 64 * 2;                 // floats: [stream][wave][4 slices][64] 8-byte words (128 KiB)
+// skip role: the relay's mailboxes [stream][wave]: the four slices' running totals as one 16-byte word per lane + one tag word per lane
+// (a wave's LDS writes are performed in order: data, then tag; the reader asks for the tag, then the data)
+constexpr int kManySkipData4 = kManyPerXcd * 8 * 64;                       // float4 units
+constexpr int kManySkipLds = kManySkipData4 * 4 + kManyPerXcd * 8 * 64;    // floats (120 KiB at twelve streams)
 constexpr int kManyLds = kManyChainLds > kManySkipLds ? kManyChainLds : kManySkipLds;
 
-__device__ __forceinline__ rsrc_t exch_rsrc(const XcdLaunch& a, int b)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(a.exch + (long long)b * XcdExch::WORDS, 0, (int)(XcdExch::WORDS * 8), 0x00020000);
-}
 
 // mixture.py:84-114 from conv1d_2's [16 chunks][32 outputs] partial table of ONE stream (the sampler half of chain_role, as a function:
 // the many-streams chain draws for two slots).  Returns the sample; `tag` = step + 1 of the step the table belongs to.
@@ -1794,18 +1802,18 @@ __device__ __forceinline__ void skip_many_role(const XArgs& xa, int xcc, int ns,
             float tot[4];
             WACC_T0();
             if (from_lds) {
-                unsigned long long qi[4];
-                const int o = ((k * 8 + m) * 4) * 64 + lane;
+                const int o = (k * 8 + m) * 64 + lane;
+                f32x4 din;
                 pl.it = 0;
                 for (;;) {
-                    bool ok = true;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { qi[j] = LDSU64(o + j * 64); ok = ok && g_tag(qi[j]) == tag; }
-                    if (__all(ok)) break;
+                    const int tg = LDSVI(kManySkipData4 * 4 + o);
+                    asm volatile("" ::: "memory");
+                    din = LDS4(o);
+                    asm volatile("" ::: "memory");
+                    if (__all((unsigned)tg == tag)) break;
                     if (!poll_tick<true>(pl, 52)) break;
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) tot[j] = g_val(qi[j]) + val[j];
+                tot[0] = din.x + val[0]; tot[1] = din.y + val[1]; tot[2] = din.z + val[2]; tot[3] = din.w + val[3];
             } else if (from_l2) {
                 u32x4s d0, d1;
                 const int uw = (int)XcdExch::SKT + ((q - 1) * 2 + hh) * 256;
@@ -1838,9 +1846,10 @@ __device__ __forceinline__ void skip_many_role(const XArgs& xa, int xcc, int ns,
                 xb_store2(rs, uw, lane, tag, tot[0], tot[1]);
                 xb_store2(rs, uw + 128, lane, tag, tot[2], tot[3]);
             } else {
-                const int o = ((k * 8 + m + 1) * 4) * 64 + lane;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) LDSU64(o + j * 64) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(tot[j]);
+                const int o = (k * 8 + m + 1) * 64 + lane;
+                LDS4(o) = f32x4{tot[0], tot[1], tot[2], tot[3]};
+                asm volatile("" ::: "memory");
+                LDSVI(kManySkipData4 * 4 + o) = (int)tag;
             }
         }
     }
@@ -2073,10 +2082,12 @@ __global__ void __launch_bounds__(512) wn_xcd_many_kernel(XArgs xa)
         }
         return;
     }
-    XStreams<kManyPerXcd> sx;
-#pragma unroll
-    for (int k = 0; k < kManyPerXcd; ++k) { sx.b[k] = (int)xcc + 8 * (k < ns ? k : 0); sx.rs[k] = exch_rsrc(a, sx.b[k]); }
-    if (role < 16) { if (!forced) conv1_role<(INSTR & 4), kManyPerXcd, true>(xa, sx, role - 8, ns, xcc == 0 ? 16 + role - 8 : -1); }
+    if (role < 16) {
+        if (!forced) {
+            const XStreamsLazy<kManyPerXcd> sx{{&a, (int)xcc, ns}, {(int)xcc, ns}};
+            conv1_role<(INSTR & 4), kManyPerXcd, true, XStreamsLazy<kManyPerXcd>>(xa, sx, role - 8, ns, xcc == 0 ? 16 + role - 8 : -1);
+        }
+    }
     else lc_many_role<INSTR>(xa, (int)xcc, ns, role - 16, xcc == 0 ? 24 + role - 16 : -1);
 }
 
@@ -2171,7 +2182,7 @@ int xcd_launch(const XcdLaunch& p, hipStream_t st)
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shm, st, xa);
     };
     if (many) {
-        if (p.B > kXcdManyStreams) return twv_fail(TWV_E_UNSUPPORTED, "the many-streams XCD kernel takes at most 64 streams");
+        if (p.B > kXcdManyStreams) return twv_fail(TWV_E_UNSUPPORTED, "the many-streams XCD kernel takes at most 96 streams");
         // a profile buffer selects the wait-accounting build here (scripts/many_profile.py), not the phase stamps of the batch <= 32 kernel
         if (instr == 3) return twv_fail(TWV_E_UNSUPPORTED, "layer dumps and wait accounting are separate builds of the many-streams kernel");
         if (instr == 1) go(wn_xcd_many_kernel<4>);

@@ -11,7 +11,7 @@ constexpr int kXcdSeg0Layers = 30;     // first chain workgroup: waves 0..5 four
 constexpr int kXcdMaxLayers = 50;      // a second chain workgroup takes layers 30.. (hparams.py has 50); limit: LDS of the service workgroup (tiles of layers 0 .. NL-33) and of the skip workgroups (value slots of two streams + tiles of layers 0 .. NL-41)
 constexpr int kXcdLs = 64;             // layer slots of the per-layer exchange arrays
 constexpr int kXcdStreams = 32;        // up to four streams per XCD (stream b runs on XCD b % 8), each with its own chain workgroup
-constexpr int kXcdManyStreams = 64;    // the many-streams kernel (30 layers or fewer): up to eight per XCD, two per chain workgroup
+constexpr int kXcdManyStreams = 96;    // the many-streams kernel (30 layers or fewer): up to twelve per XCD, two per chain workgroup
 constexpr int kXcdLcRing = 16;         // steps of lc projections the lc workgroups may run ahead of the chain
 constexpr int kXcdXlFloats = 13 * 64 * 4;   // per layer: the chain's register image [13 float4][64 lanes]
 constexpr int kXcdXcFloats = 8 * 64 * 4;    // causal kernel in the chain's lane order

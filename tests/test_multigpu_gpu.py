@@ -60,7 +60,7 @@ def test_bench_line_on_one_gpu_has_every_contract_field():
     assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and 0 < rf["frac_of_floor"] <= 1.0 and 0 < rf["fp32_frac"] < 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert line["checked_ranks"] == 1
-    assert [e["streams"] for e in line["streams_sweep"]] == [8, 16, 32, 48, 64]
+    assert [e["streams"] for e in line["streams_sweep"]] == [8, 16, 32, 48, 64, 72, 96]
     assert all("error" not in e for e in line["streams_sweep"]), line["streams_sweep"]
     assert line["streams_sweep"][-1]["kernel"] == "wn_xcd_many_kernel"
     assert line["tacotron"]["roofline"]["bound"] == "mfma" and 0 < line["tacotron"]["roofline"]["frac"] < 1

@@ -617,19 +617,20 @@ def test_xcd_kernel_with_several_streams_per_xcd(torch_cuda, oracle, B):
     assert first_mismatch(got, want) is None, first_mismatch(got, want)
 
 
-@pytest.mark.parametrize("B", [48, 64])
+@pytest.mark.parametrize("B", [48, 64, 96])
 def test_xcd_many_streams_kernel_at_bench_geometry(torch_cuda, oracle, B):
-    """more than 32 streams: the many-streams kernel (five to eight streams per XCD: two per chain / service workgroup, skip
+    """more than 32 streams: the many-streams kernel (five to twelve streams per XCD: two per chain / service workgroup, skip
     workgroups laid out as layer groups x output halves with the layer-ordered sum as a relay), BASELINE configs[1]'s model,
-    12 000 steps per stream with fused conditioning; every sample of every stream bit for bit"""
-    T = 12000
+    12 000 steps per stream (6 000 at B = 96: all 32 CUs of every XCD carry a role) with fused conditioning; every sample of
+    every stream bit for bit"""
+    T = 12000 if B <= 64 else 6000
     m, mel, gc, seed_in, u, want = _bench_case(oracle, B, T)
     assert m.fused_conditioning(), "up to 64 streams are served by the XCD kernels on an MI355X"
     got = m.generate(m.create_upsample(mel), gc, seed_in, u).cpu().numpy()
     assert first_mismatch(got, want) is None, first_mismatch(got, want)
 
 
-@pytest.mark.parametrize("B", [1, 9, 33, 43, 64])
+@pytest.mark.parametrize("B", [1, 9, 33, 43, 64, 75, 96])
 def test_xcd_many_streams_kernel_chunked_calls(torch_cuda, oracle, B):
     """the many-streams kernel (forced with the `xcd_many` option where the batch alone would not select it) against the checker:
     stream counts that leave chain workgroups with one slot, XCDs with different numbers of streams, chunked calls including
