@@ -27,7 +27,7 @@ t0 = time.perf_counter(); m.generate(U, gc, seed_in, u); torch.cuda.synchronize(
 print("B %d, T %d: %.2f us/step (accounting build)" % (B, T, dt / T * 1e6))
 p = prof.cpu().numpy().reshape(-1, 8, 8)
 names = {0: ("chain", ["PG/LG", "input", "sampler", "-"]), 4: ("service", ["layer-in", "lc-ring", "-", "-"]), 8: ("skip", ["nap", "z", "total-in", "-"]),
-         16: ("conv1", ["nap", "h1", "count", "-"]), 24: ("lc", ["throttle", "-", "-", "-"])}
+         16: ("conv1", ["nap", "h1", "count", "-"]), 24: ("lc", ["throttle", "row+stages", "dots", "publish"])}
 for role in range(28):
     base = max(k for k in names if k <= role)
     nm, cats = names[base]

@@ -180,6 +180,46 @@ __device__ __forceinline__ void dot32_dpp_x2(const float (&wa)[32], float xa0, f
     rb = (d0 + d1) + (d2 + d3);
 }
 
+// THREE independent 32-term chunks interleaved (twelve fma chains in flight): the three chunks of an 80-channel lc projection
+// (many-streams kernel's lc role).  Four terms of each chunk per asm statement (an asm statement takes at most 30 operands):
+// k = 4b .. 4b+3 goes to chains 0..3 in this order in every block, so each chain still sees its terms in ascending k.
+#define TWV_FMAC12_DPP(c, d, e, xa, xb, xc, wa, wb, wc, base, n0, n1, n2, n3)                                     \
+    asm volatile(                                                                                                  \
+        "s_nop 1\n" TWV_ALIGN8                                                                                     \
+        "v_fmac_f32_dpp %0, %12, %15 row_newbcast:" #n0 " row_mask:0xf bank_mask:0xf\n"                            \
+        "v_fmac_f32_dpp %4, %13, %19 row_newbcast:" #n0 " row_mask:0xf bank_mask:0xf\n"                            \
+        "v_fmac_f32_dpp %8, %14, %23 row_newbcast:" #n0 " row_mask:0xf bank_mask:0xf\n"                            \
+        "v_fmac_f32_dpp %1, %12, %16 row_newbcast:" #n1 " row_mask:0xf bank_mask:0xf\n"                            \
+        "v_fmac_f32_dpp %5, %13, %20 row_newbcast:" #n1 " row_mask:0xf bank_mask:0xf\n"                            \
+        "v_fmac_f32_dpp %9, %14, %24 row_newbcast:" #n1 " row_mask:0xf bank_mask:0xf\n"                            \
+        "v_fmac_f32_dpp %2, %12, %17 row_newbcast:" #n2 " row_mask:0xf bank_mask:0xf\n"                            \
+        "v_fmac_f32_dpp %6, %13, %21 row_newbcast:" #n2 " row_mask:0xf bank_mask:0xf\n"                            \
+        "v_fmac_f32_dpp %10, %14, %25 row_newbcast:" #n2 " row_mask:0xf bank_mask:0xf\n"                           \
+        "v_fmac_f32_dpp %3, %12, %18 row_newbcast:" #n3 " row_mask:0xf bank_mask:0xf\n"                            \
+        "v_fmac_f32_dpp %7, %13, %22 row_newbcast:" #n3 " row_mask:0xf bank_mask:0xf\n"                            \
+        "v_fmac_f32_dpp %11, %14, %26 row_newbcast:" #n3 " row_mask:0xf bank_mask:0xf"                             \
+        : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]),          \
+          "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3])                                                           \
+        : "v"(xa), "v"(xb), "v"(xc), "v"(wa[base]), "v"(wa[base + 1]), "v"(wa[base + 2]), "v"(wa[base + 3]),         \
+          "v"(wb[base]), "v"(wb[base + 1]), "v"(wb[base + 2]), "v"(wb[base + 3]),                                   \
+          "v"(wc[base]), "v"(wc[base + 1]), "v"(wc[base + 2]), "v"(wc[base + 3]))
+__device__ __forceinline__ void dot32_dpp_x3(const float (&wa)[32], float xa0, float xb0, const float (&wb)[32], float xa1, float xb1,
+                                             const float (&wc)[32], float xa2, float xb2, float& ra, float& rb, float& rc)
+{
+    float c[4] = {0.0f, 0.0f, 0.0f, 0.0f}, d[4] = {0.0f, 0.0f, 0.0f, 0.0f}, e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    TWV_FMAC12_DPP(c, d, e, xa0, xa1, xa2, wa, wb, wc, 0, 0, 1, 2, 3);
+    TWV_FMAC12_DPP(c, d, e, xa0, xa1, xa2, wa, wb, wc, 4, 4, 5, 6, 7);
+    TWV_FMAC12_DPP(c, d, e, xa0, xa1, xa2, wa, wb, wc, 8, 8, 9, 10, 11);
+    TWV_FMAC12_DPP(c, d, e, xa0, xa1, xa2, wa, wb, wc, 12, 12, 13, 14, 15);
+    TWV_FMAC12_DPP(c, d, e, xb0, xb1, xb2, wa, wb, wc, 16, 0, 1, 2, 3);
+    TWV_FMAC12_DPP(c, d, e, xb0, xb1, xb2, wa, wb, wc, 20, 4, 5, 6, 7);
+    TWV_FMAC12_DPP(c, d, e, xb0, xb1, xb2, wa, wb, wc, 24, 8, 9, 10, 11);
+    TWV_FMAC12_DPP(c, d, e, xb0, xb1, xb2, wa, wb, wc, 28, 12, 13, 14, 15);
+    ra = (c[0] + c[1]) + (c[2] + c[3]);
+    rb = (d[0] + d[1]) + (d[2] + d[3]);
+    rc = (e[0] + e[1]) + (e[2] + e[3]);
+}
+
 // a lane's half of a 32-term chunk: two chains, 16 terms, operand vector in the Z layout
 __device__ __forceinline__ float dot16_dpp(const float (&w)[16], float z)
 {

@@ -1867,6 +1867,9 @@ __device__ __forceinline__ void skip_many_role(const XArgs& xa, int xcc, int ns,
 //        kept per stream in wave-private LDS and a stage is re-run only when its input changed: same fmas on the same values, so the
 //        same bits, a third of the LDS round trips; the mel frame is re-read every 300 rows instead of every row;
 //      * the throttle on the chain's progress is checked every fourth row, for all streams in ONE polling round.
+//      This role is what saturates first beyond nine streams per XCD (B = 80: 11.5, B = 96: 13.7 us per step).  Measured and dropped:
+//      two layers per wave (six register tiles, the busy waves dealt out one per SIMD) -- 1.5 us per stream and wave instead of 1.1,
+//      saturated at seven streams (B = 64: 12.5 us).
 template <int INSTR>
 __device__ __forceinline__ void lc_many_role(const XArgs& xa, int xcc, int ns, int wg, const int prof_slot)
 {
@@ -1948,6 +1951,7 @@ __device__ __forceinline__ void lc_many_role(const XArgs& xa, int xcc, int ns, i
         for (int k = 0; k < ns; ++k) {
             const int b = xcc + 8 * k;
             const rsrc_t rs = exch_rsrc(a, b);
+            WACC_T0();
             if (reload) {                                               // row `frame` (mel) / row u (upsampled), zero padded to kRow
                 const float* src = payload + ((long long)b * rows + (mode == XLC_UPSAMPLED ? u : frame)) * Lc;
                 const float ra = lane < Lc ? src[lane] : 0.0f;
@@ -1976,17 +1980,30 @@ __device__ __forceinline__ void lc_many_role(const XArgs& xa, int xcc, int ns, i
                 }
             }
             const int o_cur = rowoff(k, n_up);
+            WACC_T1(1);                                             // (row + stages)
+            WACC_T0();
             // ---- projections: AC-1 chunks of 32 over the lc channels, chunk values added in order
             float resx[kLt];
 #pragma unroll
-            for (int idx = 0; idx < kLt; ++idx) {
-                resx[idx] = 0.0f;
-                if (idx < nown * NLC) {
-                    const int c = idx % NLC;
-                    const float xa_ = lds[o_cur + c * 32 + n16], xb_ = lds[o_cur + c * 32 + 16 + n16];
-                    resx[idx] = dot32_dpp(lt[idx].w, xa_, xb_);
+            for (int idx = 0; idx < kLt; ++idx) resx[idx] = 0.0f;
+            if (NLC == 3 && nown == 1) {
+                // the hparams shape (80 mel channels = three chunks, one layer per wave): the three chunk dots interleaved, all six
+                // operand words requested first (one after the other each dot waited for its own LDS reads: ~400 cycles per dot)
+                const float a0 = lds[o_cur + n16], b0 = lds[o_cur + 16 + n16], a1 = lds[o_cur + 32 + n16], b1 = lds[o_cur + 48 + n16];
+                const float a2 = lds[o_cur + 64 + n16], b2 = lds[o_cur + 80 + n16];
+                dot32_dpp_x3(lt[0].w, a0, b0, lt[1].w, a1, b1, lt[2].w, a2, b2, resx[0], resx[1], resx[2]);
+            } else {
+#pragma unroll
+                for (int idx = 0; idx < kLt; ++idx) {
+                    if (idx < nown * NLC) {
+                        const int c = idx % NLC;
+                        const float xa_ = lds[o_cur + c * 32 + n16], xb_ = lds[o_cur + c * 32 + 16 + n16];
+                        resx[idx] = dot32_dpp(lt[idx].w, xa_, xb_);
+                    }
                 }
             }
+            WACC_T1(2);                                             // (dots)
+            WACC_T0();
 #pragma unroll
             for (int j = 0; j < kLt; ++j) {
                 if (j < nown) {
@@ -2014,6 +2031,7 @@ __device__ __forceinline__ void lc_many_role(const XArgs& xa, int xcc, int ns, i
                     }
                 }
             }
+            WACC_T1(3);                                             // (combine + publish)
         }
         if (n_up > 0) {                                             // advance the phase counter (last stage fastest)
             int carry = 1;
