@@ -1383,7 +1383,7 @@ __device__ __forceinline__ void chain_many_role(const XArgs& xa, int xcc, int ns
     }
     // wave 7's per-slot state lives in LDS rows (kM_OHS) between a slot's turns: rows 0 ha, 1 hb (the causal queue, model.py:52, as two
     // row-broadcast registers), 2-5 the causal chunk without its newest term, 6 / 7 the sampler's noise terms, 8 the first input
-    auto hs = [&](int s, int row) -> float& { return lds[kM_OHS + (s * 9 + row) * 64 + lane]; };
+#define hs(s_, row_) lds[kM_OHS + ((s_) * 9 + (row_)) * 64 + lane]      /* indexed on the LDS symbol itself: a float& would make these FLAT accesses */
     float b2v = 0.0f;
     const bool sampler = head && !forced;
     const bool is15 = (lane & 15) == 15;
@@ -1577,6 +1577,7 @@ __device__ __forceinline__ void chain_many_role(const XArgs& xa, int xcc, int ns
         for (int s = 0; s < nslot; ++s) xb_store(exch_rsrc(a, stream_of(s)), (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);
     WACC_OUT(a.prof, xcc == 0 ? c : -1, w);
 }
+#undef hs
 
 // ---- SERVICE workgroup c of an XCD, two stream slots: delay lines + tap-0 chunks one step ahead (service_role for two streams) ---
 template <int INSTR>
