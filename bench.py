@@ -376,7 +376,7 @@ def main():
                 uq = torch.from_numpy(rq.random_sample((B, Tq))).to(dev)
                 fq = rq.randint(256, size=B).astype(np.int32)
                 Uq = mq.create_upsample(melq)
-                mq.generate(Uq, gc, fq, uq[:, :600])
+                mq.generate(Uq[:, :600].contiguous(), gc, fq, uq[:, :600].contiguous())
                 mq.queue_initializer()
                 torch.cuda.synchronize()
                 q0 = time.perf_counter()
