@@ -147,7 +147,7 @@ int twv_mu_law_expand(const float* y, int64_t n, int quantization_channels, floa
 int twv_wav_to_int16(const float* wav, int rows, int64_t n, int16_t* out, float* scratch, void* stream);
 
 /* elementary functions of the arithmetic contract, evaluated on the device (parity tests pin them bit for bit) */
-int twv_eval_elementwise(int fn /*0 tanh,1 sigmoid,2 exp,3 log,4 log1p*/, const float* x, int64_t n, float* out, void* stream);
+int twv_eval_elementwise(int fn /*0 tanh,1 sigmoid,2 exp,3 log,4 log1p,5 log1p(exp(x)),6 the same as the one-hot sampler's straight line (x <= 0)*/, const float* x, int64_t n, float* out, void* stream);
 int twv_eval_elementwise64(int fn /*0 exp,1 log*/, const double* x, int64_t n, double* out, void* stream);
 
 /* ======================================= Tacotron text -> mel inference =======================================

@@ -15,11 +15,13 @@ ap.add_argument("--workers", type=int, default=0)
 ap.add_argument("--layers", type=int, default=30)
 ap.add_argument("--groups", type=int, default=-1)
 ap.add_argument("--no-stamps", action="store_true")
+ap.add_argument("--onehot", action="store_true", help="mu-law-256 one-hot input, 256-way softmax output")
 args = ap.parse_args()
 hp = twvk_amd.default_hparams()
 dil = ([2 ** i for i in range(10)] * 5)[:args.layers]
 B, T = args.batch, args.steps
-m = WaveNetModel(B, dil, 2, 32, 32, 512, out_channels=30, use_biases=True, scalar_input=True, initial_filter_width=32,
+m = WaveNetModel(B, dil, 2, 32, 32, 512, out_channels=256 if args.onehot else 30, quantization_channels=256, use_biases=True,
+                 scalar_input=not args.onehot, initial_filter_width=32,
                  global_condition_channels=32, global_condition_cardinality=2, local_condition_channels=80,
                  upsample_factor=[5, 5, 12], train_mode=False)
 if args.workers: m.set_option("workers", args.workers)
@@ -28,13 +30,14 @@ m.load_weights(W.random_tensors(m.specs, 0, 0.05))
 rng = np.random.RandomState(0)
 U = torch.from_numpy(rng.uniform(-1, 1, (B, T, 80)).astype(np.float32)).cuda()
 u = torch.from_numpy(rng.uniform(1e-5, 1 - 1e-5, (B, T, 11)).astype(np.float32)).cuda()
+if args.onehot: u = torch.from_numpy(rng.uniform(0, 1, (B, T))).cuda()
 NP = min(T, 2000)
 prof = torch.zeros((NP, 80), dtype=torch.int64, device="cuda")
 _lib.check(m._L.twv_wavenet_set_profile_buffer(m._h, C.c_void_p(prof.data_ptr()), 0 if args.no_stamps else NP))
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-m.generate(U, np.zeros(B, np.int32), np.zeros(B, np.float32), u, check=True)   # warm
+m.generate(U, np.zeros(B, np.int32), np.zeros(B, np.int32 if args.onehot else np.float32), u, check=True)   # warm
 m.queue_initializer()
-e0.record(); m.generate(U, np.zeros(B, np.int32), np.zeros(B, np.float32), u, check=False); e1.record(); torch.cuda.synchronize()
+e0.record(); m.generate(U, np.zeros(B, np.int32), np.zeros(B, np.int32 if args.onehot else np.float32), u, check=False); e1.record(); torch.cuda.synchronize()
 if args.no_stamps:
     print("no stamps: %.2f us/step (events)" % (e0.elapsed_time(e1) * 1e3 / T)); sys.exit(0)
 p = prof.cpu().numpy().astype(np.int64)
@@ -64,3 +67,7 @@ hh = s[:, 52:57]
 if hh[:, 0].any():
     print("helper(0,0) wave 0: h1 published -> seen %.2f | two chunk dots %.2f | wait all partials %.2f | ordered sum %.2f | conv1d_2 partials + publish %.2f | -> table complete in the sampler wave %.2f us" % (
         us(hh[:, 0] - wk[:, 1]), us(hh[:, 1] - hh[:, 0]), us(hh[:, 2] - hh[:, 1]), us(hh[:, 3] - hh[:, 2]), us(hh[:, 4] - hh[:, 3]), us(wk[:, 4] - hh[:, 4])))
+if args.onehot:
+    oh = s[:, 58:64]
+    print("one-hot sampler: logits ready -> max+exp64 %.2f | f64 sum %.2f | log p / T %.2f | logaddexp chain + rescale %.2f | f64 cumsum %.2f | search+publish %.2f us" % (
+        us(oh[:, 1] - oh[:, 0]), us(oh[:, 2] - oh[:, 1]), us(oh[:, 3] - oh[:, 2]), us(oh[:, 4] - oh[:, 3]), us(oh[:, 5] - oh[:, 4]), us(wk[:, 7] - oh[:, 5])))

@@ -925,9 +925,9 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                 // logits were assembled (chunk partials in order + bias) by the workers into lds[o_cat .. o_cat+Q)
                 wait_seq(ctl + C_LGCNT, W * (t + 1), ctl + C_ABORT, 11);
                 ACQUIRE_WG();
+                if (wprof) wp[58] = __builtin_amdgcn_s_memtime();                  // one-hot sampler phases: logits complete
                 const int Q = L.Q;
                 const int o_lg = c.o_cat, o_lp = c.o_cat + L.Opad;                 // float logits / float log-probabilities
-                __attribute__((address_space(3))) double* e64 = (__attribute__((address_space(3))) double*)(lds + c.o_cat + 2 * L.Opad);
                 float xv[16];                                                        // lane owns classes i = lane + 64k
                 float mx = -3.0e38f;
 #pragma unroll
@@ -944,41 +944,101 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                         if (lane + 64 * k < Q)
                             a.dbg[((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)NL * 64 + lane + 64 * k] = xv[k];
                 }
+                // The three class-order loops below (float64 sum, float32 logaddexp reduce, float64 cumsum) are the reference's own
+                // sequential arithmetic and decide the drawn class to the last bit, so their ORDER is kept; what is not kept is one LDS
+                // round trip, one loop test and (in the logaddexp step) four branches per element on the dependent chain (the first
+                // version: 100 us of the one-hot model's 127 us step).  Each loop takes eight classes per trip: their operands are
+                // fetched from LDS as one batch (every lane reads the same words: the adds get wave-uniform VGPR operands; v_readlane
+                // broadcasts of register-held tables were measured 2.4x slower, scripts/ubench/seq_f64.hip) while the previous eight
+                // are being added; reads run up to 15 entries past Q -- inside the tables or the 32 words of slack behind them, never
+                // used -- and the logaddexp step is one straight line (log1p_exp_nonpos_e).
+                __attribute__((address_space(3))) double* e64 = (__attribute__((address_space(3))) double*)(lds + c.o_cat + 2 * L.Opad);
                 const double m64 = (double)mx;
+                double ev[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const int i = lane + 64 * k;
-                    if (i < Q) e64[i] = exp64_e((double)xv[k] - m64);
+                    if (i < Q) { ev[k] = exp64_e((double)xv[k] - m64); e64[i] = ev[k]; }
                 }
+                if (wprof) wp[59] = __builtin_amdgcn_s_memtime();                  // max + float64 exps
                 double sum = 0.0;                                                    // sequential, class order
-                for (int i = 0; i < Q; ++i) sum += e64[i];
+                {
+                    double nx[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) nx[j] = e64[j];
+                    int i = 0;
+                    for (; i + 8 <= Q; i += 8) {
+                        double cur[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { cur[j] = nx[j]; nx[j] = e64[i + 8 + j]; }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) sum += cur[j];
+                    }
+                    for (; i < Q; ++i) sum += e64[i];
+                }
+                if (wprof) wp[60] = __builtin_amdgcn_s_memtime();                  // float64 sum
                 const float temp32 = a.temperature;
+                bool isnan_lp = false;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const int i = lane + 64 * k;
                     if (i < Q) {
-                        const float p32 = (float)(e64[i] / sum);                    // tf.cast(softmax(float64), float32)
-                        lds[o_lp + i] = div_(log_e(p32), temp32);                   // np.log(prediction) / temperature (float32)
+                        const float p32 = (float)(ev[k] / sum);                     // tf.cast(softmax(float64), float32)
+                        const float lp = div_(log_e(p32), temp32);                  // np.log(prediction) / temperature (float32)
+                        lds[o_lp + i] = lp;
+                        isnan_lp |= lp != lp;
                     }
                 }
+                if (wprof) wp[61] = __builtin_amdgcn_s_memtime();                  // log-probabilities
                 float lse = lds[o_lp + 0];                                           // np.logaddexp.reduce, left to right
-                for (int i = 1; i < Q; ++i) {
-                    const float y = lds[o_lp + i];
-                    if (lse == y) lse = lse + 0.693147180559945309417232121458176568f;
-                    else {
-                        const float tmp = lse - y;
-                        if (tmp > 0.0f) lse = lse + log1p_e(exp_e(-tmp));
-                        else if (tmp <= 0.0f) lse = y + log1p_e(exp_e(tmp));
-                        else lse = tmp;
+                {
+                    // npy_logaddexpf(x, y): x == y -> x + ln 2;  x > y -> x + log1p(exp(y - x));  x <= y -> y + log1p(exp(x - y));
+                    // NaN (x - y) otherwise.  As one straight line: both live branches are max(x, y) + log1p(exp(-|x - y|)); the NaN
+                    // exit is sticky and any NaN operand takes it, so it is decided once for all classes (below) instead of per step.
+                    auto lae = [](float x, float y) __attribute__((always_inline)) {
+                        const float r = __builtin_fmaxf(x, y) + log1p_exp_nonpos_e(-__builtin_fabsf(x - y));
+                        return x == y ? x + 0.693147180559945309417232121458176568f : r;
+                    };
+                    float nx[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) nx[j] = lds[o_lp + 1 + j];
+                    int i = 1;
+                    for (; i + 8 <= Q; i += 8) {
+                        float cur[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { cur[j] = nx[j]; nx[j] = lds[o_lp + i + 8 + j]; }   // past Q: inside the tables, unused
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) lse = lae(lse, cur[j]);
                     }
+                    for (; i < Q; ++i) lse = lae(lse, lds[o_lp + i]);
+                    if (__ballot(isnan_lp) != 0ull) lse = __uint_as_float(0x7fc00000u);
                 }
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const int i = lane + 64 * k;
                     if (i < Q) e64[i] = (double)exp_e(lds[o_lp + i] - lse);        // scaled_prediction, then float64 for the cdf
                 }
+                if (wprof) wp[62] = __builtin_amdgcn_s_memtime();                  // logaddexp reduce + rescale
                 double cacc = 0.0;                                                   // cdf = p.cumsum() (float64, sequential)
-                for (int i = 0; i < Q; ++i) { cacc += e64[i]; if (lane == 0) e64[i] = cacc; }
+                {
+                    double nx[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) nx[j] = e64[j];
+                    int i = 0;
+                    for (; i + 8 <= Q; i += 8) {
+                        double cur[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { cur[j] = nx[j]; nx[j] = e64[i + 8 + j]; }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { cacc += cur[j]; cur[j] = cacc; }
+                        if (lane == 0) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) e64[i + j] = cur[j];
+                        }
+                    }
+                    for (; i < Q; ++i) { cacc += e64[i]; if (lane == 0) e64[i] = cacc; }
+                }
+                if (wprof) wp[63] = __builtin_amdgcn_s_memtime();                  // float64 cumsum
                 const double last = cacc;
                 const double uu = reinterpret_cast<const double*>(a.uniforms)[(long long)b * T + t];
                 int idx = Q - 1;
@@ -1176,7 +1236,7 @@ __global__ void __launch_bounds__((1 + kLoaders + D + W) * 64) wn_generate_kerne
     c.o_cpart1 = c.o_causal + L.NCA * 1024;         // [NSJ/G][NCH][64] conv1d_1 chunk partials (only when NSJ/G < W)
     c.o_skl = c.o_cpart1 + ((L.NSJ / a.G < W) ? (L.NSJ / a.G) * NCH * 64 : 0);     // [NSJ/G][NL][64] per-layer skip values (same condition)
     c.o_cat = c.o_skl + ((L.NSJ / a.G < W) ? (L.NSJ / a.G) * NL * 64 : 0);        // one-hot sampler scratch: logits, log-probs, float64 exps/cdf
-    c.o_slots = c.o_cat + (L.scalar ? 0 : 4 * L.Opad);                              // [nslot][SlotOff::FLOATS]
+    c.o_slots = c.o_cat + (L.scalar ? 0 : 4 * L.Opad + 32);                            // [nslot][SlotOff::FLOATS]
     c.stb = a.state + ((long long)c.b * a.G + c.g) * L.state_stride;
     const int* pmeta = reinterpret_cast<const int*>(a.P + L.off_meta);
     c.ring = c.stb + L.st_ring;
@@ -1282,7 +1342,9 @@ __global__ void wn_eval_kernel(int fn, const float* x, long long n, float* out)
             case 1: r = sigmoid_e(v); break;
             case 2: r = exp_e(v); break;
             case 3: r = log_e(v); break;
-            default: r = log1p_e(v); break;
+            case 4: r = log1p_e(v); break;
+            case 5: r = log1p_e(exp_e(v)); break;
+            default: r = log1p_exp_nonpos_e(v); break;
         }
         out[i] = r;
     }
@@ -1479,7 +1541,7 @@ static long long lds_fixed_floats(const Layout& L, int G)
 {
     const int nsjl = L.NSJ / G;
     return 64 * 32 + 2LL * L.S + (long long)L.NOJ * L.NCH * 64 + 64 * 4 + 32 + (long long)L.NL * 96 + (long long)L.NCA * 1024 +
-           (nsjl < kWorkers ? (long long)nsjl * (L.NCH + L.NL) * 64 : 0) + (L.scalar ? 0 : 4LL * L.Opad);
+           (nsjl < kWorkers ? (long long)nsjl * (L.NCH + L.NL) * 64 : 0) + (L.scalar ? 0 : 4LL * L.Opad + 32);
 }
 static int resolve_nslot(const Layout& L, int G)
 {
@@ -1915,7 +1977,7 @@ extern "C" int twv_selftest(float* out256, void* stream)
 }
 extern "C" int twv_eval_elementwise(int fn, const float* x, int64_t n, float* out, void* stream)
 {
-    if (!x || !out || n < 0 || fn < 0 || fn > 4) return fail(TWV_E_INVALID, "bad argument");
+    if (!x || !out || n < 0 || fn < 0 || fn > 6) return fail(TWV_E_INVALID, "bad argument");
     if (n) hipLaunchKernelGGL(wn_eval_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, fn, x, (long long)n, out);
     HIPCHK(hipGetLastError());
     return TWV_OK;

@@ -47,7 +47,7 @@ def eval_elementwise(name, x, device="cuda:0"):
             out = torch.empty_like(t)
             _lib.check(L.twv_eval_elementwise64(fn, _ptr(t), t.numel(), _ptr(out), _stream()))
         return out
-    fn = {"tanh": 0, "sigmoid": 1, "exp": 2, "log": 3, "log1p": 4}[name]
+    fn = {"tanh": 0, "sigmoid": 1, "exp": 2, "log": 3, "log1p": 4, "log1p_exp": 5, "log1p_exp_nonpos": 6}[name]
     t = torch.as_tensor(x, dtype=torch.float32, device=device).contiguous()
     with torch.cuda.device(t.device):
         out = torch.empty_like(t)

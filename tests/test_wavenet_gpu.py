@@ -62,6 +62,24 @@ def test_log_bit_exact(torch_cuda, oracle):
     assert first_mismatch(got, want) is None
 
 
+def test_logaddexp_step_form_over_all_floats(torch_cuda):
+    """The one-hot sampler's np.logaddexp step evaluates log1p(exp(t)) as ONE straight line (no branches; the division without the
+    v_div_scale / v_div_fmas / v_div_fixup instructions of the general sequence).  It must be the contract's log1p_e(exp_e(t)) bit for
+    bit for EVERY float t in [-inf, -0] -- the only arguments the left-to-right reduce hands it (generate.py:219-222)."""
+    import torch
+    from twvk_amd import ops
+    top = int(np.array([np.inf], np.float32).view(np.uint32)[0])           # magnitudes 0 .. +inf
+    step = 1 << 26
+    for lo in range(0, top + 1, step):
+        n = min(step, top + 1 - lo)
+        mag = torch.arange(lo, lo + n, dtype=torch.int64, device="cuda:0").to(torch.int32).view(torch.float32)
+        t = -mag
+        want = ops.eval_elementwise("log1p_exp", t).view(torch.int32)
+        got = ops.eval_elementwise("log1p_exp_nonpos", t).view(torch.int32)
+        bad = torch.nonzero(want != got)
+        assert bad.numel() == 0, (lo, int(bad[0]), float(t[bad[0]]))
+
+
 @pytest.mark.parametrize("name", ["exp64", "log64"])
 def test_elementwise64_bit_exact(torch_cuda, oracle, name):
     from twvk_amd import ops
