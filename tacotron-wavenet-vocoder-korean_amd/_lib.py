@@ -55,14 +55,16 @@ def build(force=False, verbose=False):
     """hipcc cross-compiles the gfx950 library in-tree (works without a GPU).  The source hash is compiled into the binary and kept
     in a sidecar file: a library whose stamp differs from the tree's hash is rebuilt (file times say nothing after a checkout)."""
     want = source_hash()
+    extra = os.environ.get("TWV_EXTRA_HIPCC_FLAGS", "").split()      # tuning aid (e.g. -DTWV_TRPROF): part of the stamp, so a variant
+    stamp_want = want + ("+" + " ".join(extra) if extra else "")       # build never passes for the plain one
     stamp = LIB_PATH + ".srchash"
-    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == stamp_want:
         return LIB_PATH
     hip = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
     # one hipcc per source file, side by side (the generation kernels alone take a minute), then one link
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
-    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + ['-DTWV_SRC_HASH="%s"' % want]
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + ['-DTWV_SRC_HASH="%s"' % want] + extra
     with tempfile.TemporaryDirectory(prefix="twv_build_") as tmp:
         def compile_one(src):
             obj = os.path.join(tmp, os.path.basename(src) + ".o")
@@ -78,7 +80,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     with open(stamp, "w") as fh:
-        fh.write(want + "\n")
+        fh.write(stamp_want + "\n")
     return LIB_PATH
 
 

@@ -708,6 +708,230 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(LayerFwdArgs a)
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------------
+//  The FUSED forward layer with every HBM access a fully coalesced 16-byte-per-lane instruction (round 3).
+//  Anatomy of tr_layer_fwd_kernel<true> (ablation builds, profiles/r03_train_layer_anatomy.txt): its time is the SUM of its phases --
+//  the CU's waves run them in step -- and the memory phases are priced per INSTRUCTION, not per byte: ~22 cycles of the CU's
+//  address path for a dword store of two 128-byte rows, ~13 for such a load, ~88 for a float4 row load that touches 32 lines; 120 of
+//  them per 32-row tile = 2.5 k of the 4.25 k cycles a tile costs a CU (MFMA 1.3 k).  Here a tile enters and leaves as 1 KB
+//  instructions (lane l: the l-th float4 of eight consecutive 128-byte rows): 8 loads and 12 (16 with the skip slice) stores per
+//  tile; the MFMA operand layouts (A: lane = row, C: lane = channel) are reached through three wave-private 32 x 36 LDS patches
+//  (144-byte row stride: the b128 row reads and the b32 column accesses are both conflict-free).  The next tile's rows are
+//  requested before this tile's MFMAs.  Same arithmetic as tr_layer_fwd_kernel<true>.
+// -------------------------------------------------------------------------------------------------------------------
+constexpr int kPatch = 32 * 36;
+#ifdef TWV_TRPROF
+// tuning aid (TWV_EXTRA_HIPCC_FLAGS=-DTWV_TRPROF): s_memtime stamps of block 0 / wave 0's first tiles, read back by twv_debug_trprof
+__device__ unsigned long long g_trprof[3][8][16];
+#define TRPROF(k_, slot_) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && threadIdx.x == 0 && tpi < 8) g_trprof[k_][tpi][slot_] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int twv_debug_trprof(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trprof), sizeof(unsigned long long) * 3 * 8 * 16) == hipSuccess ? 0 : 1; }
+#else
+#define TRPROF(k_, slot_) do { } while (0)
+#endif
+// Every global access of the kernel goes through a buffer descriptor with the array's exact size: a lane that must not touch memory
+// (row outside the utterance, tile past the end) gets the offset 0xFFFFFFFF -- the load returns 0, the store is dropped -- so the
+// loop body has NO branch around a memory instruction.  That matters more than the branch itself: s_waitcnt vmcnt counts in issue
+// order, and behind a conditional load or store the compiler has to assume it was not issued -- its wait for an older load then
+// covers the younger ones too (the first version waited for the rows it had just prefetched, and for every store of the last tile).
+struct FwdcBufs { rsrc_t x, th, sg, xn, zc, q, gc; };
+__device__ __forceinline__ f32x4t tr_bld4(rsrc_t r, unsigned off)
+{
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return f32x4t{__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)};
+}
+__device__ __forceinline__ void tr_bst4(rsrc_t r, unsigned off, f32x4t v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, r, (int)off, 0, 0);
+}
+// everything a tile reads from HBM / L2: the 32 rows of X at t and at t - d (1 KB per instruction), the lc-projection rows Q of the (at most
+// two) frames the tile touches and the gc projection of its batch entry, laid out as the B operands of the five extra k-pairs
+struct FwdcIn { f32x4t g0[4], g1[4]; float qf[4], qg[4], gcf, gcg; };
+__device__ __forceinline__ void tr_tile_fetch(FwdcIn& in_, const LayerFwdArgs& a, const FwdcBufs& bf, int tile, int ntiles, int lane)
+{
+    f32x4t (&g0)[4] = in_.g0; f32x4t (&g1)[4] = in_.g1;
+    const rsrc_t rx = bf.x;
+    tile = tile < ntiles ? tile : ntiles - 1;                                   // (past the end: any valid tile, never used)
+    const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32, cr = lane >> 3, cc = (lane & 7) * 4;
+    {
+        const int n = lane & 31, hh = lane >> 5;
+        int u0 = t0 - a.o; u0 = u0 < 0 ? 0 : u0;
+        const int fA = u0 / a.hop, fB = fA + 1 < a.F ? fA + 1 : fA;
+        const int qa = (((b * a.F + fA) * 4 + hh) * 64 + n) * 4, qb = (((b * a.F + fB) * 4 + hh) * 64 + n) * 4;   // byte offsets
+        in_.qf[0] = load_f32_b(bf.q, qa, 0); in_.qg[0] = load_f32_b(bf.q, qa + 128, 0); in_.qf[1] = load_f32_b(bf.q, qa + 512, 0); in_.qg[1] = load_f32_b(bf.q, qa + 640, 0);
+        in_.qf[2] = load_f32_b(bf.q, qb, 0); in_.qg[2] = load_f32_b(bf.q, qb + 128, 0); in_.qf[3] = load_f32_b(bf.q, qb + 512, 0); in_.qg[3] = load_f32_b(bf.q, qb + 640, 0);
+        in_.gcf = load_f32_b(bf.gc, (b * 64 + n) * 4, 0); in_.gcg = load_f32_b(bf.gc, (b * 64 + 32 + n) * 4, 0);           // 0 without gc (empty descriptor)
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = t0 + 8 * k + cr;
+        const bool in = t < a.Tn;
+        const unsigned o1 = (unsigned)(((b * a.Tn + t) * 32 + cc) * 4);
+        g1[k] = tr_bld4(rx, in ? o1 : 0xFFFFFFFFu);
+        g0[k] = tr_bld4(rx, in && t >= a.d ? o1 - (unsigned)a.d * 128u : 0xFFFFFFFFu);
+    }
+}
+// rows of a wave-private patch (p[row * 36 + channel]) to global rows row0.. of a (rows, ld) array, 1 KB per instruction; rows
+// [rlo, rhi) of the tile are written
+__device__ __forceinline__ void tr_patch_store(const float* p, rsrc_t r, long long row0, int ld, int rlo, int rhi, int lane)
+{
+    const int cr = lane >> 3, cc = (lane & 7) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = 8 * k + cr;
+        const f32x4t v = *reinterpret_cast<const f32x4t*>(p + row * 36 + cc);
+        tr_bst4(r, row >= rlo && row < rhi ? (unsigned)(((row0 + row) * ld + cc) * 4) : 0xFFFFFFFFu, v);
+    }
+}
+constexpr int kFwdcWaves = 8;                               // 2 per SIMD (3 would need <= 168 VGPRs: spills), one workgroup per CU
+__global__ void __launch_bounds__(kFwdcWaves * 64) tr_layer_fwdc_kernel(LayerFwdArgs a)
+{
+    __shared__ float bt[32 * 128];                            // [step][lane][filter, gate]
+    __shared__ __attribute__((aligned(16))) float cts[4 * 512];   // ctab (hop <= 512)
+    __shared__ float bdt[16 * 64];                            // dense: [step][lane]
+    __shared__ __attribute__((aligned(16))) float patch[kFwdcWaves][2][kPatch];
+    for (int e = threadIdx.x; e < a.hop * 4; e += kFwdcWaves * 64) cts[e] = a.ctab[e];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, hh = lane >> 5;
+    for (int e = threadIdx.x; e < 32 * 64; e += kFwdcWaves * 64) {
+        const int s = e >> 6, l = e & 63, nn = l & 31, h2 = l >> 5;
+        const float* W = s < 16 ? a.W0 : a.W1;
+        const int ij = s & 15, k = 8 * (ij >> 2) + 4 * h2 + (ij & 3);
+        bt[e * 2] = W[k * 64 + nn]; bt[e * 2 + 1] = W[k * 64 + 32 + nn];
+    }
+    for (int e = threadIdx.x; e < 16 * 64; e += kFwdcWaves * 64) {
+        const int s = e >> 6, l = e & 63;
+        bdt[e] = a.Wd[(8 * (s >> 2) + 4 * (l >> 5) + (s & 3)) * 32 + (l & 31)];
+    }
+    __syncthreads();
+    typedef float f32x2t __attribute__((ext_vector_type(2)));
+    const float vbf = a.bf ? a.bf[n] : 0.0f, vbg = a.bg ? a.bg[n] : 0.0f, vbd = a.bd ? a.bd[n] : 0.0f;
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int ntiles = a.B * a.tpb, nwaves = gridDim.x * kFwdcWaves;
+    float* pa = patch[wave][0]; float* pb = patch[wave][1];
+    const int cr = lane >> 3, cc = (lane & 7) * 4, cut = a.Tn - a.ow;
+    FwdcBufs bf;
+    {
+        const int act = (int)((long long)a.B * a.Tn * 32 * 4);
+        bf.x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, act, 0x00020000);
+        bf.th = __builtin_amdgcn_make_buffer_rsrc(a.TH, 0, act, 0x00020000);
+        bf.sg = __builtin_amdgcn_make_buffer_rsrc(a.SG, 0, act, 0x00020000);
+        bf.xn = __builtin_amdgcn_make_buffer_rsrc(a.XN, 0, act, 0x00020000);
+        bf.zc = __builtin_amdgcn_make_buffer_rsrc(a.ZC, 0, (int)((((long long)a.B * a.ow - 1) * a.ldz + 32) * 4), 0x00020000);
+        bf.q = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q), 0, (int)((long long)a.B * a.F * 4 * 64 * 4), 0x00020000);
+        bf.gc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gcp ? a.gcp : a.X), 0, a.gcp ? a.B * 64 * 4 : 0, 0x00020000);
+    }
+    FwdcIn in;
+    int tile = blockIdx.x * kFwdcWaves + wave;
+    tr_tile_fetch(in, a, bf, tile, ntiles, lane);
+    int tpi = 0;
+    for (; tile < ntiles; tile += nwaves, ++tpi) {
+        const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
+        TRPROF(0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            *reinterpret_cast<f32x4t*>(pa + (8 * k + cr) * 36 + cc) = in.g0[k];
+            *reinterpret_cast<f32x4t*>(pb + (8 * k + cr) * 36 + cc) = in.g1[k];
+        }
+        TRPROF(0, 1);
+        // The lc projection, the biases and the gc projection ride on the matrix cores as five more k-pairs:
+        //   pre += [c(ph) (1 - hi) | c(ph) hi | 1 0] . [Q(frame fA) ; Q(frame fB) ; bias + gc ; 0]        (k = 0..9; at most two frames per tile)
+        // B operand of k-pair s: lane (n, hh) carries k = 2s + hh
+        int u0 = t0 - a.o; u0 = u0 < 0 ? 0 : u0;
+        const int edge = (u0 / a.hop + 1) * a.hop;                              // first U row of the tile's second frame
+        f32x16 cf = zero, cg = zero;
+        {
+            // A operand of the five extra k-pairs: lane (row, hh) carries k = 2s + hh of its row
+            int u = t0 + n - a.o;
+            u = u < 0 ? 0 : u;                                                  // rows below the layer's offset are masked in the epilogue
+            const bool hi = u >= edge;
+            int ph = u - (hi ? edge : edge - a.hop);
+            ph = ph < a.hop ? ph : a.hop - 1;                                   // (only rows past the utterance end, never stored)
+            const f32x4t c = *reinterpret_cast<const f32x4t*>(&cts[ph * 4]);
+            const float c0 = hh ? c[1] : c[0], c1 = hh ? c[3] : c[2];
+            const float ax[4] = {hi ? 0.0f : c0, hi ? 0.0f : c1, hi ? c0 : 0.0f, hi ? c1 : 0.0f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cf = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[q], in.qf[q], cf, 0, 0, 0);
+                cg = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[q], in.qg[q], cg, 0, 0, 0);
+            }
+            const float one = hh ? 0.0f : 1.0f;
+            cf = __builtin_amdgcn_mfma_f32_32x32x2f32(one, vbf + in.gcf, cf, 0, 0, 0);
+            cg = __builtin_amdgcn_mfma_f32_32x32x2f32(one, vbg + in.gcg, cg, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);                                      // (the prefetch below overwrites `in`: after these MFMAs)
+        // the NEXT tile's operands, all of them, before anything of this tile is stored: s_waitcnt vmcnt retires in issue order, so a
+        // load issued behind a store waits for that store's acknowledgement -- with this order the wait at the top of the next trip
+        // leaves this tile's sixteen stores in flight
+        tr_tile_fetch(in, a, bf, tile + nwaves, ntiles, lane);
+        __builtin_amdgcn_sched_barrier(0);                                      // (and ahead of the tap MFMAs)
+        TRPROF(0, 2);
+        // A operands (lane = row) and the residual operand (C layout) out of the patches
+        f32x4t A0[4], A1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            A0[i] = *reinterpret_cast<const f32x4t*>(pa + n * 36 + 8 * i + 4 * hh);
+            A1[i] = *reinterpret_cast<const f32x4t*>(pb + n * 36 + 8 * i + 4 * hh);
+        }
+        float xres[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xres[r] = pb[((r & 3) + 8 * (r >> 2) + 4 * hh) * 36 + n];
+        TRPROF(0, 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2t w = *reinterpret_cast<const f32x2t*>(&bt[((4 * i + j) * 64 + lane) * 2]);
+                cf = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[i][j], w[0], cf, 0, 0, 0);
+                cg = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[i][j], w[1], cg, 0, 0, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2t w = *reinterpret_cast<const f32x2t*>(&bt[((16 + 4 * i + j) * 64 + lane) * 2]);
+                cf = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[i][j], w[0], cf, 0, 0, 0);
+                cg = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[i][j], w[1], cg, 0, 0, 0);
+            }
+        TRPROF(0, 4);
+        // ---- gated unit (C layout: lane = channel n, register r = row (r&3) + 8(r>>2) + 4hh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const bool valid = t0 + rl >= a.o;
+            const float thv = tr_tanh_fast(cf[r]), sgv = tr_sigmoid_fast(cg[r]);    // evaluated for every row: no branch in the loop body
+            const float th = valid ? thv : 0.0f, sg = valid ? sgv : 0.0f;
+            pa[rl * 36 + n] = th; pb[rl * 36 + n] = sg; cf[r] = th * sg;
+        }
+        TRPROF(0, 5);
+        const int nrows = a.Tn - t0 < 32 ? a.Tn - t0 : 32;
+        const long long grow = (long long)b * a.Tn + t0;
+        tr_patch_store(pa, bf.th, grow, 32, 0, nrows, lane);
+        tr_patch_store(pb, bf.sg, grow, 32, 0, nrows, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pa[((r & 3) + 8 * (r >> 2) + 4 * hh) * 36 + n] = cf[r];      // z: the patch TH has just left
+        const float* pz = pa;
+        // skip input slice: rows t >= cut (model.py:94-96 keeps the last ow); other tiles' stores are dropped by the descriptor
+        tr_patch_store(pz, bf.zc, (long long)b * a.ow + (t0 - cut), a.ldz, cut - t0, nrows, lane);
+        TRPROF(0, 6);
+        // ---- dense 1x1 + residual: z as A operand (row layout) back from the patch
+        f32x16 cd = zero;
+        {
+            const float* zr = pz + n * 36 + 4 * hh;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4t q = *reinterpret_cast<const f32x4t*>(zr + 8 * i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cd = __builtin_amdgcn_mfma_f32_32x32x2f32(q[j], bdt[(4 * i + j) * 64 + lane], cd, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pb[((r & 3) + 8 * (r >> 2) + 4 * hh) * 36 + n] = (xres[r] + cd[r]) + vbd;
+        TRPROF(0, 7);
+        tr_patch_store(pb, bf.xn, grow, 32, 0, nrows, lane);
+        TRPROF(0, 8);
+    }
+}
+
 // ===================================================================================================================
 //  Fused residual layer, backward.  Two kernels per layer, both on v_mfma_f32_32x32x2_f32 with 32-row tiles per wave:
 //  K1 (tr_layer_bwd1_kernel): dZ = dXn Wd^T (+ the skip path's dZC) -> gated-unit backward -> dPRE (stored once, row major)
@@ -1035,23 +1259,41 @@ __global__ void __launch_bounds__(512) tr_layer_bwd2_kernel(LayerBwdArgs a)
     __syncthreads();
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int ntiles = a.B * a.tpb, nwaves = gridDim.x * 8;
+    const rsrc_t rpre = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dPRE), 0, (int)((long long)a.B * a.Tn * 64 * 4), 0x00020000);
+    const rsrc_t rdxn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dXn), 0, (int)((long long)a.B * a.Tn * 32 * 4), 0x00020000);
+    const rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(a.dX, 0, (int)((long long)a.B * a.Tn * 32 * 4), 0x00020000);
+    const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(FUSED ? a.D : a.dX, 0, FUSED ? (int)((long long)a.B * a.T * 4 * 4) : 0, 0x00020000);
     for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += nwaves) {
         const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
         const int t = t0 + (lane & 31);
-        const float* p = a.dPRE + ((long long)b * a.Tn + t) * 64 + 4 * hh;
         f32x4t qa[8], qb[8];
+        if (FUSED) {
+            // no branch around a memory instruction (see tr_layer_fwdc_kernel): out-of-range rows read 0 through the descriptor
+            const unsigned p = (unsigned)((((long long)b * a.Tn + t) * 64 + 4 * hh) * 4);
+            const unsigned pa_ = t < a.Tn ? p : 0x80000000u, pb_ = t + a.d < a.Tn ? p + (unsigned)a.d * 256u : 0x80000000u;   // (+ 32 i stays out of range)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            qa[i] = tr_ld4(p + 8 * i, t < a.Tn);
-            qb[i] = tr_ld4(p + (long long)a.d * 64 + 8 * i, t + a.d < a.Tn);
+            for (int i = 0; i < 8; ++i) { qa[i] = tr_bld4(rpre, pa_ + 32 * i); qb[i] = tr_bld4(rpre, pb_ + 32 * i); }
+        } else {
+            const float* p = a.dPRE + ((long long)b * a.Tn + t) * 64 + 4 * hh;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                qa[i] = tr_ld4(p + 8 * i, t < a.Tn);
+                qb[i] = tr_ld4(p + (long long)a.d * 64 + 8 * i, t + a.d < a.Tn);
+            }
         }
         // operands of the read-modify-writes in the output (C) layout: requested before the MFMAs.  Interior tiles (all rows inside
         // the utterance and above the layer's receptive offset) use per-lane pointers + compile-time row offsets, no predicates.
-        const bool interior = t0 >= a.o && t0 + 32 <= a.Tn;
+        const bool interior = !FUSED && t0 >= a.o && t0 + 32 <= a.Tn;
         const long long lrow = ((long long)b * a.Tn + t0 + 4 * hh) * 32 + n;
         float* up = a.dU + ((long long)b * a.T + (t0 - a.o) + 4 * hh) * 80 + n;
         float rx[16], r0[16], r1[16], r2[16];
-        if (interior) {
+        if (FUSED) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                rx[r] = load_f32_b(rdxn, t0 + ro + 4 * hh < a.Tn ? (int)((lrow + ro * 32) * 4) : -1, 0);
+            }
+        } else if (interior) {
             const float* xp = a.dXn + lrow;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1087,11 +1329,11 @@ __global__ void __launch_bounds__(512) tr_layer_bwd2_kernel(LayerBwdArgs a)
                 }
 #pragma unroll
             for (int j = 0; j < 4; ++j) dj[j] += __shfl_xor(dj[j], 32);
-            if (hh == 0 && v) {
-                f32x4t* dp = reinterpret_cast<f32x4t*>(a.D + ((long long)b * a.T + u) * 4);
-                f32x4t cur = *dp;
+            {
+                const unsigned od = hh == 0 && v ? (unsigned)((((long long)b * a.T + u) * 4) * 4) : 0xFFFFFFFFu;
+                f32x4t cur = tr_bld4(rd, od);
                 cur[0] += dj[0]; cur[1] += dj[1]; cur[2] += dj[2]; cur[3] += dj[3];
-                *dp = cur;
+                tr_bst4(rd, od, cur);
             }
         }
         f32x16 cx = zero, c0 = zero, c1 = zero, c2 = zero;
@@ -1110,7 +1352,13 @@ __global__ void __launch_bounds__(512) tr_layer_bwd2_kernel(LayerBwdArgs a)
                 }
                 cx = __builtin_amdgcn_mfma_f32_32x32x2f32(qb[i][j], w4[1], cx, 0, 0, 0);
             }
-        if (interior) {
+        if (FUSED) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rx[r] + cx[r]), rdx, t0 + ro + 4 * hh < a.Tn ? (int)((lrow + ro * 32) * 4) : -1, 0, 0);
+            }
+        } else if (interior) {
             float* dxp = a.dX + lrow;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1501,8 +1749,9 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             {
                 const int ntiles = B * fa.tpb;
                 int nwg = (ntiles + 7) / 8; nwg = nwg > 256 ? 256 : nwg;      // one workgroup (8 waves, 2 per SIMD) per CU, each wave walks its tiles
+                int nwgc = (ntiles + kFwdcWaves - 1) / kFwdcWaves; nwgc = nwgc > 256 ? 256 : nwgc;
                 fa.Q = Qall + l * (q_ls + 64); fa.ctab = ctab; fa.hop = h->hop; fa.F = F;
-                if (fused_lc) hipLaunchKernelGGL(tr_layer_fwd_kernel<true>, dim3(nwg), dim3(512), 0, st, fa);
+                if (fused_lc) hipLaunchKernelGGL(tr_layer_fwdc_kernel, dim3(nwgc), dim3(kFwdcWaves * 64), 0, st, fa);
                 else hipLaunchKernelGGL(tr_layer_fwd_kernel<false>, dim3(nwg), dim3(512), 0, st, fa);
             }
         }
