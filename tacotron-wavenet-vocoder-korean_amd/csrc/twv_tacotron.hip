@@ -140,20 +140,20 @@ constexpr int kMmRows = 64;
 
 // the lane's four float4 of one 32-term chunk of X': k = 8i + 4*(lane>>5) + {0..3}, i = 0..3 (q[i][j] feeds chain j, pair i)
 struct MmA { f32x4 q[4]; };
-struct MmRow { const float* seq; int t; bool ok; };          // this lane's row: start of its sequence, time index, in range
-__device__ __forceinline__ void mm_load_a(MmA& A, const GemmArgs& a, const MmRow& r, int kg /* first k of the lane's first float4 */, int& tap, int& c)
+struct MmRow { unsigned seq; int t; bool ok; };              // this lane's row: float offset of its sequence's start in X, time index, in range
+// No branch around a load: X is read through a buffer descriptor of its exact extent, and a lane whose float4 lies outside the matrix
+// (row past the end, k past K, conv window outside the sequence) asks for an out-of-range offset and gets zeros.  s_waitcnt vmcnt retires
+// in issue order, and behind a BRANCHED load the compiler must assume it was not issued -- its wait for the current chunk then covered
+// the next chunk's prefetch as well (vmcnt(0) in front of every chunk's MFMAs; profiles/r03_train_layer_anatomy.txt tells the story).
+__device__ __forceinline__ void mm_load_a(MmA& A, const GemmArgs& a, rsrc_t rx, const MmRow& r, int kg /* first k of the lane's first float4 */, int& tap, int& c)
 {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r.ok && kg + 8 * i < a.K) {
-            if (a.kw == 1) v = *reinterpret_cast<const f32x4*>(r.seq + (long long)r.t * a.ldx + kg + 8 * i);
-            else {
-                const int ts = r.t + tap - a.pl;
-                if (ts >= 0 && ts < a.T) v = *reinterpret_cast<const f32x4*>(r.seq + (long long)ts * a.ldx + c);
-            }
-        }
-        A.q[i] = v;
+        const int ts = a.kw == 1 ? r.t : r.t + tap - a.pl;
+        const bool ok = r.ok && kg + 8 * i < a.K && ts >= 0 && ts < a.T;
+        const unsigned off = (r.seq + (unsigned)ts * (unsigned)a.ldx + (unsigned)(a.kw == 1 ? kg + 8 * i : c)) * 4u;
+        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? off : 0x80000000u), 0, 0);
+        A.q[i] = f32x4{__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)};
         c += 8;
         if (c >= a.Cin) { c -= a.Cin; ++tap; }
     }
@@ -175,21 +175,23 @@ __global__ void __launch_bounds__(256) tc_gemm_mfma_kernel(GemmArgs a)
         const int row = row0 + (lane & 31);
         r.ok = row < a.rows;
         r.t = r.ok ? row % a.T : 0;
-        r.seq = a.X + (long long)(r.ok ? row - r.t : 0) * a.ldx;
+        r.seq = (unsigned)(r.ok ? row - r.t : 0) * (unsigned)a.ldx;
     }
+    const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)((((long long)a.rows - 1) * a.ldx + a.Cin) * 4), 0x00020000);
     const int hh = (lane >> 5) * 4;
     int tap = 0, c = hh;                                      // conv window position of the lane's next float4 (Cin >= 8, multiple of 4)
     const float* wt = a.Wt + (long long)nb * nchunk * kTile;
     Tile tl;
     MmA A;
     load_tile(tl, wt, lane);
-    mm_load_a(A, a, r, hh, tap, c);
+    mm_load_a(A, a, rx, r, hh, tap, c);
     for (int ch = 0; ch < nchunk; ++ch) {
         Tile tn;
         MmA An;
-        if (ch + 1 < nchunk) {                                // next chunk's operands travel while this chunk's 32 MFMAs run
-            load_tile(tn, wt + (long long)(ch + 1) * kTile, lane);
-            mm_load_a(An, a, r, (ch + 1) * 32 + hh, tap, c);
+        {                                                     // next chunk's operands travel while this chunk's 32 MFMAs run (behind the
+            const int chn = ch + 1 < nchunk ? ch + 1 : ch;    // last chunk: its own tile again and k >= K, i.e. zeros -- never used)
+            load_tile(tn, wt + (long long)chn * kTile, lane);
+            mm_load_a(An, a, rx, r, (ch + 1) * 32 + hh, tap, c);
         }
         f32x16 acc0[4], acc1[4];
 #pragma unroll
@@ -208,7 +210,7 @@ __global__ void __launch_bounds__(256) tc_gemm_mfma_kernel(GemmArgs a)
         const f32x16 c1 = (acc1[0] + acc1[1]) + (acc1[2] + acc1[3]);
         tot0 = ch == 0 ? c0 : tot0 + c0;
         tot1 = ch == 0 ? c1 : tot1 + c1;
-        if (ch + 1 < nchunk) { tl = tn; A = An; }
+        tl = tn; A = An;
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -251,8 +253,9 @@ __global__ void __launch_bounds__(256) tc_gemm_mfma_ck_kernel(GemmArgs a)
         const int row = row0 + (lane & 31);
         r.ok = row < a.rows;
         r.t = r.ok ? row % a.T : 0;
-        r.seq = a.X + (long long)(r.ok ? row - r.t : 0) * a.ldx;
+        r.seq = (unsigned)(r.ok ? row - r.t : 0) * (unsigned)a.ldx;
     }
+    const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)((((long long)a.rows - 1) * a.ldx + a.Cin) * 4), 0x00020000);
     const int hh = (lane >> 5) * 4;
     const float* wt = a.Wt + (long long)nb * nchunk * kTile;
     for (int c0 = 0; c0 < nchunk; c0 += 4) {
@@ -263,7 +266,7 @@ __global__ void __launch_bounds__(256) tc_gemm_mfma_ck_kernel(GemmArgs a)
             load_tile(tl, wt + (long long)ch * kTile, lane);
             int kg = ch * 32 + hh, tap = 0, c = kg;
             if (a.kw > 1) { tap = kg / a.Cin; c = kg - tap * a.Cin; }
-            mm_load_a(A, a, r, kg, tap, c);
+            mm_load_a(A, a, rx, r, kg, tap, c);
             f32x16 acc0[4], acc1[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
