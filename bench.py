@@ -361,8 +361,8 @@ def main():
         if not args.no_sweep and world == 1:
             # the mu-law-256 variant of configs[1] (one-hot input, 256-way softmax output) -- the model north_star's integer
             # parity bar is stated on.  It runs on the generic kernel: its sampler is generate.py:219-231 taken literally (float64
-            # softmax, then a LEFT-TO-RIGHT float32 np.logaddexp.reduce over the 256 classes and a sequential float64 cumsum), a chain of
-            # 255 dependent exp+log1p evaluations per sample that no kernel layout shortens without changing the drawn indices.
+            # softmax, then a LEFT-TO-RIGHT float32 np.logaddexp.reduce over the 256 classes and a sequential float64 cumsum): 255
+            # dependent exp+log1p evaluations per sample (32 us of the step's 73) in whatever layout.
             try:
                 Tq = hp.sample_rate // 4 // hp.hop_size * hp.hop_size
                 mq = WaveNetModel(B, dil, hp.filter_width, hp.residual_channels, hp.dilation_channels, hp.skip_channels,
