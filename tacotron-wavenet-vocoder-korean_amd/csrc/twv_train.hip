@@ -1023,9 +1023,12 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
     const int ntiles = a.B * a.tpb, nwaves = gridDim.x * 4;
     int tile = blockIdx.x * 4 + wave;
     if (tile < ntiles) tr_bwd1_stage<FUSED>(a, tile, lane, base);
-    for (; tile < ntiles; tile += nwaves) {
+    int tpi = 0;
+    for (; tile < ntiles; tile += nwaves, ++tpi) {
         const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
+        TRPROF(1, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this tile's operands are in LDS
+        TRPROF(1, 1);
         // ---- dZ = dXn Wd^T  (A operand: row layout, float4 from the staged tile)
         f32x16 cz = zero;
         {
@@ -1070,7 +1073,9 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read has returned: the region may be refilled
+        TRPROF(1, 2);
         if (tile + nwaves < ntiles) tr_bwd1_stage<FUSED>(a, tile + nwaves, lane, base);
+        TRPROF(1, 3);
         float dF[16], dG[16], zc[16];
         float sf = 0.0f, sgs = 0.0f, sx = 0.0f;
         if (interior) {
@@ -1099,6 +1104,7 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
                 sf += df; sgs += dg; sx += dxc[r];
             }
         }
+        TRPROF(1, 4);
         // per-tile column sums (bias and gc gradients): halves combined, lanes 0..31 write
         {
             const float of = __shfl_xor(sf, 32), og = __shfl_xor(sgs, 32), ox = __shfl_xor(sx, 32);
@@ -1142,6 +1148,7 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
                 }
             }
         }
+        TRPROF(1, 5);
         // ---- weight gradients: A = [row rho][channel], B = dF / dG / dXn registers
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1159,6 +1166,7 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
             }
             g[GQ_WD] = __builtin_amdgcn_mfma_f32_32x32x2f32(zc[r], dxc[r], g[GQ_WD], 0, 0, 0);
         }
+        TRPROF(1, 6);
     }
     // ---- one slab per workgroup: the four waves' tiles summed through LDS (the staging area is free now) in a fixed order
     float* slab = a.slabs + (long long)blockIdx.x * GQ_N * 1024;
