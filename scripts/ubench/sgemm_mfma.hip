@@ -110,6 +110,104 @@ __global__ void __launch_bounds__(256, 2) sgemm_nt_kernel(const float* A, int ld
 #endif
 }
 
+// ---- v2: global -> LDS by LDS-DMA (global_load_lds b128: no VGPR round trip, no ds_write), three LDS buffers (the operands of step s + 2
+// travel during steps s and s + 1), unpadded 64-byte rows with an XOR swizzle of the k quad (slot p of row r holds quad p ^ ((r >> 1) & 3)):
+// the DMA writes linearly, the ds_read_b128 of eight consecutive rows hit eight disjoint 4-bank groups.
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+extern __shared__ __attribute__((aligned(16))) float dyn[];
+__global__ void __launch_bounds__(256, 2) sgemm_nt_dma_kernel(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, int M, int N, int K)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    constexpr int TB = 128 * 16;                              // floats per operand tile per step (8 KB)
+    float* As = dyn; float* Bs = dyn + 3 * TB;                // [3][128][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 1, wc = wave & 1;
+    const int n0 = blockIdx.y * 128;
+    for (int mt = blockIdx.x; mt * 128 < M; mt += gridDim.x) {
+    const int m0 = mt * 128;
+    // DMA: wave w, instruction h (0, 1): slots (w * 2 + h) * 64 + lane of the 512-slot tile; slot s: row s / 4, position s % 4
+    const float* pa[2]; const float* pb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int sl = (wave * 2 + h) * 64 + lane, row = sl >> 2, q = (sl & 3) ^ ((row >> 1) & 3);
+        const int ma = m0 + row < M ? m0 + row : M - 1, nb = n0 + row < N ? n0 + row : N - 1;
+        pa[h] = A + (long long)ma * lda + 4 * q; pb[h] = Bt + (long long)nb * ldb + 4 * q;
+    }
+    auto dma = [&](int step, int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(pa[h] + step * 16), (lptr_t)(As + buf * TB + (wave * 2 + h) * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(pb[h] + step * 16), (lptr_t)(Bs + buf * TB + (wave * 2 + h) * 256), 16, 0, 0);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int nk = K / 16;
+    dma(0, 0);
+    dma(nk > 1 ? 1 : 0, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // step 0 has landed (this wave's share)
+    __syncthreads();
+    // fragment addresses (floats): row = 64 w? + 32 b + (lane & 31), quad 2 i + hh at slot position (2 i + hh) ^ swz
+    const int hh = lane >> 5;
+    const int ra_ = wr * 64 + (lane & 31), rb_ = wc * 64 + (lane & 31);
+    const int fa0 = ra_ * 16 + ((hh ^ ((ra_ >> 1) & 3)) << 2), fa1 = ra_ * 16 + (((2 + hh) ^ ((ra_ >> 1) & 3)) << 2);
+    const int fb0 = rb_ * 16 + ((hh ^ ((rb_ >> 1) & 3)) << 2), fb1 = rb_ * 16 + (((2 + hh) ^ ((rb_ >> 1) & 3)) << 2);
+    int cur = 0;
+    for (int s = 0; s < nk; ++s) {
+        int nxt2 = cur + 2; nxt2 = nxt2 >= 3 ? nxt2 - 3 : nxt2;
+        dma(s + 2 < nk ? s + 2 : s, nxt2);                    // (past the end: a valid step again, never read)
+        const float* a_ = As + cur * TB; const float* b_ = Bs + cur * TB;
+        f32x4 fa[2][2], fb[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            fa[0][b] = *reinterpret_cast<const f32x4*>(a_ + fa0 + b * 512); fa[1][b] = *reinterpret_cast<const f32x4*>(a_ + fa1 + b * 512);
+            fb[0][b] = *reinterpret_cast<const f32x4*>(b_ + fb0 + b * 512); fb[1][b] = *reinterpret_cast<const f32x4*>(b_ + fb1 + b * 512);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y)
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][x][j], fb[i][y][j], acc[x][y], 0, 0, 0);
+        // step s + 1 has landed (this wave's share), step s + 2's four requests may still travel.  NOT __syncthreads(): its fence is
+        // s_waitcnt vmcnt(0), i.e. a wait for the requests issued a moment ago, on every step
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        cur = cur + 1 == 3 ? 0 : cur + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(C, 0, (int)((((long long)M - 1) * ldc + N) * 4), 0x00020000);
+    float* patch = dyn + wave * (32 * 36);
+    const int cr = lane >> 3, cc = (lane & 7) * 4;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hh) * 36 + (lane & 31)] = acc[x][y][r];
+            const int mb = m0 + wr * 64 + x * 32, nb = n0 + wc * 64 + y * 32;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = 8 * k + cr;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * 36 + cc);
+                const bool ok = mb + row < M && nb + cc < N;
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rc,
+                                                       (int)(ok ? (unsigned)((((long long)(mb + row)) * ldc + nb + cc) * 4) : 0x80000000u), 0, 0);
+            }
+        }
+    __syncthreads();                                          // the patches alias the staging buffers of the next tile
+    }
+#endif
+}
+
 int main(int argc, char** argv)
 {
     const int M = argc > 1 ? atoi(argv[1]) : 300736, N = argc > 2 ? atoi(argv[2]) : 512, K = argc > 3 ? atoi(argv[3]) : 960;
@@ -122,11 +220,17 @@ int main(int argc, char** argv)
     for (auto& v : hB) v = rnd();
     (void)hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice); (void)hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
     dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN);
-    hipLaunchKernelGGL(sgemm_nt_kernel, grid, dim3(256), 0, 0, dA, K, dB, K, dC, N, M, N, K);
+    const int variant = argc > 4 ? atoi(argv[4]) : 2;
+    const size_t shm = 6 * 128 * 16 * 4;
+    auto launch = [&]() {
+        if (variant >= 2) hipLaunchKernelGGL(sgemm_nt_dma_kernel, dim3(variant == 2 ? grid.x : 192, grid.y), dim3(256), shm, 0, dA, K, dB, K, dC, N, M, N, K);
+        else hipLaunchKernelGGL(sgemm_nt_kernel, grid, dim3(256), 0, 0, dA, K, dB, K, dC, N, M, N, K);
+    };
+    launch();
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0);
     const int reps = 5;
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(sgemm_nt_kernel, grid, dim3(256), 0, 0, dA, K, dB, K, dC, N, M, N, K);
+    for (int r = 0; r < reps; ++r) launch();
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
     std::vector<float> hC((size_t)64 * N);
@@ -138,6 +242,6 @@ int main(int argc, char** argv)
             for (int k = 0; k < K; ++k) ref += (double)hA[m * K + k] * hB[(size_t)j * K + k];
             worst = fmax(worst, fabs(ref - hC[(size_t)i * N + j]));
         }
-    printf("M %d N %d K %d: %.3f ms -> %.1f TFLOP/s; worst |err| vs f64 on samples %.3g (hipGetLastError %d)\n", M, N, K, ms, 2.0 * M * N * K / ms / 1e9, worst, (int)hipGetLastError());
+    printf("variant %d  M %d N %d K %d: %.3f ms -> %.1f TFLOP/s; worst |err| vs f64 on samples %.3g (hipGetLastError %d)\n", variant, M, N, K, ms, 2.0 * M * N * K / ms / 1e9, worst, (int)hipGetLastError());
     return 0;
 }
