@@ -2071,15 +2071,6 @@ __global__ void __launch_bounds__(512) wn_xcd_many_kernel(XArgs xa)
         const bool all = a.lay.use_bias && a.lay.G > 0 && a.lay.L > 0;
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const int nlw = a.lay.NL - (wv < 6 ? 4 * wv : 24 + 3 * (wv - 6));
-#ifdef TWV_EXPERIMENT_OLD_CHAIN
-        if (ns == 1 && !forced && all) {
-            const rsrc_t rs1 = exch_rsrc(a, (int)xcc);
-            if (nlw >= 4 && wv < 6) chain_role<0, true, false, false, false, 4>(xa, (int)xcc, rs1);
-            else if (nlw >= 3 && wv >= 6) chain_role<0, true, false, false, false, 3>(xa, (int)xcc, rs1);
-            else chain_role<0, true, false, false, false, -1>(xa, (int)xcc, rs1);
-            return;
-        }
-#endif
         if (forced) chain_many_role<INSTR, false, true, -1>(xa, (int)xcc, ns, ticket);
         else if (all && nlw >= 4 && wv < 6) chain_many_role<INSTR, true, false, 4>(xa, (int)xcc, ns, ticket);
         else if (all && nlw >= 3 && wv >= 6) chain_many_role<INSTR, true, false, 3>(xa, (int)xcc, ns, ticket);
@@ -2087,16 +2078,10 @@ __global__ void __launch_bounds__(512) wn_xcd_many_kernel(XArgs xa)
         else chain_many_role<INSTR, false, false, -1>(xa, (int)xcc, ns, ticket);
         return;
     }
-#ifdef TWV_EXPERIMENT_OLD_CHAIN
-    if (ticket < 2 * nch && ns == 1) { service_role<0, false>(xa, (int)xcc, exch_rsrc(a, (int)xcc)); return; }
-#endif
     if (ticket < 2 * nch) { service_many_role<INSTR>(xa, (int)xcc, ns, ticket - nch); return; }
     const int role = ticket - 2 * nch;                           // 0-7 skip, 8-15 conv1, 16.. lc
     if (role < 8) {
         if (!forced) {
-#ifdef TWV_EXPERIMENT_OLD_SKIP
-            if (ns == 1) { XStreams<1> s1; s1.b[0] = (int)xcc; s1.rs[0] = exch_rsrc(a, (int)xcc); skip_role<0, 1, false>(xa, s1, role); return; }
-#endif
             skip_many_role<INSTR>(xa, (int)xcc, ns, role);
         }
         return;
