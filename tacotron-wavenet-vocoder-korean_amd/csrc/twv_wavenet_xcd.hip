@@ -1948,8 +1948,47 @@ __device__ __forceinline__ void lc_many_role(const XArgs& xa, int xcc, int ns, i
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < n_up && i >= first) { k0[i] = a.P[L.off_up[i] + ph[i] * 2 + 0]; k1[i] = a.P[L.off_up[i] + ph[i] * 2 + 1]; }
+        // ---- the common row (only the last stage sees a new input, the hparams shape, not the call's last row): TWO streams at a time in
+        // one straight line -- stage, operand reads, the two sets of three chunk dots, publishes -- so that one stream's LDS round trips
+        // and its store travel under the other's arithmetic (one stream after the other: 1.15 us each, 12 streams = the XCD's step at
+        // batch 96).  Same operations per stream as the general body below, which takes every other row and an odd last stream.
+        int kdone = 0;
+        if (!reload && n_up >= 1 && first == n_up - 1 && NLC == 3 && nown == 1 && u + 1 < T && Lc <= 96) {
+            const int il = n_up - 1;
+            const float t0_ = il == 0 ? k0[0] : (il == 1 ? k0[1] : (il == 2 ? k0[2] : k0[3]));
+            const float t1_ = il == 0 ? k1[0] : (il == 1 ? k1[1] : (il == 2 ? k1[2] : k1[3]));
+            const int l = lfirst;
+            const int ring = ((int)XcdExch::LCR + (((u + 1) % kXcdLcRing) * kXcdLs + l) * 64);
 #pragma nounroll
-        for (int k = 0; k < ns; ++k) {
+            for (; kdone + 1 < ns; kdone += 2) {
+                WACC_T0();
+                const int oa = rowoff(kdone, il), ob = rowoff(kdone + 1, il);          // stage input rows; the output rows follow at + kRow
+                const rsrc_t rsa = exch_rsrc(a, xcc + 8 * kdone), rsb = exch_rsrc(a, xcc + 8 * (kdone + 1));
+                // out[m] = K[a][0]*in[m] + K[a][1]*in[m-1]   as a two-term AC-1 chunk (model.py:102-111); m = lane and m = 64 + lane (< 96)
+                const float xa0 = lds[oa + lane], xa1 = lane > 0 ? lds[oa + lane - 1] : 0.0f, xa2 = lane < 32 ? lds[oa + 64 + lane] : 0.0f, xa3 = lane < 32 ? lds[oa + 63 + lane] : 0.0f;
+                const float xb0 = lds[ob + lane], xb1 = lane > 0 ? lds[ob + lane - 1] : 0.0f, xb2 = lane < 32 ? lds[ob + 64 + lane] : 0.0f, xb3 = lane < 32 ? lds[ob + 63 + lane] : 0.0f;
+                const float ra0 = (fma_(t0_, xa0, 0.0f) + fma_(t1_, xa1, 0.0f)) + (0.0f + 0.0f), ra1 = (fma_(t0_, xa2, 0.0f) + fma_(t1_, xa3, 0.0f)) + (0.0f + 0.0f);
+                const float rb0 = (fma_(t0_, xb0, 0.0f) + fma_(t1_, xb1, 0.0f)) + (0.0f + 0.0f), rb1 = (fma_(t0_, xb2, 0.0f) + fma_(t1_, xb3, 0.0f)) + (0.0f + 0.0f);
+                lds[oa + kRow + lane] = lane < Lc ? ra0 : 0.0f;
+                lds[ob + kRow + lane] = lane < Lc ? rb0 : 0.0f;
+                if (lane < 32) { lds[oa + kRow + 64 + lane] = 64 + lane < Lc ? ra1 : 0.0f; lds[ob + kRow + 64 + lane] = 64 + lane < Lc ? rb1 : 0.0f; }
+                WACC_T1(1);
+                WACC_T0();
+                const int ca = oa + kRow, cb = ob + kRow;
+                const float a0 = lds[ca + n16], b0 = lds[ca + 16 + n16], a1 = lds[ca + 32 + n16], b1 = lds[ca + 48 + n16], a2 = lds[ca + 64 + n16], b2 = lds[ca + 80 + n16];
+                const float c0 = lds[cb + n16], d0 = lds[cb + 16 + n16], c1 = lds[cb + 32 + n16], d1 = lds[cb + 48 + n16], c2 = lds[cb + 64 + n16], d2 = lds[cb + 80 + n16];
+                float pa0, pa1, pa2, pb0, pb1, pb2;
+                dot32_dpp_x3(lt[0].w, a0, b0, lt[1].w, a1, b1, lt[2].w, a2, b2, pa0, pa1, pa2);
+                dot32_dpp_x3(lt[0].w, c0, d0, lt[1].w, c1, d1, lt[2].w, c2, d2, pb0, pb1, pb2);
+                WACC_T1(2);
+                WACC_T0();
+                xb_store(rsa, ring, lane, (unsigned)u + 2u, (pa0 + pa1) + pa2);
+                xb_store(rsb, ring, lane, (unsigned)u + 2u, (pb0 + pb1) + pb2);
+                WACC_T1(3);
+            }
+        }
+#pragma nounroll
+        for (int k = kdone; k < ns; ++k) {
             const int b = xcc + 8 * k;
             const rsrc_t rs = exch_rsrc(a, b);
             WACC_T0();
