@@ -279,6 +279,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
     float X = 0.0f;
     unsigned long long t_in = 0, in_period = 0, now_in = 0;   // when this wave's input arrived in the previous step, the step period
     for (int t = 0; t < T && !pl.dead; ++t) {
+        asm volatile(".p2align 6");                        // (XALIGN, see chain_many_role)
         const unsigned tag = (unsigned)t + 1u;
         // ---- wave 7, head of the step: new input sample -> causal layer -> wave 0.  On the sample-to-sample path: one fma, three adds.
         if (head) {
@@ -605,6 +606,7 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
         }
     }
     for (int t = 0; t < T && !pl.dead; ++t) {
+        asm volatile(".p2align 6");                        // (XALIGN, see chain_many_role)
         const unsigned tag = (unsigned)t + 1u;
 #pragma unroll
         for (int i = 0; i < kSlots; ++i) {
@@ -727,6 +729,7 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
 #pragma unroll
     for (int i = 0; i < kSlots + 1; ++i) seen[i] = 0;
     for (int t = 0; t < T && !pl.dead; ++t) {
+        asm volatile(".p2align 6");                        // (XALIGN, see chain_many_role)
         const unsigned tag = (unsigned)t + 1u;
         int nextl[NS];
         float tot[NS];
@@ -870,6 +873,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const SX& sx, int g,
     unsigned long long t_arr = 0, period = 0;
     WACC_DECL();
     for (int t = 0; t < T && !pl.dead; ++t) {
+        asm volatile(".p2align 6");                        // (XALIGN, see chain_many_role)
         const unsigned tag = (unsigned)t + 1u;
         WACC_T0();
         if (period) nap_until(t_arr + period - (period >> 3));
@@ -1416,6 +1420,7 @@ __device__ __forceinline__ void chain_many_role(const XArgs& xa, int xcc, int ns
     unsigned long long tin0 = 0, tin1 = 0, per0 = 0, per1 = 0;  // per slot: when the wave's input arrived in the previous step, the step period
     WACC_DECL();
     for (int t = 0; t < T && !pl.dead; ++t) {
+        asm volatile(".p2align 6");                        // the step loop starts on a 64-byte line whatever was compiled in front of it (XALIGN)
         const unsigned tag = (unsigned)t + 1u;
         // ---- wave 7: per slot, the sample of step t-1 straight into the causal layer of step t (one fma and three adds on the
         // sample-to-sample path), result to wave 0.  Slot after slot: neither stream waits for the other's post phase.
@@ -1649,6 +1654,7 @@ __device__ __forceinline__ void service_many_role(const XArgs& xa, int xcc, int 
         }
     }
     for (int t = 0; t < T && !pl.dead; ++t) {
+        asm volatile(".p2align 6");                        // the step loop starts on a 64-byte line whatever was compiled in front of it (XALIGN)
         const unsigned tag = (unsigned)t + 1u;
         const bool more = t + 1 < T;
 #pragma unroll
@@ -1761,6 +1767,7 @@ __device__ __forceinline__ void skip_many_role(const XArgs& xa, int xcc, int ns,
     unsigned long long seen = 0, period = 0;
     WACC_DECL();
     for (int t = 0; t < T && !pl.dead; ++t) {
+        asm volatile(".p2align 6");                        // the step loop starts on a 64-byte line whatever was compiled in front of it (XALIGN)
         const unsigned tag = (unsigned)t + 1u;
         WACC_T0();
         if (period) nap_until(seen + period - (period >> 3));
@@ -1953,7 +1960,8 @@ __device__ __forceinline__ void lc_many_role(const XArgs& xa, int xcc, int ns, i
         // and its store travel under the other's arithmetic (one stream after the other: 1.15 us each, 12 streams = the XCD's step at
         // batch 96).  Same operations per stream as the general body below, which takes every other row and an odd last stream.
         int kdone = 0;
-        if (!reload && n_up >= 1 && first == n_up - 1 && NLC == 3 && nown == 1 && u + 1 < T && Lc <= 96) {
+        if (ns > 9 && !reload && n_up >= 1 && first == n_up - 1 && NLC == 3 && nown == 1 && u + 1 < T && Lc <= 96) {    // (up to nine streams the
+                                                                      // role waits for the chains half of the time: one at a time, as measured)
             const int il = n_up - 1;
             const float t0_ = il == 0 ? k0[0] : (il == 1 ? k0[1] : (il == 2 ? k0[2] : k0[3]));
             const float t1_ = il == 0 ? k1[0] : (il == 1 ? k1[1] : (il == 2 ? k1[2] : k1[3]));
