@@ -16,25 +16,25 @@ pytestmark = pytest.mark.gpu
 UP = (5, 5, 12)
 
 
-def _case(dil, B, Tm, S=64, seed=0, scale=0.05, ls_bias=None, clip_audio=False, use_bias=True):
+def _case(dil, B, Tm, S=64, seed=0, scale=0.05, ls_bias=None, clip_audio=False, use_bias=True, up=UP):
     import twvk_amd  # noqa: F401
     from twvk_amd import weights as W
     from twvk_amd.train import WaveNetTrainer
-    specs = W.tensor_specs(len(dil), S=S, use_biases=use_bias)
+    specs = W.tensor_specs(len(dil), S=S, use_biases=use_bias, upsample_factor=up)
     tensors = W.random_tensors(specs, seed=seed, scale=scale)
     if ls_bias is not None:
         tensors["wavenet/conv1d_2/bias"][20:30] = ls_bias          # log-scales: exercises the cdf_delta > 1e-5 branch
-    T = Tm * 300
+    T = Tm * int(np.prod(up))
     rng = np.random.RandomState(seed + 1)
     audio = ((rng.rand(B, T) - 0.5) * 1.6).astype(np.float32)
     if clip_audio:
         audio = np.clip(audio * 1.5, -1.0, 1.0).astype(np.float32)  # some targets at +-1: the two edge branches
     lc = (rng.randn(B, Tm, 80) * 0.5).astype(np.float32)
     gc = rng.randint(0, 2, size=B).astype(np.int32)
-    net = make_model(B, dil, tensors, S=S, use_bias=use_bias)
+    net = make_model(B, dil, tensors, S=S, use_bias=use_bias, up=up)
     tr = WaveNetTrainer(net, sample_size=T)
     tr.load_weights(tensors)
-    cfg = dict(dilations=dil, initial_filter_width=32, use_biases=use_bias, upsample_factor=UP)
+    cfg = dict(dilations=dil, initial_filter_width=32, use_biases=use_bias, upsample_factor=up)
     return tr, tensors, cfg, audio, lc, gc
 
 
@@ -56,7 +56,9 @@ def _check_grads(got, ref, rtol):
     dict(dil=[1, 2, 4, 8, 16, 32, 64, 128, 256, 512], B=3, Tm=6, S=128),
     dict(dil=[1, 2, 4, 1, 2], B=2, Tm=3, ls_bias=-4.0, clip_audio=True),
     dict(dil=[1, 2, 4], B=1, Tm=2, use_bias=False),
-], ids=["small", "one-cycle", "mol-branches", "no-bias"])
+    dict(dil=[1, 2, 4, 8], B=2, Tm=21, up=(4, 4, 4)),          # hop 64: a 32-row tile of the fused layer kernels straddles a frame edge every other tile
+    dict(dil=[1, 2, 4], B=2, Tm=40, up=(2, 4, 4)),             # hop 32 = the tile height (the smallest hop the frame-rate lc path takes)
+], ids=["small", "one-cycle", "mol-branches", "no-bias", "hop64", "hop32"])
 def test_loss_and_gradients_match_torch_fp32(kw):
     tr, tensors, cfg, audio, lc, gc = _case(**kw)
     loss = float(tr.loss_and_gradients(audio, lc, gc).item())
