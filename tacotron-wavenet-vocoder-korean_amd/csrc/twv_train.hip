@@ -1408,6 +1408,101 @@ __global__ void __launch_bounds__(512) tr_layer_bwd2_kernel(LayerBwdArgs a)
     }
 }
 
+// The FUSED backward-2 layer with the dPRE tiles fetched as 1 KB instructions (lane l: the l-th float4 of four consecutive 256-byte rows)
+// and turned into MFMA A operands (lane = row) through two wave-private 32 x 68 LDS patches -- the row loads of tr_layer_bwd2_kernel
+// touch 32 lines per instruction (16 + 16 of them per tile, ~88 cycles of the CU's address path each; profiles/r03_train_layer_anatomy.txt).
+// Same arithmetic as tr_layer_bwd2_kernel<true>.
+__global__ void __launch_bounds__(512) tr_layer_bwd2c_kernel(LayerBwdArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float btc[32 * 64 * 2];          // [step][lane][W1^T, W0^T]
+    __shared__ __attribute__((aligned(16))) float pt[8][2][32 * 68];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, hh = lane >> 5;
+    for (int e = threadIdx.x; e < 32 * 64; e += 512) {
+        const int s_ = e >> 6, l = e & 63, nn = l & 31, h2 = l >> 5;
+        const int k = 8 * (s_ >> 2) + 4 * h2 + (s_ & 3);
+        btc[e * 2] = a.W1[nn * 64 + k]; btc[e * 2 + 1] = a.W0[nn * 64 + k];
+    }
+    __syncthreads();
+    typedef float f32x2t __attribute__((ext_vector_type(2)));
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int ntiles = a.B * a.tpb, nwaves = gridDim.x * 8;
+    const rsrc_t rpre = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dPRE), 0, (int)((long long)a.B * a.Tn * 64 * 4), 0x00020000);
+    const rsrc_t rdxn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dXn), 0, (int)((long long)a.B * a.Tn * 32 * 4), 0x00020000);
+    const rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(a.dX, 0, (int)((long long)a.B * a.Tn * 32 * 4), 0x00020000);
+    const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.D, 0, (int)((long long)a.B * a.T * 4 * 4), 0x00020000);
+    float* pa = pt[wave][0]; float* pb = pt[wave][1];
+    const int fr = lane >> 4, fq = (lane & 15) * 4;                           // coalesced fetch: row within the 4-row group, first column
+    for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += nwaves) {
+        const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
+        const int t = t0 + (lane & 31);
+        {
+            f32x4t ga[8], gb[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int tt = t0 + 4 * k + fr;
+                const unsigned o = (unsigned)((((long long)b * a.Tn + tt) * 64 + fq) * 4);
+                ga[k] = tr_bld4(rpre, tt < a.Tn ? o : 0x80000000u);
+                gb[k] = tr_bld4(rpre, tt + a.d < a.Tn ? o + (unsigned)a.d * 256u : 0x80000000u);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                *reinterpret_cast<f32x4t*>(pa + (4 * k + fr) * 68 + fq) = ga[k];
+                *reinterpret_cast<f32x4t*>(pb + (4 * k + fr) * 68 + fq) = gb[k];
+            }
+        }
+        const long long lrow = ((long long)b * a.Tn + t0 + 4 * hh) * 32 + n;
+        float rx[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            rx[r] = load_f32_b(rdxn, t0 + ro + 4 * hh < a.Tn ? (int)((lrow + ro * 32) * 4) : -1, 0);
+        }
+        f32x4t qa[8], qb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            qa[i] = *reinterpret_cast<const f32x4t*>(pa + n * 68 + 8 * i + 4 * hh);
+            qb[i] = *reinterpret_cast<const f32x4t*>(pb + n * 68 + 8 * i + 4 * hh);
+        }
+        {
+            // D[u][j] += dPRE[row] . Q_j[frame(u)] over the 64 columns: this lane holds 32 of them (row = lane & 31, columns 8i + 4hh + 0..3)
+            const int u = t - a.o;
+            const bool v = t < a.Tn && u >= 0;
+            const int f = v ? u / a.hop : 0;
+            const float* qr = a.Q + (((long long)b * a.F + f) * 4) * 64 + 4 * hh;
+            float dj[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4t q4 = *reinterpret_cast<const f32x4t*>(qr + j * 64 + 8 * i);
+                    dj[j] += (qa[i][0] * q4[0] + qa[i][1] * q4[1]) + (qa[i][2] * q4[2] + qa[i][3] * q4[3]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dj[j] += __shfl_xor(dj[j], 32);
+            const unsigned od = hh == 0 && v ? (unsigned)((((long long)b * a.T + u) * 4) * 4) : 0xFFFFFFFFu;
+            f32x4t cur = tr_bld4(rd, od);
+            cur[0] += dj[0]; cur[1] += dj[1]; cur[2] += dj[2]; cur[3] += dj[3];
+            tr_bst4(rd, od, cur);
+        }
+        f32x16 cx = zero;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2t w = *reinterpret_cast<const f32x2t*>(&btc[((4 * i + j) * 64 + lane) * 2]);
+                cx = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[i][j], w[0], cx, 0, 0, 0);
+                cx = __builtin_amdgcn_mfma_f32_32x32x2f32(qb[i][j], w[1], cx, 0, 0, 0);
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                                        // (rows through an LDS patch and 1 KB stores: measured, 76 against 74 us)
+            const int ro = (r & 3) + 8 * (r >> 2);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rx[r] + cx[r]), rdx, t0 + ro + 4 * hh < a.Tn ? (int)((lrow + ro * 32) * 4) : -1, 0, 0);
+        }
+    }
+}
+
 // ---- one-hot (mu-law) input model: model.py:257-271 (mu_law_encode -> one_hot -> causal conv of width 2 over Q channels) ----
 // x0[(b,t)][j] = Wc[0][q[b,t-1]][j] + Wc[1][q[b,t]][j]   (a one-hot row times a kernel is a row gather); t = 0 is masked
 __global__ void tr_onehot_causal_fwd_kernel(const float* Wc, const int32_t* q, float* x0, int B, int T, int Tn, int Q)
@@ -1846,7 +1941,7 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             ba.Q = Qall + l * (q_ls + 64); ba.D = Dbuf; ba.hop = h->hop; ba.F = F; ba.ctab = ctab; ba.PT = PTall + l * (pt_ls + 64);
             if (fused_lc) hipLaunchKernelGGL(tr_layer_bwd1_kernel<true>, dim3(nwg), dim3(256), (4 * BS_FLOATS + 2048) * 4, st, ba);
             else hipLaunchKernelGGL(tr_layer_bwd1_kernel<false>, dim3(nwg), dim3(256), 4 * BS_FLOATS * 4, st, ba);
-            if (fused_lc) hipLaunchKernelGGL(tr_layer_bwd2_kernel<true>, dim3(nwg2), dim3(512), 0, st, ba);
+            if (fused_lc) hipLaunchKernelGGL(tr_layer_bwd2c_kernel, dim3(nwg2), dim3(512), 0, st, ba);
             else hipLaunchKernelGGL(tr_layer_bwd2_kernel<false>, dim3(nwg2), dim3(512), 0, st, ba);
             float* tsw = dXn; dXn = dXc; dXc = tsw;
         }
