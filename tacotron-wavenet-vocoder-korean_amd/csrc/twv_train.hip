@@ -12,7 +12,9 @@
 // layer's receptive offset are masked.  A 'valid' dilated conv is then a contraction over all rows with a row-shifted operand
 // and every weight gradient is ONE reduction over all rows.  The residual stack runs as three fused kernels per layer on the
 // f32 matrix cores (tr_layer_fwd / tr_layer_bwd1 / tr_layer_bwd2_kernel: weights as MFMA B operands in registers or LDS,
-// 32-row tiles per wave, no pre-activation or conditioning buffer in HBM); the stacked skip 1x1, conv1d_1/2 and their
+// 32-row tiles per wave, no pre-activation or conditioning buffer in HBM; with the hparams upsampler the forward and the second
+// backward kernel are tr_layer_fwdc / tr_layer_bwd2c_kernel: 1 KB coalesced accesses through LDS patches, no branch around a
+// memory instruction); the stacked skip 1x1, conv1d_1/2 and their
 // gradients are plain library GEMMs (rocBLAS).  MoL / softmax-CE loss (forward + analytic backward), deterministic
 // reductions, the transposed-conv upsampler and the Adam/EMA update are hand-written HIP kernels.  Parameters and gradients
 // stay in the canonical checkpoint layout (TF variable order, kernels (K, N) row-major).
