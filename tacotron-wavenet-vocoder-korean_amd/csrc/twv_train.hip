@@ -1076,7 +1076,6 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read has returned: the region may be refilled
         TRPROF(1, 2);
-        if (tile + nwaves < ntiles) tr_bwd1_stage<FUSED>(a, tile + nwaves, lane, base);
         TRPROF(1, 3);
         float dF[16], dG[16], zc[16];
         float sf = 0.0f, sgs = 0.0f, sx = 0.0f;
@@ -1165,6 +1164,10 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
             }
         }
         TRPROF(1, 5);
+        // the next tile's stage, AFTER this tile's stores (dPRE, tile sums, PT): the s_waitcnt vmcnt(0) at the top of the next trip then waits
+        // for requests that are the youngest in the queue -- issued in front of the stores (right after the LDS reads, where the region becomes
+        // free) it also waited for the acknowledgement of every store behind them.  The 80 MFMAs below cover the flight (120 -> 115 us).
+        if (tile + nwaves < ntiles) tr_bwd1_stage<FUSED>(a, tile + nwaves, lane, base);
         // ---- weight gradients: A = [row rho][channel], B = dF / dG / dXn registers
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
