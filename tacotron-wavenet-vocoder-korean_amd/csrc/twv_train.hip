@@ -524,6 +524,13 @@ struct LayerFwdArgs {
 };
 constexpr int kLcSteps = 10;                                 // 80 / 8
 
+// the other half-wave's value (lane ^ 32) as ONE v_permlane32_swap_b32 -- __shfl_xor goes through the LDS crossbar (ds_bpermute) and a lone
+// wave waits out every one of them (tr_layer_bwd1_kernel: eleven per tile)
+__device__ __forceinline__ float tr_xor32(float v)
+{
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);   // sw[0]: lanes 0-31's values on both halves, sw[1]: lanes 32-63's
+    return __uint_as_float((threadIdx.x & 32) ? sw[0] : sw[1]);
+}
 __device__ __forceinline__ f32x4t tr_ld4(const float* p, bool ok) { f32x4t z = {0.f, 0.f, 0.f, 0.f}; return ok ? *reinterpret_cast<const f32x4t*>(p) : z; }
 
 struct LayerA { f32x4t x0[4], x1[4], u[kLcSteps]; };
@@ -1108,7 +1115,7 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
         TRPROF(1, 4);
         // per-tile column sums (bias and gc gradients): halves combined, lanes 0..31 write
         {
-            const float of = __shfl_xor(sf, 32), og = __shfl_xor(sgs, 32), ox = __shfl_xor(sx, 32);
+            const float of = tr_xor32(sf), og = tr_xor32(sgs), ox = tr_xor32(sx);
             if (hh == 0) { a.tsum[(long long)tile * 96 + n] = sf + of; a.tsum[(long long)tile * 96 + 32 + n] = sgs + og; a.tsum[(long long)tile * 96 + 64 + n] = sx + ox; }
         }
         if (FUSED) {
@@ -1152,13 +1159,13 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
             float* pt = a.PT + (long long)tile * 512 + n;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float f0_ = raf[j] + __shfl_xor(raf[j], 32), g0_ = rag[j] + __shfl_xor(rag[j], 32);
+                const float f0_ = raf[j] + tr_xor32(raf[j]), g0_ = rag[j] + tr_xor32(rag[j]);
                 if (hh == 0) { pt[j * 64] = f0_; pt[j * 64 + 32] = g0_; }
             }
             if (spans) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float f1_ = rbf[j] + __shfl_xor(rbf[j], 32), g1_ = rbg[j] + __shfl_xor(rbg[j], 32);
+                    const float f1_ = rbf[j] + tr_xor32(rbf[j]), g1_ = rbg[j] + tr_xor32(rbg[j]);
                     if (hh == 0) { pt[256 + j * 64] = f1_; pt[256 + j * 64 + 32] = g1_; }
                 }
             }
