@@ -51,12 +51,18 @@ def generation_hash():
     return _hash_files([os.path.join(CSRC, f) for f in GENERATION_SOURCES])
 
 
+def build_stamp():
+    """(extra hipcc flags, stamp) of the build the environment asks for.  TWV_EXTRA_HIPCC_FLAGS (a tuning aid, e.g. -DTWV_TRPROF) is part of
+    the stamp, so a variant build never passes for the plain one and the next plain import rebuilds."""
+    extra = os.environ.get("TWV_EXTRA_HIPCC_FLAGS", "").split()
+    return extra, source_hash() + ("+" + " ".join(extra) if extra else "")
+
+
 def build(force=False, verbose=False):
     """hipcc cross-compiles the gfx950 library in-tree (works without a GPU).  The source hash is compiled into the binary and kept
     in a sidecar file: a library whose stamp differs from the tree's hash is rebuilt (file times say nothing after a checkout)."""
     want = source_hash()
-    extra = os.environ.get("TWV_EXTRA_HIPCC_FLAGS", "").split()      # tuning aid (e.g. -DTWV_TRPROF): part of the stamp, so a variant
-    stamp_want = want + ("+" + " ".join(extra) if extra else "")       # build never passes for the plain one
+    extra, stamp_want = build_stamp()
     stamp = LIB_PATH + ".srchash"
     if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == stamp_want:
         return LIB_PATH

@@ -654,3 +654,14 @@ def test_bench_reports_counter_traffic_only_for_the_measured_sources(monkeypatch
     assert bench.traffic_per_step("wn_xcd_generate_kernel", "B8_NL50") is None
     monkeypatch.setattr(twvk_amd._lib, "generation_hash", lambda: "0" * 16)
     assert bench.traffic_per_step("wn_xcd_generate_kernel", "B8_NL30") is None
+
+
+def test_variant_builds_never_pass_for_the_plain_library(monkeypatch):
+    """TWV_EXTRA_HIPCC_FLAGS (tuning builds) goes into the library's build stamp: a plain import after a variant build must rebuild"""
+    from twvk_amd import _lib
+    monkeypatch.delenv("TWV_EXTRA_HIPCC_FLAGS", raising=False)
+    extra, plain = _lib.build_stamp()
+    assert extra == [] and plain == _lib.source_hash()
+    monkeypatch.setenv("TWV_EXTRA_HIPCC_FLAGS", "-DTWV_TRPROF -DX=1")
+    extra, variant = _lib.build_stamp()
+    assert extra == ["-DTWV_TRPROF", "-DX=1"] and variant != plain and variant.startswith(plain + "+")
