@@ -258,7 +258,7 @@ def main():
             mac_fwd = len(dil) * (rows_all * (2 * 32 * 64 + 32 * 32) + rows_ow * 32 * 512) + rows_ow * (512 * 512 + 512 * 30)
             flop_step = 2.0 * 3.0 * mac_fwd
             train_res = {"metric": "WaveNet training audio samples/sec (teacher-forced step: MoL loss, backward, all-reduce, Adam, EMA)",
-                         "roofline": {"bound": "mfma", "kernel": "whole step: tr_layer_{fwd,bwd1,bwd2}_kernel + the wide f32 GEMMs (rocBLAS MI16x16x4)",
+                         "roofline": {"bound": "mfma", "kernel": "whole step: tr_layer_{fwdc,bwd1,bwd2c}_kernel + the wide f32 GEMMs (rocBLAS MI16x16x4)",
                                       "achieved": flop_step / qdt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flop_step / qdt / 1e12 / 157.3,
                                       "flop_per_step": flop_step, "traffic": None,
                                       "note": "executed f32 matrix-core FLOPs only (2 x 3 x forward MACs of the dense contractions; per-kernel durations and "
