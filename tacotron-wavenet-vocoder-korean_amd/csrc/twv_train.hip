@@ -742,7 +742,7 @@ extern "C" int twv_debug_trprof(unsigned long long* out) { return hipMemcpyFromS
 // loop body has NO branch around a memory instruction.  That matters more than the branch itself: s_waitcnt vmcnt counts in issue
 // order, and behind a conditional load or store the compiler has to assume it was not issued -- its wait for an older load then
 // covers the younger ones too (the first version waited for the rows it had just prefetched, and for every store of the last tile).
-struct FwdcBufs { rsrc_t x, th, sg, xn, zc, q, gc; };
+struct FwdcBufs { rsrc_t x, th, sg, xn, q, gc; };
 __device__ __forceinline__ f32x4t tr_bld4(rsrc_t r, unsigned off)
 {
     const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
@@ -825,7 +825,6 @@ __global__ void __launch_bounds__(kFwdcWaves * 64) tr_layer_fwdc_kernel(LayerFwd
         bf.th = __builtin_amdgcn_make_buffer_rsrc(a.TH, 0, act, 0x00020000);
         bf.sg = __builtin_amdgcn_make_buffer_rsrc(a.SG, 0, act, 0x00020000);
         bf.xn = __builtin_amdgcn_make_buffer_rsrc(a.XN, 0, act, 0x00020000);
-        bf.zc = __builtin_amdgcn_make_buffer_rsrc(a.ZC, 0, (int)((((long long)a.B * a.ow - 1) * a.ldz + 32) * 4), 0x00020000);
         bf.q = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q), 0, (int)((long long)a.B * a.F * 4 * 64 * 4), 0x00020000);
         bf.gc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gcp ? a.gcp : a.X), 0, a.gcp ? a.B * 64 * 4 : 0, 0x00020000);
     }
@@ -920,7 +919,12 @@ __global__ void __launch_bounds__(kFwdcWaves * 64) tr_layer_fwdc_kernel(LayerFwd
         for (int r = 0; r < 16; ++r) pa[((r & 3) + 8 * (r >> 2) + 4 * hh) * 36 + n] = cf[r];      // z: the patch TH has just left
         const float* pz = pa;
         // skip input slice: rows t >= cut (model.py:94-96 keeps the last ow); other tiles' stores are dropped by the descriptor
-        tr_patch_store(pz, bf.zc, (long long)b * a.ow + (t0 - cut), a.ldz, cut - t0, nrows, lane);
+        {
+            // (the stacked skip input is the one array that outgrows a 32-bit byte offset -- B * ow * 960 * 4 bytes, 2 GiB from batch 117 at 7800
+            // samples: its descriptor is re-based to the tile, 32 rows of ldz floats; in front of the cut every lane is out of range)
+            const rsrc_t rzc = __builtin_amdgcn_make_buffer_rsrc(a.ZC + ((long long)b * a.ow + (t0 - cut)) * a.ldz, 0, (int)((31LL * a.ldz + 32) * 4), 0x00020000);
+            tr_patch_store(pz, rzc, 0, a.ldz, cut - t0, nrows, lane);
+        }
         TRPROF(0, 6);
         // ---- dense 1x1 + residual: z as A operand (row layout) back from the patch
         f32x16 cd = zero;
@@ -1665,6 +1669,8 @@ extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch,
     if (dims && dims->gc_channels > 0 && dims->gc_cardinality < 1)
         return twv_fail(TWV_E_UNSUPPORTED, "training needs global_condition_cardinality (the gc_embedding table is a trained variable; model.py:191-195)");
     if (!dims || !out || batch < 1) return twv_fail(TWV_E_INVALID, "bad argument");
+    if ((long long)batch * n_samples * 64 * 4 >= (1LL << 31))
+        return twv_fail(TWV_E_UNSUPPORTED, "batch x samples too large: the fused layer kernels address a layer's activations with 32-bit byte offsets (batch * samples < 8.3 M)");
     const twv_wavenet_dims& d = *dims;
     if (d.residual_channels != 32 || d.dilation_channels != 32) return twv_fail(TWV_E_UNSUPPORTED, "residual/dilation channels must be 32");
     if (d.scalar_input && (d.out_channels % 3 || d.out_channels > 96)) return twv_fail(TWV_E_UNSUPPORTED, "out_channels must be 3*nr_mix <= 96");
