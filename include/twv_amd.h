@@ -146,8 +146,15 @@ int twv_mu_law_expand(const float* y, int64_t n, int quantization_channels, floa
  * wav (rows, n) float, out (rows, n) int16, scratch: rows*64 floats. */
 int twv_wav_to_int16(const float* wav, int rows, int64_t n, int16_t* out, float* scratch, void* stream);
 
+/* generate.py:219-231 on rows of logits in device memory: model.py:243 float64 softmax -> float32, the temperature rescale
+ * (np.log(p) / T, minus its log-sum-exp, np.exp) and legacy np.random.choice (float64 cumsum / last / searchsorted 'right')
+ * with the uniform draw injected.  logits (rows, Q) float, uniforms (rows) double in [0,1), out (rows) int32 class ids,
+ * proba (rows, Q) float = generate.py:222's scaled_prediction, or NULL.  The generation kernels draw with the same code. */
+int twv_sample_categorical(const float* logits, int64_t rows, int quantization_channels, double temperature, const double* uniforms,
+                           int32_t* out, float* proba, void* stream);
+
 /* elementary functions of the arithmetic contract, evaluated on the device (parity tests pin them bit for bit) */
-int twv_eval_elementwise(int fn /*0 tanh,1 sigmoid,2 exp,3 log,4 log1p,5 log1p(exp(x)),6 the same as the one-hot sampler's straight line (x <= 0)*/, const float* x, int64_t n, float* out, void* stream);
+int twv_eval_elementwise(int fn /*0 tanh,1 sigmoid,2 exp,3 log,4 log1p*/, const float* x, int64_t n, float* out, void* stream);
 int twv_eval_elementwise64(int fn /*0 exp,1 log*/, const double* x, int64_t n, double* out, void* stream);
 
 /* ======================================= Tacotron text -> mel inference =======================================

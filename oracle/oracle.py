@@ -84,6 +84,9 @@ def lib():
         L.twvo_generate_mol.argtypes = [P, fp, C.c_void_p, fp, ip, fp, fp, C.c_int, C.c_int, fp]
         L.twvo_sample_categorical.restype = C.c_int
         L.twvo_sample_categorical.argtypes = [fp, C.c_int, C.c_double, C.c_double, fp]
+        L.twvo_sample_categorical_sequential.restype = C.c_int
+        L.twvo_sample_categorical_sequential.argtypes = [fp, C.c_int, C.c_double, C.c_double, fp]
+        L.twvo_scan64.argtypes = [dp]; L.twvo_scan64.restype = None
         L.twvo_generate_mulaw.argtypes = [P, fp, C.c_void_p, fp, ip, ip, dp, C.c_double, C.c_int, C.c_int, ip]
         L.twvo_forward_full.argtypes = [P, fp, C.c_int, C.c_int, fp, ip, fp, C.c_int, ip, fp]
     return _lib
@@ -257,11 +260,20 @@ def generate_mol(d, blob, st, U, gc_ids, seed, u):
     return out
 
 
-def sample_categorical(logits, temperature, u):
+def sample_categorical(logits, temperature, u, sequential=False):
+    """sequential=True: round 3's all-sequential form (kept for the comparison against numpy only)"""
     logits = _c32(logits)
     p = np.empty(logits.size, np.float32)
-    k = lib().twvo_sample_categorical(_f(logits), logits.size, float(temperature), float(u), _f(p))
+    fn = lib().twvo_sample_categorical_sequential if sequential else lib().twvo_sample_categorical
+    k = fn(_f(logits), logits.size, float(temperature), float(u), _f(p))
     return int(k), p
+
+
+def scan64(v):
+    v = np.ascontiguousarray(v, dtype=np.float64).copy()
+    assert v.size == 64
+    lib().twvo_scan64(_d(v))
+    return v
 
 
 def generate_mulaw(d, blob, st, U, gc_ids, seed, u, temperature=1.0):

@@ -94,6 +94,9 @@ void twvo_generate_mulaw(const twvo_dims* d, const float* blob, twvo_state* s, c
                          const int32_t* seed, const double* u, double temperature, int B, int T, int32_t* out);
 /* the categorical sampler alone: logits (Q) -> class id */
 int  twvo_sample_categorical(const float* logits, int Q, double temperature, double u, float* proba_out);
+/* round 3's all-sequential form of the same sampler (comparison test only) and the scan primitive of the current one */
+int  twvo_sample_categorical_sequential(const float* logits, int Q, double temperature, double u, float* proba_out);
+void twvo_scan64(double v[64]);
 
 /* train-mode (full convolution) forward, model.py:112-167 with train_mode=True.
  * input (B,Tin) scalar or int32 ids, lc_up (B,Tlc,L) or NULL (sliced from the front, model.py:79-80), raw_out (B,Tin-RF+1,O). */

@@ -352,8 +352,12 @@ static float logaddexpf_np(float x, float y)
     return tmp; /* NaN */
 }
 
-/* model.py:243 float64 softmax -> float32; generate.py:219-222 temperature rescale; generate.py:231 np.random.choice */
-int twvo_sample_categorical(const float* logits, int Q, double temperature, double u, float* proba_out)
+/* ROUND 3's form of the categorical sampler, kept for tests/test_cpu.py::test_categorical_sampler_contract_against_numpy only:
+ * every reduction sequential in class order (float64 softmax sum, float32 np.logaddexp.reduce left to right, float64
+ * cumsum).  Measured against numpy itself (the one piece of the reference path that runs in this image) the literal
+ * left-to-right reduce pins nothing: numpy's libm/SIMD exp/log already differ from the contract's by a few 1e-6 in the
+ * scaled probabilities, so any fixed reduction order with <= 1e-6 error is as faithful.  Not used by any kernel. */
+int twvo_sample_categorical_sequential(const float* logits, int Q, double temperature, double u, float* proba_out)
 {
     double* e = (double*)malloc(sizeof(double) * Q);
     float* lp = (float*)malloc(sizeof(float) * Q);
@@ -363,21 +367,94 @@ int twvo_sample_categorical(const float* logits, int Q, double temperature, doub
     for (int i = 0; i < Q; ++i) { e[i] = twvo_exp64((double)logits[i] - m); sum += e[i]; }
     const float temp32 = (float)temperature;
     for (int i = 0; i < Q; ++i) {
-        const float p32 = (float)(e[i] / sum);           /* tf.cast(softmax(float64), float32) */
-        lp[i] = twvo_log(p32) / temp32;                  /* generate.py:220 np.log(prediction) / temperature (float32) */
+        const float p32 = (float)(e[i] / sum);
+        lp[i] = twvo_log(p32) / temp32;
     }
-    float lse = lp[0];                                   /* generate.py:221 np.logaddexp.reduce (left to right) */
+    float lse = lp[0];
     for (int i = 1; i < Q; ++i) lse = logaddexpf_np(lse, lp[i]);
     double c = 0.0;
     for (int i = 0; i < Q; ++i) {
-        const float sp = twvo_exp(lp[i] - lse);          /* generate.py:221-222 */
+        const float sp = twvo_exp(lp[i] - lse);
         if (proba_out) proba_out[i] = sp;
-        c += (double)sp;                                 /* legacy choice: cdf = p.cumsum() in float64 */
+        c += (double)sp;
         e[i] = c;
     }
     const double last = e[Q - 1];
     int idx = Q - 1;
-    for (int i = 0; i < Q; ++i) if (e[i] / last > u) { idx = i; break; } /* cdf /= cdf[-1]; searchsorted(u, 'right') */
+    for (int i = 0; i < Q; ++i) if (e[i] / last > u) { idx = i; break; }
+    free(e); free(lp);
+    return idx;
+}
+
+/* AC-5: the ONE reduction primitive of the categorical sampler -- an inclusive prefix sum of 64
+ * doubles in the order a 64-lane wave produces with four row_shr steps inside each row of 16 lanes, then the two
+ * row-broadcast steps (lane 15 -> next row, lane 31 -> upper half).  v[63] is the total.  (Addition is commutative, so
+ * only the TREE matters, not which operand a lane holds.) */
+void twvo_scan64(double v[64])
+{
+    double t[64];
+    for (int off = 1; off <= 8; off <<= 1) {
+        memcpy(t, v, sizeof(t));
+        for (int l = 0; l < 64; ++l) if ((l & 15) >= off) v[l] = t[l] + t[l - off];
+    }
+    const double r0 = v[15], r2 = v[47];
+    for (int l = 16; l < 32; ++l) v[l] = v[l] + r0;
+    for (int l = 48; l < 64; ++l) v[l] = v[l] + r2;
+    const double h = v[31];
+    for (int l = 32; l < 64; ++l) v[l] = v[l] + h;
+}
+
+/* model.py:243 float64 softmax -> float32; generate.py:219-222 temperature rescale; generate.py:231 np.random.choice
+ * (legacy RandomState.choice: cdf = p.cumsum() in float64, cdf /= cdf[-1], searchsorted(u, 'right')).
+ *
+ * AC-5: class i sits in lane (i mod 64), block (i / 64); classes >= Q count as probability zero.  Every sum over the
+ * classes is "per lane over the blocks in block order, then twvo_scan64 over the lanes":
+ *   e_i   = exp64(y_i - max y)                                   float64   (model.py:243)
+ *   p_i   = (float)(e_i / SUM e)                                 float64 division, one rounding to float32
+ *   lp_i  = log(p_i) / (float)temperature                        float32   (generate.py:220)
+ *   lse   = M + log((float) SUM (double)exp(lp_i - M)),  M = max lp   (generate.py:221 np.logaddexp.reduce: the same
+ *           quantity, log sum exp; numpy's left-to-right pairwise form is replaced, see above)
+ *   sp_i  = exp(lp_i - lse)                                      float32   (generate.py:221-222)
+ *   cdf_i = prefix sum of (double)sp in class order: block base (sum of the earlier blocks' totals, in block order)
+ *           + scan64 inside the block;  drawn class = first i with cdf_i / cdf_last > u                                */
+int twvo_sample_categorical(const float* logits, int Q, double temperature, double u, float* proba_out)
+{
+    const int NB = (Q + 63) / 64;
+    double* e = (double*)calloc((size_t)NB * 64, sizeof(double));
+    float* lp = (float*)calloc((size_t)NB * 64, sizeof(float));
+    double lane[64];
+    float m = logits[0];
+    for (int i = 1; i < Q; ++i) if (logits[i] > m) m = logits[i];
+    for (int i = 0; i < Q; ++i) e[i] = twvo_exp64((double)logits[i] - (double)m);
+    for (int l = 0; l < 64; ++l) { lane[l] = e[l]; for (int k = 1; k < NB; ++k) lane[l] = lane[l] + e[l + 64 * k]; }
+    twvo_scan64(lane);
+    const double sum = lane[63];
+    const float temp32 = (float)temperature;
+    float m2 = 0.0f;
+    for (int i = 0; i < Q; ++i) {
+        const float p32 = (float)(e[i] / sum);           /* tf.cast(softmax(float64), float32) */
+        lp[i] = twvo_log(p32) / temp32;                  /* generate.py:220 np.log(prediction) / temperature (float32) */
+        if (i == 0 || lp[i] > m2) m2 = lp[i];
+    }
+    for (int i = 0; i < NB * 64; ++i) e[i] = i < Q ? (double)twvo_exp(lp[i] - m2) : 0.0;
+    for (int l = 0; l < 64; ++l) { lane[l] = e[l]; for (int k = 1; k < NB; ++k) lane[l] = lane[l] + e[l + 64 * k]; }
+    twvo_scan64(lane);
+    const float lse = m2 + twvo_log((float)lane[63]);    /* generate.py:221 */
+    int idx = Q - 1, found = 0;
+    double base = 0.0, last = 0.0;
+    for (int k = 0; k < NB; ++k) {
+        for (int l = 0; l < 64; ++l) {
+            const int i = l + 64 * k;
+            const float sp = i < Q ? twvo_exp(lp[i] - lse) : 0.0f;   /* generate.py:221-222 */
+            if (proba_out && i < Q) proba_out[i] = sp;
+            lane[l] = (double)sp;
+        }
+        twvo_scan64(lane);
+        for (int l = 0; l < 64; ++l) e[l + 64 * k] = k == 0 ? lane[l] : base + lane[l];
+        base = e[63 + 64 * k];
+        last = base;
+    }
+    for (int i = 0; i < Q && !found; ++i) if (e[i] / last > u) { idx = i; found = 1; } /* cdf /= cdf[-1]; searchsorted(u, 'right') */
     free(e); free(lp);
     return idx;
 }

@@ -23,7 +23,7 @@ class Dims(C.Structure):
                 ("lc_channels", C.c_int32), ("n_upsample", C.c_int32), ("upsample_factor", C.c_int32 * 4)]
 
 
-GENERATION_SOURCES = ("twv_wavenet.hip", "twv_wavenet_xcd.hip", "twv_xcd.hpp", "twv_dpp.hpp", "twv_dev.hpp", "twv_math.hpp", "twv_layout.hpp")
+GENERATION_SOURCES = ("twv_wavenet.hip", "twv_wavenet_xcd.hip", "twv_xcd.hpp", "twv_dpp.hpp", "twv_dev.hpp", "twv_categorical.hpp", "twv_math.hpp", "twv_layout.hpp")
 
 
 def _hash_files(files):
@@ -143,6 +143,7 @@ def lib():
     L.twv_eval_elementwise.argtypes = [C.c_int, fp, C.c_int64, fp, vp]
     L.twv_eval_elementwise64.argtypes = [C.c_int, dp, C.c_int64, dp, vp]
     L.twv_selftest.argtypes = [fp, vp]
+    L.twv_sample_categorical.argtypes = [fp, C.c_int64, C.c_int, C.c_double, dp, ip, fp, vp]
     L.twv_debug_occupy.argtypes = [C.c_int, C.c_int, C.c_double, vp]
     L.twv_tacotron_create.argtypes = [C.POINTER(TacoDims), C.POINTER(C.c_void_p)]
     L.twv_tacotron_destroy.argtypes = [vp]; L.twv_tacotron_destroy.restype = None
@@ -174,7 +175,7 @@ EXPORTS = ["twv_last_error", "twv_version", "twv_wavenet_create", "twv_wavenet_d
            "twv_wavenet_cond_bytes", "twv_wavenet_pack", "twv_wavenet_reset_state", "twv_wavenet_upsample",
            "twv_wavenet_condition", "twv_wavenet_fused_conditioning", "twv_wavenet_cond_bytes_mel", "twv_wavenet_condition_mel", "twv_wavenet_generate", "twv_wavenet_prime", "twv_wavenet_status", "twv_wavenet_set_option", "twv_wavenet_set_profile_buffer",
            "twv_mu_law_encode", "twv_mu_law_decode", "twv_mu_law_expand", "twv_wav_to_int16", "twv_eval_elementwise",
-           "twv_eval_elementwise64", "twv_selftest", "twv_debug_occupy", "twv_tacotron_create", "twv_tacotron_destroy", "twv_tacotron_blob_floats",
+           "twv_eval_elementwise64", "twv_sample_categorical", "twv_selftest", "twv_debug_occupy", "twv_tacotron_create", "twv_tacotron_destroy", "twv_tacotron_blob_floats",
            "twv_tacotron_packed_bytes", "twv_tacotron_workspace_bytes", "twv_tacotron_pack", "twv_tacotron_infer", "twv_tacotron_set_profile_buffer", "twv_tacotron_set_option", "twv_tacotron_gemm_stats",
            "twv_wavenet_train_create", "twv_wavenet_train_destroy", "twv_wavenet_train_param_floats", "twv_wavenet_train_workspace_bytes",
            "twv_wavenet_train_output_width", "twv_wavenet_train_loss_grad", "twv_adam_ema_step", "twv_wavenet_train_l2",

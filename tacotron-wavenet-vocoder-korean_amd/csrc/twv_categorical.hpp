@@ -1,0 +1,135 @@
+// twv_categorical.hpp -- the one-hot model's sampler on ONE wave (arithmetic contract AC-5).
+//
+// Replaces wavenet/model.py:243 (float64 softmax -> float32) + generate.py:219-231 (temperature rescale through
+// np.logaddexp.reduce, np.random.choice = float64 cumsum / last / searchsorted 'right').  Class i sits in lane (i mod 64),
+// block (i / 64); every sum over the classes is "per lane over the blocks in block order, then scan64 over the lanes" -- the
+// same tree oracle/wavenet.c:twvo_sample_categorical walks, so the drawn class is bit-identical.  Nothing in here is sequential
+// over the classes: round 3's literal left-to-right logaddexp (255 dependent exp + log1p evaluations, 32 us per draw) pinned
+// nothing -- numpy's own exp/log differ from the contract's by more than the order of the reduce does
+// (tests/test_cpu.py::test_categorical_sampler_contract_against_numpy).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "twv_math.hpp"
+
+namespace twv {
+
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, BOUND);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, BOUND);
+    return __hiloint2double(hi, lo);
+}
+// inclusive prefix sum over the 64 lanes: row_shr 1, 2, 4, 8 inside each row of 16 lanes, then lane 15 -> the next row
+// (rows 1 and 3), then lane 31 -> the upper half.  Lanes without a source add +0 (the operands are never negative zero).
+__device__ __forceinline__ double scan64_wave(double v)
+{
+    v = v + dpp_f64<0x111, 0xf, true>(v);      // row_shr:1
+    v = v + dpp_f64<0x112, 0xf, true>(v);      // row_shr:2
+    v = v + dpp_f64<0x114, 0xf, true>(v);      // row_shr:4
+    v = v + dpp_f64<0x118, 0xf, true>(v);      // row_shr:8
+    v = v + dpp_f64<0x142, 0xa, false>(v);     // row_bcast:15 -> rows 1, 3
+    v = v + dpp_f64<0x143, 0xc, false>(v);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// maximum over the wave, in every lane (max is exact: the order does not matter)
+__device__ __forceinline__ float wave_max_f32(float x)
+{
+#define TWV_ROR_(c_) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), (c_), 0xf, 0xf, false))
+    x = __builtin_fmaxf(x, TWV_ROR_(0x128));   // row_ror:8
+    x = __builtin_fmaxf(x, TWV_ROR_(0x124));   // row_ror:4
+    x = __builtin_fmaxf(x, TWV_ROR_(0x122));   // row_ror:2
+    x = __builtin_fmaxf(x, TWV_ROR_(0x121));   // row_ror:1
+#undef TWV_ROR_
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+    return __builtin_fmaxf(__builtin_fmaxf(r0, r1), __builtin_fmaxf(r2, r3));
+}
+
+// y[k] = logit of class lane + 64 k (k < NB; classes >= Q are ignored).  Returns the drawn class (wave-uniform);
+// sp_out (optional, NB floats per lane) receives the scaled probabilities of generate.py:222.
+template <int NB>
+__device__ __forceinline__ int categorical_sample(const float (&y)[NB], const int Q, const int lane, const float temp32, const double u,
+                                                  float* sp_out = nullptr)
+{
+    const float ninf = __uint_as_float(0xff800000u);
+    // ---- model.py:243 softmax in float64
+    float mx = ninf;
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+        if (64 * k < Q) { const float v = (lane + 64 * k < Q) ? y[k] : ninf; mx = v > mx ? v : mx; }
+    mx = wave_max_f32(mx);
+    const double m64 = (double)mx;
+    double e[NB];
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        e[k] = 0.0;
+        if (64 * k < Q) {
+            e[k] = (lane + 64 * k < Q) ? exp64_e((double)y[k] - m64) : 0.0;
+            s = (k == 0) ? e[k] : s + e[k];
+        }
+    }
+    const double sum = readlane_f64(scan64_wave(s), 63);
+    // ---- generate.py:220 np.log(prediction) / temperature (float32)
+    float lp[NB];
+    float m2 = ninf;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        lp[k] = ninf;
+        if (64 * k < Q) {
+            const float p32 = (float)(e[k] / sum);                 // tf.cast(softmax(float64), float32)
+            const float l = div_(log_e(p32), temp32);
+            const bool in = lane + 64 * k < Q;
+            lp[k] = l;
+            m2 = (in && l > m2) ? l : m2;
+        }
+    }
+    m2 = wave_max_f32(m2);
+    // ---- generate.py:221 log sum exp, max-shifted, summed in float64 in the contract's tree
+    double s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        if (64 * k < Q) {
+            const double x = (lane + 64 * k < Q) ? (double)exp_e(lp[k] - m2) : 0.0;
+            s2 = (k == 0) ? x : s2 + x;
+        }
+    }
+    const float lse = m2 + log_e((float)readlane_f64(scan64_wave(s2), 63));
+    // ---- generate.py:221-222 scaled probabilities; RandomState.choice: float64 cdf in class order
+    double c[NB];
+    double base = 0.0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        c[k] = 0.0;
+        if (64 * k < Q) {
+            const float sp = (lane + 64 * k < Q) ? exp_e(lp[k] - lse) : 0.0f;
+            if (sp_out) sp_out[k] = sp;
+            const double sc = scan64_wave((double)sp);
+            c[k] = (k == 0) ? sc : base + sc;
+            base = readlane_f64(c[k], 63);
+        }
+    }
+    const double last = base;
+    // ---- cdf /= cdf[-1]; searchsorted(u, side='right'): the first class whose normalised cdf exceeds u
+    int idx = Q - 1;
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        if (64 * k < Q) {
+            const bool hit = (lane + 64 * k < Q) && (c[k] / last > u);
+            const unsigned long long mask = __ballot(hit);
+            if (!found && mask != 0ull) { idx = 64 * k + (int)__ffsll((long long)mask) - 1; found = true; }
+        }
+    }
+    return idx;
+}
+
+}  // namespace twv

@@ -12,22 +12,6 @@ namespace twv {
 
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ float div_(float a, float b) { return __fdiv_rn(a, b); }
-// a / b correctly rounded for normal a, b whose exponents are moderate (|a| >= 2^-102, no denormal reciprocal or quotient): the
-// compiler's IEEE sequence for __fdiv_rn WITHOUT its v_div_scale_f32 x2 (no operand is rescaled in that range), with a plain fma in place
-// of v_div_fmas_f32 (no scale to undo) and without v_div_fixup_f32 (no zero / inf / NaN / denormal case to patch) -- the same rcp and
-// the same six fmas, so the same bits; five instructions fewer.  Only for call sites that prove the range (log1p_exp_nonpos_e below:
-// pinned over every float argument by tests/test_wavenet_gpu.py::test_logaddexp_step_form_over_all_floats).
-__device__ __forceinline__ float div_moderate_(float a, float b)
-{
-    const float r0 = __builtin_amdgcn_rcpf(b);
-    const float e0 = fma_(-b, r0, 1.0f);
-    const float r1 = fma_(e0, r0, r0);
-    const float q0 = a * r1;
-    const float e1 = fma_(-b, q0, a);
-    const float q1 = fma_(e1, r1, q0);
-    const float e2 = fma_(-b, q1, a);
-    return fma_(e2, r1, q1);
-}
 
 // ---- tanh / sigmoid: Eigen-3.3-style rationals (odd P / even Q) -------------------------------
 // Unified form used by the gated unit: the filter half-wave evaluates tanh, the gate half-wave the
@@ -118,11 +102,7 @@ __device__ __forceinline__ float tanh_e(float x) { return act_eval(act_coef(fals
 __device__ __forceinline__ float sigmoid_e(float x) { return act_eval(act_coef(true), x); }
 
 // ---- exp / log: Cephes single-precision forms as vectorised in Eigen 3.3 ---------------------------
-// the body after the clamp to [exp_lo, exp_hi].  SERIAL: for a lone dependent chain (the one-hot sampler's logaddexp reduce), where
-// result latency is what counts: keeps the compiler from pairing two independent scalar operations into one v_pk_* instruction (an
-// opaque register pass-through between them), whose result arrives later than a plain VALU result's; the arithmetic is the same.
-#define TWV_OPAQUE(v_) asm("" : "+v"(v_))
-template <bool SERIAL = false>
+// the body after the clamp to [exp_lo, exp_hi]
 __device__ __forceinline__ float exp_clamped_e(float x)
 {
     const float LOG2EF = 1.44269504088896341f;
@@ -131,7 +111,6 @@ __device__ __forceinline__ float exp_clamped_e(float x)
                 p4 = 1.6666665459E-1f, p5 = 5.0000001201E-1f;
     const float fx = __builtin_floorf(fma_(x, LOG2EF, 0.5f));
     float tmp = fx * C1, z0 = fx * C2;
-    if (SERIAL) TWV_OPAQUE(tmp);
     x = x - tmp;
     x = x - z0;
     const float z = x * x;
@@ -155,8 +134,7 @@ __device__ __forceinline__ float exp_e(float x0)
     return exp_clamped_e(x);
 }
 
-// the body for a positive, normal, finite argument (SERIAL: as for exp_clamped_e)
-template <bool SERIAL = false>
+// the body for a positive, normal, finite argument
 __device__ __forceinline__ float log_normal_e(float x)
 {
     const float SQRTHF = 0.707106781186547524f;
@@ -178,10 +156,8 @@ __device__ __forceinline__ float log_normal_e(float x)
     y = fma_(y, x3, y2);
     y = y * x3;
     y1 = e * q1;
-    if (SERIAL) TWV_OPAQUE(y1);
     const float tmp = x2 * 0.5f;
     y = y + y1;
-    if (SERIAL) TWV_OPAQUE(y);
     x = x - tmp;
     y2 = e * q2;
     x = x + y;
@@ -203,23 +179,6 @@ __device__ __forceinline__ float log1p_e(float x)
     if (u == 1.0f) return x;
     return log_e(u) * div_(x, u - 1.0f);
 }
-// log1p_e(exp_e(t)) for t <= 0, one straight line for the sequential np.logaddexp.reduce of the one-hot sampler (255 dependent
-// evaluations per drawn sample on a lone wave, where every branch costs a pipeline refill): the same operations in the same order on
-// every path a non-positive t can take -- exp_e's upper clamp and log_e's NaN / negative / zero / denormal exits are unreachable
-// because u = 1 + exp(t) lies in [1, 2].  NOT NaN-preserving (a NaN t comes back finite): the caller decides NaN separately.  Pinned
-// against log1p_e(exp_e(t)) over every float t <= 0 by tests/test_wavenet_gpu.py::test_logaddexp_step_form_over_all_floats.
-// (Threading the division's eight dependent instructions through the logarithm by hand instead of leaving them behind it: no gain,
-// 32.7 vs 32.1 us per 255 steps.)
-__device__ __forceinline__ float log1p_exp_nonpos_e(float t)
-{
-    const float exp_lo = -88.3762626647949f;
-    const float x = exp_clamped_e<true>(t > exp_lo ? t : exp_lo);
-    const float u = 1.0f + x;
-    const float l = log_normal_e<true>(u) * div_moderate_(x, u - 1.0f);   // u != 1: x > 2^-24 and u - 1 >= 2^-23, quotient in [1/2, 2];
-                                                                          // u == 1: 0 * NaN, discarded
-    return u == 1.0f ? x : l;
-}
-
 // ---- float64 (model.py:243 softmax in float64; np.random.choice's float64 cdf) ---------------------
 __device__ __forceinline__ double exp64_e(double x)
 {

@@ -28,6 +28,7 @@
 #include "twv_layout.hpp"
 #include "twv_math.hpp"
 #include "twv_dev.hpp"
+#include "twv_categorical.hpp"
 #include "twv_xcd.hpp"
 
 using namespace twv;
@@ -920,136 +921,30 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                 }
             }
             if (!SCALAR) {
-                // ---- one-hot output: model.py:243 float64 softmax -> float32, generate.py:219-222 temperature rescale with a
-                // left-to-right np.logaddexp.reduce, generate.py:231 legacy np.random.choice = searchsorted(cumsum(p)/last, u, 'right')
+                // ---- one-hot output: model.py:243 float64 softmax -> float32, generate.py:219-222 temperature rescale,
+                // generate.py:231 legacy np.random.choice = searchsorted(cumsum(p)/last, u, 'right'): twv_categorical.hpp (AC-5: one wave,
+                // nothing sequential over the classes; round 3's left-to-right logaddexp chain was 32 us of a 73 us step).
                 // logits were assembled (chunk partials in order + bias) by the workers into lds[o_cat .. o_cat+Q)
                 wait_seq(ctl + C_LGCNT, W * (t + 1), ctl + C_ABORT, 11);
                 ACQUIRE_WG();
                 if (wprof) wp[58] = __builtin_amdgcn_s_memtime();                  // one-hot sampler phases: logits complete
                 const int Q = L.Q;
-                const int o_lg = c.o_cat, o_lp = c.o_cat + L.Opad;                 // float logits / float log-probabilities
+                const int o_lg = c.o_cat;
                 float xv[16];                                                        // lane owns classes i = lane + 64k
-                float mx = -3.0e38f;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const int i = lane + 64 * k;
-                    xv[k] = (i < Q) ? lds[o_lg + i] : -3.0e38f;
-                    mx = xv[k] > mx ? xv[k] : mx;
+                    xv[k] = (i < Q) ? lds[o_lg + i] : 0.0f;
                 }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
                 if (INSTR && a.dbg != nullptr && g == 0 && t < a.dbg_steps) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k)
                         if (lane + 64 * k < Q)
                             a.dbg[((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)NL * 64 + lane + 64 * k] = xv[k];
                 }
-                // The three class-order loops below (float64 sum, float32 logaddexp reduce, float64 cumsum) are the reference's own
-                // sequential arithmetic and decide the drawn class to the last bit, so their ORDER is kept; what is not kept is one LDS
-                // round trip, one loop test and (in the logaddexp step) four branches per element on the dependent chain (the first
-                // version: 100 us of the one-hot model's 127 us step).  Each loop takes eight classes per trip: their operands are
-                // fetched from LDS as one batch (every lane reads the same words: the adds get wave-uniform VGPR operands; v_readlane
-                // broadcasts of register-held tables were measured 2.4x slower, scripts/ubench/seq_f64.hip) while the previous eight
-                // are being added; reads run up to 15 entries past Q -- inside the tables or the 32 words of slack behind them, never
-                // used -- and the logaddexp step is one straight line (log1p_exp_nonpos_e).
-                __attribute__((address_space(3))) double* e64 = (__attribute__((address_space(3))) double*)(lds + c.o_cat + 2 * L.Opad);
-                const double m64 = (double)mx;
-                double ev[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int i = lane + 64 * k;
-                    if (i < Q) { ev[k] = exp64_e((double)xv[k] - m64); e64[i] = ev[k]; }
-                }
-                if (wprof) wp[59] = __builtin_amdgcn_s_memtime();                  // max + float64 exps
-                double sum = 0.0;                                                    // sequential, class order
-                {
-                    double nx[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) nx[j] = e64[j];
-                    int i = 0;
-                    for (; i + 8 <= Q; i += 8) {
-                        double cur[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) { cur[j] = nx[j]; nx[j] = e64[i + 8 + j]; }
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) sum += cur[j];
-                    }
-                    for (; i < Q; ++i) sum += e64[i];
-                }
-                if (wprof) wp[60] = __builtin_amdgcn_s_memtime();                  // float64 sum
-                const float temp32 = a.temperature;
-                bool isnan_lp = false;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int i = lane + 64 * k;
-                    if (i < Q) {
-                        const float p32 = (float)(ev[k] / sum);                     // tf.cast(softmax(float64), float32)
-                        const float lp = div_(log_e(p32), temp32);                  // np.log(prediction) / temperature (float32)
-                        lds[o_lp + i] = lp;
-                        isnan_lp |= lp != lp;
-                    }
-                }
-                if (wprof) wp[61] = __builtin_amdgcn_s_memtime();                  // log-probabilities
-                float lse = lds[o_lp + 0];                                           // np.logaddexp.reduce, left to right
-                {
-                    // npy_logaddexpf(x, y): x == y -> x + ln 2;  x > y -> x + log1p(exp(y - x));  x <= y -> y + log1p(exp(x - y));
-                    // NaN (x - y) otherwise.  As one straight line: both live branches are max(x, y) + log1p(exp(-|x - y|)); the NaN
-                    // exit is sticky and any NaN operand takes it, so it is decided once for all classes (below) instead of per step.
-                    auto lae = [](float x, float y) __attribute__((always_inline)) {
-                        const float r = __builtin_fmaxf(x, y) + log1p_exp_nonpos_e(-__builtin_fabsf(x - y));
-                        return x == y ? x + 0.693147180559945309417232121458176568f : r;
-                    };
-                    float nx[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) nx[j] = lds[o_lp + 1 + j];
-                    int i = 1;
-                    for (; i + 8 <= Q; i += 8) {
-                        float cur[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) { cur[j] = nx[j]; nx[j] = lds[o_lp + i + 8 + j]; }   // past Q: inside the tables, unused
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) lse = lae(lse, cur[j]);
-                    }
-                    for (; i < Q; ++i) lse = lae(lse, lds[o_lp + i]);
-                    if (__ballot(isnan_lp) != 0ull) lse = __uint_as_float(0x7fc00000u);
-                }
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int i = lane + 64 * k;
-                    if (i < Q) e64[i] = (double)exp_e(lds[o_lp + i] - lse);        // scaled_prediction, then float64 for the cdf
-                }
-                if (wprof) wp[62] = __builtin_amdgcn_s_memtime();                  // logaddexp reduce + rescale
-                double cacc = 0.0;                                                   // cdf = p.cumsum() (float64, sequential)
-                {
-                    double nx[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) nx[j] = e64[j];
-                    int i = 0;
-                    for (; i + 8 <= Q; i += 8) {
-                        double cur[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) { cur[j] = nx[j]; nx[j] = e64[i + 8 + j]; }
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) { cacc += cur[j]; cur[j] = cacc; }
-                        if (lane == 0) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) e64[i + j] = cur[j];
-                        }
-                    }
-                    for (; i < Q; ++i) { cacc += e64[i]; if (lane == 0) e64[i] = cacc; }
-                }
-                if (wprof) wp[63] = __builtin_amdgcn_s_memtime();                  // float64 cumsum
-                const double last = cacc;
                 const double uu = reinterpret_cast<const double*>(a.uniforms)[(long long)b * T + t];
-                int idx = Q - 1;
-                bool found = false;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int i = lane + 64 * k;
-                    const bool hit = (i < Q) && (e64[i] / last > uu);                 // cdf /= cdf[-1]; searchsorted(u, 'right')
-                    const unsigned long long mask = __ballot(hit);
-                    if (!found && mask != 0ull) { idx = 64 * k + (int)__ffsll((long long)mask) - 1; found = true; }
-                }
+                const int idx = categorical_sample<16>(xv, Q, lane, a.temperature, uu);
+                if (wprof) wp[63] = __builtin_amdgcn_s_memtime();                  // drawn
                 if (lane == 0) {
                     if (g == 0) reinterpret_cast<int*>(a.out)[(long long)b * T + t] = idx;
                     LDSI(ctl + C_SAMPLE) = idx;
@@ -1342,9 +1237,7 @@ __global__ void wn_eval_kernel(int fn, const float* x, long long n, float* out)
             case 1: r = sigmoid_e(v); break;
             case 2: r = exp_e(v); break;
             case 3: r = log_e(v); break;
-            case 4: r = log1p_e(v); break;
-            case 5: r = log1p_e(exp_e(v)); break;
-            default: r = log1p_exp_nonpos_e(v); break;
+            default: r = log1p_e(v); break;
         }
         out[i] = r;
     }
@@ -1949,6 +1842,36 @@ extern "C" int twv_wav_to_int16(const float* wav, int rows, int64_t n, int16_t* 
     const int nchunk = 64;
     hipLaunchKernelGGL(wn_wav_peak_kernel, dim3(nchunk, rows), dim3(256), 0, (hipStream_t)stream, wav, (long long)n, nchunk, scratch);
     hipLaunchKernelGGL(wn_wav_int16_kernel, dim3(grid_for(n, 256), rows), dim3(256), 0, (hipStream_t)stream, wav, (long long)n, nchunk, scratch, out);
+    HIPCHK(hipGetLastError());
+    return TWV_OK;
+}
+// generate.py:219-231 for rows of logits that are already in HBM: one wave per row (twv_categorical.hpp, AC-5)
+__global__ void __launch_bounds__(64) wn_categorical_rows_kernel(const float* logits, int Q, long long rows, float temperature, const double* u,
+                                                                  int32_t* out, float* proba)
+{
+    const int lane = threadIdx.x;
+    for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+        float y[16], sp[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) y[k] = (lane + 64 * k < Q) ? logits[r * Q + lane + 64 * k] : 0.0f;
+        const int idx = categorical_sample<16>(y, Q, lane, temperature, u[r], sp);
+        if (lane == 0) out[r] = idx;
+        if (proba != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (lane + 64 * k < Q) proba[r * Q + lane + 64 * k] = sp[k];
+        }
+    }
+}
+extern "C" int twv_sample_categorical(const float* logits, int64_t rows, int Q, double temperature, const double* uniforms, int32_t* out,
+                                      float* proba, void* stream)
+{
+    if (!logits || !uniforms || !out || rows < 0 || Q < 1 || Q > 1024) return fail(TWV_E_INVALID, "bad argument (1 <= quantization_channels <= 1024)");
+    if (rows) {
+        const int grid = (int)(rows < 4096 ? rows : 4096);
+        hipLaunchKernelGGL(wn_categorical_rows_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, logits, Q, (long long)rows, (float)temperature,
+                           uniforms, out, proba);
+    }
     HIPCHK(hipGetLastError());
     return TWV_OK;
 }

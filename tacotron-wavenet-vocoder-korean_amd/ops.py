@@ -37,6 +37,22 @@ def mu_law_decode(output, quantization_channels, quantization=True, device="cuda
     return out
 
 
+def sample_categorical(logits, temperature, uniforms, want_proba=False, device="cuda:0"):
+    """generate.py:219-231 (+ model.py:243's float64 softmax) on rows of logits: (rows, Q) float32 logits, (rows,) float64
+    uniforms in [0,1) -> (rows,) int32 class ids [, (rows, Q) scaled probabilities].  The draw np.random.choice makes from its
+    RandomState is an INPUT here, as in the generation kernels."""
+    y = torch.as_tensor(logits, dtype=torch.float32, device=device).contiguous()
+    assert y.dim() == 2
+    u = torch.as_tensor(uniforms, dtype=torch.float64, device=device).contiguous()
+    assert u.numel() == y.shape[0]
+    with torch.cuda.device(y.device):
+        out = torch.empty(y.shape[0], dtype=torch.int32, device=y.device)
+        proba = torch.empty_like(y) if want_proba else None
+        _lib.check(_lib.lib().twv_sample_categorical(_ptr(y), y.shape[0], y.shape[1], float(temperature), _ptr(u), _ptr(out),
+                                                     _ptr(proba) if want_proba else None, _stream()))
+    return (out, proba) if want_proba else out
+
+
 def eval_elementwise(name, x, device="cuda:0"):
     """contract functions evaluated on the device (parity tests)."""
     L = _lib.lib()
@@ -47,7 +63,7 @@ def eval_elementwise(name, x, device="cuda:0"):
             out = torch.empty_like(t)
             _lib.check(L.twv_eval_elementwise64(fn, _ptr(t), t.numel(), _ptr(out), _stream()))
         return out
-    fn = {"tanh": 0, "sigmoid": 1, "exp": 2, "log": 3, "log1p": 4, "log1p_exp": 5, "log1p_exp_nonpos": 6}[name]
+    fn = {"tanh": 0, "sigmoid": 1, "exp": 2, "log": 3, "log1p": 4}[name]
     t = torch.as_tensor(x, dtype=torch.float32, device=device).contiguous()
     with torch.cuda.device(t.device):
         out = torch.empty_like(t)

@@ -179,6 +179,80 @@ def test_categorical_sampler_matches_numpy_legacy_choice(oracle):
     assert agree >= 298        # the two may differ only when u falls within float32 noise of a cdf boundary
 
 
+def test_scan64_is_a_prefix_sum_in_the_documented_tree_order(oracle):
+    """AC-5's one reduction primitive: exact prefix sums on integers, and the documented row_shr / row_bcast tree on floats"""
+    v = np.arange(1, 65, dtype=np.float64)
+    assert np.array_equal(oracle.scan64(v), np.cumsum(v))
+    rng = np.random.RandomState(3)
+    v = rng.uniform(0, 1, 64) * 10.0 ** rng.randint(-12, 3, 64)
+    w = v.copy()
+    for off in (1, 2, 4, 8):
+        t = w.copy()
+        for l in range(64):
+            if (l & 15) >= off:
+                w[l] = t[l] + t[l - off]
+    w[16:32] += w[15]; w[48:64] += w[47]
+    w[32:64] += w[31]
+    got = oracle.scan64(v)
+    assert np.array_equal(got, w)
+    assert np.allclose(got, np.cumsum(v), rtol=1e-14)
+
+
+def test_categorical_sampler_contract_against_numpy(oracle):
+    """VERDICT r03 next-1(i).  generate.py:219-231 is pure numpy -- the one piece of the reference path that RUNS in this image --
+    so the sampler contract (AC-5) is founded on it: the lines are executed literally (float32 `np.log(p) / T`, left-to-right
+    float32 `np.logaddexp.reduce`, `np.exp`, then legacy `RandomState.choice` = float64 cumsum / last / searchsorted 'right')
+    over 100 000 rows per temperature, and both forms of the oracle's sampler are held against it:
+      * round 3's all-sequential form (`sequential=True`), which reproduced the ORDER of numpy's reduce with the contract's
+        exp/log -- its scaled probabilities still differ from numpy's by a few 1e-6 (libm/SIMD vs Cephes), so the order pinned nothing;
+      * the current form (max-shifted log-sum-exp, every sum in the lane-then-scan64 tree), which the kernels implement.
+    The current form must agree with numpy on the drawn class at least as often as the sequential one."""
+    Q, N = 256, 100_000
+    rng = np.random.RandomState(11)
+    lib = oracle.lib()
+    import ctypes as C
+    fp = C.POINTER(C.c_float)
+    report = {}
+    for temp in (1.0, 0.8, 1.3):
+        logits = (rng.randn(N, Q) * rng.uniform(0.5, 4.0, (N, 1))).astype(np.float32)
+        x = logits.astype(np.float64)
+        p = np.exp(x - x.max(axis=1, keepdims=True)); p = (p / p.sum(axis=1, keepdims=True)).astype(np.float32)   # model.py:243
+        with np.errstate(divide="ignore"):
+            sp = np.log(p) / temp                                                      # generate.py:220
+            sp = sp - np.logaddexp.reduce(sp, axis=-1, keepdims=True)                  # generate.py:221
+            sp = np.exp(sp)                                                            # generate.py:222
+        assert sp.dtype == np.float32
+        if temp == 1.0:
+            np.testing.assert_allclose(p, sp, atol=1e-5)                               # generate.py:227-228
+        u = rng.random_sample(N)
+        cdf = sp.astype(np.float64).cumsum(axis=1)                                     # RandomState.choice (legacy)
+        cdf /= cdf[:, -1:]
+        want = (cdf > u[:, None]).argmax(axis=1)                                       # searchsorted(u, side='right')
+        # spot-check that formula against numpy's own choice() on a few rows
+        for i in range(0, N, N // 50):
+            rs = np.random.RandomState(i); ui = np.random.RandomState(i).random_sample()
+            assert rs.choice(np.arange(Q), p=sp[i]) == np.searchsorted(cdf[i], ui, side="right")
+        pr = np.empty(Q, np.float32)
+        for name, fn in (("sequential", lib.twvo_sample_categorical_sequential), ("current", lib.twvo_sample_categorical)):
+            agree, maxrel = 0, 0.0
+            for i in range(N):
+                k = fn(logits[i].ctypes.data_as(fp), Q, temp, float(u[i]), pr.ctypes.data_as(fp))
+                agree += int(k == want[i])
+                if i % 16 == 0:
+                    nz = sp[i] > 1e-30
+                    maxrel = max(maxrel, float(np.max(np.abs(pr[nz] - sp[i][nz]) / sp[i][nz])))
+            report[(temp, name)] = (agree, maxrel)
+    print("categorical sampler vs numpy (agreeing draws of %d, max relative p error):" % N)
+    for key in sorted(report):
+        print("   T=%.1f %-10s %6d  %.2e" % (key[0], key[1], report[key][0], report[key][1]))
+    for temp in (1.0, 0.8, 1.3):
+        a_new, e_new = report[(temp, "current")]
+        a_old, e_old = report[(temp, "sequential")]
+        assert a_new >= a_old, (temp, a_new, a_old)
+        assert a_new >= N - 3, (temp, a_new)          # u within float32 noise of a cdf boundary: a few per million
+        assert e_new < 2e-5 and e_old < 2e-5          # both differ from numpy by the exp/log implementations, not by the order
+
+
 def test_restatement_fixtures(oracle):
     """the committed restatement_* fixtures pin the oracle against drift (they are NOT reference goldens)"""
     f = np.load(os.path.join(GOLD, "restatement_codec_math.npz"))

@@ -62,22 +62,27 @@ def test_log_bit_exact(torch_cuda, oracle):
     assert first_mismatch(got, want) is None
 
 
-def test_logaddexp_step_form_over_all_floats(torch_cuda):
-    """The one-hot sampler's np.logaddexp step evaluates log1p(exp(t)) as ONE straight line (no branches; the division without the
-    v_div_scale / v_div_fmas / v_div_fixup instructions of the general sequence).  It must be the contract's log1p_e(exp_e(t)) bit for
-    bit for EVERY float t in [-inf, -0] -- the only arguments the left-to-right reduce hands it (generate.py:219-222)."""
-    import torch
+@pytest.mark.parametrize("Q", [256, 100, 1000, 16])
+def test_categorical_sampler_rows_bit_exact(torch_cuda, oracle, Q):
+    """generate.py:219-231 + model.py:243 on the device (twv_sample_categorical, the code both generation kernels draw with) against
+    the checker: drawn class ids equal element for element, scaled probabilities bit for bit, three temperatures.  The contract
+    itself (AC-5) is held against numpy's literal execution of those lines in tests/test_cpu.py."""
     from twvk_amd import ops
-    top = int(np.array([np.inf], np.float32).view(np.uint32)[0])           # magnitudes 0 .. +inf
-    step = 1 << 26
-    for lo in range(0, top + 1, step):
-        n = min(step, top + 1 - lo)
-        mag = torch.arange(lo, lo + n, dtype=torch.int64, device="cuda:0").to(torch.int32).view(torch.float32)
-        t = -mag
-        want = ops.eval_elementwise("log1p_exp", t).view(torch.int32)
-        got = ops.eval_elementwise("log1p_exp_nonpos", t).view(torch.int32)
-        bad = torch.nonzero(want != got)
-        assert bad.numel() == 0, (lo, int(bad[0]), float(t[bad[0]]))
+    rng = np.random.RandomState(100 + Q)
+    N = 6000
+    for temp in (1.0, 0.8, 1.3):
+        logits = (rng.randn(N, Q) * rng.uniform(0.5, 4.0, (N, 1))).astype(np.float32)
+        u = rng.random_sample(N)
+        u[:8] = [0.0, 1.0 - 2.0 ** -53, 0.5, 1e-300, 0.999999, 1e-9, 0.25, 0.75]
+        got, proba = ops.sample_categorical(logits, temp, u, want_proba=True)
+        got, proba = got.cpu().numpy(), proba.cpu().numpy()
+        want = np.empty(N, np.int32); wp = np.empty((N, Q), np.float32)
+        for i in range(N):
+            k, p = oracle.sample_categorical(logits[i], temp, u[i])
+            want[i] = k; wp[i] = p
+        assert np.array_equal(got, want), (temp, first_mismatch(got, want))
+        assert first_mismatch(proba, wp) is None, (temp, first_mismatch(proba, wp))
+        assert got.min() >= 0 and got.max() < Q
 
 
 @pytest.mark.parametrize("name", ["exp64", "log64"])
