@@ -1737,7 +1737,7 @@ static int generate_impl(const twv_wavenet* h, const void* packed, void* state, 
         // stream b on XCD b % 8, every weight register-resident across the XCD's CUs (twv_wavenet_xcd.hip)
         XcdLaunch x;
         x.P = a.P; x.state = a.state; x.cond = a.cond; x.first_input = first_input; x.forced = forced;
-        x.uniforms = (const float*)uniforms; x.out = (float*)out; x.status = status; x.dbg = debug; x.dbg_steps = a.dbg_steps;
+        x.uniforms = (const float*)uniforms; x.temperature = (float)temperature; x.out = (float*)out; x.status = status; x.dbg = debug; x.dbg_steps = a.dbg_steps;
         x.prof = a.prof; x.prof_steps = a.prof_steps;
         { const char* e = getenv("TWV_XCD_PROF_STREAM"); x.prof_stream = e ? atoi(e) : 0; if (x.prof_stream < 0 || x.prof_stream >= batch) x.prof_stream = 0; }
         x.B = batch; x.T = n_steps; x.lay = L; x.many = h->xcd_many;

@@ -41,6 +41,7 @@
 #include "twv_math.hpp"
 #include "twv_dev.hpp"
 #include "twv_dpp.hpp"
+#include "twv_categorical.hpp"
 #include "twv_xcd.hpp"
 
 using namespace twv;
@@ -191,7 +192,10 @@ constexpr int kConvLdsFloats = 16 * 64 + 64; // LDS floats per stream in a conv1
 //  CHAIN workgroup: model.py:41-46 causal layer (wave 0), model.py:66-101 residual layers (relay over the waves),
 //  mixture.py:84-114 sampler (wave 7)
 // =====================================================================================================================
-template <int INSTR, bool ALL, bool FORCED, bool SEG1, bool TWOSEG, int NC>
+// ONEHOT (scalar_input False, the mu-law-256 model of generate.py:219-231): the head wave feeds the causal layer with two kernel ROWS
+// (model.py:41-46 over one-hot input: every AC-1 chunk holds at most one non-zero term, so the k = 2 conv is W0[q(t-1)] + W1[q(t)];
+// only the W1 row waits for the sample) and draws the next class with twv_categorical.hpp from the 256 logits the conv1 workgroups publish.
+template <int INSTR, bool ALL, bool FORCED, bool SEG1, bool TWOSEG, int NC, bool ONEHOT = false>
 __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
 {
     const XcdLaunch& a = xa.p;
@@ -242,6 +246,11 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
     // ha: every row hist[n], hb: every row hist[16+n]  (hist[31] = newest input)
     float ha = 0.0f, hb = 0.0f, first_in = 0.0f, b2v = 0.0f, s_lnl = 0.0f, s_tq = 0.0f, samp = 0.0f;
     float cp[4] = {0.0f, 0.0f, 0.0f, 0.0f};                   // the causal chunk without its newest term
+    // one-hot model: previous input class (the tap-0 row is fetched a step ahead), the class just drawn, the step's uniform draw
+    int q_prev = 0, q_valid = 0, samp_q = 0, first_q = 0;
+    float w0row = 0.0f;
+    double u_next = 0.0;
+    const int chx = dpp_dense_out(lane);                      // residual channel of this lane in the X layout
     const bool sampler = head && !forced;
     const bool is15 = (lane & 15) == 15;
     // model.py:122 queue shift (the slot of the newest sample stays open) + the 31 terms that do not need it
@@ -261,14 +270,22 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
         s_tq = log_e(uu) - log_e(1.0f - uu);
     };
     if (head) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.P + L.off_xc) + lane;
+        if constexpr (ONEHOT) {
+            const int* meta = reinterpret_cast<const int*>(stb + L.st_meta);
+            q_valid = __builtin_amdgcn_readfirstlane(meta[M_PREV_VALID]);      // model.py:52 causal queue: zeros after queue_initializer
+            q_prev = __builtin_amdgcn_readfirstlane(meta[M_QPREV]) & (L.Q - 1);
+            w0row = a.P[L.off_causal + (long long)q_prev * 32 + chx];
+            if (!forced) first_q = reinterpret_cast<const int*>(a.first_input)[b];
+        } else {
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.P + L.off_xc) + lane;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { const f32x4 v = src[q * 64]; W[3].wc[4 * q] = v.x; W[3].wc[4 * q + 1] = v.y; W[3].wc[4 * q + 2] = v.z; W[3].wc[4 * q + 3] = v.w; }
-        ha = stb[L.st_hist + (lane & 15)];
-        hb = stb[L.st_hist + 16 + (lane & 15)];
-        if (!forced) first_in = reinterpret_cast<const float*>(a.first_input)[b];
-        if (sampler && use_bias && lane < L.O) b2v = a.P[L.off_b2 + lane];
-        causal_prepare();
+            for (int q = 0; q < 8; ++q) { const f32x4 v = src[q * 64]; W[3].wc[4 * q] = v.x; W[3].wc[4 * q + 1] = v.y; W[3].wc[4 * q + 2] = v.z; W[3].wc[4 * q + 3] = v.w; }
+            ha = stb[L.st_hist + (lane & 15)];
+            hb = stb[L.st_hist + 16 + (lane & 15)];
+            if (!forced) first_in = reinterpret_cast<const float*>(a.first_input)[b];
+            if (sampler && use_bias && lane < L.O) b2v = a.P[L.off_b2 + lane];
+            causal_prepare();
+        }
     }
     __builtin_amdgcn_s_waitcnt(0);        // every register image and LDS copy has landed before the relay starts
     // The step loop starts at a fixed offset inside a 64-byte fetch window: the same instructions with the same registers ran at
@@ -294,6 +311,21 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                 if (pl.dead) break;
             }
             XSTAMP(true, 0);
+            if constexpr (ONEHOT) {
+                const int q_raw = forced ? reinterpret_cast<const int*>(a.forced)[(long long)b * T + t] : (t == 0 ? first_q : samp_q);
+                const int q_in = __builtin_amdgcn_readfirstlane(q_raw) & (L.Q - 1);
+                const float w1row = a.P[L.off_causal + ((long long)L.Q + q_in) * 32 + chx];       // on the sample path: one row load, one add
+                const float x0 = q_valid ? w0row + w1row : w1row;       // model.py:41-46; the queue's older slot is empty after a reset
+                LDSU64(0 * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(x0);
+                XSTAMP(true, 1);
+                if (lane == 0) {
+                    if (sampler && t > 0) reinterpret_cast<int*>(a.out)[(long long)b * T + t - 1] = samp_q;
+                    xb_store(rs, (int)XcdExch::CTRL, 0, tag, 0.0f);    // step t has started (the lc workgroups throttle on it)
+                }
+                q_prev = q_in; q_valid = 1;                             // model.py:122 queue shift
+                w0row = a.P[L.off_causal + (long long)q_in * 32 + chx]; // the next step's tap-0 row, a step ahead
+                if (sampler) u_next = reinterpret_cast<const double*>(a.uniforms)[(long long)b * T + t];      // generate.py:231's draw
+            } else {
             const float s_in = forced ? reinterpret_cast<const float*>(a.forced)[(long long)b * T + t] : (t == 0 ? first_in : samp);
             const float c3 = fma_(W[3].wc[31], s_in, cp[3]);            // k = 31, the last term of chain 3
             const float x0 = (cp[0] + cp[1]) + (cp[2] + c3);            // model.py:41-46: one AC-1 chunk, no bias; X layout
@@ -307,6 +339,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
             hb = is15 ? s_in : hb;                                      // (ha, hb) = the queue after step t
             if (t + 1 < T) causal_prepare();
             if (sampler) noise(t);
+            }
             __builtin_amdgcn_s_setprio(0);
         }
         XMARK(SEG1 ? 30 : ROLE_CHAIN, 1);
@@ -406,6 +439,32 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
         XSTAMP(nl > 0, (SEG1 ? 48 : 10) + w);
         XMARK(SEG1 ? 30 : ROLE_CHAIN, 4);
         // ---- sampler: conv1d_2's [16 chunks][32 lanes] partial table from the conv1 workgroups -> mixture.py:84-114
+        if constexpr (ONEHOT) {
+          if (sampler) {
+            __builtin_amdgcn_s_setprio(3);
+            // the 256 logits (conv1d_2 summed in chunk order + bias by the conv1 workgroups): class lane + 64 k in granule 4 lane + k,
+            // two 16-byte loads per lane
+            u32x4s d0, d1;
+            pl.it = 0;
+            for (;;) {
+                d0 = xb_load2(rs, (int)XcdExch::QL, lane * 2);
+                d1 = xb_load2(rs, (int)XcdExch::QL, lane * 2 + 1);
+                if (__all(d0.y == tag && d0.w == tag && d1.y == tag && d1.w == tag)) break;
+                if (!poll_tick(pl, 34)) break;
+            }
+            XSTAMP(true, 18);
+            XMARK(SEG1 ? 30 : ROLE_CHAIN, 5);
+            const float y[4] = {__uint_as_float(d0.x), __uint_as_float(d0.z), __uint_as_float(d1.x), __uint_as_float(d1.z)};
+            if ((INSTR & 2) && a.dbg != nullptr && t < a.dbg_steps) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    a.dbg[((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)NL * 64 + lane + 64 * k] = y[k];
+            }
+            // model.py:243 + generate.py:219-231 (AC-5, twv_categorical.hpp): the drawn class is the next step's input
+            samp_q = categorical_sample<4>(y, L.Q, lane, a.temperature, u_next);
+            XSTAMP(true, 19);
+          }
+        } else
         if (sampler) {
             __builtin_amdgcn_s_setprio(3);
             // the [8 chunk pairs][32 outputs][2] partial table, each granule once, FOUR 16-byte loads per round (every load in a polling
@@ -469,12 +528,22 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
 
     // ---- persist (model.py:49-64 causal queue): canonical order, element k = k-th oldest input
     if (head) {
+        if constexpr (ONEHOT) {
+            if (lane == 0) {
+                if (sampler && !pl.dead && T > 0) reinterpret_cast<int*>(a.out)[(long long)b * T + T - 1] = samp_q;
+                int* meta = reinterpret_cast<int*>(stb + L.st_meta);
+                meta[M_TABS] = meta[M_TABS] + T;
+                meta[M_PREV_VALID] = q_valid;
+                meta[M_QPREV] = q_prev;
+            }
+        } else {
         if (sampler && !pl.dead && T > 0 && lane == 0) a.out[(long long)b * T + T - 1] = samp;
         if (lane < 16) stb[L.st_hist + lane] = ha;
         else if (lane < 32) stb[L.st_hist + lane] = hb;
         if (lane == 0) {
             int* meta = reinterpret_cast<int*>(stb + L.st_meta);
             meta[M_TABS] = meta[M_TABS] + T;
+        }
         }
     }
 }
@@ -954,6 +1023,138 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const SX& sx, int g,
 }
 
 // =====================================================================================================================
+//  CONV1 workgroup g of the ONE-HOT model (256-way softmax output, model.py:161-165 with quantization_channels filters): conv1d_2
+//  is 256 x 512 here, sixteen times the MoL head, so it is split by OUTPUT instead of shipping a [16 chunks][256] partial table to
+//  the sampler: workgroup g publishes its block of relu(conv1d_1) (64 values), every conv1 workgroup gathers all eight blocks (wave v
+//  polls exactly block v: the two chunks 2v, 2v+1 of its conv1d_2 dot, one granule per lane -- the same pattern as the h1 gather),
+//  computes the logits of classes 32g .. 32g+31 (lanes 0-31: chunk 2v, lanes 32-63: chunk 2v+1 of the same 32 outputs; ONE 32-term
+//  DPP dot per wave), adds the sixteen chunk values in chunk order through LDS (AC-1), then the bias, and publishes 32 logits.
+//  One more L2 hop than the MoL head (h2), 256 granules instead of 4096 for the sampler to collect.
+// =====================================================================================================================
+constexpr int kConvQLdsFloats = 16 * 64 + 64 + 8 * 64;   // LDS floats per stream: conv1d_1 chunk partials | two arrival counters | conv1d_2 chunk partials
+template <int INSTR, int NS>
+__device__ __forceinline__ void conv1_onehot_role(const XArgs& xa, const XStreams<NS>& sx, int g)
+{
+    const XcdLaunch& a = xa.p;
+    const Layout& L = a.lay;
+    const int v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int T = a.T, NCH = L.NCH;
+    const bool use_bias = L.use_bias != 0;
+    Poll pl{sx.rs[0], a.status, 0, false};
+    constexpr int O_PART = 0, O_CNT = 16 * 64, O_P2 = 16 * 64 + 64;
+    if (threadIdx.x < NS) { LDSI(threadIdx.x * kConvQLdsFloats + O_CNT) = 0; LDSI(threadIdx.x * kConvQLdsFloats + O_CNT + 1) = 0; }
+    __syncthreads();
+    const int c0 = 2 * v, c1 = 2 * v + 1;                                 // this wave's chunks (of conv1d_1 AND of conv1d_2)
+    Tile ta, tb;
+    load_tile(ta, a.P + L.off_w1 + ((long long)g * NCH + c0) * kTile, lane);
+    load_tile(tb, a.P + L.off_w1 + ((long long)g * NCH + c1) * kTile, lane);
+    // conv1d_2: output 32 g + (lane & 31), chunk 2v (lanes 0-31) / 2v+1 (lanes 32-63): column (g & 1) * 32 + (lane & 31) of tile
+    // [oblk = g / 2][chunk] in the packed [kq][64][4] layout
+    float w2[32];
+    {
+        const int ch2 = lane < 32 ? c0 : c1;
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.P + L.off_w2 + ((long long)(g >> 1) * NCH + ch2) * kTile) + ((g & 1) * 32 + (lane & 31));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const f32x4 w = src[q * 64]; w2[4 * q] = w.x; w2[4 * q + 1] = w.y; w2[4 * q + 2] = w.z; w2[4 * q + 3] = w.w; }
+    }
+    float b1v = 0.0f, b2v = 0.0f;
+    if (use_bias && v == 0) b1v = a.P[L.off_b1 + g * 64 + lane];
+    if (use_bias && v == 1 && lane < 32) b2v = a.P[L.off_b2 + g * 32 + lane];
+    const int cls = g * 32 + (lane & 31);                                 // the class whose logit lanes 0-31 of wave 1 publish
+    const int ql_word = (cls & 63) * 4 + (cls >> 6);
+    unsigned long long t_arr = 0, period = 0;
+    for (int t = 0; t < T && !pl.dead; ++t) {
+        asm volatile(".p2align 6");
+        const unsigned tag = (unsigned)t + 1u;
+        if (period) nap_until(t_arr + period - (period >> 3));
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (pl.dead) break;
+            const rsrc_t rs = sx.rs[k];
+            const int ob = k * kConvQLdsFloats;
+            pl.rs = rs;
+            // ---- model.py:158-160 conv1d_1 + relu for output block g, as in conv1_role
+            unsigned long long q;
+            pl.it = 0;
+            for (;;) {
+                q = xb_load(rs, (int)XcdExch::H1 + v * 64, lane);
+                if (__all(g_tag(q) == tag)) break;
+                if (!poll_tick(pl, 61)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            unsigned long long now_arr = 0;
+            if (k == 0) now_arr = __builtin_amdgcn_s_memtime();
+            {
+                const unsigned hq = (unsigned)q;
+                const auto p16 = __builtin_amdgcn_permlane16_swap(hq, hq, false, false);        // [r0,r0,r2,r2], [r1,r1,r3,r3]
+                const auto pa = __builtin_amdgcn_permlane32_swap(p16[0], p16[0], false, false);  // [r0 x4], [r2 x4]
+                const auto pb = __builtin_amdgcn_permlane32_swap(p16[1], p16[1], false, false);  // [r1 x4], [r3 x4]
+                float r0, r1;
+                dot32_dpp_x2(ta.w, __uint_as_float(pa[0]), __uint_as_float(pb[0]), tb.w, __uint_as_float(pa[1]), __uint_as_float(pb[1]), r0, r1);
+                lds[ob + O_PART + c0 * 64 + lane] = r0;
+                lds[ob + O_PART + c1 * 64 + lane] = r1;
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&LDSI(ob + O_CNT), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (k == 0) {
+                const unsigned long long d = now_arr - t_arr;
+                period = (t_arr != 0 && d < (1ull << 18)) ? d : 0;
+                t_arr = now_arr;
+            }
+            if (v == 0) {
+                pl.it = 0;
+                while (LDSVI(ob + O_CNT) < 8 * (t + 1)) { if (!poll_tick(pl, 62)) break; }
+                asm volatile("" ::: "memory");
+                float cp[16];
+#pragma unroll
+                for (int ch = 0; ch < 16; ++ch) cp[ch] = lds[ob + O_PART + ch * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+                float r = cp[0];                                            // AC-1: chunk values added in chunk order
+#pragma unroll
+                for (int ch = 1; ch < 16; ++ch) r = r + cp[ch];
+                if (use_bias) r = r + b1v;
+                const float h = r > 0.0f ? r : 0.0f;                         // model.py:160
+                xb_store(rs, (int)XcdExch::H2 + g * 64, lane, tag, h);
+            }
+            // ---- model.py:161-165 conv1d_2, classes 32g .. 32g+31: this wave's two chunks read block v of relu(conv1d_1)
+            pl.it = 0;
+            for (;;) {
+                q = xb_load(rs, (int)XcdExch::H2 + v * 64, lane);
+                if (__all(g_tag(q) == tag)) break;
+                if (!poll_tick(pl, 63)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            {
+                const unsigned hq = (unsigned)q;
+                const auto p16 = __builtin_amdgcn_permlane16_swap(hq, hq, false, false);        // rows 0,1: h[0..15] | h[16..31]; rows 2,3: h[32..47] | h[48..63]
+                const float r2 = dot32_dpp(w2, __uint_as_float(p16[0]), __uint_as_float(p16[1]));
+                lds[ob + O_P2 + v * 64 + lane] = r2;                         // = [chunk 2v + lane / 32][output lane & 31]
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&LDSI(ob + O_CNT + 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (v == 1) {
+                pl.it = 0;
+                while (LDSVI(ob + O_CNT + 1) < 8 * (t + 1)) { if (!poll_tick(pl, 64)) break; }
+                asm volatile("" ::: "memory");
+                float cp[16];
+#pragma unroll
+                for (int ch = 0; ch < 16; ++ch) cp[ch] = lds[ob + O_P2 + ch * 32 + (lane & 31)];
+                __builtin_amdgcn_sched_barrier(0);
+                float y = cp[0];                                            // AC-1: chunk values added in chunk order
+#pragma unroll
+                for (int ch = 1; ch < 16; ++ch) y = y + cp[ch];
+                if (use_bias) y = y + b2v;
+                if (lane < 32) xb_store(rs, (int)XcdExch::QL, ql_word, tag, y);
+            }
+        }
+    }
+    if (pl.dead && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) xb_store(sx.rs[k], (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);
+    }
+}
+
+// =====================================================================================================================
 //  LC workgroups: model.py:102-111 create_upsample (row by row) and model.py:75-83 lc_filter|lc_gate of every layer,
 //  ahead of the chain through the ring XcdExch::LCR.  Wave gw owns layers gw*lpw .. gw*lpw+lpw-1 (NLC tiles each).
 // =====================================================================================================================
@@ -1168,7 +1369,8 @@ __device__ __forceinline__ bool roles_resident(const XArgs& xa)
 // ONE: see xcd_launch.  BIGK: the instantiation for 31-50 layers (second chain workgroup, helper waves with LDS-resident early tiles).  It is a kernel of
 // its own so that the register allocation of the 30-layer kernel is not touched by it (as ONE kernel the sampling loop of the bench
 // configuration ran at 13.3 instead of 10.4 us per step).
-template <int INSTR, bool BIGK, bool ONE>
+// ONEHOT: the one-hot mu-law model (scalar_input False, 256 classes): its own kernel instantiations, the MoL kernels carry none of it.
+template <int INSTR, bool BIGK, bool ONE, bool ONEHOT = false>
 __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
 {
     const XcdLaunch& a = xa.p;
@@ -1204,12 +1406,13 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
                 // the sampling chain of the hparams-default model once per layer count of a wave (first chain workgroup: 4 or 3)
                 const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
                 const int nlw = a.lay.NL - (wv < 6 ? 4 * wv : 24 + 3 * (wv - 6));
-                if (forced) chain_role<INSTR, false, true, false, BIGK, -1>(xa, b, rs);
-                else if (all && nlw >= 4 && wv < 6) chain_role<INSTR, true, false, false, BIGK, 4>(xa, b, rs);
-                else if (all && nlw >= 3 && wv >= 6) chain_role<INSTR, true, false, false, BIGK, 3>(xa, b, rs);
-                else if (all) chain_role<INSTR, true, false, false, BIGK, -1>(xa, b, rs);
-                else chain_role<INSTR, false, false, false, BIGK, -1>(xa, b, rs);
+                if (forced) chain_role<INSTR, false, true, false, BIGK, -1, ONEHOT>(xa, b, rs);
+                else if (all && nlw >= 4 && wv < 6) chain_role<INSTR, true, false, false, BIGK, 4, ONEHOT>(xa, b, rs);
+                else if (all && nlw >= 3 && wv >= 6) chain_role<INSTR, true, false, false, BIGK, 3, ONEHOT>(xa, b, rs);
+                else if (all) chain_role<INSTR, true, false, false, BIGK, -1, ONEHOT>(xa, b, rs);
+                else chain_role<INSTR, false, false, false, BIGK, -1, ONEHOT>(xa, b, rs);
             } else if constexpr (BIGK) {
+                // (the second chain workgroup has no head: nothing of it depends on the input / output type)
                 const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
                 if (forced) chain_role<INSTR, false, true, true, true, -1>(xa, b, rs);
                 else if (all && a.lay.NL - kXcdSeg0Layers - 4 * wv >= 4) chain_role<INSTR, true, false, true, true, 4>(xa, b, rs);
@@ -1227,7 +1430,12 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
 #pragma unroll
         for (int k = 0; k < NS; ++k) { sx.b[k] = (int)xcc + 8 * k; sx.rs[k] = exch_of(sx.b[k]); }
         if (role < 8) { if (!forced) skip_role<INSTR, NS, BIGK>(xa, sx, role); }
-        else if (role < 16) { if (!forced) conv1_role<INSTR, NS>(xa, sx, role - 8); }
+        else if (role < 16) {
+            if (!forced) {
+                if constexpr (ONEHOT) conv1_onehot_role<INSTR, NS>(xa, sx, role - 8);
+                else conv1_role<INSTR, NS>(xa, sx, role - 8);
+            }
+        }
         else lc_role<INSTR, NS, BIGK>(xa, sx, role - 16);
     };
     if constexpr (BIGK) {                                         // at most two streams per XCD (LDS of the skip workgroups)
@@ -2182,11 +2390,14 @@ namespace twv {
 
 bool xcd_model_ok(const Layout& L)
 {
-    return L.scalar && L.ifw == 32 && L.S == 512 && L.O <= 32 && L.NOJ == 1 && L.NL >= 1 && L.NL <= kXcdMaxLayers && L.NLC <= 4;
+    // scalar input: the MoL head (initial_filter_width 32, out_channels <= 32); one-hot input: the mu-law-256 model (256 classes over
+    // the 8 conv1 workgroups, 32 each)
+    const bool head_ok = L.scalar ? (L.ifw == 32 && L.O <= 32 && L.NOJ == 1) : (L.Q == 256 && L.O == 256);
+    return head_ok && L.S == 512 && L.NL >= 1 && L.NL <= kXcdMaxLayers && L.NLC <= 4;
 }
 // many-streams kernel: every lc wave caches (n_up + 1) rows of NLC*32 floats for each of the XCD's eight streams in its eighth of the LDS
 static bool xcd_many_lc_fits(const Layout& L) { return (long long)kManyPerXcd * (L.n_up + 1) * L.NLC * 32 <= kManyLds / 8; }
-int xcd_max_streams(const Layout& L) { return L.NL > kXcdSeg0Layers ? kXcdStreams / 2 : (xcd_many_lc_fits(L) ? kXcdManyStreams : kXcdStreams); }
+int xcd_max_streams(const Layout& L) { return L.NL > kXcdSeg0Layers ? kXcdStreams / 2 : (L.scalar && xcd_many_lc_fits(L) ? kXcdManyStreams : kXcdStreams); }
 static int lc_layers_per_wave(const Layout& L) { const int n = L.NLC > 0 ? (L.NL > kXcdSeg0Layers ? 6 : 4) / L.NLC : 1; return n < 1 ? 1 : (n > 4 ? 4 : n); }
 int xcd_lc_workgroups(const Layout& L)
 {
@@ -2209,7 +2420,7 @@ int xcd_launch(const XcdLaunch& p, hipStream_t st)
     xa.lc_lpw = lc_layers_per_wave(p.lay);
     // chain workgroup: hand-off boxes + the dense kernels of its layers (136 KiB); more than 32 layers: the skip / service workgroups
     // keep the tiles of layers 0 .. NL-41 in LDS next to their value slots (159 KiB of the CU's 160)
-    const bool many = (p.B > kXcdStreams || p.many != 0) && p.lay.NL <= kXcdSeg0Layers && xcd_many_lc_fits(p.lay);
+    const bool many = p.lay.scalar && (p.B > kXcdStreams || p.many != 0) && p.lay.NL <= kXcdSeg0Layers && xcd_many_lc_fits(p.lay);
     xa.total_roles = 0;
     for (int x = 0; x < 8 && x < p.B; ++x) {
         const int ns = (p.B - x + 7) / 8;
@@ -2239,6 +2450,16 @@ int xcd_launch(const XcdLaunch& p, hipStream_t st)
         if (instr == 1) go(wn_xcd_many_kernel<4>);
         else if (instr == 2) go(wn_xcd_many_kernel<2>);
         else go(wn_xcd_many_kernel<0>);
+    }
+    else if (!p.lay.scalar) {
+        // the one-hot mu-law-256 model: its own instantiations (per-layer dumps for the 30-layer kernel only; no phase stamps)
+        if (p.B > (p.lay.NL > kXcdSeg0Layers ? kXcdStreams / 2 : kXcdStreams)) return twv_fail(TWV_E_UNSUPPORTED, "the one-hot XCD kernel takes at most 32 streams (16 above 30 layers)");
+        if ((instr & 1) || (instr != 0 && p.lay.NL > kXcdSeg0Layers))
+            return twv_fail(TWV_E_UNSUPPORTED, "the one-hot XCD kernel has layer dumps up to 30 layers and no phase stamps (set option \"xcd\" = 0 for the generic kernel)");
+        if (p.lay.NL > kXcdSeg0Layers) go(wn_xcd_generate_kernel<0, true, false, true>);
+        else if (instr == 2) go(wn_xcd_generate_kernel<2, false, false, true>);
+        else if (p.B <= 8) go(wn_xcd_generate_kernel<0, false, true, true>);
+        else go(wn_xcd_generate_kernel<0, false, false, true>);
     }
     else if (p.lay.NL > kXcdSeg0Layers) {
         if (instr != 0) return twv_fail(TWV_E_UNSUPPORTED, "layer dumps / phase stamps exist for the 30-layer XCD kernel only (set option \"xcd\" = 0 for the generic kernel)");

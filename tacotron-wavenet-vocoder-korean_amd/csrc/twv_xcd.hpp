@@ -34,7 +34,9 @@ struct XcdExch {
     static constexpr long long SEG = MARK + 256;                        // [64] residual vector, first -> second chain workgroup (more than 30 layers)
     static constexpr long long DONE = SEG + 64;                         // [64] end of a teacher-forced step, second chain workgroup -> head
     static constexpr long long SKT = DONE + 64;                         // [3 hops][2 halves][2 pairs][64 lanes][2] running skip total, layer group -> next group (many-streams kernel)
-    static constexpr long long WORDS = SKT + 3 * 2 * 256;
+    static constexpr long long H2 = SKT + 3 * 2 * 256;                  // [512] relu(conv1d_1)                conv1 -> conv1 (one-hot model: conv1d_2 is split by OUTPUT)
+    static constexpr long long QL = H2 + 512;                           // [64 lanes][4] logits of class lane + 64 k   conv1 -> sampler (one-hot model)
+    static constexpr long long WORDS = QL + 256;
     // (slots of layers a model does not have are never touched: they cost address space, not cache)
 };
 
@@ -44,8 +46,9 @@ struct XcdLaunch {
     const float* cond;
     const void* first_input;
     const void* forced;
-    const float* uniforms;
-    float* out;
+    const float* uniforms;         // scalar input: (B, T, nr_mix + 1) float; one-hot: (B, T) double
+    float temperature;             // one-hot model: generate.py:220
+    float* out;                    // scalar input: float samples; one-hot: int32 class ids
     int* status;
     float* dbg;
     int dbg_steps;
@@ -60,7 +63,7 @@ struct XcdLaunch {
 };
 
 bool xcd_model_ok(const Layout& L);                       // shape the kernel is written for
-int xcd_max_streams(const Layout& L);                     // 64 (30 layers or fewer), 16 above
+int xcd_max_streams(const Layout& L);                     // MoL: 96 (30 layers or fewer), 16 above; one-hot: 32 / 16
 int xcd_lc_workgroups(const Layout& L);                   // lc workgroups per stream
 int xcd_workgroups_per_stream(const Layout& L);
 size_t xcd_exchange_bytes(int batch);                     // exchange area + role tickets

@@ -242,9 +242,13 @@ class WaveNetModel(object):
         configs[1], linear in B*T).  Longer requests are cut into calls of at most MAX_COND_BYTES of it -- a whole number of hops, so the
         upsampled rows of a chunk come from whole mel frames; the state carries over between calls (as between the sess.run calls of
         generate.py:211), so the samples do not change.  The fused (XCD) path has no such table: one call."""
-        if self.fused_conditioning() or not self.local_condition_channels:
+        if self.fused_conditioning():
             return n_steps
-        per_step = 4 * self.batch_size * len(self.dilations) * 64
+        # what one more step adds to the table of the kernel in use (0 on the XCD kernels without local conditioning; the generic
+        # kernel's table holds a row per step even for a gc-only model)
+        per_step = int(self._L.twv_wavenet_cond_bytes(self._h, self.batch_size, 2)) - int(self._L.twv_wavenet_cond_bytes(self._h, self.batch_size, 1))
+        if per_step <= 0:
+            return n_steps
         hop = max(1, self.hop_size)
         steps = max(hop, (self.MAX_COND_BYTES // per_step) // hop * hop)
         return min(n_steps, steps)

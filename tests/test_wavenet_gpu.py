@@ -392,6 +392,82 @@ def test_generate_onehot_variants(torch_cuda, oracle, kw):
     assert np.array_equal(got.cpu().numpy(), want), kw
 
 
+def _onehot_xcd_case(oracle, nl, B, T, use_bias=True, G=32, L=80, temperature=1.0, seed=1):
+    dil = ([2 ** i for i in range(10)] * 5)[:nl]
+    d, tensors, blob = make_case(oracle, dil, scalar_input=False, S=512, Q=256, scale=0.12, use_bias=use_bias, G=G, L=L)
+    m = make_model(B, dil, tensors, scalar_input=False, S=512, Q=256, use_bias=use_bias, G=G, L=L)
+    rng = np.random.RandomState(seed)
+    U = rng.uniform(-4, 4, (B, T, L)).astype(np.float32) if L else None
+    gc = (np.arange(B) % 2).astype(np.int32) if G else None
+    seed_in = rng.randint(256, size=B).astype(np.int32)
+    u = np.random.RandomState(seed + 1).random_sample((B, T))
+    return d, blob, m, U, gc, seed_in, u
+
+
+@pytest.mark.parametrize("nl,B,kw", [(30, 8, {}), (30, 1, {}), (7, 3, dict(use_bias=False)), (12, 9, dict(G=0)), (30, 19, dict(L=0)),
+                                     (30, 32, {}), (1, 2, {}), (33, 2, {}), (50, 9, {})])
+def test_xcd_onehot_kernel_shapes(torch_cuda, oracle, nl, B, kw):
+    """the one-hot mu-law-256 model (scalar_input False; model.py:41-46,223-227,243, generate.py:219-231) on the
+    XCD-per-stream kernel: int32 class ids equal to the checker's element for element -- one to four streams per XCD, 1..50 layers
+    (second chain workgroup above 30), without bias / gc / lc, temperature 0.8 on one case."""
+    T = 160 if B <= 9 else 90
+    temp = 0.8 if (nl, B) == (30, 1) else 1.0
+    d, blob, m, U, gc, seed_in, u = _onehot_xcd_case(oracle, nl, B, T, temperature=temp, **kw)
+    if kw.get("L", 80):
+        assert m.fused_conditioning(), "the one-hot model must take the XCD kernel at S = 512, Q = 256"
+    oracle.set_threads(min(8, oracle.set_threads(1)))
+    try:
+        want = oracle.generate_mulaw(d, blob, oracle.State(d, B), U, gc, seed_in, u, temp)
+    finally:
+        oracle.set_threads(1)
+    got = m.generate(U, gc, seed_in, u, temperature=temp).cpu().numpy()
+    assert got.dtype == np.int32
+    assert np.array_equal(got, want), first_mismatch(got, want)
+
+
+def test_xcd_onehot_kernel_layer_dumps_and_chunked_calls(torch_cuda, oracle):
+    """per-layer z / x and the 256 logits of the first steps bit for bit (debug build of the one-hot XCD kernel); then the same
+    utterance in calls of 1, 7, 50 and the remaining steps: the state (delay lines, the causal queue's previous class) carries over"""
+    nl, B, T, dbg = 30, 3, 120, 3
+    d, blob, m, U, gc, seed_in, u = _onehot_xcd_case(oracle, nl, B, T, seed=5)
+    want = oracle.generate_mulaw(d, blob, oracle.State(d, B), U, gc, seed_in, u, 1.0)
+    got, dump = m.generate(U, gc, seed_in, u, debug_steps=dbg)
+    dump = dump.cpu().numpy()
+    st = oracle.State(d, B)
+    inp = seed_in.copy()
+    for t in range(dbg):
+        raw, dz, dx = oracle.step(d, blob, st, inp, U[:, t], gc, debug=True)
+        gz = dump[:, t, :nl * 64].reshape(B, nl, 2, 32)
+        assert first_mismatch(gz[:, :, 0], dz) is None, ("z", t)
+        assert first_mismatch(gz[:, :, 1], dx) is None, ("x", t)
+        assert first_mismatch(dump[:, t, nl * 64:nl * 64 + 256], raw) is None, ("logits", t)
+        inp = want[:, t]
+    assert np.array_equal(got.cpu().numpy(), want)
+    m.queue_initializer()
+    outs, fi, p = [], seed_in, 0
+    for n in (1, 7, 50, T - 58):
+        o = m.generate(U[:, p:p + n].copy(), gc, fi, u[:, p:p + n].copy()).cpu().numpy()
+        outs.append(o); fi = o[:, -1]; p += n
+    assert np.array_equal(np.concatenate(outs, axis=1), want)
+
+
+@pytest.mark.parametrize("nl,B", [(30, 3), (41, 2)])
+def test_xcd_onehot_kernel_priming_then_generation(torch_cuda, oracle, nl, B):
+    """generate.py:168-180 on the one-hot XCD kernel: teacher-forced class ids (zero lc), then generation from the primed queues"""
+    T, n_prime = 60, 700
+    d, blob, m, U, gc, seed_in, u = _onehot_xcd_case(oracle, nl, B, T, seed=7)
+    rng = np.random.RandomState(17)
+    seedwave = rng.randint(256, size=(B, n_prime)).astype(np.int32)
+    st = oracle.State(d, B)
+    zeros = np.zeros((B, 80), np.float32)
+    for i in range(n_prime - 1):
+        oracle.step(d, blob, st, seedwave[:, i], zeros, gc)
+    want = oracle.generate_mulaw(d, blob, st, U, gc, seedwave[:, -1], u, 1.0)
+    m.prime(seedwave[:, :n_prime - 1], None, gc)
+    got = m.generate(U, gc, seedwave[:, -1], u).cpu().numpy()
+    assert np.array_equal(got, want), first_mismatch(got, want)
+
+
 @pytest.mark.parametrize("scalar", [True, False])
 def test_priming_then_generation(torch_cuda, oracle, scalar):
     """generate.py:168-180: prime with RF-1 seed samples (zero lc, predictions discarded), then generate"""
