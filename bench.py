@@ -360,35 +360,80 @@ def main():
                 res["hparams_default_50_layers"] = {"error": repr(e)}
         if not args.no_sweep and world == 1:
             # the mu-law-256 variant of configs[1] (one-hot input, 256-way softmax output) -- the model north_star's integer
-            # parity bar is stated on.  It runs on the generic kernel: its sampler is generate.py:219-231 taken literally (float64
-            # softmax, then a LEFT-TO-RIGHT float32 np.logaddexp.reduce over the 256 classes and a sequential float64 cumsum): 255
-            # dependent exp+log1p evaluations per sample (32 us of the step's 73) in whatever layout.
+            # parity bar is stated on.  Round 4: on the XCD-per-stream kernel (wn_xcd_generate_kernel<.., ONEHOT>): causal layer as two
+            # kernel rows, conv1d_2 split by output over the conv1 workgroups, generate.py:219-231's sampler lane-parallel on the head wave
+            # (AC-5, founded on numpy itself: tests/test_cpu.py::test_categorical_sampler_contract_against_numpy).
             try:
-                Tq = hp.sample_rate // 4 // hp.hop_size * hp.hop_size
+                Tq = hp.sample_rate // 2 // hp.hop_size * hp.hop_size
                 mq = WaveNetModel(B, dil, hp.filter_width, hp.residual_channels, hp.dilation_channels, hp.skip_channels,
                                   quantization_channels=256, out_channels=hp.out_channels, use_biases=hp.use_biases, scalar_input=False,
                                   initial_filter_width=hp.initial_filter_width, global_condition_channels=hp.gc_channels,
                                   global_condition_cardinality=2, local_condition_channels=hp.num_mels, upsample_factor=hp.upsample_factor,
                                   train_mode=False, device=dev)
-                mq.load_weights(W.random_tensors(mq.specs, seed=0, scale=0.05))
+                if args.xcd >= 0:
+                    mq.set_option("xcd", args.xcd)
+                tq = W.random_tensors(mq.specs, seed=0, scale=0.05)
+                mq.load_weights(tq)
                 rq = np.random.RandomState(91)
-                melq = torch.from_numpy(rq.uniform(-4, 4, (B, Tq // hp.hop_size, hp.num_mels)).astype(np.float32)).to(dev)
-                uq = torch.from_numpy(rq.random_sample((B, Tq))).to(dev)
+                melq_h = rq.uniform(-4, 4, (B, Tq // hp.hop_size, hp.num_mels)).astype(np.float32)
+                uq_h = rq.random_sample((B, Tq))
+                melq = torch.from_numpy(melq_h).to(dev)
+                uq = torch.from_numpy(uq_h).to(dev)
                 fq = rq.randint(256, size=B).astype(np.int32)
-                Uq = mq.create_upsample(melq)
-                mq.generate(Uq[:, :600].contiguous(), gc, fq, uq[:, :600].contiguous())
-                mq.queue_initializer()
-                torch.cuda.synchronize()
-                q0 = time.perf_counter()
-                oq = mq.generate(Uq, gc, fq, uq)
-                torch.cuda.synchronize()
-                qdt = time.perf_counter() - q0
-                res["mulaw_256"] = {"streams": B, "samples_per_s": B * Tq / qdt, "us_per_generation_step": qdt / Tq * 1e6,
-                                    "realtime_factor_per_stream": Tq / qdt / hp.sample_rate, "kernel": "wn_generate_kernel",
-                                    "classes_drawn": int(torch.unique(oq).numel()),
-                                    "config": {"workload": "configs[1]'s stack with one-hot mu-law-256 input and a 256-way softmax output, batch=%d x %d steps; "
-                                                           "bit-exact int32 indices vs the checker in tests/test_wavenet_gpu.py::test_generate_c2_mulaw_variant_at_batch_8" % (B, Tq)}}
-                del mq, Uq
+                fqd = torch.as_tensor(fq, device=dev)
+                qfused = mq.fused_conditioning()
+
+                def q_pass():
+                    mq.queue_initializer()
+                    Uq = mq.create_upsample(melq)
+                    condq = mq._condition(Uq, gc, Tq)
+                    oq_ = torch.empty((B, Tq), dtype=torch.int32, device=dev)
+                    s0 = torch.cuda.Event(enable_timing=True); s1 = torch.cuda.Event(enable_timing=True)
+                    s0.record()
+                    _lib.check(mq._L.twv_wavenet_generate(mq._h, C.c_void_p(mq._packed.data_ptr()), C.c_void_p(mq._state.data_ptr()),
+                                                          C.c_void_p(condq.data_ptr()), C.c_void_p(fqd.data_ptr()), C.c_void_p(uq.data_ptr()), 1.0,
+                                                          B, Tq, C.c_void_p(oq_.data_ptr()), C.c_void_p(mq._status.data_ptr()), None, 0,
+                                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                    s1.record()
+                    torch.cuda.synchronize()
+                    _lib.check(mq._L.twv_wavenet_status(C.c_void_p(mq._status.data_ptr()), None))
+                    return oq_, s0.elapsed_time(s1), condq
+                q_pass()
+                oq, qms, _cq = q_pass()
+                q_us = qms * 1e3 / Tq
+                # algorithmic bytes per step (SURVEY 8d's convention: every weight re-read per step): the layers as above, the one-hot
+                # causal kernel (2 x 256 x 32), conv1d_1, the 512 x 256 conv1d_2; I/O per stream: 80 lc floats, class in, class out, one f64 draw
+                q_wfloats = NL * per_layer + (512 * 512 + 512) + (512 * 256 + 256) + 2 * 256 * 32
+                q_bytes = q_wfloats * 4 + B * (80 * 4 + 4 + 4 + 8)
+                q_floor = NL * 0.200 + 8 * 0.075 + 0.18 + (4 * 0.26 + 0.22 + 0.28 + 0.12 + 0.17 + 0.12 + 1.55)
+                q_match = None
+                if not args.no_cpu_baseline:
+                    nq = 400
+                    dq = O.make_dims(dil, scalar_input=False, Q=256)
+                    blobq = O.blob_from_tensors(dq, tq)
+                    Uo = O.upsample(dq, blobq, melq_h[:, :(nq + hp.hop_size - 1) // hp.hop_size])[:, :nq]
+                    O.set_threads(min(B, O.set_threads(1)))
+                    wantq = O.generate_mulaw(dq, blobq, O.State(dq, B), Uo, gc, fq, uq_h[:, :nq], 1.0)
+                    O.set_threads(1)
+                    q_match = bool(np.array_equal(oq[:, :nq].cpu().numpy(), wantq))
+                    assert q_match, "mu-law-256 variant: timed output differs from the CPU checker"
+                res["mulaw_256"] = {"streams": B, "samples_per_s": B * Tq / (qms * 1e-3), "us_per_generation_step": q_us,
+                                    "realtime_factor_per_stream": Tq / (qms * 1e-3) / hp.sample_rate,
+                                    "kernel": "wn_xcd_generate_kernel (one-hot instantiation)" if qfused else "wn_generate_kernel",
+                                    "classes_drawn": int(torch.unique(oq).numel()), "dtype": "f32 network, f64 softmax/cdf, int32 class ids",
+                                    "checked_against_oracle": None if q_match is None else "first 400 class ids of all %d streams: identical" % B,
+                                    "roofline": {"bound": "hbm", "achieved": q_bytes / (q_us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                                 "frac": q_bytes / (q_us * 1e-6) / 1e9 / 8000.0, "algorithmic_bytes_per_step": q_bytes, "traffic": None,
+                                                 "kernel_ms": qms, "latency_floor_us": q_floor, "frac_of_floor": q_floor / q_us,
+                                                 "latency_floor_formula": "%d layers x 0.200 us + 8 wave hand-offs x 0.075 + causal row load 0.18 + post phase: 4 L2 hops x 0.26 "
+                                                                          "(z, h1, h2, logits) + skip 0.22 + conv1d_1 chunk dots 0.28 + ordered sum 0.12 + conv1d_2 chunk dot 0.17 + "
+                                                                          "ordered sum 0.12 + sampler 1.55 (its ~850 VALU instructions at 4 cycles each, one wave, 2.2 GHz; measured 3.18); "
+                                                                          "pieces: profiles/r04_xcd_onehot_phase_profile_v1.txt" % NL,
+                                                 "note": "as for the headline kernel: weights are register-resident, the step is a dependent chain (latency), "
+                                                         "algorithmic bytes assume every weight re-read per step (SURVEY.md 8d)"},
+                                    "config": {"workload": "configs[1]'s stack with one-hot mu-law-256 input and a 256-way softmax output (model.py:223-227,243; "
+                                                           "generate.py:219-231 with the uniform draw injected), batch=%d x %d steps" % (B, Tq)}}
+                del mq
             except Exception as e:
                 res["mulaw_256"] = {"error": repr(e)}
         if not args.no_cpu_baseline:

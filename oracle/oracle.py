@@ -361,8 +361,10 @@ def taco_tensor_specs(d):
     moving_mean, moving_variance; the blob stores the derived (inv, shift) pair instead (see taco_blob)."""
     E, SE, P0, P1, RN, A, AS, DR, M, R = d.emb, d.spk_emb, d.enc_prenet[0], d.enc_prenet[1], d.enc_rnn, d.att, d.att_state, d.dec_rnn, d.num_mels, d.r
     ENC = 2 * RN
-    s = [("embedding", (d.n_symbols, E)), ("speaker_embedding", (d.n_speakers, SE))]
-    dn = [P1, 2 * RN, AS] + [DR] * d.dec_layers
+    s = [("embedding", (d.n_symbols, E))]
+    dn = ([P1, 2 * RN, AS] + [DR] * d.dec_layers) if d.n_speakers > 1 else []      # tacotron.py:62-104
+    if d.n_speakers > 1:
+        s += [("speaker_embedding", (d.n_speakers, SE))]
     for i, n in enumerate(dn):
         nm = "dense" if i == 0 else "dense_%d" % i
         s += [(nm + "/kernel", (SE, n)), (nm + "/bias", (n,))]
@@ -384,7 +386,7 @@ def taco_tensor_specs(d):
         s += [(p + "gates/kernel", (2 * DR, 2 * DR)), (p + "gates/bias", (2 * DR,)), (p + "candidate/kernel", (2 * DR, DR)), (p + "candidate/bias", (DR,))]
     s += [("decoder/output_projection_wrapper/kernel", (DR, M * R)), ("decoder/output_projection_wrapper/bias", (M * R,))]
     s += _cbhg_specs("post_cbhg", M, d.post_bank, d.post_bank_ch, tuple(d.post_proj), d.post_proj_w, d.post_hw_depth, d.post_rnn)
-    nm = "dense_%d" % len(dn)
+    nm = "dense_%d" % len(dn) if dn else "dense"
     s += [(nm + "/kernel", (2 * d.post_rnn, d.num_freq)), (nm + "/bias", (d.num_freq,))]
     return s
 
@@ -443,7 +445,8 @@ def taco_blob(d, tensors):
 
 
 def taco_infer(d, blob, tokens, lengths, speaker_ids, want_linear=True, want_align=True):
-    tokens = _ci(tokens); lengths = _ci(lengths); speaker_ids = _ci(speaker_ids)
+    tokens = _ci(tokens); lengths = _ci(lengths)
+    speaker_ids = _ci(speaker_ids) if d.n_speakers > 1 else None
     N, T = tokens.shape
     TO = d.max_iters * d.r
     mel = np.empty((N, TO, d.num_mels), np.float32)

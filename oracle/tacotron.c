@@ -3,7 +3,8 @@
  * Restates /root/reference/tacotron/tacotron.py:36-235 (initialize, inference branch: rnn_decoder_test_mode=True,
  * linear_targets=None), tacotron/modules.py:10-96, tacotron/rnn_wrappers.py:282-467, tacotron/helpers.py:10-41 for the
  * default hparams path: model_type 'deepvoice' with num_speakers > 1 and speaker_embedding_size != 1
- * (hparams.py:123-124), attention_type 'bah_mon_norm' (hparams.py:140).
+ * (hparams.py:123-124), or a single speaker (tacotron.py:97-104; synthesizer.py:375's default), attention_type
+ * 'bah_mon_norm' (hparams.py:140).
  *
  * PARITY UNPINNED, twice over: (1) no TensorFlow here and no reference goldens (see twv_oracle.h); (2) the pieces that
  * live inside tf.contrib / tf.layers -- GRUCell gate order and update rule, bidirectional_dynamic_rnn's handling of
@@ -200,11 +201,14 @@ void twvo_taco_infer(const twvo_taco_dims* d, const float* blob, const int32_t* 
     const int E = d->emb, SE = d->spk_emb, P0 = d->enc_prenet[0], P1 = d->enc_prenet[1], RN = d->enc_rnn, A = d->att,
               AS = d->att_state, DR = d->dec_rnn, M = d->num_mels, R = d->r, ENC = 2 * RN;
     const float* emb = take(&c, (size_t)d->n_symbols * E);                 /* tacotron.py:51 'embedding' */
-    const float* semb = take(&c, (size_t)d->n_speakers * SE);              /* tacotron.py:67 'speaker_embedding' */
+    /* tacotron.py:62-104: the speaker tensors exist only when num_speakers > 1; otherwise before_highway and every initial
+     * state is None (zero_state) */
+    const int multi = d->n_speakers > 1;
+    const float* semb = multi ? take(&c, (size_t)d->n_speakers * SE) : NULL;   /* tacotron.py:67 'speaker_embedding' */
     /* tacotron.py:76-82 deep_dense (softsign): before_highway, encoder rnn init, attention rnn init, decoder rnn inits */
     const float *dW[8], *db[8];
     const int dn[8] = { P1, 2 * RN, AS, DR, DR, DR, DR, DR };
-    const int ndense = 3 + d->dec_layers;
+    const int ndense = multi ? 3 + d->dec_layers : 0;
     for (int i = 0; i < ndense; ++i) { dW[i] = take(&c, (size_t)SE * dn[i]); db[i] = take(&c, dn[i]); }
     const float* pW1 = take(&c, (size_t)E * P0); const float* pb1 = take(&c, P0);      /* prenet, modules.py:15-23 */
     const float* pW2 = take(&c, (size_t)P0 * P1); const float* pb2 = take(&c, P1);
@@ -255,14 +259,17 @@ void twvo_taco_infer(const twvo_taco_dims* d, const float* blob, const int32_t* 
             if (tok == 0) memset(x0 + (size_t)t * E, 0, sizeof(float) * E);
             else memcpy(x0 + (size_t)t * E, emb + (size_t)tok * E, sizeof(float) * E);
         }
-        const float* se = semb + (size_t)speaker_ids[n] * SE;
         float init[8][512];
-        for (int i = 0; i < ndense; ++i) dense_rows(se, 1, SE, dW[i], db[i], dn[i], ACT_SOFTSIGN, init[i]);
+        memset(init, 0, sizeof(init));                                      /* single speaker: zero states (tacotron.py:97-104) */
+        if (multi) {
+            const float* se = semb + (size_t)speaker_ids[n] * SE;
+            for (int i = 0; i < ndense; ++i) dense_rows(se, 1, SE, dW[i], db[i], dn[i], ACT_SOFTSIGN, init[i]);
+        }
         dense_rows(x0, T, E, pW1, pb1, P0, ACT_RELU, x1);                 /* tacotron.py:108 prenet (dropout rate 0) */
         dense_rows(x1, T, P0, pW2, pb2, P1, ACT_RELU, x2);
         /* tacotron.py:113 encoder cbhg; encoder_rnn_init_state split into fw | bw (modules.py:66) */
         cbhg_one(&enc, x2, T, len, P1, d->enc_bank, d->enc_bank_ch, d->enc_proj, d->enc_proj_w, d->enc_hw_depth, RN,
-                 init[0], init[1], init[1] + RN, memo);
+                 multi ? init[0] : NULL, multi ? init[1] : NULL, multi ? init[1] + RN : NULL, memo);
         /* [RECALLED-TF _prepare_memory]: memory zeroed past input_lengths (the biGRU already outputs zeros there) */
         for (int t = len; t < T; ++t) memset(memo + (size_t)t * ENC, 0, sizeof(float) * ENC);
         dense_rows(memo, T, ENC, Wm, NULL, A, ACT_NONE, keys);              /* keys = memory_layer(memory) */
@@ -343,9 +350,12 @@ size_t twvo_taco_blob_floats(const twvo_taco_dims* d)
     size_t n = 0;
     const int E = d->emb, SE = d->spk_emb, P0 = d->enc_prenet[0], P1 = d->enc_prenet[1], RN = d->enc_rnn, A = d->att,
               AS = d->att_state, DR = d->dec_rnn, M = d->num_mels, R = d->r, ENC = 2 * RN;
-    n += (size_t)d->n_symbols * E + (size_t)d->n_speakers * SE;
+    n += (size_t)d->n_symbols * E;
     const int dn[8] = { P1, 2 * RN, AS, DR, DR, DR, DR, DR };
-    for (int i = 0; i < 3 + d->dec_layers; ++i) n += (size_t)SE * dn[i] + dn[i];
+    if (d->n_speakers > 1) {
+        n += (size_t)d->n_speakers * SE;
+        for (int i = 0; i < 3 + d->dec_layers; ++i) n += (size_t)SE * dn[i] + dn[i];
+    }
     n += (size_t)E * P0 + P0 + (size_t)P0 * P1 + P1;
 #define CBHG_N(Cin, bank, bch, proj, pw, depth, rnn)                                                              \
     do {                                                                                                          \

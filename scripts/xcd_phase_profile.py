@@ -13,11 +13,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=3000)
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--layers", type=int, default=30)
+ap.add_argument("--onehot", action="store_true", help="the one-hot mu-law-256 model (scalar_input False) instead of the MoL model")
 ap.add_argument("--ghz", type=float, default=0.0, help="s_memtime ticks per ns (0 = calibrate from the event time of the launch)")
 args = ap.parse_args()
 dil = ([2 ** i for i in range(10)] * 5)[:args.layers]
 B, T = args.batch, args.steps
-m = WaveNetModel(B, dil, 2, 32, 32, 512, out_channels=30, use_biases=True, scalar_input=True, initial_filter_width=32,
+m = WaveNetModel(B, dil, 2, 32, 32, 512, out_channels=30, use_biases=True, scalar_input=not args.onehot, initial_filter_width=32,
                  global_condition_channels=32, global_condition_cardinality=2, local_condition_channels=80,
                  upsample_factor=[5, 5, 12], train_mode=False)
 m.load_weights(W.random_tensors(m.specs, 0, 0.05))
@@ -25,11 +26,11 @@ assert m.fused_conditioning(), "the XCD-per-stream kernel does not serve this co
 rng = np.random.RandomState(0)
 mel = rng.uniform(-4, 4, (B, (T + 299) // 300, 80)).astype(np.float32)
 U = m.create_upsample(mel)
-u = torch.from_numpy(rng.uniform(1e-5, 1 - 1e-5, (B, T, 11)).astype(np.float32)).cuda()
+u = torch.from_numpy(rng.random_sample((B, T))).cuda() if args.onehot else torch.from_numpy(rng.uniform(1e-5, 1 - 1e-5, (B, T, 11)).astype(np.float32)).cuda()
 NP = T
 prof = torch.zeros((NP, 64), dtype=torch.int64, device="cuda")
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-gc, fi = np.zeros(B, np.int32), np.zeros(B, np.float32)
+gc, fi = np.zeros(B, np.int32), (np.full(B, 128, np.int32) if args.onehot else np.zeros(B, np.float32))
 m.generate(U, gc, fi, u)   # warm
 m.queue_initializer()
 e0.record(); m.generate(U, gc, fi, u, check=False); e1.record(); torch.cuda.synchronize()
@@ -58,9 +59,18 @@ print("      skip dot + ordered sum + relu -> h1 published %.2f" % us(p[:, 21] -
 print("      h1 -> conv1 workgroup sees it                 %.2f" % us(p[:, 22] - p[:, 21]))
 print("      two chunk dots -> partials in LDS             %.2f" % us(p[:, 23] - p[:, 22]))
 print("      wait for the other waves                      %.2f" % us(p[:, 24] - p[:, 23]))
-print("      ordered sum, relu, conv1d_2 chunk, publish    %.2f" % us(p[:, 25] - p[:, 24]))
-print("      partial table -> sampler has all of it        %.2f" % us(p[:, 18] - p[:, 25]))
-print("      sampler                                       %.2f" % us(p[:, 19] - p[:, 18]))
+if args.onehot:
+    print("      ordered sum, relu -> h2 block published       %.2f" % us(p[:, 25] - p[:, 24]))
+    print("      h2 -> wave 1 of conv1 workgroup 0 sees block 1 %.2f" % us(p[:, 34] - p[:, 25]))
+    print("      conv1d_2 chunk dot -> partials in LDS         %.2f" % us(p[:, 35] - p[:, 34]))
+    print("      wait for the other waves                      %.2f" % us(p[:, 36] - p[:, 35]))
+    print("      ordered sum, bias -> 32 logits published      %.2f" % us(p[:, 37] - p[:, 36]))
+    print("      logits -> sampler has all 256                 %.2f" % us(p[:, 18] - p[:, 37]))
+    print("      sampler (f64 softmax, rescale, cdf, search)   %.2f" % us(p[:, 19] - p[:, 18]))
+else:
+    print("      ordered sum, relu, conv1d_2 chunk, publish    %.2f" % us(p[:, 25] - p[:, 24]))
+    print("      partial table -> sampler has all of it        %.2f" % us(p[:, 18] - p[:, 25]))
+    print("      sampler                                       %.2f" % us(p[:, 19] - p[:, 18]))
 print("      sample -> next step's head                    %.2f" % us(p[1:, 0] - p[:-1, 19]))
 print("post total (last layer out -> next head)            %.2f" % us(p[1:, 0] - done[last][:-1]))
 for w in range(nw):

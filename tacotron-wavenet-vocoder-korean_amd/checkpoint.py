@@ -480,6 +480,108 @@ def tacotron_variable_names(spec_names, scope="model/inference/"):
     return out
 
 
+# ---------------------------------------------------------------- name-tolerant restore
+# TensorFlow numbers layers that are created without an explicit name (tf.layers.dense -> "dense", "dense_1", ...;
+# tf.layers.conv1d -> "conv1d", "conv1d_1", ...) per GRAPH, in creation order.  The names weights.py / tacotron.py list are this
+# project's reading of that rule for the reference graph; a checkpoint written by a graph that created one more (or one fewer)
+# unnamed layer first -- another TF version, a train-mode graph, an extra tower -- carries the same tensors under shifted
+# suffixes.  When an exact name is missing, the restore below falls back to (scope path with the auto-suffix removed, shape,
+# creation order) and reports every remapping it made.
+_AUTO_BASES = ("dense", "conv1d", "conv2d_transpose", "batch_normalization", "gru_cell", "embedding", "multi_rnn_cell", "output_projection_wrapper",
+               "attention_wrapper", "bahdanau_monotonic_attention", "memory_layer")
+
+
+def _split_auto(component):
+    """('dense', 3) for 'dense_3', ('dense', 0) for 'dense'; (component, None) when it is not an auto-numbered layer name"""
+    for base in _AUTO_BASES:
+        if component == base:
+            return base, 0
+        if component.startswith(base + "_") and component[len(base) + 1:].isdigit():
+            return base, int(component[len(base) + 1:])
+    return component, None
+
+
+def _stem(name):
+    """(path with auto-suffixes removed, tuple of the removed indices)"""
+    comps, idx = [], []
+    for c in name.split("/"):
+        base, i = _split_auto(c)
+        comps.append(base)
+        if i is not None:
+            idx.append(i)
+    return "/".join(comps), tuple(idx)
+
+
+def bundle_shapes(prefix, verify=None):
+    """{variable name: shape tuple} of a bundle, from its index alone (no tensor data is read)"""
+    out = {}
+    for key, val in read_table(prefix + ".index", verify)[1:]:
+        e = _parse_entry(val)
+        if e["dtype"] in DT and not e["slices"]:
+            out[key.decode("utf-8")] = tuple(int(v) for v in e["shape"])
+    return out
+
+
+def remap_names(wanted, available):
+    """wanted: ordered [(variable name, shape)] the graph expects; available: {variable name: shape} of the checkpoint.
+    Returns {wanted name: checkpoint name}.  Tensors are grouped by (scope path without auto-suffixes, shape).  A group whose
+    wanted names ALL exist in the checkpoint with the right shape is taken by name; otherwise the whole group is matched in
+    creation order (ascending auto-suffix) -- a shifted numbering makes SOME names collide with their neighbours' ("dense_2" of
+    the checkpoint is the graph's "dense_1"), so partial exact matches inside a group would silently load the wrong tensors --
+    and only when the group sizes agree.  Anything else stays unmatched and the caller reports it."""
+    out = {}
+    groups_w, groups_a = {}, {}
+    for name, shape in wanted:
+        st, idx = _stem(name)
+        groups_w.setdefault((st, tuple(shape)), []).append((idx, name))
+    for name, shape in available.items():
+        st, idx = _stem(name)
+        groups_a.setdefault((st, tuple(shape)), []).append((idx, name))
+    for key, ws in groups_w.items():
+        if all(n in available and tuple(available[n]) == key[1] for _, n in ws):
+            for _, n in ws:
+                out[n] = n
+            continue
+        cand = groups_a.get(key, [])
+        if len(cand) != len(ws):
+            continue
+        for (_, wn), (_, an) in zip(sorted(ws), sorted(cand)):
+            out[wn] = an
+    return out
+
+
+def restore_variables(prefix, wanted, verify=True, log=None):
+    """{wanted name: ndarray} from the bundle `prefix` (generate.py:157-161 / synthesizer.py:69-70 Saver.restore): by exact variable
+    name where the checkpoint has it, else through remap_names; every remapping is reported through `log` (default: print).
+    Raises CheckpointError listing what could not be placed."""
+    wanted = [(n, tuple(s)) for n, s in wanted]
+    shapes = bundle_shapes(prefix, verify=None)
+    mapping = remap_names(wanted, shapes)
+    missing = [n for n, _ in wanted if n not in mapping]
+    if missing:
+        raise CheckpointError("checkpoint lacks %d tensors (no variable of the same scope path and shape either), first: %s"
+                              % (len(missing), ", ".join(missing[:4])))
+    moved = [(w, a) for w, a in mapping.items() if w != a]
+    if moved:
+        say = log or print
+        say("checkpoint: %d variables restored under a different auto-generated name:" % len(moved))
+        for w, a in sorted(moved):
+            say("    %s  <-  %s" % (w, a))
+    data = read_bundle(prefix, verify=verify, names=set(mapping.values()))
+    return {w: data[a] for w, a in mapping.items()}
+
+
+def tacotron_variable_specs(specs, scope="model/inference/"):
+    """[(bundle variable name, shape)] behind `tacotron.tacotron_specs` entries (batch-norm entries are four variables)"""
+    out = []
+    for name, shape in specs:
+        if name.endswith("batch_normalization"):
+            out += [(scope + name + "/" + p, (shape[1],)) for p in BN_PARTS]
+        else:
+            out.append((scope + name, tuple(shape)))
+    return out
+
+
 def all_checkpoint_paths(logdir):
     """all_model_checkpoint_paths of the `checkpoint` state file, oldest first (tf.train.Saver's max_to_keep bookkeeping)"""
     state = os.path.join(logdir, "checkpoint")

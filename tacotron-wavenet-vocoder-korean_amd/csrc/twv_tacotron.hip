@@ -1656,10 +1656,14 @@ static void taco_build(twv_tacotron* h)
               RN = d.enc_rnn_size, A = d.attention_size, AS = d.attention_state_size, DR = d.dec_rnn_size, M = d.num_mels,
               R = d.reduction_factor, ENC = 2 * RN;
     h->emb = raw(d.n_symbols, E);
-    h->semb = raw(d.num_speakers, SE);
-    h->ndense = 3 + d.dec_layer_num;
+    // tacotron.py:63-104: the speaker tensors exist for num_speakers > 1 only; a single-speaker model (synthesizer.py:375's default)
+    // has no speaker embedding, no before_highway and zero initial states
+    h->ndense = d.num_speakers > 1 ? 3 + d.dec_layer_num : 0;
     const int dn[8] = {P1, 2 * RN, AS, DR, DR, DR, DR, DR};
-    for (int i = 0; i < h->ndense; ++i) { h->dn[i] = dn[i]; h->dW[i] = mat(SE, dn[i]); h->db[i] = vec(dn[i]); }
+    if (d.num_speakers > 1) {
+        h->semb = raw(d.num_speakers, SE);
+        for (int i = 0; i < h->ndense; ++i) { h->dn[i] = dn[i]; h->dW[i] = mat(SE, dn[i]); h->db[i] = vec(dn[i]); }
+    }
     h->pW1 = mat(E, P0); h->pb1 = vec(P0); h->pW2 = mat(P0, P1); h->pb2 = vec(P1);
     cbhg(h->enc, P1, d.enc_bank_size, d.enc_bank_channel_size, d.enc_proj_sizes, d.enc_proj_width, d.enc_highway_depth, RN);
     h->Wm = mat(ENC, A); h->Wq = mat(AS, A);
@@ -1698,7 +1702,9 @@ extern "C" int twv_tacotron_create(const twv_tacotron_dims* dims, twv_tacotron**
     if (d.dec_prenet_sizes[1] % 32 || d.dec_prenet_sizes[0] > 512 || d.num_mels * d.reduction_factor > 512 || d.dec_layer_num > 4 || d.dec_layer_num < 1)
         return twv_fail(TWV_E_UNSUPPORTED, "decoder sizes out of range");
     if (d.enc_bank_size > 16 || d.post_bank_size > 16 || d.enc_highway_depth > 8 || d.post_highway_depth > 8) return twv_fail(TWV_E_UNSUPPORTED, "bank / highway depth out of range");
-    if (d.num_speakers < 2 || d.speaker_embedding_size < 2) return twv_fail(TWV_E_UNSUPPORTED, "the deepvoice multi-speaker path needs num_speakers > 1");
+    if (d.num_speakers < 1) return twv_fail(TWV_E_INVALID, "num_speakers must be >= 1");
+    if (d.num_speakers > 1 && d.speaker_embedding_size < 2)
+        return twv_fail(TWV_E_UNSUPPORTED, "multi-speaker: the deepvoice path with speaker_embedding_size > 1 is built (tacotron.py:76-82); the get_embed tables of speaker_embedding_size == 1 are not");
     twv_tacotron* h = new twv_tacotron();
     h->d = d;
     taco_build(h);
@@ -1916,7 +1922,8 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
                                   const int32_t* speaker_ids, int batch, int t_in, void* workspace, float* mel, float* linear,
                                   float* alignments, int32_t* status, void* stream)
 {
-    if (!h || !packed || !tokens || !lengths || !speaker_ids || !workspace || !mel || !status) return twv_fail(TWV_E_INVALID, "null argument");
+    if (!h || !packed || !tokens || !lengths || !workspace || !mel || !status) return twv_fail(TWV_E_INVALID, "null argument");
+    if (!speaker_ids && h->d.num_speakers > 1) return twv_fail(TWV_E_INVALID, "speaker_ids is required for a multi-speaker model");
     if (batch < 1 || t_in < 1 || t_in > 1024) return twv_fail(TWV_E_INVALID, "batch >= 1 and 1 <= t_in <= 1024 required");
     const twv_tacotron_dims& d = h->d;
     hipStream_t st = (hipStream_t)stream;
@@ -1946,17 +1953,24 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
     float* xexch = w; w += 8LL * 2 * kXU * 512 * 2 + 64;    // XCD-local decoder: granules [8][2][kXU*512] + tickets
     // ---- tacotron.py:51-60 embedding, :67-82 speaker embedding + deep_dense (softsign)
     hipLaunchKernelGGL(tc_embed_kernel, dim3(tgrid((long long)rows * E)), dim3(256), 0, st, P + h->emb.off, tokens, rows, E, ra);
-    hipLaunchKernelGGL(tc_gather_rows_kernel, dim3(tgrid((long long)N * SE)), dim3(256), 0, st, P + h->semb.off, speaker_ids, N, SE, spk);
+    const bool multi = d.num_speakers > 1;
     // spk layout: [N][SE] at 0, then per dense i a [N][dn_i] block
-    float* sv[8]; { float* q = spk + (long long)N * 64; for (int i = 0; i < h->ndense; ++i) { sv[i] = q; q += (long long)N * h->dn[i]; } }
-    for (int i = 0; i < h->ndense; ++i)
-        launch_gemm(st, P, spk, SE, N, 1, SE, 1, h->dW[i], &h->db[i], TACT_SOFTSIGN, nullptr, nullptr, nullptr, 0, nullptr, 0, sv[i], h->dn[i], 0);
+    float* sv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // decoder initial states gathered as [N][AS + layers*DR]
     float* dinit = spk + (long long)N * 2048;
-    for (int i = 0; i < 1 + d.dec_layer_num; ++i) {
-        const int wdt = i == 0 ? AS : DR;
-        HIPCHK(hipMemcpy2DAsync(dinit + (i == 0 ? 0 : AS + (i - 1) * DR), (size_t)(AS + d.dec_layer_num * DR) * 4, sv[2 + i], (size_t)wdt * 4,
-                                (size_t)wdt * 4, N, hipMemcpyDeviceToDevice, st));
+    if (multi) {
+        hipLaunchKernelGGL(tc_gather_rows_kernel, dim3(tgrid((long long)N * SE)), dim3(256), 0, st, P + h->semb.off, speaker_ids, N, SE, spk);
+        { float* q = spk + (long long)N * 64; for (int i = 0; i < h->ndense; ++i) { sv[i] = q; q += (long long)N * h->dn[i]; } }
+        for (int i = 0; i < h->ndense; ++i)
+            launch_gemm(st, P, spk, SE, N, 1, SE, 1, h->dW[i], &h->db[i], TACT_SOFTSIGN, nullptr, nullptr, nullptr, 0, nullptr, 0, sv[i], h->dn[i], 0);
+        for (int i = 0; i < 1 + d.dec_layer_num; ++i) {
+            const int wdt = i == 0 ? AS : DR;
+            HIPCHK(hipMemcpy2DAsync(dinit + (i == 0 ? 0 : AS + (i - 1) * DR), (size_t)(AS + d.dec_layer_num * DR) * 4, sv[2 + i], (size_t)wdt * 4,
+                                    (size_t)wdt * 4, N, hipMemcpyDeviceToDevice, st));
+        }
+    } else {
+        // tacotron.py:97-104: no before_highway (sv[0] stays null: the residual is proj + inputs), zero GRU / attention-cell states
+        HIPCHK(hipMemsetAsync(dinit, 0, (size_t)N * (AS + d.dec_layer_num * DR) * 4, st));
     }
     // ---- tacotron.py:108 prenet, :113 encoder CBHG
     launch_gemm(st, P, ra, E, rows, T, E, 1, h->pW1, &h->pb1, TACT_RELU, nullptr, nullptr, nullptr, 0, nullptr, 0, rb, P0, 0);

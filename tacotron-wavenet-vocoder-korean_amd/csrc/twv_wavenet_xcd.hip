@@ -1072,6 +1072,8 @@ __device__ __forceinline__ void conv1_onehot_role(const XArgs& xa, const XStream
             if (pl.dead) break;
             const rsrc_t rs = sx.rs[k];
             const int ob = k * kConvQLdsFloats;
+            const int b = sx.b[k];
+            (void)b;
             pl.rs = rs;
             // ---- model.py:158-160 conv1d_1 + relu for output block g, as in conv1_role
             unsigned long long q;
@@ -1084,6 +1086,7 @@ __device__ __forceinline__ void conv1_onehot_role(const XArgs& xa, const XStream
             }
             unsigned long long now_arr = 0;
             if (k == 0) now_arr = __builtin_amdgcn_s_memtime();
+            XSTAMP(g == 0 && v == 0, 22);
             {
                 const unsigned hq = (unsigned)q;
                 const auto p16 = __builtin_amdgcn_permlane16_swap(hq, hq, false, false);        // [r0,r0,r2,r2], [r1,r1,r3,r3]
@@ -1101,10 +1104,12 @@ __device__ __forceinline__ void conv1_onehot_role(const XArgs& xa, const XStream
                 period = (t_arr != 0 && d < (1ull << 18)) ? d : 0;
                 t_arr = now_arr;
             }
+            XSTAMP(g == 0 && v == 0, 23);
             if (v == 0) {
                 pl.it = 0;
                 while (LDSVI(ob + O_CNT) < 8 * (t + 1)) { if (!poll_tick(pl, 62)) break; }
                 asm volatile("" ::: "memory");
+                XSTAMP(g == 0, 24);
                 float cp[16];
 #pragma unroll
                 for (int ch = 0; ch < 16; ++ch) cp[ch] = lds[ob + O_PART + ch * 64 + lane];
@@ -1115,6 +1120,7 @@ __device__ __forceinline__ void conv1_onehot_role(const XArgs& xa, const XStream
                 if (use_bias) r = r + b1v;
                 const float h = r > 0.0f ? r : 0.0f;                         // model.py:160
                 xb_store(rs, (int)XcdExch::H2 + g * 64, lane, tag, h);
+                XSTAMP(g == 0, 25);
             }
             // ---- model.py:161-165 conv1d_2, classes 32g .. 32g+31: this wave's two chunks read block v of relu(conv1d_1)
             pl.it = 0;
@@ -1124,6 +1130,7 @@ __device__ __forceinline__ void conv1_onehot_role(const XArgs& xa, const XStream
                 if (!poll_tick(pl, 63)) break;
                 __builtin_amdgcn_s_sleep(1);
             }
+            XSTAMP(g == 0 && v == 1, 34);
             {
                 const unsigned hq = (unsigned)q;
                 const auto p16 = __builtin_amdgcn_permlane16_swap(hq, hq, false, false);        // rows 0,1: h[0..15] | h[16..31]; rows 2,3: h[32..47] | h[48..63]
@@ -1132,10 +1139,12 @@ __device__ __forceinline__ void conv1_onehot_role(const XArgs& xa, const XStream
             }
             asm volatile("" ::: "memory");
             if (lane == 0) __hip_atomic_fetch_add(&LDSI(ob + O_CNT + 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            XSTAMP(g == 0 && v == 1, 35);
             if (v == 1) {
                 pl.it = 0;
                 while (LDSVI(ob + O_CNT + 1) < 8 * (t + 1)) { if (!poll_tick(pl, 64)) break; }
                 asm volatile("" ::: "memory");
+                XSTAMP(g == 0, 36);
                 float cp[16];
 #pragma unroll
                 for (int ch = 0; ch < 16; ++ch) cp[ch] = lds[ob + O_P2 + ch * 32 + (lane & 31)];
@@ -1145,6 +1154,7 @@ __device__ __forceinline__ void conv1_onehot_role(const XArgs& xa, const XStream
                 for (int ch = 1; ch < 16; ++ch) y = y + cp[ch];
                 if (use_bias) y = y + b2v;
                 if (lane < 32) xb_store(rs, (int)XcdExch::QL, ql_word, tag, y);
+                XSTAMP(g == 0, 37);
             }
         }
     }
@@ -2454,10 +2464,11 @@ int xcd_launch(const XcdLaunch& p, hipStream_t st)
     else if (!p.lay.scalar) {
         // the one-hot mu-law-256 model: its own instantiations (per-layer dumps for the 30-layer kernel only; no phase stamps)
         if (p.B > (p.lay.NL > kXcdSeg0Layers ? kXcdStreams / 2 : kXcdStreams)) return twv_fail(TWV_E_UNSUPPORTED, "the one-hot XCD kernel takes at most 32 streams (16 above 30 layers)");
-        if ((instr & 1) || (instr != 0 && p.lay.NL > kXcdSeg0Layers))
-            return twv_fail(TWV_E_UNSUPPORTED, "the one-hot XCD kernel has layer dumps up to 30 layers and no phase stamps (set option \"xcd\" = 0 for the generic kernel)");
+        if (instr == 3 || (instr != 0 && p.lay.NL > kXcdSeg0Layers))
+            return twv_fail(TWV_E_UNSUPPORTED, "the one-hot XCD kernel has layer dumps OR phase stamps, up to 30 layers (set option \"xcd\" = 0 for the generic kernel)");
         if (p.lay.NL > kXcdSeg0Layers) go(wn_xcd_generate_kernel<0, true, false, true>);
         else if (instr == 2) go(wn_xcd_generate_kernel<2, false, false, true>);
+        else if (instr == 1) go(wn_xcd_generate_kernel<1, false, false, true>);
         else if (p.B <= 8) go(wn_xcd_generate_kernel<0, false, true, true>);
         else go(wn_xcd_generate_kernel<0, false, false, true>);
     }

@@ -96,7 +96,7 @@ def main(argv=None):
         print("  Global step was: {}".format(ckpt.checkpoint_step(prefix)))
         # raw variables by name (generate.py:157): only the model's own variables are read (not the Adam moments / EMA shadows the
         # training graph also saved), every tensor's CRC-32C is checked
-        tensors = ckpt.wavenet_tensors(ckpt.read_bundle(prefix, verify=True, names=set(n for n, _ in net.specs)), net.specs)
+        tensors = ckpt.wavenet_tensors(ckpt.restore_variables(prefix, net.specs, verify=True), net.specs)     # generate.py:157-161, name-tolerant
     elif os.path.exists(wpath):
         print('Restoring model from {}'.format(config.checkpoint_dir))
         tensors = dict(np.load(wpath))

@@ -87,8 +87,9 @@ class Synthesizer(object):
         if isinstance(checkpoint_path, str) and not checkpoint_path.endswith(".npz"):
             from . import checkpoint as ckpt
             print('Loading checkpoint: %s' % checkpoint_path)
-            names = set(n for n, _ in self.model.specs)
-            tensors = ckpt.tacotron_tensors(ckpt.read_bundle(ckpt.resolve(checkpoint_path), verify=True, names=ckpt.tacotron_variable_names(names)),
+            # by variable name (synthesizer.py:69-70 Saver.restore); names TensorFlow auto-generated (dense_N, ...) may be shifted in a
+            # checkpoint written by a differently-built graph: checkpoint.restore_variables falls back to (scope, shape, creation order)
+            tensors = ckpt.tacotron_tensors(ckpt.restore_variables(ckpt.resolve(checkpoint_path), ckpt.tacotron_variable_specs(self.model.specs), verify=True),
                                             self.model.specs)
         else:
             tensors = dict(np.load(checkpoint_path)) if isinstance(checkpoint_path, str) else checkpoint_path

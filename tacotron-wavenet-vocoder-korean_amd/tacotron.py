@@ -1,7 +1,7 @@
 """Host-side mirror of the reference's Tacotron inference surface (tacotron/tacotron.py `Tacotron.initialize(...,
 rnn_decoder_test_mode=True)` and synthesizer.py `Synthesizer.load / synthesize`) over the HIP C-ABI.
 
-Default hparams path only (model_type 'deepvoice', num_speakers > 1, attention_type 'bah_mon_norm'); tokens in, mel /
+Default hparams path (model_type 'deepvoice' with num_speakers > 1, or a single speaker; attention_type 'bah_mon_norm'); tokens in, mel /
 linear / alignments out.  Text -> token ids (text/*, jamo) and Griffin-Lim are host DSP outside this path."""
 import ctypes as C
 import os
@@ -43,8 +43,12 @@ def tacotron_specs(hp, num_speakers, n_symbols=80):
     P0, P1 = hp.enc_prenet_sizes
     RN, A, AS, DR, M, R = hp.enc_rnn_size, hp.attention_size, hp.attention_state_size, hp.dec_rnn_size, hp.num_mels, hp.reduction_factor
     ENC = 2 * RN
-    s = [("embedding", (n_symbols, E)), ("speaker_embedding", (num_speakers, SE))]
-    dn = [P1, 2 * RN, AS] + [DR] * hp.dec_layer_num
+    s = [("embedding", (n_symbols, E))]
+    # tacotron.py:62-104: speaker embedding + the five deep_dense layers exist for num_speakers > 1 only; tf.layers.dense layers
+    # are auto-named dense, dense_1, ... in creation order, so the linear-spectrogram layer is "dense" in a single-speaker graph
+    dn = ([P1, 2 * RN, AS] + [DR] * hp.dec_layer_num) if num_speakers > 1 else []
+    if num_speakers > 1:
+        s += [("speaker_embedding", (num_speakers, SE))]
     for i, n in enumerate(dn):
         nm = "dense" if i == 0 else "dense_%d" % i
         s += [(nm + "/kernel", (SE, n)), (nm + "/bias", (n,))]
@@ -68,7 +72,7 @@ def tacotron_specs(hp, num_speakers, n_symbols=80):
     s += [("decoder/output_projection_wrapper/kernel", (DR, M * R)), ("decoder/output_projection_wrapper/bias", (M * R,))]
     s += _cbhg_specs("post_cbhg", M, hp.post_bank_size, hp.post_bank_channel_size, tuple(hp.post_proj_sizes), hp.post_proj_width,
                      hp.post_highway_depth, hp.post_rnn_size)
-    nm = "dense_%d" % len(dn)
+    nm = "dense_%d" % len(dn) if dn else "dense"
     s += [(nm + "/kernel", (2 * hp.post_rnn_size, hp.num_freq)), (nm + "/bias", (hp.num_freq,))]
     return s
 
@@ -108,8 +112,9 @@ class Tacotron(object):
 
     def __init__(self, hparams, num_speakers=2, n_symbols=80, device="cuda:0"):
         hp = self._hparams = hparams
-        if hp.model_type != 'deepvoice' or hp.attention_type != 'bah_mon_norm' or num_speakers < 2:
-            raise NotImplementedError("only the default path is built: model_type 'deepvoice', attention_type 'bah_mon_norm', num_speakers > 1")
+        if hp.attention_type != 'bah_mon_norm' or num_speakers < 1 or (num_speakers > 1 and (hp.model_type != 'deepvoice' or hp.speaker_embedding_size == 1)):
+            raise NotImplementedError("built: attention_type 'bah_mon_norm'; single speaker (tacotron.py:97-104), or model_type 'deepvoice' with "
+                                      "speaker_embedding_size > 1 (tacotron.py:76-82)")
         self.num_speakers = num_speakers
         self.device = torch.device(device)
         self.specs = tacotron_specs(hp, num_speakers, n_symbols)
@@ -167,7 +172,9 @@ class Tacotron(object):
             tok = torch.as_tensor(np.asarray(inputs, np.int32), device=self.device).contiguous()
             N, T = tok.shape
             ln = torch.as_tensor(np.asarray(input_lengths, np.int32), device=self.device).contiguous()
-            sp = torch.as_tensor(np.asarray(speaker_id, np.int32), device=self.device).contiguous()
+            sp = None                                        # synthesizer.py:150-151: no speaker_id feed for a single-speaker model
+            if self.num_speakers > 1:
+                sp = torch.as_tensor(np.asarray(speaker_id, np.int32), device=self.device).contiguous()
             need = self._L.twv_tacotron_workspace_bytes(self._h, N, T) // 4
             if self._ws is None or self._ws.numel() < need:
                 self._ws = torch.empty(need, dtype=torch.float32, device=self.device)

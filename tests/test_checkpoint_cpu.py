@@ -246,3 +246,91 @@ def test_sharded_bundle_and_unsupported_entries(tmp_path):
     open(str(tmp_path / "p.data-00000-of-00001"), "wb").write(bytes(16))
     with pytest.raises(ck.CheckpointError, match="partitioned"):
         ck.read_bundle(str(tmp_path / "p"))
+
+
+def _shift_auto_names(variables, base, delta, scope="model/inference/"):
+    """rename every top-level `<scope><base>[_N]/...` variable to `<base>_{N+delta}` (N = 0 for the bare name)"""
+    out = {}
+    for k, v in variables.items():
+        rest = k[len(scope):] if k.startswith(scope) else None
+        if rest is not None:
+            head, _, tail = rest.partition("/")
+            b, i = ck._split_auto(head)
+            if b == base and i is not None:
+                n = i + delta
+                out[scope + (base if n == 0 else "%s_%d" % (base, n)) + "/" + tail] = v
+                continue
+        out[k] = v
+    return out
+
+
+def test_restore_tolerates_shifted_auto_generated_names(tmp_path, capsys):
+    """the names TensorFlow auto-generates (dense, dense_1, ...) are this project's RECOLLECTION of its numbering
+    rule.  A checkpoint whose graph created one more unnamed dense layer first carries the same tensors as dense_1 .. dense_6: the
+    restore falls back to (scope path without the suffix, shape, creation order), lists what it remapped, and loads the same model."""
+    from twvk_amd.hparams import hparams as hp
+    from twvk_amd.tacotron import tacotron_specs
+    specs = tacotron_specs(hp, 2)
+    rng = np.random.RandomState(0)
+    tensors = {n: rng.randn(*s).astype(np.float32) for n, s in specs}
+    variables = ck.tacotron_variables(tensors)
+    # plus what a training checkpoint also holds: Adam slots and the global step
+    extra = {k + "/Adam": np.zeros_like(v) for k, v in list(variables.items())[:5]}
+    extra["global_step"] = np.array(7, np.int64)
+    shifted = _shift_auto_names(variables, "dense", +1)
+    assert "model/inference/dense_6/kernel" in shifted and "model/inference/dense/kernel" not in shifted
+    assert "model/inference/prenet/dense_1/kernel" in shifted           # explicitly named layers (modules.py:20) are not touched
+    ck.write_bundle(str(tmp_path / "model.ckpt-1"), dict(shifted, **extra))
+    wanted = ck.tacotron_variable_specs(specs)
+    got = ck.tacotron_tensors(ck.restore_variables(str(tmp_path / "model.ckpt-1"), wanted), specs)
+    for n, _ in specs:
+        assert np.array_equal(got[n], tensors[n]), n
+    report = capsys.readouterr().out
+    assert "12 variables restored under a different auto-generated name" in report
+    assert "model/inference/dense/kernel  <-  model/inference/dense_1/kernel" in report
+    assert "model/inference/dense_5/bias  <-  model/inference/dense_6/bias" in report
+    # the unshifted checkpoint restores silently
+    ck.write_bundle(str(tmp_path / "model.ckpt-2"), variables)
+    got2 = ck.restore_variables(str(tmp_path / "model.ckpt-2"), wanted)
+    assert capsys.readouterr().out == "" and set(got2) == set(n for n, _ in wanted)
+    # single-speaker graph (tacotron.py:97-104): its only unnamed dense layer is the linear projection, "dense"; a checkpoint that
+    # calls it dense_3 still loads, one that lacks it does not
+    specs1 = tacotron_specs(hp, 1)
+    t1 = {n: rng.randn(*s).astype(np.float32) for n, s in specs1}
+    v1 = _shift_auto_names(ck.tacotron_variables(t1), "dense", +3)
+    ck.write_bundle(str(tmp_path / "model.ckpt-3"), v1)
+    g1 = ck.tacotron_tensors(ck.restore_variables(str(tmp_path / "model.ckpt-3"), ck.tacotron_variable_specs(specs1), log=lambda m: None), specs1)
+    assert np.array_equal(g1["dense/kernel"], t1["dense/kernel"])
+    del v1["model/inference/dense_3/kernel"]
+    ck.write_bundle(str(tmp_path / "model.ckpt-4"), v1)
+    with pytest.raises(ck.CheckpointError, match="lacks 1 tensors"):
+        ck.restore_variables(str(tmp_path / "model.ckpt-4"), ck.tacotron_variable_specs(specs1))
+    # an ambiguous group (two candidates of the same stem and shape for one wanted tensor) is refused, not guessed
+    v2 = dict(ck.tacotron_variables(t1))
+    lin = v2.pop("model/inference/dense/kernel")
+    v2["model/inference/dense_1/kernel"] = lin
+    v2["model/inference/dense_2/kernel"] = lin + 1
+    ck.write_bundle(str(tmp_path / "model.ckpt-5"), v2)
+    with pytest.raises(ck.CheckpointError):
+        ck.restore_variables(str(tmp_path / "model.ckpt-5"), ck.tacotron_variable_specs(specs1))
+
+
+def test_wavenet_restore_tolerates_shifted_conv1d_names(tmp_path):
+    """generate.py:157-161: wavenet/conv1d (causal), conv1d_1, conv1d_2 (post-processing) are auto-numbered tf.layers.conv1d layers"""
+    from twvk_amd import weights as W
+    specs = W.tensor_specs(3)
+    tensors = W.random_tensors(specs, seed=1, scale=0.1)
+    shifted = {}
+    for k, v in tensors.items():
+        parts = k.split("/")
+        b, i = ck._split_auto(parts[1])
+        if b == "conv1d" and i is not None and len(parts) == 3:
+            parts[1] = "conv1d_%d" % (i + 2)
+        shifted["/".join(parts)] = v
+    assert "wavenet/conv1d_2/kernel" in shifted and "wavenet/conv1d/kernel" not in shifted
+    ck.write_bundle(str(tmp_path / "model.ckpt-9"), shifted)
+    notes = []
+    got = ck.wavenet_tensors(ck.restore_variables(str(tmp_path / "model.ckpt-9"), specs, log=notes.append), specs)
+    for n, _ in specs:
+        assert np.array_equal(got[n], tensors[n]), n
+    assert any("wavenet/conv1d/kernel  <-  wavenet/conv1d_2/kernel" in m for m in notes)

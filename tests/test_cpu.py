@@ -289,6 +289,35 @@ def test_restatement_fixtures_mulaw_and_tacotron(oracle):
     assert t["mel"].shape == (3, 30, 80) and t["linear"].shape == (3, 30, 129) and t["alignments"].shape == (3, 17, 6)
 
 
+@pytest.mark.parametrize("n_speakers", [2, 1])
+def test_torch_tacotron_reference_agrees_with_the_c_restatement(oracle, n_speakers):
+    """oracle/tacotron.c gets a second opinion -- tests/torch_tacotron_ref.py, a float64 torch restatement of
+    tacotron.py:36-235 + modules.py + rnn_wrappers.py written from the reference source and TensorFlow's published semantics, not from
+    the C file.  Default dims (hparams.py:126-165), 25 decoder steps, ragged lengths; multi-speaker (deepvoice) and single speaker.
+    1e-5 absolute on mel / linear (values of order 1), 1e-6 on the alignments: float32 chain vs float64."""
+    import torch_tacotron_ref as R
+    d = oracle.taco_dims(max_iters=25, n_speakers=n_speakers)
+    w = oracle.taco_random_tensors(d, seed=3)
+    blob = oracle.taco_blob(d, w)
+    rng = np.random.RandomState(4)
+    N, T = 3, 19
+    lengths = np.array([19, 12, 7], np.int32)
+    tok = rng.randint(2, 80, (N, T)).astype(np.int32)
+    for n, ln in enumerate(lengths):
+        tok[n, ln - 1] = 1
+        tok[n, ln:] = 0
+    spk = np.array([0, 1, 0], np.int32) if n_speakers > 1 else None
+    mel, lin, al = oracle.taco_infer(d, blob, tok, lengths, spk)
+    m2, l2, a2 = R.infer(w, d, tok, lengths, spk)
+    assert mel.shape == m2.shape == (N, 125, 80) and lin.shape == l2.shape and al.shape == a2.shape == (N, T, 25)
+    assert np.abs(mel - m2).max() <= 1e-5, np.abs(mel - m2).max()
+    assert np.abs(lin - l2).max() <= 1e-5, np.abs(lin - l2).max()
+    assert np.abs(al - a2).max() <= 1e-6, np.abs(al - a2).max()
+    assert np.abs(m2).max() > 0.5 and a2[1, 12:].max() == 0.0           # a real signal; nothing attends past input_lengths
+    if n_speakers == 1:                                                  # tacotron.py:97-104: no speaker tensors at all
+        assert "speaker_embedding" not in w and w["dense/kernel"].shape == (2 * d.post_rnn, d.num_freq) and "dense_1/kernel" not in w
+
+
 # ---------------------------------------------------------------- host side of the product
 def test_blob_layout_agrees_with_oracle(oracle):
     """the product's canonical blob (weights.py + the C-ABI's count) and the oracle's independent one"""

@@ -26,11 +26,11 @@ def _hp(**kw):
     return hp
 
 
-def _case(oracle, hp, N, T, lengths, seed=0):
+def _case(oracle, hp, N, T, lengths, seed=0, num_speakers=2):
     from twvk_amd.tacotron import Tacotron
     d = oracle.taco_dims(enc_bank=hp.enc_bank_size, post_bank=hp.post_bank_size, enc_hw_depth=hp.enc_highway_depth,
                          post_hw_depth=hp.post_highway_depth, dec_layers=hp.dec_layer_num, max_iters=hp.max_iters, num_freq=hp.num_freq,
-                         r=hp.reduction_factor)
+                         r=hp.reduction_factor, n_speakers=num_speakers)
     tensors = oracle.taco_random_tensors(d, seed=seed)
     blob = oracle.taco_blob(d, tensors)
     rng = np.random.RandomState(seed + 1)
@@ -38,8 +38,8 @@ def _case(oracle, hp, N, T, lengths, seed=0):
     for n, ln in enumerate(lengths):
         tok[n, ln - 1] = 1                      # EOS
         tok[n, ln:] = 0                         # pad
-    spk = (np.arange(N) % 2).astype(np.int32)
-    m = Tacotron(hp, num_speakers=2)
+    spk = (np.arange(N) % 2).astype(np.int32) if num_speakers > 1 else None
+    m = Tacotron(hp, num_speakers=num_speakers)
     assert [n for n, _ in m.specs] == [n for n, _ in oracle.taco_tensor_specs(d)]
     m.load_weights(tensors)
     return d, blob, tok, np.asarray(lengths, np.int32), spk, m
@@ -55,6 +55,26 @@ def test_tacotron_small(torch_cuda, oracle):
     assert first_mismatch(mel.cpu().numpy(), mel_o) is None, ("mel", first_mismatch(mel.cpu().numpy(), mel_o))
     assert first_mismatch(lin.cpu().numpy(), lin_o) is None, ("linear", first_mismatch(lin.cpu().numpy(), lin_o))
     assert np.all(al.cpu().numpy()[1, 12:] == 0)                       # nothing attends past input_lengths
+
+
+@pytest.mark.parametrize("dims", ["small", "default"])
+def test_tacotron_single_speaker(torch_cuda, oracle, dims):
+    """tacotron.py:97-104 (num_speakers == 1, the reference CLI's default, synthesizer.py:375): no speaker embedding, no before_highway,
+    zero initial states of the encoder biGRU, the attention cell and the decoder GRUs; the linear layer is the graph's first
+    tf.layers.dense ("dense").  Bit for bit against the checker, ragged lengths."""
+    hp = _hp(max_iters=6, enc_bank_size=4, post_bank_size=3, num_freq=129) if dims == "small" else _hp(max_iters=25)
+    N, T, lengths = (3, 19, [19, 12, 7]) if dims == "small" else (5, 40, [40, 33, 21, 8, 1])
+    d, blob, tok, ln, spk, m = _case(oracle, hp, N, T, lengths, seed=31, num_speakers=1)
+    names = [n for n, _ in m.specs]
+    assert "speaker_embedding" not in names and "dense/kernel" in names and "dense_1/kernel" not in names
+    mel_o, lin_o, al_o = oracle.taco_infer(d, blob, tok, ln, None)
+    mel, lin, al = m.infer(tok, ln, None)
+    assert first_mismatch(al.cpu().numpy(), al_o) is None, ("alignments", first_mismatch(al.cpu().numpy(), al_o))
+    assert first_mismatch(mel.cpu().numpy(), mel_o) is None, ("mel", first_mismatch(mel.cpu().numpy(), mel_o))
+    assert first_mismatch(lin.cpu().numpy(), lin_o) is None, ("linear", first_mismatch(lin.cpu().numpy(), lin_o))
+    # a speaker id passed to a single-speaker model is ignored (synthesizer.py:150-151 feeds none)
+    mel2, _, _ = m.infer(tok, ln, np.zeros(N, np.int32), want_linear=False, want_alignments=False)
+    assert first_mismatch(mel2.cpu().numpy(), mel_o) is None
 
 
 def test_committed_restatement_fixture_tacotron(torch_cuda, oracle):
@@ -217,6 +237,14 @@ def test_synthesizer_cli(torch_cuda, oracle, tmp_path):
     assert synth_main(["--load_path", str(logdir), "--sample_path", str(out), "--tokens", "5,9,33,12,1", "--num_speakers", "2",
                        "--speaker_id", "1", "--seed", "3"]) is True
     assert len(list(out.glob("*.wav"))) == 1 and len(list(out.glob("*.npy"))) == 1
+    # the CLI's own default (--num_speakers 1, synthesizer.py:375): a single-speaker checkpoint
+    d1 = oracle.taco_dims(max_iters=4, num_freq=hp.num_freq, n_speakers=1)
+    logdir1 = tmp_path / "logdir1"; logdir1.mkdir()
+    save_hparams(str(logdir1), hp)
+    ckpt.write_bundle(str(logdir1 / "model.ckpt-500"), ckpt.tacotron_variables(oracle.taco_random_tensors(d1, seed=6)))
+    out1 = tmp_path / "samples1"
+    assert synth_main(["--load_path", str(logdir1), "--sample_path", str(out1), "--tokens", "5,9,33,12,1", "--seed", "3"]) is True
+    assert len(list(out1.glob("*.wav"))) == 1
 
 
 def test_xcd_local_decoder_at_bench_geometry(torch_cuda, oracle):
