@@ -939,7 +939,10 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
         if (wave + 16 < ntn_) load_tile_b(t2, rs, lane * 16, decg_off(wn_, q2_, ncn_, gn_, lgn_));                               \
     }
     DECG_PREFETCH(0)
-#define TWV_STAMP(k) if (PROF && a.prof && blockIdx.x == 0 && tid == 0) a.prof[it * 16 + (k)] = __builtin_amdgcn_s_memtime();
+// instrumented build (its own instantiation): workgroup 0, thread 0 stamps s_memtime (calibrated against the launch's event time) into prof[it][64]:
+//   4*st + 0 stage start | + 1 this wave's tile dots done | + 2 chunk sums, bias, activation, publish done | + 3 gathered + barrier
+//   48 score chunk dots done | 49 p gathered | 50 recurrence done | 51 context partials done | 52 context gathered | 53 end of the step
+#define TWV_STAMP(k) if (PROF && a.prof && blockIdx.x == 0 && tid == 0) a.prof[it * 64 + (k)] = __builtin_amdgcn_s_memtime();
 
     for (int it = 0; it < a.iters && ok; ++it) {
         for (int st = 0; st < nst && ok; ++st) {
@@ -953,8 +956,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
             const int nchunk = (K + 31) >> 5, nblk = (N + 63) >> 6;
             const int nmine = nblk > gg ? (nblk - gg + GG - 1) >> lgg : 0;
             const int ntile = nmine * nchunk;
-            if (st == 0) { TWV_STAMP(0) }
-            if (PROF && st == 5) { TWV_STAMP(10) }
+            TWV_STAMP(4 * st + 0)
             // ---- this workgroup's tiles: wave w takes local tiles w, w+8, ... (three in flight), partials to LDS.  The first three
             // were requested while the previous stage was still combining / exchanging (weights do not depend on data).
             {
@@ -986,11 +988,9 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                         if (i + 40 < ntile) load_tile_b(t2, rs, vo, decg_off(w_bytes, p2, nchunk, gg, lgg));
                     }
                 }
-                if (PROF && st == 5) { TWV_STAMP(11) }
+                TWV_STAMP(4 * st + 1)
             }
-            if (PROF && st == 5) { TWV_STAMP(12) }
             __syncthreads();
-            if (PROF && st == 5) { TWV_STAMP(13) }
             // ---- epilogue: chunk sums in order (AC-1) + bias + activation; split stages publish and all-gather
             {
                 const bool xch = split && G > 1;
@@ -1007,12 +1007,12 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                         if (xch) decg_store(Xb + j, ep, v); else lds[dst + j] = v;
                     }
                 }
-                if (PROF && st == 5) { TWV_STAMP(14) }
+                TWV_STAMP(4 * st + 2)
                 // the next stage's first tiles are requested only now: this workgroup's values are already on their way to the others
                 DECG_PREFETCH(st + 1 < nst ? st + 1 : 0)
                 if (xch) decg_gather(Xb, N, ep, dst, tid, o_abort);
-                if (PROF && st == 5) { TWV_STAMP(15) }
                 __syncthreads();
+                TWV_STAMP(4 * st + 3)
                 ok = LDSI(o_abort) == 0;
             }
             // ---- what follows the matvec
@@ -1020,7 +1020,6 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                 for (int i = tid; i < ENC; i += 512) lds[o_cat + D1 + i] = lds[o_ctx + i];
                 for (int i = tid; i < AS; i += 512) lds[o_cat + D1 + ENC + i] = lds[o_ha + i];
                 __syncthreads();
-                TWV_STAMP(1)
             } else if (post == DP_GATES) {               // tf.contrib.rnn.GRUCell, gate order r | u: keep h, cat <- [x, r*h]
                 const int nin = __builtin_amdgcn_readfirstlane(LDSI(q + DS_P0)), U = __builtin_amdgcn_readfirstlane(LDSI(q + DS_P1));
                 for (int i = tid; i < U; i += 512) {
@@ -1044,11 +1043,9 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                     }
                 }
                 __syncthreads();
-                if (o_next < 0) { TWV_STAMP(2) }
             } else if (post == DP_PROJ) {
                 for (int i = tid; i < DR; i += 512) { lds[o_cat + i] = lds[o_y + i]; lds[o_cat + DR + i] = lds[o_hr0 + i]; }
                 __syncthreads();
-                TWV_STAMP(7)
             } else if (post == DP_OUT) {                 // tacotron.py:204 reshape; helpers.py:40 last frame fed back
                 for (int i = tid; i < M * R; i += 512) {
                     const float v = lds[o_out + i];
@@ -1056,9 +1053,8 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                     if (i >= M * (R - 1)) lds[o_frame + i - M * (R - 1)] = v;
                 }
                 __syncthreads();
-                TWV_STAMP(9)
+                TWV_STAMP(53)
             } else if (post == DP_QUERY) {
-                TWV_STAMP(3)
                 // [RECALLED-TF BahdanauMonotonicAttention.__call__] score for the time steps t = g, g+G, ...: one (t, chunk) per thread
                 const int nt = T > g ? (T - g + G - 1) >> lg : 0;
                 // one thread per (t, chunk, chain k): s_k = fma chain over j = k, k+4, ..., k+28; the four chains of a chunk sit in
@@ -1084,6 +1080,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                     if (live && k == 0) lds[o_scp + tl * 8 + ch] = pr + p2;
                 }
                 __syncthreads();
+                TWV_STAMP(48)
                 {
                     ++ep;
                     unsigned long long* Xb = X + (ep & 1) * kExN;
@@ -1099,7 +1096,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                     __syncthreads();
                     ok = LDSI(o_abort) == 0;
                 }
-                TWV_STAMP(4)
+                TWV_STAMP(49)
                 // monotonic attention recurrence (redundant in every workgroup), all in wave 0 and in registers:
                 // cumprod(1 - p) as exp(exclusive cumsum(log(clip(1 - p)))) [RECALLED-TF safe_cumprod], then
                 // alignments = p * cumprod * inclusive cumsum(previous / clip(cumprod, 1e-10, 1))
@@ -1129,7 +1126,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                     for (int t = T + lane; t < Tp; t += 64) lds[o_al + t] = 0.0f;
                 }
                 __syncthreads();
-                TWV_STAMP(5)
+                TWV_STAMP(50)
                 // rnn_wrappers.py:390 context = alignments . values: workgroup g takes the columns [g*ENC/G, (g+1)*ENC/G) -- its XCD's
                 // L2 then only ever sees that column slice of the encoder memory -- one thread per (column, 32-step chunk), all-gather
                 {
@@ -1158,6 +1155,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                         lds[o_part + ch * ncol + cl] = (s0 + s1) + (s2 + s3);
                     }
                     __syncthreads();
+                    TWV_STAMP(51)
                     ++ep;
                     unsigned long long* Xb = X + (ep & 1) * kExN;
                     if (tid < ncol) {
@@ -1169,7 +1167,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                     __syncthreads();
                     ok = LDSI(o_abort) == 0;
                 }
-                TWV_STAMP(6)
+                TWV_STAMP(52)
                 for (int i = tid; i < AS; i += 512) lds[o_cat + i] = lds[o_ha + i];
                 for (int i = tid; i < ENC; i += 512) lds[o_cat + AS + i] = lds[o_ctx + i];
                 __syncthreads();
