@@ -22,11 +22,13 @@ def random_tensors(specs, seed=0):
     return t
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--steps", type=int, default=3)
-ap.add_argument("--no-linear", action="store_true"); ap.add_argument("--decoder-groups", type=int, default=0); args = ap.parse_args()
+ap.add_argument("--no-linear", action="store_true"); ap.add_argument("--decoder-groups", type=int, default=0)
+ap.add_argument("--gemm-group", type=int, default=-1, help="0: one launch per GEMM and separate highway kernels (A/B against the grouped launches)"); args = ap.parse_args()
 hp = twvk_amd.default_hparams()
 m = Tacotron(hp, num_speakers=2)
 m.load_weights(random_tensors(m.specs))
 if args.decoder_groups: m.set_option("decoder_groups", args.decoder_groups)
+if args.gemm_group >= 0: m.set_option("gemm_group", args.gemm_group)
 rng = np.random.RandomState(1)
 N, T = args.batch, 101
 tok = rng.randint(2, 80, (N, T)).astype(np.int32); tok[:, -1] = 1

@@ -18,11 +18,13 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include "../../include/twv_amd.h"
 #include "twv_dev.hpp"
 #include "twv_dpp.hpp"
 
 static int g_gemm_valu = 0;            // "gemm_valu" option: 1 = the VALU kernel (cross-check of the MFMA one)
+static int g_gemm_group = 1;           // "gemm_group" option: 0 = one launch per GEMM, separate highway kernels (A/B runs, cross-check)
 // "gemm_timing" option (measurement aid, bench.py's `tacotron.roofline`): every GEMM launch is bracketed by a pair of HIP events on
 // its stream and its useful FLOPs (2 * rows * K * N, unpadded) are counted; twv_tacotron_gemm_stats sums both since the option was set.
 struct GemmStat {
@@ -58,6 +60,7 @@ struct GemmArgs {
     const float* add1; int ld1;           // + add1[row, n]
     const float* add2; int ld2;           // + add2[sequence, n]
     float* Y; int ldy, col0;
+    const float* bias2; int mode;         // mode 1 (MFMA kernel only): highway pair tiles -- see mm_body
 };
 constexpr int kGemmRows = 16, kGemmKS = 512;
 
@@ -159,14 +162,23 @@ __device__ __forceinline__ void mm_load_a(MmA& A, const GemmArgs& a, rsrc_t rx, 
     }
 }
 
-__global__ void __launch_bounds__(256) tc_gemm_mfma_kernel(GemmArgs a)
+// mode 1, the HIGHWAY layer in one launch (modules.py:83-89): the weight tiles interleave the two dense kernels -- tile nb holds columns
+// [32 nb, 32 nb + 32) of H in lanes 0-31 and the same columns of T in lanes 32-63 -- so a wave's two column halves are H and T of the
+// SAME 32 outputs and the epilogue finishes the layer: relu(H + bias) * sigmoid(T + bias2) + x * (1 - sigmoid(..)), x = add1 (the layer's
+// input, which is also the A operand: the output goes to another buffer).  Same operations in the same order as the two GEMMs +
+// tc_highway_kernel it replaces.
+// (MODE is a template parameter and `a` travels by value: with a run-time mode test and a reference into the kernel arguments the
+// compiler scheduled the chunk loop with s_waitcnt vmcnt(0) in front of the MFMAs -- the next chunk's prefetch waited for right behind
+// its issue -- and every launch ran 35-50 % longer)
+template <int MODE>
+__device__ __forceinline__ void mm_body(const GemmArgs a, const int bx, const int by)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;                  // wave tile: rows wr*32.., columns (2*blockIdx.y + wc)*64..
-    const int row0 = blockIdx.x * kMmRows + wr * 32;
+    const int wr = wave >> 1, wc = wave & 1;                  // wave tile: rows wr*32.., columns (2*by + wc)*64..
+    const int row0 = bx * kMmRows + wr * 32;
     const int nblk_total = (a.N + 63) / 64, nchunk = (a.K + 31) / 32;
-    const int nb = blockIdx.y * 2 + wc;
+    const int nb = by * 2 + wc;
     if (nb >= nblk_total) return;
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     f32x16 tot0 = zero, tot1 = zero;                          // column halves
@@ -193,24 +205,52 @@ __global__ void __launch_bounds__(256) tc_gemm_mfma_kernel(GemmArgs a)
             load_tile(tn, wt + (long long)chn * kTile, lane);
             mm_load_a(An, a, rx, r, (ch + 1) * 32 + hh, tap, c);
         }
-        f32x16 acc0[4], acc1[4];
+        // the prefetch stays HERE: left to itself the scheduler may sink the twelve loads down to their first uses in the next trip
+        // (fewer live registers, but then every MFMA group waits for its operand with vmcnt(0): measured 35-50 % longer launches when an
+        // unrelated edit of the epilogue tipped its heuristic that way)
+        __builtin_amdgcn_sched_barrier(0);
+        // The two column halves one after the other, on ONE set of four accumulators (64 registers instead of 128): together with the
+        // waves-per-SIMD bound of the kernels this keeps a wave under 256 registers -- two waves per SIMD, so one wave's chunk sums
+        // and address arithmetic run under the other's MFMAs (inside a wave they do not overlap at all) -- and the accumulators stay
+        // in ordinary VGPRs: the v_pk_add_f32 of the chunk sums read them directly instead of through 128 v_accvgpr_read per chunk.
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                         // k pair (j + 8i, j + 8i + 4)
+        for (int h = 0; h < 2; ++h) {
+            f32x16 acc[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {                     // chain
-                const int ka = j + 8 * i;
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tl.w[ka]), __float_as_uint(tl.w[ka + 4]), false, false);
-                const float b0 = __uint_as_float(sw[0]), b1 = __uint_as_float(sw[1]);
-                const float a0 = A.q[i][j];
-                acc0[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, i == 0 ? zero : acc0[j], 0, 0, 0);
-                acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, i == 0 ? zero : acc1[j], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {                     // k pair (j + 8i, j + 8i + 4)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                 // chain
+                    const int ka = j + 8 * i;
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tl.w[ka]), __float_as_uint(tl.w[ka + 4]), false, false);
+                    const float bh = __uint_as_float(sw[h]);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.q[i][j], bh, i == 0 ? zero : acc[j], 0, 0, 0);
+                }
+            }
+            const f32x16 cs = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            if (h == 0) tot0 = ch == 0 ? cs : tot0 + cs;
+            else tot1 = ch == 0 ? cs : tot1 + cs;
+        }
+        tl = tn; A = An;
+    }
+    if constexpr (MODE == 1) {                                // highway pair: tot0 = H, tot1 = T of output column n
+        const int n = nb * 32 + (lane & 31);
+        if (2 * n < a.N) {
+            const float bh = a.bias[n], bt = a.bias2[n];
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = row0 + (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
+                if (row < a.rows) {
+                    float hv = tot0[rr] + bh;
+                    hv = hv > 0.0f ? hv : 0.0f;
+                    const float tv = sigmoid_e(tot1[rr] + bt);
+                    const float x = a.add1[(long long)row * a.ld1 + n];
+                    const float p0 = hv * tv, p1 = 1.0f - tv;
+                    const float p2 = x * p1;
+                    a.Y[(long long)row * a.ldy + a.col0 + n] = p0 + p2;
+                }
             }
         }
-        const f32x16 c0 = (acc0[0] + acc0[1]) + (acc0[2] + acc0[3]);
-        const f32x16 c1 = (acc1[0] + acc1[1]) + (acc1[2] + acc1[3]);
-        tot0 = ch == 0 ? c0 : tot0 + c0;
-        tot1 = ch == 0 ? c1 : tot1 + c1;
-        tl = tn; A = An;
+        return;
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -233,6 +273,32 @@ __global__ void __launch_bounds__(256) tc_gemm_mfma_kernel(GemmArgs a)
             }
         }
     }
+}
+#define TWV_TWO_WAVES __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(256) TWV_TWO_WAVES tc_gemm_mfma_kernel(GemmArgs a) { mm_body<0>(a, blockIdx.x, blockIdx.y); }
+__global__ void __launch_bounds__(256) TWV_TWO_WAVES tc_gemm_mfma_highway_kernel(GemmArgs a) { mm_body<1>(a, blockIdx.x, blockIdx.y); }
+
+// SEVERAL problems in one launch: the conv bank of a CBHG is 16 (encoder) / 8 (post-net) independent GEMMs over the
+// same rows (modules.py:30-35), the four input halves of the biGRU kernels and the five speaker dense layers likewise.  One at a time
+// each fills a fraction of the chip (3232 encoder rows = 51 row tiles) and pays its own launch; here the workgroups of all of them form
+// one grid, deepest contraction first.  The problems travel in the kernel arguments.
+constexpr int kGroupMax = 16;
+struct GemmGroup {
+    int n;
+    int start[kGroupMax + 1];             // first linear workgroup of problem p
+    int nby[kGroupMax];                   // its column blocks (of 128)
+    GemmArgs a[kGroupMax];
+};
+__global__ void __launch_bounds__(256) TWV_TWO_WAVES tc_gemm_mfma_group_kernel(GemmGroup g)
+{
+    int p = 0;
+    const int wg = blockIdx.x;
+#pragma unroll 1
+    while (p + 1 < g.n && wg >= g.start[p + 1]) ++p;
+    const int local = wg - g.start[p];
+    const int by = local % g.nby[p], bx = local / g.nby[p];
+    const GemmArgs a = g.a[p];
+    mm_body<0>(a, bx, by);
 }
 
 // Few rows, deep contraction (encoder CBHG: 3232 rows, K up to 6144): the 64-row kernel would fill ~50 CUs and run 192 chunks
@@ -1599,6 +1665,7 @@ struct TCbhg {
     TMat pW[2]; TVec pb[2], pinv[2], pshift[2];
     int has_dense; TMat dW; TVec db;
     TMat hH[8], hT[8]; TVec hHb[8], hTb[8];
+    TMat hHT[8];                    // highway pair tiles: tile nb = [H columns 32 nb .. | T columns 32 nb ..] (mm_body mode 1)
     TMat gWgx[2], gWgh[2], gWcx[2], gWch[2]; TVec gbg[2], gbc[2];
 };
 struct twv_tacotron {
@@ -1644,7 +1711,16 @@ static void taco_build(twv_tacotron* h)
         for (int i = 0; i < 2; ++i) { c.pW[i] = mat(pw * cin, proj[i]); c.pb[i] = vec(proj[i]); c.pinv[i] = vec(proj[i]); c.pshift[i] = vec(proj[i]); cin = proj[i]; }
         c.has_dense = proj[1] != rnn;
         if (c.has_dense) { c.dW = mat(proj[1], rnn); c.db = vec(rnn); }
-        for (int i = 0; i < depth; ++i) { c.hH[i] = mat(rnn, rnn); c.hHb[i] = vec(rnn); c.hT[i] = mat(rnn, rnn); c.hTb[i] = vec(rnn); }
+        for (int i = 0; i < depth; ++i) {
+            const long long sH = src;
+            c.hH[i] = mat(rnn, rnn); c.hHb[i] = vec(rnn);
+            const long long sT = src;
+            c.hT[i] = mat(rnn, rnn); c.hTb[i] = vec(rnn);
+            // the same two kernels once more as pair tiles: rnn/32 tiles per chunk, lanes 0-31 from H, lanes 32-63 from T
+            c.hHT[i] = TMat{dst, rnn, 2 * rnn};
+            h->items.push_back({2, sH, dst, rnn, rnn, (int)(sT - sH), 0});
+            dst += (long long)(rnn / 32) * ((rnn + 31) / 32) * kTile;
+        }
         for (int dr = 0; dr < 2; ++dr) {
             gru_split(rnn, rnn, 2 * rnn, c.gWgx[dr], c.gWgh[dr]); c.gbg[dr] = vec(2 * rnn);
             gru_split(rnn, rnn, rnn, c.gWcx[dr], c.gWch[dr]); c.gbc[dr] = vec(rnn);
@@ -1715,6 +1791,7 @@ extern "C" int twv_tacotron_set_option(twv_tacotron* h, const char* name, int va
 {
     if (!h || !name) return twv_fail(TWV_E_INVALID, "null argument");
     if (!strcmp(name, "gemm_valu")) { g_gemm_valu = value ? 1 : 0; return TWV_OK; }
+    if (!strcmp(name, "gemm_group")) { g_gemm_group = value ? 1 : 0; return TWV_OK; }   // 0: one launch per GEMM, separate highway kernels (A/B runs, cross-check)
     if (!strcmp(name, "gemm_timing")) {   // 1: start counting (resets the sums), 0: stop
         g_gemm_stat.on = value != 0;
         g_gemm_stat.flop = 0.0; g_gemm_stat.launches = 0; g_gemm_stat.used = 0;
@@ -1805,6 +1882,11 @@ extern "C" int twv_tacotron_pack(const twv_tacotron* h, const float* blob, void*
     HIPCHK(hipMemsetAsync(dst, 0, (size_t)h->packed_floats * 4, st));
     for (const auto& it : h->items) {
         if (it.kind == 1) twv_launch_copy(dst + it.dst, blob + it.src, (long long)it.K * it.N, st);
+        else if (it.kind == 2) {    // highway pair tiles: group g = 32 output columns; lanes 0-31 <- H[:, 32g + l], lanes 32-63 <- T[:, 32g + l]
+            const int nchunk = (it.K + 31) / 32;
+            PackTiles p{it.dst, (long long)nchunk * kTile, it.src, it.src + it.r0, 32, it.N / 32, 1, nchunk, it.K, it.N, it.N, 1, 64};
+            twv_launch_pack_tiles(dst, blob, p, st);
+        }
         else {
             const int K = it.r1 - it.r0;
             PackTiles p{it.dst, 0, it.src + (long long)it.r0 * it.N, 0, 0, 1, (it.N + 63) / 64, (K + 31) / 32, K, it.N, it.N, 0, 64};
@@ -1844,9 +1926,9 @@ extern "C" size_t twv_tacotron_workspace_bytes(const twv_tacotron* h, int batch,
 
 static inline int tgrid(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g)); }
 
-static void launch_gemm(hipStream_t st, const float* P, const float* X, int ldx, int rows, int T, int Cin, int kw, const TMat& W,
-                        const TVec* bias, int act, const TVec* inv, const TVec* shift, const float* add1, int ld1, const float* add2,
-                        int ld2, float* Y, int ldy, int col0)
+static GemmArgs gemm_args(const float* P, const float* X, int ldx, int rows, int T, int Cin, int kw, const TMat& W,
+                          const TVec* bias, int act, const TVec* inv, const TVec* shift, const float* add1, int ld1, const float* add2,
+                          int ld2, float* Y, int ldy, int col0)
 {
     GemmArgs a;
     a.X = X; a.ldx = ldx; a.rows = rows; a.T = T; a.Cin = Cin; a.kw = kw; a.pl = (kw - 1) / 2;
@@ -1854,31 +1936,79 @@ static void launch_gemm(hipStream_t st, const float* P, const float* X, int ldx,
     a.bias = bias ? P + bias->off : nullptr; a.act = act;
     a.bn_inv = inv ? P + inv->off : nullptr; a.bn_shift = shift ? P + shift->off : nullptr;
     a.add1 = add1; a.ld1 = ld1; a.add2 = add2; a.ld2 = ld2; a.Y = Y; a.ldy = ldy; a.col0 = col0;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (g_gemm_stat.on) {
+    a.bias2 = nullptr; a.mode = 0;
+    return a;
+}
+// "gemm_timing": a pair of events around the launch(es) of one call, useful FLOPs counted per problem
+struct GemmTimed {
+    hipEvent_t e1 = nullptr;
+    hipStream_t st;
+    GemmTimed(hipStream_t st_, double flop, int launches) : st(st_)
+    {
+        if (!g_gemm_stat.on) return;
         if (g_gemm_stat.used == g_gemm_stat.ev.size()) {
             hipEvent_t x0, x1;
             if (hipEventCreate(&x0) == hipSuccess && hipEventCreate(&x1) == hipSuccess) g_gemm_stat.ev.push_back({x0, x1});
         }
         if (g_gemm_stat.used < g_gemm_stat.ev.size()) {
-            e0 = g_gemm_stat.ev[g_gemm_stat.used].first; e1 = g_gemm_stat.ev[g_gemm_stat.used].second;
+            hipEvent_t e0 = g_gemm_stat.ev[g_gemm_stat.used].first;
+            e1 = g_gemm_stat.ev[g_gemm_stat.used].second;
             ++g_gemm_stat.used;
             (void)hipEventRecord(e0, st);
         }
-        g_gemm_stat.flop += 2.0 * (double)rows * (double)W.K * (double)W.N;
-        ++g_gemm_stat.launches;
+        g_gemm_stat.flop += flop;
+        g_gemm_stat.launches += launches;
     }
+    ~GemmTimed() { if (e1) (void)hipEventRecord(e1, st); }
+};
+static void launch_gemm_args(hipStream_t st, const GemmArgs& a)
+{
+    // mode 1 (highway pair): N counts H and T columns, each useful once
+    GemmTimed tm(st, 2.0 * (double)a.rows * (double)a.K * (double)a.N, 1);
     if (g_gemm_valu)
-        hipLaunchKernelGGL(tc_gemm_kernel, dim3((rows + kGemmRows - 1) / kGemmRows), dim3(256), kGemmRows * kGemmKS * 4, st, a);
+        hipLaunchKernelGGL(tc_gemm_kernel, dim3((a.rows + kGemmRows - 1) / kGemmRows), dim3(256), kGemmRows * kGemmKS * 4, st, a);
     else {
-        const int nchunk_ = (W.K + 31) / 32;
-        const long long wgs = (long long)((rows + kMmRows - 1) / kMmRows) * ((W.N + 127) / 128);
-        if (wgs < 192 && nchunk_ >= 8)      // too few tiles for the chip and a deep contraction: chunk-parallel waves
-            hipLaunchKernelGGL(tc_gemm_mfma_ck_kernel, dim3((rows + 31) / 32, (W.N + 63) / 64), dim3(256), 0, st, a);
+        const int nchunk_ = (a.K + 31) / 32;
+        const long long wgs = (long long)((a.rows + kMmRows - 1) / kMmRows) * ((a.N + 127) / 128);
+        if (a.mode == 1)
+            hipLaunchKernelGGL(tc_gemm_mfma_highway_kernel, dim3((a.rows + kMmRows - 1) / kMmRows, (a.N + 127) / 128), dim3(256), 0, st, a);
+        else if (wgs < 192 && nchunk_ >= 8)      // too few tiles for the chip and a deep contraction: chunk-parallel waves
+            hipLaunchKernelGGL(tc_gemm_mfma_ck_kernel, dim3((a.rows + 31) / 32, (a.N + 63) / 64), dim3(256), 0, st, a);
         else
-            hipLaunchKernelGGL(tc_gemm_mfma_kernel, dim3((rows + kMmRows - 1) / kMmRows, (W.N + 127) / 128), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(tc_gemm_mfma_kernel, dim3((a.rows + kMmRows - 1) / kMmRows, (a.N + 127) / 128), dim3(256), 0, st, a);
     }
-    if (e1) (void)hipEventRecord(e1, st);
+}
+static void launch_gemm(hipStream_t st, const float* P, const float* X, int ldx, int rows, int T, int Cin, int kw, const TMat& W,
+                        const TVec* bias, int act, const TVec* inv, const TVec* shift, const float* add1, int ld1, const float* add2,
+                        int ld2, float* Y, int ldy, int col0)
+{
+    launch_gemm_args(st, gemm_args(P, X, ldx, rows, T, Cin, kw, W, bias, act, inv, shift, add1, ld1, add2, ld2, Y, ldy, col0));
+}
+// independent problems as ONE grid (tc_gemm_mfma_group_kernel), deepest contraction first; with the "gemm_valu" cross-check option, or when
+// grouping is switched off ("gemm_group" = 0: A/B runs), one launch per problem as before
+static void launch_gemm_group(hipStream_t st, std::vector<GemmArgs> v)
+{
+    if (v.empty()) return;
+    if (g_gemm_valu || !g_gemm_group || v.size() == 1) { for (const auto& a : v) launch_gemm_args(st, a); return; }
+    std::stable_sort(v.begin(), v.end(), [](const GemmArgs& x, const GemmArgs& y) { return x.K > y.K; });
+    for (size_t i0 = 0; i0 < v.size(); i0 += kGroupMax) {
+        GemmGroup g;
+        g.n = (int)std::min<size_t>(kGroupMax, v.size() - i0);
+        double flop = 0.0;
+        int wg = 0;
+        for (int p = 0; p < g.n; ++p) {
+            const GemmArgs& a = v[i0 + p];
+            g.a[p] = a;
+            g.start[p] = wg;
+            g.nby[p] = (a.N + 127) / 128;
+            wg += ((a.rows + kMmRows - 1) / kMmRows) * g.nby[p];
+            flop += 2.0 * (double)a.rows * (double)a.K * (double)a.N;
+        }
+        for (int p = g.n; p <= kGroupMax; ++p) g.start[p] = wg;
+        for (int p = g.n; p < kGroupMax; ++p) { g.nby[p] = 1; g.a[p] = v[i0]; }
+        GemmTimed tm(st, flop, 1);
+        hipLaunchKernelGGL(tc_gemm_mfma_group_kernel, dim3(wg), dim3(256), 0, st, g);
+    }
 }
 
 // modules.py:25-74 for `rows` = N*T rows
@@ -1887,8 +2017,12 @@ static void run_cbhg(hipStream_t st, const twv_tacotron* h, const float* P, cons
                      const int32_t* lengths, float* bankbuf, float* poolbuf, float* ra, float* rb, float* rc, float* gx, float* cx, float* out)
 {
     const int rows = N * T, CB = bank * bch, rnn = 128;
-    for (int k = 1; k <= bank; ++k)     // conv bank -> concatenated channels
-        launch_gemm(st, P, in, Cin, rows, T, Cin, k, c.W[k], &c.b[k], TACT_RELU, &c.inv[k], &c.shift[k], nullptr, 0, nullptr, 0, bankbuf, CB, (k - 1) * bch);
+    {                                   // conv bank -> concatenated channels: `bank` independent GEMMs, one grid
+        std::vector<GemmArgs> v;
+        for (int k = 1; k <= bank; ++k)
+            v.push_back(gemm_args(P, in, Cin, rows, T, Cin, k, c.W[k], &c.b[k], TACT_RELU, &c.inv[k], &c.shift[k], nullptr, 0, nullptr, 0, bankbuf, CB, (k - 1) * bch));
+        launch_gemm_group(st, v);
+    }
     hipLaunchKernelGGL(tc_maxpool2_kernel, dim3(tgrid((long long)rows * CB)), dim3(256), 0, st, bankbuf, rows, T, CB, poolbuf);
     launch_gemm(st, P, poolbuf, CB, rows, T, CB, pw, c.pW[0], &c.pb[0], TACT_RELU, &c.pinv[0], &c.pshift[0], nullptr, 0, nullptr, 0, ra, proj[0], 0);
     // second projection + residual: (proj + inputs) + before_highway
@@ -1898,14 +2032,27 @@ static void run_cbhg(hipStream_t st, const twv_tacotron* h, const float* P, cons
     float* hH = ra;
     float* hT = (hw == rc) ? rb : rc;
     for (int i = 0; i < depth; ++i) {
+        if (!g_gemm_valu && g_gemm_group) {
+            // the whole highway layer in one launch (mm_body, mode 1): H and T columns interleaved in the tiles, output to the other buffer
+            GemmArgs a = gemm_args(P, hw, rnn, rows, T, rnn, 1, c.hHT[i], &c.hHb[i], TACT_NONE, nullptr, nullptr, hw, rnn, nullptr, 0, hH, rnn, 0);
+            a.bias2 = P + c.hTb[i].off; a.mode = 1;
+            launch_gemm_args(st, a);
+            float* t = hw; hw = hH; hH = t;
+            if (hT == hw) hT = hH;
+            continue;
+        }
         launch_gemm(st, P, hw, rnn, rows, T, rnn, 1, c.hH[i], &c.hHb[i], TACT_RELU, nullptr, nullptr, nullptr, 0, nullptr, 0, hH, rnn, 0);
         launch_gemm(st, P, hw, rnn, rows, T, rnn, 1, c.hT[i], &c.hTb[i], TACT_SIGMOID, nullptr, nullptr, nullptr, 0, nullptr, 0, hT, rnn, 0);
         hipLaunchKernelGGL(tc_highway_kernel, dim3(tgrid((long long)rows * rnn)), dim3(256), 0, st, hH, hT, hw, (long long)rows * rnn);
     }
-    // biGRU: hoisted x halves, then the recurrent kernel
-    for (int dr = 0; dr < 2; ++dr) {
-        launch_gemm(st, P, hw, rnn, rows, T, rnn, 1, c.gWgx[dr], nullptr, TACT_NONE, nullptr, nullptr, nullptr, 0, nullptr, 0, gx + (long long)dr * rows * 2 * rnn, 2 * rnn, 0);
-        launch_gemm(st, P, hw, rnn, rows, T, rnn, 1, c.gWcx[dr], nullptr, TACT_NONE, nullptr, nullptr, nullptr, 0, nullptr, 0, cx + (long long)dr * rows * rnn, rnn, 0);
+    // biGRU: hoisted x halves (four GEMMs over the same rows: one grid), then the recurrent kernel
+    {
+        std::vector<GemmArgs> v;
+        for (int dr = 0; dr < 2; ++dr) {
+            v.push_back(gemm_args(P, hw, rnn, rows, T, rnn, 1, c.gWgx[dr], nullptr, TACT_NONE, nullptr, nullptr, nullptr, 0, nullptr, 0, gx + (long long)dr * rows * 2 * rnn, 2 * rnn, 0));
+            v.push_back(gemm_args(P, hw, rnn, rows, T, rnn, 1, c.gWcx[dr], nullptr, TACT_NONE, nullptr, nullptr, nullptr, 0, nullptr, 0, cx + (long long)dr * rows * rnn, rnn, 0));
+        }
+        launch_gemm_group(st, v);
     }
     hipLaunchKernelGGL(tc_zero_kernel, dim3(tgrid((long long)rows * 2 * rnn)), dim3(256), 0, st, out, (long long)rows * 2 * rnn);
     GruSeqArgs g;
@@ -1959,8 +2106,12 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
     if (multi) {
         hipLaunchKernelGGL(tc_gather_rows_kernel, dim3(tgrid((long long)N * SE)), dim3(256), 0, st, P + h->semb.off, speaker_ids, N, SE, spk);
         { float* q = spk + (long long)N * 64; for (int i = 0; i < h->ndense; ++i) { sv[i] = q; q += (long long)N * h->dn[i]; } }
-        for (int i = 0; i < h->ndense; ++i)
-            launch_gemm(st, P, spk, SE, N, 1, SE, 1, h->dW[i], &h->db[i], TACT_SOFTSIGN, nullptr, nullptr, nullptr, 0, nullptr, 0, sv[i], h->dn[i], 0);
+        {
+            std::vector<GemmArgs> v;
+            for (int i = 0; i < h->ndense; ++i)
+                v.push_back(gemm_args(P, spk, SE, N, 1, SE, 1, h->dW[i], &h->db[i], TACT_SOFTSIGN, nullptr, nullptr, nullptr, 0, nullptr, 0, sv[i], h->dn[i], 0));
+            launch_gemm_group(st, v);
+        }
         for (int i = 0; i < 1 + d.dec_layer_num; ++i) {
             const int wdt = i == 0 ? AS : DR;
             HIPCHK(hipMemcpy2DAsync(dinit + (i == 0 ? 0 : AS + (i - 1) * DR), (size_t)(AS + d.dec_layer_num * DR) * 4, sv[2 + i], (size_t)wdt * 4,
