@@ -226,6 +226,9 @@ def main():
     # gradient all-reduce over RCCL when N > 1 -- every rank takes part, so it runs before the rank-0 report is assembled
     train_res = None
     if not args.no_train:
+        # set-up first, then ONE agreement (MAX of a failure flag over the ranks) before anything enters the gradient all-reduce: a
+        # rank that could not build its trainer must not leave the others waiting inside trn.step's collective
+        trn, train_err = None, None
         try:
             from twvk_amd.train import WaveNetTrainer
             tnet = WaveNetModel(64, dil, hp.filter_width, hp.residual_channels, hp.dilation_channels, hp.skip_channels,
@@ -240,6 +243,16 @@ def main():
             taudio = torch.from_numpy((trng.rand(64, TT_) - 0.5).astype(np.float32)).to(dev)
             tlc = torch.from_numpy((trng.randn(64, TT_ // tnet.hop_size, hp.num_mels) * 0.5).astype(np.float32)).to(dev)
             tgc = torch.from_numpy(trng.randint(0, 2, 64).astype(np.int32)).to(dev)
+        except Exception as e:
+            train_err = e
+        if dist is not None:
+            tf_ = torch.tensor([0.0 if train_err is None else 1.0], dtype=torch.float32, device=dev)
+            dist.all_reduce(tf_, op=dist.ReduceOp.MAX)
+            if float(tf_.item()) > 0.0 and train_err is None:
+                train_err = RuntimeError("another rank could not set the training step up")
+        try:
+            if train_err is not None:
+                raise train_err
             l0 = float(trn.step(taudio, tlc, tgc).item())
             sync_all()
             q0 = time.perf_counter()
@@ -307,6 +320,13 @@ def main():
                          # HBM bytes per launch from rocprofv3 PMC (separate --pmc passes; FETCH_SIZE / WRITE_SIZE with the guide's gfx950
                          # corrections), per generated step, for THESE generation-kernel sources (profiles/traffic.json is keyed by _lib.generation_hash())
                          "traffic": None if tps is None else tps * T, "algorithmic_bytes_per_launch": bytes_per_step * T,
+                         # SURVEY 8d's second convention, reported beside the streamed-weights one: with every weight resident on chip the
+                         # algorithmic HBM bytes of a step are its I/O only (per stream 80 lc floats in, one sample in, one out)
+                         "weights_on_chip": {"algorithmic_bytes_per_step": B * (80 + 1 + 1) * 4,
+                                             "measured_bytes_per_step": tps,
+                                             "measured_over_algorithmic": None if tps is None else tps / (B * (80 + 1 + 1) * 4),
+                                             "note": "counter traffic / I-O-only bytes: what the register-resident kernel really moves "
+                                                     "(uniforms in, progress / exchange words that spill from L2 included)"},
                          "kernel_ms": k_ms, "us_per_generation_step": us_step,
                          "latency_floor_us": floor_us, "frac_of_floor": floor_us / us_step,
                          "latency_floor_formula": "%d layers x 0.200 us (a layer's dependent arithmetic alone: 32+16 dependent fmas, 6 adds, 21-deep rational "

@@ -155,7 +155,7 @@ int twv_sample_categorical(const float* logits, int64_t rows, int quantization_c
 
 /* elementary functions of the arithmetic contract, evaluated on the device (parity tests pin them bit for bit) */
 int twv_eval_elementwise(int fn /*0 tanh,1 sigmoid,2 exp,3 log,4 log1p*/, const float* x, int64_t n, float* out, void* stream);
-int twv_eval_elementwise64(int fn /*0 exp,1 log*/, const double* x, int64_t n, double* out, void* stream);
+int twv_eval_elementwise64(int fn /*0 exp,1 log,2 exp for x <= 0 (the sampler's straight-line form)*/, const double* x, int64_t n, double* out, void* stream);
 
 /* ======================================= Tacotron text -> mel inference =======================================
  * Replaces the graph synthesizer.py:56 builds with Tacotron.initialize(inputs, input_lengths, num_speakers, speaker_id,

@@ -67,6 +67,8 @@ if args.onehot:
     print("      ordered sum, bias -> 32 logits published      %.2f" % us(p[:, 37] - p[:, 36]))
     print("      logits -> sampler has all 256                 %.2f" % us(p[:, 18] - p[:, 37]))
     print("      sampler (f64 softmax, rescale, cdf, search)   %.2f" % us(p[:, 19] - p[:, 18]))
+    print("        max + 4 float64 exps %.2f | denominator scan %.2f | e/sum, log p / T, max %.2f | log-sum-exp %.2f | exp + 4 cdf scans %.2f | search %.2f"
+          % (us(p[:, 38] - p[:, 18]), us(p[:, 39] - p[:, 38]), us(p[:, 40] - p[:, 39]), us(p[:, 41] - p[:, 40]), us(p[:, 42] - p[:, 41]), us(p[:, 43] - p[:, 42])))
 else:
     print("      ordered sum, relu, conv1d_2 chunk, publish    %.2f" % us(p[:, 25] - p[:, 24]))
     print("      partial table -> sampler has all of it        %.2f" % us(p[:, 18] - p[:, 25]))

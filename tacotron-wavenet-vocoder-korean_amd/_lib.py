@@ -195,6 +195,9 @@ class TacoDims(C.Structure):
                 ("num_mels", C.c_int32), ("reduction_factor", C.c_int32), ("num_freq", C.c_int32), ("max_iters", C.c_int32)]
 
 
+TWV_E_BUSY = 5          # include/twv_amd.h: a persistent kernel found the device occupied: nothing was done, retry later
+
+
 class TwvError(RuntimeError):
     pass
 

@@ -55,9 +55,11 @@ __device__ __forceinline__ float wave_max_f32(float x)
 
 // y[k] = logit of class lane + 64 k (k < NB; classes >= Q are ignored).  Returns the drawn class (wave-uniform);
 // sp_out (optional, NB floats per lane) receives the scaled probabilities of generate.py:222.
+// stamps (optional, tuning aid): eight 64-bit slots that receive the chip-wide clock at the phase boundaries marked TWV_CSTAMP
+#define TWV_CSTAMP(i_) do { if (stamps != nullptr && lane == 0) stamps[i_] = wall_clock64(); } while (0)
 template <int NB>
 __device__ __forceinline__ int categorical_sample(const float (&y)[NB], const int Q, const int lane, const float temp32, const double u,
-                                                  float* sp_out = nullptr)
+                                                  float* sp_out = nullptr, unsigned long long* stamps = nullptr)
 {
     const float ninf = __uint_as_float(0xff800000u);
     // ---- model.py:243 softmax in float64
@@ -73,12 +75,15 @@ __device__ __forceinline__ int categorical_sample(const float (&y)[NB], const in
     for (int k = 0; k < NB; ++k) {
         e[k] = 0.0;
         if (64 * k < Q) {
-            e[k] = (lane + 64 * k < Q) ? exp64_e((double)y[k] - m64) : 0.0;
+            e[k] = (lane + 64 * k < Q) ? exp64_nonpos_e((double)y[k] - m64) : 0.0;
             s = (k == 0) ? e[k] : s + e[k];
         }
     }
+    TWV_CSTAMP(0);                                                 // max + float64 exps done
     const double sum = readlane_f64(scan64_wave(s), 63);
+    TWV_CSTAMP(1);                                                 // softmax denominator
     // ---- generate.py:220 np.log(prediction) / temperature (float32)
+    const bool t_is_one = __builtin_amdgcn_readfirstlane(__float_as_int(temp32)) == 0x3f800000;
     float lp[NB];
     float m2 = ninf;
 #pragma unroll
@@ -86,13 +91,15 @@ __device__ __forceinline__ int categorical_sample(const float (&y)[NB], const in
         lp[k] = ninf;
         if (64 * k < Q) {
             const float p32 = (float)(e[k] / sum);                 // tf.cast(softmax(float64), float32)
-            const float l = div_(log_e(p32), temp32);
+            const float lg = log_e(p32);
+            const float l = t_is_one ? lg : div_(lg, temp32);      // x / 1.0f == x exactly: the IEEE sequence is skipped, not approximated
             const bool in = lane + 64 * k < Q;
             lp[k] = l;
             m2 = (in && l > m2) ? l : m2;
         }
     }
     m2 = wave_max_f32(m2);
+    TWV_CSTAMP(2);                                                 // p = e / sum, log p / T, their maximum
     // ---- generate.py:221 log sum exp, max-shifted, summed in float64 in the contract's tree
     double s2 = 0.0;
 #pragma unroll
@@ -103,6 +110,7 @@ __device__ __forceinline__ int categorical_sample(const float (&y)[NB], const in
         }
     }
     const float lse = m2 + log_e((float)readlane_f64(scan64_wave(s2), 63));
+    TWV_CSTAMP(3);                                                 // log-sum-exp
     // ---- generate.py:221-222 scaled probabilities; RandomState.choice: float64 cdf in class order
     double c[NB];
     double base = 0.0;
@@ -118,18 +126,33 @@ __device__ __forceinline__ int categorical_sample(const float (&y)[NB], const in
         }
     }
     const double last = base;
+    TWV_CSTAMP(4);                                                 // scaled probabilities + float64 cdf
     // ---- cdf /= cdf[-1]; searchsorted(u, side='right'): the first class whose normalised cdf exceeds u
-    int idx = Q - 1;
-    bool found = false;
+    // The quotient is only needed where it decides the comparison: with ul = fl(u * last), c > ul (1 + 2^-50) implies fl(c / last) > u
+    // and c < ul (1 - 2^-50) implies fl(c / last) <= u (each rounding moves a value by at most 2^-53 relative); the division itself is
+    // done -- for the whole wave -- only when some class falls inside that band: about once in 10^12 draws.  Same answer, always.
+    const double ul = u * last;
+    const double band_hi = ul * (1.0 + 0x1p-50), band_lo = ul * (1.0 - 0x1p-50);
+    bool close = false;
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        if (64 * k < Q) {
-            const bool hit = (lane + 64 * k < Q) && (c[k] / last > u);
-            const unsigned long long mask = __ballot(hit);
-            if (!found && mask != 0ull) { idx = 64 * k + (int)__ffsll((long long)mask) - 1; found = true; }
-        }
+    for (int k = 0; k < NB; ++k)
+        if (64 * k < Q) close = close || (lane + 64 * k < Q && !(c[k] > band_hi) && !(c[k] < band_lo));
+    const bool exact_div = __any(close) != 0;
+    unsigned long long mask[NB];
+    if (exact_div) {                                                // (a real branch: the divisions must not be speculated)
+#pragma unroll
+        for (int k = 0; k < NB; ++k) mask[k] = (64 * k < Q) ? __ballot((lane + 64 * k < Q) && (c[k] / last > u)) : 0ull;
+    } else {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) mask[k] = (64 * k < Q) ? __ballot((lane + 64 * k < Q) && (c[k] > band_hi)) : 0ull;
     }
+    int idx = Q - 1;
+#pragma unroll
+    for (int k = NB - 1; k >= 0; --k)
+        if (mask[k] != 0ull) idx = 64 * k + (int)__ffsll((long long)mask[k]) - 1;      // the lowest block with a hit wins
+    TWV_CSTAMP(5);                                                 // search
     return idx;
 }
+#undef TWV_CSTAMP
 
 }  // namespace twv

@@ -201,6 +201,32 @@ __device__ __forceinline__ double exp64_e(double x)
     return y * __longlong_as_double((long long)(k + 1000 + 1023) << 52) * __longlong_as_double((long long)(-1000 + 1023) << 52);
 }
 
+// exp64_e for a non-positive finite argument (the float64 softmax of model.py:243 evaluates exp(logit - max)), as ONE straight line:
+// the same operations in the same order on every path such an argument can take -- the overflow exit is unreachable, the underflow
+// exit and the subnormal scaling become selects -- so four of them interleave in one instruction stream instead of running as four
+// branchy calls one after the other.  Bit-identical to exp64_e on [-inf, 0] (tests/test_wavenet_gpu.py::test_elementwise64_bit_exact).
+__device__ __forceinline__ double exp64_nonpos_e(double x)
+{
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    const bool tiny = x < -745.13321910194110842;
+    const double xc = tiny ? -745.0 : x;                           // keeps k in range; the result is replaced below
+    const double kf = __builtin_floor(xc * invln2 + 0.5);
+    const int k = (int)kf;
+    const double hi = xc - kf * ln2HI, lo = kf * ln2LO;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    const bool normal = k >= -1021;
+    const int k1 = normal ? k : k + 1000;
+    const double scaled = y * __longlong_as_double((long long)(k1 + 1023) << 52);
+    const double res = normal ? scaled : scaled * __longlong_as_double((long long)(-1000 + 1023) << 52);
+    return tiny ? 0.0 : res;
+}
+
 __device__ __forceinline__ double log64_e(double x)
 {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;

@@ -27,6 +27,8 @@ static int g_gemm_valu = 0;            // "gemm_valu" option: 1 = the VALU kerne
 static int g_gemm_group = 1;           // "gemm_group" option: 0 = one launch per GEMM, separate highway kernels (A/B runs, cross-check)
 // "gemm_timing" option (measurement aid, bench.py's `tacotron.roofline`): every GEMM launch is bracketed by a pair of HIP events on
 // its stream and its useful FLOPs (2 * rows * K * N, unpadded) are counted; twv_tacotron_gemm_stats sums both since the option was set.
+// PROCESS-WIDE and single-threaded by design (one bench process, one model): the option set through any handle counts the launches of
+// every handle and the events live until the process ends.
 struct GemmStat {
     bool on = false;
     double flop = 0.0;

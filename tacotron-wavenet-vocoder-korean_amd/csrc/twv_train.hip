@@ -1297,9 +1297,10 @@ __global__ void __launch_bounds__(512) tr_layer_bwd2_kernel(LayerBwdArgs a)
     __syncthreads();
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int ntiles = a.B * a.tpb, nwaves = gridDim.x * 8;
-    const rsrc_t rpre = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dPRE), 0, (int)((long long)a.B * a.Tn * 64 * 4), 0x00020000);
-    const rsrc_t rdxn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dXn), 0, (int)((long long)a.B * a.Tn * 32 * 4), 0x00020000);
-    const rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(a.dX, 0, (int)((long long)a.B * a.Tn * 32 * 4), 0x00020000);
+    // (descriptors are the FUSED path's: twv_wavenet_train_create bounds the sizes to 31 bits only for that path; the pointer path takes any size)
+    const rsrc_t rpre = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dPRE), 0, FUSED ? (int)((long long)a.B * a.Tn * 64 * 4) : 0, 0x00020000);
+    const rsrc_t rdxn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dXn), 0, FUSED ? (int)((long long)a.B * a.Tn * 32 * 4) : 0, 0x00020000);
+    const rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(a.dX, 0, FUSED ? (int)((long long)a.B * a.Tn * 32 * 4) : 0, 0x00020000);
     const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(FUSED ? a.D : a.dX, 0, FUSED ? (int)((long long)a.B * a.T * 4 * 4) : 0, 0x00020000);
     for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += nwaves) {
         const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
@@ -1669,9 +1670,17 @@ extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch,
     if (dims && dims->gc_channels > 0 && dims->gc_cardinality < 1)
         return twv_fail(TWV_E_UNSUPPORTED, "training needs global_condition_cardinality (the gc_embedding table is a trained variable; model.py:191-195)");
     if (!dims || !out || batch < 1) return twv_fail(TWV_E_INVALID, "bad argument");
-    if ((long long)batch * n_samples * 64 * 4 >= (1LL << 31))
-        return twv_fail(TWV_E_UNSUPPORTED, "batch x samples too large: the fused layer kernels address a layer's activations with 32-bit byte offsets (batch * samples < 8.3 M)");
     const twv_wavenet_dims& d = *dims;
+    {
+        // only the FUSED layer kernels (tr_layer_fwdc_kernel / tr_layer_bwd2c_kernel: three upsampling stages, 32 <= hop <= 512, 80 mel
+        // channels -- the same test as fused_lc in twv_wavenet_train_loss_grad) address a layer's activations with 32-bit byte offsets;
+        // the pointer kernels of every other model keep 64-bit addresses and take any size
+        int hop = 1;
+        for (int i = 0; i < d.n_upsample; ++i) hop *= d.upsample_factor[i];
+        const bool fused_lc = d.n_upsample == 3 && hop >= 32 && hop <= 512 && d.lc_channels == 80;
+        if (fused_lc && (long long)batch * n_samples * 64 * 4 >= (1LL << 31))
+            return twv_fail(TWV_E_UNSUPPORTED, "batch x samples too large: the fused layer kernels address a layer's activations with 32-bit byte offsets (batch * samples < 8.3 M)");
+    }
     if (d.residual_channels != 32 || d.dilation_channels != 32) return twv_fail(TWV_E_UNSUPPORTED, "residual/dilation channels must be 32");
     if (d.scalar_input && (d.out_channels % 3 || d.out_channels > 96)) return twv_fail(TWV_E_UNSUPPORTED, "out_channels must be 3*nr_mix <= 96");
     if (!d.scalar_input && (d.quantization_channels < 2 || d.quantization_channels > 512)) return twv_fail(TWV_E_UNSUPPORTED, "quantization_channels must be in [2, 512] for training");

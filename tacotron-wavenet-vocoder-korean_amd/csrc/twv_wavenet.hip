@@ -1245,7 +1245,7 @@ __global__ void wn_eval_kernel(int fn, const float* x, long long n, float* out)
 __global__ void wn_eval64_kernel(int fn, const double* x, long long n, double* out)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        out[i] = fn == 0 ? exp64_e(x[i]) : log64_e(x[i]);
+        out[i] = fn == 0 ? exp64_e(x[i]) : (fn == 2 ? exp64_nonpos_e(x[i]) : log64_e(x[i]));
 }
 
 
@@ -1900,14 +1900,14 @@ extern "C" int twv_selftest(float* out256, void* stream)
 }
 extern "C" int twv_eval_elementwise(int fn, const float* x, int64_t n, float* out, void* stream)
 {
-    if (!x || !out || n < 0 || fn < 0 || fn > 6) return fail(TWV_E_INVALID, "bad argument");
+    if (!x || !out || n < 0 || fn < 0 || fn > 4) return fail(TWV_E_INVALID, "bad argument");
     if (n) hipLaunchKernelGGL(wn_eval_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, fn, x, (long long)n, out);
     HIPCHK(hipGetLastError());
     return TWV_OK;
 }
 extern "C" int twv_eval_elementwise64(int fn, const double* x, int64_t n, double* out, void* stream)
 {
-    if (!x || !out || n < 0 || fn < 0 || fn > 1) return fail(TWV_E_INVALID, "bad argument");
+    if (!x || !out || n < 0 || fn < 0 || fn > 2) return fail(TWV_E_INVALID, "bad argument");
     if (n) hipLaunchKernelGGL(wn_eval64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, fn, x, (long long)n, out);
     HIPCHK(hipGetLastError());
     return TWV_OK;

@@ -461,7 +461,8 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                     a.dbg[((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)NL * 64 + lane + 64 * k] = y[k];
             }
             // model.py:243 + generate.py:219-231 (AC-5, twv_categorical.hpp): the drawn class is the next step's input
-            samp_q = categorical_sample<4>(y, L.Q, lane, a.temperature, u_next);
+            samp_q = categorical_sample<4>(y, L.Q, lane, a.temperature, u_next, nullptr,
+                                           ((INSTR & 1) && a.prof != nullptr && b == a.prof_stream && t < a.prof_steps) ? a.prof + (long long)t * 64 + 38 : nullptr);
             XSTAMP(true, 19);
           }
         } else
@@ -950,7 +951,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const SX& sx, int g,
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             if (pl.dead) break;
-            if (k >= ns_rt) break;                                     // (many-streams kernel: NS = 8 slots, ns_rt streams on this XCD)
+            if (k >= ns_rt) break;                                     // (many-streams kernel: NS = kManyPerXcd = 12 slots, ns_rt streams on this XCD)
             const rsrc_t rs = sx.rs[k];
             const int b = sx.b[k];
             const int ob = k * kConvLdsFloats;
@@ -1462,15 +1463,17 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
 }
 
 // =====================================================================================================================
-//  THE MANY-STREAMS KERNEL (batch 33 .. 64: five to eight streams per XCD).
+//  THE MANY-STREAMS KERNEL (batch 33 .. 96: five to twelve streams per XCD, two per chain workgroup).
 //
 //  The chain workgroup's weights serve a stream ~1 us of every ~9.5 us step per wave (SQ_WAIT_ANY 0.83 at batch 8), so TWO streams
 //  rotate through one chain workgroup here (slots 0 / 1 = streams 2c / 2c + 1 of the XCD): wave w runs slot 0's layers, hands
 //  the residual vector on, runs slot 1's layers; register-resident kernels shared, per-slot state = the hand-off boxes, the gc
 //  projections (LDS) and, on wave 7, the causal queue and the sampler's noise terms.  Wave 7 draws a slot's sample and feeds its
 //  causal layer in one go (sampler(t-1) -> head(t) per slot, then the slots' layers): neither stream waits for the other's post phase.
-//  The service workgroup carries the same two streams (tap-0 kernels shared, delay lines per stream).  4 chain + 4 service + 8 skip
-//  + 8 conv1 + 4 lc workgroups = 28 of the XCD's 32 CUs serve eight streams.
+//  The service workgroup carries the same two streams (tap-0 kernels shared, delay lines per stream).  Eight streams: 4 chain + 4
+//  service + 8 skip + 8 conv1 + 4 lc workgroups = 28 of the XCD's 32 CUs; TWELVE streams (batch 96, kManyChains = 6): 6 + 6 + 8 + 8 + 4 =
+//  all 32 CUs carry a role -- at 89 .. 96 streams there is no CU to spare, any other resident kernel ends the launch with TWV_E_BUSY
+//  (nothing done; the Python generate() retries a few times).
 //
 //  The skip role is laid out differently: with eight streams the 32 (layer, stream) polls per wave and step of skip_role (a wave
 //  owns slice g of FOUR layers) are an L2 round trip each -- more than the step.  Here a wave owns FOUR SLICES of ONE layer: one
@@ -2327,7 +2330,7 @@ __global__ void __launch_bounds__(512) wn_xcd_many_kernel(XArgs xa)
     for (int i = threadIdx.x; i < kManyLds; i += blockDim.x) lds[i] = 0.0f;      // LDS hand-off words start at zero
     __syncthreads();
     ticket = s_ticket;
-    const int ns = xcc < (unsigned)a.B && xcc < 8u ? (a.B - (int)xcc + 7) / 8 : 0;     // streams on this XCD (<= 8)
+    const int ns = xcc < (unsigned)a.B && xcc < 8u ? (a.B - (int)xcc + 7) / 8 : 0;     // streams on this XCD (<= kManyPerXcd = 12)
     const int nch = (ns + kMS - 1) / kMS;                         // chain (and service) workgroups: two streams each
     if (ticket >= 2 * nch + 16 + xa.n_lc_wg) return;            // surplus workgroup (or an XCD without a stream)
     if (!roles_resident(xa)) return;                            // the device is busy: nobody starts (status 90)

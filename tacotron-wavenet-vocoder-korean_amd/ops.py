@@ -56,8 +56,8 @@ def sample_categorical(logits, temperature, uniforms, want_proba=False, device="
 def eval_elementwise(name, x, device="cuda:0"):
     """contract functions evaluated on the device (parity tests)."""
     L = _lib.lib()
-    if name.endswith("64"):
-        fn = {"exp64": 0, "log64": 1}[name]
+    if name in ("exp64", "log64", "exp64_nonpos"):
+        fn = {"exp64": 0, "log64": 1, "exp64_nonpos": 2}[name]
         t = torch.as_tensor(x, dtype=torch.float64, device=device).contiguous()
         with torch.cuda.device(t.device):
             out = torch.empty_like(t)

@@ -70,7 +70,12 @@ class WaveNetTrainer(object):
         self.params = None
         with torch.cuda.device(self.device):
             self._ws = torch.empty(self._L.twv_wavenet_train_workspace_bytes(h) // 4, dtype=torch.float32, device=self.device)
-            self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+            # the gradient buffer carries ONE extra word behind the gradients: a failure flag that rides in the same all-reduce
+            # (a rank that cannot produce its batch must not leave the others waiting in the collective, and a separate flag
+            # all-reduce + host sync in front of every step would cost a round trip per step)
+            self._gbuf = torch.zeros(self.n_params + 1, dtype=torch.float32, device=self.device)
+            self.grads = self._gbuf[:self.n_params]
+            self._flag = self._gbuf[self.n_params:]
             self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     def __del__(self):
@@ -205,9 +210,22 @@ class WaveNetTrainer(object):
         self.global_step += 1
         return lr
 
-    def step(self, audio, local_condition, gc_ids):
-        """one sess.run([net.loss, net.optimize]) (train_vocoder.py:163); returns the (local) loss as a device tensor"""
-        loss = self.loss_and_gradients(audio, local_condition, gc_ids)
-        world = allreduce_sum_(self.grads, self.group)
-        self.apply_gradients(world)
+    def step(self, audio, local_condition, gc_ids, failed=False):
+        """one sess.run([net.loss, net.optimize]) (train_vocoder.py:163); returns the (local) loss as a device tensor.
+        failed=True: this rank has no batch (its feeder raised): it still joins the gradient all-reduce -- with zero gradients and the
+        failure flag set -- so that no rank is left waiting, and applies nothing; every rank sees `peer_failure()` afterwards."""
+        if failed:
+            self._gbuf.zero_()
+            self._flag.fill_(1.0)
+            loss = self.loss
+        else:
+            self._flag.zero_()
+            loss = self.loss_and_gradients(audio, local_condition, gc_ids)
+        world = allreduce_sum_(self._gbuf, self.group)
+        if not failed:
+            self.apply_gradients(world)
         return loss
+
+    def peer_failure(self):
+        """True when some rank joined the last step's all-reduce with failed=True (host sync: call it where the loss is read anyway)"""
+        return bool(float(self._flag.item()) > 0.0)

@@ -175,19 +175,23 @@ def main(argv=None, log=print):
             dist.init_process_group("nccl", device_id=torch.device("cuda:%d" % local_rank))
     # rank 0 decides the directories (a default logdir carries a timestamp: every rank computing its own would give N directories)
     # and creates them / writes params.json; the others take its answer
-    directories = None
+    directories, setup_error = None, None
     if rank == 0:
         try:
             directories = validate_directories(config, hparams)
         except ValueError as e:
             print("Some arguments are wrong:")
             print(str(e))
+        except Exception as e:                                      # makedirs / save_hparams: the other ranks are waiting in the broadcast
+            setup_error = e
     if dist is not None:
         box = [directories]
-        dist.broadcast_object_list(box, src=0)
+        dist.broadcast_object_list(box, src=0)                      # None = rank 0 could not set the run up: every rank leaves
         directories = box[0]
         if directories is not None and rank != 0 and os.path.exists(os.path.join(directories['logdir'], "params.json")):
             load_hparams(hparams, directories['logdir'])
+    if setup_error is not None:
+        raise setup_error
     if directories is None:
         return None
     logdir, restore_from = directories['logdir'], directories['restore_from']
@@ -224,16 +228,14 @@ def main(argv=None, log=print):
             audio, lc, gc = reader.next_batch()
         except Exception as e:                                      # a rank that cannot feed must not leave the others in the all-reduce
             failure = e
-        if dist is not None:
-            flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device="cuda:%d" % local_rank if torch.cuda.is_available() else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if int(flag.item()) and failure is None:
-                failure = RuntimeError("another rank's feeder failed at step %d" % (step + 1))
+        # the failure flag rides in the gradient all-reduce itself (WaveNetTrainer.step): a failing rank still joins the collective
+        loss = trainer.step(None, None, None, failed=True) if failure is not None else trainer.step(audio, lc, gc)
         if failure is not None:
             raise failure
-        loss = trainer.step(audio, lc, gc)
         step = trainer.global_step
         loss_value = float(loss.item())
+        if dist is not None and trainer.peer_failure():             # read where the loss is read: the stream is drained already
+            raise RuntimeError("another rank's feeder failed at step %d" % step)
         log('step {:d} - loss = {:.3f}, ({:.3f} sec/step)'.format(step, loss_value, time.time() - start_time))
         if step % config.checkpoint_every == 0 and rank == 0:
             log('Storing checkpoint to {} ...'.format(logdir))

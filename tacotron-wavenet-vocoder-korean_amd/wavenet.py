@@ -236,6 +236,7 @@ class WaveNetModel(object):
 
     # ---- the generic kernel's hoisted conditioning, bounded ----
     MAX_COND_BYTES = 1 << 30
+    BUSY_RETRIES = 3                 # generate(check=True): relaunches after TWV_E_BUSY (device shared with another kernel at launch time)
 
     def _steps_per_call(self, n_steps):
         """The generic kernel reads a hoisted projection table cond[B][T][layers][64] (4 * B * T * layers * 64 bytes: 11.8 GB at BASELINE
@@ -299,11 +300,21 @@ class WaveNetModel(object):
             if debug_steps:
                 opad = (((self.out_channels if self.scalar_input else self.quantization_channels) + 63) // 64) * 64
                 dbg = torch.zeros((B, debug_steps, len(self.dilations) * 64 + opad), dtype=torch.float32, device=self.device)
-            _lib.check(self._L.twv_wavenet_generate(self._h, _ptr(self._packed), _ptr(self._state), _ptr(cond), _ptr(fi), _ptr(u),
-                                                    float(temperature), B, T, _ptr(out), _ptr(self._status), _ptr(dbg),
-                                                    int(debug_steps), _stream()))
-            if check:
-                _lib.check(self._L.twv_wavenet_status(_ptr(self._status), _stream()))
+            # TWV_E_BUSY (the persistent kernel's role workgroups were not all resident within ~50 ms: another kernel held CUs) means
+            # NOTHING was done -- no sample written, state unchanged -- so the launch is simply repeated, a few times, with a pause
+            for attempt in range(self.BUSY_RETRIES + 1):
+                _lib.check(self._L.twv_wavenet_generate(self._h, _ptr(self._packed), _ptr(self._state), _ptr(cond), _ptr(fi), _ptr(u),
+                                                        float(temperature), B, T, _ptr(out), _ptr(self._status), _ptr(dbg),
+                                                        int(debug_steps), _stream()))
+                if not check:
+                    break
+                rc = self._L.twv_wavenet_status(_ptr(self._status), _stream())
+                if rc == _lib.TWV_E_BUSY and attempt < self.BUSY_RETRIES:
+                    import time
+                    time.sleep(0.05 * (attempt + 1))
+                    continue
+                _lib.check(rc)
+                break
         return (out, dbg) if debug_steps else out
 
     # ---- generate.py:168-180 priming loop: feed the seed samples, discard the predictions ----

@@ -74,6 +74,13 @@ def test_categorical_sampler_rows_bit_exact(torch_cuda, oracle, Q):
         logits = (rng.randn(N, Q) * rng.uniform(0.5, 4.0, (N, 1))).astype(np.float32)
         u = rng.random_sample(N)
         u[:8] = [0.0, 1.0 - 2.0 ** -53, 0.5, 1e-300, 0.999999, 1e-9, 0.25, 0.75]
+        # draws that sit ON a cdf boundary to within an ulp or two (the kernel compares against u * last and only divides inside a
+        # 2^-50 band around it: these rows take the division, and must still equal the checker's plain division)
+        for i in range(8, 264):
+            _, p0 = oracle.sample_categorical(logits[i], temp, 0.5)
+            cdf = np.cumsum(p0.astype(np.float64)); cdf /= cdf[-1]
+            j = int(rng.randint(0, Q - 1))
+            u[i] = min(np.nextafter(cdf[j], [0.0, 1.0, cdf[j]][i % 3]), 1.0 - 2.0 ** -53)
         got, proba = ops.sample_categorical(logits, temp, u, want_proba=True)
         got, proba = got.cpu().numpy(), proba.cpu().numpy()
         want = np.empty(N, np.int32); wp = np.empty((N, Q), np.float32)
@@ -85,10 +92,19 @@ def test_categorical_sampler_rows_bit_exact(torch_cuda, oracle, Q):
         assert got.min() >= 0 and got.max() < Q
 
 
-@pytest.mark.parametrize("name", ["exp64", "log64"])
+@pytest.mark.parametrize("name", ["exp64", "log64", "exp64_nonpos"])
 def test_elementwise64_bit_exact(torch_cuda, oracle, name):
+    """exp64_nonpos: the float64 softmax's straight-line exp (x = logit - max <= 0) against the contract's exp64 over the whole
+    non-positive range, the subnormal results and the underflow edge included"""
     from twvk_amd import ops
     rng = np.random.RandomState(7)
+    if name == "exp64_nonpos":
+        x = np.concatenate([-rng.uniform(0, 760, 60000), -np.exp(rng.uniform(-40, 7, 20000)), np.linspace(-746.0, -700.0, 20001),
+                            [0.0, -0.0, -745.13321910194110842, -745.1332191019412, -745.133219101941, -708.39641853226408, -1e-320, -np.inf]])
+        got = ops.eval_elementwise(name, x).cpu().numpy()
+        want = oracle.elementwise("exp64", x)
+        assert first_mismatch(got, want) is None, first_mismatch(got, want)
+        return
     x = rng.uniform(-700, 700, 50000) if name == "exp64" else np.exp(rng.uniform(-700, 700, 50000))
     got = ops.eval_elementwise(name, x).cpu().numpy()
     want = oracle.elementwise(name, x)
@@ -833,11 +849,19 @@ def test_busy_device_is_a_clean_error_not_a_hang(torch_cuda, oracle):
     twvk_amd._lib.check(m._L.twv_debug_occupy(128, 100 * 1024, 400.0, C.c_void_p(side.cuda_stream)))
     time.sleep(0.02)
     t0 = time.perf_counter()
+    m.BUSY_RETRIES = 0                                                               # the raw behaviour first: one launch, one refusal
     with pytest.raises(TwvError, match="busy"):
         m.generate(m.create_upsample(mel), gc, seed_in, u)
     assert time.perf_counter() - t0 < 0.35, "the refusal must come from the start-up check (~50 ms), not from a watchdog"
     torch.cuda.synchronize()
     got = m.generate(m.create_upsample(mel), gc, seed_in, u).cpu().numpy()           # no queue_initializer in between: the state was not touched
+    assert first_mismatch(got, want) is None, first_mismatch(got, want)
+    # generate()'s bounded retry: the occupier leaves after ~150 ms, the third or fourth launch goes through -- same samples
+    m.queue_initializer()
+    m.BUSY_RETRIES = 6
+    twvk_amd._lib.check(m._L.twv_debug_occupy(128, 100 * 1024, 150.0, C.c_void_p(side.cuda_stream)))
+    time.sleep(0.02)
+    got = m.generate(m.create_upsample(mel), gc, seed_in, u).cpu().numpy()
     assert first_mismatch(got, want) is None, first_mismatch(got, want)
 
 
