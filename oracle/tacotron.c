@@ -92,6 +92,37 @@ static void gru_step(const float* x, int nin, const float* h, int nu, const floa
 
 
 
+/* AC-6: inclusive prefix sum of 64 floats in the order a 64-lane wave produces with four row_shr steps inside each row of 16
+ * lanes, then lane 15 -> the next row, then lane 31 -> the upper half (the float32 twin of twvo_scan64, wavenet.c) */
+static void scan64f(float v[64])
+{
+    float t[64];
+    for (int off = 1; off <= 8; off <<= 1) {
+        memcpy(t, v, sizeof(t));
+        for (int l = 0; l < 64; ++l) if ((l & 15) >= off) v[l] = t[l] + t[l - off];
+    }
+    const float r0 = v[15], r2 = v[47];
+    for (int l = 16; l < 32; ++l) v[l] = v[l] + r0;
+    for (int l = 48; l < 64; ++l) v[l] = v[l] + r2;
+    const float h = v[31];
+    for (int l = 32; l < 64; ++l) v[l] = v[l] + h;
+}
+/* cumulative sum of x[0..T) in blocks of 64 (zero padded): block values = scan64f, plus the total of the earlier blocks
+ * (carry + value; the first block has no carry).  inclusive = 0: out[t] = the inclusive value of t-1 (0 for t = 0). */
+static void scan_blocks(const float* x, int T, int inclusive, float* out)
+{
+    float carry = 0.0f;
+    for (int base = 0; base < T; base += 64) {
+        float v[64];
+        for (int l = 0; l < 64; ++l) v[l] = base + l < T ? x[base + l] : 0.0f;
+        scan64f(v);
+        for (int l = 0; l < 64; ++l) if (base > 0) v[l] = carry + v[l];
+        for (int l = 0; l < 64 && base + l < T; ++l)
+            out[base + l] = inclusive ? v[l] : (l == 0 ? (base == 0 ? 0.0f : carry) : v[l - 1]);
+        carry = v[63];
+    }
+}
+
 /* ---- canonical blob: tensors in the order of tacotron_specs() in oracle.py / the product's weights module ---- */
 typedef struct { const float* p; } cur_t;
 static const float* take(cur_t* c, size_t n) { const float* r = c->p; c->p += n; return r; }
@@ -298,25 +329,25 @@ void twvo_taco_infer(const twvo_taco_dims* d, const float* blob, const int32_t* 
                 p[t] = t < len ? twvo_sigmoid(sc[t]) : 0.0f;                /* _maybe_mask_score(-inf) -> sigmoid = 0 */
             }
             /* monotonic_attention, mode 'parallel': p * cumprod_excl(1-p) * cumsum(prev / clip(cumprod, 1e-10, 1));
-             * safe_cumprod = exp(cumsum_excl(log(clip(1-p, tiny, 1)))) */
+             * safe_cumprod = exp(cumsum_excl(log(clip(1-p, tiny, 1)))).  TensorFlow leaves the order of the two cumulative sums
+             * open; the contract (AC-6) runs them in blocks of 64 time steps -- scan64 tree in float32
+             * inside a block (zero padded), the earlier blocks' total added in front -- see scan_blocks below. */
             {
-                float run = 0.0f;
                 for (int t = 0; t < T; ++t) {
                     float om = 1.0f - p[t];
                     const float tiny = 1.17549435e-38f;
                     om = om < tiny ? tiny : (om > 1.0f ? 1.0f : om);
                     lg[t] = twvo_log(om);
-                    cp[t] = twvo_exp(run);
-                    run = run + lg[t];
                 }
-                float cs = 0.0f;
+                scan_blocks(lg, T, 0, cp);                                   /* exclusive cumsum of the logs */
                 for (int t = 0; t < T; ++t) {
+                    cp[t] = twvo_exp(cp[t]);
                     float den = cp[t];
                     den = den < 1e-10f ? 1e-10f : (den > 1.0f ? 1.0f : den);
-                    cs = cs + align[t] / den;
-                    const float pc = p[t] * cp[t];
-                    nal[t] = pc * cs;
+                    lg[t] = align[t] / den;
                 }
+                scan_blocks(lg, T, 1, nal);                                  /* inclusive cumsum */
+                for (int t = 0; t < T; ++t) { const float pc = p[t] * cp[t]; nal[t] = pc * nal[t]; }
                 memcpy(align, nal, sizeof(float) * T);
             }
             if (align_out) for (int t = 0; t < T; ++t) align_out[((size_t)n * T + t) * iters + it] = align[t];   /* tacotron.py:223 */

@@ -509,6 +509,34 @@ __global__ void __launch_bounds__(512) tc_gru_seq_kernel(GruSeqArgs a)
     }
 }
 
+// AC-6: the two cumulative sums of the monotonic attention (exclusive cumsum of log(1 - p), inclusive cumsum of
+// previous / cumprod; tf.contrib.seq2seq.monotonic_attention 'parallel' mode, whose reduction order TensorFlow does not specify) run in
+// BLOCKS OF 64 time steps: inside a block the scan64 tree in float32 -- row_shr 1, 2, 4, 8 inside each row of 16 lanes, lane 15 -> the
+// next row, lane 31 -> the upper half; padding lanes hold +0 -- and the total of the earlier blocks is added in front of the block's
+// values.  Lane i holds element i of the block; returns the lane's inclusive or exclusive prefix and advances `carry` past the block.
+// (Rounds 1-3 ran one add chain over all T steps, v_readlane by v_readlane: 4.8 us of the 41 us decoder step at T = 101.)
+__device__ __forceinline__ float scan64_f32_wave(float v)
+{
+#define TWV_SHR_(c_, m_, b_) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (c_), (m_), 0xf, (b_)))
+    v = v + TWV_SHR_(0x111, 0xf, true);        // row_shr:1
+    v = v + TWV_SHR_(0x112, 0xf, true);        // row_shr:2
+    v = v + TWV_SHR_(0x114, 0xf, true);        // row_shr:4
+    v = v + TWV_SHR_(0x118, 0xf, true);        // row_shr:8
+    v = v + TWV_SHR_(0x142, 0xa, false);       // row_bcast:15 -> rows 1, 3
+    v = v + TWV_SHR_(0x143, 0xc, false);       // row_bcast:31 -> rows 2, 3
+#undef TWV_SHR_
+    return v;
+}
+__device__ __forceinline__ float decg_scan_block(float v, float& carry, bool first, int lane, bool inclusive)
+{
+    const float sc = scan64_f32_wave(v);
+    const float incl = first ? sc : carry + sc;
+    const float up = __shfl_up(incl, 1);
+    const float excl = lane == 0 ? (first ? 0.0f : carry) : up;
+    carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+    return inclusive ? incl : excl;
+}
+
 // =====================================================================================================
 //  the decoder: ONE persistent launch, one workgroup (8 waves) per utterance, max_iters steps
 // =====================================================================================================
@@ -689,9 +717,13 @@ __global__ void __launch_bounds__(512) tc_decoder_kernel(DecArgs a)
             lds[o_q + t] = log_e(om);
         }
         __syncthreads();
-        if (tid == 0) {   // exclusive cumsum of the logs (sequential, T terms)
+        if (wave == 0) {  // exclusive cumsum of the logs (AC-6: blocks of 64, scan64 tree)
             float run = 0.0f;
-            for (int t = 0; t < T; ++t) { const float l = lds[o_q + t]; lds[o_q + t] = run; run = run + l; }
+            for (int base = 0; base < T; base += 64) {
+                const int t = base + lane;
+                const float r = decg_scan_block(t < T ? lds[o_q + t] : 0.0f, run, base == 0, lane, false);
+                if (t < T) lds[o_q + t] = r;
+            }
         }
         __syncthreads();
         for (int t = tid; t < T; t += 512) {
@@ -702,9 +734,13 @@ __global__ void __launch_bounds__(512) tc_decoder_kernel(DecArgs a)
             lds[o_q + t] = div_(lds[o_al + t], den);
         }
         __syncthreads();
-        if (tid == 0) {   // inclusive cumsum (sequential)
+        if (wave == 0) {  // inclusive cumsum (AC-6)
             float cs = 0.0f;
-            for (int t = 0; t < T; ++t) { cs = cs + lds[o_q + t]; lds[o_q + t] = cs; }
+            for (int base = 0; base < T; base += 64) {
+                const int t = base + lane;
+                const float r = decg_scan_block(t < T ? lds[o_q + t] : 0.0f, cs, base == 0, lane, true);
+                if (t < T) lds[o_q + t] = r;
+            }
         }
         __syncthreads();
         for (int t = tid; t < T; t += 512) {
@@ -862,27 +898,6 @@ __device__ __forceinline__ void decg_scan(int o, int T, int lane, bool inclusive
         }
         if (base + lane < T) lds[o + base + lane] = res;
     }
-}
-
-// one batch of a running sum in index order: lane i holds element i (padding lanes hold 0); returns the lane's exclusive or
-// inclusive prefix continued from `run` and advances `run` past the batch (one add chain, eight v_readlane issued ahead)
-__device__ __forceinline__ float decg_scan_regs(float v, float& run, int n, int lane, bool inclusive)
-{
-    float res = 0.0f;
-    for (int i = 0; i < n; i += 8) {
-        float x[8];
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) x[kk] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (i + kk) & 63));
-        float prev = run;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const float nx = prev + x[kk];
-            if (lane == i + kk) res = inclusive ? nx : prev;
-            prev = nx;
-        }
-        run = prev;
-    }
-    return res;
 }
 
 // The decoder step is a table-driven sequence of matvec stages, so the tile-streaming code exists ONCE (inlined in the stage
@@ -1178,12 +1193,12 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                         const float tiny = 1.17549435e-38f;
                         om = om < tiny ? tiny : (om > 1.0f ? 1.0f : om);
                         const float lq = live ? log_e(om) : 0.0f;
-                        const float ex = decg_scan_regs(lq, run, nb_, lane, false);
+                        const float ex = decg_scan_block(lq, run, base == 0, lane, false);
                         const float cpv = exp_e(ex);
                         float den = cpv;
                         den = den < 1e-10f ? 1e-10f : (den > 1.0f ? 1.0f : den);
                         const float q2 = live ? div_(lds[o_al + t], den) : 0.0f;
-                        const float cs = decg_scan_regs(q2, run2, nb_, lane, true);
+                        const float cs = decg_scan_block(q2, run2, base == 0, lane, true);
                         if (live) {
                             const float pc = pv * cpv;
                             const float al = pc * cs;
@@ -1199,28 +1214,27 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                 // L2 then only ever sees that column slice of the encoder memory -- one thread per (column, 32-step chunk), all-gather
                 {
                     const int nch = (T + 31) / 32, ncol = ENC >> lg, c0 = g * ncol;
-                    for (int task = tid; task < ncol * nch; task += 512) {
-                        const int cl = task % ncol, ch = task / ncol;
-                        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                    // one thread per (column, 32-step chunk, CHAIN k): the chunk's four interleaved fma chains (AC-1) sit in four adjacent
+                    // lanes, eight dependent fmas each instead of thirty-two in one thread (1.8 us of the step when a thread ran all four),
+                    // and meet as (s0+s1)+(s2+s3) through two lane exchanges -- the same adds in the same order
+                    for (int task0 = 0; task0 < ncol * nch * 4; task0 += 512) {
+                        const int task = task0 + tid;
+                        const bool live = task < ncol * nch * 4;
+                        const int k = task & 3, tc = live ? task >> 2 : 0;
+                        const int cl = tc % ncol, ch = tc / ncol;
                         const int ta = ch * 32, tb = T < ta + 32 ? T : ta + 32;
+                        float sk = 0.f;
                         if (kv) {
                             const int mo = o_memo + cl;
-                            for (int t = ta; t < tb; t += 4) {
-                                s0 = fma_(lds[mo + t * ncol], lds[o_al + t], s0);
-                                if (t + 1 < tb) s1 = fma_(lds[mo + (t + 1) * ncol], lds[o_al + t + 1], s1);
-                                if (t + 2 < tb) s2 = fma_(lds[mo + (t + 2) * ncol], lds[o_al + t + 2], s2);
-                                if (t + 3 < tb) s3 = fma_(lds[mo + (t + 3) * ncol], lds[o_al + t + 3], s3);
-                            }
+                            for (int t = ta + k; t < tb; t += 4) sk = fma_(lds[mo + t * ncol], lds[o_al + t], sk);
                         } else {
                             const float* mp = memo + c0 + cl;
-                            for (int t = ta; t < tb; t += 4) {
-                                s0 = fma_(mp[(long long)t * ENC], lds[o_al + t], s0);
-                                if (t + 1 < tb) s1 = fma_(mp[(long long)(t + 1) * ENC], lds[o_al + t + 1], s1);
-                                if (t + 2 < tb) s2 = fma_(mp[(long long)(t + 2) * ENC], lds[o_al + t + 2], s2);
-                                if (t + 3 < tb) s3 = fma_(mp[(long long)(t + 3) * ENC], lds[o_al + t + 3], s3);
-                            }
+                            for (int t = ta + k; t < tb; t += 4) sk = fma_(mp[(long long)t * ENC], lds[o_al + t], sk);
                         }
-                        lds[o_part + ch * ncol + cl] = (s0 + s1) + (s2 + s3);
+                        const float s1 = __shfl_xor(sk, 1);
+                        const float pr = (k & 1) ? s1 + sk : sk + s1;       // lanes k = 0,1 hold s0+s1 ; k = 2,3 hold s2+s3 (operand order as written)
+                        const float p2 = __shfl_xor(pr, 2);
+                        if (live && k == 0) lds[o_part + ch * ncol + cl] = pr + p2;
                     }
                     __syncthreads();
                     TWV_STAMP(51)
@@ -1601,12 +1615,12 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                         const float tiny = 1.17549435e-38f;
                         om = om < tiny ? tiny : (om > 1.0f ? 1.0f : om);
                         const float lq = live ? log_e(om) : 0.0f;
-                        const float ex = decg_scan_regs(lq, run, nb_, lane, false);
+                        const float ex = decg_scan_block(lq, run, base == 0, lane, false);
                         const float cpv = exp_e(ex);
                         float den = cpv;
                         den = den < 1e-10f ? 1e-10f : (den > 1.0f ? 1.0f : den);
                         const float q2 = live ? div_(lds[ub + u_al + t], den) : 0.0f;
-                        const float cs = decg_scan_regs(q2, run2, nb_, lane, true);
+                        const float cs = decg_scan_block(q2, run2, base == 0, lane, true);
                         if (live) {
                             const float pc = pv * cpv;
                             const float al = pc * cs;
