@@ -426,6 +426,7 @@ def main():
                 q_wfloats = NL * per_layer + (512 * 512 + 512) + (512 * 256 + 256) + 2 * 256 * 32
                 q_bytes = q_wfloats * 4 + B * (80 * 4 + 4 + 4 + 8)
                 q_floor = NL * 0.200 + 8 * 0.075 + 0.18 + (4 * 0.26 + 0.22 + 0.28 + 0.12 + 0.17 + 0.12 + 1.55)
+                q_tps = traffic_per_step("wn_xcd_generate_kernel_onehot", "B%d_NL%d" % (B, NL)) if qfused else None
                 q_match = None
                 if not args.no_cpu_baseline:
                     nq = 400
@@ -443,7 +444,8 @@ def main():
                                     "classes_drawn": int(torch.unique(oq).numel()), "dtype": "f32 network, f64 softmax/cdf, int32 class ids",
                                     "checked_against_oracle": None if q_match is None else "first 400 class ids of all %d streams: identical" % B,
                                     "roofline": {"bound": "hbm", "achieved": q_bytes / (q_us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                                 "frac": q_bytes / (q_us * 1e-6) / 1e9 / 8000.0, "algorithmic_bytes_per_step": q_bytes, "traffic": None,
+                                                 "frac": q_bytes / (q_us * 1e-6) / 1e9 / 8000.0, "algorithmic_bytes_per_step": q_bytes,
+                                                 "traffic": None if q_tps is None else q_tps * Tq, "measured_bytes_per_step": q_tps,
                                                  "kernel_ms": qms, "latency_floor_us": q_floor, "frac_of_floor": q_floor / q_us,
                                                  "latency_floor_formula": "%d layers x 0.200 us + 8 wave hand-offs x 0.075 + causal row load 0.18 + post phase: 4 L2 hops x 0.26 "
                                                                           "(z, h1, h2, logits) + skip 0.22 + conv1d_1 chunk dots 0.28 + ordered sum 0.12 + conv1d_2 chunk dot 0.17 + "

@@ -76,6 +76,32 @@ if "FETCH_SIZE" in mv and "WRITE_SIZE" in mv:
     t = json.load(open(p)) if os.path.exists(p) else {}
     t.setdefault(h, {}).setdefault("wn_xcd_many_kernel", {})["B64_NL30"] = {"fetch_bytes_per_step": fetch, "write_bytes_per_step": write, "profile": "profiles/%s_rocprofv3_generation_summary.txt" % tag}
     json.dump(t, open(p, "w"), indent=1, sort_keys=True)
+# ---- the one-hot mu-law-256 model (scripts/mulaw_bench.py: a 600-step warm-up launch + the 12 000-step launch, same kernel name)
+qstats = sorted(rows("stats_mulaw/**/*kernel_stats.csv"), key=lambda r: -float(r["TotalDurationNs"]))
+qg = [r for r in qstats if "generate_kernel" in r["Name"]]
+if qg:
+    lines.append("")
+    lines.append("one-hot mu-law-256 model on the XCD kernel, scripts/mulaw_bench.py --batch 8 --steps 12000 (launches of 600 + 12 000 steps):")
+    lines.append("  %-60s calls %3s  total %12.1f us  max %12.1f us => %.3f us per generation step (the 12 000-step launch)" % (
+        re.search(r"wn_\w+", qg[0]["Name"]).group(0) + " (ONEHOT)", qg[0]["Calls"], float(qg[0]["TotalDurationNs"]) / 1e3, float(qg[0]["MaxNs"]) / 1e3,
+        float(qg[0]["MaxNs"]) / 1e3 / 12000))
+qv = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for r in rows("pmc_mulaw_%s/**/*counter_collection.csv" % c):
+        if "generate_kernel" in r["Kernel_Name"]:
+            qv.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+if "FETCH_SIZE" in qv and "WRITE_SIZE" in qv:
+    qsteps = 12600.0
+    fetch = 2.0 * 1024.0 * sum(qv["FETCH_SIZE"]) / qsteps
+    write = 1024.0 * sum(qv["WRITE_SIZE"]) / qsteps
+    lines.append("  PMC (both launches, 12 600 steps): FETCH_SIZE %.1f KiB, WRITE_SIZE %.1f KiB => %.0f B read (x2 gfx950 correction) + %.0f B written per generation step (all 8 streams)" % (
+        sum(qv["FETCH_SIZE"]), sum(qv["WRITE_SIZE"]), fetch, write))
+    import twvk_amd
+    h = twvk_amd._lib.generation_hash()
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    t = json.load(open(p)) if os.path.exists(p) else {}
+    t.setdefault(h, {}).setdefault("wn_xcd_generate_kernel_onehot", {})["B8_NL30"] = {"fetch_bytes_per_step": fetch, "write_bytes_per_step": write, "profile": "profiles/%s_rocprofv3_generation_summary.txt" % tag}
+    json.dump(t, open(p, "w"), indent=1, sort_keys=True)
 if "SQ_WAVE_CYCLES" in vals:
     wc = sum(vals["SQ_WAVE_CYCLES"]) / len(vals["SQ_WAVE_CYCLES"])
     for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):

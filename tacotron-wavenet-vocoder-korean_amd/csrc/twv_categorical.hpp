@@ -3,7 +3,7 @@
 // Replaces wavenet/model.py:243 (float64 softmax -> float32) + generate.py:219-231 (temperature rescale through
 // np.logaddexp.reduce, np.random.choice = float64 cumsum / last / searchsorted 'right').  Class i sits in lane (i mod 64),
 // block (i / 64); every sum over the classes is "per lane over the blocks in block order, then scan64 over the lanes" -- the
-// same tree oracle/wavenet.c:twvo_sample_categorical walks, so the drawn class is bit-identical.  Nothing in here is sequential
+// same tree the CPU checker walks, so the drawn class is bit-identical.  Nothing in here is sequential
 // over the classes: round 3's literal left-to-right logaddexp (255 dependent exp + log1p evaluations, 32 us per draw) pinned
 // nothing -- numpy's own exp/log differ from the contract's by more than the order of the reduce does
 // (tests/test_cpu.py::test_categorical_sampler_contract_against_numpy).
