@@ -456,6 +456,38 @@ def main():
                                     "config": {"workload": "configs[1]'s stack with one-hot mu-law-256 input and a 256-way softmax output (model.py:223-227,243; "
                                                            "generate.py:219-231 with the uniform draw injected), batch=%d x %d steps" % (B, Tq)}}
                 del mq
+                # more streams on the same GPU (two and four per XCD), 0.25 s of audio per stream
+                qs = []
+                for Bs in (16, 32):
+                    try:
+                        mqs = WaveNetModel(Bs, dil, hp.filter_width, hp.residual_channels, hp.dilation_channels, hp.skip_channels,
+                                           quantization_channels=256, out_channels=hp.out_channels, use_biases=hp.use_biases, scalar_input=False,
+                                           initial_filter_width=hp.initial_filter_width, global_condition_channels=hp.gc_channels,
+                                           global_condition_cardinality=2, local_condition_channels=hp.num_mels, upsample_factor=hp.upsample_factor,
+                                           train_mode=False, device=dev)
+                        if args.xcd >= 0:
+                            mqs.set_option("xcd", args.xcd)
+                        mqs.load_weights(tq)
+                        Ts = hp.sample_rate // 4 // hp.hop_size * hp.hop_size
+                        rs_ = np.random.RandomState(92 + Bs)
+                        mels = torch.from_numpy(rs_.uniform(-4, 4, (Bs, Ts // hp.hop_size, hp.num_mels)).astype(np.float32)).to(dev)
+                        us_ = torch.from_numpy(rs_.random_sample((Bs, Ts))).to(dev)
+                        fs_ = rs_.randint(256, size=Bs).astype(np.int32)
+                        gcs_ = (np.arange(Bs) % 2).astype(np.int32)
+                        Us_ = mqs.create_upsample(mels)
+                        mqs.generate(Us_, gcs_, fs_, us_)
+                        mqs.queue_initializer()
+                        torch.cuda.synchronize()
+                        c0 = time.perf_counter()
+                        mqs.generate(Us_, gcs_, fs_, us_)
+                        torch.cuda.synchronize()
+                        cdt = time.perf_counter() - c0
+                        qs.append({"streams": Bs, "samples_per_s": Bs * Ts / cdt, "us_per_generation_step": cdt / Ts * 1e6,
+                                   "realtime_factor_per_stream": Ts / cdt / hp.sample_rate})
+                        del mqs
+                    except Exception as e:
+                        qs.append({"streams": Bs, "error": repr(e)})
+                res["mulaw_256"]["streams_sweep"] = qs
             except Exception as e:
                 res["mulaw_256"] = {"error": repr(e)}
         if not args.no_cpu_baseline:

@@ -163,6 +163,15 @@ def test_tacotron_gemm_kernels_agree(torch_cuda, oracle):
     assert first_mismatch(lin_a.cpu().numpy(), lin_b.cpu().numpy()) is None
     mel_o, lin_o, _ = oracle.taco_infer(d, blob, tok, ln, spk)
     assert first_mismatch(mel_a.cpu().numpy(), mel_o) is None and first_mismatch(lin_a.cpu().numpy(), lin_o) is None
+    # round 4's launch structure (conv banks / GRU input halves / speaker layers as grouped grids, the highway layer fused into one
+    # MFMA launch with interleaved H | T tiles) against one launch per GEMM + the separate highway kernel: the same bits
+    m.set_option("gemm_group", 0)
+    try:
+        mel_c, lin_c, al_c = m.infer(tok, ln, spk)
+    finally:
+        m.set_option("gemm_group", 1)
+    assert first_mismatch(mel_a.cpu().numpy(), mel_c.cpu().numpy()) is None
+    assert first_mismatch(lin_a.cpu().numpy(), lin_c.cpu().numpy()) is None
 
 
 @pytest.mark.parametrize("steps", [25, 200])
