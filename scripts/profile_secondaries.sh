@@ -5,7 +5,7 @@
 # Kernel stats in one run; counters in their own runs with --kernel-trace only (MI355X_MICROARCH.md: 8 SQ slots per pass).
 # Outputs land in gpurun_out/prof_<tag>/; scripts/pmc_to_mfma.py condenses them into summary_mfma_<tag>.txt.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 REPO=$PWD
