@@ -869,6 +869,29 @@ __device__ __forceinline__ bool decg_gather(unsigned long long* X, int n, unsign
     LDSVI(o_abort) = 1;
     return false;
 }
+// the same collection with the consumer inlined: f(j, value) runs in the thread that received element j, as soon as it arrives.  The
+// split stages of tc_decoder_g_kernel finish their cell update there (r * h, the GRU blend, the residual add, the next stage's
+// concatenation: all elementwise in j) instead of in a separate pass over LDS behind one more barrier.
+template <class F>
+__device__ __forceinline__ bool decg_gather_apply(unsigned long long* X, int n, unsigned epoch, int tid, int o_abort, F f)
+{
+    bool done0 = tid >= n, done1 = tid + 512 >= n;
+    for (int it = 0; it < (1 << 20); ++it) {
+        if (!done0) {
+            const unsigned long long v = __hip_atomic_load((tgu64*)(X + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(v >> 32) == epoch) { f(tid, __uint_as_float((unsigned)v)); done0 = true; }
+        }
+        if (!done1) {
+            const unsigned long long v = __hip_atomic_load((tgu64*)(X + tid + 512), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(v >> 32) == epoch) { f(tid + 512, __uint_as_float((unsigned)v)); done1 = true; }
+        }
+        if (__all(done0 && done1)) return true;
+        if ((it & 63) == 63 && LDSVI(o_abort)) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    LDSVI(o_abort) = 1;
+    return false;
+}
 __device__ __forceinline__ void decg_store(unsigned long long* p, unsigned epoch, float v)
 {
     __hip_atomic_store((tgu64*)p, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
@@ -903,7 +926,11 @@ __device__ __forceinline__ void decg_scan(int o, int T, int lane, bool inclusive
 // The decoder step is a table-driven sequence of matvec stages, so the tile-streaming code exists ONCE (inlined in the stage
 // loop): twelve inlined copies made the register allocator spill ~1000 VGPRs, and a real call costs ~4000 cycles because the
 // callee saves its VGPRs to scratch (scripts/ubench/gemv_call.hip).
-enum { DS_W = 0, DS_BIAS, DS_K, DS_N, DS_X, DS_DST, DS_ACT, DS_SPLIT, DS_POST, DS_P0, DS_P1, DS_P2, DS_BIASG, DS_STRIDE };
+// one stage = one 64-byte record: every wave fetches it with three 16-byte LDS reads (thirteen dword reads, each with its own
+// wait in front of the v_readfirstlane, were 0.3 us of every stage)
+enum { DS_W = 0, DS_BIAS, DS_K, DS_N, DS_X, DS_DST, DS_ACT, DS_SPLIT, DS_POST, DS_P0, DS_P1, DS_P2, DS_BIASG, DS_STRIDE = 16 };
+typedef int i32x4s __attribute__((ext_vector_type(4)));
+#define LDS4I(off4) (((__attribute__((address_space(3))) i32x4s*)lds)[(off4)])
 enum { DP_NONE = 0, DP_CAT_ATT, DP_GATES, DP_CAND, DP_QUERY, DP_PROJ, DP_OUT };
 enum { DA_NONE = 0, DA_SIGMOID, DA_TANH, DA_RELU };
 
@@ -942,7 +969,8 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     const int o_pq = o; o += A;
     const int o_scp = o; o += Tp * 8;
     const int o_abort = o; o += 4;
-    const int o_tab = o; o += 16 * DS_STRIDE;             // stage table
+    o = (o + 3) & ~3;
+    const int o_tab = o; o += 16 * DS_STRIDE;             // stage table (16-byte aligned records)
     const int o_nv = o; o += A;                           // normed_v, attention bias
     const int o_ab = o; o += A;
     const int o_bias = o; o += a.nbias;                   // every stage's bias vector, in stage order
@@ -1008,8 +1036,9 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
 #define DECG_PREFETCH(sn)                                                                                                       \
     {                                                                                                                            \
         const int qn_ = o_tab + (sn) * DS_STRIDE;                                                                                \
-        const int wn_ = __builtin_amdgcn_readfirstlane(LDSI(qn_ + DS_W)), Kn_ = __builtin_amdgcn_readfirstlane(LDSI(qn_ + DS_K)); \
-        const int Nn_ = __builtin_amdgcn_readfirstlane(LDSI(qn_ + DS_N)), sp_ = __builtin_amdgcn_readfirstlane(LDSI(qn_ + DS_SPLIT)); \
+        const i32x4s n0_ = LDS4I(qn_ >> 2), n1_ = LDS4I((qn_ >> 2) + 1);                                                         \
+        const int wn_ = __builtin_amdgcn_readfirstlane(n0_.x), Kn_ = __builtin_amdgcn_readfirstlane(n0_.z);                      \
+        const int Nn_ = __builtin_amdgcn_readfirstlane(n0_.w), sp_ = __builtin_amdgcn_readfirstlane(n1_.w);                      \
         const int gn_ = sp_ ? g : 0, lgn_ = sp_ ? lg : 0;                                                                        \
         const int ncn_ = (Kn_ + 31) >> 5, nbn_ = (Nn_ + 63) >> 6;                                                                \
         const int ntn_ = nbn_ > gn_ ? ((nbn_ - gn_ + (1 << lgn_) - 1) >> lgn_) * ncn_ : 0;                                       \
@@ -1030,11 +1059,13 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     for (int it = 0; it < a.iters && ok; ++it) {
         for (int st = 0; st < nst && ok; ++st) {
             const int q = o_tab + st * DS_STRIDE;
-            const int w_bytes = __builtin_amdgcn_readfirstlane(LDSI(q + DS_W)), bias = __builtin_amdgcn_readfirstlane(LDSI(q + DS_BIAS));
-            const int K = __builtin_amdgcn_readfirstlane(LDSI(q + DS_K)), N = __builtin_amdgcn_readfirstlane(LDSI(q + DS_N));
-            const int xo = __builtin_amdgcn_readfirstlane(LDSI(q + DS_X)), dst = __builtin_amdgcn_readfirstlane(LDSI(q + DS_DST));
-            const int act = __builtin_amdgcn_readfirstlane(LDSI(q + DS_ACT)), split = __builtin_amdgcn_readfirstlane(LDSI(q + DS_SPLIT));
-            const int post = __builtin_amdgcn_readfirstlane(LDSI(q + DS_POST));
+            const i32x4s sr0 = LDS4I(q >> 2), sr1 = LDS4I((q >> 2) + 1), sr2 = LDS4I((q >> 2) + 2);
+            const int w_bytes = __builtin_amdgcn_readfirstlane(sr0.x), bias = __builtin_amdgcn_readfirstlane(sr0.y);
+            const int K = __builtin_amdgcn_readfirstlane(sr0.z), N = __builtin_amdgcn_readfirstlane(sr0.w);
+            const int xo = __builtin_amdgcn_readfirstlane(sr1.x), dst = __builtin_amdgcn_readfirstlane(sr1.y);
+            const int act = __builtin_amdgcn_readfirstlane(sr1.z), split = __builtin_amdgcn_readfirstlane(sr1.w);
+            const int post = __builtin_amdgcn_readfirstlane(sr2.x);
+            const int sp0 = __builtin_amdgcn_readfirstlane(sr2.y), sp1 = __builtin_amdgcn_readfirstlane(sr2.z), sp2 = __builtin_amdgcn_readfirstlane(sr2.w);
             const int gg = split ? g : 0, lgg = split ? lg : 0, GG = 1 << lgg;
             const int nchunk = (K + 31) >> 5, nblk = (N + 63) >> 6;
             const int nmine = nblk > gg ? (nblk - gg + GG - 1) >> lgg : 0;
@@ -1093,18 +1124,53 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                 TWV_STAMP(4 * st + 2)
                 // the next stage's first tiles are requested only now: this workgroup's values are already on their way to the others
                 DECG_PREFETCH(st + 1 < nst ? st + 1 : 0)
-                if (xch) decg_gather(Xb, N, ep, dst, tid, o_abort);
+                if (xch) {
+                    // a split stage's values arrive one per thread: the cell update that follows the matvec is elementwise in the
+                    // output index, so the receiving thread does it on arrival (no second pass over LDS, no second barrier)
+                    const int p0 = sp0, p1 = sp1, p2 = sp2;
+                    decg_gather_apply(Xb, N, ep, tid, o_abort, [&](const int j, const float v) {
+                        if (post == DP_GATES) {              // tf.contrib.rnn.GRUCell, gate order r | u: keep h, cat <- [x, r*h]   (p0 = nin, p1 = U)
+                            lds[dst + j] = v;
+                            if (j < p1) {
+                                const float h = lds[o_cat + p0 + j];
+                                lds[o_keep + j] = h;
+                                lds[o_cat + p0 + j] = v * h;
+                            }
+                        } else if (post == DP_CAND) {        // h <- u*h + (1-u)*c   (p0 = U, p1 = where h lives, p2 = the next layer's h / 0 / -1)
+                            const float u = lds[o_vec + p0 + j], h = lds[o_keep + j];
+                            const float t1 = u * h, t2 = 1.0f - u, t3 = t2 * v;
+                            const float hn = t1 + t3;
+                            lds[p1 + j] = hn;
+                            if (p2 >= 0) {                   // residual layer: y <- y + h ; next layer's input [y | h_next]
+                                const float yn = lds[o_y + j] + hn;
+                                lds[o_y + j] = yn;
+                                if (p2 > 0) { lds[o_cat + j] = yn; lds[o_cat + DR + j] = lds[p2 + j]; }
+                            }
+                        } else if (post == DP_PROJ) {
+                            lds[o_y + j] = v; lds[o_cat + j] = v; lds[o_cat + DR + j] = lds[o_hr0 + j];
+                        } else if (post == DP_OUT) {         // tacotron.py:204 reshape; helpers.py:40 last frame fed back
+                            if (g == 0) a.mel[((long long)n * a.iters + it) * M * R + j] = v;
+                            if (j >= M * (R - 1)) lds[o_frame + j - M * (R - 1)] = v;
+                        } else {
+                            lds[dst + j] = v;
+                        }
+                    });
+                }
                 __syncthreads();
                 TWV_STAMP(4 * st + 3)
                 ok = LDSI(o_abort) == 0;
+                if (xch && post != DP_QUERY && post != DP_CAT_ATT && post != DP_NONE) {
+                    if (post == DP_OUT) { TWV_STAMP(53) }
+                    continue;
+                }
             }
-            // ---- what follows the matvec
+            // ---- what follows the matvec (stages that were not exchanged: one workgroup per utterance, the redundant stages)
             if (post == DP_CAT_ATT) {
                 for (int i = tid; i < ENC; i += 512) lds[o_cat + D1 + i] = lds[o_ctx + i];
                 for (int i = tid; i < AS; i += 512) lds[o_cat + D1 + ENC + i] = lds[o_ha + i];
                 __syncthreads();
             } else if (post == DP_GATES) {               // tf.contrib.rnn.GRUCell, gate order r | u: keep h, cat <- [x, r*h]
-                const int nin = __builtin_amdgcn_readfirstlane(LDSI(q + DS_P0)), U = __builtin_amdgcn_readfirstlane(LDSI(q + DS_P1));
+                const int nin = sp0, U = sp1;
                 for (int i = tid; i < U; i += 512) {
                     const float h = lds[o_cat + nin + i];
                     lds[o_keep + i] = h;
@@ -1112,8 +1178,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                 }
                 __syncthreads();
             } else if (post == DP_CAND) {                // h <- u*h + (1-u)*c
-                const int U = __builtin_amdgcn_readfirstlane(LDSI(q + DS_P0)), o_h = __builtin_amdgcn_readfirstlane(LDSI(q + DS_P1));
-                const int o_next = __builtin_amdgcn_readfirstlane(LDSI(q + DS_P2));
+                const int U = sp0, o_h = sp1, o_next = sp2;
                 for (int i = tid; i < U; i += 512) {
                     const float c = lds[o_cand + i], u = lds[o_vec + U + i], h = lds[o_keep + i];
                     const float t1 = u * h, t2 = 1.0f - u, t3 = t2 * c;
@@ -2215,7 +2280,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             ga.d = da; ga.G = G; ga.exch = reinterpret_cast<unsigned long long*>(exch);
             HIPCHK(hipMemsetAsync(exch, 0, (size_t)N * 2 * kExN * 8, st));
             long long fl = 1024 * 2 + 512 * 2 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + (M * R + 63) / 64 * 64 + Tp * 4 + A +
-                           Tp * 8 + 4 + 16 * 13 + 2 * A + da.nbias + pmax;
+                           Tp * 8 + 4 + 3 + 16 * 16 + 2 * A + da.nbias + pmax;
             const long long kvf = (long long)((T + G - 1) / G) * A + (long long)T * (ENC / G);
             ga.kv_lds = (fl + kvf) * 4 <= 160 * 1024 ? 1 : 0;
             if (ga.kv_lds) fl += kvf;
