@@ -584,7 +584,7 @@ def main():
                     return (time.perf_counter() - c0) / reps
                 dec_us = (_mel_only(tm) - _mel_only(tm1)) * 1e6 / (hp.max_iters - 1)
                 # pieces of one step (us, workgroup 0 of utterance 0, 160 steps averaged): everything that is not an exchange, and the hop
-                DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US = 23.18, 10, 0.39
+                DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US = 22.46, 10, 0.39
                 dec_floor = DEC_NONEXCH_US + DEC_EXCHANGES * DEC_HOP_US
                 del tm1
                 res["tacotron"] = {"metric": "Tacotron mel frames/sec", "value": TN * hp.max_iters * hp.reduction_factor / qdt,
@@ -599,10 +599,10 @@ def main():
                                                 "decoder": {"kernel": "tc_decoder_g_kernel (8 workgroups per utterance, 11 matvec stages + attention, 10 all-gathers per step)",
                                                             "bound": "latency", "us_per_step": dec_us, "ms_per_pass": dec_us * hp.max_iters * 1e-3,
                                                             "latency_floor_us": dec_floor, "frac_of_floor": dec_floor / dec_us,
-                                                            "formula": "per step: tile dots 7.08 + chunk sums / bias / activation / publish 6.96 + barriers and stage set-up 4.98 + "
-                                                                       "attention compute 4.16 (score dots 1.98, monotonic recurrence 1.06, context dots 0.76, concat 0.36) = %.2f us that is "
+                                                            "formula": "per step: tile dots 6.93 + chunk sums / bias / activation / publish 6.83 + barriers and stage set-up 4.74 + "
+                                                                       "attention compute 3.96 (score dots 1.96, monotonic recurrence 1.05, context dots 0.77, the rest 0.18) = %.2f us that is "
                                                                        "not exchange, + %d exchanges x %.2f us (one-way granule hop between XCDs measured in isolation; in the kernel an "
-                                                                       "exchange averages 1.33 us incl. the cell update done on arrival: the difference is skew between the utterance's 8 workgroups); "
+                                                                       "exchange averages 1.35 us incl. the cell update done on arrival: the difference is skew between the utterance's 8 workgroups); "
                                                                        "profiles/r04_tacotron_decoder_phase_profile.txt (round 3's step: 41.4 us, ..._v1_before.txt)" % (DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US)}},
                                    "config": {"workload": "configs[2]: Tacotron text->mel (CBHG encoder, monotonic Bahdanau attention decoder, post-CBHG, "
                                                           "linear), batch=32, 101 tokens, 200 decoder steps = 1000 mel frames/utterance, random-init weights"},

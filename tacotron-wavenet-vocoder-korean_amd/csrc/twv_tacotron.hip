@@ -929,6 +929,7 @@ __device__ __forceinline__ void decg_scan(int o, int T, int lane, bool inclusive
 // one stage = one 64-byte record: every wave fetches it with three 16-byte LDS reads (thirteen dword reads, each with its own
 // wait in front of the v_readfirstlane, were 0.3 us of every stage)
 enum { DS_W = 0, DS_BIAS, DS_K, DS_N, DS_X, DS_DST, DS_ACT, DS_SPLIT, DS_POST, DS_P0, DS_P1, DS_P2, DS_BIASG, DS_STRIDE = 16 };
+// (for the GRU stages DS_X is also the buffer the cell update works in: [x | h] -> [x | r*h])
 typedef int i32x4s __attribute__((ext_vector_type(4)));
 #define LDS4I(off4) (((__attribute__((address_space(3))) i32x4s*)lds)[(off4)])
 enum { DP_NONE = 0, DP_CAT_ATT, DP_GATES, DP_CAND, DP_QUERY, DP_PROJ, DP_OUT };
@@ -952,6 +953,10 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     // ---- LDS carve
     int o = 0;
     const int o_cat = o; o += 1024;
+    // the attention GRU's input [prenet_out | attention | ha] has a buffer of its own: its three parts are written where they are
+    // produced (the prenet's epilogue, the context's gather of the PREVIOUS step, the attention cell's update), not copied together
+    // behind a barrier at the start of every step
+    const int o_cat2 = o; o += ((D1 + ENC + AS + 63) / 64) * 64;
     const int o_vec = o; o += 1024;                       // gathered gates (r | u), prenet hidden
     const int o_cand = o; o += 512;
     const int o_keep = o; o += 512;                       // h before the update
@@ -984,7 +989,8 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     for (int i = tid; i < AS; i += 512) lds[o_ha + i] = init[i];
     for (int i = tid; i < a.layers * DR; i += 512) lds[o_hr0 + i] = init[AS + i];
     for (int i = tid; i < ((M + 31) / 32) * 32; i += 512) lds[o_frame + i] = 0.0f;
-    for (int i = tid; i < ENC; i += 512) lds[o_ctx + i] = 0.0f;
+    for (int i = tid; i < ENC; i += 512) { lds[o_ctx + i] = 0.0f; lds[o_cat2 + D1 + i] = 0.0f; }
+    for (int i = tid; i < AS; i += 512) lds[o_cat2 + D1 + ENC + i] = init[i];
     for (int i = tid; i < Tp; i += 512) lds[o_al + i] = i == 0 ? 1.0f : 0.0f;
     if (tid < 4) LDSI(o_abort + tid) = 0;
     for (int i = tid; i < A; i += 512) { lds[o_nv + i] = P[a.w.nv + i]; lds[o_ab + i] = P[a.w.ab + i]; }
@@ -1006,10 +1012,10 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
         };
         // rnn_wrappers.py:425 decoder prenet (redundant in every workgroup: 28 tiles)
         put(a.w.dp1, a.w.dp1b, M, D0, o_frame, o_vec, DA_RELU, 0, DP_NONE, 0, 0, 0);
-        put(a.w.dp2, a.w.dp2b, D0, D1, o_vec, o_cat, DA_RELU, 0, DP_CAT_ATT, 0, 0, 0);
+        put(a.w.dp2, a.w.dp2b, D0, D1, o_vec, o_cat2, DA_RELU, 0, DP_NONE, 0, 0, 0);
         // rnn_wrappers.py:310-312 attention GRU on [prenet_out | attention | ha]
-        put(a.w.aWg, a.w.abg, D1 + ENC + AS, 2 * AS, o_cat, o_vec, DA_SIGMOID, 1, DP_GATES, D1 + ENC, AS, 0);
-        put(a.w.aWc, a.w.abc, D1 + ENC + AS, AS, o_cat, o_cand, DA_TANH, 1, DP_CAND, AS, o_ha, -1);
+        put(a.w.aWg, a.w.abg, D1 + ENC + AS, 2 * AS, o_cat2, o_vec, DA_SIGMOID, 1, DP_GATES, D1 + ENC, AS, 0);
+        put(a.w.aWc, a.w.abc, D1 + ENC + AS, AS, o_cat2, o_cand, DA_TANH, 1, DP_CAND, AS, o_ha, -1);
         // attention query layer (redundant: 32 tiles), then score / recurrence / context
         put(a.w.Wq, -1, AS, A, o_ha, o_pq, DA_NONE, 0, DP_QUERY, 0, 0, 0);
         // rnn_wrappers.py:463 concat(output, attention) -> OutputProjectionWrapper(dec_rnn)
@@ -1132,9 +1138,9 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                         if (post == DP_GATES) {              // tf.contrib.rnn.GRUCell, gate order r | u: keep h, cat <- [x, r*h]   (p0 = nin, p1 = U)
                             lds[dst + j] = v;
                             if (j < p1) {
-                                const float h = lds[o_cat + p0 + j];
+                                const float h = lds[xo + p0 + j];
                                 lds[o_keep + j] = h;
-                                lds[o_cat + p0 + j] = v * h;
+                                lds[xo + p0 + j] = v * h;
                             }
                         } else if (post == DP_CAND) {        // h <- u*h + (1-u)*c   (p0 = U, p1 = where h lives, p2 = the next layer's h / 0 / -1)
                             const float u = lds[o_vec + p0 + j], h = lds[o_keep + j];
@@ -1145,6 +1151,9 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                                 const float yn = lds[o_y + j] + hn;
                                 lds[o_y + j] = yn;
                                 if (p2 > 0) { lds[o_cat + j] = yn; lds[o_cat + DR + j] = lds[p2 + j]; }
+                            } else {                         // the attention cell: its new state is the tail of its own next input and
+                                lds[xo + D1 + ENC + j] = hn; // the head of the concat projection's input (rnn_wrappers.py:463)
+                                lds[o_cat + j] = hn;
                             }
                         } else if (post == DP_PROJ) {
                             lds[o_y + j] = v; lds[o_cat + j] = v; lds[o_cat + DR + j] = lds[o_hr0 + j];
@@ -1159,22 +1168,18 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                 __syncthreads();
                 TWV_STAMP(4 * st + 3)
                 ok = LDSI(o_abort) == 0;
-                if (xch && post != DP_QUERY && post != DP_CAT_ATT && post != DP_NONE) {
+                if (xch && post != DP_QUERY && post != DP_NONE) {
                     if (post == DP_OUT) { TWV_STAMP(53) }
                     continue;
                 }
             }
             // ---- what follows the matvec (stages that were not exchanged: one workgroup per utterance, the redundant stages)
-            if (post == DP_CAT_ATT) {
-                for (int i = tid; i < ENC; i += 512) lds[o_cat + D1 + i] = lds[o_ctx + i];
-                for (int i = tid; i < AS; i += 512) lds[o_cat + D1 + ENC + i] = lds[o_ha + i];
-                __syncthreads();
-            } else if (post == DP_GATES) {               // tf.contrib.rnn.GRUCell, gate order r | u: keep h, cat <- [x, r*h]
+            if (post == DP_GATES) {               // tf.contrib.rnn.GRUCell, gate order r | u: keep h, cat <- [x, r*h]
                 const int nin = sp0, U = sp1;
                 for (int i = tid; i < U; i += 512) {
-                    const float h = lds[o_cat + nin + i];
+                    const float h = lds[xo + nin + i];
                     lds[o_keep + i] = h;
-                    lds[o_cat + nin + i] = lds[o_vec + i] * h;
+                    lds[xo + nin + i] = lds[o_vec + i] * h;
                 }
                 __syncthreads();
             } else if (post == DP_CAND) {                // h <- u*h + (1-u)*c
@@ -1188,6 +1193,9 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                         const float yn = lds[o_y + i] + hn;
                         lds[o_y + i] = yn;
                         if (o_next > 0) { lds[o_cat + i] = yn; lds[o_cat + DR + i] = lds[o_next + i]; }
+                    } else {
+                        lds[xo + D1 + ENC + i] = hn;
+                        lds[o_cat + i] = hn;
                     }
                 }
                 __syncthreads();
@@ -1305,19 +1313,22 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                     TWV_STAMP(51)
                     ++ep;
                     unsigned long long* Xb = X + (ep & 1) * kExN;
+                    // the context goes where it is read: the concat projection's input [ha | context] of this step and the attention
+                    // cell's input [prenet | context | ha] of the NEXT step (AttentionWrapper feeds state.attention back, rnn_wrappers.py:310)
                     if (tid < ncol) {
                         float v = 0.0f;
                         for (int ch = 0; ch < nch; ++ch) { const float c = lds[o_part + ch * ncol + tid]; v = ch == 0 ? c : v + c; }
-                        if (G == 1) lds[o_ctx + tid] = v; else decg_store(Xb + c0 + tid, ep, v);
+                        if (G == 1) { lds[o_ctx + tid] = v; lds[o_cat + AS + tid] = v; lds[o_cat2 + D1 + tid] = v; }
+                        else decg_store(Xb + c0 + tid, ep, v);
                     }
-                    if (G > 1) decg_gather(Xb, ENC, ep, o_ctx, tid, o_abort);
+                    if (G > 1)
+                        decg_gather_apply(Xb, ENC, ep, tid, o_abort, [&](const int j, const float v) {
+                            lds[o_ctx + j] = v; lds[o_cat + AS + j] = v; lds[o_cat2 + D1 + j] = v;
+                        });
                     __syncthreads();
                     ok = LDSI(o_abort) == 0;
                 }
                 TWV_STAMP(52)
-                for (int i = tid; i < AS; i += 512) lds[o_cat + i] = lds[o_ha + i];
-                for (int i = tid; i < ENC; i += 512) lds[o_cat + AS + i] = lds[o_ctx + i];
-                __syncthreads();
             }
         }
     }
@@ -2279,7 +2290,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             DecGArgs ga;
             ga.d = da; ga.G = G; ga.exch = reinterpret_cast<unsigned long long*>(exch);
             HIPCHK(hipMemsetAsync(exch, 0, (size_t)N * 2 * kExN * 8, st));
-            long long fl = 1024 * 2 + 512 * 2 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + (M * R + 63) / 64 * 64 + Tp * 4 + A +
+            long long fl = 1024 * 2 + (da.D1 + ENC + AS + 63) / 64 * 64 + 512 * 2 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + (M * R + 63) / 64 * 64 + Tp * 4 + A +
                            Tp * 8 + 4 + 3 + 16 * 16 + 2 * A + da.nbias + pmax;
             const long long kvf = (long long)((T + G - 1) / G) * A + (long long)T * (ENC / G);
             ga.kv_lds = (fl + kvf) * 4 <= 160 * 1024 ? 1 : 0;
