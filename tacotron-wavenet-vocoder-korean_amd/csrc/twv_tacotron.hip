@@ -452,60 +452,114 @@ struct GruSeqArgs {
     int T;
     float* out;           // [rows][2U], rows past the length left untouched (pre-zeroed)
 };
+// workgroup barrier that orders LDS traffic only: outstanding global loads / stores stay in flight across it
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Round 4.  One workgroup walks one (utterance, direction); a step is strictly serial (gates need h, the candidate needs r * h), so
+// the step time is the dependent path.  Rounds 1-3 spent it on three things this version removes:
+//   * every lane read all 32 operand values of a chunk from LDS itself (24 ds_read_b128 per wave and step: 1536 LDS cycles of a
+//     2500-cycle step).  Now a row of 16 lanes reads the chunk once (two 4-byte reads per lane) and v_fmac_f32_dpp row broadcasts
+//     feed the fmas (dot32_dpp, twv_dpp.hpp);
+//   * the chunk values of an output met through LDS partials: FOUR barriers per step.  Now a wave owns whole outputs and the chunk
+//     values meet in registers: TWO barriers (r * h and u visible; h visible);
+//   * the x-parts of a step (a fresh row of Gx / Cx every step, out of HBM or the memory-side cache) were loaded when needed.  Now
+//     they are fetched kDepth steps ahead into a register ring, and the barriers wait for LDS only (a __syncthreads() is also a fence
+//     that drains every outstanding global access).
+// Work split (VALU issue is what is left, so no activation is evaluated on idle lanes):
+//   waves 0-3 "gate waves":      outputs 64 w + lane of the 2U = 256 gate outputs (waves 0, 1: r; waves 2, 3: u), all four chunks:
+//                                four dots, one sigmoid on 64 useful lanes
+//   waves 4-7 "candidate waves": outputs 32 (w - 4) + (lane mod 32); lanes 0-31 run chunks 0, 1, lanes 32-63 chunks 2, 3 of the same
+//                                outputs; v_permlane32_swap brings chunks 2, 3 to the lower half; tanh and the state update there
+// The sums keep their order -- ((((x-part + c0) + c1) + c2) + c3) + bias -- so the bits are those of rounds 1-3.
+__device__ __forceinline__ void gru_load_column(float (&w)[32], const float* tile, int out_lane)
+{
+    const f32x4* p = reinterpret_cast<const f32x4*>(tile) + out_lane;       // tile = [kq][64 output lanes][4]
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) { const f32x4 x = p[kq * 64]; w[4 * kq] = x.x; w[4 * kq + 1] = x.y; w[4 * kq + 2] = x.z; w[4 * kq + 3] = x.w; }
+}
 __global__ void __launch_bounds__(512) tc_gru_seq_kernel(GruSeqArgs a)
 {
     constexpr int U = 128;
+    constexpr int kDepth = 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const int len = a.lengths ? a.lengths[n] : a.T;
-    // LDS: hs[128] | rh[128] | ug[128] | gp[4 nblk][4 chunk][64] | cp[2][4][64]
-    const int o_h = 0, o_rh = 128, o_ug = 256, o_gp = 384, o_cp = 384 + 1024;
-    Tile tg0, tg1, tc0;
-    const int gnb = wave >> 1, gch = (wave & 1) * 2;       // gate tiles (gnb, gch), (gnb, gch+1)
-    const int cnb = wave >> 2, cch = wave & 3;             // candidate tile (cnb, cch)
-    load_tile(tg0, a.Wgh[dir] + ((long long)gnb * 4 + gch) * kTile, lane);
-    load_tile(tg1, a.Wgh[dir] + ((long long)gnb * 4 + gch + 1) * kTile, lane);
-    load_tile(tc0, a.Wch[dir] + ((long long)cnb * 4 + cch) * kTile, lane);
-    const float bgv = tid < 2 * U ? a.bg[dir][tid] : 0.0f;
-    const float bcv = tid < U ? a.bc[dir][tid] : 0.0f;
+    // LDS: hs[128] | rh[128] | ug[128]
+    const int o_h = 0, o_rh = 128, o_ug = 256;
     if (tid < U) lds[o_h + tid] = a.init ? a.init[(long long)n * 2 * U + dir * U + tid] : 0.0f;
     __syncthreads();
-    const float* Gx = a.Gx + dir * a.gx_dstride;
-    const float* Cx = a.Cx + dir * a.cx_dstride;
-    for (int s = 0; s < len; ++s) {
-        const int t = dir == 0 ? s : len - 1 - s;
-        const long long row = (long long)n * a.T + t;
-        const float gx = tid < 2 * U ? Gx[row * 2 * U + tid] : 0.0f;
-        const float cx = tid < U ? Cx[row * U + tid] : 0.0f;
-        lds[o_gp + (gnb * 4 + gch) * 64 + lane] = dot_ldso(tg0, o_h + gch * 32);
-        lds[o_gp + (gnb * 4 + gch + 1) * 64 + lane] = dot_ldso(tg1, o_h + (gch + 1) * 32);
-        __syncthreads();
-        if (tid < 2 * U) {
-            const int nb = tid >> 6;
-            float g = gx;
+    if (len <= 0) return;
+    auto row_of = [&](int s) { const int sc = s < len ? s : len - 1; return (long long)n * a.T + (dir == 0 ? sc : len - 1 - sc); };
+    if (wave < 4) {
+        const int go = 64 * wave + lane;
+        float w0[32], w1[32], w2[32], w3[32];
+        const float* tiles = a.Wgh[dir] + (long long)wave * 4 * kTile;        // standard tiles [nblk][chunk][kq][64 output lanes][4]
+        gru_load_column(w0, tiles, lane); gru_load_column(w1, tiles + kTile, lane);
+        gru_load_column(w2, tiles + 2 * kTile, lane); gru_load_column(w3, tiles + 3 * kTile, lane);
+        const float bgv = a.bg[dir][go];
+        const float* Gx = a.Gx + dir * a.gx_dstride + go;
+        float gxr[kDepth];
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch) g = g + lds[o_gp + (nb * 4 + ch) * 64 + lane];
-            g = sigmoid_e(g + bgv);
-            if (tid < U) lds[o_rh + tid] = g * lds[o_h + tid];      // r * h
-            else lds[o_ug + tid - U] = g;                           // u
-        }
-        __syncthreads();
-        lds[o_cp + (cnb * 4 + cch) * 64 + lane] = dot_ldso(tc0, o_rh + cch * 32);
-        __syncthreads();
-        if (tid < U) {
-            const int nb = tid >> 6;
-            float c = cx;
+        for (int j = 0; j < kDepth; ++j) gxr[j] = Gx[row_of(j) * 2 * U];
+        const int xo = o_h + (lane & 15);
+        for (int s0 = 0; s0 < len; s0 += kDepth) {
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch) c = c + lds[o_cp + (nb * 4 + ch) * 64 + lane];
-            c = tanh_e(c + bcv);
-            const float u = lds[o_ug + tid], h = lds[o_h + tid];
-            const float t1 = u * h, t2 = 1.0f - u, t3 = t2 * c;
-            const float hn = t1 + t3;
-            a.out[row * 2 * U + dir * U + tid] = hn;
-            lds[o_h + tid] = hn;
+            for (int j = 0; j < kDepth; ++j) {
+                const int s = s0 + j;
+                if (s >= len) break;
+                const float gx = gxr[j];
+                gxr[j] = Gx[row_of(s + kDepth) * 2 * U];
+                float d0, d1, d2, d3;
+                dot32_dpp_x2(w0, lds[xo], lds[xo + 16], w1, lds[xo + 32], lds[xo + 48], d0, d1);
+                dot32_dpp_x2(w2, lds[xo + 64], lds[xo + 80], w3, lds[xo + 96], lds[xo + 112], d2, d3);
+                float g = gx;
+                g = g + d0; g = g + d1; g = g + d2; g = g + d3;
+                g = sigmoid_e(g + bgv);
+                if (go < U) lds[o_rh + go] = g * lds[o_h + go];            // r * h
+                else lds[o_ug + go - U] = g;                               // u
+                lds_barrier();                                             // r * h, u visible
+                lds_barrier();                                             // (the candidate waves' half of the step)
+            }
         }
-        __syncthreads();
+    } else {
+        const int co = 32 * (wave - 4) + (lane & 31);
+        const int cch = (lane >> 5) * 2;
+        float w0[32], w1[32];
+        const float* tiles = a.Wch[dir] + ((long long)(co >> 6) * 4 + cch) * kTile;
+        gru_load_column(w0, tiles, co & 63); gru_load_column(w1, tiles + kTile, co & 63);
+        const float bcv = a.bc[dir][co];
+        const float* Cx = a.Cx + dir * a.cx_dstride + co;
+        float cxr[kDepth];
+#pragma unroll
+        for (int j = 0; j < kDepth; ++j) cxr[j] = Cx[row_of(j) * U];
+        const int xo = o_rh + cch * 32 + (lane & 15);
+        for (int s0 = 0; s0 < len; s0 += kDepth) {
+#pragma unroll
+            for (int j = 0; j < kDepth; ++j) {
+                const int s = s0 + j;
+                if (s >= len) break;
+                const long long row = row_of(s);
+                const float cx = cxr[j];
+                cxr[j] = Cx[row_of(s + kDepth) * U];
+                lds_barrier();                                             // r * h, u visible
+                float e0, e1;
+                dot32_dpp_x2(w0, lds[xo], lds[xo + 16], w1, lds[xo + 32], lds[xo + 48], e0, e1);
+                const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(e0), __float_as_uint(e0), false, false);   // [1]: lanes 32-63's values on both halves
+                const auto s3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(e1), __float_as_uint(e1), false, false);
+                float c = cx;
+                c = c + e0; c = c + e1;                                            // chunks 0, 1 (lower half)
+                c = c + __uint_as_float(s2[1]); c = c + __uint_as_float(s3[1]);    // chunks 2, 3
+                c = tanh_e(c + bcv);
+                if (lane < 32) {
+                    const float u = lds[o_ug + co], h = lds[o_h + co];
+                    const float t1 = u * h, t2 = 1.0f - u, t3 = t2 * c;
+                    const float hn = t1 + t3;
+                    a.out[row * 2 * U + dir * U + co] = hn;
+                    lds[o_h + co] = hn;
+                }
+                lds_barrier();                                             // h visible
+            }
+        }
     }
 }
 
@@ -2151,7 +2205,7 @@ static void run_cbhg(hipStream_t st, const twv_tacotron* h, const float* P, cons
     g.Gx = gx; g.Cx = cx; g.gx_dstride = (long long)rows * 2 * rnn; g.cx_dstride = (long long)rows * rnn;
     for (int dr = 0; dr < 2; ++dr) { g.Wgh[dr] = P + c.gWgh[dr].off; g.Wch[dr] = P + c.gWch[dr].off; g.bg[dr] = P + c.gbg[dr].off; g.bc[dr] = P + c.gbc[dr].off; }
     g.init = init; g.lengths = lengths; g.T = T; g.out = out;
-    hipLaunchKernelGGL(tc_gru_seq_kernel, dim3(N * 2), dim3(512), (384 + 1024 + 512) * 4, st, g);
+    hipLaunchKernelGGL(tc_gru_seq_kernel, dim3(N * 2), dim3(512), 384 * 4, st, g);
     (void)h;
 }
 
