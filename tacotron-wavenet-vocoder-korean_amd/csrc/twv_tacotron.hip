@@ -872,6 +872,8 @@ struct DecGArgs {
     int G;
     unsigned long long* exch;       // [N][2][kExN]
     int kv_lds;                     // 1: key rows / memory columns of the workgroup fit in LDS
+    int local;                      // 1: the G workgroups of an utterance share one XCD and exchange through its L2
+    int* tickets;                   // [8] role tickets of the local mode, zeroed before the launch
 };
 
 struct DecgPos { int m, ch; };
@@ -883,6 +885,55 @@ __device__ __forceinline__ void decg_adv(DecgPos& p, int step, int nchunk)
 __device__ __forceinline__ int decg_off(int wt_bytes, const DecgPos& p, int nchunk, int g, int lg)
 {
     return wt_bytes + ((((p.m << lg) + g) * nchunk + p.ch) << 13);        // kTile * 4 = 8192 bytes per tile
+}
+// Which tiles of a stage a workgroup owns.  A tile is 64 columns x one 32-term chunk (lane = column).  A split stage with fewer
+// column blocks than workgroups (N = 256 at G = 8: four blocks) would leave half of the utterance's workgroups idle while the other
+// half streams and multiplies twice its share, so such a stage runs in HALF-BLOCK form: workgroup g owns columns
+// [32 g, 32 g + 32) and a tile is 32 columns x TWO chunks -- lanes 0-31 chunk 2i, lanes 32-63 chunk 2i + 1 of the same columns (the
+// same 8 KB per tile: two half tiles of the standard image, 8192 bytes apart).  Chunk values still meet in LDS in chunk order.
+struct DecgGeo {
+    int nchunk;     // 32-term chunks of the reduction
+    int nct;        // tiles per column block (nchunk, or ceil(nchunk / 2) in half-block form)
+    int ntile;      // this workgroup's tiles
+    int nmine;      // this workgroup's column blocks
+    int gT, lgT;    // block index = (m << lgT) + gT
+    int hf;         // 1 = half-block form
+};
+__device__ __forceinline__ DecgGeo decg_geo(int K, int N, int split, int g, int lg)
+{
+    DecgGeo e;
+    const int G = 1 << lg;
+    e.nchunk = (K + 31) >> 5;
+    const int nblk = (N + 63) >> 6;
+    e.hf = (split && G > 1 && 2 * nblk <= G) ? 1 : 0;
+    if (e.hf) {
+        e.gT = g >> 1; e.lgT = 0;
+        e.nct = (e.nchunk + 1) >> 1;
+        e.nmine = (g >> 1) < nblk ? 1 : 0;
+    } else {
+        e.gT = split ? g : 0; e.lgT = split ? lg : 0;
+        e.nct = e.nchunk;
+        e.nmine = nblk > e.gT ? (nblk - e.gT + (1 << e.lgT) - 1) >> e.lgT : 0;
+    }
+    e.ntile = e.nmine * e.nct;
+    return e;
+}
+__device__ __forceinline__ int decg_toff(int wt_bytes, const DecgGeo& e, const DecgPos& p)
+{
+    return wt_bytes + ((((p.m << e.lgT) + e.gT) * e.nchunk + (p.ch << e.hf)) << 13);
+}
+// per-lane byte offset inside a tile's image
+__device__ __forceinline__ int decg_voff(const DecgGeo& e, int g, int lane)
+{
+    return e.hf ? ((lane >> 5) << 13) + ((((g & 1) << 5) + (lane & 31)) << 4) : lane << 4;
+}
+__device__ __forceinline__ int decg_geo_pack(const DecgGeo& e) { return e.hf | (e.lgT << 1) | (e.gT << 4) | (e.nmine << 12); }
+__device__ __forceinline__ DecgGeo decg_geo_unpack(int K, int nct, int ntile, int geo)
+{
+    DecgGeo e;
+    e.nchunk = (K + 31) >> 5; e.nct = nct; e.ntile = ntile;
+    e.hf = geo & 1; e.lgT = (geo >> 1) & 7; e.gT = (geo >> 4) & 255; e.nmine = geo >> 12;
+    return e;
 }
 // local block m, lane l: chunk values summed in order (AC-1); the LDS reads of four chunks are issued together
 __device__ __forceinline__ float decg_combine(int o_part, int nchunk, int m, int l)
@@ -946,10 +997,13 @@ __device__ __forceinline__ bool decg_gather_apply(unsigned long long* X, int n, 
     LDSVI(o_abort) = 1;
     return false;
 }
-__device__ __forceinline__ void decg_store(unsigned long long* p, unsigned epoch, float v)
+// local: writer and readers sit on ONE XCD -- a plain store leaves the line in that XCD's L2, where the readers' sc1 loads (L1
+// bypassed) find it (the recipe of twv_wavenet_xcd.hip); otherwise an agent-scope store writes through to the memory side
+__device__ __forceinline__ void decg_store(unsigned long long* p, unsigned epoch, float v, bool local)
 {
-    __hip_atomic_store((tgu64*)p, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long q = ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v);
+    if (local) { *(tgu64*)p = q; asm volatile("" ::: "memory"); }
+    else __hip_atomic_store((tgu64*)p, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // running sums over lds[o .. o+T) in index order (one add chain), one wave, staged through registers; eight v_readlane
 // are issued ahead of the dependent adds (padding lanes hold 0 and their results are never stored)
@@ -982,7 +1036,8 @@ __device__ __forceinline__ void decg_scan(int o, int T, int lane, bool inclusive
 // callee saves its VGPRs to scratch (scripts/ubench/gemv_call.hip).
 // one stage = one 64-byte record: every wave fetches it with three 16-byte LDS reads (thirteen dword reads, each with its own
 // wait in front of the v_readfirstlane, were 0.3 us of every stage)
-enum { DS_W = 0, DS_BIAS, DS_K, DS_N, DS_X, DS_DST, DS_ACT, DS_SPLIT, DS_POST, DS_P0, DS_P1, DS_P2, DS_BIASG, DS_STRIDE = 16 };
+enum { DS_W = 0, DS_BIAS, DS_K, DS_N, DS_X, DS_DST, DS_ACT, DS_SPLIT, DS_POST, DS_P0, DS_P1, DS_P2, DS_BIASG, DS_NCT, DS_NTILE, DS_GEO, DS_STRIDE = 16 };
+// DS_NCT, DS_NTILE, DS_GEO: this workgroup's tile geometry of the stage (DecgGeo), worked out once when the table is written
 // (for the GRU stages DS_X is also the buffer the cell update works in: [x | h] -> [x | r*h])
 typedef int i32x4s __attribute__((ext_vector_type(4)));
 #define LDS4I(off4) (((__attribute__((address_space(3))) i32x4s*)lds)[(off4)])
@@ -996,8 +1051,28 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lg = ga.G == 8 ? 3 : (ga.G == 4 ? 2 : (ga.G == 2 ? 1 : 0)), G = 1 << lg;
-    const int n = blockIdx.x >> lg, g = blockIdx.x & (G - 1);
+    // workgroup -> (utterance n, slice g):
+    //   spread (local = 0): n = id / G, g = id % G.  Workgroups go to the XCDs round-robin, so slice g of the weights lives in XCD
+    //                       g's L2 -- and every exchange of the step crosses XCDs (a memory-side hop)
+    //   local  (local = 1): XCD x hosts the utterances x, x + 8, ... with all their slices: exchanges stay inside one L2 (plain
+    //                       stores, sc1 loads), the weights stream through it (6.4 MB through 4 MB: the memory-side cache feeds
+    //                       them, four utterances per fetch).  The XCD is read from the hardware and the role is a ticket of that
+    //                       XCD, so the placement does not rest on the dispatcher's order.
+    const bool loc = ga.local != 0;
+    int n = blockIdx.x >> lg, g = blockIdx.x & (G - 1);
+    if (loc) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 15u;
+        __shared__ int s_ticket;
+        if (tid == 0) s_ticket = xcc < 8u ? atomicAdd(ga.tickets + xcc, 1) : 1 << 20;
+        __syncthreads();
+        const int slot = __builtin_amdgcn_readfirstlane(s_ticket);
+        g = slot & (G - 1);
+        n = slot < (1 << 20) ? ((slot >> lg) << 3) + (int)xcc : a.N;
+    }
     const int T = a.T, M = a.M, R = a.R, A = a.A, AS = a.AS, ENC = a.ENC, DR = a.DR, D0 = a.D0, D1 = a.D1;
+    if (n >= a.N) return;
     const int len = a.lengths[n];
     const float* P = a.P;
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.P), 0, (int)a.packed_bytes, 0x00020000);
@@ -1062,6 +1137,8 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
             if (b >= 0) bo += N; LDSI(q + DS_K) = K; LDSI(q + DS_N) = N; LDSI(q + DS_X) = x;
             LDSI(q + DS_DST) = dst; LDSI(q + DS_ACT) = act; LDSI(q + DS_SPLIT) = split; LDSI(q + DS_POST) = post;
             LDSI(q + DS_P0) = p0; LDSI(q + DS_P1) = p1; LDSI(q + DS_P2) = p2;
+            const DecgGeo e = decg_geo(K, N, split, g, lg);
+            LDSI(q + DS_NCT) = e.nct; LDSI(q + DS_NTILE) = e.ntile; LDSI(q + DS_GEO) = decg_geo_pack(e);
             ++s;
         };
         // rnn_wrappers.py:425 decoder prenet (redundant in every workgroup: 28 tiles)
@@ -1092,24 +1169,25 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     unsigned ep = 0;                                      // exchanges completed so far
     bool ok = true;
     Tile t0, t1, t2;
-    // request the first three tiles of stage `sn` for this wave
-#define DECG_PREFETCH(sn)                                                                                                       \
+    // request the first three tiles of stage `sn` for this wave, in two parts (see the stage loop): part A = the first tile, part B =
+    // the other two
+#define DECG_PREFETCH_(sn, A_, B_)                                                                                              \
     {                                                                                                                            \
         const int qn_ = o_tab + (sn) * DS_STRIDE;                                                                                \
-        const i32x4s n0_ = LDS4I(qn_ >> 2), n1_ = LDS4I((qn_ >> 2) + 1);                                                         \
+        const i32x4s n0_ = LDS4I(qn_ >> 2), n3_ = LDS4I((qn_ >> 2) + 3);                                                         \
         const int wn_ = __builtin_amdgcn_readfirstlane(n0_.x), Kn_ = __builtin_amdgcn_readfirstlane(n0_.z);                      \
-        const int Nn_ = __builtin_amdgcn_readfirstlane(n0_.w), sp_ = __builtin_amdgcn_readfirstlane(n1_.w);                      \
-        const int gn_ = sp_ ? g : 0, lgn_ = sp_ ? lg : 0;                                                                        \
-        const int ncn_ = (Kn_ + 31) >> 5, nbn_ = (Nn_ + 63) >> 6;                                                                \
-        const int ntn_ = nbn_ > gn_ ? ((nbn_ - gn_ + (1 << lgn_) - 1) >> lgn_) * ncn_ : 0;                                       \
+        const DecgGeo en_ = decg_geo_unpack(Kn_, __builtin_amdgcn_readfirstlane(n3_.y), __builtin_amdgcn_readfirstlane(n3_.z),   \
+                                            __builtin_amdgcn_readfirstlane(n3_.w));                                              \
+        const int von_ = decg_voff(en_, g, lane);                                                                                \
         DecgPos q0_{0, 0}, q1_, q2_;                                                                                             \
-        decg_adv(q0_, wave, ncn_);                                                                                               \
-        q1_ = q0_; decg_adv(q1_, 8, ncn_);                                                                                       \
-        q2_ = q1_; decg_adv(q2_, 8, ncn_);                                                                                       \
-        if (wave < ntn_) load_tile_b(t0, rs, lane * 16, decg_off(wn_, q0_, ncn_, gn_, lgn_));                                    \
-        if (wave + 8 < ntn_) load_tile_b(t1, rs, lane * 16, decg_off(wn_, q1_, ncn_, gn_, lgn_));                                \
-        if (wave + 16 < ntn_) load_tile_b(t2, rs, lane * 16, decg_off(wn_, q2_, ncn_, gn_, lgn_));                               \
+        decg_adv(q0_, wave, en_.nct);                                                                                            \
+        q1_ = q0_; decg_adv(q1_, 8, en_.nct);                                                                                    \
+        q2_ = q1_; decg_adv(q2_, 8, en_.nct);                                                                                    \
+        if ((A_) && wave < en_.ntile) load_tile_b(t0, rs, von_, decg_toff(wn_, en_, q0_));                                       \
+        if ((B_) && wave + 8 < en_.ntile) load_tile_b(t1, rs, von_, decg_toff(wn_, en_, q1_));                                   \
+        if ((B_) && wave + 16 < en_.ntile) load_tile_b(t2, rs, von_, decg_toff(wn_, en_, q2_));                                  \
     }
+#define DECG_PREFETCH(sn) DECG_PREFETCH_(sn, true, true)
     DECG_PREFETCH(0)
 // instrumented build (its own instantiation): workgroup 0, thread 0 stamps s_memtime (calibrated against the launch's event time) into prof[it][64]:
 //   4*st + 0 stage start | + 1 this wave's tile dots done | + 2 chunk sums, bias, activation, publish done | + 3 gathered + barrier
@@ -1119,71 +1197,72 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     for (int it = 0; it < a.iters && ok; ++it) {
         for (int st = 0; st < nst && ok; ++st) {
             const int q = o_tab + st * DS_STRIDE;
-            const i32x4s sr0 = LDS4I(q >> 2), sr1 = LDS4I((q >> 2) + 1), sr2 = LDS4I((q >> 2) + 2);
+            const i32x4s sr0 = LDS4I(q >> 2), sr1 = LDS4I((q >> 2) + 1), sr2 = LDS4I((q >> 2) + 2), sr3 = LDS4I((q >> 2) + 3);
             const int w_bytes = __builtin_amdgcn_readfirstlane(sr0.x), bias = __builtin_amdgcn_readfirstlane(sr0.y);
             const int K = __builtin_amdgcn_readfirstlane(sr0.z), N = __builtin_amdgcn_readfirstlane(sr0.w);
             const int xo = __builtin_amdgcn_readfirstlane(sr1.x), dst = __builtin_amdgcn_readfirstlane(sr1.y);
             const int act = __builtin_amdgcn_readfirstlane(sr1.z), split = __builtin_amdgcn_readfirstlane(sr1.w);
             const int post = __builtin_amdgcn_readfirstlane(sr2.x);
             const int sp0 = __builtin_amdgcn_readfirstlane(sr2.y), sp1 = __builtin_amdgcn_readfirstlane(sr2.z), sp2 = __builtin_amdgcn_readfirstlane(sr2.w);
-            const int gg = split ? g : 0, lgg = split ? lg : 0, GG = 1 << lgg;
-            const int nchunk = (K + 31) >> 5, nblk = (N + 63) >> 6;
-            const int nmine = nblk > gg ? (nblk - gg + GG - 1) >> lgg : 0;
-            const int ntile = nmine * nchunk;
+            const DecgGeo e = decg_geo_unpack(K, __builtin_amdgcn_readfirstlane(sr3.y), __builtin_amdgcn_readfirstlane(sr3.z), __builtin_amdgcn_readfirstlane(sr3.w));
+            const int nchunk = e.nchunk, nmine = e.nmine, ntile = e.ntile;
             TWV_STAMP(4 * st + 0)
             // ---- this workgroup's tiles: wave w takes local tiles w, w+8, ... (three in flight), partials to LDS.  The first three
             // were requested while the previous stage was still combining / exchanging (weights do not depend on data).
             {
-                const int vo = lane * 16;
+                const int vo = decg_voff(e, g, lane);
+                const int hi = e.hf ? lane >> 5 : 0;                       // half-block form: the upper half runs the odd chunk
+                const int pl = e.hf ? lane & 31 : lane;                    // column inside the partial row
                 DecgPos p0{0, 0}, p1, p2;
-                decg_adv(p0, wave, nchunk);
-                p1 = p0; decg_adv(p1, 8, nchunk);
-                p2 = p1; decg_adv(p2, 8, nchunk);
+                decg_adv(p0, wave, e.nct);
+                p1 = p0; decg_adv(p1, 8, e.nct);
+                p2 = p1; decg_adv(p2, 8, e.nct);
+#define DECG_DOT(T_, P_, I_)                                                                                                    \
+                    {                                                                                                            \
+                        const int c_ = (P_.ch << e.hf) + hi;                      /* this lane's chunk */                        \
+                        const int xq = xo + c_ * 32 + (lane & 15);                                                               \
+                        const float r = dot32_dpp(T_.w, lds[xq], lds[xq + 16]);                                                  \
+                        __builtin_amdgcn_sched_barrier(0);                                                                       \
+                        if (c_ < nchunk) lds[o_part + (P_.m * nchunk + c_) * 64 + pl] = r;                                       \
+                        decg_adv(P_, 24, e.nct);                                                                                 \
+                        if ((I_) + 24 < ntile) load_tile_b(T_, rs, vo, decg_toff(w_bytes, e, P_));                               \
+                    }
                 for (int i = wave; i < ntile; i += 24) {
-                    {
-                        const float r = dot_ldso(t0, xo + p0.ch * 32);
-                        __builtin_amdgcn_sched_barrier(0);
-                        lds[o_part + i * 64 + lane] = r;
-                        decg_adv(p0, 24, nchunk);
-                        if (i + 24 < ntile) load_tile_b(t0, rs, vo, decg_off(w_bytes, p0, nchunk, gg, lgg));
-                    }
-                    if (i + 8 < ntile) {
-                        const float r = dot_ldso(t1, xo + p1.ch * 32);
-                        __builtin_amdgcn_sched_barrier(0);
-                        lds[o_part + (i + 8) * 64 + lane] = r;
-                        decg_adv(p1, 24, nchunk);
-                        if (i + 32 < ntile) load_tile_b(t1, rs, vo, decg_off(w_bytes, p1, nchunk, gg, lgg));
-                    }
-                    if (i + 16 < ntile) {
-                        const float r = dot_ldso(t2, xo + p2.ch * 32);
-                        __builtin_amdgcn_sched_barrier(0);
-                        lds[o_part + (i + 16) * 64 + lane] = r;
-                        decg_adv(p2, 24, nchunk);
-                        if (i + 40 < ntile) load_tile_b(t2, rs, vo, decg_off(w_bytes, p2, nchunk, gg, lgg));
-                    }
+                    DECG_DOT(t0, p0, i)
+                    if (i + 8 < ntile) DECG_DOT(t1, p1, i + 8)
+                    if (i + 16 < ntile) DECG_DOT(t2, p2, i + 16)
                 }
+#undef DECG_DOT
                 TWV_STAMP(4 * st + 1)
             }
-            __syncthreads();
+            // A CU's vector-memory pipeline is one FIFO of ~64 B/clk: a stage's tiles (up to 160 KB per workgroup) take ~1 us to pass
+            // through it, and everything issued behind them -- the publish stores of the epilogue, the polls of the gather -- waits its
+            // turn.  So the wave's FIRST tile of the next stage is requested here, where the chunk sums and activations (LDS and VALU
+            // only) cover it, and the other two after the publish.  All three here delayed every publish (36.2 -> 40.4 us per step,
+            // round 4); all three after the publish left the gather waiting for 1.1 us of tile traffic behind a 0.4 us hop.
+            DECG_PREFETCH_(st + 1 < nst ? st + 1 : 0, true, false)
+            lds_barrier();                                // partials visible (LDS only: the tile request stays in flight)
             // ---- epilogue: chunk sums in order (AC-1) + bias + activation; split stages publish and all-gather
             {
                 const bool xch = split && G > 1;
                 unsigned long long* Xb = X;
                 if (xch) { ++ep; Xb = X + (ep & 1) * kExN; }
-                for (int qq = tid; qq < nmine * 64; qq += 512) {
-                    const int m = qq >> 6, j = (((m << lgg) + gg) << 6) + (qq & 63);
+                const int ncolw = e.hf ? 32 : 64;                          // columns per owned block
+                for (int qq = tid; qq < nmine * ncolw; qq += 512) {
+                    const int m = e.hf ? 0 : qq >> 6;
+                    const int j = e.hf ? (e.gT << 6) + ((g & 1) << 5) + qq : (((m << e.lgT) + e.gT) << 6) + (qq & 63);
                     if (j < N) {
                         float v = decg_combine(o_part, nchunk, m, qq & 63);
                         if (bias >= 0) v = v + lds[bias + j];
                         if (act == DA_SIGMOID) v = sigmoid_e(v);
                         else if (act == DA_TANH) v = tanh_e(v);
                         else if (act == DA_RELU) v = v > 0.0f ? v : 0.0f;
-                        if (xch) decg_store(Xb + j, ep, v); else lds[dst + j] = v;
+                        if (xch) decg_store(Xb + j, ep, v, loc); else lds[dst + j] = v;
                     }
                 }
                 TWV_STAMP(4 * st + 2)
-                // the next stage's first tiles are requested only now: this workgroup's values are already on their way to the others
-                DECG_PREFETCH(st + 1 < nst ? st + 1 : 0)
+                // the rest of the next stage's first tiles: this workgroup's values are already on their way to the others
+                DECG_PREFETCH_(st + 1 < nst ? st + 1 : 0, false, true)
                 if (xch) {
                     // a split stage's values arrive one per thread: the cell update that follows the matvec is elementwise in the
                     // output index, so the receiving thread does it on arrival (no second pass over LDS, no second barrier)
@@ -1300,7 +1379,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                         for (int ch = 0; ch < nAch; ++ch) { const float c = lds[o_scp + tl * 8 + ch]; sc = ch == 0 ? c : sc + c; }
                         sc = sc + P[a.w.asb];
                         const float pv = t < len ? sigmoid_e(sc) : 0.0f;       // _maybe_mask_score(-inf) -> p = 0
-                        if (G == 1) lds[o_p + t] = pv; else decg_store(Xb + t, ep, pv);
+                        if (G == 1) lds[o_p + t] = pv; else decg_store(Xb + t, ep, pv, loc);
                     }
                     if (G > 1) decg_gather(Xb, T, ep, o_p, tid, o_abort);
                     __syncthreads();
@@ -1373,7 +1452,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                         float v = 0.0f;
                         for (int ch = 0; ch < nch; ++ch) { const float c = lds[o_part + ch * ncol + tid]; v = ch == 0 ? c : v + c; }
                         if (G == 1) { lds[o_ctx + tid] = v; lds[o_cat + AS + tid] = v; lds[o_cat2 + D1 + tid] = v; }
-                        else decg_store(Xb + c0 + tid, ep, v);
+                        else decg_store(Xb + c0 + tid, ep, v, loc);
                     }
                     if (G > 1)
                         decg_gather_apply(Xb, ENC, ep, tid, o_abort, [&](const int j, const float v) {
@@ -1389,6 +1468,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     if (!ok && tid == 0) a.status[0] = 21;                    // exchange watchdog
 #undef TWV_STAMP
 #undef DECG_PREFETCH
+#undef DECG_PREFETCH_
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -1818,6 +1898,7 @@ struct twv_tacotron {
     twv_tacotron_dims d;
     unsigned long long* prof = nullptr;
     int dec_groups = 0;             // 0 auto (8, halved until N*G fits the CUs), -1 single-workgroup kernel
+    int dec_local = 1;              // split kernel: 1 = an utterance's workgroups on one XCD (exchanges through its L2), 0 = spread over the XCDs
     long long blob_floats, packed_floats;
     long long xt_off = 0;           // row tiles of the XCD-local decoder kernel [32 slices][8 waves][kXSlots][2048]
     TMat emb, semb;                 // raw tables (K rows x N)
@@ -1943,6 +2024,7 @@ extern "C" int twv_tacotron_set_option(twv_tacotron* h, const char* name, int va
         g_gemm_stat.flop = 0.0; g_gemm_stat.launches = 0; g_gemm_stat.used = 0;
         return TWV_OK;
     }
+    if (!strcmp(name, "decoder_local")) { h->dec_local = value ? 1 : 0; return TWV_OK; }
     if (!strcmp(name, "decoder_groups")) {
         if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 32)
             return twv_fail(TWV_E_INVALID, "decoder_groups must be -1, 0, 1, 2, 4, 8 or 32 (32 = the XCD-local kernel)");
@@ -2064,7 +2146,7 @@ static long long taco_ws_floats(const twv_tacotron* h, int N, int T)
     f += rowsE * 256 * 2;               // encoder output (memory), keys
     f += (long long)N * 4096;           // speaker-dependent vectors
     f += rowsP * 256;                   // post CBHG output
-    f += (long long)N * 4096;           // decoder exchange granules
+    f += (long long)N * 4096 + 16;      // decoder exchange granules + the local mode's role tickets
     f += 8LL * 2 * kXU * 512 * 2 + 64;  // XCD-local decoder: exchange granules per XCD + role tickets
     return f + 1024;
 }
@@ -2240,7 +2322,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
     float* keys = w; w += (long long)rows * 256;
     float* spk = w; w += (long long)N * 4096;
     float* postout = w; w += (long long)rowsP * 256;
-    float* exch = w; w += (long long)N * 2 * kExN * 2;      // decoder exchange granules (8 bytes each)
+    float* exch = w; w += (long long)N * 2 * kExN * 2 + 16; // decoder exchange granules (8 bytes each) + 8 role tickets
     float* xexch = w; w += 8LL * 2 * kXU * 512 * 2 + 64;    // XCD-local decoder: granules [8][2][kXU*512] + tickets
     // ---- tacotron.py:51-60 embedding, :67-82 speaker embedding + deep_dense (softsign)
     hipLaunchKernelGGL(tc_embed_kernel, dim3(tgrid((long long)rows * E)), dim3(256), 0, st, P + h->emb.off, tokens, rows, E, ra);
@@ -2343,7 +2425,11 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
         } else {
             DecGArgs ga;
             ga.d = da; ga.G = G; ga.exch = reinterpret_cast<unsigned long long*>(exch);
-            HIPCHK(hipMemsetAsync(exch, 0, (size_t)N * 2 * kExN * 8, st));
+            const int wgs_local = 8 * G * ((N + 7) / 8);
+            ga.local = (h->dec_local && G > 1 && wgs_local <= cus) ? 1 : 0;
+            const int wgs = ga.local ? wgs_local : N * G;
+            HIPCHK(hipMemsetAsync(exch, 0, (size_t)N * 2 * kExN * 8 + 64, st));
+            ga.tickets = reinterpret_cast<int*>(exch + (long long)N * 2 * kExN * 2);
             long long fl = 1024 * 2 + (da.D1 + ENC + AS + 63) / 64 * 64 + 512 * 2 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + (M * R + 63) / 64 * 64 + Tp * 4 + A +
                            Tp * 8 + 4 + 3 + 16 * 16 + 2 * A + da.nbias + pmax;
             const long long kvf = (long long)((T + G - 1) / G) * A + (long long)T * (ENC / G);
@@ -2354,10 +2440,10 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             // plain launch (N * G <= CU count is enforced above); a cooperative launch was measured and dropped, see twv_wavenet.hip
             if (da.prof) {     // the instrumented build (phase stamps) is its own instantiation
                 HIPCHK(hipFuncSetAttribute((const void*)tc_decoder_g_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-                hipLaunchKernelGGL(tc_decoder_g_kernel<true>, dim3(N * G), dim3(512), shm, st, ga);
+                hipLaunchKernelGGL(tc_decoder_g_kernel<true>, dim3(wgs), dim3(512), shm, st, ga);
             } else {
                 HIPCHK(hipFuncSetAttribute((const void*)tc_decoder_g_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-                hipLaunchKernelGGL(tc_decoder_g_kernel<false>, dim3(N * G), dim3(512), shm, st, ga);
+                hipLaunchKernelGGL(tc_decoder_g_kernel<false>, dim3(wgs), dim3(512), shm, st, ga);
             }
         }
     }
