@@ -24,12 +24,14 @@ def random_tensors(specs, seed=0):
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--steps", type=int, default=3); ap.add_argument("--no-post", action="store_true")
 ap.add_argument("--no-linear", action="store_true"); ap.add_argument("--decoder-groups", type=int, default=0)
 ap.add_argument("--decoder-local", type=int, default=-1, help="1: an utterance's decoder workgroups on one XCD, 0: spread over the XCDs")
+ap.add_argument("--split-all", type=int, default=-1)
 ap.add_argument("--gemm-group", type=int, default=-1, help="0: one launch per GEMM and separate highway kernels (A/B against the grouped launches)"); args = ap.parse_args()
 hp = twvk_amd.default_hparams()
 m = Tacotron(hp, num_speakers=2)
 m.load_weights(random_tensors(m.specs))
 if args.decoder_groups: m.set_option("decoder_groups", args.decoder_groups)
 if args.decoder_local >= 0: m.set_option("decoder_local", args.decoder_local)
+if args.split_all >= 0: m.set_option("decoder_split_all", args.split_all)
 if args.gemm_group >= 0: m.set_option("gemm_group", args.gemm_group)
 rng = np.random.RandomState(1)
 N, T = args.batch, 101

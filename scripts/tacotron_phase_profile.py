@@ -48,10 +48,14 @@ dec_inst_us = (inst_ms - front_ms) * 1e3 / (ITERS - 1)
 tick = steps[20:180].mean() / dec_inst_us                    # ticks per microsecond
 us = lambda a: float(np.mean(a)) / tick
 P = p[20:180]
-names = ["prenet dense_1 (redundant)", "prenet dense_2 (redundant)", "attention GRU gates", "attention GRU candidate", "query layer (redundant)",
+SPLIT_ALL = LOCAL != 0            # the library's default: prenet and query layer are split when the exchanges are L2-local
+tag = "" if SPLIT_ALL else " (redundant)"
+names = ["prenet dense_1" + tag, "prenet dense_2" + tag, "attention GRU gates", "attention GRU candidate", "query layer" + tag,
          "concat projection", "res GRU 1 gates", "res GRU 1 candidate", "res GRU 2 gates", "res GRU 2 candidate", "output projection"]
-split = [0, 0, 1, 1, 0, 1, 1, 1, 1, 1, 1]
-HOP = 0.39        # one-way granule exchange between workgroups on different XCDs, measured in isolation (scripts/ubench/tile_latency.hip: ~930 cycles)
+split = [int(SPLIT_ALL), int(SPLIT_ALL), 1, 1, int(SPLIT_ALL), 1, 1, 1, 1, 1, 1]
+# one-way granule exchange measured in isolation: 0.27 us inside one XCD's L2 (plain store, sc1 load: the hand-offs of twv_wavenet_xcd.hip),
+# 0.39 us between workgroups on different XCDs (scripts/ubench/tile_latency.hip: ~930 cycles)
+HOP = 0.39 if LOCAL == 0 else 0.27
 print("decoder step: %.2f us (production build, HIP events, (200-step pass - 1-step pass) / 199); instrumented build %.2f us; %.1f ticks/us" % (dec_plain_us, dec_inst_us, tick))
 print("%-30s %7s %7s %9s %9s %7s" % ("stage", "dots", "combine", "exchange", "post", "total"))
 tot_dots = tot_comb = tot_exch = tot_post = 0.0
@@ -77,6 +81,6 @@ step_sum = tot_dots + tot_comb + tot_exch + tot_post + att
 floor = tot_dots + tot_comb + tot_post + att + n_exch * HOP
 print("sum of the pieces %.2f us (stamped step %.2f): tile dots %.2f + chunk sums/activation/publish %.2f + barriers/cell updates %.2f + attention compute %.2f + %d exchanges %.2f"
       % (step_sum, us(steps[20:180]), tot_dots, tot_comb, tot_post, att, n_exch, tot_exch))
-print("exchanges: %.2f us each on average against a %.2f us one-way hop measured in isolation -- the rest is skew between the 8 workgroups of the utterance" % (tot_exch / n_exch, HOP))
+print("exchanges: %.2f us each on average against a %.2f us one-way hop measured in isolation -- the rest is the next stage's weight tiles queued in front of the polls in the CU's memory pipeline, and skew between the 8 workgroups" % (tot_exch / n_exch, HOP))
 print("latency floor of this decomposition = everything but the exchanges + %d x %.2f = %.2f us  (instrumented step %.2f: frac_of_floor %.3f)" % (n_exch, HOP, floor, dec_inst_us, floor / dec_inst_us))
 print("JSON {\"us_per_step\": %.3f, \"us_per_step_instrumented\": %.3f, \"latency_floor_us\": %.3f, \"exchanges\": %d, \"exchange_us_mean\": %.3f, \"hop_us\": %.2f}" % (dec_plain_us, dec_inst_us, floor, n_exch, tot_exch / n_exch, HOP))

@@ -874,6 +874,8 @@ struct DecGArgs {
     int kv_lds;                     // 1: key rows / memory columns of the workgroup fit in LDS
     int local;                      // 1: the G workgroups of an utterance share one XCD and exchange through its L2
     int* tickets;                   // [8] role tickets of the local mode, zeroed before the launch
+    int split_all;                  // 1: the prenet and the query layer are split over the workgroups too (three more exchanges, 300 KB
+                                    //    less weight traffic per workgroup and step); 0: every workgroup computes them whole
 };
 
 struct DecgPos { int m, ch; };
@@ -1142,13 +1144,13 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
             ++s;
         };
         // rnn_wrappers.py:425 decoder prenet (redundant in every workgroup: 28 tiles)
-        put(a.w.dp1, a.w.dp1b, M, D0, o_frame, o_vec, DA_RELU, 0, DP_NONE, 0, 0, 0);
-        put(a.w.dp2, a.w.dp2b, D0, D1, o_vec, o_cat2, DA_RELU, 0, DP_NONE, 0, 0, 0);
+        put(a.w.dp1, a.w.dp1b, M, D0, o_frame, o_vec, DA_RELU, ga.split_all, DP_NONE, 0, 0, 0);
+        put(a.w.dp2, a.w.dp2b, D0, D1, o_vec, o_cat2, DA_RELU, ga.split_all, DP_NONE, 0, 0, 0);
         // rnn_wrappers.py:310-312 attention GRU on [prenet_out | attention | ha]
         put(a.w.aWg, a.w.abg, D1 + ENC + AS, 2 * AS, o_cat2, o_vec, DA_SIGMOID, 1, DP_GATES, D1 + ENC, AS, 0);
         put(a.w.aWc, a.w.abc, D1 + ENC + AS, AS, o_cat2, o_cand, DA_TANH, 1, DP_CAND, AS, o_ha, -1);
         // attention query layer (redundant: 32 tiles), then score / recurrence / context
-        put(a.w.Wq, -1, AS, A, o_ha, o_pq, DA_NONE, 0, DP_QUERY, 0, 0, 0);
+        put(a.w.Wq, -1, AS, A, o_ha, o_pq, DA_NONE, ga.split_all, DP_QUERY, 0, 0, 0);
         // rnn_wrappers.py:463 concat(output, attention) -> OutputProjectionWrapper(dec_rnn)
         put(a.w.cW, a.w.cb, AS + ENC, DR, o_cat, o_y, DA_NONE, 1, DP_PROJ, 0, 0, 0);
         // tacotron.py:167 ResidualWrapper(GRUCell(dec_rnn)): y <- y + GRU(y, h_l)
@@ -1898,6 +1900,7 @@ struct twv_tacotron {
     twv_tacotron_dims d;
     unsigned long long* prof = nullptr;
     int dec_groups = 0;             // 0 auto (8, halved until N*G fits the CUs), -1 single-workgroup kernel
+    int dec_split_all = -1;         // prenet + query layer split over the workgroups: -1 = when the exchanges are L2-local, 0 / 1
     int dec_local = 1;              // split kernel: 1 = an utterance's workgroups on one XCD (exchanges through its L2), 0 = spread over the XCDs
     long long blob_floats, packed_floats;
     long long xt_off = 0;           // row tiles of the XCD-local decoder kernel [32 slices][8 waves][kXSlots][2048]
@@ -2024,6 +2027,7 @@ extern "C" int twv_tacotron_set_option(twv_tacotron* h, const char* name, int va
         g_gemm_stat.flop = 0.0; g_gemm_stat.launches = 0; g_gemm_stat.used = 0;
         return TWV_OK;
     }
+    if (!strcmp(name, "decoder_split_all")) { h->dec_split_all = value < 0 ? -1 : (value ? 1 : 0); return TWV_OK; }
     if (!strcmp(name, "decoder_local")) { h->dec_local = value ? 1 : 0; return TWV_OK; }
     if (!strcmp(name, "decoder_groups")) {
         if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 32)
@@ -2428,6 +2432,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             const int wgs_local = 8 * G * ((N + 7) / 8);
             ga.local = (h->dec_local && G > 1 && wgs_local <= cus) ? 1 : 0;
             const int wgs = ga.local ? wgs_local : N * G;
+            ga.split_all = h->dec_split_all < 0 ? ga.local : h->dec_split_all;
             HIPCHK(hipMemsetAsync(exch, 0, (size_t)N * 2 * kExN * 8 + 64, st));
             ga.tickets = reinterpret_cast<int*>(exch + (long long)N * 2 * kExN * 2);
             long long fl = 1024 * 2 + (da.D1 + ENC + AS + 63) / 64 * 64 + 512 * 2 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + (M * R + 63) / 64 * 64 + Tp * 4 + A +
