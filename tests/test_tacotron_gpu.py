@@ -137,6 +137,33 @@ def test_decoder_launch_geometry_does_not_change_results(torch_cuda, oracle, gro
     assert first_mismatch(mel2.cpu().numpy(), mel_o) is None
 
 
+_PLACEMENT_ORACLE = {}
+
+
+@pytest.mark.parametrize("local,split_all", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("batch", [3, 32])
+def test_decoder_placement_does_not_change_results(torch_cuda, oracle, local, split_all, batch):
+    """the split decoder with an utterance's workgroups on one XCD (exchanges through its L2; the default) or spread over the XCDs,
+    with the prenet and the query layer split over the workgroups or computed whole in each: the same bits as the oracle.
+    batch 3: three XCDs host one utterance each; batch 32 with ragged lengths: all 256 workgroups, four utterances per XCD"""
+    hp = _hp(max_iters=9) if batch == 32 else _hp(max_iters=7, enc_bank_size=3, post_bank_size=2, num_freq=65)
+    T = 61
+    rng = np.random.RandomState(5)
+    lens = [T] + [int(x) for x in rng.randint(3, T + 1, batch - 1)]
+    d, blob, tok, ln, spk, m = _case(oracle, hp, batch, T, lens, seed=17)
+    if batch not in _PLACEMENT_ORACLE:                                  # one CPU evaluation per batch, shared by the four placements
+        _PLACEMENT_ORACLE[batch] = oracle.taco_infer(d, blob, tok, ln, spk)
+    mel_o, lin_o, al_o = _PLACEMENT_ORACLE[batch]
+    m.set_option("decoder_groups", 8)
+    m.set_option("decoder_local", local)
+    m.set_option("decoder_split_all", split_all)
+    for _ in range(2):                                                  # the second pass reuses the exchange buffers and tickets
+        mel, lin, al = m.infer(tok, ln, spk)
+        assert first_mismatch(al.cpu().numpy(), al_o) is None, ("alignments", first_mismatch(al.cpu().numpy(), al_o))
+        assert first_mismatch(mel.cpu().numpy(), mel_o) is None, ("mel", first_mismatch(mel.cpu().numpy(), mel_o))
+        assert first_mismatch(lin.cpu().numpy(), lin_o) is None
+
+
 def test_tacotron_minimal_and_long_inputs(torch_cuda, oracle):
     """edge cases: a single EOS token; one utterance; an input longer than 256 tokens (more than one key row per thread)"""
     hp = _hp(max_iters=3, enc_bank_size=2, post_bank_size=2, num_freq=33)
