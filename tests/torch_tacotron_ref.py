@@ -149,11 +149,11 @@ def _monotonic_attention_parallel(p_choose, previous):
     return p_choose * cp * torch.cumsum(previous / torch.clamp(cp, 1e-10, 1.0), dim=1)
 
 
+@torch.no_grad()
 def infer(w, dims, tokens, lengths, speaker_ids):
     """tacotron.py:36-235 with rnn_decoder_test_mode=True, linear_targets=None (synthesizer.py:56): returns
     (mel (N, max_iters*r, num_mels), linear (N, max_iters*r, num_freq), alignments (N, T_in, max_iters)) as float64 numpy.
     `dims`: any object with n_speakers, enc_bank, post_bank, enc_hw_depth, post_hw_depth, dec_layers, num_mels, r, max_iters."""
-    torch.set_grad_enabled(False)
     tokens = np.asarray(tokens); lengths = np.asarray(lengths)
     w = {k: _t(v) for k, v in w.items()}                             # float64 once, not per use
     N, T_in = tokens.shape
