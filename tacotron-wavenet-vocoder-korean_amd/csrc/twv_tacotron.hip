@@ -464,11 +464,13 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 //   * the x-parts of a step (a fresh row of Gx / Cx every step, out of HBM or the memory-side cache) were loaded when needed.  Now
 //     they are fetched kDepth steps ahead into a register ring, and the barriers wait for LDS only (a __syncthreads() is also a fence
 //     that drains every outstanding global access).
-// Work split (VALU issue is what is left, so no activation is evaluated on idle lanes):
-//   waves 0-3 "gate waves":      outputs 64 w + lane of the 2U = 256 gate outputs (waves 0, 1: r; waves 2, 3: u), all four chunks:
-//                                four dots, one sigmoid on 64 useful lanes
-//   waves 4-7 "candidate waves": outputs 32 (w - 4) + (lane mod 32); lanes 0-31 run chunks 0, 1, lanes 32-63 chunks 2, 3 of the same
-//                                outputs; v_permlane32_swap brings chunks 2, 3 to the lower half; tanh and the state update there
+// Work split, all in half-wave form (lanes 0-31 run chunks 0, 1 and lanes 32-63 chunks 2, 3 of the same 32 outputs; v_permlane32_swap
+// brings chunks 2, 3 to the lower half):
+//   waves 0-3 "r waves":             r gates 32 w + (lane mod 32): two dots, sigmoid, r * h to LDS -- the critical first half of the
+//                                    step, at raised priority (s_setprio) so that their SIMD-mates do not slow their dots
+//   waves 4-7 "u + candidate waves": before the first barrier the u gate's two dots for outputs 32 (w - 4) + (lane mod 32) (its sigmoid
+//                                    is evaluated next to the candidate's tanh, where two independent chains share the latency); after
+//                                    it the candidate's two dots, tanh, and the blend with the u that never left the lane's registers
 // The sums keep their order -- ((((x-part + c0) + c1) + c2) + c3) + bias -- so the bits are those of rounds 1-3.
 __device__ __forceinline__ void gru_load_column(float (&w)[32], const float* tile, int out_lane)
 {
@@ -484,24 +486,26 @@ __global__ void __launch_bounds__(512) tc_gru_seq_kernel(GruSeqArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const int len = a.lengths ? a.lengths[n] : a.T;
-    // LDS: hs[128] | rh[128] | ug[128]
-    const int o_h = 0, o_rh = 128, o_ug = 256;
+    // LDS: hs[128] | rh[128]
+    const int o_h = 0, o_rh = 128;
     if (tid < U) lds[o_h + tid] = a.init ? a.init[(long long)n * 2 * U + dir * U + tid] : 0.0f;
     __syncthreads();
     if (len <= 0) return;
     auto row_of = [&](int s) { const int sc = s < len ? s : len - 1; return (long long)n * a.T + (dir == 0 ? sc : len - 1 - sc); };
+    const int hch = (lane >> 5) * 2;                          // half-wave form: lanes 0-31 run chunks 0, 1, lanes 32-63 chunks 2, 3
     if (wave < 4) {
-        const int go = 64 * wave + lane;
-        float w0[32], w1[32], w2[32], w3[32];
-        const float* tiles = a.Wgh[dir] + (long long)wave * 4 * kTile;        // standard tiles [nblk][chunk][kq][64 output lanes][4]
-        gru_load_column(w0, tiles, lane); gru_load_column(w1, tiles + kTile, lane);
-        gru_load_column(w2, tiles + 2 * kTile, lane); gru_load_column(w3, tiles + 3 * kTile, lane);
-        const float bgv = a.bg[dir][go];
-        const float* Gx = a.Gx + dir * a.gx_dstride + go;
+        // ---- r waves: the step's critical first half (r * h feeds the candidate), so they outrank their SIMD-mates
+        __builtin_amdgcn_s_setprio(3);
+        const int ro = 32 * wave + (lane & 31);               // gate output 0 .. 127 = r
+        float w0[32], w1[32];
+        const float* tiles = a.Wgh[dir] + ((long long)(ro >> 6) * 4 + hch) * kTile;      // standard tiles [nblk][chunk][kq][64 output lanes][4]
+        gru_load_column(w0, tiles, ro & 63); gru_load_column(w1, tiles + kTile, ro & 63);
+        const float bgv = a.bg[dir][ro];
+        const float* Gx = a.Gx + dir * a.gx_dstride + ro;
         float gxr[kDepth];
 #pragma unroll
         for (int j = 0; j < kDepth; ++j) gxr[j] = Gx[row_of(j) * 2 * U];
-        const int xo = o_h + (lane & 15);
+        const int xo = o_h + hch * 32 + (lane & 15);
         for (int s0 = 0; s0 < len; s0 += kDepth) {
 #pragma unroll
             for (int j = 0; j < kDepth; ++j) {
@@ -509,39 +513,57 @@ __global__ void __launch_bounds__(512) tc_gru_seq_kernel(GruSeqArgs a)
                 if (s >= len) break;
                 const float gx = gxr[j];
                 gxr[j] = Gx[row_of(s + kDepth) * 2 * U];
-                float d0, d1, d2, d3;
+                float d0, d1;
                 dot32_dpp_x2(w0, lds[xo], lds[xo + 16], w1, lds[xo + 32], lds[xo + 48], d0, d1);
-                dot32_dpp_x2(w2, lds[xo + 64], lds[xo + 80], w3, lds[xo + 96], lds[xo + 112], d2, d3);
+                const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d0), __float_as_uint(d0), false, false);   // [1]: lanes 32-63's values on both halves
+                const auto s3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d1), __float_as_uint(d1), false, false);
                 float g = gx;
-                g = g + d0; g = g + d1; g = g + d2; g = g + d3;
+                g = g + d0; g = g + d1;                                            // chunks 0, 1 (lower half)
+                g = g + __uint_as_float(s2[1]); g = g + __uint_as_float(s3[1]);    // chunks 2, 3
                 g = sigmoid_e(g + bgv);
-                if (go < U) lds[o_rh + go] = g * lds[o_h + go];            // r * h
-                else lds[o_ug + go - U] = g;                               // u
-                lds_barrier();                                             // r * h, u visible
+                if (lane < 32) lds[o_rh + ro] = g * lds[o_h + ro];                 // r * h
+                lds_barrier();                                             // r * h visible
                 lds_barrier();                                             // (the candidate waves' half of the step)
             }
         }
     } else {
+        // ---- u + candidate waves: the u gate's dots run in the shadow of the r waves (its sigmoid waits until it is needed and then
+        // interleaves with the candidate's tanh); u never leaves the registers of the lane that blends with it
         const int co = 32 * (wave - 4) + (lane & 31);
-        const int cch = (lane >> 5) * 2;
-        float w0[32], w1[32];
-        const float* tiles = a.Wch[dir] + ((long long)(co >> 6) * 4 + cch) * kTile;
+        float w0[32], w1[32], wu0[32], wu1[32];
+        const float* tiles = a.Wch[dir] + ((long long)(co >> 6) * 4 + hch) * kTile;
         gru_load_column(w0, tiles, co & 63); gru_load_column(w1, tiles + kTile, co & 63);
-        const float bcv = a.bc[dir][co];
+        const float* utiles = a.Wgh[dir] + ((long long)((U + co) >> 6) * 4 + hch) * kTile;
+        gru_load_column(wu0, utiles, (U + co) & 63); gru_load_column(wu1, utiles + kTile, (U + co) & 63);
+        const float bcv = a.bc[dir][co], buv = a.bg[dir][U + co];
         const float* Cx = a.Cx + dir * a.cx_dstride + co;
-        float cxr[kDepth];
+        const float* Gx = a.Gx + dir * a.gx_dstride + U + co;
+        float cxr[kDepth], uxr[kDepth];
 #pragma unroll
-        for (int j = 0; j < kDepth; ++j) cxr[j] = Cx[row_of(j) * U];
-        const int xo = o_rh + cch * 32 + (lane & 15);
+        for (int j = 0; j < kDepth; ++j) { cxr[j] = Cx[row_of(j) * U]; uxr[j] = Gx[row_of(j) * 2 * U]; }
+        const int xo = o_rh + hch * 32 + (lane & 15), xh = o_h + hch * 32 + (lane & 15);
         for (int s0 = 0; s0 < len; s0 += kDepth) {
 #pragma unroll
             for (int j = 0; j < kDepth; ++j) {
                 const int s = s0 + j;
                 if (s >= len) break;
                 const long long row = row_of(s);
-                const float cx = cxr[j];
+                const float cx = cxr[j], ux = uxr[j];
                 cxr[j] = Cx[row_of(s + kDepth) * U];
-                lds_barrier();                                             // r * h, u visible
+                uxr[j] = Gx[row_of(s + kDepth) * 2 * U];
+                float gu;
+                {
+                    float d0, d1;
+                    dot32_dpp_x2(wu0, lds[xh], lds[xh + 16], wu1, lds[xh + 32], lds[xh + 48], d0, d1);
+                    const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d0), __float_as_uint(d0), false, false);
+                    const auto s3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d1), __float_as_uint(d1), false, false);
+                    gu = ux;
+                    gu = gu + d0; gu = gu + d1;
+                    gu = gu + __uint_as_float(s2[1]); gu = gu + __uint_as_float(s3[1]);
+                    gu = gu + buv;
+                }
+                const float h = lds[o_h + co];
+                lds_barrier();                                             // r * h visible
                 float e0, e1;
                 dot32_dpp_x2(w0, lds[xo], lds[xo + 16], w1, lds[xo + 32], lds[xo + 48], e0, e1);
                 const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(e0), __float_as_uint(e0), false, false);   // [1]: lanes 32-63's values on both halves
@@ -550,8 +572,8 @@ __global__ void __launch_bounds__(512) tc_gru_seq_kernel(GruSeqArgs a)
                 c = c + e0; c = c + e1;                                            // chunks 0, 1 (lower half)
                 c = c + __uint_as_float(s2[1]); c = c + __uint_as_float(s3[1]);    // chunks 2, 3
                 c = tanh_e(c + bcv);
+                const float u = sigmoid_e(gu);
                 if (lane < 32) {
-                    const float u = lds[o_ug + co], h = lds[o_h + co];
                     const float t1 = u * h, t2 = 1.0f - u, t3 = t2 * c;
                     const float hn = t1 + t3;
                     a.out[row * 2 * U + dir * U + co] = hn;
