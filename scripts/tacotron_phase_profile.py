@@ -84,3 +84,6 @@ print("sum of the pieces %.2f us (stamped step %.2f): tile dots %.2f + chunk sum
 print("exchanges: %.2f us each on average against a %.2f us one-way hop measured in isolation -- the rest is the next stage's weight tiles queued in front of the polls in the CU's memory pipeline, and skew between the 8 workgroups" % (tot_exch / n_exch, HOP))
 print("latency floor of this decomposition = everything but the exchanges + %d x %.2f = %.2f us  (instrumented step %.2f: frac_of_floor %.3f)" % (n_exch, HOP, floor, dec_inst_us, floor / dec_inst_us))
 print("JSON {\"us_per_step\": %.3f, \"us_per_step_instrumented\": %.3f, \"latency_floor_us\": %.3f, \"exchanges\": %d, \"exchange_us_mean\": %.3f, \"hop_us\": %.2f}" % (dec_plain_us, dec_inst_us, floor, n_exch, tot_exch / n_exch, HOP))
+if P[:, 54].any():
+    print("score phase detail (thread 0): query stage end -> indices %.2f | eight tanh terms + fma chain %.2f | lane exchanges + store %.2f | barrier %.2f" % (
+        us(P[:, 54] - P[:, 4 * 4 + 3]), us(P[:, 55] - P[:, 54]), us(P[:, 56] - P[:, 55]), us(P[:, 48] - P[:, 56])))

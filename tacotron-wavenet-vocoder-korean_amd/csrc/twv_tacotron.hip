@@ -1134,7 +1134,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     const int o_bias = o; o += a.nbias;                   // every stage's bias vector, in stage order
     const bool kv = ga.kv_lds != 0;                       // this workgroup's key rows / memory columns held in LDS
     const int nt_all = T > g ? (T - g + G - 1) >> lg : 0;
-    const int o_keys = o; o += kv ? ((T + G - 1) >> lg) * A : 0;
+    const int o_keys = o; o += kv ? ((T + G - 1) >> lg) * (A + A / 32) : 0;
     const int o_memo = o; o += kv ? T * (ENC >> lg) : 0;
     const int o_part = o;
 
@@ -1148,7 +1148,8 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     if (tid < 4) LDSI(o_abort + tid) = 0;
     for (int i = tid; i < A; i += 512) { lds[o_nv + i] = P[a.w.nv + i]; lds[o_ab + i] = P[a.w.ab + i]; }
     if (kv) {
-        for (int i = tid; i < nt_all * A; i += 512) { const int tl = i / A, j = i - tl * A; lds[o_keys + i] = keys[(long long)((tl << lg) + g) * A + j]; }
+        // (rows skewed by one word per 32: the score's threads -- one per (t, chunk, chain) -- read addresses 32 and 128 apart)
+        for (int i = tid; i < nt_all * A; i += 512) { const int tl = i / A, j = i - tl * A; lds[o_keys + i + (i >> 5)] = keys[(long long)((tl << lg) + g) * A + j]; }
         const int ncol = ENC >> lg;
         for (int i = tid; i < T * ncol; i += 512) { const int t = i / ncol, cl = i - t * ncol; lds[o_memo + i] = memo[(long long)t * ENC + g * ncol + cl]; }
     }
@@ -1379,7 +1380,8 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                     const int tl = live ? tc / nAch : 0, ch = live ? tc - tl * nAch : 0, t = (tl << lg) + g;
                     float sk = 0.f;
                     const float* kr = keys + (long long)t * A + ch * 32 + k;
-                    const int jb = ch * 32 + k, kl = o_keys + tl * A + jb;
+                    const int jb = ch * 32 + k, kl = o_keys + tl * A + jb + tl * nAch + ch;
+                    TWV_STAMP(54)
                     if (kv) {
 #pragma unroll
                         for (int j = 0; j < 32; j += 4) sk = fma_(lds[o_nv + jb + j], tanh_e((lds[kl + j] + lds[o_pq + jb + j]) + lds[o_ab + jb + j]), sk);
@@ -1387,11 +1389,13 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
 #pragma unroll
                         for (int j = 0; j < 32; j += 4) sk = fma_(lds[o_nv + jb + j], tanh_e((kr[j] + lds[o_pq + jb + j]) + lds[o_ab + jb + j]), sk);
                     }
+                    TWV_STAMP(55)
                     const float s1 = __shfl_xor(sk, 1);
                     const float pr = (k & 1) ? s1 + sk : sk + s1;       // lanes k=0,1 hold s0+s1 ; k=2,3 hold s2+s3 (operand order as written)
                     const float p2 = __shfl_xor(pr, 2);
                     if (live && k == 0) lds[o_scp + tl * 8 + ch] = pr + p2;
                 }
+                TWV_STAMP(56)
                 __syncthreads();
                 TWV_STAMP(48)
                 {
@@ -2459,7 +2463,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             ga.tickets = reinterpret_cast<int*>(exch + (long long)N * 2 * kExN * 2);
             long long fl = 1024 * 2 + (da.D1 + ENC + AS + 63) / 64 * 64 + 512 * 2 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + (M * R + 63) / 64 * 64 + Tp * 4 + A +
                            Tp * 8 + 4 + 3 + 16 * 16 + 2 * A + da.nbias + pmax;
-            const long long kvf = (long long)((T + G - 1) / G) * A + (long long)T * (ENC / G);
+            const long long kvf = (long long)((T + G - 1) / G) * (A + A / 32) + (long long)T * (ENC / G);
             ga.kv_lds = (fl + kvf) * 4 <= 160 * 1024 ? 1 : 0;
             if (ga.kv_lds) fl += kvf;
             const size_t shm = (size_t)fl * 4;
