@@ -1124,17 +1124,17 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     const int o_p = o; o += Tp;
     const int o_cp = o; o += Tp;
     const int o_q = o; o += Tp;
-    const int o_pq = o; o += A;
+    const int o_pq = o; o += A + A / 8;                   // attention tables are skewed by 4 words per 32 (see the score phase)
     const int o_scp = o; o += Tp * 8;
     const int o_abort = o; o += 4;
     o = (o + 3) & ~3;
     const int o_tab = o; o += 16 * DS_STRIDE;             // stage table (16-byte aligned records)
-    const int o_nv = o; o += A;                           // normed_v, attention bias
-    const int o_ab = o; o += A;
+    const int o_nv = o; o += A + A / 8;                   // normed_v, attention bias
+    const int o_ab = o; o += A + A / 8;
     const int o_bias = o; o += a.nbias;                   // every stage's bias vector, in stage order
     const bool kv = ga.kv_lds != 0;                       // this workgroup's key rows / memory columns held in LDS
     const int nt_all = T > g ? (T - g + G - 1) >> lg : 0;
-    const int o_keys = o; o += kv ? ((T + G - 1) >> lg) * (A + A / 32) : 0;
+    const int o_keys = o; o += kv ? ((T + G - 1) >> lg) * (A + A / 8) : 0;
     const int o_memo = o; o += kv ? T * (ENC >> lg) : 0;
     const int o_part = o;
 
@@ -1146,10 +1146,11 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     for (int i = tid; i < AS; i += 512) lds[o_cat2 + D1 + ENC + i] = init[i];
     for (int i = tid; i < Tp; i += 512) lds[o_al + i] = i == 0 ? 1.0f : 0.0f;
     if (tid < 4) LDSI(o_abort + tid) = 0;
-    for (int i = tid; i < A; i += 512) { lds[o_nv + i] = P[a.w.nv + i]; lds[o_ab + i] = P[a.w.ab + i]; }
+    for (int i = tid; i < A; i += 512) { lds[o_nv + i + ((i >> 5) << 2)] = P[a.w.nv + i]; lds[o_ab + i + ((i >> 5) << 2)] = P[a.w.ab + i]; }
     if (kv) {
-        // (rows skewed by one word per 32: the score's threads -- one per (t, chunk, chain) -- read addresses 32 and 128 apart)
-        for (int i = tid; i < nt_all * A; i += 512) { const int tl = i / A, j = i - tl * A; lds[o_keys + i + (i >> 5)] = keys[(long long)((tl << lg) + g) * A + j]; }
+        // (every 32-word chunk of the attention tables is skewed by 4 words: the score's threads -- one per (t, chunk, chain) -- read
+        // addresses 32 and 128 words apart, i.e. all in four of the 32 LDS banks without the skew: the phase was these reads)
+        for (int i = tid; i < nt_all * A; i += 512) { const int tl = i / A, j = i - tl * A; lds[o_keys + i + ((i >> 5) << 2)] = keys[(long long)((tl << lg) + g) * A + j]; }
         const int ncol = ENC >> lg;
         for (int i = tid; i < T * ncol; i += 512) { const int t = i / ncol, cl = i - t * ncol; lds[o_memo + i] = memo[(long long)t * ENC + g * ncol + cl]; }
     }
@@ -1282,7 +1283,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                         if (act == DA_SIGMOID) v = sigmoid_e(v);
                         else if (act == DA_TANH) v = tanh_e(v);
                         else if (act == DA_RELU) v = v > 0.0f ? v : 0.0f;
-                        if (xch) decg_store(Xb + j, ep, v, loc); else lds[dst + j] = v;
+                        if (xch) decg_store(Xb + j, ep, v, loc); else lds[dst + (post == DP_QUERY ? j + ((j >> 5) << 2) : j)] = v;
                     }
                 }
                 TWV_STAMP(4 * st + 2)
@@ -1318,6 +1319,8 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                         } else if (post == DP_OUT) {         // tacotron.py:204 reshape; helpers.py:40 last frame fed back
                             if (g == 0) a.mel[((long long)n * a.iters + it) * M * R + j] = v;
                             if (j >= M * (R - 1)) lds[o_frame + j - M * (R - 1)] = v;
+                        } else if (post == DP_QUERY) {       // the processed query goes into its skewed table
+                            lds[dst + j + ((j >> 5) << 2)] = v;
                         } else {
                             lds[dst + j] = v;
                         }
@@ -1380,14 +1383,14 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                     const int tl = live ? tc / nAch : 0, ch = live ? tc - tl * nAch : 0, t = (tl << lg) + g;
                     float sk = 0.f;
                     const float* kr = keys + (long long)t * A + ch * 32 + k;
-                    const int jb = ch * 32 + k, kl = o_keys + tl * A + jb + tl * nAch + ch;
+                    const int jb = ch * 32 + k, js = jb + 4 * ch, kl = o_keys + tl * A + jb + 4 * (tl * nAch + ch);      // js, kl: skewed
                     TWV_STAMP(54)
                     if (kv) {
 #pragma unroll
-                        for (int j = 0; j < 32; j += 4) sk = fma_(lds[o_nv + jb + j], tanh_e((lds[kl + j] + lds[o_pq + jb + j]) + lds[o_ab + jb + j]), sk);
+                        for (int j = 0; j < 32; j += 4) sk = fma_(lds[o_nv + js + j], tanh_e((lds[kl + j] + lds[o_pq + js + j]) + lds[o_ab + js + j]), sk);
                     } else {
 #pragma unroll
-                        for (int j = 0; j < 32; j += 4) sk = fma_(lds[o_nv + jb + j], tanh_e((kr[j] + lds[o_pq + jb + j]) + lds[o_ab + jb + j]), sk);
+                        for (int j = 0; j < 32; j += 4) sk = fma_(lds[o_nv + js + j], tanh_e((kr[j] + lds[o_pq + js + j]) + lds[o_ab + js + j]), sk);
                     }
                     TWV_STAMP(55)
                     const float s1 = __shfl_xor(sk, 1);
@@ -2462,8 +2465,8 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             HIPCHK(hipMemsetAsync(exch, 0, (size_t)N * 2 * kExN * 8 + 64, st));
             ga.tickets = reinterpret_cast<int*>(exch + (long long)N * 2 * kExN * 2);
             long long fl = 1024 * 2 + (da.D1 + ENC + AS + 63) / 64 * 64 + 512 * 2 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + (M * R + 63) / 64 * 64 + Tp * 4 + A +
-                           Tp * 8 + 4 + 3 + 16 * 16 + 2 * A + da.nbias + pmax;
-            const long long kvf = (long long)((T + G - 1) / G) * (A + A / 32) + (long long)T * (ENC / G);
+                           Tp * 8 + 4 + 3 + 16 * 16 + 2 * A + 3 * (A / 8) + da.nbias + pmax;
+            const long long kvf = (long long)((T + G - 1) / G) * (A + A / 8) + (long long)T * (ENC / G);
             ga.kv_lds = (fl + kvf) * 4 <= 160 * 1024 ? 1 : 0;
             if (ga.kv_lds) fl += kvf;
             const size_t shm = (size_t)fl * 4;
