@@ -1135,7 +1135,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     const bool kv = ga.kv_lds != 0;                       // this workgroup's key rows / memory columns held in LDS
     const int nt_all = T > g ? (T - g + G - 1) >> lg : 0;
     const int o_keys = o; o += kv ? ((T + G - 1) >> lg) * (A + A / 8) : 0;
-    const int o_memo = o; o += kv ? T * (ENC >> lg) : 0;
+    const int o_memo = o; o += kv ? T * ((ENC >> lg) + 8) : 0;   // rows 8 words apart in the banks: the context's chains k = t mod 4 read four rows at once
     const int o_part = o;
 
     const float* init = a.init + (long long)n * (AS + a.layers * DR);
@@ -1152,7 +1152,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
         // addresses 32 and 128 words apart, i.e. all in four of the 32 LDS banks without the skew: the phase was these reads)
         for (int i = tid; i < nt_all * A; i += 512) { const int tl = i / A, j = i - tl * A; lds[o_keys + i + ((i >> 5) << 2)] = keys[(long long)((tl << lg) + g) * A + j]; }
         const int ncol = ENC >> lg;
-        for (int i = tid; i < T * ncol; i += 512) { const int t = i / ncol, cl = i - t * ncol; lds[o_memo + i] = memo[(long long)t * ENC + g * ncol + cl]; }
+        for (int i = tid; i < T * ncol; i += 512) { const int t = i / ncol, cl = i - t * ncol; lds[o_memo + t * (ncol + 8) + cl] = memo[(long long)t * ENC + g * ncol + cl]; }
     }
     const int nst = 7 + 2 * a.layers;
     if (tid == 0) {
@@ -1420,30 +1420,64 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                 // monotonic attention recurrence (redundant in every workgroup), all in wave 0 and in registers:
                 // cumprod(1 - p) as exp(exclusive cumsum(log(clip(1 - p)))) [RECALLED-TF safe_cumprod], then
                 // alignments = p * cumprod * inclusive cumsum(previous / clip(cumprod, 1e-10, 1))
-                if (wave == 0) {
-                    float run = 0.0f, run2 = 0.0f;
-                    for (int base = 0; base < T; base += 64) {
-                        const int t = base + lane, nb_ = T - base < 64 ? T - base : 64;
-                        const bool live = t < T;
+                // The 64-step blocks of AC-6 run side by side, one wave each (eight blocks per round): a block needs from its
+                // predecessors only the running total in front of its own scan, and that is the same chain of adds -- total of block
+                // 0, + block 1's own total, ... -- whether the blocks are scanned one after the other or their totals are summed
+                // afterwards.  (One wave walking the blocks: 1.02 us at T = 101, most of it the log / exp / division of block 2 waiting
+                // behind block 1's.)
+                {
+                    const int o_tot = o_scp;                               // block totals (the score chunk values are consumed)
+                    float run = 0.0f, run2 = 0.0f;                         // totals in front of this round's first block
+                    for (int base0 = 0; base0 < T; base0 += 512) {
+                        const int base = base0 + wave * 64, t = base + lane;
+                        const bool mine = base < T, live = t < T;
+                        const int nblk = (T - base0 + 63) >> 6 < 8 ? (T - base0 + 63) >> 6 : 8;
                         const float pv = live ? lds[o_p + t] : 0.0f;
                         float om = 1.0f - pv;
                         const float tiny = 1.17549435e-38f;
                         om = om < tiny ? tiny : (om > 1.0f ? 1.0f : om);
                         const float lq = live ? log_e(om) : 0.0f;
-                        const float ex = decg_scan_block(lq, run, base == 0, lane, false);
+                        const float sc = scan64_f32_wave(lq);
+                        if (mine && lane == 63) lds[o_tot + wave] = sc;
+                        __syncthreads();
+                        float carry = run, all = run;                      // this block's carry; the total after the round's last block
+                        for (int b = 0; b < nblk; ++b) {
+                            const float tb = lds[o_tot + b];
+                            const float nx = (base0 == 0 && b == 0) ? tb : all + tb;
+                            if (b < wave) carry = nx;
+                            all = nx;
+                        }
+                        run = all;
+                        const bool first = base0 == 0 && wave == 0;
+                        const float incl = first ? sc : carry + sc;
+                        const float up = __shfl_up(incl, 1);
+                        const float ex = lane == 0 ? (first ? 0.0f : carry) : up;
                         const float cpv = exp_e(ex);
                         float den = cpv;
                         den = den < 1e-10f ? 1e-10f : (den > 1.0f ? 1.0f : den);
                         const float q2 = live ? div_(lds[o_al + t], den) : 0.0f;
-                        const float cs = decg_scan_block(q2, run2, base == 0, lane, true);
+                        const float sc2 = scan64_f32_wave(q2);
+                        __syncthreads();                                   // (the first totals have been read)
+                        if (mine && lane == 63) lds[o_tot + wave] = sc2;
+                        __syncthreads();
+                        float carry2 = run2, all2 = run2;
+                        for (int b = 0; b < nblk; ++b) {
+                            const float tb = lds[o_tot + b];
+                            const float nx = (base0 == 0 && b == 0) ? tb : all2 + tb;
+                            if (b < wave) carry2 = nx;
+                            all2 = nx;
+                        }
+                        run2 = all2;
+                        const float cs = first ? sc2 : carry2 + sc2;
                         if (live) {
                             const float pc = pv * cpv;
                             const float al = pc * cs;
                             lds[o_al + t] = al;
                             if (a.align && g == 0) a.align[((long long)n * T + t) * a.iters + it] = al;      // tacotron.py:223
                         }
+                        __syncthreads();                                   // (the second totals have been read)
                     }
-                    for (int t = T + lane; t < Tp; t += 64) lds[o_al + t] = 0.0f;
+                    for (int t = T + tid; t < Tp; t += 512) lds[o_al + t] = 0.0f;
                 }
                 __syncthreads();
                 TWV_STAMP(50)
@@ -1463,7 +1497,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                         float sk = 0.f;
                         if (kv) {
                             const int mo = o_memo + cl;
-                            for (int t = ta + k; t < tb; t += 4) sk = fma_(lds[mo + t * ncol], lds[o_al + t], sk);
+                            for (int t = ta + k; t < tb; t += 4) sk = fma_(lds[mo + t * (ncol + 8)], lds[o_al + t], sk);
                         } else {
                             const float* mp = memo + c0 + cl;
                             for (int t = ta + k; t < tb; t += 4) sk = fma_(mp[(long long)t * ENC], lds[o_al + t], sk);
@@ -2466,7 +2500,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             ga.tickets = reinterpret_cast<int*>(exch + (long long)N * 2 * kExN * 2);
             long long fl = 1024 * 2 + (da.D1 + ENC + AS + 63) / 64 * 64 + 512 * 2 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + (M * R + 63) / 64 * 64 + Tp * 4 + A +
                            Tp * 8 + 4 + 3 + 16 * 16 + 2 * A + 3 * (A / 8) + da.nbias + pmax;
-            const long long kvf = (long long)((T + G - 1) / G) * (A + A / 8) + (long long)T * (ENC / G);
+            const long long kvf = (long long)((T + G - 1) / G) * (A + A / 8) + (long long)T * (ENC / G + 8);
             ga.kv_lds = (fl + kvf) * 4 <= 160 * 1024 ? 1 : 0;
             if (ga.kv_lds) fl += kvf;
             const size_t shm = (size_t)fl * 4;

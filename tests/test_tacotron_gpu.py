@@ -165,9 +165,10 @@ def test_decoder_placement_does_not_change_results(torch_cuda, oracle, local, sp
 
 
 def test_tacotron_minimal_and_long_inputs(torch_cuda, oracle):
-    """edge cases: a single EOS token; one utterance; an input longer than 256 tokens (more than one key row per thread)"""
+    """edge cases: a single EOS token; one utterance; an input longer than 256 tokens (more than one key row per thread); more than 512
+    (the attention recurrence's 64-step blocks take a second round of the eight waves)"""
     hp = _hp(max_iters=3, enc_bank_size=2, post_bank_size=2, num_freq=33)
-    for N, T, lengths in ((1, 1, [1]), (2, 2, [2, 1]), (1, 300, [300])):
+    for N, T, lengths in ((1, 1, [1]), (2, 2, [2, 1]), (1, 300, [300]), (2, 600, [600, 531])):
         d, blob, tok, ln, spk, m = _case(oracle, hp, N, T, lengths, seed=7)
         mel_o, lin_o, al_o = oracle.taco_infer(d, blob, tok, ln, spk)
         mel, lin, al = m.infer(tok, ln, spk)
