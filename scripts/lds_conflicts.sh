@@ -23,7 +23,7 @@ for w in ("gen", "mulaw", "tacotron", "train"):
     if not fs: print(w, "no counters"); continue
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(fs[0])):
-        acc[r["Kernel_Name"].split("(")[0][:48]][r["Counter_Name"]] += float(r["Counter_Value"])
+        acc[r["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0][:48]][r["Counter_Name"]] += float(r["Counter_Value"])
     print("==", w)
     for k, c in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_LDS_IDX_ACTIVE", 0)):
         idx = c.get("SQ_LDS_IDX_ACTIVE", 0.0)
