@@ -878,12 +878,19 @@ __global__ void __launch_bounds__(512) tc_decoder_kernel(DecArgs a)
 //  decoder, G workgroups per utterance (the default when N*G workgroups fit the chip)
 // -----------------------------------------------------------------------------------------------------
 // The 1.6 M decoder weights (6.4 MB) do not fit one XCD's 4 MB L2, so one workgroup per utterance streams them from the
-// memory side every step.  Here workgroup (n, g) owns the 64-column output blocks jb = g, g+G, ... of every wide matvec,
-// and blockIdx -> (n = id / G, g = id % G) puts slice g of the weights into XCD g's L2 (0.8 MB at G = 8).  Each workgroup
-// keeps a full replica of the utterance's recurrent state in LDS; after a split matvec the activated outputs travel as
-// {epoch, value} granules (one agent-scope store each, readers poll -- same mechanism as the WaveNet generation kernel),
-// two alternating buffers: a workgroup can only publish exchange e+2 after it gathered e+1, which needs every workgroup
-// to have finished reading e.  Small matvecs (prenet, query) and the attention recurrence run redundantly.
+// memory side every step.  Here workgroup (n, g) owns the 64-column output blocks jb = g, g+G, ... of every wide matvec (32-column
+// half blocks where a stage has fewer blocks than workgroups: DecgGeo).  Each workgroup keeps a full replica of the utterance's
+// recurrent state in LDS; after a split matvec the activated outputs travel as {epoch, value} granules (one 8-byte store each,
+// readers poll -- same mechanism as the WaveNet generation kernel), two alternating buffers: a workgroup can only publish exchange
+// e+2 after it gathered e+1, which needs every workgroup to have finished reading e.
+// Placement (DecGArgs::local):
+//   local  (default): the G workgroups of an utterance sit on ONE XCD (XCD x: utterances x, x+8, ...; the XCD is read from the
+//                     hardware, the role is a ticket of that XCD) and exchange through its L2 -- plain stores, sc1 loads; the
+//                     weights stream through that L2.  The prenet and the query layer are split stages too (split_all).
+//   spread:           blockIdx -> (n = id / G, g = id % G) puts slice g of the weights into XCD g's L2 (0.8 MB at G = 8) and
+//                     every exchange crosses XCDs (agent-scope stores, a memory-side hop); prenet and query layer run whole in
+//                     every workgroup.
+// The attention recurrence runs redundantly in every workgroup.
 // Arithmetic is unchanged: every output column's chunks are still summed in order inside one workgroup.
 constexpr int kExN = 1024;          // granules per exchange buffer
 typedef __attribute__((address_space(1))) unsigned long long tgu64;
