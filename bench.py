@@ -587,8 +587,20 @@ def main():
                 DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US = 22.37, 13, 0.27
                 dec_floor = DEC_NONEXCH_US + DEC_EXCHANGES * DEC_HOP_US
                 del tm1
+                # other batch sizes on the same GPU (not the metric's configuration: the decoder is a latency chain, so more utterances
+                # per pass cost little; at 64 the 256 CUs hold 4 workgroups per utterance instead of 8)
+                bsweep = []
+                for TB in (8, 16, 64):
+                    tokb = trng.randint(2, 80, (TB, TT)).astype(np.int32); tokb[:, -1] = 1
+                    tlb = np.full(TB, TT, np.int32); tsb = (np.arange(TB) % 2).astype(np.int32)
+                    tm.infer(tokb, tlb, tsb); torch.cuda.synchronize()
+                    c0 = time.perf_counter()
+                    for _ in range(2): tm.infer(tokb, tlb, tsb)
+                    torch.cuda.synchronize()
+                    bdt = (time.perf_counter() - c0) / 2
+                    bsweep.append({"batch": TB, "ms_per_pass": bdt * 1e3, "mel_frames_per_s": TB * hp.max_iters * hp.reduction_factor / bdt})
                 res["tacotron"] = {"metric": "Tacotron mel frames/sec", "value": TN * hp.max_iters * hp.reduction_factor / qdt,
-                                   "unit": "mel frames/s", "ms_per_pass": qdt * 1e3, "dtype": "f32",
+                                   "unit": "mel frames/s", "ms_per_pass": qdt * 1e3, "dtype": "f32", "batch_sweep": bsweep,
                                    "roofline": {"bound": "mfma", "kernel": "tc_gemm_mfma_{,group_,highway_,ck_}kernel (%d launches per pass: CBHG conv banks as one grouped launch each, projections, "
                                                                         "fused highway layers, grouped GRU input halves, attention keys, linear)" % gn,
                                                 "achieved": gflop / (gms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": gflop / (gms * 1e-3) / 1e12 / 157.3,
