@@ -2472,7 +2472,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             xfl = ust * nu + 2 * A + 16 * xt.nst + (long long)nu * ntm * 8 + (long long)nu * ntm * A + (long long)nu * T * ncol + (p1 > p2 ? p1 : p2) + 4 + kXStages * 12 + 64;
         }
         const bool xok = taco_xdec_ok(h, xt) && cus >= 256 && upx <= kXU && T <= 512 && xfl * 4 <= 160 * 1024;
-        if (h->dec_groups == 32 && xok) {      // opt-in: measured 43.5 us per decoder step against the split kernel's 47, the whole pass is not faster yet
+        if (h->dec_groups == 32 && xok) {      // opt-in cross-check: 44.6 us per decoder step against the split kernel's 30.5
             // XCD-local kernel: every XCD's 32 workgroups hold the decoder in registers and serve that XCD's utterances
             DecXArgs xa;
             xa.d = da; xa.tab = xt; xa.upx = upx; xa.xt_off = h->xt_off;
