@@ -919,16 +919,17 @@ __device__ __forceinline__ int decg_off(int wt_bytes, const DecgPos& p, int nchu
 }
 // Which tiles of a stage a workgroup owns.  A tile is 64 columns x one 32-term chunk (lane = column).  A split stage with fewer
 // column blocks than workgroups (N = 256 at G = 8: four blocks) would leave half of the utterance's workgroups idle while the other
-// half streams and multiplies twice its share, so such a stage runs in HALF-BLOCK form: workgroup g owns columns
-// [32 g, 32 g + 32) and a tile is 32 columns x TWO chunks -- lanes 0-31 chunk 2i, lanes 32-63 chunk 2i + 1 of the same columns (the
-// same 8 KB per tile: two half tiles of the standard image, 8192 bytes apart).  Chunk values still meet in LDS in chunk order.
+// half streams and multiplies twice its share, so such a stage runs in PART-BLOCK form with sh = 1 or 2: workgroup g owns the
+// 64 >> sh columns [(64 >> sh) g, ...) and a tile is (64 >> sh) columns x (1 << sh) chunks -- the wave's lanes are 1 << sh groups, group
+// h runs chunk (i << sh) + h of the same columns (the same 8 KB per tile: part tiles of the standard image, 8192 bytes apart).
+// Chunk values still meet in LDS in chunk order.
 struct DecgGeo {
     int nchunk;     // 32-term chunks of the reduction
-    int nct;        // tiles per column block (nchunk, or ceil(nchunk / 2) in half-block form)
+    int nct;        // tiles per column block (ceil(nchunk >> sh))
     int ntile;      // this workgroup's tiles
     int nmine;      // this workgroup's column blocks
     int gT, lgT;    // block index = (m << lgT) + gT
-    int hf;         // 1 = half-block form
+    int sh;         // 0 = whole 64-column blocks; 1, 2 = half / quarter blocks
 };
 __device__ __forceinline__ DecgGeo decg_geo(int K, int N, int split, int g, int lg)
 {
@@ -936,11 +937,12 @@ __device__ __forceinline__ DecgGeo decg_geo(int K, int N, int split, int g, int 
     const int G = 1 << lg;
     e.nchunk = (K + 31) >> 5;
     const int nblk = (N + 63) >> 6;
-    e.hf = (split && G > 1 && 2 * nblk <= G) ? 1 : 0;
-    if (e.hf) {
-        e.gT = g >> 1; e.lgT = 0;
-        e.nct = (e.nchunk + 1) >> 1;
-        e.nmine = (g >> 1) < nblk ? 1 : 0;
+    e.sh = 0;
+    if (split && G > 1) while (e.sh < 2 && (nblk << (e.sh + 1)) <= G) ++e.sh;
+    if (e.sh) {
+        e.gT = g >> e.sh; e.lgT = 0;
+        e.nct = (e.nchunk + (1 << e.sh) - 1) >> e.sh;
+        e.nmine = (g >> e.sh) < nblk ? 1 : 0;
     } else {
         e.gT = split ? g : 0; e.lgT = split ? lg : 0;
         e.nct = e.nchunk;
@@ -951,19 +953,20 @@ __device__ __forceinline__ DecgGeo decg_geo(int K, int N, int split, int g, int 
 }
 __device__ __forceinline__ int decg_toff(int wt_bytes, const DecgGeo& e, const DecgPos& p)
 {
-    return wt_bytes + ((((p.m << e.lgT) + e.gT) * e.nchunk + (p.ch << e.hf)) << 13);
+    return wt_bytes + ((((p.m << e.lgT) + e.gT) * e.nchunk + (p.ch << e.sh)) << 13);
 }
-// per-lane byte offset inside a tile's image
+// per-lane byte offset inside a tile's image: lane group h = lane >> (6 - sh) reads part tile h, columns sub * (64 >> sh) + ...
 __device__ __forceinline__ int decg_voff(const DecgGeo& e, int g, int lane)
 {
-    return e.hf ? ((lane >> 5) << 13) + ((((g & 1) << 5) + (lane & 31)) << 4) : lane << 4;
+    const int cw = 64 >> e.sh, sub = g & ((1 << e.sh) - 1);
+    return ((lane >> (6 - e.sh)) << 13) + ((sub * cw + (lane & (cw - 1))) << 4);      // (sh = 0: lane << 4)
 }
-__device__ __forceinline__ int decg_geo_pack(const DecgGeo& e) { return e.hf | (e.lgT << 1) | (e.gT << 4) | (e.nmine << 12); }
+__device__ __forceinline__ int decg_geo_pack(const DecgGeo& e) { return e.sh | (e.lgT << 2) | (e.gT << 5) | (e.nmine << 13); }
 __device__ __forceinline__ DecgGeo decg_geo_unpack(int K, int nct, int ntile, int geo)
 {
     DecgGeo e;
     e.nchunk = (K + 31) >> 5; e.nct = nct; e.ntile = ntile;
-    e.hf = geo & 1; e.lgT = (geo >> 1) & 7; e.gT = (geo >> 4) & 255; e.nmine = geo >> 12;
+    e.sh = geo & 3; e.lgT = (geo >> 2) & 7; e.gT = (geo >> 5) & 255; e.nmine = geo >> 13;
     return e;
 }
 // local block m, lane l: chunk values summed in order (AC-1); the LDS reads of four chunks are issued together
@@ -1081,7 +1084,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     const DecArgs& a = ga.d;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lg = ga.G == 8 ? 3 : (ga.G == 4 ? 2 : (ga.G == 2 ? 1 : 0)), G = 1 << lg;
+    const int lg = ga.G == 16 ? 4 : (ga.G == 8 ? 3 : (ga.G == 4 ? 2 : (ga.G == 2 ? 1 : 0))), G = 1 << lg;
     // workgroup -> (utterance n, slice g):
     //   spread (local = 0): n = id / G, g = id % G.  Workgroups go to the XCDs round-robin, so slice g of the weights lives in XCD
     //                       g's L2 -- and every exchange of the step crosses XCDs (a memory-side hop)
@@ -1244,15 +1247,15 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
             // were requested while the previous stage was still combining / exchanging (weights do not depend on data).
             {
                 const int vo = decg_voff(e, g, lane);
-                const int hi = e.hf ? lane >> 5 : 0;                       // half-block form: the upper half runs the odd chunk
-                const int pl = e.hf ? lane & 31 : lane;                    // column inside the partial row
+                const int hi = lane >> (6 - e.sh);                         // part-block form: lane group h runs chunk (i << sh) + h
+                const int pl = lane & ((64 >> e.sh) - 1);                  // column inside the partial row
                 DecgPos p0{0, 0}, p1, p2;
                 decg_adv(p0, wave, e.nct);
                 p1 = p0; decg_adv(p1, 8, e.nct);
                 p2 = p1; decg_adv(p2, 8, e.nct);
 #define DECG_DOT(T_, P_, I_)                                                                                                    \
                     {                                                                                                            \
-                        const int c_ = (P_.ch << e.hf) + hi;                      /* this lane's chunk */                        \
+                        const int c_ = (P_.ch << e.sh) + hi;                      /* this lane's chunk */                        \
                         const int xq = xo + c_ * 32 + (lane & 15);                                                               \
                         const float r = dot32_dpp(T_.w, lds[xq], lds[xq + 16]);                                                  \
                         __builtin_amdgcn_sched_barrier(0);                                                                       \
@@ -1280,10 +1283,10 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                 const bool xch = split && G > 1;
                 unsigned long long* Xb = X;
                 if (xch) { ++ep; Xb = X + (ep & 1) * kExN; }
-                const int ncolw = e.hf ? 32 : 64;                          // columns per owned block
+                const int ncolw = 64 >> e.sh;                              // columns per owned block
                 for (int qq = tid; qq < nmine * ncolw; qq += 512) {
-                    const int m = e.hf ? 0 : qq >> 6;
-                    const int j = e.hf ? (e.gT << 6) + ((g & 1) << 5) + qq : (((m << e.lgT) + e.gT) << 6) + (qq & 63);
+                    const int m = e.sh ? 0 : qq >> 6;
+                    const int j = e.sh ? (e.gT << 6) + (g & ((1 << e.sh) - 1)) * ncolw + qq : (((m << e.lgT) + e.gT) << 6) + (qq & 63);
                     if (j < N) {
                         float v = decg_combine(o_part, nchunk, m, qq & 63);
                         if (bias >= 0) v = v + lds[bias + j];
@@ -1969,7 +1972,7 @@ struct TCbhg {
 struct twv_tacotron {
     twv_tacotron_dims d;
     unsigned long long* prof = nullptr;
-    int dec_groups = 0;             // 0 auto (8, halved until N*G fits the CUs), -1 single-workgroup kernel
+    int dec_groups = 0;             // 0 auto (16, halved until N*G fits the CUs), -1 single-workgroup kernel
     int dec_split_all = -1;         // prenet + query layer split over the workgroups: -1 = when the exchanges are L2-local, 0 / 1
     int dec_local = 1;              // split kernel: 1 = an utterance's workgroups on one XCD (exchanges through its L2), 0 = spread over the XCDs
     long long blob_floats, packed_floats;
@@ -2100,8 +2103,8 @@ extern "C" int twv_tacotron_set_option(twv_tacotron* h, const char* name, int va
     if (!strcmp(name, "decoder_split_all")) { h->dec_split_all = value < 0 ? -1 : (value ? 1 : 0); return TWV_OK; }
     if (!strcmp(name, "decoder_local")) { h->dec_local = value ? 1 : 0; return TWV_OK; }
     if (!strcmp(name, "decoder_groups")) {
-        if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 32)
-            return twv_fail(TWV_E_INVALID, "decoder_groups must be -1, 0, 1, 2, 4, 8 or 32 (32 = the XCD-local kernel)");
+        if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32)
+            return twv_fail(TWV_E_INVALID, "decoder_groups must be -1, 0, 1, 2, 4, 8, 16 or 32 (32 = the XCD-local kernel)");
         h->dec_groups = value;
         return TWV_OK;
     }
@@ -2457,7 +2460,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
         int cus = 0, devid = 0;
         HIPCHK(hipGetDevice(&devid));
         HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid));
-        int G = h->dec_groups > 0 ? h->dec_groups : 8;
+        int G = h->dec_groups > 0 ? h->dec_groups : 16;        // 16 workgroups per utterance up to batch 16, 8 up to 32, 4 up to 64, ...
         while (G > 1 && (long long)N * G > cus) G >>= 1;
         if (2 * (AS > DR ? AS : DR) > kExN || M * R > kExN || T > kExN || ENC > kExN) G = 1;
         while (G > 1 && ENC % G) G >>= 1;

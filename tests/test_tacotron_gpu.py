@@ -121,7 +121,7 @@ def test_synthesizer_surface(torch_cuda, oracle):
     assert first_mismatch(out["mel"].cpu().numpy(), mel_o) is None
 
 
-@pytest.mark.parametrize("groups", [-1, 1, 2, 4, 8, 32])
+@pytest.mark.parametrize("groups", [-1, 1, 2, 4, 8, 16, 32])
 def test_decoder_launch_geometry_does_not_change_results(torch_cuda, oracle, groups):
     """decoder split over G workgroups per utterance (exchange through polled granules) == single-workgroup kernel == the XCD-local
     register-resident kernel (32) == oracle"""
