@@ -1078,13 +1078,17 @@ typedef int i32x4s __attribute__((ext_vector_type(4)));
 enum { DP_NONE = 0, DP_CAT_ATT, DP_GATES, DP_CAND, DP_QUERY, DP_PROJ, DP_OUT };
 enum { DA_NONE = 0, DA_SIGMOID, DA_TANH, DA_RELU };
 
-template <bool PROF>
+// DEF: the hparams-default decoder sizes (hparams.py:126-158: num_mels 80, r 5, prenet 256 / 128, attention 256, rnn sizes 256, two
+// residual layers) with 8 workgroups per utterance as compile-time constants.  The kernel is short of scalar registers (a table-driven
+// loop over run-time sizes keeps ~100 scalars alive: 85-105 SGPR spills, ~40 v_readlane / v_writelane per stage); with the sizes
+// folded the LDS carve and most index arithmetic are constants.  Any other shape runs the same code with DEF = false.
+template <bool PROF, bool DEF>
 __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
 {
     const DecArgs& a = ga.d;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lg = ga.G == 16 ? 4 : (ga.G == 8 ? 3 : (ga.G == 4 ? 2 : (ga.G == 2 ? 1 : 0))), G = 1 << lg;
+    const int lg = DEF ? 3 : (ga.G == 16 ? 4 : (ga.G == 8 ? 3 : (ga.G == 4 ? 2 : (ga.G == 2 ? 1 : 0)))), G = 1 << lg;
     // workgroup -> (utterance n, slice g):
     //   spread (local = 0): n = id / G, g = id % G.  Workgroups go to the XCDs round-robin, so slice g of the weights lives in XCD
     //                       g's L2 -- and every exchange of the step crosses XCDs (a memory-side hop)
@@ -1105,7 +1109,8 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
         g = slot & (G - 1);
         n = slot < (1 << 20) ? ((slot >> lg) << 3) + (int)xcc : a.N;
     }
-    const int T = a.T, M = a.M, R = a.R, A = a.A, AS = a.AS, ENC = a.ENC, DR = a.DR, D0 = a.D0, D1 = a.D1;
+    const int T = a.T, M = DEF ? 80 : a.M, R = DEF ? 5 : a.R, A = DEF ? 256 : a.A, AS = DEF ? 256 : a.AS, ENC = DEF ? 256 : a.ENC;
+    const int DR = DEF ? 256 : a.DR, D0 = DEF ? 256 : a.D0, D1 = DEF ? 128 : a.D1, NL = DEF ? 2 : a.layers;
     if (n >= a.N) return;
     const int len = a.lengths[n];
     const float* P = a.P;
@@ -1124,7 +1129,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     const int o_cand = o; o += 512;
     const int o_keep = o; o += 512;                       // h before the update
     const int o_ha = o; o += AS;
-    const int o_hr0 = o; o += a.layers * DR;              // residual GRU states, layer l at o_hr0 + l*DR
+    const int o_hr0 = o; o += NL * DR;              // residual GRU states, layer l at o_hr0 + l*DR
     const int o_frame = o; o += ((M + 31) / 32) * 32;
     const int o_ctx = o; o += ENC;
     const int o_y = o; o += DR;
@@ -1141,16 +1146,16 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     const int o_tab = o; o += 16 * DS_STRIDE;             // stage table (16-byte aligned records)
     const int o_nv = o; o += A + A / 8;                   // normed_v, attention bias
     const int o_ab = o; o += A + A / 8;
-    const int o_bias = o; o += a.nbias;                   // every stage's bias vector, in stage order
+    const int o_bias = o; o += DEF ? 256 + 128 + 3 * 256 + 256 + 2 * 3 * 256 + 400 : a.nbias;   // every stage's bias vector, in stage order
     const bool kv = ga.kv_lds != 0;                       // this workgroup's key rows / memory columns held in LDS
     const int nt_all = T > g ? (T - g + G - 1) >> lg : 0;
     const int o_keys = o; o += kv ? ((T + G - 1) >> lg) * (A + A / 8) : 0;
     const int o_memo = o; o += kv ? T * ((ENC >> lg) + 8) : 0;   // rows 8 words apart in the banks: the context's chains k = t mod 4 read four rows at once
     const int o_part = o;
 
-    const float* init = a.init + (long long)n * (AS + a.layers * DR);
+    const float* init = a.init + (long long)n * (AS + NL * DR);
     for (int i = tid; i < AS; i += 512) lds[o_ha + i] = init[i];
-    for (int i = tid; i < a.layers * DR; i += 512) lds[o_hr0 + i] = init[AS + i];
+    for (int i = tid; i < NL * DR; i += 512) lds[o_hr0 + i] = init[AS + i];
     for (int i = tid; i < ((M + 31) / 32) * 32; i += 512) lds[o_frame + i] = 0.0f;
     for (int i = tid; i < ENC; i += 512) { lds[o_ctx + i] = 0.0f; lds[o_cat2 + D1 + i] = 0.0f; }
     for (int i = tid; i < AS; i += 512) lds[o_cat2 + D1 + ENC + i] = init[i];
@@ -1164,7 +1169,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
         const int ncol = ENC >> lg;
         for (int i = tid; i < T * ncol; i += 512) { const int t = i / ncol, cl = i - t * ncol; lds[o_memo + t * (ncol + 8) + cl] = memo[(long long)t * ENC + g * ncol + cl]; }
     }
-    const int nst = 7 + 2 * a.layers;
+    const int nst = 7 + 2 * NL;
     if (tid == 0) {
         int s = 0, bo = o_bias;
         auto put = [&](long long w, long long b, int K, int N, int x, int dst, int act, int split, int post, int p0, int p1, int p2) {
@@ -1188,9 +1193,9 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
         // rnn_wrappers.py:463 concat(output, attention) -> OutputProjectionWrapper(dec_rnn)
         put(a.w.cW, a.w.cb, AS + ENC, DR, o_cat, o_y, DA_NONE, 1, DP_PROJ, 0, 0, 0);
         // tacotron.py:167 ResidualWrapper(GRUCell(dec_rnn)): y <- y + GRU(y, h_l)
-        for (int l = 0; l < a.layers; ++l) {
+        for (int l = 0; l < NL; ++l) {
             put(a.w.rWg[l], a.w.rbg[l], 2 * DR, 2 * DR, o_cat, o_vec, DA_SIGMOID, 1, DP_GATES, DR, DR, 0);
-            put(a.w.rWc[l], a.w.rbc[l], 2 * DR, DR, o_cat, o_cand, DA_TANH, 1, DP_CAND, DR, o_hr0 + l * DR, l + 1 < a.layers ? o_hr0 + (l + 1) * DR : 0);
+            put(a.w.rWc[l], a.w.rbc[l], 2 * DR, DR, o_cat, o_cand, DA_TANH, 1, DP_CAND, DR, o_hr0 + l * DR, l + 1 < NL ? o_hr0 + (l + 1) * DR : 0);
         }
         // tacotron.py:173 OutputProjectionWrapper(num_mels * r)
         put(a.w.oW, a.w.ob, DR, M * R, o_y, o_out, DA_NONE, 1, DP_OUT, 0, 0, 0);
@@ -2516,13 +2521,14 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             const size_t shm = (size_t)fl * 4;
             if (shm > 160 * 1024) return twv_fail(TWV_E_UNSUPPORTED, "decoder LDS footprint exceeds 160 KiB (t_in too large)");
             // plain launch (N * G <= CU count is enforced above); a cooperative launch was measured and dropped, see twv_wavenet.hip
-            if (da.prof) {     // the instrumented build (phase stamps) is its own instantiation
-                HIPCHK(hipFuncSetAttribute((const void*)tc_decoder_g_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-                hipLaunchKernelGGL(tc_decoder_g_kernel<true>, dim3(wgs), dim3(512), shm, st, ga);
-            } else {
-                HIPCHK(hipFuncSetAttribute((const void*)tc_decoder_g_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-                hipLaunchKernelGGL(tc_decoder_g_kernel<false>, dim3(wgs), dim3(512), shm, st, ga);
-            }
+            // the hparams-default sizes have an instantiation of their own (sizes folded: half the scalar-register spills); the
+            // instrumented build (phase stamps) likewise
+            const bool def = G == 8 && M == 80 && R == 5 && A == 256 && AS == 256 && ENC == 256 && DR == 256 && da.D0 == 256 && da.D1 == 128 && d.dec_layer_num == 2;
+            const void* kfn = da.prof ? (def ? (const void*)tc_decoder_g_kernel<true, true> : (const void*)tc_decoder_g_kernel<true, false>)
+                                      : (def ? (const void*)tc_decoder_g_kernel<false, true> : (const void*)tc_decoder_g_kernel<false, false>);
+            HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            void* kargs[] = {&ga};
+            HIPCHK(hipLaunchKernel(kfn, dim3(wgs), dim3(512), kargs, shm, st));
         }
     }
     // ---- tacotron.py:209 post CBHG (no lengths, zero init), :219 linear projection
