@@ -903,6 +903,7 @@ struct DecGArgs {
     int kv_lds;                     // 1: key rows / memory columns of the workgroup fit in LDS
     int local;                      // 1: the G workgroups of an utterance share one XCD and exchange through its L2
     int* tickets;                   // [8] role tickets of the local mode, zeroed before the launch
+    int* stab;                      // [workgroups][16 stages][16]: every workgroup's copy of its stage table (read with scalar loads)
     int split_all;                  // 1: the prenet and the query layer are split over the workgroups too (three more exchanges, 300 KB
                                     //    less weight traffic per workgroup and step); 0: every workgroup computes them whole
 };
@@ -1082,6 +1083,21 @@ enum { DA_NONE = 0, DA_SIGMOID, DA_TANH, DA_RELU };
 // residual layers) with 8 workgroups per utterance as compile-time constants.  The kernel is short of scalar registers (a table-driven
 // loop over run-time sizes keeps ~100 scalars alive: 85-105 SGPR spills, ~40 v_readlane / v_writelane per stage); with the sizes
 // folded the LDS carve and most index arithmetic are constants.  Any other shape runs the same code with DEF = false.
+// A stage's 64-byte record straight into scalar registers (s_load from the workgroup's copy of the table in global memory, served by
+// the scalar cache): the LDS copy cost four ds_read_b128, their wait and sixteen v_readfirstlane at every stage start, and again
+// twice per stage for the next stage's tile requests -- 0.3 us of a 2.4 us stage.
+typedef int i32x16s __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ i32x16s decg_sload16(const int* p)
+{
+    i32x16s r;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+    return r;
+}
+// words 0-3 and 12-15 of a record (what a tile request needs: weights, K, tile geometry)
+__device__ __forceinline__ void decg_sload_geo(const int* p, i32x4s& lo, i32x4s& hi)
+{
+    asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x30\n\ts_waitcnt lgkmcnt(0)" : "=&s"(lo), "=&s"(hi) : "s"(p) : "memory");
+}
 template <bool PROF, bool DEF>
 __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
 {
@@ -1205,7 +1221,12 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
         const int q = o_tab + st * DS_STRIDE, bl = LDSI(q + DS_BIAS), bg = LDSI(q + DS_BIASG), N = LDSI(q + DS_N);
         if (bl >= 0) for (int i = tid; i < N; i += 512) lds[bl + i] = P[bg + i];
     }
+    // the stage table, once more, where scalar loads can reach it
+    int* const stab = ga.stab + (long long)blockIdx.x * (16 * DS_STRIDE);
+    for (int e = tid; e < 16 * DS_STRIDE; e += 512) stab[e] = LDSI(o_tab + e);
+    __threadfence();
     __syncthreads();
+    __builtin_amdgcn_s_dcache_inv();
     const int nAch = A / 32;
     unsigned ep = 0;                                      // exchanges completed so far
     bool ok = true;
@@ -1214,11 +1235,10 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     // the other two
 #define DECG_PREFETCH_(sn, A_, B_)                                                                                              \
     {                                                                                                                            \
-        const int qn_ = o_tab + (sn) * DS_STRIDE;                                                                                \
-        const i32x4s n0_ = LDS4I(qn_ >> 2), n3_ = LDS4I((qn_ >> 2) + 3);                                                         \
-        const int wn_ = __builtin_amdgcn_readfirstlane(n0_.x), Kn_ = __builtin_amdgcn_readfirstlane(n0_.z);                      \
-        const DecgGeo en_ = decg_geo_unpack(Kn_, __builtin_amdgcn_readfirstlane(n3_.y), __builtin_amdgcn_readfirstlane(n3_.z),   \
-                                            __builtin_amdgcn_readfirstlane(n3_.w));                                              \
+        i32x4s n0_, n3_;                                                                                                         \
+        decg_sload_geo(stab + (sn) * DS_STRIDE, n0_, n3_);                                                                       \
+        const int wn_ = n0_.x, Kn_ = n0_.z;                                                                                      \
+        const DecgGeo en_ = decg_geo_unpack(Kn_, n3_.y, n3_.z, n3_.w);                                                           \
         const int von_ = decg_voff(en_, g, lane);                                                                                \
         DecgPos q0_{0, 0}, q1_, q2_;                                                                                             \
         decg_adv(q0_, wave, en_.nct);                                                                                            \
@@ -1237,15 +1257,10 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
 
     for (int it = 0; it < a.iters && ok; ++it) {
         for (int st = 0; st < nst && ok; ++st) {
-            const int q = o_tab + st * DS_STRIDE;
-            const i32x4s sr0 = LDS4I(q >> 2), sr1 = LDS4I((q >> 2) + 1), sr2 = LDS4I((q >> 2) + 2), sr3 = LDS4I((q >> 2) + 3);
-            const int w_bytes = __builtin_amdgcn_readfirstlane(sr0.x), bias = __builtin_amdgcn_readfirstlane(sr0.y);
-            const int K = __builtin_amdgcn_readfirstlane(sr0.z), N = __builtin_amdgcn_readfirstlane(sr0.w);
-            const int xo = __builtin_amdgcn_readfirstlane(sr1.x), dst = __builtin_amdgcn_readfirstlane(sr1.y);
-            const int act = __builtin_amdgcn_readfirstlane(sr1.z), split = __builtin_amdgcn_readfirstlane(sr1.w);
-            const int post = __builtin_amdgcn_readfirstlane(sr2.x);
-            const int sp0 = __builtin_amdgcn_readfirstlane(sr2.y), sp1 = __builtin_amdgcn_readfirstlane(sr2.z), sp2 = __builtin_amdgcn_readfirstlane(sr2.w);
-            const DecgGeo e = decg_geo_unpack(K, __builtin_amdgcn_readfirstlane(sr3.y), __builtin_amdgcn_readfirstlane(sr3.z), __builtin_amdgcn_readfirstlane(sr3.w));
+            const i32x16s rec = decg_sload16(stab + st * DS_STRIDE);
+            const int w_bytes = rec[DS_W], bias = rec[DS_BIAS], K = rec[DS_K], N = rec[DS_N], xo = rec[DS_X], dst = rec[DS_DST];
+            const int act = rec[DS_ACT], split = rec[DS_SPLIT], post = rec[DS_POST], sp0 = rec[DS_P0], sp1 = rec[DS_P1], sp2 = rec[DS_P2];
+            const DecgGeo e = decg_geo_unpack(K, rec[DS_NCT], rec[DS_NTILE], rec[DS_GEO]);
             const int nchunk = e.nchunk, nmine = e.nmine, ntile = e.ntile;
             TWV_STAMP(4 * st + 0)
             // ---- this workgroup's tiles: wave w takes local tiles w, w+8, ... (three in flight), partials to LDS.  The first three
@@ -2229,6 +2244,7 @@ static long long taco_ws_floats(const twv_tacotron* h, int N, int T)
     f += (long long)N * 4096;           // speaker-dependent vectors
     f += rowsP * 256;                   // post CBHG output
     f += (long long)N * 4096 + 16;      // decoder exchange granules + the local mode's role tickets
+    f += 512 * 256;                     // split decoder: stage tables
     f += 8LL * 2 * kXU * 512 * 2 + 64;  // XCD-local decoder: exchange granules per XCD + role tickets
     return f + 1024;
 }
@@ -2405,6 +2421,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
     float* spk = w; w += (long long)N * 4096;
     float* postout = w; w += (long long)rowsP * 256;
     float* exch = w; w += (long long)N * 2 * kExN * 2 + 16; // decoder exchange granules (8 bytes each) + 8 role tickets
+    float* stabf = w; w += 512 * 256;                       // the split decoder's per-workgroup stage tables (up to 512 workgroups)
     float* xexch = w; w += 8LL * 2 * kXU * 512 * 2 + 64;    // XCD-local decoder: granules [8][2][kXU*512] + tickets
     // ---- tacotron.py:51-60 embedding, :67-82 speaker embedding + deep_dense (softsign)
     hipLaunchKernelGGL(tc_embed_kernel, dim3(tgrid((long long)rows * E)), dim3(256), 0, st, P + h->emb.off, tokens, rows, E, ra);
@@ -2511,6 +2528,8 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             ga.local = (h->dec_local && G > 1 && wgs_local <= cus) ? 1 : 0;
             const int wgs = ga.local ? wgs_local : N * G;
             ga.split_all = h->dec_split_all < 0 ? ga.local : h->dec_split_all;
+            ga.stab = reinterpret_cast<int*>(stabf);
+            if (wgs > 512) return twv_fail(TWV_E_UNSUPPORTED, "more than 512 decoder workgroups");
             HIPCHK(hipMemsetAsync(exch, 0, (size_t)N * 2 * kExN * 8 + 64, st));
             ga.tickets = reinterpret_cast<int*>(exch + (long long)N * 2 * kExN * 2);
             long long fl = 1024 * 2 + (da.D1 + ENC + AS + 63) / 64 * 64 + 512 * 2 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + (M * R + 63) / 64 * 64 + Tp * 4 + A +
