@@ -1150,19 +1150,20 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     const int o_ctx = o; o += ENC;
     const int o_y = o; o += DR;
     const int o_out = o; o += ((M * R + 63) / 64) * 64;
-    const int Tp = ((T + 3) / 4) * 4;
-    const int o_al = o; o += Tp;
-    const int o_p = o; o += Tp;
-    const int o_cp = o; o += Tp;
-    const int o_q = o; o += Tp;
+    // (areas whose size does not depend on the input length first: with the default sizes folded in, their offsets are constants)
     const int o_pq = o; o += A + A / 8;                   // attention tables are skewed by 4 words per 32 (see the score phase)
-    const int o_scp = o; o += Tp * 8;
     const int o_abort = o; o += 4;
     o = (o + 3) & ~3;
     const int o_tab = o; o += 16 * DS_STRIDE;             // stage table (16-byte aligned records)
     const int o_nv = o; o += A + A / 8;                   // normed_v, attention bias
     const int o_ab = o; o += A + A / 8;
     const int o_bias = o; o += DEF ? 256 + 128 + 3 * 256 + 256 + 2 * 3 * 256 + 400 : a.nbias;   // every stage's bias vector, in stage order
+    const int Tp = ((T + 3) / 4) * 4;
+    const int o_al = o; o += Tp;
+    const int o_p = o; o += Tp;
+    const int o_cp = o; o += Tp;
+    const int o_q = o; o += Tp;
+    const int o_scp = o; o += Tp * 8;
     const bool kv = ga.kv_lds != 0;                       // this workgroup's key rows / memory columns held in LDS
     const int nt_all = T > g ? (T - g + G - 1) >> lg : 0;
     const int o_keys = o; o += kv ? ((T + G - 1) >> lg) * (A + A / 8) : 0;
