@@ -584,7 +584,7 @@ def main():
                     return (time.perf_counter() - c0) / reps
                 dec_us = (_mel_only(tm) - _mel_only(tm1)) * 1e6 / (hp.max_iters - 1)
                 # pieces of one step (us, workgroup 0 of utterance 0, 160 steps averaged): everything that is not an exchange, and the hop
-                DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US = 22.37, 13, 0.27
+                DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US = 19.84, 13, 0.27
                 dec_floor = DEC_NONEXCH_US + DEC_EXCHANGES * DEC_HOP_US
                 del tm1
                 # other batch sizes on the same GPU (not the metric's configuration: the decoder is a latency chain, so more utterances
@@ -611,11 +611,11 @@ def main():
                                                 "decoder": {"kernel": "tc_decoder_g_kernel (8 workgroups per utterance on one XCD, 11 matvec stages + attention, 13 all-gathers per step through that XCD's L2)",
                                                             "bound": "latency", "us_per_step": dec_us, "ms_per_pass": dec_us * hp.max_iters * 1e-3,
                                                             "latency_floor_us": dec_floor, "frac_of_floor": dec_floor / dec_us,
-                                                            "formula": "per step: tile dots 5.26 + chunk sums / bias / activation / publish 11.32 (of which ~0.4 per stage is the publish store waiting "
-                                                                       "behind the next stage's first weight tiles in the CU's memory pipeline) + barriers and cell updates 2.68 + "
-                                                                       "attention compute 3.11 (score dots 1.27, monotonic recurrence 0.91, context dots 0.73, the rest 0.19) = %.2f us that is "
+                                                            "formula": "per step: tile dots 5.26 + chunk sums / bias / activation / publish 9.75 (of which ~0.4 per stage is the publish store waiting "
+                                                                       "behind the next stage's first weight tiles in the CU's memory pipeline) + barriers and cell updates 2.00 + "
+                                                                       "attention compute 2.83 (score dots 1.20, monotonic recurrence 0.93, context dots 0.57, the rest 0.12) = %.2f us that is "
                                                                        "not exchange, + %d exchanges x %.2f us (one-way granule hop inside an XCD's L2 measured in isolation; in the kernel an "
-                                                                       "exchange averages 0.69 us incl. the cell update done on arrival: the polls queue behind the next stage's weight tiles); "
+                                                                       "exchange averages 0.71 us incl. the cell update done on arrival: the polls queue behind the next stage's weight tiles); "
                                                                        "profiles/r04_tacotron_decoder_phase_profile.txt (workgroups spread over the XCDs: ..._spread.txt; round 3: 41.4 us)" % (DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US)}},
                                    "config": {"workload": "configs[2]: Tacotron text->mel (CBHG encoder, monotonic Bahdanau attention decoder, post-CBHG, "
                                                           "linear), batch=32, 101 tokens, 200 decoder steps = 1000 mel frames/utterance, random-init weights"},
