@@ -67,24 +67,38 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == stamp_want:
         return LIB_PATH
     hip = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
-    # one hipcc per source file, side by side (the generation kernels alone take a minute), then one link
-    import tempfile
+    # one hipcc per source file, side by side (the generation kernels alone take minutes), then one link.  Objects are cached per
+    # file under _objcache/ (git- and gpurun-ignored), keyed by the file's text + every header + the flags: an edit of one kernel
+    # file recompiles that file only.  The source-hash stamp goes into twv_ckpt.hip alone (it exports twv_version).
     from concurrent.futures import ThreadPoolExecutor
-    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + ['-DTWV_SRC_HASH="%s"' % want] + extra
-    with tempfile.TemporaryDirectory(prefix="twv_build_") as tmp:
-        def compile_one(src):
-            obj = os.path.join(tmp, os.path.basename(src) + ".o")
-            cmd = ["hipcc"] + cflags + ["-c", src, "-o", obj]
+    base_flags = [f for f in HIPCC_FLAGS if f != "-shared"] + extra
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hpp", ".h"))] + [os.path.join(_HERE, "..", "include", "twv_amd.h")]
+    cache = os.path.join(_HERE, "_objcache")
+    os.makedirs(cache, exist_ok=True)
+
+    def compile_one(src):
+        flags = list(base_flags)
+        if os.path.basename(src) == "twv_ckpt.hip":
+            flags.append('-DTWV_SRC_HASH="%s"' % want)
+        import hashlib
+        key = hashlib.sha256((_hash_files([src] + headers) + " ".join(flags)).encode()).hexdigest()[:20]
+        obj = os.path.join(cache, "%s.%s.o" % (os.path.basename(src), key))
+        if force or not os.path.exists(obj):
+            for old in os.listdir(cache):                       # one object per source file is kept
+                if old.startswith(os.path.basename(src) + "."):
+                    os.remove(os.path.join(cache, old))
+            cmd = ["hipcc"] + flags + ["-c", src, "-o", obj + ".tmp.o"]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-            return obj
-        with ThreadPoolExecutor(max_workers=min(len(hip), os.cpu_count() or 1)) as pool:
-            objs = list(pool.map(compile_one, hip))
-        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH, "-L/opt/rocm/lib", "-lrocblas", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+            os.replace(obj + ".tmp.o", obj)
+        return obj
+    with ThreadPoolExecutor(max_workers=min(len(hip), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, hip))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH, "-L/opt/rocm/lib", "-lrocblas", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
     with open(stamp, "w") as fh:
         fh.write(stamp_want + "\n")
     return LIB_PATH

@@ -524,7 +524,8 @@ def bundle_shapes(prefix, verify=None):
 
 def remap_names(wanted, available):
     """wanted: ordered [(variable name, shape)] the graph expects; available: {variable name: shape} of the checkpoint.
-    Returns {wanted name: checkpoint name}.  Tensors are grouped by (scope path without auto-suffixes, shape).  A group whose
+    Returns {wanted name: checkpoint name}.  Tensors are grouped by (scope path without auto-suffixes, shape).  Only groups with as
+    many members in the checkpoint as in the graph are matched at all.  A group whose
     wanted names ALL exist in the checkpoint with the right shape is taken by name; otherwise the whole group is matched in
     creation order (ascending auto-suffix) -- a shifted numbering makes SOME names collide with their neighbours' ("dense_2" of
     the checkpoint is the graph's "dense_1"), so partial exact matches inside a group would silently load the wrong tensors --
@@ -538,12 +539,16 @@ def remap_names(wanted, available):
         st, idx = _stem(name)
         groups_a.setdefault((st, tuple(shape)), []).append((idx, name))
     for key, ws in groups_w.items():
+        cand = groups_a.get(key, [])
+        if len(cand) != len(ws):
+            # the checkpoint holds more (or fewer) variables of this scope path and shape than the graph wants: even if every wanted
+            # NAME exists, one extra auto-numbered layer created first shifts the numbering ("dense" of the checkpoint is then the
+            # extra layer, "dense_1" the graph's "dense") and an exact-name match would load the wrong tensors without a word --
+            # the group stays unmatched and the caller reports it
+            continue
         if all(n in available and tuple(available[n]) == key[1] for _, n in ws):
             for _, n in ws:
                 out[n] = n
-            continue
-        cand = groups_a.get(key, [])
-        if len(cand) != len(ws):
             continue
         for (_, wn), (_, an) in zip(sorted(ws), sorted(cand)):
             out[wn] = an

@@ -37,3 +37,11 @@ extern "C" uint32_t twv_crc32c(const void* data, size_t n, uint32_t crc) {
     while (n--) c = g_crc.t[0][(c ^ *p++) & 0xffu] ^ (c >> 8);
     return ~c;
 }
+
+// the build stamps the binary with the hash of ALL its sources (_lib.source_hash): tests assert that the library they loaded IS the
+// tree.  This small host-only file is the only one compiled with the stamp (-DTWV_SRC_HASH), so the kernel files' objects can be
+// cached per file (_lib.build).
+#ifndef TWV_SRC_HASH
+#define TWV_SRC_HASH "unstamped"
+#endif
+extern "C" const char* twv_version(void) { return "twv_amd 0.2 (gfx950) src:" TWV_SRC_HASH; }

@@ -1313,11 +1313,8 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
     } while (0)
 
 extern "C" const char* twv_last_error(void) { return g_err.c_str(); }
-#ifndef TWV_SRC_HASH
-#define TWV_SRC_HASH "unstamped"
-#endif
-// the build stamps the binary with the hash of its sources (_lib.source_hash): tests assert that the library they loaded IS the tree
-extern "C" const char* twv_version(void) { return "twv_amd 0.2 (gfx950) src:" TWV_SRC_HASH; }
+// (twv_version lives in twv_ckpt.hip: the one file that is compiled with the source-hash stamp, so that an edit of one kernel file
+// recompiles that file only)
 
 static inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
 

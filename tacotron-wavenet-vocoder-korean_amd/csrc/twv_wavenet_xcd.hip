@@ -393,6 +393,13 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
             XMARK(SEG1 ? 30 : ROLE_CHAIN, 3);
         }
         // ---- the wave's layers (the loop is compiled once per layer count: a run-time count costs a branch pair per layer)
+        // DEFER (round 5): the granule store of a layer costs the wave ~40 issue cycles (tuple assembly, the 1 KB of store data, the
+        // hazard wait: profiles/r05_chain_contract_ubench.txt, shape P against N) and nobody needs z / the layer input of an EARLY wave
+        // at once -- the skip workgroups' sum only completes with the LAST layer, the service workgroup works a step ahead -- so the
+        // waves that never carry the head (the four-layer instantiation: waves 0..5) keep {z, input} in registers and store all four
+        // granules behind the hand-off to the next wave, off the sample-to-sample path.  Waves 6 / 7 (the stack's last layers) store at once.
+        constexpr bool DEFER = ALL && !FORCED && !SEG1 && NC == 4;
+        float zs[4] = {0.0f, 0.0f, 0.0f, 0.0f}, xs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         auto run_layers = [&](auto nc) {
             constexpr int N = decltype(nc)::value;
 #pragma unroll
@@ -406,7 +413,8 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                 const float z = layer_front_dpp<ALL>(W[i].wc, W[i].bfg, W[i].gcv, coef, X, pre[i], lcv[i], use_bias, has_gc, has_lc);
                 // one 16-byte store, two self-tagged halves: {z, tag} -> skip workgroups, {layer input, tag} -> service workgroup
                 // (model.py:145: the queue takes the layer INPUT)
-                xb_store2(rs, (int)XcdExch::ZX + (l0 + i) * 128, lane, tag, z, X);
+                if (DEFER) { zs[i] = z; xs[i] = X; }
+                else xb_store2(rs, (int)XcdExch::ZX + (l0 + i) * 128, lane, tag, z, X);
                 layer_back_dpp<ALL>(wd, W[i].bd, z, X, use_bias);
                 if ((INSTR & 2) && a.dbg != nullptr && t < a.dbg_steps) {
                     float* dp = a.dbg + ((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)(l0 + i) * 64;
@@ -424,6 +432,10 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
         }
         if (to_seg1) xb_store(rs, (int)XcdExch::SEG, lane, tag, X);
         else if (nlc > 0) LDSU64((next_has ? w + 1 : 9) * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(X);   // nobody reads box 9: no branch on the hand-off
+        if (DEFER) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xb_store2(rs, (int)XcdExch::ZX + (l0 + i) * 128, lane, tag, zs[i], xs[i]);
+        }
         // teacher-forced steps (twv_wavenet_prime): nothing makes the head wait for the stack (there is no sample to wait for), so
         // the wave that runs the last layer reports the end of the step in box 8 and the head starts the next one after that
         if (forced && nl > 0 && !next_has) {

@@ -315,6 +315,24 @@ def test_restore_tolerates_shifted_auto_generated_names(tmp_path, capsys):
         ck.restore_variables(str(tmp_path / "model.ckpt-5"), ck.tacotron_variable_specs(specs1))
 
 
+def test_restore_refuses_an_exact_name_inside_a_shifted_group(tmp_path):
+    """the checkpoint's graph created ONE MORE unnamed dense layer of the same shape first, so its `dense` is that extra
+    layer and its `dense_1` is the graph's `dense`.  The wanted name exists, with the right shape -- and holds the WRONG tensor: a
+    group is only matched when the checkpoint has as many members of that (scope path, shape) as the graph, so this is refused."""
+    from twvk_amd.hparams import hparams as hp
+    from twvk_amd.tacotron import tacotron_specs
+    specs1 = tacotron_specs(hp, 1)
+    rng = np.random.RandomState(3)
+    t1 = {n: rng.randn(*s).astype(np.float32) for n, s in specs1}
+    v = dict(ck.tacotron_variables(t1))
+    lin_k, lin_b = v.pop("model/inference/dense/kernel"), v.pop("model/inference/dense/bias")
+    v["model/inference/dense/kernel"], v["model/inference/dense/bias"] = lin_k * 0 + 7, lin_b * 0 + 7     # the extra layer
+    v["model/inference/dense_1/kernel"], v["model/inference/dense_1/bias"] = lin_k, lin_b              # the graph's `dense`
+    ck.write_bundle(str(tmp_path / "model.ckpt-1"), v)
+    with pytest.raises(ck.CheckpointError, match="lacks 2 tensors"):
+        ck.restore_variables(str(tmp_path / "model.ckpt-1"), ck.tacotron_variable_specs(specs1))
+
+
 def test_wavenet_restore_tolerates_shifted_conv1d_names(tmp_path):
     """generate.py:157-161: wavenet/conv1d (causal), conv1d_1, conv1d_2 (post-processing) are auto-numbered tf.layers.conv1d layers"""
     from twvk_amd import weights as W
