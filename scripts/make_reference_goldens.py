@@ -21,6 +21,11 @@ What is pinned, with the same seeds / inputs as tests/golden/make_restatement.py
   reference_tacotron_small.npz   Tacotron.initialize(..., rnn_decoder_test_mode=True) (tacotron.py:36-235): mel, linear, alignments
   reference_variable_names.json  the variable names TensorFlow actually gave each graph (closes the [RECALLED-TF] auto-naming
                                  question of checkpoint.py / weights.py)
+  reference_ckpt_wavenet/        a REAL tf.train.Saver bundle (model.ckpt-7.index / .data-00000-of-00001 + the `checkpoint` state file)
+  reference_ckpt_tacotron/       of a small WaveNet generation graph and of a small (1/8-width) two-speaker Tacotron graph, next to
+                                 values.npz = the same variables read back through TensorFlow itself: what checkpoint.read_bundle /
+                                 restore_variables (generate.py:157-161, synthesizer.py:69-70 Saver.restore) are held to bit for bit
+                                 -- the importer has only ever read files it wrote itself
 """
 import argparse
 import json
@@ -201,11 +206,65 @@ def tacotron(tf, ref, out, report):
                             **{"dims_" + k: v for k, v in kw.items()})
 
 
+def _save_bundle(tf, sess, out_dir, step, dims):
+    """tf.train.Saver over every non-queue global variable (what generate.py:157-161 / synthesizer.py:69-70 restore) + the values
+    TensorFlow itself reads back, as data"""
+    os.makedirs(out_dir, exist_ok=True)
+    gvars = [v for v in tf.global_variables() if "queue" not in v.name]
+    saver = tf.train.Saver(var_list=gvars, max_to_keep=3)
+    prefix = saver.save(sess, os.path.join(out_dir, "model.ckpt"), global_step=step, write_meta_graph=False)
+    names = [v.name.split(":")[0] for v in gvars]
+    vals = sess.run(gvars)
+    np.savez_compressed(os.path.join(out_dir, "values.npz"), **{"t%d" % i: np.asarray(a) for i, a in enumerate(vals)})
+    with open(os.path.join(out_dir, "values.json"), "w") as fh:
+        json.dump({"prefix": os.path.basename(prefix), "names": names, "dtypes": [str(np.asarray(a).dtype) for a in vals],
+                   "shapes": [list(np.shape(a)) for a in vals], "dims": dims, "tensorflow": tf.__version__}, fh, indent=1)
+    return prefix
+
+
+def saver_bundles(tf, ref, out, report):
+    from wavenet import WaveNetModel
+    # ---- WaveNet: the generation graph of generate.py:117-147 (small), random initial values under a fixed graph seed
+    dil = [1, 2, 4, 8, 1, 2, 4, 8]
+    wdims = dict(dilations=dil, residual_channels=32, dilation_channels=32, skip_channels=128, quantization_channels=256, out_channels=30,
+                 scalar_input=True, initial_filter_width=32, gc_channels=32, gc_cardinality=2, lc_channels=80, upsample_factor=[5, 5, 12])
+    with tf.Graph().as_default(), tf.Session() as sess:
+        tf.set_random_seed(51)
+        net = WaveNetModel(batch_size=2, dilations=dil, filter_width=2, residual_channels=32, dilation_channels=32, skip_channels=128,
+                           quantization_channels=256, out_channels=30, use_biases=True, scalar_input=True, initial_filter_width=32,
+                           global_condition_channels=32, global_condition_cardinality=2, local_condition_channels=80,
+                           upsample_factor=[5, 5, 12], train_mode=False)
+        samples = tf.placeholder(tf.float32, [2, None]); lc = tf.placeholder(tf.float32, [2, 80])
+        net.predict_proba_incremental(samples, lc, [0, 1])                               # generate.py:147
+        with tf.variable_scope("wavenet", reuse=tf.AUTO_REUSE):
+            net.create_upsample(tf.zeros([2, 1, 80]))                                    # generate.py:153-155
+        tf.train.get_or_create_global_step()                                             # an int64 scalar, as train_vocoder.py's bundles carry
+        sess.run(tf.global_variables_initializer())
+        _save_bundle(tf, sess, os.path.join(out, "reference_ckpt_wavenet"), 7, wdims)
+    # ---- Tacotron: synthesizer.py:52-56 with every width at 1/8 (a default-width bundle is ~28 MB: not a fixture)
+    from hparams import hparams as hp
+    from tacotron import create_model
+    from text.symbols import symbols
+    tdims = dict(embedding_size=32, enc_prenet_sizes=[32, 16], enc_bank_size=4, enc_bank_channel_size=16, enc_proj_sizes=[16, 16],
+                 enc_rnn_size=16, attention_size=32, attention_state_size=32, dec_rnn_size=32, dec_prenet_sizes=[32, 16],
+                 post_bank_size=3, post_bank_channel_size=16, post_proj_sizes=[32, 80], post_rnn_size=16, num_freq=129, max_iters=4)
+    for k, v in tdims.items():
+        setattr(hp, k, v)
+    with tf.Graph().as_default(), tf.Session() as sess:
+        tf.set_random_seed(52)
+        inputs = tf.placeholder(tf.int32, [None, None]); ilen = tf.placeholder(tf.int32, [None]); sid = tf.placeholder(tf.int32, [None])
+        with tf.variable_scope("model"):
+            model = create_model(hp)
+            model.initialize(inputs, ilen, 2, sid, rnn_decoder_test_mode=True)
+        sess.run(tf.global_variables_initializer())
+        _save_bundle(tf, sess, os.path.join(out, "reference_ckpt_tacotron"), 3, dict(tdims, n_symbols=len(symbols), num_speakers=2))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference", help="checkout of hccho2/Tacotron-Wavenet-Vocoder-Korean")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
-    ap.add_argument("--only", default="", help="comma list of: codec,mol,mulaw,tacotron")
+    ap.add_argument("--only", default="", help="comma list of: codec,mol,mulaw,tacotron,ckpt")
     args = ap.parse_args()
     try:
         import tensorflow as tf
@@ -225,6 +284,8 @@ def main():
         wavenet_mulaw(tf, args.reference, args.out, report)
     if not only or "tacotron" in only:
         tacotron(tf, args.reference, args.out, report)
+    if not only or "ckpt" in only:
+        saver_bundles(tf, args.reference, args.out, report)      # last: it edits the reference's hparams singleton
     with open(os.path.join(args.out, "reference_variable_names.json"), "w") as fh:
         json.dump(report, fh, indent=1, sort_keys=True)
     print("wrote reference_*.npz to", args.out)

@@ -23,8 +23,10 @@
 #include "twv_dev.hpp"
 #include "twv_dpp.hpp"
 
-static int g_gemm_valu = 0;            // "gemm_valu" option: 1 = the VALU kernel (cross-check of the MFMA one)
-static int g_gemm_group = 1;           // "gemm_group" option: 0 = one launch per GEMM, separate highway kernels (A/B runs, cross-check)
+// the GEMM options of the pass in flight on this thread: copied from the HANDLE at the top of twv_tacotron_infer (they are per-handle
+// options -- one model's A/B toggle must not change another model's launches in the same process)
+static thread_local int g_gemm_valu = 0;            // "gemm_valu" option: 1 = the VALU kernel (cross-check of the MFMA one)
+static thread_local int g_gemm_group = 1;           // "gemm_group" option: 0 = one launch per GEMM, separate highway kernels (A/B runs, cross-check)
 // "gemm_timing" option (measurement aid, bench.py's `tacotron.roofline`): every GEMM launch is bracketed by a pair of HIP events on
 // its stream and its useful FLOPs (2 * rows * K * N, unpadded) are counted; twv_tacotron_gemm_stats sums both since the option was set.
 // PROCESS-WIDE and single-threaded by design (one bench process, one model): the option set through any handle counts the launches of
@@ -1996,6 +1998,7 @@ struct twv_tacotron {
     int dec_groups = 0;             // 0 auto (16, halved until N*G fits the CUs), -1 single-workgroup kernel
     int dec_split_all = -1;         // prenet + query layer split over the workgroups: -1 = when the exchanges are L2-local, 0 / 1
     int dec_local = 1;              // split kernel: 1 = an utterance's workgroups on one XCD (exchanges through its L2), 0 = spread over the XCDs
+    int gemm_valu = 0, gemm_group = 1;   // see g_gemm_valu / g_gemm_group
     long long blob_floats, packed_floats;
     long long xt_off = 0;           // row tiles of the XCD-local decoder kernel [32 slices][8 waves][kXSlots][2048]
     TMat emb, semb;                 // raw tables (K rows x N)
@@ -2114,8 +2117,8 @@ extern "C" size_t twv_tacotron_blob_floats(const twv_tacotron* h) { return (size
 extern "C" int twv_tacotron_set_option(twv_tacotron* h, const char* name, int value)
 {
     if (!h || !name) return twv_fail(TWV_E_INVALID, "null argument");
-    if (!strcmp(name, "gemm_valu")) { g_gemm_valu = value ? 1 : 0; return TWV_OK; }
-    if (!strcmp(name, "gemm_group")) { g_gemm_group = value ? 1 : 0; return TWV_OK; }   // 0: one launch per GEMM, separate highway kernels (A/B runs, cross-check)
+    if (!strcmp(name, "gemm_valu")) { h->gemm_valu = value ? 1 : 0; return TWV_OK; }
+    if (!strcmp(name, "gemm_group")) { h->gemm_group = value ? 1 : 0; return TWV_OK; }   // 0: one launch per GEMM, separate highway kernels (A/B runs, cross-check)
     if (!strcmp(name, "gemm_timing")) {   // 1: start counting (resets the sums), 0: stop
         g_gemm_stat.on = value != 0;
         g_gemm_stat.flop = 0.0; g_gemm_stat.launches = 0; g_gemm_stat.used = 0;
@@ -2397,6 +2400,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
     if (!h || !packed || !tokens || !lengths || !workspace || !mel || !status) return twv_fail(TWV_E_INVALID, "null argument");
     if (!speaker_ids && h->d.num_speakers > 1) return twv_fail(TWV_E_INVALID, "speaker_ids is required for a multi-speaker model");
     if (batch < 1 || t_in < 1 || t_in > 1024) return twv_fail(TWV_E_INVALID, "batch >= 1 and 1 <= t_in <= 1024 required");
+    g_gemm_valu = h->gemm_valu; g_gemm_group = h->gemm_group;
     const twv_tacotron_dims& d = h->d;
     hipStream_t st = (hipStream_t)stream;
     const float* P = (const float*)packed;
@@ -2526,7 +2530,11 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             DecGArgs ga;
             ga.d = da; ga.G = G; ga.exch = reinterpret_cast<unsigned long long*>(exch);
             const int wgs_local = 8 * G * ((N + 7) / 8);
-            ga.local = (h->dec_local && G > 1 && wgs_local <= cus) ? 1 : 0;
+            // 'local' maps workgroup -> (utterance, slice) by per-XCD tickets and assumes EIGHT XCDs that each receive G * ceil(N / 8)
+            // of the launch's workgroups: true of the 256-CU part in SPX mode (the same guard as the WaveNet XCD kernels, use_xcd).  On a
+            // part / partition with fewer XCDs or CUs (6-XCD devices, CPX) utterances whose n % 8 names a missing XCD would get no
+            // workgroup at all and their outputs would stay unwritten -- there the spread mapping is used.
+            ga.local = (h->dec_local && G > 1 && wgs_local <= cus && cus >= 256) ? 1 : 0;
             const int wgs = ga.local ? wgs_local : N * G;
             ga.split_all = h->dec_split_all < 0 ? ga.local : h->dec_split_all;
             ga.stab = reinterpret_cast<int*>(stabf);

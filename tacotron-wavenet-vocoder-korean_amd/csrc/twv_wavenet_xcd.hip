@@ -195,7 +195,9 @@ constexpr int kConvLdsFloats = 16 * 64 + 64; // LDS floats per stream in a conv1
 // ONEHOT (scalar_input False, the mu-law-256 model of generate.py:219-231): the head wave feeds the causal layer with two kernel ROWS
 // (model.py:41-46 over one-hot input: every AC-1 chunk holds at most one non-zero term, so the k = 2 conv is W0[q(t-1)] + W1[q(t)];
 // only the W1 row waits for the sample) and draws the next class with twv_categorical.hpp from the 256 logits the conv1 workgroups publish.
-template <int INSTR, bool ALL, bool FORCED, bool SEG1, bool TWOSEG, int NC, bool ONEHOT = false>
+// HW: 1 = this wave is the head (wave 7 of the first chain workgroup), 0 = it is not, -1 = decided at run time.  Known at compile time
+// the instantiations of waves 0..6 carry none of the head's code (causal layer, sampler) and may defer their granule stores (DEFER).
+template <int INSTR, bool ALL, bool FORCED, bool SEG1, bool TWOSEG, int NC, bool ONEHOT = false, int HW = -1>
 __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
 {
     const XcdLaunch& a = xa.p;
@@ -216,7 +218,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
     // on the count (three compare-and-branch pairs on the wave-to-wave hand-off path)
     const int nlc = NC >= 0 ? NC : nl;
     const bool next_has = (l0 + nl < NL);                      // a later wave continues the stack
-    const bool head = !SEG1 && (w == 7);                       // sampler + causal layer
+    const bool head = HW >= 0 ? (HW == 1) : (!SEG1 && (w == 7));      // sampler + causal layer
     const bool to_seg1 = TWOSEG && !SEG1 && w == 7 && next_has;     // the stack goes on in the second chain workgroup
     constexpr bool two_seg = TWOSEG;
     if (nl == 0 && !head) return;
@@ -396,9 +398,9 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
         // DEFER (round 5): the granule store of a layer costs the wave ~40 issue cycles (tuple assembly, the 1 KB of store data, the
         // hazard wait: profiles/r05_chain_contract_ubench.txt, shape P against N) and nobody needs z / the layer input of an EARLY wave
         // at once -- the skip workgroups' sum only completes with the LAST layer, the service workgroup works a step ahead -- so the
-        // waves that never carry the head (the four-layer instantiation: waves 0..5) keep {z, input} in registers and store all four
-        // granules behind the hand-off to the next wave, off the sample-to-sample path.  Waves 6 / 7 (the stack's last layers) store at once.
-        constexpr bool DEFER = ALL && !FORCED && !SEG1 && NC == 4;
+        // waves that are not the head (HW == 0: waves 0..6) keep {z, input} in registers and store their granules behind the hand-off
+        // to the next wave, off the sample-to-sample path.  The head wave (the stack's last layers) stores at once.
+        constexpr bool DEFER = ALL && !FORCED && !SEG1 && NC > 0 && HW == 0;
         float zs[4] = {0.0f, 0.0f, 0.0f, 0.0f}, xs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         auto run_layers = [&](auto nc) {
             constexpr int N = decltype(nc)::value;
@@ -434,7 +436,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
         else if (nlc > 0) LDSU64((next_has ? w + 1 : 9) * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(X);   // nobody reads box 9: no branch on the hand-off
         if (DEFER) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xb_store2(rs, (int)XcdExch::ZX + (l0 + i) * 128, lane, tag, zs[i], xs[i]);
+            for (int i = 0; i < (NC > 0 ? NC : 0); ++i) xb_store2(rs, (int)XcdExch::ZX + (l0 + i) * 128, lane, tag, zs[i], xs[i]);
         }
         // teacher-forced steps (twv_wavenet_prime): nothing makes the head wait for the stack (there is no sample to wait for), so
         // the wave that runs the last layer reports the end of the step in box 8 and the head starts the next one after that
@@ -1430,8 +1432,9 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
                 const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
                 const int nlw = a.lay.NL - (wv < 6 ? 4 * wv : 24 + 3 * (wv - 6));
                 if (forced) chain_role<INSTR, false, true, false, BIGK, -1, ONEHOT>(xa, b, rs);
-                else if (all && nlw >= 4 && wv < 6) chain_role<INSTR, true, false, false, BIGK, 4, ONEHOT>(xa, b, rs);
-                else if (all && nlw >= 3 && wv >= 6) chain_role<INSTR, true, false, false, BIGK, 3, ONEHOT>(xa, b, rs);
+                else if (all && nlw >= 4 && wv < 6) chain_role<INSTR, true, false, false, BIGK, 4, ONEHOT, 0>(xa, b, rs);
+                else if (all && nlw >= 3 && wv == 6) chain_role<INSTR, true, false, false, BIGK, 3, ONEHOT, 0>(xa, b, rs);
+                else if (all && nlw >= 3 && wv == 7) chain_role<INSTR, true, false, false, BIGK, 3, ONEHOT, 1>(xa, b, rs);
                 else if (all) chain_role<INSTR, true, false, false, BIGK, -1, ONEHOT>(xa, b, rs);
                 else chain_role<INSTR, false, false, false, BIGK, -1, ONEHOT>(xa, b, rs);
             } else if constexpr (BIGK) {

@@ -213,16 +213,26 @@ class WaveNetTrainer(object):
     def step(self, audio, local_condition, gc_ids, failed=False):
         """one sess.run([net.loss, net.optimize]) (train_vocoder.py:163); returns the (local) loss as a device tensor.
         failed=True: this rank has no batch (its feeder raised): it still joins the gradient all-reduce -- with zero gradients and the
-        failure flag set -- so that no rank is left waiting, and applies nothing; every rank sees `peer_failure()` afterwards."""
+        failure flag set -- so that no rank is left waiting, and applies nothing; every rank sees `peer_failure()` afterwards.
+        A rank whose loss / gradient computation raises joins the all-reduce the same way before re-raising, and NO rank applies a step
+        whose reduced gradient contains a failed rank's zeros: with more than one rank the flag is read (one host sync per step)
+        before Adam / EMA / global_step move, so a caller that never polls peer_failure() cannot train on a corrupted step."""
+        err = None
         if failed:
-            self._gbuf.zero_()
-            self._flag.fill_(1.0)
             loss = self.loss
         else:
             self._flag.zero_()
-            loss = self.loss_and_gradients(audio, local_condition, gc_ids)
+            try:
+                loss = self.loss_and_gradients(audio, local_condition, gc_ids)
+            except Exception as e:                     # noqa: BLE001 -- re-raised below, after the peers have been released
+                err, failed, loss = e, True, self.loss
+        if failed:
+            self._gbuf.zero_()
+            self._flag.fill_(1.0)
         world = allreduce_sum_(self._gbuf, self.group)
-        if not failed:
+        if err is not None:
+            raise err
+        if not failed and (world == 1 or not self.peer_failure()):
             self.apply_gradients(world)
         return loss
 

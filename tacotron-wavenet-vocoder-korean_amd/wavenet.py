@@ -4,6 +4,7 @@ Same constructor arguments, `receptive_field`, `create_upsample`, `predict_proba
 `queue_initializer`; plus `generate`, the generate.py:199-233 sample loop as ONE persistent kernel launch.
 PyTorch is used for device memory and streams only.  No fallback: without the HIP library this raises."""
 import ctypes as C
+import time
 
 import numpy as np
 import torch
@@ -289,12 +290,12 @@ class WaveNetModel(object):
                 u = torch.as_tensor(uniforms, dtype=torch.float32, device=self.device).contiguous()
                 T = u.shape[1]
                 fi = torch.as_tensor(np.asarray(first_input, dtype=np.float32).reshape(B), device=self.device)
-                out = torch.empty((B, T), dtype=torch.float32, device=self.device)
+                out = torch.zeros((B, T), dtype=torch.float32, device=self.device)      # zeros: with check=False a launch that found the device busy writes nothing
             else:
                 u = torch.as_tensor(uniforms, dtype=torch.float64, device=self.device).contiguous()
                 T = u.shape[1]
                 fi = torch.as_tensor(np.asarray(first_input, dtype=np.int32).reshape(B), device=self.device)
-                out = torch.empty((B, T), dtype=torch.int32, device=self.device)
+                out = torch.zeros((B, T), dtype=torch.int32, device=self.device)
             cond = self._condition(upsampled_local_condition, global_condition, T)
             dbg = None
             if debug_steps:
@@ -310,7 +311,6 @@ class WaveNetModel(object):
                     break
                 rc = self._L.twv_wavenet_status(_ptr(self._status), _stream())
                 if rc == _lib.TWV_E_BUSY and attempt < self.BUSY_RETRIES:
-                    import time
                     time.sleep(0.05 * (attempt + 1))
                     continue
                 _lib.check(rc)

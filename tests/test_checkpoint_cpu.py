@@ -352,3 +352,46 @@ def test_wavenet_restore_tolerates_shifted_conv1d_names(tmp_path):
     for n, _ in specs:
         assert np.array_equal(got[n], tensors[n]), n
     assert any("wavenet/conv1d/kernel  <-  wavenet/conv1d_2/kernel" in m for m in notes)
+
+
+@pytest.mark.parametrize("kind", ["wavenet", "tacotron"])
+def test_the_saver_bundle_test_runs_on_a_bundle_of_the_same_layout(tmp_path, monkeypatch, kind):
+    """tests/test_reference_goldens.py::test_reference_saver_bundle_reads_back_bit_for_bit cannot run here (it needs a bundle written by
+    TensorFlow: scripts/make_reference_goldens.py --only ckpt).  So that it does not rot unexecuted, the same test function is driven
+    here over a directory of the same layout written by THIS repo's writer with the names this repo expects: it proves the test's own
+    logic, not the importer's fidelity to TensorFlow."""
+    import json
+    import twvk_amd
+    import test_reference_goldens as T
+    rng = np.random.RandomState(5)
+    if kind == "wavenet":
+        from twvk_amd import weights as W
+        dims = dict(dilations=[1, 2, 4, 8, 1, 2, 4, 8], residual_channels=32, dilation_channels=32, skip_channels=128, quantization_channels=256,
+                    out_channels=30, scalar_input=True, initial_filter_width=32, gc_channels=32, gc_cardinality=2, lc_channels=80, upsample_factor=[5, 5, 12])
+        specs = W.tensor_specs(8, S=128)
+        variables = {n: rng.randn(*s).astype(np.float32) for n, s in specs}
+        step = 7
+    else:
+        from twvk_amd.tacotron import tacotron_specs
+        dims = dict(embedding_size=32, enc_prenet_sizes=[32, 16], enc_bank_size=4, enc_bank_channel_size=16, enc_proj_sizes=[16, 16],
+                    enc_rnn_size=16, attention_size=32, attention_state_size=32, dec_rnn_size=32, dec_prenet_sizes=[32, 16],
+                    post_bank_size=3, post_bank_channel_size=16, post_proj_sizes=[32, 80], post_rnn_size=16, num_freq=129, max_iters=4,
+                    n_symbols=80, num_speakers=2)
+        hp = twvk_amd.default_hparams()
+        for k, v in dims.items():
+            if hasattr(hp, k):
+                setattr(hp, k, v)
+        specs = tacotron_specs(hp, 2)
+        variables = ck.tacotron_variables({n: rng.randn(*s).astype(np.float32) for n, s in specs})
+        step = 3
+    variables["global_step"] = np.array(step, np.int64)
+    d = tmp_path / ("reference_ckpt_" + kind)
+    d.mkdir()
+    prefix = str(d / ("model.ckpt-%d" % step))
+    ck.write_bundle(prefix, variables)
+    ck.write_checkpoint_state(str(d), prefix)
+    names = sorted(variables)
+    np.savez_compressed(str(d / "values.npz"), **{"t%d" % i: variables[n] for i, n in enumerate(names)})
+    json.dump({"prefix": os.path.basename(prefix), "names": names, "dims": dims}, open(str(d / "values.json"), "w"))
+    monkeypatch.setattr(T, "GOLD", str(tmp_path))
+    T.test_reference_saver_bundle_reads_back_bit_for_bit(kind)

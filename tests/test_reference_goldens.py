@@ -77,3 +77,52 @@ def test_reference_variable_names():
     rep = json.load(open(path))
     renamed = {k: v["renamed"] for k, v in rep.items() if isinstance(v, dict) and v.get("renamed")}
     assert not renamed, "TensorFlow names differ from the recalled ones: %r" % renamed
+
+
+@pytest.mark.parametrize("kind", ["wavenet", "tacotron"])
+def test_reference_saver_bundle_reads_back_bit_for_bit(kind):
+    """a bundle written by tf.train.Saver ITSELF (scripts/make_reference_goldens.py, `ckpt`) through
+    checkpoint.read_bundle (CRC-32C verified) == the values TensorFlow read back from its own variables, every tensor, every dtype;
+    and generate.py:157-161 / synthesizer.py:69-70's restore -- the names weights.py / tacotron.py expect -- finds every tensor
+    (by name or through remap_names) and returns the same bits."""
+    import sys
+    d = os.path.join(GOLD, "reference_ckpt_" + kind)
+    if not os.path.exists(os.path.join(d, "values.json")):
+        pytest.skip("tests/golden/reference_ckpt_%s is absent: run scripts/make_reference_goldens.py --only ckpt where TensorFlow 1.x and the reference exist" % kind)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import twvk_amd                                     # noqa: F401
+    from twvk_amd import checkpoint as ck
+    meta = json.load(open(os.path.join(d, "values.json")))
+    vals = np.load(os.path.join(d, "values.npz"))
+    truth = {n: vals["t%d" % i] for i, n in enumerate(meta["names"])}
+    prefix = os.path.join(d, meta["prefix"])
+    assert ck.latest_checkpoint(d) is not None and os.path.basename(ck.latest_checkpoint(d)) == meta["prefix"]     # the `checkpoint` state file
+    got = ck.read_bundle(prefix, verify=True)
+    assert sorted(got) == sorted(truth)
+    for n, a in truth.items():
+        assert got[n].dtype == a.dtype and got[n].shape == a.shape and got[n].tobytes() == np.ascontiguousarray(a).tobytes(), n
+    shapes = ck.bundle_shapes(prefix)
+    assert shapes == {n: tuple(a.shape) for n, a in truth.items() if a.dtype == np.float32 or n in shapes}
+    dims = meta["dims"]
+    if kind == "wavenet":
+        from twvk_amd import weights as W
+        wanted = W.tensor_specs(len(dims["dilations"]), R=dims["residual_channels"], D=dims["dilation_channels"], S=dims["skip_channels"],
+                                Q=dims["quantization_channels"], out_channels=dims["out_channels"], scalar_input=dims["scalar_input"],
+                                initial_filter_width=dims["initial_filter_width"], gc_channels=dims["gc_channels"],
+                                gc_cardinality=dims["gc_cardinality"], lc_channels=dims["lc_channels"], upsample_factor=tuple(dims["upsample_factor"]))
+    else:
+        from twvk_amd.tacotron import tacotron_specs
+        hp = twvk_amd.default_hparams()
+        for k, v in dims.items():
+            if hasattr(hp, k):
+                setattr(hp, k, v)
+        wanted = ck.tacotron_variable_specs(tacotron_specs(hp, dims["num_speakers"], n_symbols=dims["n_symbols"]))
+    notes = []
+    restored = ck.restore_variables(prefix, wanted, verify=True, log=notes.append)
+    mapping = ck.remap_names([(n, tuple(s)) for n, s in wanted], shapes)
+    assert sorted(restored) == sorted(n for n, _ in wanted)
+    for n, _ in wanted:
+        assert np.array_equal(restored[n], truth[mapping[n]]), (n, mapping[n])
+    # nothing of the model is left over in the bundle (only the global step may be)
+    left = sorted(set(truth) - set(mapping.values()) - {"global_step"})
+    assert not left, "variables of the reference graph this repo does not know: %s" % left
