@@ -298,8 +298,18 @@ def main():
         kernel = ("wn_xcd_many_kernel" if B > 32 else "wn_xcd_generate_kernel") if fused else "wn_generate_kernel"
         us_step = k_ms * 1e3 / T
         # what binds this kernel is the sample-to-sample dependency chain, not HBM: the floor of that chain from the micro-benchmarks
-        # (scripts/ubench/xcd_chain_ubench.hip -> profiles/r02_xcd_chain_ubench*.txt, profiles/r02_xcd_phase_profile_v6.txt)
-        floor_us = NL * 0.200 + 8 * 0.075 + 0.15 + (3 * 0.26 + 1.08)
+        # (scripts/ubench/chain_contract_ubench.hip -> profiles/r05_chain_contract_ubench.txt: contract C0, shape R = 460 core clocks =
+        # 0.192 us per layer; hand-offs / post phase: scripts/xcd_phase_profile.py -> profiles/r05_xcd_phase_profile_v1.txt)
+        LAYER_US, HANDOFF_US, CAUSAL_US, POST_US = 0.192, 0.075, 0.15, 3 * 0.26 + 1.08
+        floor_us = NL * LAYER_US + 8 * HANDOFF_US + CAUSAL_US + POST_US
+        # BASELINE.json north_star: >= 100x real time at batch 8 = 2.4 M samples/s = one generation step every 3.33 us.  Round 5 priced the
+        # alternatives (profiles/r05_chain_contract_ubench.txt): the chain wave is ISSUE-bound (a layer is ~117 instructions at ~4.5 core
+        # clocks each on a lone wave; 48 of them are the fmas of the two dot products, which no arithmetic contract removes), so the
+        # cheapest bit-reproducible contract measured (C5: conditioning addend and dense bias as chain start values, Estrin rational with a
+        # software reciprocal; shape M: no store on the path, dense kernel in registers) is 454 clocks = 0.189 us per layer -- 19 % below
+        # the product's 562, and 30 x 0.189 alone is 5.7 us.
+        target_us = 1e6 / (100.0 * hp.sample_rate / B)
+        best_contract_floor_us = NL * 0.189 + 8 * HANDOFF_US + CAUSAL_US + POST_US
         macs_stream = NL * (2 * 32 * 64 + 32 * 32 + 32 * 512 + 80 * 64) + 32 * 32 + 512 * 512 + 512 * 30   # executed per stream and step (gc hoisted)
         flop_step = 2.0 * macs_stream * B
         tps = traffic_per_step(kernel, "B%d_NL%d" % (B, NL))
@@ -313,6 +323,13 @@ def main():
                                    "injected uniforms" % (B, T / hp.sample_rate, T),
                        "batch_per_gpu": B, "samples_per_utterance": T, "sharding": "utterances, one batch of %d per GPU, no collective" % B,
                        "kernel": kernel + (" (stream b on XCD b % 8, weights register-resident, create_upsample + lc projections fused into the launch)" if fused else "")},
+            "target_100x_at_batch_8": {"reachable": False, "target_us_per_step": target_us, "us_per_step": us_step,
+                                       "floor_us": floor_us, "floor_us_under_the_cheapest_contract_priced": best_contract_floor_us,
+                                       "evidence": "profiles/r05_chain_contract_ubench.txt (contracts C0-C6 x shapes R/P/D/G/N/M, each bit-checked "
+                                                   "against its canonical fmaf form); DESIGN.md section 15",
+                                       "note": "a 30-layer step is a dependent chain issued by ONE wave per layer: 30 x (32 + 16 fmas + activation) "
+                                               "cannot be issued in 3.33 us under any contract priced (best -19 % per layer); the per-GPU figure "
+                                               "comes with more streams (streams_sweep: 100x real time is passed at batch 32)"},
             "realtime_factor_aggregate": value / hp.sample_rate,
             "realtime_factor_per_stream": value / hp.sample_rate / (n_ok * B),
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
@@ -329,10 +346,10 @@ def main():
                                                      "(uniforms in, progress / exchange words that spill from L2 included)"},
                          "kernel_ms": k_ms, "us_per_generation_step": us_step,
                          "latency_floor_us": floor_us, "frac_of_floor": floor_us / us_step,
-                         "latency_floor_formula": "%d layers x 0.200 us (a layer's dependent arithmetic alone: 32+16 dependent fmas, 6 adds, 21-deep rational "
-                                                  "activation) + 8 wave hand-offs x 0.075 + causal layer 0.15 + post phase (3 L2 hops x 0.26 + skip 0.22 + "
-                                                  "chunk dots 0.28 + ordered sum/conv1d_2 0.27 + sampler 0.31); measured pieces, "
-                                                  "profiles/r02_xcd_chain_ubench_3b.txt and profiles/r02_xcd_phase_profile_v6.txt" % NL,
+                         "latency_floor_formula": "%d layers x 0.192 us (a layer's arithmetic alone on a lone wave, registers only: 32+16 fmas, 6 adds, "
+                                                  "rational activation with one IEEE division; 460 core clocks) + 8 wave hand-offs x 0.075 + causal layer 0.15 + "
+                                                  "post phase (3 L2 hops x 0.26 + skip 0.22 + chunk dots 0.28 + ordered sum/conv1d_2 0.27 + sampler 0.31); "
+                                                  "measured pieces, profiles/r05_chain_contract_ubench.txt and profiles/r05_xcd_phase_profile_v1.txt" % NL,
                          "fp32_flop_per_step": flop_step, "fp32_tflops": flop_step / (us_step * 1e-6) / 1e12,
                          "fp32_frac": flop_step / (us_step * 1e-6) / 1e12 / 157.3,
                          "note": "weights are register-/L2-resident: the sample loop is a dependent chain (latency), not a bandwidth stream; "

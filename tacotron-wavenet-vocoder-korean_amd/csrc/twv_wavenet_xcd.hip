@@ -434,6 +434,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
         }
         if (to_seg1) xb_store(rs, (int)XcdExch::SEG, lane, tag, X);
         else if (nlc > 0) LDSU64((next_has ? w + 1 : 9) * 64 + lane) = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(X);   // nobody reads box 9: no branch on the hand-off
+        XSTAMP(DEFER && nl > 0, (SEG1 ? 48 : 10) + w);       // (instrumented build: "layers done" = the hand-off, in front of the deferred stores)
         if (DEFER) {
 #pragma unroll
             for (int i = 0; i < (NC > 0 ? NC : 0); ++i) xb_store2(rs, (int)XcdExch::ZX + (l0 + i) * 128, lane, tag, zs[i], xs[i]);
@@ -450,7 +451,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
             t_in = now_in;
         }
         if (!sampler) __builtin_amdgcn_s_setprio(0);
-        XSTAMP(nl > 0, (SEG1 ? 48 : 10) + w);
+        XSTAMP(!DEFER && nl > 0, (SEG1 ? 48 : 10) + w);
         XMARK(SEG1 ? 30 : ROLE_CHAIN, 4);
         // ---- sampler: conv1d_2's [16 chunks][32 lanes] partial table from the conv1 workgroups -> mixture.py:84-114
         if constexpr (ONEHOT) {

@@ -38,17 +38,45 @@ def _case(dil, B, Tm, S=64, seed=0, scale=0.05, ls_bias=None, clip_audio=False, 
     return tr, tensors, cfg, audio, lc, gc
 
 
+# Bars, from the data of scripts/train_parity_report.py (profiles/r05_train_parity_report.txt: every geometry below, per tensor
+# e = max|g - g64| / max|g64| for the HIP gradients and for the float32 torch model, both against the float64 torch model):
+#   * wherever a float32 model has a measurable error of its own the HIP path was at most 4.1x further from float64 than the torch
+#     float32 model (16 x 3600: layer4 skip kernel; full size 2.1x; MoL-branch case 1.5x) -> asserted: 8x;
+#   * tensors the torch float32 model gets right to ~1e-7 (one ulp of the largest element) the HIP path gets right to 3.3e-6 at worst
+#     (chunked / split-K summation orders) -> absolute floor 5e-6 (rounds 1-4 carried 2e-3 here, which would have hidden a wrong
+#     bias-gradient term in a small tensor);
+#   * loss: at most 10x the float32 model's own distance from float64, floor 2e-6 relative (worst seen 3.7e-7).
+RATIO, FLOOR, LOSS_FLOOR = 8.0, 5e-6, 2e-6
+
+
 def _check_grads(got, ref, rtol):
-    worst = ("", 0.0)
+    """the older form (one float32 reference, a flat tolerance relative to each tensor's largest element): only for the L2 / clipping
+    options case below, whose sigma = 0.3 weights saturate the gates"""
     for name, r in ref.items():
         g = got[name]
         scale = max(float(np.abs(r).max()), 1e-12)
         err = float(np.abs(g - r).max()) / scale
-        if err > worst[1]:
-            worst = (name, err)
         assert np.isfinite(g).all(), name
         assert err <= rtol, "%s: max|diff| = %.3g of max|ref| %.3g" % (name, err, scale)
-    return worst
+
+
+def _assert_against_float64(label, loss, got, l64, g64, l32, g32):
+    assert abs(loss - l64) <= max(10 * abs(l32 - l64), LOSS_FLOOR * abs(l64)), (label, loss, l32, l64)
+    worst_e, worst_r = ("", 0.0, 0.0), ("", 0.0)
+    for k in g64:
+        scale = max(float(np.abs(g64[k]).max()), 1e-30)
+        e_hip = float(np.abs(got[k] - g64[k]).max()) / scale
+        e_t32 = float(np.abs(g32[k] - g64[k]).max()) / scale
+        assert np.isfinite(got[k]).all(), k
+        assert e_hip <= max(RATIO * e_t32, FLOOR), ("%s %s: HIP %.3g vs torch-f32 %.3g (relative to the tensor's max, against float64): ratio %.1f"
+                                                    % (label, k, e_hip, e_t32, e_hip / max(e_t32, 1e-30)))
+        if e_hip > worst_e[1]:
+            worst_e = (k, e_hip, e_t32)
+        if e_hip > FLOOR and e_hip / e_t32 > worst_r[1]:
+            worst_r = (k, e_hip / e_t32)
+    print("%s: loss %.7f (f64 %.7f, f32 %.7f); worst gradient tensor %s at %.2e of its max (torch f32: %.2e); worst e_hip / e_t32 above the floor: %.2f (%s)"
+          % (label, loss, l64, l32, worst_e[0], worst_e[1], worst_e[2], worst_r[1], worst_r[0] or "none above the floor"))
+    return worst_e, worst_r
 
 
 @pytest.mark.parametrize("kw", [
@@ -59,44 +87,33 @@ def _check_grads(got, ref, rtol):
     dict(dil=[1, 2, 4, 8], B=2, Tm=21, up=(4, 4, 4)),          # hop 64: a 32-row tile of the fused layer kernels straddles a frame edge every other tile
     dict(dil=[1, 2, 4], B=2, Tm=40, up=(2, 4, 4)),             # hop 32 = the tile height (the smallest hop the frame-rate lc path takes)
 ], ids=["small", "one-cycle", "mol-branches", "no-bias", "hop64", "hop32"])
-def test_loss_and_gradients_match_torch_fp32(kw):
+def test_loss_and_gradients_match_torch_fp32(kw, request):
     tr, tensors, cfg, audio, lc, gc = _case(**kw)
     loss = float(tr.loss_and_gradients(audio, lc, gc).item())
-    ref_loss, ref_g = R.loss_and_grads(tensors, cfg, audio, lc, gc)
-    # tolerance: the loss is a mean of O(10) terms over B*out_w rows summed in a different (chunked, fixed) order -> 2e-5 relative
-    assert abs(loss - ref_loss) <= 2e-5 * abs(ref_loss), (loss, ref_loss)
-    # tolerance: every gradient tensor within 2e-3 of its own max magnitude (fp32 reductions over up to B*T rows in a
-    # different order; float64 torch agrees with float32 torch to ~1e-4 on the same scale)
-    _check_grads(tr.gradients(), ref_g, 2e-3)
+    l64, g64 = R.loss_and_grads(tensors, cfg, audio, lc, gc, dtype=torch.float64)
+    l32, g32 = R.loss_and_grads(tensors, cfg, audio, lc, gc, dtype=torch.float32)
+    _assert_against_float64(request.node.callspec.id, loss, tr.gradients(), l64, g64, l32, g32)
 
 
 def test_loss_and_gradients_at_bench_geometry():
     """BASELINE configs[3]'s own geometry in the small: 30 layers (3x[1..512], receptive field 3101), S = 512 and a batch of
     16 x 3600 samples, which takes the 16-slab split-K path of the wide weight gradients that bench.py's B = 64 takes.  Through 30
     layers some gradients (lc kernels of the early layers) are ~1e-9 of the largest and sit at fp32 round-off of a 57 600-row
-    reduction, so the bar is stated against float64: the HIP path may be at most 10x further from the float64 gradients than the
-    float32 torch model is (floor 2e-3 of the tensor's largest element, the tolerance of the small cases)."""
+    reduction (the float32 torch model is 4e-3 of the tensor's max away from float64 there), so the bar is stated against float64,
+    relative to the float32 torch model's own distance (RATIO / FLOOR above)."""
     tr, tensors, cfg, audio, lc, gc = _case(dil=[2 ** i for i in range(10)] * 3, B=16, Tm=12, S=512)
     loss = float(tr.loss_and_gradients(audio, lc, gc).item())
     got = tr.gradients()
     l64, g64 = R.loss_and_grads(tensors, cfg, audio, lc, gc, dtype=torch.float64)
     l32, g32 = R.loss_and_grads(tensors, cfg, audio, lc, gc, dtype=torch.float32)
-    assert abs(loss - l64) <= max(10 * abs(l32 - l64), 2e-5 * abs(l64)), (loss, l32, l64)
-    for k in g64:
-        scale = max(float(np.abs(g64[k]).max()), 1e-30)
-        e_hip = float(np.abs(got[k] - g64[k]).max()) / scale
-        e_t32 = float(np.abs(g32[k] - g64[k]).max()) / scale
-        assert np.isfinite(got[k]).all(), k
-        assert e_hip <= max(10 * e_t32, 2e-3), "%s: HIP %.3g vs torch-f32 %.3g (relative to the tensor's max, against float64)" % (k, e_hip, e_t32)
+    _assert_against_float64("16 x 3600", loss, got, l64, g64, l32, g32)
 
 
 def test_one_step_at_the_full_configs3_batch():
     """BASELINE configs[3] at its own size: ONE teacher-forced step of B = 64 crops x 7800 samples (8000 floored to a hop multiple,
     datafeeder_wavenet.py:41-47), 30 layers, S = 512, MoL loss -- the batch bench.py times.  The checker is the torch restatement
     in float64, run on the GPU in its matmul form (tests/torch_train_ref.py:network_mm; ~0.5 M rows per matmul); the float32
-    torch model beside it gives the scale of plain round-off.  Bar (as for the 16 x 3600 case): loss within 10x the f32 model's own
-    distance from float64 (floor 2e-5 relative); every gradient tensor at most 10x further from float64 than the f32 model is
-    (floor 2e-3 of the tensor's largest element)."""
+    torch model beside it gives the scale of plain round-off.  Same bars as every other geometry (RATIO / FLOOR / LOSS_FLOOR above)."""
     dil = [2 ** i for i in range(10)] * 3
     tr, tensors, cfg, audio, lc, gc = _case(dil=dil, B=64, Tm=26, S=512)
     assert audio.shape == (64, 7800)
@@ -106,20 +123,10 @@ def test_one_step_at_the_full_configs3_batch():
     torch.cuda.empty_cache()
     l32, g32 = R.loss_and_grads(tensors, cfg, audio, lc, gc, dtype=torch.float32, device="cuda:0", matmul_form=True)
     torch.cuda.empty_cache()
-    assert abs(loss - l64) <= max(10 * abs(l32 - l64), 2e-5 * abs(l64)), (loss, l32, l64)
     sampled = ["wavenet/conv1d_2/kernel", "wavenet/dilated_stack/layer29/dilation_layer/skip/kernel",
                "wavenet/dilated_stack/layer0/dilation_layer/conv_filter/kernel", "wavenet/upsample0/kernel"]
     assert all(k in g64 for k in sampled)
-    worst = ("", 0.0)
-    for k in g64:
-        scale = max(float(np.abs(g64[k]).max()), 1e-30)
-        e_hip = float(np.abs(got[k] - g64[k]).max()) / scale
-        e_t32 = float(np.abs(g32[k] - g64[k]).max()) / scale
-        assert np.isfinite(got[k]).all(), k
-        assert e_hip <= max(10 * e_t32, 2e-3), "%s: HIP %.3g vs torch-f32 %.3g (relative to the tensor's max, against float64)" % (k, e_hip, e_t32)
-        if e_hip > worst[1]:
-            worst = (k, e_hip)
-    print("full-size step: loss %.6f (f64 %.6f, f32 %.6f); worst gradient tensor %s at %.2e of its max" % (loss, l64, l32, worst[0], worst[1]))
+    _assert_against_float64("64 x 7800", loss, got, l64, g64, l32, g32)
 
 
 def test_gradients_against_float64_reference_are_closer_than_float32_noise():
@@ -201,9 +208,9 @@ def test_onehot_mulaw_model_loss_and_gradients():
     loss = float(tr.loss_and_gradients(audio, lc, gc).item())
     q = mu_law_encode(torch.from_numpy(audio).cuda(), Q).cpu().numpy()      # the quantizer itself is pinned bit-exact elsewhere
     cfg = dict(dilations=dil, initial_filter_width=32, use_biases=True, upsample_factor=UP, scalar_input=False, Q=Q)
-    ref_loss, ref_g = R.loss_and_grads(tensors, cfg, audio, lc, gc, quantized=q)
-    assert abs(loss - ref_loss) <= 2e-5 * abs(ref_loss), (loss, ref_loss)      # tolerance: fp32 mean over B*out_w rows
-    _check_grads(tr.gradients(), ref_g, 2e-3)                                  # tolerance: as for the MoL model
+    l64, g64 = R.loss_and_grads(tensors, cfg, audio, lc, gc, quantized=q, dtype=torch.float64)
+    l32, g32 = R.loss_and_grads(tensors, cfg, audio, lc, gc, quantized=q, dtype=torch.float32)
+    _assert_against_float64("one-hot", loss, tr.gradients(), l64, g64, l32, g32)      # the same bars as the MoL model
     l0 = float(tr.step(audio, lc, gc).item())
     for _ in range(20):
         l1 = float(tr.step(audio, lc, gc).item())
