@@ -4,8 +4,9 @@
  * wavenet/mixture.py:103-111) and np.log / np.exp / np.logaddexp (generate.py:219-222); their
  * implementations live in TensorFlow/Eigen/numpy, absent from /root/reference and unpinned.  The
  * contract (DESIGN.md "AC-2") fixes them as the single-precision rational / Cephes-polynomial forms
- * Eigen 3.3 ships for CPU [recalled, parity unpinned], evaluated with fused multiply-adds and one
- * IEEE division, so the same bits come out of gcc here and of the gfx950 kernels.
+ * Eigen 3.3 ships for CPU [recalled, parity unpinned], evaluated with fused multiply-adds (tanh / logistic since round 5: Estrin
+ * order and a software-specified reciprocal instead of the division, see below), so the same bits come out of gcc here and of
+ * the gfx950 kernels.
  *
  * Build with -ffp-contract=off: every fusion below is an explicit fmaf().
  */
@@ -14,54 +15,49 @@
 #include "twv_oracle.h"
 
 static inline float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
-
-/* tanh: odd 13th-degree / even 6th-degree rational, input clamped to [-9, 9] */
-float twvo_tanh(float x)
-{
-    const float a1 = 4.89352455891786e-03f, a3 = 6.37261928875436e-04f, a5 = 1.48572235717979e-05f,
-                a7 = 5.12229709037114e-08f, a9 = -8.60467152213735e-11f, a11 = 2.00018790482477e-13f,
-                a13 = -2.76076847742355e-16f;
-    const float b0 = 4.89352518554385e-03f, b2 = 2.26843463243900e-03f, b4 = 1.18534705686654e-04f,
-                b6 = 1.19825839466702e-06f;
-    x = clampf(x, -9.0f, 9.0f);
-    const float x2 = x * x;
-    float p = fmaf(x2, a13, a11);
-    p = fmaf(x2, p, a9);
-    p = fmaf(x2, p, a7);
-    p = fmaf(x2, p, a5);
-    p = fmaf(x2, p, a3);
-    p = fmaf(x2, p, a1);
-    p = x * p;
-    float q = fmaf(x2, b6, b4);
-    q = fmaf(x2, q, b2);
-    q = fmaf(x2, q, b0);
-    return p / q;
-}
-
-/* logistic: odd 9th-degree / even 10th-degree rational + 0.5, input clamped to [-18, 18] */
-float twvo_sigmoid(float x)
-{
-    const float a1 = 2.48287947061529e-01f, a3 = 8.51377133304701e-03f, a5 = 6.08574864600143e-05f,
-                a7 = 1.15627324459942e-07f, a9 = 4.37031012579801e-11f;
-    const float b0 = 9.93151921023180e-01f, b2 = 1.16817656904453e-01f, b4 = 1.70198817374094e-03f,
-                b6 = 6.29106785017040e-06f, b8 = 5.76102136993427e-09f, b10 = 6.10247389755681e-13f;
-    x = clampf(x, -18.0f, 18.0f);
-    const float x2 = x * x;
-    float p = fmaf(x2, a9, a7);
-    p = fmaf(x2, p, a5);
-    p = fmaf(x2, p, a3);
-    p = fmaf(x2, p, a1);
-    p = x * p;
-    float q = fmaf(x2, b10, b8);
-    q = fmaf(x2, q, b6);
-    q = fmaf(x2, q, b4);
-    q = fmaf(x2, q, b2);
-    q = fmaf(x2, q, b0);
-    return p / q + 0.5f;
-}
-
 static inline float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* AC-2 (round 5): the rational P(x^2) x / Q(x^2) of Eigen 3.3's ptanh / plogistic -- the same coefficients as rounds 1-4 -- evaluated
+ * for a lone GPU wave, where the number of instructions and the depth of the dependency chain are what a layer of the generation
+ * chain costs (profiles/r05_chain_contract_ubench.txt): numerator and denominator by Estrin's scheme (t = x^2, t^2, t^4: depth 4
+ * instead of 6 Horner steps), and the division replaced by a SOFTWARE-SPECIFIED reciprocal of the denominator that runs next to the
+ * numerator -- integer seed 0x7EF311C7 - bits(Q) (within 5.1 % for every positive normal Q), one cubic and one quadratic Newton
+ * step in fmaf (relative error of r <= 7.7e-8) -- and the result is ONE fma: fma(x P, r, half), half = 0.5 for the logistic and -0
+ * for tanh (x + -0 == x, signed zeros included).  Every step is an IEEE operation a C compiler reproduces; max abs error against
+ * float64: tanh 3.2e-7, logistic 1.9e-7 (rounds 1-4's Horner + IEEE division: 2.3e-7 / 1.4e-7; tests/test_cpu.py).
+ * Q is positive and normal on the clamped domain (tanh: [4.9e-3, 1.61], logistic: [0.99, 497]): no special cases. */
+typedef struct { float cl, a1, a3, a5, a7, a9, a11, a13, b0, b2, b4, b6, b8, b10, half; } act_coef;
+static const act_coef TANH_C = { 9.0f, 4.89352455891786e-03f, 6.37261928875436e-04f, 1.48572235717979e-05f, 5.12229709037114e-08f,
+                                 -8.60467152213735e-11f, 2.00018790482477e-13f, -2.76076847742355e-16f,
+                                 4.89352518554385e-03f, 2.26843463243900e-03f, 1.18534705686654e-04f, 1.19825839466702e-06f, 0.0f, 0.0f, -0.0f };
+static const act_coef SIGM_C = { 18.0f, 2.48287947061529e-01f, 8.51377133304701e-03f, 6.08574864600143e-05f, 1.15627324459942e-07f,
+                                 4.37031012579801e-11f, 0.0f, 0.0f,
+                                 9.93151921023180e-01f, 1.16817656904453e-01f, 1.70198817374094e-03f, 6.29106785017040e-06f,
+                                 5.76102136993427e-09f, 6.10247389755681e-13f, 0.5f };
+#define TWVO_RCP_MAGIC 0x7EF311C7u
+static float act_eval(const act_coef* c, float x)
+{
+    x = clampf(x, -c->cl, c->cl);
+    const float t = x * x, t2 = t * t, t4 = t2 * t2;
+    const float p01 = fmaf(c->a3, t, c->a1), p23 = fmaf(c->a7, t, c->a5), p45 = fmaf(c->a11, t, c->a9);
+    const float q01 = fmaf(c->b2, t, c->b0), q23 = fmaf(c->b6, t, c->b4), q45 = fmaf(c->b10, t, c->b8);
+    const float p456 = fmaf(c->a13, t2, p45);
+    const float p03 = fmaf(p23, t2, p01), q03 = fmaf(q23, t2, q01);
+    const float P = fmaf(p456, t4, p03), Q = fmaf(q45, t4, q03);
+    const float xp = x * P;
+    float r = bits2f(TWVO_RCP_MAGIC - f2bits(Q));
+    float e = fmaf(-Q, r, 1.0f);
+    const float s = fmaf(e, e, e);
+    r = fmaf(r, s, r);                          /* cubic step: r (1 + e + e^2) */
+    e = fmaf(-Q, r, 1.0f);
+    r = fmaf(r, e, r);                          /* quadratic step */
+    return fmaf(xp, r, c->half);
+}
+/* tanh: odd 13th-degree / even 6th-degree rational, input clamped to [-9, 9] */
+float twvo_tanh(float x) { return act_eval(&TANH_C, x); }
+/* logistic: odd 9th-degree / even 10th-degree rational + 0.5, input clamped to [-18, 18] */
+float twvo_sigmoid(float x) { return act_eval(&SIGM_C, x); }
 
 /* exp: Cephes expf as vectorised in Eigen 3.3 (range reduction by ln2 split C1+C2, degree-5 polynomial) */
 float twvo_exp(float x0)
@@ -227,5 +223,28 @@ void twvo_cdot_rows(const float* w, int ncols, const float* x, int K, float* out
                 out[j0 + j] = (k0 == 0) ? a : out[j0 + j] + a;
             }
         }
+    }
+}
+
+/* AC-1b (round 5), for the two contractions ON the generation chain's sample-to-sample path (model.py:68-69 conv_filter|conv_gate,
+ * model.py:89 dense): the contraction's LAST 32-term chunk does not start its chain 0 from +0 but from the ADDEND -- everything
+ * that is added to the contraction anyway and is known before the chunk's operand exists (the earlier chunks, the bias, the gc and lc
+ * projections) -- so no add follows the dot product on the dependency chain.
+ *   twvo_cdot_rows_head: r[j] = the chunks before the last one, added in order (AC-1); returns 0 when there is none (K <= 32)
+ *   twvo_cdot_rows_tail: out[j] = (s0 + s1) + (s2 + s3) of the last chunk with s0 started from addend[j] (s1..s3 from +0) */
+int twvo_cdot_rows_head(const float* w, int ncols, const float* x, int K, float* r)
+{
+    const int klast = ((K - 1) / 32) * 32;
+    if (klast <= 0) return 0;
+    twvo_cdot_rows(w, ncols, x, klast, r);
+    return 1;
+}
+void twvo_cdot_rows_tail(const float* w, int ncols, const float* x, int K, const float* addend, float* out)
+{
+    const int k0 = ((K - 1) / 32) * 32;
+    for (int j = 0; j < ncols; ++j) {
+        float s[4] = { addend[j], 0.0f, 0.0f, 0.0f };
+        for (int k = k0; k < K; ++k) s[(k - k0) & 3] = fmaf(w[(size_t)k * ncols + j], x[k], s[(k - k0) & 3]);
+        out[j] = (s[0] + s[1]) + (s[2] + s[3]);
     }
 }

@@ -56,6 +56,8 @@ double twvo_log64(double x);
 float  twvo_log1p(float x);
 float  twvo_cdot(const float* w, int wstride, const float* x, int K);
 void   twvo_cdot_rows(const float* w, int ncols, const float* x, int K, float* out); /* out[j] = twvo_cdot(w+j, ncols, x, K) */
+int    twvo_cdot_rows_head(const float* w, int ncols, const float* x, int K, float* r);                       /* AC-1b: chunks before the last */
+void   twvo_cdot_rows_tail(const float* w, int ncols, const float* x, int K, const float* addend, float* out); /* AC-1b: last chunk from the addend */
 
 /* ops.py:22-47 */
 void twvo_mu_law_encode(const float* audio, int n, int Q, int32_t* out);

@@ -188,23 +188,35 @@ static void dilation_layer_at(const twvo_dims* d, const float* blob, const layer
     float taps[2 * 512], f[512], g[512], t1[512], t2[512];
     memcpy(taps, x_old, sizeof(float) * R);
     memcpy(taps + R, x_new, sizeof(float) * R);
-    /* model.py:68-69 conv_filter / conv_gate: k=2, dilation d, 'valid', bias */
-    twvo_cdot_rows(blob + l->wf, D, taps, 2 * R, f);
-    twvo_cdot_rows(blob + l->wg, D, taps, 2 * R, g);
-    if (d->use_bias) for (int j = 0; j < D; ++j) { f[j] = f[j] + blob[l->bf + j]; g[j] = g[j] + blob[l->bg + j]; }
+    /* model.py:68-69 conv_filter / conv_gate: k=2, dilation d, 'valid', bias; model.py:71-73 gc, model.py:75-83 lc.
+     * Statement order of the reference: ((conv + bias) + gc) + lc.  AC-1b: the conv's last chunk (with R = 32: the tap that reads
+     * x[t], the only operand on the sample-to-sample path) is started FROM the addend ((earlier chunks + bias) + gc) + lc. */
+    float af[512], ag[512];
+    const int hf = twvo_cdot_rows_head(blob + l->wf, D, taps, 2 * R, af);
+    const int hg = twvo_cdot_rows_head(blob + l->wg, D, taps, 2 * R, ag);
+    if (!hf) for (int j = 0; j < D; ++j) af[j] = 0.0f;
+    if (!hg) for (int j = 0; j < D; ++j) ag[j] = 0.0f;
+    if (d->use_bias) for (int j = 0; j < D; ++j) { af[j] = af[j] + blob[l->bf + j]; ag[j] = ag[j] + blob[l->bg + j]; }
     if (emb) { /* model.py:71-73 */
         twvo_cdot_rows(blob + l->gcf, D, emb, d->G, t1);
         twvo_cdot_rows(blob + l->gcg, D, emb, d->G, t2);
-        for (int j = 0; j < D; ++j) { f[j] = f[j] + t1[j]; g[j] = g[j] + t2[j]; }
+        for (int j = 0; j < D; ++j) { af[j] = af[j] + t1[j]; ag[j] = ag[j] + t2[j]; }
     }
     if (lc) { /* model.py:75-83 */
         twvo_cdot_rows(blob + l->lcf, D, lc, d->L, t1);
         twvo_cdot_rows(blob + l->lcg, D, lc, d->L, t2);
-        for (int j = 0; j < D; ++j) { f[j] = f[j] + t1[j]; g[j] = g[j] + t2[j]; }
+        for (int j = 0; j < D; ++j) { af[j] = af[j] + t1[j]; ag[j] = ag[j] + t2[j]; }
     }
+    twvo_cdot_rows_tail(blob + l->wf, D, taps, 2 * R, af, f);
+    twvo_cdot_rows_tail(blob + l->wg, D, taps, 2 * R, ag, g);
     for (int j = 0; j < D; ++j) z[j] = twvo_tanh(f[j]) * twvo_sigmoid(g[j]); /* model.py:86 */
-    twvo_cdot_rows(blob + l->wd, R, z, D, transformed); /* model.py:89 dense 1x1 */
-    if (d->use_bias) for (int r = 0; r < R; ++r) transformed[r] = transformed[r] + blob[l->bd + r];
+    /* model.py:89 dense 1x1 + bias: the bias (after the earlier chunks, if D > 32) is the start value of the last chunk (AC-1b) */
+    {
+        float ad[512];
+        if (!twvo_cdot_rows_head(blob + l->wd, R, z, D, ad)) for (int r = 0; r < R; ++r) ad[r] = 0.0f;
+        if (d->use_bias) for (int r = 0; r < R; ++r) ad[r] = ad[r] + blob[l->bd + r];
+        twvo_cdot_rows_tail(blob + l->wd, R, z, D, ad, transformed);
+    }
     if (skip) { /* model.py:96 skip 1x1 */
         twvo_cdot_rows(blob + l->ws, S, z, D, skip);
         if (d->use_bias) for (int s = 0; s < S; ++s) skip[s] = skip[s] + blob[l->bs + s];

@@ -27,6 +27,92 @@
 #include "../../tacotron-wavenet-vocoder-korean_amd/csrc/twv_dpp.hpp"
 using namespace twv;
 
+// ---------------------------------------------------------------- rounds 1-4's activation (contract C0): Horner rational + IEEE division.
+// (the product's twv_math.hpp carries the candidate of this file since round 5 adopted it; the old form lives on here as the base line)
+namespace ac2_r04 {
+struct ActCoef {
+    float clampv, a13, a11, a9, a7, a5, a3, a1, b10, b8, b6, b4, b2, b0;
+    int is_sig;
+};
+__device__ __forceinline__ ActCoef act_coef(bool sig)
+{
+    ActCoef c;
+    c.is_sig = sig ? 1 : 0;
+    c.clampv = sig ? 18.0f : 9.0f;
+    c.a13 = sig ? 0.0f : -2.76076847742355e-16f;
+    c.a11 = sig ? 0.0f : 2.00018790482477e-13f;
+    c.a9 = sig ? 4.37031012579801e-11f : -8.60467152213735e-11f;
+    c.a7 = sig ? 1.15627324459942e-07f : 5.12229709037114e-08f;
+    c.a5 = sig ? 6.08574864600143e-05f : 1.48572235717979e-05f;
+    c.a3 = sig ? 8.51377133304701e-03f : 6.37261928875436e-04f;
+    c.a1 = sig ? 2.48287947061529e-01f : 4.89352455891786e-03f;
+    c.b10 = sig ? 6.10247389755681e-13f : 0.0f;
+    c.b8 = sig ? 5.76102136993427e-09f : 0.0f;
+    c.b6 = sig ? 6.29106785017040e-06f : 1.19825839466702e-06f;
+    c.b4 = sig ? 1.70198817374094e-03f : 1.18534705686654e-04f;
+    c.b2 = sig ? 1.16817656904453e-01f : 2.26843463243900e-03f;
+    c.b0 = sig ? 9.93151921023180e-01f : 4.89352518554385e-03f;
+    return c;
+}
+__device__ __forceinline__ float act_eval(const ActCoef& c, float x)
+{
+    x = x < -c.clampv ? -c.clampv : (x > c.clampv ? c.clampv : x);
+    const float x2 = x * x;
+    float p = fma_(x2, c.a13, c.a11);
+    p = fma_(x2, p, c.a9);
+    p = fma_(x2, p, c.a7);
+    p = fma_(x2, p, c.a5);
+    p = fma_(x2, p, c.a3);
+    p = fma_(x2, p, c.a1);
+    p = x * p;
+    float q = fma_(x2, c.b10, c.b8);
+    q = fma_(x2, q, c.b6);
+    q = fma_(x2, q, c.b4);
+    q = fma_(x2, q, c.b2);
+    q = fma_(x2, q, c.b0);
+    const float r = div_(p, q);
+    return c.is_sig ? r + 0.5f : r;
+}
+// Latency-oriented form for the generation chain wave (one evaluation per layer on a lone wave, where instruction count is
+// what matters): the odd numerator polynomial p (6 Horner steps) and the even denominator q (5 steps) share the multiplier
+// x^2, so steps 2..6 of p run packed with steps 1..5 of q (v_pk_fma_f32) -- the same fmas, half the instructions.  In
+// throughput code (many independent evaluations per thread, e.g. the Tacotron attention scores) the scalar form above is
+// faster (measured: 13.7 vs 15.3 ms per Tacotron pass).
+typedef float f32x2m __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float act_eval_pk(const ActCoef& c, float x)
+{
+    x = x < -c.clampv ? -c.clampv : (x > c.clampv ? c.clampv : x);
+    const float x2 = x * x;
+    const f32x2m xx = {x2, x2};
+    f32x2m pq = {fma_(x2, c.a13, c.a11), c.b10};
+    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a9, c.b8});
+    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a7, c.b6});
+    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a5, c.b4});
+    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a3, c.b2});
+    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a1, c.b0});
+    const float p = x * pq[0];
+    const float r = div_(p, pq[1]);
+    return c.is_sig ? r + 0.5f : r;
+}
+// the same with the clamp as ONE v_med3_f32 (three dependent instructions fewer per layer of the generation chain); identical for
+// every non-NaN input (a NaN input stays NaN in both forms' consumers: the rational of a NaN is NaN)
+__device__ __forceinline__ float act_eval_pk_med3(const ActCoef& c, float x)
+{
+    x = __builtin_amdgcn_fmed3f(x, -c.clampv, c.clampv);
+    const float x2 = x * x;
+    const f32x2m xx = {x2, x2};
+    f32x2m pq = {fma_(x2, c.a13, c.a11), c.b10};
+    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a9, c.b8});
+    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a7, c.b6});
+    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a5, c.b4});
+    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a3, c.b2});
+    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a1, c.b0});
+    const float p = x * pq[0];
+    const float r = div_(p, pq[1]);
+    return c.is_sig ? r + 0.5f : r;
+}
+}  // namespace ac2_r04
+
 #define CHECK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(r_), __LINE__); exit(1); } } while (0)
 
 constexpr int NLU = 4;
@@ -37,7 +123,7 @@ struct LayerCanon {
 };
 
 // ---------------------------------------------------------------- the candidate activation (contract C3)
-constexpr unsigned kRcpMagic = 0x7EF311C7u;
+constexpr unsigned kRcpMagicU = 0x7EF311C7u;
 struct ActCoef2 { float cl, a1, a3, a5, a7, a9, a11, a13, b0, b2, b4, b6, b8, b10, half; };
 __host__ __device__ inline ActCoef2 act_coef2(bool sig)
 {
@@ -71,7 +157,7 @@ __host__ __device__ inline float act2_plain(const ActCoef2& c, float x)
     const float P = fmaf(p456, t4, p03), Q = fmaf(q45, t4, q03);
     const float xp = x * P;
     unsigned qb; memcpy(&qb, &Q, 4);
-    const unsigned rb = kRcpMagic - qb;
+    const unsigned rb = kRcpMagicU - qb;
     float r; memcpy(&r, &rb, 4);
     float e = fmaf(-Q, r, 1.0f);
     const float s = fmaf(e, e, e);
@@ -97,7 +183,7 @@ __device__ __forceinline__ float act2_pk(const ActCoef2& c, float x)
     const f2 PQ = __builtin_elementwise_fma(f2{p456, pq45[1]}, f2{t4, t4}, pq03);
     const float xp = x * PQ[0];
     const float Q = PQ[1];
-    float r = __uint_as_float(kRcpMagic - __float_as_uint(Q));
+    float r = __uint_as_float(kRcpMagicU - __float_as_uint(Q));
     float e = fma_(-Q, r, 1.0f);
     const float s = fma_(e, e, e);
     r = fma_(r, s, r);
@@ -197,7 +283,7 @@ __device__ __forceinline__ float dot32_readlane_pk(const float (&w)[32], float X
 // ---------------------------------------------------------------- the layer body under contract C
 struct LayerIn { float pre, bfg, gcv, lcv, A, bd, bd_init; };
 template <int C>
-__device__ __forceinline__ float front(const float (&wc)[32], const LayerIn& p, const ActCoef& co, const ActCoef2& co2, float X)
+__device__ __forceinline__ float front(const float (&wc)[32], const LayerIn& p, const ac2_r04::ActCoef& co, const ActCoef2& co2, float X)
 {
     float v;
     if (C == 6) {
@@ -215,7 +301,7 @@ __device__ __forceinline__ float front(const float (&wc)[32], const LayerIn& p, 
             v = dot32_dpp_init(wc, xa, xb, p.A);
         }
     }
-    const float act = (C >= 3 && C <= 5) ? act2_pk(co2, v) : act_eval_pk_med3(co, v);
+    const float act = (C >= 3 && C <= 5) ? act2_pk(co2, v) : ac2_r04::act_eval_pk_med3(co, v);
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
     return __uint_as_float(sw[0]) * __uint_as_float(sw[1]);
 }
@@ -240,7 +326,7 @@ template <int C>
 __global__ void __launch_bounds__(64) layer_ref_kernel(const LayerCanon* Lc, const float* x0, float* xout, int steps)
 {
     const int lane = threadIdx.x;
-    const ActCoef coef = act_coef(lane >= 32);
+    const ac2_r04::ActCoef coef = ac2_r04::act_coef(lane >= 32);
     const ActCoef2 coef2 = act_coef2(lane >= 32);
     constexpr bool presum = (C == 1 || C == 2 || C == 4 || C == 5), init = (C == 2 || C == 5), act2 = (C >= 3 && C <= 5);
     float x = x0[lane & 31];
@@ -255,7 +341,7 @@ __global__ void __launch_bounds__(64) layer_ref_kernel(const LayerCanon* Lc, con
             if (init) v = chunk;
             else if (presum) v = chunk + A;
             else { v = P.pre[lane] + chunk; v = v + P.bfg[lane]; v = v + P.gcv[lane]; v = v + P.lcv[lane]; }
-            const float act = act2 ? act2_plain(coef2, v) : act_eval(coef, v);
+            const float act = act2 ? act2_plain(coef2, v) : ac2_r04::act_eval(coef, v);
             const float z = __shfl(act, lane & 31) * __shfl(act, 32 + (lane & 31));
             float q[4] = {init ? P.bd[lane & 31] : 0.0f, 0, 0, 0};
             for (int k = 0; k < 32; ++k) q[k & 3] = fma_(P.Wd[k][lane & 31], __shfl(z, k), q[k & 3]);
@@ -278,7 +364,7 @@ template <int C, int SHAPE>
 __global__ void __launch_bounds__(64) layer_var_kernel(const LayerCanon* Lc, const float* x0, float* xout, int steps, unsigned long long* cyc, unsigned long long* gran, int nl_rt)
 {
     const int lane = threadIdx.x;
-    const ActCoef coef = act_coef(lane >= 32);
+    const ac2_r04::ActCoef coef = ac2_r04::act_coef(lane >= 32);
     const ActCoef2 coef2 = act_coef2(lane >= 32);
     float wc[NLU][32], wdr[NLU][16];
     LayerIn in[NLU];
@@ -358,12 +444,12 @@ template <int WHICH>
 __global__ void __launch_bounds__(64) act_time_kernel(float* out, unsigned long long* cyc, int reps)
 {
     const int lane = threadIdx.x;
-    const ActCoef coef = act_coef(lane >= 32);
+    const ac2_r04::ActCoef coef = ac2_r04::act_coef(lane >= 32);
     const ActCoef2 coef2 = act_coef2(lane >= 32);
     float v = 0.01f * (float)lane - 0.3f;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int r = 0; r < reps; ++r) {
-        const float a = WHICH ? act2_pk(coef2, v) : act_eval_pk_med3(coef, v);
+        const float a = WHICH ? act2_pk(coef2, v) : ac2_r04::act_eval_pk_med3(coef, v);
         v = a * 0.9f + 0.05f;
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();

@@ -1,4 +1,7 @@
 // Round-2 design probes for the XCD-per-stream generation kernel (tuning aid, not product code).
+// (Round 5: sections 3 / 3b follow the product's arithmetic contract AC-1b / AC-2 as adopted in round 5 -- conditioning addend and dense
+//  bias as chain start values, Estrin rational with a software reciprocal; the numbers of profiles/r02_xcd_chain_ubench*.txt were taken
+//  under rounds 1-4's contract, which scripts/ubench/chain_contract_ubench.hip keeps as its base line C0.)
 //   1. lane-crossing primitives: DPP row_newbcast on a 32-bit VOP2, v_permlane16_swap, v_permlane32_swap (semantics on gfx950)
 //   2. a 32-term AC-1 chunk as 32 v_fmac_f32_dpp (no v_readlane): bit-exactness vs fmaf chains, cycles per dot
 //   3. the whole residual-layer body in the row-broadcast lane layout with register-resident weights: bits vs the canonical
@@ -77,16 +80,14 @@ __global__ void __launch_bounds__(64) layer_ref_kernel(const LayerCanon* Lc, con
     for (int t = 0; t < steps; ++t) {
         for (int l = 0; l < NLU; ++l) {
             const LayerCanon& P = Lc[l];
-            float s[4] = {0, 0, 0, 0};
+            float s[4] = {((P.pre[lane] + P.bfg[lane]) + P.gcv[lane]) + P.lcv[lane], 0, 0, 0};      // AC-1b: chain 0 starts from the addend
             for (int k = 0; k < 32; ++k) s[k & 3] = fma_(P.Wc[k][lane], __shfl(x, k), s[k & 3]);
-            float v = P.pre[lane] + ((s[0] + s[1]) + (s[2] + s[3]));
-            v = v + P.bfg[lane]; v = v + P.gcv[lane]; v = v + P.lcv[lane];
+            const float v = (s[0] + s[1]) + (s[2] + s[3]);
             const float act = act_eval(coef, v);
             const float z = __shfl(act, lane & 31) * __shfl(act, 32 + (lane & 31));
-            float q[4] = {0, 0, 0, 0};
+            float q[4] = {P.bd[lane & 31], 0, 0, 0};                                                // AC-1b: the bias is the start value
             for (int k = 0; k < 32; ++k) q[k & 3] = fma_(P.Wd[k][lane & 31], __shfl(z, k), q[k & 3]);
-            float tr = (q[0] + q[1]) + (q[2] + q[3]);
-            tr = tr + P.bd[lane & 31];
+            const float tr = (q[0] + q[1]) + (q[2] + q[3]);
             x = x + tr;
             if (t == steps - 1) zout[l * 32 + (lane & 31)] = z;
         }
@@ -108,8 +109,8 @@ __global__ void __launch_bounds__(64) layer_dpp_kernel(const LayerCanon* Lc, con
         for (int k = 0; k < 32; ++k) W[l].wc[k] = Lc[l].Wc[k][oc];
 #pragma unroll
         for (int i = 0; i < 16; ++i) W[l].wd[i] = Lc[l].Wd[dpp_dense_k(lane, i)][od];
-        W[l].bfg = Lc[l].bfg[oc]; W[l].gcv = Lc[l].gcv[oc]; W[l].bd = Lc[l].bd[od];
-        pre[l] = Lc[l].pre[oc]; lcv[l] = Lc[l].lcv[oc];
+        W[l].bd_init = dense_bias_init(lane, Lc[l].bd[od]);
+        pre[l] = ((Lc[l].pre[oc] + Lc[l].bfg[oc]) + Lc[l].gcv[oc]) + Lc[l].lcv[oc]; lcv[l] = 0.0f;
     }
     float X = x0[od];
     float z = 0.0f;
@@ -118,7 +119,7 @@ __global__ void __launch_bounds__(64) layer_dpp_kernel(const LayerCanon* Lc, con
     for (int t = 0; t < steps; ++t) {
 #pragma unroll
         for (int l = 0; l < NLU; ++l) {
-            z = layer_body_dpp(W[l], coef, X, pre[l], lcv[l]);
+            z = layer_body_dpp(W[l], coef, X, pre[l]);
             if (t == steps - 1 && lane < 32) zout[l * 32 + dpp_z_index(lane)] = z;
         }
         X = X * 0.25f;
@@ -154,8 +155,8 @@ __global__ void __launch_bounds__(64) layer_var_kernel(const LayerCanon* Lc, con
         for (int i = 0; i < 16; ++i) { W[l].wd[i] = Lc[l].Wd[dpp_dense_k(lane, i)][od]; }
 #pragma unroll
         for (int q = 0; q < 4; ++q) ULDS4((l * 4 + q) * 64 + lane) = f32x4t{W[l].wd[4 * q], W[l].wd[4 * q + 1], W[l].wd[4 * q + 2], W[l].wd[4 * q + 3]};
-        W[l].bfg = Lc[l].bfg[oc]; W[l].gcv = Lc[l].gcv[oc]; W[l].bd = Lc[l].bd[od];
-        pre[l] = Lc[l].pre[oc]; lcv[l] = Lc[l].lcv[oc];
+        W[l].bd_init = dense_bias_init(lane, Lc[l].bd[od]);
+        pre[l] = ((Lc[l].pre[oc] + Lc[l].bfg[oc]) + Lc[l].gcv[oc]) + Lc[l].lcv[oc]; lcv[l] = 0.0f;
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gran, 0, 1 << 20, 0x00020000);
     float X = x0[od];
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(64) layer_var_kernel(const LayerCanon* Lc, con
 #pragma unroll
                     for (int i = 0; i < 16; ++i) wd[i] = W[l].wd[i];
                 }
-                const float z = layer_front_dpp<true>(W[l].wc, W[l].bfg, W[l].gcv, coef, X, pre[l], lcv[l], true, true, true);
+                const float z = layer_front_dpp(W[l].wc, coef, X, pre[l]);
                 if (MODE & 2) {
                     const u32x4t d = {__float_as_uint(z), tag, __float_as_uint(X), tag};
                     __builtin_amdgcn_raw_buffer_store_b128(d, rs, lane * 16, l * 1024, 0);
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(64) layer_var_kernel(const LayerCanon* Lc, con
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2t{__float_as_uint(X), tag}, rs, lane * 8, l * 1024 + 512, 0);
                     asm volatile("" ::: "memory");
                 }
-                layer_back_dpp<true>(wd, W[l].bd, z, X, true);
+                layer_back_dpp(wd, W[l].bd_init, z, X);
             }
         }
         X = X * 0.25f;

@@ -122,8 +122,86 @@ __device__ __forceinline__ float dot_readlane_pipe_a(const float (&tw)[32], floa
         : "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
     return (a[0] + a[1]) + (b[0] + b[1]);
 }
+// the same with chain 0 started from `init` instead of +0 (AC-1b: the last chunk of a contraction on the generation chain starts from
+// the addend -- earlier chunks, bias, conditioning -- so no add follows the dot product on the sample-to-sample path)
+__device__ __forceinline__ float dot_readlane_pipe_init_a(const float (&tw)[32], float xv, float init)
+{
+    f32x2p a, b;
+    asm volatile(
+        "s_nop 1\n"                                    // the operand may come straight out of a VALU instruction: hazards inside inline asm are ours
+        "\t.p2align 3\n"                              // 8-byte instructions at 8-byte addresses (see TWV_ALIGN8, twv_dpp.hpp)
+        "v_readlane_b32 s84, %[x], 0\n"
+        "v_readlane_b32 s85, %[x], 1\n"
+        "v_readlane_b32 s86, %[x], 2\n"
+        "v_readlane_b32 s87, %[x], 3\n"
+        "v_readlane_b32 s88, %[x], 4\n"
+        "v_readlane_b32 s89, %[x], 5\n"
+        "v_pk_fma_f32 %[a], %[p0], s[84:85], %[i]\n"
+        "v_readlane_b32 s90, %[x], 6\n"
+        "v_readlane_b32 s91, %[x], 7\n"
+        "v_pk_fma_f32 %[b], %[p1], s[86:87], 0 op_sel_hi:[1,1,0]\n"
+        "v_readlane_b32 s92, %[x], 8\n"
+        "v_readlane_b32 s93, %[x], 9\n"
+        "v_pk_fma_f32 %[a], %[p2], s[88:89], %[a]\n"
+        "v_readlane_b32 s94, %[x], 10\n"
+        "v_readlane_b32 s95, %[x], 11\n"
+        "v_pk_fma_f32 %[b], %[p3], s[90:91], %[b]\n"
+        "v_readlane_b32 s96, %[x], 12\n"
+        "v_readlane_b32 s97, %[x], 13\n"
+        "v_pk_fma_f32 %[a], %[p4], s[92:93], %[a]\n"
+        "v_readlane_b32 s98, %[x], 14\n"
+        "v_readlane_b32 s99, %[x], 15\n"
+        "v_pk_fma_f32 %[b], %[p5], s[94:95], %[b]\n"
+        "v_readlane_b32 s84, %[x], 16\n"
+        "v_readlane_b32 s85, %[x], 17\n"
+        "v_pk_fma_f32 %[a], %[p6], s[96:97], %[a]\n"
+        "v_readlane_b32 s86, %[x], 18\n"
+        "v_readlane_b32 s87, %[x], 19\n"
+        "v_pk_fma_f32 %[b], %[p7], s[98:99], %[b]\n"
+        "v_readlane_b32 s88, %[x], 20\n"
+        "v_readlane_b32 s89, %[x], 21\n"
+        "v_pk_fma_f32 %[a], %[p8], s[84:85], %[a]\n"
+        "v_readlane_b32 s90, %[x], 22\n"
+        "v_readlane_b32 s91, %[x], 23\n"
+        "v_pk_fma_f32 %[b], %[p9], s[86:87], %[b]\n"
+        "v_readlane_b32 s92, %[x], 24\n"
+        "v_readlane_b32 s93, %[x], 25\n"
+        "v_pk_fma_f32 %[a], %[p10], s[88:89], %[a]\n"
+        "v_readlane_b32 s94, %[x], 26\n"
+        "v_readlane_b32 s95, %[x], 27\n"
+        "v_pk_fma_f32 %[b], %[p11], s[90:91], %[b]\n"
+        "v_readlane_b32 s96, %[x], 28\n"
+        "v_readlane_b32 s97, %[x], 29\n"
+        "v_pk_fma_f32 %[a], %[p12], s[92:93], %[a]\n"
+        "v_readlane_b32 s98, %[x], 30\n"
+        "v_readlane_b32 s99, %[x], 31\n"
+        "v_pk_fma_f32 %[b], %[p13], s[94:95], %[b]\n"
+        "v_pk_fma_f32 %[a], %[p14], s[96:97], %[a]\n"
+        "v_pk_fma_f32 %[b], %[p15], s[98:99], %[b]"
+        : [a] "=&v"(a), [b] "=&v"(b)
+        : [x] "v"(xv), [i] "v"(f32x2p{init, 0.0f}),
+          [p0] "v"(f32x2p{tw[0], tw[1]}),
+          [p1] "v"(f32x2p{tw[2], tw[3]}),
+          [p2] "v"(f32x2p{tw[4], tw[5]}),
+          [p3] "v"(f32x2p{tw[6], tw[7]}),
+          [p4] "v"(f32x2p{tw[8], tw[9]}),
+          [p5] "v"(f32x2p{tw[10], tw[11]}),
+          [p6] "v"(f32x2p{tw[12], tw[13]}),
+          [p7] "v"(f32x2p{tw[14], tw[15]}),
+          [p8] "v"(f32x2p{tw[16], tw[17]}),
+          [p9] "v"(f32x2p{tw[18], tw[19]}),
+          [p10] "v"(f32x2p{tw[20], tw[21]}),
+          [p11] "v"(f32x2p{tw[22], tw[23]}),
+          [p12] "v"(f32x2p{tw[24], tw[25]}),
+          [p13] "v"(f32x2p{tw[26], tw[27]}),
+          [p14] "v"(f32x2p{tw[28], tw[29]}),
+          [p15] "v"(f32x2p{tw[30], tw[31]})
+        : "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
+    return (a[0] + a[1]) + (b[0] + b[1]);
+}
 
 __device__ __forceinline__ float dot_readlane_pipe(const Tile& t, float xv) { return dot_readlane_pipe_a(t.w, xv); }
+__device__ __forceinline__ float dot_readlane_pipe_init(const Tile& t, float xv, float init) { return dot_readlane_pipe_init_a(t.w, xv, init); }
 
 // the same with the operand vector in lanes 32..63 of `xv` (helper workgroups: second chunk of a wave)
 __device__ __forceinline__ float dot_readlane_pipe32(const Tile& t, float xv)

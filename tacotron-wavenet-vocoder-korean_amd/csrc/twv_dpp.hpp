@@ -36,17 +36,11 @@ __host__ __device__ inline int dpp_dense_k(int lane, int i) { return dpp_a(i) + 
 // z element held by a lane of the Z layout
 __host__ __device__ inline int dpp_z_index(int lane) { return dpp_a(lane & 15) + (((lane >> 4) & 1) ? 2 : 0); }
 
-// one layer's chain operands, register-resident for the whole launch (51 VGPRs)
-struct LayerRegs {
-    float wc[32];          // tap-1 conv kernel column of this lane's conv output
-    float wd[16];          // this lane's half of the dense kernel column
-    float bfg, gcv, bd;    // conv bias, gc projection (model.py:71-73), dense bias
-};
-
-// 32-term AC-1 chunk: acc_j += w[k] * x[k]  (k = 0..15 from XA, 16..31 from XB)
-__device__ __forceinline__ float dot32_dpp(const float (&w)[32], float xa, float xb)
+// 32-term AC-1 chunk: acc_j += w[k] * x[k]  (k = 0..15 from XA, 16..31 from XB).  init: the start value of chain 0 (AC-1b: the
+// contraction's last chunk on the generation chain starts from the addend; +0 everywhere else)
+__device__ __forceinline__ float dot32_dpp(const float (&w)[32], float xa, float xb, float init = 0.0f)
 {
-    float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+    float c0 = init, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
     asm volatile(
         "s_nop 1\n" TWV_ALIGN8
         "v_fmac_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
@@ -220,10 +214,11 @@ __device__ __forceinline__ void dot32_dpp_x3(const float (&wa)[32], float xa0, f
     rc = (e[0] + e[1]) + (e[2] + e[3]);
 }
 
-// a lane's half of a 32-term chunk: two chains, 16 terms, operand vector in the Z layout
-__device__ __forceinline__ float dot16_dpp(const float (&w)[16], float z)
+// a lane's half of a 32-term chunk: two chains, 16 terms, operand vector in the Z layout.  init: start value of the lane's first
+// chain (even rows hold the chunk's chains 0 and 1: their first chain is chain 0 of AC-1b)
+__device__ __forceinline__ float dot16_dpp(const float (&w)[16], float z, float init = 0.0f)
 {
-    float c0 = 0.0f, c1 = 0.0f;
+    float c0 = init, c1 = 0.0f;
     asm volatile(
         "s_nop 1\n" TWV_ALIGN8
         "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
@@ -248,51 +243,38 @@ __device__ __forceinline__ float dot16_dpp(const float (&w)[16], float z)
 }
 
 // model.py:66-101 for one step of one stream, in two halves so that the caller can publish z between them.
-// front: X (X layout) -> z (Z layout).  pre = tap-0 chunk (x[t-d], computed off the chain), lcv = lc projection (model.py:75-83);
-// statement order of the reference: ((conv + bias) + gc) + lc, conv = chunk(tap 0) + chunk(tap 1).
-// ALL = biases, gc and lc all present (hparams default): no selects on the dependency chain.
-template <bool ALL>
-__device__ __forceinline__ float layer_front_dpp(const float (&wc)[32], float bfg, float gcv, const ActCoef& coef, float X, float pre,
-                                                 float lcv, bool use_bias, bool has_gc, bool has_lc)
+// front: X (X layout) -> z (Z layout).  AC-1b (round 5): `addend` = ((tap-0 chunk + bias) + gc) + lc -- the reference's statement
+// order ((conv + bias) + gc) + lc (model.py:68-83) with conv = chunk(tap 0) + chunk(tap 1) -- is computed OFF the chain (service
+// workgroup / loader waves: nothing in it depends on x[t]) and is the start value of chain 0 of the tap-1 chunk: no add follows the
+// dot product on the sample-to-sample path (profiles/r05_chain_contract_ubench.txt: contracts C2 / C5).
+__device__ __forceinline__ float layer_front_dpp(const float (&wc)[32], const ActCoef& coef, float X, float addend)
 {
     const auto xs = __builtin_amdgcn_permlane32_swap(__float_as_uint(X), __float_as_uint(X), false, false);
-    const float acc1 = dot32_dpp(wc, __uint_as_float(xs[0]), __uint_as_float(xs[1]));
-    float v = pre + acc1;
-    if (ALL) {
-        v = v + bfg;
-        v = v + gcv;
-        v = v + lcv;
-    } else {
-        if (use_bias) v = v + bfg;
-        if (has_gc) v = v + gcv;                                             // model.py:71-73
-        if (has_lc) v = v + lcv;                                             // model.py:75-83
-    }
+    const float v = dot32_dpp(wc, __uint_as_float(xs[0]), __uint_as_float(xs[1]), addend);
     const float act = act_eval_pk_med3(coef, v);                             // model.py:86: lanes 0-31 tanh, 32-63 logistic
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
     return __uint_as_float(sw[0]) * __uint_as_float(sw[1]);
 }
-// back: model.py:89 dense 1x1 of z, model.py:98-101 residual; X in / out in the X layout
-template <bool ALL>
-__device__ __forceinline__ void layer_back_dpp(const float (&wd)[16], float bd, float z, float& X, bool use_bias)
+// back: model.py:89 dense 1x1 of z, model.py:98-101 residual; X in / out in the X layout.  bd_init: the dense bias on the lanes that
+// hold chain 0 of the chunk (even rows), +0 on the odd rows (dense_bias_init): the bias is the chain's start value (AC-1b).
+__device__ __forceinline__ float dense_bias_init(int lane, float bd) { return ((lane >> 4) & 1) ? 0.0f : bd; }
+__device__ __forceinline__ void layer_back_dpp(const float (&wd)[16], float bd_init, float z, float& X)
 {
-    const float s = dot16_dpp(wd, z);
+    const float s = dot16_dpp(wd, z, bd_init);
     const auto ds = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-    float tr = __uint_as_float(ds[0]) + __uint_as_float(ds[1]);
-    if (ALL || use_bias) tr = tr + bd;
-    X = X + tr;
+    X = X + (__uint_as_float(ds[0]) + __uint_as_float(ds[1]));
 }
-__device__ __forceinline__ float layer_body_dpp2(const float (&wc)[32], const float (&wd)[16], float bfg, float gcv, float bd,
-                                                 const ActCoef& coef, float& X, float pre, float lcv, bool use_bias, bool has_gc,
-                                                 bool has_lc)
+// one layer's chain operands, register-resident for the whole launch (micro-benchmarks)
+struct LayerRegs {
+    float wc[32];          // tap-1 conv kernel column of this lane's conv output
+    float wd[16];          // this lane's half of the dense kernel column
+    float bd_init;         // dense_bias_init
+};
+__device__ __forceinline__ float layer_body_dpp(const LayerRegs& W, const ActCoef& coef, float& X, float addend)
 {
-    const float z = layer_front_dpp<false>(wc, bfg, gcv, coef, X, pre, lcv, use_bias, has_gc, has_lc);
-    layer_back_dpp<false>(wd, bd, z, X, use_bias);
+    const float z = layer_front_dpp(W.wc, coef, X, addend);
+    layer_back_dpp(W.wd, W.bd_init, z, X);
     return z;
-}
-__device__ __forceinline__ float layer_body_dpp(const LayerRegs& W, const ActCoef& coef, float& X, float pre, float lcv,
-                                                bool use_bias = true, bool has_gc = true, bool has_lc = true)
-{
-    return layer_body_dpp2(W.wc, W.wd, W.bfg, W.gcv, W.bd, coef, X, pre, lcv, use_bias, has_gc, has_lc);
 }
 
 // The causal layer's chunk (model.py:41-46) with the newest sample split off: the queue holds the last 32 inputs, k = 31 the newest.

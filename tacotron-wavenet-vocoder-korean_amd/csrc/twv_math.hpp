@@ -1,7 +1,7 @@
 // twv_math.hpp -- gfx950 device implementations of the arithmetic contract's elementary functions
 // (DESIGN.md "AC-2").  Every fusion is an explicit fma; the translation unit is built with
-// -ffp-contract=off, IEEE division, f32 subnormals kept -- so these return the same bits as the
-// CPU checker.  Replaces tf.tanh / tf.sigmoid / tf.exp / tf.log as called by
+// -ffp-contract=off, IEEE division (exp / log / float64 forms; tanh and the logistic carry no division since round 5),
+// f32 subnormals kept -- so these return the same bits as the CPU checker.  Replaces tf.tanh / tf.sigmoid / tf.exp / tf.log as called by
 // wavenet/model.py:86 and wavenet/mixture.py:103-111 and np.log/np.exp/np.logaddexp of
 // generate.py:219-222 (implementations live in TensorFlow/Eigen/numpy, un-vendored).
 #pragma once
@@ -13,18 +13,23 @@ namespace twv {
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ float div_(float a, float b) { return __fdiv_rn(a, b); }
 
-// ---- tanh / sigmoid: Eigen-3.3-style rationals (odd P / even Q) -------------------------------
-// Unified form used by the gated unit: the filter half-wave evaluates tanh, the gate half-wave the
-// logistic, with the SAME instruction stream and per-lane coefficients.  Leading zero coefficients
-// reproduce the shorter Horner chains exactly (fma(x2, +0, c) == c).
+// ---- tanh / sigmoid: Eigen-3.3-style rationals (odd P / even Q), AC-2 as of round 5 ---------------------------
+// The same rational P(x^2) x / Q(x^2) (+ 0.5 for the logistic) with the same coefficients as rounds 1-4, evaluated for a lone wave
+// of the generation chain, which is ISSUE-bound (a layer is ~117 instructions at ~4.5 clocks each: profiles/r05_chain_contract_ubench.txt):
+// numerator and denominator by Estrin's scheme (t = x^2, t^2, t^4), and instead of the IEEE division (v_div_scale x2, v_rcp_f32,
+// five fmas, v_div_fmas, v_div_fixup: 12 instructions behind BOTH polynomials) a software-specified reciprocal of the denominator
+// that runs next to the numerator: integer seed kRcpMagic - bits(Q) (within 5.1 % for every positive normal Q), one cubic and one
+// quadratic Newton step in fma, then ONE fma(x P, r, half).  18 instructions instead of 24, dependency depth 12 instead of 21,
+// every one an IEEE operation gcc reproduces (oracle/mathfn.c: act_eval).  Q is positive and normal on the clamped domain.
+// Unified form used by the gated unit: the filter half-wave evaluates tanh, the gate half-wave the logistic, with the SAME
+// instruction stream and per-lane coefficients (zero coefficients reproduce the shorter polynomials exactly: fma(t, +0, c) == c).
+constexpr unsigned kRcpMagic = 0x7EF311C7u;
 struct ActCoef {
-    float clampv, a13, a11, a9, a7, a5, a3, a1, b10, b8, b6, b4, b2, b0;
-    int is_sig;
+    float clampv, a1, a3, a5, a7, a9, a11, a13, b0, b2, b4, b6, b8, b10, half;
 };
 __device__ __forceinline__ ActCoef act_coef(bool sig)
 {
     ActCoef c;
-    c.is_sig = sig ? 1 : 0;
     c.clampv = sig ? 18.0f : 9.0f;
     c.a13 = sig ? 0.0f : -2.76076847742355e-16f;
     c.a11 = sig ? 0.0f : 2.00018790482477e-13f;
@@ -39,64 +44,58 @@ __device__ __forceinline__ ActCoef act_coef(bool sig)
     c.b4 = sig ? 1.70198817374094e-03f : 1.18534705686654e-04f;
     c.b2 = sig ? 1.16817656904453e-01f : 2.26843463243900e-03f;
     c.b0 = sig ? 9.93151921023180e-01f : 4.89352518554385e-03f;
+    c.half = sig ? 0.5f : -0.0f;          // x + (-0) == x for every x, signed zeros included
     return c;
 }
+// the reciprocal and the final fma (shared tail of every form)
+__device__ __forceinline__ float act_tail(float xp, float Q, float half)
+{
+    float r = __uint_as_float(kRcpMagic - __float_as_uint(Q));
+    float e = fma_(-Q, r, 1.0f);
+    const float s = fma_(e, e, e);
+    r = fma_(r, s, r);                    // cubic step: r (1 + e + e^2)
+    e = fma_(-Q, r, 1.0f);
+    r = fma_(r, e, r);                    // quadratic step
+    return fma_(xp, r, half);
+}
+// scalar form: throughput code (many independent evaluations per thread: Tacotron attention scores, GRU gates)
 __device__ __forceinline__ float act_eval(const ActCoef& c, float x)
 {
     x = x < -c.clampv ? -c.clampv : (x > c.clampv ? c.clampv : x);
-    const float x2 = x * x;
-    float p = fma_(x2, c.a13, c.a11);
-    p = fma_(x2, p, c.a9);
-    p = fma_(x2, p, c.a7);
-    p = fma_(x2, p, c.a5);
-    p = fma_(x2, p, c.a3);
-    p = fma_(x2, p, c.a1);
-    p = x * p;
-    float q = fma_(x2, c.b10, c.b8);
-    q = fma_(x2, q, c.b6);
-    q = fma_(x2, q, c.b4);
-    q = fma_(x2, q, c.b2);
-    q = fma_(x2, q, c.b0);
-    const float r = div_(p, q);
-    return c.is_sig ? r + 0.5f : r;
+    const float t = x * x, t2 = t * t, t4 = t2 * t2;
+    const float p01 = fma_(c.a3, t, c.a1), p23 = fma_(c.a7, t, c.a5), p45 = fma_(c.a11, t, c.a9);
+    const float q01 = fma_(c.b2, t, c.b0), q23 = fma_(c.b6, t, c.b4), q45 = fma_(c.b10, t, c.b8);
+    const float p456 = fma_(c.a13, t2, p45);
+    const float p03 = fma_(p23, t2, p01), q03 = fma_(q23, t2, q01);
+    const float P = fma_(p456, t4, p03), Q = fma_(q45, t4, q03);
+    return act_tail(x * P, Q, c.half);
 }
-// Latency-oriented form for the generation chain wave (one evaluation per layer on a lone wave, where instruction count is
-// what matters): the odd numerator polynomial p (6 Horner steps) and the even denominator q (5 steps) share the multiplier
-// x^2, so steps 2..6 of p run packed with steps 1..5 of q (v_pk_fma_f32) -- the same fmas, half the instructions.  In
-// throughput code (many independent evaluations per thread, e.g. the Tacotron attention scores) the scalar form above is
-// faster (measured: 13.7 vs 15.3 ms per Tacotron pass).
+// Latency-oriented form for the generation chain wave (one evaluation per layer on a lone wave, where instruction count is what
+// matters): the steps of P and Q that share a multiplier run packed (v_pk_fma_f32) -- the same fmas, fewer instructions.
 typedef float f32x2m __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float act_eval_pk_clamped(const ActCoef& c, float x)
+{
+    const float t = x * x;
+    const f32x2m tt = {t, t};
+    const f32x2m pq01 = __builtin_elementwise_fma(f32x2m{c.a3, c.b2}, tt, f32x2m{c.a1, c.b0});
+    const f32x2m pq23 = __builtin_elementwise_fma(f32x2m{c.a7, c.b6}, tt, f32x2m{c.a5, c.b4});
+    const f32x2m pq45 = __builtin_elementwise_fma(f32x2m{c.a11, c.b10}, tt, f32x2m{c.a9, c.b8});
+    const float t2 = t * t;
+    const float p456 = fma_(c.a13, t2, pq45[0]);
+    const float t4 = t2 * t2;
+    const f32x2m pq03 = __builtin_elementwise_fma(pq23, f32x2m{t2, t2}, pq01);
+    const f32x2m PQ = __builtin_elementwise_fma(f32x2m{p456, pq45[1]}, f32x2m{t4, t4}, pq03);
+    return act_tail(x * PQ[0], PQ[1], c.half);
+}
 __device__ __forceinline__ float act_eval_pk(const ActCoef& c, float x)
 {
     x = x < -c.clampv ? -c.clampv : (x > c.clampv ? c.clampv : x);
-    const float x2 = x * x;
-    const f32x2m xx = {x2, x2};
-    f32x2m pq = {fma_(x2, c.a13, c.a11), c.b10};
-    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a9, c.b8});
-    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a7, c.b6});
-    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a5, c.b4});
-    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a3, c.b2});
-    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a1, c.b0});
-    const float p = x * pq[0];
-    const float r = div_(p, pq[1]);
-    return c.is_sig ? r + 0.5f : r;
+    return act_eval_pk_clamped(c, x);
 }
-// the same with the clamp as ONE v_med3_f32 (three dependent instructions fewer per layer of the generation chain); identical for
-// every non-NaN input (a NaN input stays NaN in both forms' consumers: the rational of a NaN is NaN)
+// the same with the clamp as ONE v_med3_f32; identical for every non-NaN input
 __device__ __forceinline__ float act_eval_pk_med3(const ActCoef& c, float x)
 {
-    x = __builtin_amdgcn_fmed3f(x, -c.clampv, c.clampv);
-    const float x2 = x * x;
-    const f32x2m xx = {x2, x2};
-    f32x2m pq = {fma_(x2, c.a13, c.a11), c.b10};
-    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a9, c.b8});
-    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a7, c.b6});
-    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a5, c.b4});
-    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a3, c.b2});
-    pq = __builtin_elementwise_fma(xx, pq, f32x2m{c.a1, c.b0});
-    const float p = x * pq[0];
-    const float r = div_(p, pq[1]);
-    return c.is_sig ? r + 0.5f : r;
+    return act_eval_pk_clamped(c, __builtin_amdgcn_fmed3f(x, -c.clampv, c.clampv));
 }
 __device__ __forceinline__ float tanh_e(float x) { return act_eval(act_coef(false), x); }
 __device__ __forceinline__ float sigmoid_e(float x) { return act_eval(act_coef(true), x); }

@@ -310,11 +310,10 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
     // right after its last use in the current layer, so the LDS latency hides under the rest of the layer.
     Tile w1;                           // tap-1 conv tile                (re-fetched after the conv)
     Tile wd;                           // dense half tile                (re-fetched after the dense conv)
-    float pre, bfg, gcv, lcv, bd;      // tap-0 chunk (by a loader), biases, gc / lc projections
+    float pre, bd;                     // the conv's addend ((tap-0 chunk + bias) + gc) + lc (summed by a loader, AC-1b), dense bias
     auto fetch_conv = [&](int sb, int l) {
         lds_tile(w1, sb + SlotOff::T1, lane);
-        const f32x4 q = LDS4(((sb + SlotOff::PK) >> 2) + lane);   // packed by the loader
-        pre = q.x; bfg = q.y; gcv = q.z; lcv = q.w;
+        pre = lds[sb + SlotOff::PK + lane];
         (void)l;
     };
     auto fetch_dense = [&](int sb) {
@@ -398,12 +397,9 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
             const bool have_next = item + 1 < total;
             const int rdy = have_next ? LDSVI(c.o_ready + slot_n) : 0x7fffffff;
 
-            // model.py:68-69 conv_filter | conv_gate: chunk(tap0) [precomputed by a loader] + chunk(tap1)
-            const float acc1 = dot_readlane_pipe(w1, x);
-            float v = pre + acc1;
-            if (use_bias) v = v + bfg;
-            if (has_gc) v = v + gcv;      // model.py:71-73
-            if (has_lc) v = v + lcv;      // model.py:75-83
+            // model.py:68-69 conv_filter | conv_gate + model.py:71-83 conditioning: the tap-1 chunk, its chain 0 started from the addend
+            // ((chunk(tap 0) + bias) + gc) + lc a loader has summed (AC-1b)
+            const float v = dot_readlane_pipe_init(w1, x, pre);
             if (fine) pp[74] = __builtin_amdgcn_s_memtime();
             // conv operands of the NEXT item -> registers (latency hides under the gated unit and the dense conv)
             // (fetched unconditionally: guarding the fetch with `have_next` made the tile a two-way merge and cost 33 register
@@ -420,8 +416,7 @@ __device__ __forceinline__ void chain_main(const GenArgs& a, const Ctx& c, int& 
             if (fine) pp[75] = __builtin_amdgcn_s_memtime();
 
             // model.py:89 dense 1x1, model.py:98-101 residual
-            float tr = dot_readlane_pipe(wd, z);
-            if (use_bias) tr = tr + bd;
+            const float tr = dot_readlane_pipe_init(wd, z, bd);      // the bias is the start value of chain 0 (AC-1b)
             x = x + tr;
             fetch_dense(sbn);
             if (INSTR && a.dbg != nullptr && c.g == 0 && t < a.dbg_steps) {
@@ -532,12 +527,12 @@ __device__ __forceinline__ void loader_main(const GenArgs& a, const Ctx& c, rsrc
                 // chain wave's critical path: acc0[lane] = sum_c T0[c][lane] * x[t-d][c]   (one AC-1 chunk)
                 const int sbA = c.o_slots + slotA * SlotOff::FLOATS;
                 const int xsrc = LDSI(c.o_meta + layA) == 1 ? c.o_ring1 + layA * 32 : sbA + SlotOff::XO;
-                f32x4 pk;
-                pk.x = dot_ldso(t0A, xsrc);
-                pk.y = L.use_bias ? lds[sbA + SlotOff::BFG + lane] : 0.0f;
-                pk.z = L.G > 0 ? lds[c.o_gc + layA * 64 + lane] : 0.0f;
-                pk.w = has_lc ? lds[sbA + SlotOff::LC + lane] : 0.0f;
-                LDS4(((sbA + SlotOff::PK) >> 2) + lane) = pk;
+                // AC-1b: the addend the chain starts its tap-1 chunk from, in the reference's statement order ((conv + bias) + gc) + lc
+                float ad = dot_ldso(t0A, xsrc);
+                if (L.use_bias) ad = ad + lds[sbA + SlotOff::BFG + lane];
+                if (L.G > 0) ad = ad + lds[c.o_gc + layA * 64 + lane];      // model.py:71-73
+                if (has_lc) ad = ad + lds[sbA + SlotOff::LC + lane];        // model.py:75-83
+                lds[sbA + SlotOff::PK + lane] = ad;
             }
             publish(c.o_ready + slotA, itemA + 1, lane);
             if (aprof) a.prof[(long long)tA * 80 + 43] = __builtin_amdgcn_s_memtime();

@@ -141,8 +141,10 @@ __device__ __forceinline__ void nap_until(unsigned long long target)
 __device__ __forceinline__ int lane_of_z(int k) { return ((k & 2) ? 16 : 0) + 2 * (k >> 2) + (k & 1); }
 __device__ __forceinline__ int lane_of_x(int j) { return j < 16 ? j : 16 + j; }
 
-// a chain wave's per-layer registers (the dense kernel lives in LDS)
-struct ChainRegs { float wc[32]; float bfg, gcv, bd; };
+// a chain wave's per-layer registers (the dense kernel lives in LDS): tap-1 conv kernel, dense bias as the start value of the dense
+// chunk's chain 0 (AC-1b, twv_dpp.hpp: dense_bias_init).  Conv bias, gc and lc projections reach the chain inside the ADDEND the
+// service workgroup publishes.
+struct ChainRegs { float wc[32]; float bd; };
 
 // phase stamps (instrumented build only): lane 0 of stream 0's workgroups; s_memrealtime (100 MHz, ONE clock for the chip --
 // s_memtime counters of different CUs are offset against each other by milliseconds)
@@ -239,8 +241,7 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
 #pragma unroll
             for (int q = 0; q < 4; ++q) LDS4((O_WD >> 2) + ((lw0 + i) * 4 + q) * 64 + lane) = src[(8 + q) * 64];
             const f32x4 v = src[12 * 64];
-            W[i].bfg = v.x; W[i].bd = v.y;
-            W[i].gcv = has_gc ? a.cond[XH_WORDS + ((long long)b * NL + l0 + i) * 64 + oc] : 0.0f;     // model.py:71-73, hoisted
+            W[i].bd = dense_bias_init(lane, use_bias ? v.y : 0.0f);
         }
     }
     // wave 7: causal kernel (model.py:41-46), every lane the 32 taps of ITS residual channel (X layout), in the registers of the
@@ -345,8 +346,8 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
             __builtin_amdgcn_s_setprio(0);
         }
         XMARK(SEG1 ? 30 : ROLE_CHAIN, 1);
-        // ---- (A) this step's tap-0 chunks and lc projections of the wave's layers (service workgroup; long since published)
-        float pre[4] = {0.0f, 0.0f, 0.0f, 0.0f}, lcv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        // ---- (A) this step's addends of the wave's layers: ((tap-0 chunk + bias) + gc) + lc (service workgroup; long since published)
+        float pre[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (nlc > 0) {
             pl.it = 0;
             for (;;) {
@@ -355,9 +356,8 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                 for (int i = 0; i < 4; ++i) {
                     if (i < nlc) {
                         const unsigned long long qp = xb_load(rs, (int)XcdExch::PG + (l0 + i) * 64, oc);
-                        const unsigned long long ql = xb_load(rs, (int)XcdExch::LG + (l0 + i) * 64, oc);
-                        ok = ok && g_tag(qp) == tag && g_tag(ql) == tag;
-                        pre[i] = g_val(qp); lcv[i] = g_val(ql);
+                        ok = ok && g_tag(qp) == tag;
+                        pre[i] = g_val(qp);
                     }
                 }
                 if (__all(ok)) break;
@@ -412,12 +412,12 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                     const f32x4 v = LDS4((O_WD >> 2) + ((lw0 + i) * 4 + q) * 64 + lane);
                     wd[4 * q] = v.x; wd[4 * q + 1] = v.y; wd[4 * q + 2] = v.z; wd[4 * q + 3] = v.w;
                 }
-                const float z = layer_front_dpp<ALL>(W[i].wc, W[i].bfg, W[i].gcv, coef, X, pre[i], lcv[i], use_bias, has_gc, has_lc);
+                const float z = layer_front_dpp(W[i].wc, coef, X, pre[i]);
                 // one 16-byte store, two self-tagged halves: {z, tag} -> skip workgroups, {layer input, tag} -> service workgroup
                 // (model.py:145: the queue takes the layer INPUT)
                 if (DEFER) { zs[i] = z; xs[i] = X; }
                 else xb_store2(rs, (int)XcdExch::ZX + (l0 + i) * 128, lane, tag, z, X);
-                layer_back_dpp<ALL>(wd, W[i].bd, z, X, use_bias);
+                layer_back_dpp(wd, W[i].bd, z, X);
                 if ((INSTR & 2) && a.dbg != nullptr && t < a.dbg_steps) {
                     float* dp = a.dbg + ((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)(l0 + i) * 64;
                     if (lane < 32) dp[dpp_z_index(lane)] = z;
@@ -628,7 +628,7 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
     const Layout& L = a.lay;
     const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int NL = L.NL, T = a.T;
-    const bool has_lc = L.L > 0;
+    const bool has_lc = L.L > 0, use_bias = L.use_bias != 0, has_gc = L.G > 0;
     float* stb = a.state + (long long)b * L.state_stride;
     float* ring = stb + L.st_ring;
     const int* pmeta = reinterpret_cast<const int*>(a.P + L.off_meta);
@@ -647,9 +647,10 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
     Tile t0[kReg];
     unsigned dil[kSlots], roff[kSlots], pos0[kSlots];
     int lay_of[kSlots];
+    float bfg[kSlots], gcv[kSlots];          // conv bias (model.py:68-69) and the hoisted gc projection (model.py:71-73) of this lane's conv output
 #pragma unroll
     for (int i = 0; i < kSlots; ++i) {
-        dil[i] = 1; roff[i] = 0; pos0[i] = 0;
+        dil[i] = 1; roff[i] = 0; pos0[i] = 0; bfg[i] = 0.0f; gcv[i] = 0.0f;
         const bool is_lds = i < kLds;
         const int l = is_lds ? s + 8 * i : NLDS + s + 8 * (i - kLds);
         const bool have = is_lds ? i < nlds : (i - kLds) < nown;
@@ -659,8 +660,19 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
             if (is_lds) copy_tile_to_lds(l * (kTile / 4), src, lane);     // own layers only: written and read by this wave alone
             else load_tile(t0[i - kLds < 0 ? 0 : i - kLds], src, lane);
             dil[i] = (unsigned)pmeta[l]; roff[i] = (unsigned)pmeta[64 + l]; pos0[i] = (unsigned)ringpos[l];
+            if (use_bias) bfg[i] = a.P[L.off_layer0 + (long long)l * L.layer_stride + LayerOff::BFG + lane];
+            if (has_gc) gcv[i] = a.cond[XH_WORDS + ((long long)b * NL + l) * 64 + lane];
         }
     }
+    // AC-1b: what the chain starts its tap-1 chunk from -- the reference's statement order ((conv + bias) + gc) + lc (model.py:68-83)
+    // with conv = chunk(tap 0) + chunk(tap 1): everything but the tap-1 chunk, summed here, a step ahead of the chain
+    auto addend = [&](int i, float pre, float lcv) __attribute__((always_inline)) -> float {
+        float v = pre;
+        if (use_bias) v = v + bfg[i];
+        if (has_gc) v = v + gcv[i];
+        if (has_lc) v = v + lcv;
+        return v;
+    };
     const int n16 = lane & 15;
     // operand of the tap-0 chunk of step t: x[t-d] = the slot the delay line overwrites at step t
     auto tap0 = [&](int i, unsigned t, float& xa_, float& xb_) __attribute__((always_inline)) {
@@ -686,8 +698,7 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
             tap0(i, 0u, xa_, xb_);
             const float pre = dot_slot(i, xa_, xb_);
             const float lcv = has_lc ? stb[L.st_lcprev + l * 64 + lane] : 0.0f;     // frame pushed by the previous call (zeros after reset)
-            xb_store(rs, (int)XcdExch::PG + l * 64, lane, 1u, pre);
-            xb_store(rs, (int)XcdExch::LG + l * 64, lane, 1u, lcv);
+            xb_store(rs, (int)XcdExch::PG + l * 64, lane, 1u, addend(i, pre, lcv));
         }
     }
     for (int t = 0; t < T && !pl.dead; ++t) {
@@ -736,8 +747,7 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
                         if (pl.dead) break;
                         lcv = g_val(ql);
                     }
-                    xb_store(rs, (int)XcdExch::PG + l * 64, lane, tag + 1u, pre);
-                    xb_store(rs, (int)XcdExch::LG + l * 64, lane, tag + 1u, lcv);
+                    xb_store(rs, (int)XcdExch::PG + l * 64, lane, tag + 1u, addend(i, pre, lcv));
                 }
             }
         }
@@ -1320,13 +1330,13 @@ __device__ __forceinline__ void lc_role(const XArgs& xa, const XStreams<NS>& sx,
                     if (u + 1 < T) xb_store(rs, (int)XcdExch::LCR + (((u + 1) % kXcdLcRing) * kXcdLs + l) * 64, lane, (unsigned)u + 2u, r);
                     else {
                         // the frame the NEXT call uses at its step 0.  In a short call nothing has throttled this wave yet, and the service
-                        // workgroup may not have read the PREVIOUS call's frame from the same slot: it publishes that frame as LG tag 1 right
-                        // after reading it (found by a one-step call at batch 64: the many-streams service reads its second slot later)
+                        // workgroup may not have read the PREVIOUS call's frame from the same slot: its step-0 addend (PG tag 1) carries that
+                        // frame, so the tag says it has been read (found by a one-step call at batch 64: the many-streams service reads its second slot later)
                         if (T <= kXcdLcRing + 1) {
                             pl.rs = rs;
                             pl.it = 0;
                             for (;;) {
-                                const unsigned long long ql = xb_load_t<BAR>(rs, (int)XcdExch::LG + l * 64, lane);
+                                const unsigned long long ql = xb_load_t<BAR>(rs, (int)XcdExch::PG + l * 64, lane);
                                 if (__all(g_tag(ql) >= 1u)) break;
                                 if (!poll_tick<BAR>(pl, 73)) break;
                                 __builtin_amdgcn_s_sleep(8);
@@ -1427,24 +1437,23 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
         const int b = (int)xcc + 8 * k;
         const rsrc_t rs = exch_of(b);
         if (ticket < nchain) {
-            const bool all = a.lay.use_bias && a.lay.G > 0 && a.lay.L > 0;       // hparams default: no selects on the dependency chain
+            // (AC-1b: bias / gc / lc reach the chain inside the service workgroup's addend: the chain code does not depend on which of
+            // them the model has, every model takes the instantiations with the layer count folded)
             if (ticket % nseg == 0) {
                 // the sampling chain of the hparams-default model once per layer count of a wave (first chain workgroup: 4 or 3)
                 const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
                 const int nlw = a.lay.NL - (wv < 6 ? 4 * wv : 24 + 3 * (wv - 6));
-                if (forced) chain_role<INSTR, false, true, false, BIGK, -1, ONEHOT>(xa, b, rs);
-                else if (all && nlw >= 4 && wv < 6) chain_role<INSTR, true, false, false, BIGK, 4, ONEHOT, 0>(xa, b, rs);
-                else if (all && nlw >= 3 && wv == 6) chain_role<INSTR, true, false, false, BIGK, 3, ONEHOT, 0>(xa, b, rs);
-                else if (all && nlw >= 3 && wv == 7) chain_role<INSTR, true, false, false, BIGK, 3, ONEHOT, 1>(xa, b, rs);
-                else if (all) chain_role<INSTR, true, false, false, BIGK, -1, ONEHOT>(xa, b, rs);
-                else chain_role<INSTR, false, false, false, BIGK, -1, ONEHOT>(xa, b, rs);
+                if (forced) chain_role<INSTR, true, true, false, BIGK, -1, ONEHOT>(xa, b, rs);
+                else if (nlw >= 4 && wv < 6) chain_role<INSTR, true, false, false, BIGK, 4, ONEHOT, 0>(xa, b, rs);
+                else if (nlw >= 3 && wv == 6) chain_role<INSTR, true, false, false, BIGK, 3, ONEHOT, 0>(xa, b, rs);
+                else if (nlw >= 3 && wv == 7) chain_role<INSTR, true, false, false, BIGK, 3, ONEHOT, 1>(xa, b, rs);
+                else chain_role<INSTR, true, false, false, BIGK, -1, ONEHOT>(xa, b, rs);
             } else if constexpr (BIGK) {
                 // (the second chain workgroup has no head: nothing of it depends on the input / output type)
                 const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-                if (forced) chain_role<INSTR, false, true, true, true, -1>(xa, b, rs);
-                else if (all && a.lay.NL - kXcdSeg0Layers - 4 * wv >= 4) chain_role<INSTR, true, false, true, true, 4>(xa, b, rs);
-                else if (all) chain_role<INSTR, true, false, true, true, -1>(xa, b, rs);
-                else chain_role<INSTR, false, false, true, true, -1>(xa, b, rs);
+                if (forced) chain_role<INSTR, true, true, true, true, -1>(xa, b, rs);
+                else if (a.lay.NL - kXcdSeg0Layers - 4 * wv >= 4) chain_role<INSTR, true, false, true, true, 4>(xa, b, rs);
+                else chain_role<INSTR, true, false, true, true, -1>(xa, b, rs);
             }
         }
         else service_role<INSTR, BIGK>(xa, b, rs);
@@ -1617,9 +1626,7 @@ __device__ __forceinline__ void chain_many_role(const XArgs& xa, int xcc, int ns
 #pragma unroll
             for (int q = 0; q < 4; ++q) LDS4((kM_OWD >> 2) + ((l0 + i) * 4 + q) * 64 + lane) = src[(8 + q) * 64];
             const f32x4 v = src[12 * 64];
-            W[i].bfg = v.x; W[i].bd = v.y; W[i].gcv = 0.0f;
-            for (int s = 0; s < nslot; ++s)                      // model.py:71-73, hoisted: per stream
-                lds[kM_OGC + (s * kXcdSeg0Layers + l0 + i) * 64 + lane] = has_gc ? a.cond[XH_WORDS + ((long long)stream_of(s) * NL + l0 + i) * 64 + oc] : 0.0f;
+            W[i].bd = dense_bias_init(lane, use_bias ? v.y : 0.0f);
         }
     }
     // wave 7's per-slot state lives in LDS rows (kM_OHS) between a slot's turns: rows 0 ha, 1 hb (the causal queue, model.py:52, as two
@@ -1720,10 +1727,10 @@ __device__ __forceinline__ void chain_many_role(const XArgs& xa, int xcc, int ns
                 const int b = stream_of(s);
                 const rsrc_t rs = exch_rsrc(a, b);
                 pl.rs = rs;
-                float pre[4] = {0.0f, 0.0f, 0.0f, 0.0f}, lcv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                float pre[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 MMARK(rs, w, 3);
                 WACC_T0();
-                // (A) this step's tap-0 chunks and lc projections of the wave's layers (service workgroup; long since published)
+                // (A) this step's addends of the wave's layers: ((tap-0 chunk + bias) + gc) + lc (service workgroup; long since published)
                 pl.it = 0;
                 for (;;) {
                     bool ok = true;
@@ -1731,9 +1738,8 @@ __device__ __forceinline__ void chain_many_role(const XArgs& xa, int xcc, int ns
                     for (int i = 0; i < 4; ++i) {
                         if (i < nlc) {
                             const unsigned long long qp = xbm_load(rs, (int)XcdExch::PG + (l0 + i) * 64, oc);
-                            const unsigned long long ql = xbm_load(rs, (int)XcdExch::LG + (l0 + i) * 64, oc);
-                            ok = ok && g_tag(qp) == tag && g_tag(ql) == tag;
-                            pre[i] = g_val(qp); lcv[i] = g_val(ql);
+                            ok = ok && g_tag(qp) == tag;
+                            pre[i] = g_val(qp);
                         }
                     }
                     if (__all(ok)) break;
@@ -1767,11 +1773,10 @@ __device__ __forceinline__ void chain_many_role(const XArgs& xa, int xcc, int ns
                             const f32x4 v = LDS4((kM_OWD >> 2) + ((l0 + i) * 4 + qq) * 64 + lane);
                             wd[4 * qq] = v.x; wd[4 * qq + 1] = v.y; wd[4 * qq + 2] = v.z; wd[4 * qq + 3] = v.w;
                         }
-                        const float gcv = lds[kM_OGC + (s * kXcdSeg0Layers + l0 + i) * 64 + lane];
-                        const float z = layer_front_dpp<ALL>(W[i].wc, W[i].bfg, gcv, coef, X, pre[i], lcv[i], use_bias, has_gc, has_lc);
+                        const float z = layer_front_dpp(W[i].wc, coef, X, pre[i]);
                         xb_store2(rs, (int)XcdExch::ZX + (l0 + i) * 128, lane, tag, z, X);     // {z, tag} -> skip, {layer input, tag} -> service
                         WTRACE(xcc == 0 && c == 0 && s == 0, 64 + l0 + i);
-                        layer_back_dpp<ALL>(wd, W[i].bd, z, X, use_bias);
+                        layer_back_dpp(wd, W[i].bd, z, X);
                         if ((INSTR & 2) && a.dbg != nullptr && t < a.dbg_steps) {
                             float* dp = a.dbg + ((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)(l0 + i) * 64;
                             if (lane < 32) dp[dpp_z_index(lane)] = z;
@@ -1829,7 +1834,7 @@ __device__ __forceinline__ void service_many_role(const XArgs& xa, int xcc, int 
     const Layout& L = a.lay;
     const int sv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int NL = L.NL, T = a.T;
-    const bool has_lc = L.L > 0;
+    const bool has_lc = L.L > 0, use_bias = L.use_bias != 0, has_gc = L.G > 0;
     const int* pmeta = reinterpret_cast<const int*>(a.P + L.off_meta);
     constexpr int kReg = 4;
     int nown = 0;
@@ -1839,11 +1844,13 @@ __device__ __forceinline__ void service_many_role(const XArgs& xa, int xcc, int 
     bool ex[kMS];
     rsrc_t rsv[kMS];
     float* stb[kMS];
+    int bof[kMS];
 #pragma unroll
     for (int j = 0; j < kMS; ++j) {
         const int k = 2 * c + j;                               // the chain workgroup's two streams
         ex[j] = k < ns;
         const int b = ex[j] ? xcc + 8 * k : xcc + 8 * 2 * c;
+        bof[j] = b;
         rsv[j] = exch_rsrc(a, b);
         stb[j] = a.state + (long long)b * L.state_stride;
     }
@@ -1851,19 +1858,33 @@ __device__ __forceinline__ void service_many_role(const XArgs& xa, int xcc, int 
     WACC_DECL();
     Tile t0[kReg];
     unsigned dil[kReg], roff[kReg], pos0[kReg][kMS];
+    float bfg[kReg], gcv[kReg][kMS];         // conv bias and the hoisted gc projection (per stream) of this lane's conv output
 #pragma unroll
     for (int i = 0; i < kReg; ++i) {
-        dil[i] = 1; roff[i] = 0;
+        dil[i] = 1; roff[i] = 0; bfg[i] = 0.0f;
 #pragma unroll
-        for (int j = 0; j < kMS; ++j) pos0[i][j] = 0;
+        for (int j = 0; j < kMS; ++j) { pos0[i][j] = 0; gcv[i][j] = 0.0f; }
         if (i < nown) {
             const int l = sv + 8 * i;
             load_tile(t0[i], a.P + L.off_layer0 + (long long)l * L.layer_stride + LayerOff::T0, lane);
             dil[i] = (unsigned)pmeta[l]; roff[i] = (unsigned)pmeta[64 + l];
+            if (use_bias) bfg[i] = a.P[L.off_layer0 + (long long)l * L.layer_stride + LayerOff::BFG + lane];
 #pragma unroll
-            for (int j = 0; j < kMS; ++j) if (ex[j]) pos0[i][j] = (unsigned)reinterpret_cast<const int*>(stb[j] + L.st_ringpos)[l];
+            for (int j = 0; j < kMS; ++j) {
+                if (!ex[j]) continue;
+                pos0[i][j] = (unsigned)reinterpret_cast<const int*>(stb[j] + L.st_ringpos)[l];
+                if (has_gc) gcv[i][j] = a.cond[XH_WORDS + ((long long)bof[j] * NL + l) * 64 + lane];
+            }
         }
     }
+    // AC-1b addend (see service_role): ((tap-0 chunk + bias) + gc) + lc
+    auto addend = [&](int i, int j, float pre, float lcv) __attribute__((always_inline)) -> float {
+        float v = pre;
+        if (use_bias) v = v + bfg[i];
+        if (has_gc) v = v + gcv[i][j];
+        if (has_lc) v = v + lcv;
+        return v;
+    };
     const int n16 = lane & 15;
     auto tap0 = [&](const float* ring, unsigned pos0_, unsigned d_, unsigned roff_, unsigned t, float& xa_, float& xb_) __attribute__((always_inline)) {
         const unsigned slot = ring_slot(pos0_, t, d_);
@@ -1885,8 +1906,7 @@ __device__ __forceinline__ void service_many_role(const XArgs& xa, int xcc, int 
                 tap0(stb[j] + L.st_ring, pos0[i][j], dil[i], roff[i], 0u, xa_, xb_);
                 const float pre = dot32_dpp(t0[i].w, xa_, xb_);
                 const float lcv = has_lc ? stb[j][L.st_lcprev + l * 64 + lane] : 0.0f;
-                xb_store(rsv[j], (int)XcdExch::PG + l * 64, lane, 1u, pre);
-                xb_store(rsv[j], (int)XcdExch::LG + l * 64, lane, 1u, lcv);
+                xb_store(rsv[j], (int)XcdExch::PG + l * 64, lane, 1u, addend(i, j, pre, lcv));
             }
         }
     }
@@ -1940,8 +1960,7 @@ __device__ __forceinline__ void service_many_role(const XArgs& xa, int xcc, int 
                         if (pl.dead) continue;
                         lcv = g_val(ql);
                     }
-                    xb_store(rs, (int)XcdExch::PG + l * 64, lane, tag + 1u, pre);
-                    xb_store(rs, (int)XcdExch::LG + l * 64, lane, tag + 1u, lcv);
+                    xb_store(rs, (int)XcdExch::PG + l * 64, lane, tag + 1u, addend(i, j, pre, lcv));
                 }
             }
         }
@@ -2301,12 +2320,12 @@ __device__ __forceinline__ void lc_many_role(const XArgs& xa, int xcc, int ns, i
                     if (u + 1 < T) xb_store(rs, (int)XcdExch::LCR + (((u + 1) % kXcdLcRing) * kXcdLs + l) * 64, lane, (unsigned)u + 2u, r);
                     else {
                         // the frame the NEXT call uses at its step 0; in a short call wait until the service workgroup has read the
-                        // previous call's frame from the same slot (it publishes it as LG tag 1 right after reading it; see lc_role)
+                        // previous call's frame from the same slot (its step-0 addend, PG tag 1, carries that frame; see lc_role)
                         if (T <= kXcdLcRing + 1) {
                             pl.rs = rs;
                             pl.it = 0;
                             for (;;) {
-                                const unsigned long long ql = xbm_load(rs, (int)XcdExch::LG + l * 64, lane);
+                                const unsigned long long ql = xbm_load(rs, (int)XcdExch::PG + l * 64, lane);
                                 if (__all(g_tag(ql) >= 1u)) break;
                                 if (!poll_tick<true>(pl, 73)) break;
                                 __builtin_amdgcn_s_sleep(8);
@@ -2352,14 +2371,14 @@ __global__ void __launch_bounds__(512) wn_xcd_many_kernel(XArgs xa)
     if (!roles_resident(xa)) return;                            // the device is busy: nobody starts (status 90)
     const bool forced = a.forced != nullptr;
     if (ticket < nch) {
-        const bool all = a.lay.use_bias && a.lay.G > 0 && a.lay.L > 0;
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const int nlw = a.lay.NL - (wv < 6 ? 4 * wv : 24 + 3 * (wv - 6));
-        if (forced) chain_many_role<INSTR, false, true, -1>(xa, (int)xcc, ns, ticket);
-        else if (all && nlw >= 4 && wv < 6) chain_many_role<INSTR, true, false, 4>(xa, (int)xcc, ns, ticket);
-        else if (all && nlw >= 3 && wv >= 6) chain_many_role<INSTR, true, false, 3>(xa, (int)xcc, ns, ticket);
-        else if (all) chain_many_role<INSTR, true, false, -1>(xa, (int)xcc, ns, ticket);
-        else chain_many_role<INSTR, false, false, -1>(xa, (int)xcc, ns, ticket);
+        // (AC-1b: bias / gc / lc reach the chain inside the service workgroup's addend, so the chain code no longer depends on which of
+        // them a model has: one set of instantiations serves every model)
+        if (forced) chain_many_role<INSTR, true, true, -1>(xa, (int)xcc, ns, ticket);
+        else if (nlw >= 4 && wv < 6) chain_many_role<INSTR, true, false, 4>(xa, (int)xcc, ns, ticket);
+        else if (nlw >= 3 && wv >= 6) chain_many_role<INSTR, true, false, 3>(xa, (int)xcc, ns, ticket);
+        else chain_many_role<INSTR, true, false, -1>(xa, (int)xcc, ns, ticket);
         return;
     }
     if (ticket < 2 * nch) { service_many_role<INSTR>(xa, (int)xcc, ns, ticket - nch); return; }

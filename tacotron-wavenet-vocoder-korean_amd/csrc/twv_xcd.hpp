@@ -24,8 +24,8 @@ enum { XLC_NONE = 0, XLC_UPSAMPLED = 1, XLC_MEL = 2 };
 // exchange area of one stream, in 8-byte granules {tag, value}
 struct XcdExch {
     static constexpr long long ZX = 0;                                  // [Ls][64] x {z, tag | layer input, tag}: chain -> skip | service
-    static constexpr long long PG = ZX + kXcdLs * 128;                  // [Ls][64] tap-0 chunk                 service -> chain
-    static constexpr long long LG = PG + kXcdLs * 64;                   // [Ls][64] lc projection               service -> chain
+    static constexpr long long PG = ZX + kXcdLs * 128;                  // [Ls][64] addend ((tap-0 chunk + bias) + gc) + lc (AC-1b)   service -> chain
+    static constexpr long long LG = PG + kXcdLs * 64;                   // [Ls][64] (unused since round 5: the lc projection travels inside the addend)
     static constexpr long long H1 = LG + kXcdLs * 64;                   // [512] relu(skip sum)                 skip -> conv1
     static constexpr long long PT = H1 + 512;                           // [16][32] conv1d_2 chunk partials     conv1 -> sampler
     static constexpr long long LCR = PT + 512;                          // [ring][Ls][64] lc projections        lc -> service
