@@ -231,7 +231,8 @@ void twvo_cdot_rows(const float* w, int ncols, const float* x, int K, float* out
  * that is added to the contraction anyway and is known before the chunk's operand exists (the earlier chunks, the bias, the gc and lc
  * projections) -- so no add follows the dot product on the dependency chain.
  *   twvo_cdot_rows_head: r[j] = the chunks before the last one, added in order (AC-1); returns 0 when there is none (K <= 32)
- *   twvo_cdot_rows_tail: out[j] = (s0 + s1) + (s2 + s3) of the last chunk with s0 started from addend[j] (s1..s3 from +0) */
+ *   twvo_cdot_rows_tail: out[j] = (s0 + s1) + (s2 + s3) of the last chunk with s0 started from addend[j] and s1..s3 from their FIRST
+ *                        PRODUCT (= an fma chain from -0): the kernels need no zero-initialised accumulators for them */
 int twvo_cdot_rows_head(const float* w, int ncols, const float* x, int K, float* r)
 {
     const int klast = ((K - 1) / 32) * 32;
@@ -243,7 +244,7 @@ void twvo_cdot_rows_tail(const float* w, int ncols, const float* x, int K, const
 {
     const int k0 = ((K - 1) / 32) * 32;
     for (int j = 0; j < ncols; ++j) {
-        float s[4] = { addend[j], 0.0f, 0.0f, 0.0f };
+        float s[4] = { addend[j], -0.0f, -0.0f, -0.0f };   /* fmaf(w, x, -0) == w * x: chains 1..3 start from their first product */
         for (int k = k0; k < K; ++k) s[(k - k0) & 3] = fmaf(w[(size_t)k * ncols + j], x[k], s[(k - k0) & 3]);
         out[j] = (s[0] + s[1]) + (s[2] + s[3]);
     }

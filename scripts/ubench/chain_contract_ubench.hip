@@ -11,6 +11,7 @@
 //            of 6), the division replaced by a software-specified reciprocal of the denominator -- integer seed 0x7EF311C7 - bits(Q)
 //            (5 % off), one cubic and one quadratic Newton step, all fmaf -- that runs NEXT TO the numerator, result fma(x P, r, half)
 //   C4  C1 + C3        C5  C2 + C3
+//   C7  C5 + chains 1..3 (dense: the lane's second chain, and chain 2) start from their first product instead of +0 (priced after C5 was adopted)
 //   C6  (a)  C0's bits with the tap-1 chunk as v_readlane + v_pk_fma_f32 (two accumulators per register pair) instead of DPP fmacs
 // Shapes: R registers only | P product shape (dense kernel from LDS, one 16-byte granule store per layer, run-time layer count)
 //         | D product shape with the granule stores DEFERRED to behind the wave's last layer (a scheduling change, not a contract)
@@ -263,6 +264,80 @@ __device__ __forceinline__ float dot16_dpp_init(const float (&w)[16], float z, f
         : "v"(z), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
     return c0 + c1;
 }
+// contract C7: chain 0 from the addend, chains 1..3 from their FIRST PRODUCT (v_mul_f32_dpp: no zero-initialised accumulators;
+// fma(w, x, -0) == w * x for every w, x, so a C restatement starts those chains from -0)
+__device__ __forceinline__ float dot32_dpp_pf(const float (&w)[32], float xa, float xb, float init)
+{
+    float c0 = init, c1, c2, c3;
+    asm volatile(
+        "s_nop 1\n" TWV_ALIGN8
+        "v_fmac_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+        "v_mul_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+        "v_mul_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+        "v_mul_f32_dpp %3, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %10 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %19 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %20 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
+        : "v"(xa), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
+    asm volatile(
+        TWV_ALIGN8
+        "v_fmac_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %10 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %19 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %20 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+        : "v"(xb), "v"(w[16]), "v"(w[17]), "v"(w[18]), "v"(w[19]), "v"(w[20]), "v"(w[21]), "v"(w[22]), "v"(w[23]), "v"(w[24]), "v"(w[25]), "v"(w[26]), "v"(w[27]), "v"(w[28]), "v"(w[29]), "v"(w[30]), "v"(w[31]));
+    return (c0 + c1) + (c2 + c3);
+}
+// dense half chunk: the lane's first chain from `init` (even rows: the bias = chain 0; odd rows: -0 = chain 2's first product), its
+// second chain from the first product
+__device__ __forceinline__ float dot16_dpp_pf(const float (&w)[16], float z, float init)
+{
+    float c0 = init, c1;
+    asm volatile(
+        "s_nop 1\n" TWV_ALIGN8
+        "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+        "v_mul_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(c0), "=&v"(c1)
+        : "v"(z), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
+    return c0 + c1;
+}
 // (a) C0's chunk through scalar broadcasts: x[k] -> SGPR with v_readlane, two packed accumulators (chains 0|1 and 2|3)
 __device__ __forceinline__ float dot32_readlane_pk(const float (&w)[32], float X)
 {
@@ -281,7 +356,7 @@ __device__ __forceinline__ float dot32_readlane_pk(const float (&w)[32], float X
 }
 
 // ---------------------------------------------------------------- the layer body under contract C
-struct LayerIn { float pre, bfg, gcv, lcv, A, bd, bd_init; };
+struct LayerIn { float pre, bfg, gcv, lcv, A, bd, bd_init, bd_init7; };
 template <int C>
 __device__ __forceinline__ float front(const float (&wc)[32], const LayerIn& p, const ac2_r04::ActCoef& co, const ActCoef2& co2, float X)
 {
@@ -297,18 +372,24 @@ __device__ __forceinline__ float front(const float (&wc)[32], const LayerIn& p, 
             v = v + p.bfg; v = v + p.gcv; v = v + p.lcv;
         } else if (C == 1 || C == 4) {
             v = dot32_dpp(wc, xa, xb) + p.A;
+        } else if (C == 7) {
+            v = dot32_dpp_pf(wc, xa, xb, p.A);
         } else {
             v = dot32_dpp_init(wc, xa, xb, p.A);
         }
     }
-    const float act = (C >= 3 && C <= 5) ? act2_pk(co2, v) : ac2_r04::act_eval_pk_med3(co, v);
+    const float act = ((C >= 3 && C <= 5) || C == 7) ? act2_pk(co2, v) : ac2_r04::act_eval_pk_med3(co, v);
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
     return __uint_as_float(sw[0]) * __uint_as_float(sw[1]);
 }
 template <int C>
 __device__ __forceinline__ void back(const float (&wd)[16], const LayerIn& p, float z, float& X)
 {
-    if (C == 2 || C == 5) {
+    if (C == 7) {
+        const float s = dot16_dpp_pf(wd, z, p.bd_init7);
+        const auto ds = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+        X = X + (__uint_as_float(ds[0]) + __uint_as_float(ds[1]));
+    } else if (C == 2 || C == 5) {
         const float s = dot16_dpp_init(wd, z, p.bd_init);
         const auto ds = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
         X = X + (__uint_as_float(ds[0]) + __uint_as_float(ds[1]));
@@ -328,13 +409,14 @@ __global__ void __launch_bounds__(64) layer_ref_kernel(const LayerCanon* Lc, con
     const int lane = threadIdx.x;
     const ac2_r04::ActCoef coef = ac2_r04::act_coef(lane >= 32);
     const ActCoef2 coef2 = act_coef2(lane >= 32);
-    constexpr bool presum = (C == 1 || C == 2 || C == 4 || C == 5), init = (C == 2 || C == 5), act2 = (C >= 3 && C <= 5);
+    constexpr bool presum = (C == 1 || C == 2 || C == 4 || C == 5 || C == 7), init = (C == 2 || C == 5 || C == 7), act2 = ((C >= 3 && C <= 5) || C == 7);
+    constexpr float z0 = (C == 7) ? -0.0f : 0.0f;             // C7: the chains without a start value begin with their first product
     float x = x0[lane & 31];
     for (int t = 0; t < steps; ++t) {
         for (int l = 0; l < NLU; ++l) {
             const LayerCanon& P = Lc[l];
             const float A = ((P.pre[lane] + P.bfg[lane]) + P.gcv[lane]) + P.lcv[lane];
-            float s[4] = {init ? A : 0.0f, 0, 0, 0};
+            float s[4] = {init ? A : 0.0f, z0, z0, z0};
             for (int k = 0; k < 32; ++k) s[k & 3] = fma_(P.Wc[k][lane], __shfl(x, k), s[k & 3]);
             const float chunk = (s[0] + s[1]) + (s[2] + s[3]);
             float v;
@@ -343,7 +425,7 @@ __global__ void __launch_bounds__(64) layer_ref_kernel(const LayerCanon* Lc, con
             else { v = P.pre[lane] + chunk; v = v + P.bfg[lane]; v = v + P.gcv[lane]; v = v + P.lcv[lane]; }
             const float act = act2 ? act2_plain(coef2, v) : ac2_r04::act_eval(coef, v);
             const float z = __shfl(act, lane & 31) * __shfl(act, 32 + (lane & 31));
-            float q[4] = {init ? P.bd[lane & 31] : 0.0f, 0, 0, 0};
+            float q[4] = {init ? P.bd[lane & 31] : 0.0f, z0, z0, z0};
             for (int k = 0; k < 32; ++k) q[k & 3] = fma_(P.Wd[k][lane & 31], __shfl(z, k), q[k & 3]);
             float tr = (q[0] + q[1]) + (q[2] + q[3]);
             if (!init) tr = tr + P.bd[lane & 31];
@@ -381,6 +463,7 @@ __global__ void __launch_bounds__(64) layer_var_kernel(const LayerCanon* Lc, con
         in[l].A = ((in[l].pre + in[l].bfg) + in[l].gcv) + in[l].lcv;
         in[l].bd = Lc[l].bd[od];
         in[l].bd_init = ((lane >> 4) & 1) ? 0.0f : in[l].bd;        // chain 0 of the dense chunk lives on the even rows
+        in[l].bd_init7 = ((lane >> 4) & 1) ? -0.0f : in[l].bd;      // C7: the odd rows' first chain (chain 2) starts from its first product
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(gran, 0, 1 << 20, 0x00020000);
     float X = x0[od];
@@ -555,5 +638,6 @@ int main()
     run_contract<3>("C3  (c) Estrin rational + software reciprocal", dL, dx0, dxa, dxb, dc, gran, steps, base_p);
     run_contract<4>("C4  (b) + (c)", dL, dx0, dxa, dxb, dc, gran, steps, base_p);
     run_contract<5>("C5  (b') + (c)", dL, dx0, dxa, dxb, dc, gran, steps, base_p);
+    run_contract<7>("C7  C5 + the chains without a start value begin with their first product   [= the product's contract since round 5: AC-1b / AC-2]", dL, dx0, dxa, dxb, dc, gran, steps, base_p);
     return 0;
 }

@@ -80,12 +80,12 @@ __global__ void __launch_bounds__(64) layer_ref_kernel(const LayerCanon* Lc, con
     for (int t = 0; t < steps; ++t) {
         for (int l = 0; l < NLU; ++l) {
             const LayerCanon& P = Lc[l];
-            float s[4] = {((P.pre[lane] + P.bfg[lane]) + P.gcv[lane]) + P.lcv[lane], 0, 0, 0};      // AC-1b: chain 0 starts from the addend
+            float s[4] = {((P.pre[lane] + P.bfg[lane]) + P.gcv[lane]) + P.lcv[lane], -0.0f, -0.0f, -0.0f};      // AC-1b: chain 0 starts from the addend, the others from their first product
             for (int k = 0; k < 32; ++k) s[k & 3] = fma_(P.Wc[k][lane], __shfl(x, k), s[k & 3]);
             const float v = (s[0] + s[1]) + (s[2] + s[3]);
             const float act = act_eval(coef, v);
             const float z = __shfl(act, lane & 31) * __shfl(act, 32 + (lane & 31));
-            float q[4] = {P.bd[lane & 31], 0, 0, 0};                                                // AC-1b: the bias is the start value
+            float q[4] = {P.bd[lane & 31], -0.0f, -0.0f, -0.0f};                                    // AC-1b: the bias is the start value
             for (int k = 0; k < 32; ++k) q[k & 3] = fma_(P.Wd[k][lane & 31], __shfl(z, k), q[k & 3]);
             const float tr = (q[0] + q[1]) + (q[2] + q[3]);
             x = x + tr;

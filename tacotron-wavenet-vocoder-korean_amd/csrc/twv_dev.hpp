@@ -122,7 +122,7 @@ __device__ __forceinline__ float dot_readlane_pipe_a(const float (&tw)[32], floa
         : "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
     return (a[0] + a[1]) + (b[0] + b[1]);
 }
-// the same with chain 0 started from `init` instead of +0 (AC-1b: the last chunk of a contraction on the generation chain starts from
+// the same with chain 0 started from `init` and chains 1..3 from their first product (= from -0) instead of +0 (AC-1b: the last chunk of a contraction on the generation chain starts from
 // the addend -- earlier chunks, bias, conditioning -- so no add follows the dot product on the sample-to-sample path)
 __device__ __forceinline__ float dot_readlane_pipe_init_a(const float (&tw)[32], float xv, float init)
 {
@@ -139,7 +139,7 @@ __device__ __forceinline__ float dot_readlane_pipe_init_a(const float (&tw)[32],
         "v_pk_fma_f32 %[a], %[p0], s[84:85], %[i]\n"
         "v_readlane_b32 s90, %[x], 6\n"
         "v_readlane_b32 s91, %[x], 7\n"
-        "v_pk_fma_f32 %[b], %[p1], s[86:87], 0 op_sel_hi:[1,1,0]\n"
+        "v_pk_mul_f32 %[b], %[p1], s[86:87]\n"
         "v_readlane_b32 s92, %[x], 8\n"
         "v_readlane_b32 s93, %[x], 9\n"
         "v_pk_fma_f32 %[a], %[p2], s[88:89], %[a]\n"
@@ -179,7 +179,7 @@ __device__ __forceinline__ float dot_readlane_pipe_init_a(const float (&tw)[32],
         "v_pk_fma_f32 %[a], %[p14], s[96:97], %[a]\n"
         "v_pk_fma_f32 %[b], %[p15], s[98:99], %[b]"
         : [a] "=&v"(a), [b] "=&v"(b)
-        : [x] "v"(xv), [i] "v"(f32x2p{init, 0.0f}),
+        : [x] "v"(xv), [i] "v"(f32x2p{init, -0.0f}),
           [p0] "v"(f32x2p{tw[0], tw[1]}),
           [p1] "v"(f32x2p{tw[2], tw[3]}),
           [p2] "v"(f32x2p{tw[4], tw[5]}),

@@ -242,6 +242,81 @@ __device__ __forceinline__ float dot16_dpp(const float (&w)[16], float z, float 
     return c0 + c1;
 }
 
+// ---- the two contractions ON the generation chain (AC-1b): chain 0 starts from the addend, the other chains from their FIRST PRODUCT
+// (v_mul_f32_dpp -- no zero-initialised accumulators: four v_mov fewer per layer; fma(w, x, -0) == w * x for every w and x, so the C
+// restatement starts those chains from -0: oracle/mathfn.c twvo_cdot_rows_tail).  profiles/r05_chain_contract_ubench.txt, contract C7.
+__device__ __forceinline__ float dot32_dpp_chain(const float (&w)[32], float xa, float xb, float init)
+{
+    float c0 = init, c1, c2, c3;
+    asm volatile(
+        "s_nop 1\n" TWV_ALIGN8
+        "v_fmac_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+        "v_mul_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+        "v_mul_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+        "v_mul_f32_dpp %3, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %10 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %19 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %20 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3)
+        : "v"(xa), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
+    asm volatile(
+        TWV_ALIGN8
+        "v_fmac_f32_dpp %0, %4, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %7 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %10 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %13 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %14 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %15 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %4, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %4, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %2, %4, %19 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %3, %4, %20 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+        : "v"(xb), "v"(w[16]), "v"(w[17]), "v"(w[18]), "v"(w[19]), "v"(w[20]), "v"(w[21]), "v"(w[22]), "v"(w[23]), "v"(w[24]), "v"(w[25]), "v"(w[26]), "v"(w[27]), "v"(w[28]), "v"(w[29]), "v"(w[30]), "v"(w[31]));
+    return (c0 + c1) + (c2 + c3);
+}
+// dense half chunk: the lane's first chain from `init` (even rows: the bias = chain 0; odd rows: -0 = chain 2's first product), its
+// second chain from the first product
+__device__ __forceinline__ float dot16_dpp_chain(const float (&w)[16], float z, float init)
+{
+    float c0 = init, c1;
+    asm volatile(
+        "s_nop 1\n" TWV_ALIGN8
+        "v_fmac_f32_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n"
+        "v_mul_f32_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n"
+        "v_fmac_f32_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(c0), "=&v"(c1)
+        : "v"(z), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
+    return c0 + c1;
+}
 // model.py:66-101 for one step of one stream, in two halves so that the caller can publish z between them.
 // front: X (X layout) -> z (Z layout).  AC-1b (round 5): `addend` = ((tap-0 chunk + bias) + gc) + lc -- the reference's statement
 // order ((conv + bias) + gc) + lc (model.py:68-83) with conv = chunk(tap 0) + chunk(tap 1) -- is computed OFF the chain (service
@@ -250,17 +325,18 @@ __device__ __forceinline__ float dot16_dpp(const float (&w)[16], float z, float 
 __device__ __forceinline__ float layer_front_dpp(const float (&wc)[32], const ActCoef& coef, float X, float addend)
 {
     const auto xs = __builtin_amdgcn_permlane32_swap(__float_as_uint(X), __float_as_uint(X), false, false);
-    const float v = dot32_dpp(wc, __uint_as_float(xs[0]), __uint_as_float(xs[1]), addend);
+    const float v = dot32_dpp_chain(wc, __uint_as_float(xs[0]), __uint_as_float(xs[1]), addend);
     const float act = act_eval_pk_med3(coef, v);                             // model.py:86: lanes 0-31 tanh, 32-63 logistic
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
     return __uint_as_float(sw[0]) * __uint_as_float(sw[1]);
 }
 // back: model.py:89 dense 1x1 of z, model.py:98-101 residual; X in / out in the X layout.  bd_init: the dense bias on the lanes that
-// hold chain 0 of the chunk (even rows), +0 on the odd rows (dense_bias_init): the bias is the chain's start value (AC-1b).
-__device__ __forceinline__ float dense_bias_init(int lane, float bd) { return ((lane >> 4) & 1) ? 0.0f : bd; }
+// hold chain 0 of the chunk (even rows), -0 on the odd rows, whose first chain is chain 2: it starts from its first product
+// (dense_bias_init): the bias is the start value of chain 0 (AC-1b).
+__device__ __forceinline__ float dense_bias_init(int lane, float bd) { return ((lane >> 4) & 1) ? -0.0f : bd; }
 __device__ __forceinline__ void layer_back_dpp(const float (&wd)[16], float bd_init, float z, float& X)
 {
-    const float s = dot16_dpp(wd, z, bd_init);
+    const float s = dot16_dpp_chain(wd, z, bd_init);
     const auto ds = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
     X = X + (__uint_as_float(ds[0]) + __uint_as_float(ds[1]));
 }
