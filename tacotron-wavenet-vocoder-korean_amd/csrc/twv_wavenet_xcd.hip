@@ -49,6 +49,9 @@ using namespace twv;
 #ifndef TWV_CHAIN_PAD
 #define TWV_CHAIN_PAD 0
 #endif
+#ifndef TWV_WATCHDOG_LOG2
+#define TWV_WATCHDOG_LOG2 21            // polls before a wait gives up (a tuning build may lower it: -DTWV_WATCHDOG_LOG2=14 finds a deadlock in milliseconds)
+#endif
 #define TWV_STR2(x) #x
 #define TWV_STR(x) TWV_STR2(x)
 namespace {
@@ -122,7 +125,7 @@ __device__ __forceinline__ bool poll_tick(Poll& p, int code)
     if (p.dead) return false;
     if (((++p.it) & 63) == 0) {
         if (xb_load_t<BAR>(p.rs, (int)XcdExch::CTRL + 1, 0) != 0ull) { p.dead = true; return false; }
-        if (p.it > (1 << 21)) {
+        if (p.it > (1 << TWV_WATCHDOG_LOG2)) {
             atomicMax(p.status, code);
             xb_store(p.rs, (int)XcdExch::CTRL + 1, 0, 1u, 0.0f);
             p.dead = true;
