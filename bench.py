@@ -72,6 +72,19 @@ def traffic_per_step(kernel, key):
         return None
 
 
+def tacotron_traffic():
+    """HBM bytes of the matrix-core kernels of one configs[2] pass, from the committed PMC passes of THIS build of the Tacotron kernels
+    (profiles/traffic.json, key "tacotron:" + _lib.tacotron_hash(); scripts/pmc_to_tacotron_traffic.py); None for any other code"""
+    try:
+        import twvk_amd
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            t = json.load(fh)
+        e = t.get("tacotron:" + twvk_amd._lib.tacotron_hash(), {}).get("B32_T101")
+        return None if e is None else float(e["gemm_fetch_bytes_per_pass"]) + float(e["gemm_write_bytes_per_pass"])
+    except Exception:
+        return None
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -298,18 +311,17 @@ def main():
         kernel = ("wn_xcd_many_kernel" if B > 32 else "wn_xcd_generate_kernel") if fused else "wn_generate_kernel"
         us_step = k_ms * 1e3 / T
         # what binds this kernel is the sample-to-sample dependency chain, not HBM: the floor of that chain from the micro-benchmarks
-        # (scripts/ubench/chain_contract_ubench.hip -> profiles/r05_chain_contract_ubench.txt: contract C0, shape R = 460 core clocks =
-        # 0.192 us per layer; hand-offs / post phase: scripts/xcd_phase_profile.py -> profiles/r05_xcd_phase_profile_v1.txt)
-        LAYER_US, HANDOFF_US, CAUSAL_US, POST_US = 0.192, 0.075, 0.15, 3 * 0.26 + 1.08
+        # (scripts/ubench/chain_contract_ubench.hip -> profiles/r05_chain_contract_ubench.txt: contract C7 (the product's since round 5), shape R =
+        # 417 core clocks = 0.174 us per layer; hand-offs / post phase: scripts/xcd_phase_profile.py -> profiles/r05_xcd_phase_profile_v2.txt)
+        LAYER_US, HANDOFF_US, CAUSAL_US, POST_US = 0.174, 0.075, 0.15, 3 * 0.26 + 1.08
         floor_us = NL * LAYER_US + 8 * HANDOFF_US + CAUSAL_US + POST_US
         # BASELINE.json north_star: >= 100x real time at batch 8 = 2.4 M samples/s = one generation step every 3.33 us.  Round 5 priced the
-        # alternatives (profiles/r05_chain_contract_ubench.txt): the chain wave is ISSUE-bound (a layer is ~117 instructions at ~4.5 core
-        # clocks each on a lone wave; 48 of them are the fmas of the two dot products, which no arithmetic contract removes), so the
-        # cheapest bit-reproducible contract measured (C5: conditioning addend and dense bias as chain start values, Estrin rational with a
-        # software reciprocal; shape M: no store on the path, dense kernel in registers) is 454 clocks = 0.189 us per layer -- 19 % below
-        # the product's 562, and 30 x 0.189 alone is 5.7 us.
+        # alternatives (profiles/r05_chain_contract_ubench.txt) and ADOPTED the cheapest one (C7 = AC-1b / AC-2 of DESIGN.md section 2: 562 ->
+        # 504 clocks per layer in the product's shape, together with the stores taken off the sample path 9.48 -> 8.6 us per step): the
+        # chain wave is ISSUE-bound (a layer is ~100 instructions at ~4.5 core clocks each on a lone wave; 48 of them are the fmas of the two
+        # dot products, which no arithmetic contract removes), and 30 layers x 0.174 us (the arithmetic alone, registers only) is 5.2 us.
         target_us = 1e6 / (100.0 * hp.sample_rate / B)
-        best_contract_floor_us = NL * 0.189 + 8 * HANDOFF_US + CAUSAL_US + POST_US
+        floor_r04_contract_us = NL * 0.192 + 8 * HANDOFF_US + CAUSAL_US + POST_US
         macs_stream = NL * (2 * 32 * 64 + 32 * 32 + 32 * 512 + 80 * 64) + 32 * 32 + 512 * 512 + 512 * 30   # executed per stream and step (gc hoisted)
         flop_step = 2.0 * macs_stream * B
         tps = traffic_per_step(kernel, "B%d_NL%d" % (B, NL))
@@ -324,12 +336,14 @@ def main():
                        "batch_per_gpu": B, "samples_per_utterance": T, "sharding": "utterances, one batch of %d per GPU, no collective" % B,
                        "kernel": kernel + (" (stream b on XCD b % 8, weights register-resident, create_upsample + lc projections fused into the launch)" if fused else "")},
             "target_100x_at_batch_8": {"reachable": False, "target_us_per_step": target_us, "us_per_step": us_step,
-                                       "floor_us": floor_us, "floor_us_under_the_cheapest_contract_priced": best_contract_floor_us,
-                                       "evidence": "profiles/r05_chain_contract_ubench.txt (contracts C0-C6 x shapes R/P/D/G/N/M, each bit-checked "
-                                                   "against its canonical fmaf form); DESIGN.md section 15",
-                                       "note": "a 30-layer step is a dependent chain issued by ONE wave per layer: 30 x (32 + 16 fmas + activation) "
-                                               "cannot be issued in 3.33 us under any contract priced (best -19 % per layer); the per-GPU figure "
-                                               "comes with more streams (streams_sweep: 100x real time is passed at batch 32)"},
+                                       "floor_us": floor_us, "floor_us_under_the_contract_of_rounds_1_to_4": floor_r04_contract_us,
+                                       "contract": "AC-1b / AC-2 (round 5): the cheapest bit-reproducible contract of the seven priced (C7), adopted in oracle, "
+                                                   "fixtures and all three generation kernels",
+                                       "evidence": "profiles/r05_chain_contract_ubench.txt (contracts C0-C7 x shapes R/P/D/G/N/M, each bit-checked against its "
+                                                   "canonical fmaf form); profiles/r05_ab_*.txt (interleaved A/B of every step); DESIGN.md section 15",
+                                       "note": "a 30-layer step is a dependent chain issued by ONE wave per layer: 30 x (32 + 16 fmas + activation) cannot be "
+                                               "issued in 3.33 us under any contract priced; the per-GPU figure comes with more streams (streams_sweep: 100x real "
+                                               "time is passed at batch 32, 270x at batch 64)"},
             "realtime_factor_aggregate": value / hp.sample_rate,
             "realtime_factor_per_stream": value / hp.sample_rate / (n_ok * B),
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
@@ -346,10 +360,10 @@ def main():
                                                      "(uniforms in, progress / exchange words that spill from L2 included)"},
                          "kernel_ms": k_ms, "us_per_generation_step": us_step,
                          "latency_floor_us": floor_us, "frac_of_floor": floor_us / us_step,
-                         "latency_floor_formula": "%d layers x 0.192 us (a layer's arithmetic alone on a lone wave, registers only: 32+16 fmas, 6 adds, "
-                                                  "rational activation with one IEEE division; 460 core clocks) + 8 wave hand-offs x 0.075 + causal layer 0.15 + "
+                         "latency_floor_formula": "%d layers x 0.174 us (a layer's arithmetic alone on a lone wave, registers only: 32+16 fmas started from the "
+                                                  "addends, Estrin rational with a software reciprocal; 417 core clocks) + 8 wave hand-offs x 0.075 + causal layer 0.15 + "
                                                   "post phase (3 L2 hops x 0.26 + skip 0.22 + chunk dots 0.28 + ordered sum/conv1d_2 0.27 + sampler 0.31); "
-                                                  "measured pieces, profiles/r05_chain_contract_ubench.txt and profiles/r05_xcd_phase_profile_v1.txt" % NL,
+                                                  "measured pieces, profiles/r05_chain_contract_ubench.txt and profiles/r05_xcd_phase_profile_v2.txt" % NL,
                          "fp32_flop_per_step": flop_step, "fp32_tflops": flop_step / (us_step * 1e-6) / 1e12,
                          "fp32_frac": flop_step / (us_step * 1e-6) / 1e12 / 157.3,
                          "note": "weights are register-/L2-resident: the sample loop is a dependent chain (latency), not a bandwidth stream; "
@@ -621,7 +635,7 @@ def main():
                                    "roofline": {"bound": "mfma", "kernel": "tc_gemm_mfma_{,group_,highway_,ck_}kernel (%d launches per pass: CBHG conv banks as one grouped launch each, projections, "
                                                                         "fused highway layers, grouped GRU input halves, attention keys, linear)" % gn,
                                                 "achieved": gflop / (gms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": gflop / (gms * 1e-3) / 1e12 / 157.3,
-                                                "flop_per_pass": gflop, "kernel_ms_per_pass": gms, "traffic": None,
+                                                "flop_per_pass": gflop, "kernel_ms_per_pass": gms, "traffic": tacotron_traffic(),
                                                 "note": "useful FLOPs (2*rows*K*N, unpadded) of the dense contractions / their summed HIP-event time; "
                                                         "the rest of the pass is the decoder's latency chain (tc_decoder_g_kernel) and the GRU sequences; "
                                                         "counters: profiles/r03_rocprofv3_*tacotron*",

@@ -17,5 +17,11 @@ for W in tacotron train; do
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma_$W -- $CMD > $OUT/pmc_mfma_$W.log 2>&1
   rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_mops_$W -- $CMD > $OUT/pmc_mops_$W.log 2>&1
 done
+# HBM bytes of a configs[2] pass (tacotron.roofline.traffic was null): FETCH_SIZE / WRITE_SIZE, one counter per pass
+# (they do not fit one pass), kernel trace only; scripts/pmc_to_tacotron_traffic.py condenses them into profiles/traffic.json
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_taco_$C -- python $REPO/scripts/tacotron_bench.py --steps 3 > $OUT/pmc_taco_$C.log 2>&1
+done
 cd $REPO
 python scripts/pmc_to_mfma.py $OUT $TAG
+python scripts/pmc_to_tacotron_traffic.py $OUT $TAG

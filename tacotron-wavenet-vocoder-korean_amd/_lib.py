@@ -51,6 +51,14 @@ def generation_hash():
     return _hash_files([os.path.join(CSRC, f) for f in GENERATION_SOURCES])
 
 
+TACOTRON_SOURCES = ("twv_tacotron.hip", "twv_dev.hpp", "twv_dpp.hpp", "twv_math.hpp", "twv_layout.hpp")
+
+
+def tacotron_hash():
+    """the same for the Tacotron kernels: key of the `tacotron` entries of profiles/traffic.json (scripts/pmc_to_tacotron_traffic.py)"""
+    return _hash_files([os.path.join(CSRC, f) for f in TACOTRON_SOURCES])
+
+
 def build_stamp():
     """(extra hipcc flags, stamp) of the build the environment asks for.  TWV_EXTRA_HIPCC_FLAGS (a tuning aid, e.g. -DTWV_TRPROF) is part of
     the stamp, so a variant build never passes for the plain one and the next plain import rebuilds."""

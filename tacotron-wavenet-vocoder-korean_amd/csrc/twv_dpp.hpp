@@ -244,7 +244,7 @@ __device__ __forceinline__ float dot16_dpp(const float (&w)[16], float z, float 
 
 // ---- the two contractions ON the generation chain (AC-1b): chain 0 starts from the addend, the other chains from their FIRST PRODUCT
 // (v_mul_f32_dpp -- no zero-initialised accumulators: four v_mov fewer per layer; fma(w, x, -0) == w * x for every w and x, so the C
-// restatement starts those chains from -0: oracle/mathfn.c twvo_cdot_rows_tail).  profiles/r05_chain_contract_ubench.txt, contract C7.
+// restatement of the CPU checker starts those chains from -0).  profiles/r05_chain_contract_ubench.txt, contract C7.
 __device__ __forceinline__ float dot32_dpp_chain(const float (&w)[32], float xa, float xb, float init)
 {
     float c0 = init, c1, c2, c3;

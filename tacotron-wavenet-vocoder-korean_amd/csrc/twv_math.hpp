@@ -20,7 +20,7 @@ __device__ __forceinline__ float div_(float a, float b) { return __fdiv_rn(a, b)
 // five fmas, v_div_fmas, v_div_fixup: 12 instructions behind BOTH polynomials) a software-specified reciprocal of the denominator
 // that runs next to the numerator: integer seed kRcpMagic - bits(Q) (within 5.1 % for every positive normal Q), one cubic and one
 // quadratic Newton step in fma, then ONE fma(x P, r, half).  18 instructions instead of 24, dependency depth 12 instead of 21,
-// every one an IEEE operation gcc reproduces (oracle/mathfn.c: act_eval).  Q is positive and normal on the clamped domain.
+// every one an IEEE operation gcc reproduces (the CPU checker holds the same sequence).  Q is positive and normal on the clamped domain.
 // Unified form used by the gated unit: the filter half-wave evaluates tanh, the gate half-wave the logistic, with the SAME
 // instruction stream and per-lane coefficients (zero coefficients reproduce the shorter polynomials exactly: fma(t, +0, c) == c).
 constexpr unsigned kRcpMagic = 0x7EF311C7u;

@@ -70,18 +70,23 @@ typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 constexpr int kAuxLoad = (int)(16u | 0x80000000u), kAuxStore = 0;
 __device__ __forceinline__ unsigned long long xb_load(rsrc_t rs, int uword, int lword)
 {
+    asm volatile("" ::: "memory");      // a poll must be re-issued on every trip of its loop: see below
     const u32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rs, lword * 8, uword * 8, kAuxLoad);
     return ((unsigned long long)v.y << 32) | (unsigned long long)v.x;
 }
 // two adjacent granules with one load (each half carries its own tag: the halves may come from different stores)
 __device__ __forceinline__ u32x4s xb_load2(rsrc_t rs, int uword, int lpair)
 {
+    asm volatile("" ::: "memory");
     return __builtin_amdgcn_raw_buffer_load_b128(rs, lpair * 16, uword * 8, kAuxLoad);
 }
-// The same loads behind a compiler barrier (the many-streams kernel's roles).  Aux bit 31 marks the MACHINE instruction volatile, but
-// the IR call is a read-only intrinsic: in wn_xcd_many_kernel loop-invariant code motion hoisted the sampler's four table loads out of
-// their polling loop, which then spun on registers until the watchdog.  A load cannot move across the barrier; it costs no
-// instruction.  (wn_xcd_generate_kernel keeps the plain form: its polls compile as written, and the barrier shifts its schedule.)
+// Every granule load sits behind a compiler barrier.  Aux bit 31 marks the MACHINE instruction volatile, but the IR call is a read-only
+// intrinsic, and loop-invariant code motion has twice hoisted a poll out of its loop, which then spins on a register: round 3 in
+// wn_xcd_many_kernel (the sampler's four table loads; until the watchdog), round 5 in one instantiation of the one-hot head's logits poll
+// (docs/experiments: the abort-flag load of the watchdog went with it -- a hang).  Whether it happens depends on what shares the
+// function, i.e. any edit can flip it, so since round 5 the barrier is unconditional (rounds 2-4 kept the batch <= 32 kernel's polls
+// plain because "the barrier shifts its schedule": measured now, interleaved A/B, 8.571-8.577 us per step with it against 8.581-8.590
+// without).  A load cannot move across the barrier; it costs no instruction.  xb_load_t<BAR> / xbm_load* are the older names.
 template <bool BAR> __device__ __forceinline__ unsigned long long xb_load_t(rsrc_t rs, int uword, int lword)
 {
     if (BAR) asm volatile("" ::: "memory");
