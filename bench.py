@@ -288,7 +288,7 @@ def main():
                                       "achieved": flop_step / qdt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flop_step / qdt / 1e12 / 157.3,
                                       "flop_per_step": flop_step, "traffic": None,
                                       "note": "executed f32 matrix-core FLOPs only (2 x 3 x forward MACs of the dense contractions; per-kernel durations and "
-                                              "SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F32 counters: profiles/r03_rocprofv3_*train*)"},
+                                              "SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F32 counters: profiles/r05_rocprofv3_mfma_summary_tacotron_train_v1.txt, r05_rocprofv3_kernel_stats_train_c4_v1.csv)"},
                          "value": world * 64 * TT_ / qdt, "unit": "audio samples/s", "steps_per_s": 1.0 / qdt, "ms_per_step": qdt * 1e3,
                          "n_gpus": world, "scaling": "weak", "dtype": "f32",
                          "collective": "all-reduce(sum) of one flat f32 gradient buffer, %d elements, RCCL" % trn.n_params if world > 1 else "none (1 GPU)",
@@ -308,7 +308,7 @@ def main():
         bytes_per_step = wfloats * 4 + B * (80 + 1 + 1) * 4
         k_ms = float(np.mean(gen_ms))
         achieved = bytes_per_step * T / (k_ms * 1e-3) / 1e9
-        kernel = ("wn_xcd_many_kernel" if B > 32 else "wn_xcd_generate_kernel") if fused else "wn_generate_kernel"
+        kernel = ("wn_xcd_many_kernel" if B > 20 else "wn_xcd_generate_kernel") if fused else "wn_generate_kernel"
         us_step = k_ms * 1e3 / T
         # what binds this kernel is the sample-to-sample dependency chain, not HBM: the floor of that chain from the micro-benchmarks
         # (scripts/ubench/chain_contract_ubench.hip -> profiles/r05_chain_contract_ubench.txt: contract C7 (the product's since round 5), shape R =
@@ -340,7 +340,7 @@ def main():
                                        "contract": "AC-1b / AC-2 (round 5): the cheapest bit-reproducible contract of the seven priced (C7), adopted in oracle, "
                                                    "fixtures and all three generation kernels",
                                        "evidence": "profiles/r05_chain_contract_ubench.txt (contracts C0-C7 x shapes R/P/D/G/N/M, each bit-checked against its "
-                                                   "canonical fmaf form); profiles/r05_ab_*.txt (interleaved A/B of every step); DESIGN.md section 15",
+                                                   "canonical fmaf form); profiles/r05_ab_*.txt (interleaved A/B of every step); DESIGN.md sections 3, 11, 12",
                                        "note": "a 30-layer step is a dependent chain issued by ONE wave per layer: 30 x (32 + 16 fmas + activation) cannot be "
                                                "issued in 3.33 us under any contract priced; the per-GPU figure comes with more streams (streams_sweep: 100x real "
                                                "time is passed at batch 32, 270x at batch 64)"},
@@ -387,7 +387,7 @@ def main():
                                   "realtime_factor_aggregate": Bs * T1 / (kms * 1e-3) / hp.sample_rate,
                                   "realtime_factor_per_stream": T1 / (kms * 1e-3) / hp.sample_rate,
                                   "fp32_frac": 2.0 * macs_stream * Bs / (kms * 1e-3 / T1) / 1e12 / 157.3,
-                                  "kernel": ("wn_xcd_many_kernel" if Bs > 32 else "wn_xcd_generate_kernel") if ms.fused_conditioning() else "wn_generate_kernel"})
+                                  "kernel": ("wn_xcd_many_kernel" if Bs > 20 else "wn_xcd_generate_kernel") if ms.fused_conditioning() else "wn_generate_kernel"})
                     if ms is not m:
                         del ms
                 except Exception as e:
@@ -456,7 +456,7 @@ def main():
                 # causal kernel (2 x 256 x 32), conv1d_1, the 512 x 256 conv1d_2; I/O per stream: 80 lc floats, class in, class out, one f64 draw
                 q_wfloats = NL * per_layer + (512 * 512 + 512) + (512 * 256 + 256) + 2 * 256 * 32
                 q_bytes = q_wfloats * 4 + B * (80 * 4 + 4 + 4 + 8)
-                q_floor = NL * 0.200 + 8 * 0.075 + 0.18 + (4 * 0.26 + 0.22 + 0.28 + 0.12 + 0.17 + 0.12 + 1.55)
+                q_floor = NL * 0.174 + 8 * 0.075 + 0.18 + (4 * 0.26 + 0.22 + 0.28 + 0.12 + 0.17 + 0.12 + 1.55)
                 q_tps = traffic_per_step("wn_xcd_generate_kernel_onehot", "B%d_NL%d" % (B, NL)) if qfused else None
                 q_match = None
                 if not args.no_cpu_baseline:
@@ -478,10 +478,10 @@ def main():
                                                  "frac": q_bytes / (q_us * 1e-6) / 1e9 / 8000.0, "algorithmic_bytes_per_step": q_bytes,
                                                  "traffic": None if q_tps is None else q_tps * Tq, "measured_bytes_per_step": q_tps,
                                                  "kernel_ms": qms, "latency_floor_us": q_floor, "frac_of_floor": q_floor / q_us,
-                                                 "latency_floor_formula": "%d layers x 0.200 us + 8 wave hand-offs x 0.075 + causal row load 0.18 + post phase: 4 L2 hops x 0.26 "
+                                                 "latency_floor_formula": "%d layers x 0.174 us + 8 wave hand-offs x 0.075 + causal row load 0.18 + post phase: 4 L2 hops x 0.26 "
                                                                           "(z, h1, h2, logits) + skip 0.22 + conv1d_1 chunk dots 0.28 + ordered sum 0.12 + conv1d_2 chunk dot 0.17 + "
                                                                           "ordered sum 0.12 + sampler 1.55 (its ~850 VALU instructions at 4 cycles each, one wave, 2.2 GHz; measured 3.18); "
-                                                                          "pieces: profiles/r04_xcd_onehot_phase_profile_v1.txt" % NL,
+                                                                          "pieces: profiles/r05_chain_contract_ubench.txt, profiles/r05_xcd_onehot_phase_profile_v1.txt" % NL,
                                                  "note": "as for the headline kernel: weights are register-resident, the step is a dependent chain (latency), "
                                                          "algorithmic bytes assume every weight re-read per step (SURVEY.md 8d)"},
                                     "config": {"workload": "configs[1]'s stack with one-hot mu-law-256 input and a 256-way softmax output (model.py:223-227,243; "
@@ -602,7 +602,7 @@ def main():
                 tm.set_option("gemm_timing", 0)
                 # the decoder (tc_decoder_g_kernel: one persistent launch, 200 steps): per-step time = (200-step pass - 1-step pass) / 199,
                 # both without the post-net; its ruler is a latency floor, from the stamped anatomy of the same kernel
-                # (scripts/tacotron_phase_profile.py -> profiles/r04_tacotron_decoder_phase_profile.txt)
+                # (scripts/tacotron_phase_profile.py -> profiles/r05_tacotron_decoder_phase_profile.txt)
                 import copy
                 hp1 = copy.copy(hp); hp1.max_iters = 1
                 tm1 = Tacotron(hp1, num_speakers=2, device=dev)
@@ -615,7 +615,7 @@ def main():
                     return (time.perf_counter() - c0) / reps
                 dec_us = (_mel_only(tm) - _mel_only(tm1)) * 1e6 / (hp.max_iters - 1)
                 # pieces of one step (us, workgroup 0 of utterance 0, 160 steps averaged): everything that is not an exchange, and the hop
-                DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US = 19.84, 13, 0.27
+                DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US = 20.52, 13, 0.27
                 dec_floor = DEC_NONEXCH_US + DEC_EXCHANGES * DEC_HOP_US
                 del tm1
                 # other batch sizes on the same GPU (not the metric's configuration: the decoder is a latency chain, so more utterances
@@ -638,16 +638,16 @@ def main():
                                                 "flop_per_pass": gflop, "kernel_ms_per_pass": gms, "traffic": tacotron_traffic(),
                                                 "note": "useful FLOPs (2*rows*K*N, unpadded) of the dense contractions / their summed HIP-event time; "
                                                         "the rest of the pass is the decoder's latency chain (tc_decoder_g_kernel) and the GRU sequences; "
-                                                        "counters: profiles/r03_rocprofv3_*tacotron*",
+                                                        "counters: profiles/r05_rocprofv3_mfma_summary_tacotron_train_v1.txt, r05_rocprofv3_kernel_stats_tacotron_c3_v1.csv; HBM bytes (`traffic`): r05_rocprofv3_tacotron_traffic.txt",
                                                 "decoder": {"kernel": "tc_decoder_g_kernel (8 workgroups per utterance on one XCD, 11 matvec stages + attention, 13 all-gathers per step through that XCD's L2)",
                                                             "bound": "latency", "us_per_step": dec_us, "ms_per_pass": dec_us * hp.max_iters * 1e-3,
                                                             "latency_floor_us": dec_floor, "frac_of_floor": dec_floor / dec_us,
-                                                            "formula": "per step: tile dots 5.26 + chunk sums / bias / activation / publish 9.75 (of which ~0.4 per stage is the publish store waiting "
+                                                            "formula": "per step: tile dots 5.52 + chunk sums / bias / activation / publish 10.35 (of which ~0.4 per stage is the publish store waiting "
                                                                        "behind the next stage's first weight tiles in the CU's memory pipeline) + barriers and cell updates 2.00 + "
-                                                                       "attention compute 2.83 (score dots 1.20, monotonic recurrence 0.93, context dots 0.57, the rest 0.12) = %.2f us that is "
+                                                                       "attention compute 2.66 (score dots 1.02, monotonic recurrence 0.94, context dots 0.59, the rest 0.11) = %.2f us that is "
                                                                        "not exchange, + %d exchanges x %.2f us (one-way granule hop inside an XCD's L2 measured in isolation; in the kernel an "
-                                                                       "exchange averages 0.71 us incl. the cell update done on arrival: the polls queue behind the next stage's weight tiles); "
-                                                                       "profiles/r04_tacotron_decoder_phase_profile.txt (workgroups spread over the XCDs: ..._spread.txt; round 3: 41.4 us)" % (DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US)}},
+                                                                       "exchange averages 0.64 us incl. the cell update done on arrival: the polls queue behind the next stage's weight tiles); "
+                                                                       "profiles/r05_tacotron_decoder_phase_profile.txt (round 4: r04_..., spread placement r04_..._spread.txt; round 3: 41.4 us)" % (DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US)}},
                                    "config": {"workload": "configs[2]: Tacotron text->mel (CBHG encoder, monotonic Bahdanau attention decoder, post-CBHG, "
                                                           "linear), batch=32, 101 tokens, 200 decoder steps = 1000 mel frames/utterance, random-init weights"},
                                    "finite": bool(torch.isfinite(tmel).all().item())}

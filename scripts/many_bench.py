@@ -11,12 +11,14 @@ from twvk_amd import weights as W
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64); ap.add_argument("--seconds", type=float, default=1.0)
 ap.add_argument("--steps", type=int, default=2); ap.add_argument("--warmup", type=int, default=1)
+ap.add_argument("--many", type=int, default=-1, help="1 / 0: force the many-streams kernel on / off at batch <= 32 (option xcd_many); -1: the library's choice")
 args = ap.parse_args()
 B = args.batch
 T = int(args.seconds * 24000) // 300 * 300
 dil = [2 ** i for i in range(10)] * 3
 specs = W.tensor_specs(len(dil), 32, 32, 512, 256, 30, True, 32, True, 32, 2, 80, (5, 5, 12))
 m = make_model(B, dil, W.random_tensors(specs, seed=0, scale=0.05))
+if args.many >= 0: m.set_option("xcd_many", args.many)
 assert m.fused_conditioning()
 rng = np.random.RandomState(1)
 mel = torch.from_numpy(rng.uniform(-4, 4, (B, T // 300, 80)).astype(np.float32)).cuda()
@@ -39,5 +41,5 @@ for i in range(args.warmup + args.steps):
     if i >= args.warmup:
         ms.append(e0.elapsed_time(e1))
 k = float(np.mean(ms))
-print(json.dumps({"kernel": "wn_xcd_many_kernel" if B > 32 else "wn_xcd_generate_kernel", "streams": B, "steps_per_launch": T, "kernel_ms": k,
+print(json.dumps({"kernel": "wn_xcd_many_kernel" if (B > 32 or args.many == 1) else "wn_xcd_generate_kernel", "streams": B, "steps_per_launch": T, "kernel_ms": k,
                   "us_per_generation_step": k * 1e3 / T, "samples_per_s": B * T / (k * 1e-3), "finite": bool(torch.isfinite(out).all())}))

@@ -26,13 +26,22 @@ class Dims(C.Structure):
 GENERATION_SOURCES = ("twv_wavenet.hip", "twv_wavenet_xcd.hip", "twv_xcd.hpp", "twv_dpp.hpp", "twv_dev.hpp", "twv_categorical.hpp", "twv_math.hpp", "twv_layout.hpp")
 
 
-def _hash_files(files):
+def _code_only(text):
+    """C / C++ source with comments removed and white space collapsed: what the compiler sees, give or take a string literal"""
+    import re
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    return " ".join(text.split())
+
+
+def _hash_files(files, code_only=False):
     import hashlib
     h = hashlib.sha256()
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:
-            h.update(fh.read())
+            data = fh.read()
+        h.update(_code_only(data.decode("utf-8")).encode() if code_only else data)
     h.update(" ".join(HIPCC_FLAGS).encode())
     return h.hexdigest()[:16]
 
@@ -47,8 +56,9 @@ def source_hash():
 
 def generation_hash():
     """sha256 over the sources the two generation kernels are compiled from (and the flags): the key of profiles/traffic.json --
-    counter measurements of the generation kernel stay valid while only the Tacotron / training sources change."""
-    return _hash_files([os.path.join(CSRC, f) for f in GENERATION_SOURCES])
+    counter measurements of the generation kernel stay valid while only the Tacotron / training sources change -- or only COMMENTS do
+    (the hash is taken over the code with comments and white space removed: an edit of a comment does not orphan a measurement)."""
+    return _hash_files([os.path.join(CSRC, f) for f in GENERATION_SOURCES], code_only=True)
 
 
 TACOTRON_SOURCES = ("twv_tacotron.hip", "twv_dev.hpp", "twv_dpp.hpp", "twv_math.hpp", "twv_layout.hpp")
@@ -56,7 +66,7 @@ TACOTRON_SOURCES = ("twv_tacotron.hip", "twv_dev.hpp", "twv_dpp.hpp", "twv_math.
 
 def tacotron_hash():
     """the same for the Tacotron kernels: key of the `tacotron` entries of profiles/traffic.json (scripts/pmc_to_tacotron_traffic.py)"""
-    return _hash_files([os.path.join(CSRC, f) for f in TACOTRON_SOURCES])
+    return _hash_files([os.path.join(CSRC, f) for f in TACOTRON_SOURCES], code_only=True)
 
 
 def build_stamp():

@@ -1294,7 +1294,7 @@ struct twv_wavenet {
     int helpers;   // 1 = helper workgroups when the launch qualifies (conv1d_1, and conv1d_2's partials if O <= 32; default),
                    // 2 = conv1d_1 only, 0 = never
     int xcd;       // 1 (default) = the XCD-per-stream kernel (twv_wavenet_xcd.hip) whenever model, batch and device qualify; 0 = never
-    int xcd_many;  // 1 = its many-streams form (two streams per chain workgroup; what batch 33..64 runs) also at batch <= 32
+    int xcd_many;  // 0 = the library chooses (the many-streams form from batch 21 on), 1 = the many-streams form at every batch, 2 = never below batch 33
     unsigned long long* prof;
     int prof_steps;
 };
@@ -1507,8 +1507,10 @@ extern "C" int twv_wavenet_set_option(twv_wavenet* h, const char* name, int valu
         h->xcd = value;
         return TWV_OK;
     }
-    if (!strcmp(name, "xcd_many")) { // 1: the many-streams XCD kernel (two streams per chain workgroup) also at batch <= 32 (it is what batch 33..64 runs)
-        if (value != 0 && value != 1) return fail(TWV_E_INVALID, "xcd_many must be 0 or 1");
+    if (!strcmp(name, "xcd_many")) { // 0: the library chooses (round 5: the many-streams XCD kernel -- two streams per chain workgroup -- from batch 21 on: at
+                                     // batch 24 / 32 it runs at 9.54 / 9.60 us per step against the batch <= 32 kernel's 9.65 / 11.0), 1: the many-streams
+                                     // kernel at every batch, 2: the batch <= 32 kernel wherever it can run (tests, A/B)
+        if (value < 0 || value > 2) return fail(TWV_E_INVALID, "xcd_many must be 0, 1 or 2");
         h->xcd_many = value;
         return TWV_OK;
     }

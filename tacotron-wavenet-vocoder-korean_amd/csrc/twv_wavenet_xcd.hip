@@ -2476,7 +2476,7 @@ int xcd_launch(const XcdLaunch& p, hipStream_t st)
     xa.lc_lpw = lc_layers_per_wave(p.lay);
     // chain workgroup: hand-off boxes + the dense kernels of its layers (136 KiB); more than 32 layers: the skip / service workgroups
     // keep the tiles of layers 0 .. NL-41 in LDS next to their value slots (159 KiB of the CU's 160)
-    const bool many = p.lay.scalar && (p.B > kXcdStreams || p.many != 0) && p.lay.NL <= kXcdSeg0Layers && xcd_many_lc_fits(p.lay);
+    const bool many = p.lay.scalar && (p.B > kXcdStreams || p.many == 1 || (p.many == 0 && p.B >= kXcdManyFrom)) && p.lay.NL <= kXcdSeg0Layers && xcd_many_lc_fits(p.lay);
     xa.total_roles = 0;
     for (int x = 0; x < 8 && x < p.B; ++x) {
         const int ns = (p.B - x + 7) / 8;

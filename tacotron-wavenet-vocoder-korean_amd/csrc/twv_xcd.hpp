@@ -11,6 +11,7 @@ constexpr int kXcdSeg0Layers = 30;     // first chain workgroup: waves 0..5 four
 constexpr int kXcdMaxLayers = 50;      // a second chain workgroup takes layers 30.. (hparams.py has 50); limit: LDS of the service workgroup (tiles of layers 0 .. NL-33) and of the skip workgroups (value slots of two streams + tiles of layers 0 .. NL-41)
 constexpr int kXcdLs = 64;             // layer slots of the per-layer exchange arrays
 constexpr int kXcdStreams = 32;        // up to four streams per XCD (stream b runs on XCD b % 8), each with its own chain workgroup
+constexpr int kXcdManyFrom = 21;       // batch from which the many-streams kernel is the default choice (measured: B = 16 9.25 vs 9.57 us per step, B = 24 9.65 vs 9.54, B = 32 11.0 vs 9.60)
 constexpr int kXcdManyStreams = 96;    // the many-streams kernel (30 layers or fewer): up to twelve per XCD, two per chain workgroup
 constexpr int kXcdLcRing = 16;         // steps of lc projections the lc workgroups may run ahead of the chain
 constexpr int kXcdXlFloats = 13 * 64 * 4;   // per layer: the chain's register image [13 float4][64 lanes]
@@ -56,7 +57,7 @@ struct XcdLaunch {
     int prof_steps;
     int prof_stream;               // the stream whose workgroups stamp (0; TWV_XCD_PROF_STREAM picks another one: tuning aid)
     int B, T;
-    int many;                      // 1: the many-streams kernel even where batch <= 32 (option "xcd_many": tests, A/B runs)
+    int many;                      // option "xcd_many": 0 = from batch kXcdManyFrom on, 1 = at every batch, 2 = only above batch 32
     unsigned long long* exch;      // [B][XcdExch::WORDS]
     int* roles;                    // [8] role tickets per XCD (zeroed before the launch)
     Layout lay;

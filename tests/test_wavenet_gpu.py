@@ -727,6 +727,7 @@ def test_xcd_kernel_with_several_streams_per_xcd(torch_cuda, oracle, B):
     workgroups per XCD serving them in turn), 12 000 steps; bit for bit"""
     T = 12000
     m, mel, gc, seed_in, u, want = _bench_case(oracle, B, T)
+    m.set_option("xcd_many", 2)           # the batch <= 32 kernel (since round 5 the library takes the many-streams kernel from batch 21 on)
     assert m.fused_conditioning(), "up to 32 streams are served by the XCD kernel on an MI355X"
     got = m.generate(m.create_upsample(mel), gc, seed_in, u).cpu().numpy()
     assert first_mismatch(got, want) is None, first_mismatch(got, want)
@@ -946,7 +947,7 @@ def test_xcd_kernel_matches_generic_kernel(torch_cuda, oracle, B):
     u = mol_uniforms(B, T, 10)
     outs = []
     for xcd in (1, 0):
-        m = make_model(B, dil, tensors, xcd=xcd)
+        m = make_model(B, dil, tensors, xcd=xcd, xcd_many=2)      # 2: the batch <= 32 XCD kernel also where the library would take the many-streams one
         U = m.create_upsample(mel)
         a = m.generate(U[:, :500].contiguous(), gc, seed_in, u[:, :500]).cpu().numpy()
         b = m.generate(U[:, 500:].contiguous(), gc, a[:, -1], u[:, 500:]).cpu().numpy()
