@@ -364,8 +364,10 @@ __global__ __launch_bounds__(256) void tr_tn_reduce_kernel(const float* part, in
 // conv1d_2, 512 -> 30).  rocBLAS spends 0.6 ms on this 9-GFLOP product; it is a single pass over X.  Wave = 32 rows: every lane
 // reads 32 contiguous bytes of its row per 16-wide k step (lanes l and l+32 the two halves of one 64-byte piece) and feeds eight
 // v_mfma_f32_32x32x2_f32 with the k pairs (t, 8 + t); W sits in LDS as [k][32] (zero-padded columns).
+// XRELU: X holds pre-activations, the operand is relu(X[r][k] + xb[k]) (xb nullable, 16-byte aligned): the activation pass over X is never run.
+template <bool XRELU>
 __global__ __launch_bounds__(256) void tr_skinny_nn_kernel(const float* X, int ldx, const float* W, int ldw, const float* bias, long long rows, int K, int N,
-                                                           float* Y, int ldy)
+                                                           float* Y, int ldy, const float* xb)
 {
     extern __shared__ float wl[];                       // [K][32]
     for (int i = threadIdx.x; i < K * 32; i += 256) { const int k = i >> 5, n = i & 31; wl[i] = n < N ? W[(long long)k * ldw + n] : 0.0f; }
@@ -382,7 +384,14 @@ __global__ __launch_bounds__(256) void tr_skinny_nn_kernel(const float* X, int l
         for (int k0 = 0; k0 < K; k0 += 16) {
             float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
             if (rok) { a0 = *reinterpret_cast<const float4*>(xp + k0); a1 = *reinterpret_cast<const float4*>(xp + k0 + 4); }
-            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            if (XRELU) {                                 // (rows past the end: their outputs are not stored)
+                float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+                if (xb) { b0 = *reinterpret_cast<const float4*>(xb + k0 + half * 8); b1 = *reinterpret_cast<const float4*>(xb + k0 + half * 8 + 4); }
+                const float bv8[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int t = 0; t < 8; ++t) { const float v = av[t] + bv8[t]; av[t] = v > 0.0f ? v : 0.0f; }
+            }
 #pragma unroll
             for (int t = 0; t < 8; ++t)                  // lanes < 32 carry k = k0 + t, lanes >= 32 carry k = k0 + 8 + t
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], wl[(k0 + half * 8 + t) * 32 + col], acc, 0, 0, 0);
@@ -441,55 +450,89 @@ __global__ void tr_scatter_emb_kernel(const float* demb, const int32_t* ids, flo
 // one thread per (b, p); y (rows, 3*nr), target = audio[b, p + rf]
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigm_f(float x) { return 1.0f / (1.0f + expf(-x)); }
-__global__ void tr_mol_loss_kernel(const float* y, const float* audio, int B, int T, int ow, int rf, int nr, float inv_count,
-                                   float* row_loss, float* dy)
+// one row of the discretized mix-logistic loss and its analytic gradient (mixture.py:27-81): yr = the row's 3 nr outputs, dr = its gradient
+// (may alias yr: entry i, nr + i, 2 nr + i is read before it is written); returns the row's loss term.
+// NR > 0: the number of mixtures as a compile-time constant (hparams: out_channels 30 -> 10): the five per-mixture arrays stay in registers
+// (with a run-time count they lived in 400 bytes of scratch per thread: 0.36 GB read + 0.30 GB written per launch for 72 MB of I/O)
+template <int NR>
+__device__ __forceinline__ float tr_mol_row(const float* yr, float* dr, float tgt, int nr_, float inv_count)
+{
+    const int nr = NR > 0 ? NR : nr_;
+    constexpr int CAP = NR > 0 ? NR : 32;
+    const float lsmin = -32.23619130191664f, h = 1.0f / 65535.0f, logc = logf(65535.0f / 2.0f);
+    float lm = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < nr; ++i) lm = fmaxf(lm, yr[i]);
+    float se = 0.0f;
+#pragma unroll
+    for (int i = 0; i < nr; ++i) se += expf(yr[i] - lm);
+    const float lse_logit = lm + logf(se);
+    float a[CAP], dplus[CAP], dmin[CAP], dmid[CAP], dsdirect[CAP];
+    float amax = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < nr; ++i) {
+        const float mu = yr[nr + i], sraw = yr[2 * nr + i];
+        const float s = fmaxf(sraw, lsmin);
+        const float cen = tgt - mu, inv = expf(-s);
+        const float plus = inv * (cen + h), mn = inv * (cen - h), mid = inv * cen;
+        const float cp = sigm_f(plus), cm = sigm_f(mn), delta = cp - cm;
+        float lp;
+        dplus[i] = dmin[i] = dmid[i] = dsdirect[i] = 0.0f;
+        if (tgt < -0.999f) { lp = plus - softplus_f(plus); dplus[i] = 1.0f - cp; }
+        else if (tgt > 0.999f) { lp = -softplus_f(mn); dmin[i] = -cm; }
+        else if (delta > 1e-5f) { lp = logf(fmaxf(delta, 1e-12f)); dplus[i] = cp * (1.0f - cp) / delta; dmin[i] = -cm * (1.0f - cm) / delta; }
+        else { lp = mid - s - 2.0f * softplus_f(mid) - logc; dmid[i] = 1.0f - 2.0f * sigm_f(mid); dsdirect[i] = -1.0f; }
+        a[i] = lp + (yr[i] - lse_logit);
+        amax = fmaxf(amax, a[i]);
+    }
+    float sa = 0.0f;
+#pragma unroll
+    for (int i = 0; i < nr; ++i) sa += expf(a[i] - amax);
+    const float lse = amax + logf(sa);
+#pragma unroll
+    for (int i = 0; i < nr; ++i) {
+        const float w = expf(a[i] - lse);                      // softmax(a)
+        const float sm = expf(yr[i] - lse_logit);              // softmax(logits)
+        const float mu = yr[nr + i], sraw = yr[2 * nr + i];
+        const float s = fmaxf(sraw, lsmin);
+        const float cen = tgt - mu, inv = expf(-s);
+        const float plus = inv * (cen + h), mn = inv * (cen - h), mid = inv * cen;
+        const float dlp = -w;                                   // dL/dlp_i
+        const float gmu = dlp * (-(inv)) * (dplus[i] + dmin[i] + dmid[i]);
+        const float gs = dlp * (-(dplus[i] * plus + dmin[i] * mn + dmid[i] * mid) + dsdirect[i]);
+        dr[i] = (sm - w) * inv_count;
+        dr[nr + i] = gmu * inv_count;
+        dr[2 * nr + i] = (sraw > lsmin ? gs : 0.0f) * inv_count;
+    }
+    return -lse * inv_count;
+}
+// NR > 0: a workgroup's 256 rows (contiguous: 256 x 3 NR floats) travel through LDS in whole lines -- a thread reading its own 120-byte row
+// touched 64 cache lines per load instruction
+template <int NR>
+__global__ __launch_bounds__(256) void tr_mol_loss_kernel(const float* y, const float* audio, int B, int T, int ow, int rf, int nr, float inv_count,
+                                                          float* row_loss, float* dy)
 {
     const long long rows = (long long)B * ow;
-    GRID_STRIDE(r, rows) {
-        const int p = (int)(r % ow), b = (int)(r / ow);
-        const float tgt = audio[(long long)b * T + p + rf];
-        const float* yr = y + r * 3 * nr;
-        const float lsmin = -32.23619130191664f, h = 1.0f / 65535.0f, logc = logf(65535.0f / 2.0f);
-        float lm = -3.0e38f;
-        for (int i = 0; i < nr; ++i) lm = fmaxf(lm, yr[i]);
-        float se = 0.0f;
-        for (int i = 0; i < nr; ++i) se += expf(yr[i] - lm);
-        const float lse_logit = lm + logf(se);
-        float a[32], dplus[32], dmin[32], dmid[32], dsdirect[32];
-        float amax = -3.0e38f;
-        for (int i = 0; i < nr; ++i) {
-            const float mu = yr[nr + i], sraw = yr[2 * nr + i];
-            const float s = fmaxf(sraw, lsmin);
-            const float cen = tgt - mu, inv = expf(-s);
-            const float plus = inv * (cen + h), mn = inv * (cen - h), mid = inv * cen;
-            const float cp = sigm_f(plus), cm = sigm_f(mn), delta = cp - cm;
-            float lp;
-            dplus[i] = dmin[i] = dmid[i] = dsdirect[i] = 0.0f;
-            if (tgt < -0.999f) { lp = plus - softplus_f(plus); dplus[i] = 1.0f - cp; }
-            else if (tgt > 0.999f) { lp = -softplus_f(mn); dmin[i] = -cm; }
-            else if (delta > 1e-5f) { lp = logf(fmaxf(delta, 1e-12f)); dplus[i] = cp * (1.0f - cp) / delta; dmin[i] = -cm * (1.0f - cm) / delta; }
-            else { lp = mid - s - 2.0f * softplus_f(mid) - logc; dmid[i] = 1.0f - 2.0f * sigm_f(mid); dsdirect[i] = -1.0f; }
-            a[i] = lp + (yr[i] - lse_logit);
-            amax = fmaxf(amax, a[i]);
+    if constexpr (NR > 0) {
+        __shared__ float sy[256 * 3 * NR];
+        for (long long base = (long long)blockIdx.x * 256; base < rows; base += (long long)gridDim.x * 256) {
+            const int nrow = rows - base < 256 ? (int)(rows - base) : 256, ne = nrow * 3 * NR;
+            __syncthreads();
+            for (int e = threadIdx.x; e < ne; e += 256) sy[e] = y[base * 3 * NR + e];
+            __syncthreads();
+            if ((int)threadIdx.x < nrow) {
+                const long long r = base + threadIdx.x;
+                const int p = (int)(r % ow), b = (int)(r / ow);
+                float* row = sy + threadIdx.x * 3 * NR;
+                row_loss[r] = tr_mol_row<NR>(row, row, audio[(long long)b * T + p + rf], NR, inv_count);
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < ne; e += 256) dy[base * 3 * NR + e] = sy[e];
         }
-        float sa = 0.0f;
-        for (int i = 0; i < nr; ++i) sa += expf(a[i] - amax);
-        const float lse = amax + logf(sa);
-        row_loss[r] = -lse * inv_count;
-        float* dr = dy + r * 3 * nr;
-        for (int i = 0; i < nr; ++i) {
-            const float w = expf(a[i] - lse);                      // softmax(a)
-            const float sm = expf(yr[i] - lse_logit);              // softmax(logits)
-            const float mu = yr[nr + i], sraw = yr[2 * nr + i];
-            const float s = fmaxf(sraw, lsmin);
-            const float cen = tgt - mu, inv = expf(-s);
-            const float plus = inv * (cen + h), mn = inv * (cen - h), mid = inv * cen;
-            const float dlp = -w;                                   // dL/dlp_i
-            const float gmu = dlp * (-(inv)) * (dplus[i] + dmin[i] + dmid[i]);
-            const float gs = dlp * (-(dplus[i] * plus + dmin[i] * mn + dmid[i] * mid) + dsdirect[i]);
-            dr[i] = (sm - w) * inv_count;
-            dr[nr + i] = gmu * inv_count;
-            dr[2 * nr + i] = (sraw > lsmin ? gs : 0.0f) * inv_count;
+    } else {
+        GRID_STRIDE(r, rows) {
+            const int p = (int)(r % ow), b = (int)(r / ow);
+            row_loss[r] = tr_mol_row<0>(y + r * 3 * nr, dy + r * 3 * nr, audio[(long long)b * T + p + rf], nr, inv_count);
         }
     }
 }
@@ -532,6 +575,90 @@ __device__ __forceinline__ float tr_xor32(float v)
     return __uint_as_float((threadIdx.x & 32) ? sw[0] : sw[1]);
 }
 __device__ __forceinline__ f32x4t tr_ld4(const float* p, bool ok) { f32x4t z = {0.f, 0.f, 0.f, 0.f}; return ok ? *reinterpret_cast<const f32x4t*>(p) : z; }
+
+// conv1d_2's backward in ONE pass over the (rows, S) activations (model.py:161-165 backward), K = O <= 32, S % 64 == 0:
+//   dS[r][c]  = [Y1[r][c] + yb[c] > 0] * sum_k dY[r][k] * W2[c][k]        (input gradient with conv1d_1's relu backward)
+//   part[chunk][c]       = the chunk's column sums of dS                  (-> db1)
+//   wpart[chunk][c][32]  = the chunk's share of dW2[c][k] = sum_r relu(Y1[r][c] + yb[c]) * dY[r][k]
+// Before: a library product (K = 30: a 616 MB store), the relu-backward / column-sum pass over it (another 1.8 GB) and the tall-skinny
+// dW2 contraction (616 MB again) = 3.1 GB and 0.79 ms; this moves 1.27 GB.  yb == nullptr: no bias vector (mask = Y1 > 0; Y1 holds
+// PRE-activations either way: conv1d_1's own relu pass is never run, see the host code).
+// A wave keeps its 64 columns of W2 as MFMA B operands (lane (n, hh): W2[c][k = 16 hh + t]) for the whole launch and walks 32-row tiles.
+// Per tile: dY's rows twice (row layout = A operand of dS, C layout = B operand of dW2; 3.8 KB, L1 hits), 32 + 32 v_mfma_f32_32x32x2_f32;
+// both results come out in the C layout (lane = column) where the mask, the store, the column sum and the dW2 operand relu(Y1 + yb)
+// [row rho + 4 hh][c] need no exchange.  Waves of one column group: gw % CG == cg; two waves per SIMD cover each other's loads.
+__global__ __launch_bounds__(256, 2) void tr_conv2_bwd_kernel(const float* dY, int O, const float* W2, const float* Y1, const float* yb,
+                                                              long long rows, int S, float* dS, float* part, float* wpart)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 31, hh = lane >> 5;
+    const int CG = S >> 6, gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
+    const int cg = gw % CG, c0 = cg * 64;
+    float bw[2][16], bias[2], cs[2];
+    f32x16 wacc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = c0 + 32 * j + n;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { const int k = 16 * hh + t; bw[j][t] = k < O ? W2[(long long)c * O + k] : 0.0f; }
+        bias[j] = yb ? yb[c] : 0.0f;
+        cs[j] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wacc[j][i] = 0.0f;
+    }
+    const rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dY), 0, (int)(rows * O * 4), 0x00020000);
+    const rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Y1), 0, (int)(rows * S * 4), 0x00020000);
+    const rsrc_t rds = __builtin_amdgcn_make_buffer_rsrc(dS, 0, (int)(rows * S * 4), 0x00020000);
+    const int ntile = (int)((rows + 31) / 32);
+    for (int tile = gw / CG; tile < ntile; tile += nw / CG) {
+        // every request of the tile first: dY in its two layouts (the padded k get the out-of-range offset; rows past the end lie behind the
+        // descriptor's size: loads return 0, stores are dropped), then the 32 activation dwords (two 128-byte row pieces per instruction;
+        // per-lane offset of the tile + a scalar row offset), which travel while the first MFMAs run
+        float av[16], dyc[16];
+        {
+            const unsigned va = (unsigned)(((tile * 32 + n) * O + 16 * hh) * 4), vc = (unsigned)(((tile * 32 + 4 * hh) * O + n) * 4);
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                av[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdy, 16 * hh + t < O ? (int)(va + t * 4) : -1, 0, 0));
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                dyc[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdy, n < O ? (int)vc : -1, ((i & 3) + 8 * (i >> 2)) * O * 4, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned vb = (unsigned)(((tile * 32 + 4 * hh) * S + c0 + n) * 4);
+        float y[2][16];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                y[j][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, (int)(vb + j * 128), ((i & 3) + 8 * (i >> 2)) * S * 4, 0));
+        __builtin_amdgcn_sched_barrier(0);               // (the scheduler moved the activation loads BEHIND the MFMAs otherwise)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bw[j][t], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);           // (keeps the masks -- and the wait for their loads -- behind the MFMAs)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pre = y[j][i] + bias[j];
+                const bool on = pre > 0.0f;
+                const float v = on ? acc[i] : 0.0f;                                       // rows past the end: acc = 0 (their A rows are 0)
+                cs[j] += v;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rds, (int)(vb + j * 128), ((i & 3) + 8 * (i >> 2)) * S * 4, 0);
+                wacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(on ? pre : 0.0f, dyc[i], wacc[j], 0, 0, 0);   // rows past the end: dyc = 0
+            }
+        }
+    }
+    const long long chunk = gw / CG;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float o = tr_xor32(cs[j]);
+        if (hh == 0) part[chunk * S + c0 + 32 * j + n] = cs[j] + o;
+        // wacc[j]: lane n = k, register i = column (i & 3) + 8 (i >> 2) + 4 hh of the 32-column tile
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wpart[(chunk * S + c0 + 32 * j + (i & 3) + 8 * (i >> 2) + 4 * hh) * 32 + n] = wacc[j][i];
+    }
+}
 
 struct LayerA { f32x4t x0[4], x1[4], u[kLcSteps]; };
 template <bool FUSED>
@@ -1244,6 +1371,7 @@ struct SlabDst { float* out[GQ_N]; int ldo[GQ_N]; int mrows[GQ_N]; long long lst
 __global__ __launch_bounds__(256) void tr_slab_reduce_kernel(const float* slabs, long long slab_lstride, int nslab, SlabDst dst)
 {
     const int q = blockIdx.y, l = blockIdx.z;
+    if (dst.mrows[q] == 0) return;                           // (fused lc path: six of the eleven tiles are neither written nor wanted)
     const int i = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     const float* sl = slabs + (long long)l * slab_lstride;
     float s = 0.0f;
@@ -1264,18 +1392,25 @@ __global__ void tr_split_bias_kernel(const float* s64, float* base, long long ls
     }
 }
 // demb[b][g] += sum over layers l (ascending), j (ascending) of dGCP[l][b][j] * Wgc_l[g][j]   (Wgc_l = views + l*vstride, row g of (G x 64))
-__global__ void tr_demb_kernel(const float* dgcp, const float* wgc0, long long vstride, float* demb, int NL, int B, int G)
+// one wave per (batch entry, embedding column): lane j carries column j of the 64-wide projection through the layers (coalesced 256-byte
+// rows), then a butterfly over the lanes (fixed order).  One THREAD per output walked 30 x 64 dependent loads: 73 us for 2.5 MB.
+__global__ __launch_bounds__(256) void tr_demb_kernel(const float* dgcp, const float* wgc0, long long vstride, float* demb, int NL, int B, int G)
 {
-    GRID_STRIDE(i, (long long)B * G) {
-        const int b = (int)(i / G), g = (int)(i % G);
-        float s = 0.0f;
-        for (int l = 0; l < NL; ++l) {
-            const float* dg = dgcp + ((long long)l * B + b) * 64;
-            const float* w = wgc0 + (long long)l * vstride + (long long)g * 64;
-            for (int j = 0; j < 64; ++j) s += dg[j] * w[j];
-        }
-        demb[i] += s;
+    const int lane = threadIdx.x & 63;
+    const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= (long long)B * G) return;
+    const int b = (int)(i / G), g = (int)(i % G);
+    float s0 = 0.0f, s1 = 0.0f;
+    int l = 0;
+    for (; l + 1 < NL; l += 2) {
+        s0 += dgcp[((long long)l * B + b) * 64 + lane] * wgc0[(long long)l * vstride + (long long)g * 64 + lane];
+        s1 += dgcp[((long long)(l + 1) * B + b) * 64 + lane] * wgc0[(long long)(l + 1) * vstride + (long long)g * 64 + lane];
     }
+    if (l < NL) s0 += dgcp[((long long)l * B + b) * 64 + lane] * wgc0[(long long)l * vstride + (long long)g * 64 + lane];
+    float s = s0 + s1;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) demb[i] += s;
 }
 
 // Two waves per SIMD as in the forward kernel: the transposed weights (B operands) live in LDS, [step][lane][8] with
@@ -1737,6 +1872,7 @@ extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch,
     f += RT * 4 + 64 + 4LL * 512 + 64;          // fused lc backward: per-row dot products, phase-table gradient
     f += ((long long)batch * ((h->Tn + 31) / 32) * 512 + 64 + RT / h->hop * 256 + 64) * h->NL;   // per-tile / per-frame sums of ctab * dPRE (dW_lc)
     f += 4LL * 512 + 64 + RT / h->hop * 4 * h->L + 64 + (RT / h->hop * 4 * 64 + 64) * h->NL;   // fused lc projection: tap table, shifted mel, per-layer frame projections
+    f += 2048LL * 64 * 32 + 64;                 // conv1d_2's fused backward: per-wave shares of dW2
     f += 64 * 64;                               // rounding slack
     h->ws_floats = f;
     *out = h;
@@ -1801,6 +1937,7 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
     float* slabs = take(slab_ls * NL);                       // every layer's gradient slabs: reduced in one launch after the layer loop
     float* zpage = take(1024);
     float* kpart = take(16LL * (ZW > S ? ZW : S) * S);       // split-K partials (dW1, dW2, stacked dWs)
+    float* wpart = take(2048LL * 64 * 32);                   // tr_conv2_bwd_kernel: [2048 / CG chunks][S][32] = 2048 x 64 x 32 whatever S is
     const int F = T / h->hop;                                // mel frames per entry
     const bool fused_lc = d.n_upsample == 3 && h->hop >= 32 && h->hop <= 512 && L == 80;
     float* ctab = take(4LL * 512);
@@ -1841,7 +1978,10 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
     auto wgrad = [&](const float* A, int lda, const float* Bm, int ldb, long long K, int M, int N, float* C, int ldc) {
         const int mb = (M + 31) / 32, nb = (N + 31) / 32;
         const long long cap = (512LL * 96 * 64 + 1024LL * 512) / ((long long)mb * nb * 1024);     // `part` holds chunks x (mb*32) x (nb*32)
-        int chunks = (int)(K / 1024); chunks = chunks < 1 ? 1 : (chunks > 256 ? 256 : chunks);
+        // enough workgroups to fill the chip whatever the tile count: a single-tile product (the causal kernel's gradient: M = N = 32) ran on
+        // 256 workgroups of dependent two-row steps: 124 us for 128 MB
+        int chunks = (int)(K / 512); chunks = chunks < 1 ? 1 : (chunks > 1024 ? 1024 : chunks);
+        if (chunks * mb * nb > 4096) chunks = 4096 / (mb * nb) > 0 ? 4096 / (mb * nb) : 1;
         if (chunks > cap) chunks = (int)cap;
         long long rpc = (K + chunks - 1) / chunks; rpc = (rpc + 7) / 8 * 8;
         chunks = (int)((K + rpc - 1) / rpc);
@@ -1911,10 +2051,19 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             K1(tr_bias_relu_kernel, RO * S, SK, ub ? LP(0) + h->lo.bs : nullptr, ub ? NL : 0, h->c_lstride, nullptr, S, RO * S);
         }
         if ((rc = gemm_rm(bl, false, false, (int)RO, S, S, 1.f, SK, S, P + h->c_w1, S, 0.f, C1, S))) break;
-        if ((S & 3) == 0 && (h->c_b1 & 3) == 0) K1(tr_bias_relu4_kernel, RO * S / 4, (float4*)C1, ub ? (const float4*)(P + h->c_b1) : nullptr, S / 4, RO * S / 4);
-        else K1(tr_bias_relu_kernel, RO * S, C1, nullptr, 0, 0, ub ? P + h->c_b1 : nullptr, S, RO * S);
-        if (O <= 32 && (S & 15) == 0 && S * 32 * 4 <= 64 * 1024) {
-            hipLaunchKernelGGL(tr_skinny_nn_kernel, dim3(1024), dim3(256), (size_t)S * 32 * 4, st, C1, S, P + h->c_w2, O, ub ? P + h->c_b2 : nullptr, RO, S, O, Y, O);
+        // conv1d_1's activation: with the skinny output projection (MoL head) the relu(. + b1) pass over the (RO, S) array is never run --
+        // its readers (the projection forward; conv1d_2's fused backward: mask of dC1 and operand of dW2) apply it to what they load
+        const bool skinny = O <= 32 && (S & 15) == 0 && S * 32 * 4 <= 64 * 1024;
+        const bool fuse_c2 = skinny && (S & 63) == 0 && 2048 % (S >> 6) == 0 && RO * S * 4 < (1LL << 31) && (h->c_b1 & 3) == 0;   // (`part`: 2048 x 64 floats)
+        const bool c1_raw = fuse_c2;
+        const float* b1p = ub ? P + h->c_b1 : nullptr;
+        if (!c1_raw) {
+            if ((S & 3) == 0 && (h->c_b1 & 3) == 0) K1(tr_bias_relu4_kernel, RO * S / 4, (float4*)C1, ub ? (const float4*)(P + h->c_b1) : nullptr, S / 4, RO * S / 4);
+            else K1(tr_bias_relu_kernel, RO * S, C1, nullptr, 0, 0, ub ? P + h->c_b1 : nullptr, S, RO * S);
+        }
+        if (skinny) {
+            if (c1_raw) hipLaunchKernelGGL(tr_skinny_nn_kernel<true>, dim3(1024), dim3(256), (size_t)S * 32 * 4, st, C1, S, P + h->c_w2, O, ub ? P + h->c_b2 : nullptr, RO, S, O, Y, O, b1p);
+            else hipLaunchKernelGGL(tr_skinny_nn_kernel<false>, dim3(1024), dim3(256), (size_t)S * 32 * 4, st, C1, S, P + h->c_w2, O, ub ? P + h->c_b2 : nullptr, RO, S, O, Y, O, (const float*)nullptr);
         } else {
             if ((rc = gemm_rm(bl, false, false, (int)RO, O, S, 1.f, C1, S, P + h->c_w2, O, 0.f, Y, O))) break;
             if (ub) K1(tr_bias_add_kernel, RO * O, Y, P + h->c_b2, O, RO * O);
@@ -1922,16 +2071,24 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         // model.py:286-290 loss
         // per-row terms, then the same two-stage column sum as the bias gradients: the loss is bit-reproducible run to run
         float* row_loss = dS;                                       // (RO) scratch: dS is not written before the backward pass
-        if (d.scalar_input) K1(tr_mol_loss_kernel, RO, Y, audio, B, T, ow, rf, nr, 1.0f / (float)RO, row_loss, dY);
+        if (d.scalar_input && nr == 10) K1(tr_mol_loss_kernel<10>, RO, Y, audio, B, T, ow, rf, nr, 1.0f / (float)RO, row_loss, dY);
+        else if (d.scalar_input) K1(tr_mol_loss_kernel<0>, RO, Y, audio, B, T, ow, rf, nr, 1.0f / (float)RO, row_loss, dY);
         else hipLaunchKernelGGL(tr_softmax_ce_kernel, dim3(tg(RO * 64)), dim3(256), 0, st, Y, qin, B, T, ow, rf, O, 1.0f / (float)RO, row_loss, dY);
         colsum(row_loss, RO, 1, 1, 1, loss, 1);
         // ================= backward =================
-        wgrad(C1, S, dY, O, RO, S, O, Gd + h->c_w2, O);                                                           // dW2 = H2^T dY (512 x 30: the tall-skinny MFMA kernel)
+        if (!fuse_c2) wgrad(C1, S, dY, O, RO, S, O, Gd + h->c_w2, O);                                              // dW2 = H2^T dY (the tall-skinny MFMA kernel)
         if (ub) colsum(dY, RO, O, O, 1, Gd + h->c_b2, O);
-        rc |= gemm_rm(bl, false, true, (int)RO, S, O, 1.f, dY, O, P + h->c_w2, O, 0.f, dS, S);                   // dH2
-        if (ub) relu_bwd_colsum(dS, C1, RO, S, Gd + h->c_b1);                                                    // dC1, db1
-        else if ((S & 3) == 0) K1(tr_relu_bwd4_kernel, RO * S / 4, (float4*)dS, (const float4*)C1, RO * S / 4);
-        else K1(tr_relu_bwd_kernel, RO * S, dS, C1, RO * S);
+        if (fuse_c2) {                                                                                           // dC1, db1 and dW2: one pass
+            const int nwg = 512, nchunk = nwg * 4 / (S >> 6);             // two workgroups per CU (171 registers; at three, 168 + spills: 276 vs 263 us)
+            hipLaunchKernelGGL(tr_conv2_bwd_kernel, dim3(nwg), dim3(256), 0, st, dY, O, P + h->c_w2, C1, b1p, RO, S, dS, part, wpart);
+            if (ub) hipLaunchKernelGGL(tr_colsum_final_kernel, dim3((S + 63) / 64), dim3(256), 0, st, part, nchunk, S, 1, Gd + h->c_b1, S);
+            hipLaunchKernelGGL(tr_tn_reduce_kernel, dim3((S * O + 63) / 64), dim3(256), 0, st, wpart, nchunk, S, 32, S, O, Gd + h->c_w2, O);
+        } else {
+            rc |= gemm_rm(bl, false, true, (int)RO, S, O, 1.f, dY, O, P + h->c_w2, O, 0.f, dS, S);               // dH2
+            if (ub) relu_bwd_colsum(dS, C1, RO, S, Gd + h->c_b1);                                                // dC1, db1
+            else if ((S & 3) == 0) K1(tr_relu_bwd4_kernel, RO * S / 4, (float4*)dS, (const float4*)C1, RO * S / 4);
+            else K1(tr_relu_bwd_kernel, RO * S, dS, C1, RO * S);
+        }
         rc |= gemm_tn_splitk(bl, st, S, S, RO, SK, S, dS, S, Gd + h->c_w1, S, nsplit, kpart);                     // dW1 = H1^T dC1
         rc |= gemm_rm(bl, false, true, (int)RO, S, S, 1.f, dS, S, P + h->c_w1, S, 0.f, C1, S);                   // dH1 -> C1 buffer
         if (ub) relu_bwd_colsum(C1, SK, RO, S, LG(0) + h->lo.bs);                                                 // dSK, dbs (layer 0's slot)
@@ -2011,7 +2168,7 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
                 rc |= rocblas_sgemm_strided_batched(bl, rocblas_operation_none, rocblas_operation_transpose, 64, G, B, &one, dGCPall, 64, (long long)B * 64,
                                                     emb, G, 0, &zero, GV + (64 + L) * 64, 64, vstride, NL);
             }
-            K1(tr_demb_kernel, (long long)B * G, dGCPall, WV + (64 + L) * 64, vstride, demb, NL, B, G);
+            hipLaunchKernelGGL(tr_demb_kernel, dim3((unsigned)(((long long)B * G + 3) / 4)), dim3(256), 0, st, dGCPall, WV + (64 + L) * 64, vstride, demb, NL, B, G);
         }
         if (rc) break;
         // causal layer, gc embedding table, upsampler, and the gradient views back into the canonical order

@@ -86,7 +86,9 @@ def _assert_against_float64(label, loss, got, l64, g64, l32, g32):
     dict(dil=[1, 2, 4], B=1, Tm=2, use_bias=False),
     dict(dil=[1, 2, 4, 8], B=2, Tm=21, up=(4, 4, 4)),          # hop 64: a 32-row tile of the fused layer kernels straddles a frame edge every other tile
     dict(dil=[1, 2, 4], B=2, Tm=40, up=(2, 4, 4)),             # hop 32 = the tile height (the smallest hop the frame-rate lc path takes)
-], ids=["small", "one-cycle", "mol-branches", "no-bias", "hop64", "hop32"])
+    dict(dil=[1, 2, 4], B=2, Tm=5, S=128, use_bias=False),     # S % 128 == 0 takes the fused conv1d_2 backward; here without bias vectors
+    dict(dil=[1, 2], B=1, Tm=4, S=256),                        # two column groups of the fused conv1d_2 backward, a ragged last row tile
+], ids=["small", "one-cycle", "mol-branches", "no-bias", "hop64", "hop32", "no-bias-s128", "s256"])
 def test_loss_and_gradients_match_torch_fp32(kw, request):
     tr, tensors, cfg, audio, lc, gc = _case(**kw)
     loss = float(tr.loss_and_gradients(audio, lc, gc).item())
