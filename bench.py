@@ -85,6 +85,19 @@ def tacotron_traffic():
         return None
 
 
+def train_traffic():
+    """HBM bytes of one configs[3] training step (all kernels), from the committed FETCH_SIZE / WRITE_SIZE passes of THIS build of the
+    training kernels (profiles/traffic.json, key "train:" + _lib.train_hash(); scripts/train_traffic.sh); None for any other code"""
+    try:
+        import twvk_amd
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            t = json.load(fh)
+        e = t.get("train:" + twvk_amd._lib.train_hash(), {}).get("B64_T7800")
+        return None if e is None else float(e["step_fetch_bytes"]) + float(e["step_write_bytes"])
+    except Exception:
+        return None
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -283,12 +296,17 @@ def main():
             rows_all = 64 * (TT_ - 1); rows_ow = 64 * trn.output_width
             mac_fwd = len(dil) * (rows_all * (2 * 32 * 64 + 32 * 32) + rows_ow * 32 * 512) + rows_ow * (512 * 512 + 512 * 30)
             flop_step = 2.0 * 3.0 * mac_fwd
+            ttraf_ = train_traffic() if (TT_ == 7800 and len(dil) == 30) else None
             train_res = {"metric": "WaveNet training audio samples/sec (teacher-forced step: MoL loss, backward, all-reduce, Adam, EMA)",
                          "roofline": {"bound": "mfma", "kernel": "whole step: tr_layer_{fwdc,bwd1,bwd2c}_kernel + the wide f32 GEMMs (rocBLAS MI16x16x4)",
                                       "achieved": flop_step / qdt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flop_step / qdt / 1e12 / 157.3,
-                                      "flop_per_step": flop_step, "traffic": None,
+                                      "flop_per_step": flop_step, "traffic": ttraf_,
+                                      "hbm": None if ttraf_ is None else {"bytes_per_step": ttraf_, "achieved": ttraf_ / qdt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                                                           "frac": ttraf_ / qdt / 1e9 / 8000.0,
+                                                                           "note": "the step's second ruler: the fused layer kernels (39 % of it) run at 3.6-4.2 TB/s, the elementwise "
+                                                                                   "passes at 5-6 TB/s; profiles/r05_train_traffic_v1.txt"},
                                       "note": "executed f32 matrix-core FLOPs only (2 x 3 x forward MACs of the dense contractions; per-kernel durations and "
-                                              "SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F32 counters: profiles/r05_rocprofv3_mfma_summary_tacotron_train_v1.txt, r05_rocprofv3_kernel_stats_train_c4_v1.csv)"},
+                                              "SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F32 counters: profiles/r05_rocprofv3_mfma_summary_tacotron_train_v1.txt, r05_rocprofv3_kernel_stats_train_c4_v2.csv)"},
                          "value": world * 64 * TT_ / qdt, "unit": "audio samples/s", "steps_per_s": 1.0 / qdt, "ms_per_step": qdt * 1e3,
                          "n_gpus": world, "scaling": "weak", "dtype": "f32",
                          "collective": "all-reduce(sum) of one flat f32 gradient buffer, %d elements, RCCL" % trn.n_params if world > 1 else "none (1 GPU)",

@@ -69,6 +69,14 @@ def tacotron_hash():
     return _hash_files([os.path.join(CSRC, f) for f in TACOTRON_SOURCES], code_only=True)
 
 
+TRAIN_SOURCES = ("twv_train.hip", "twv_dev.hpp")
+
+
+def train_hash():
+    """the same for the training step: key of the `train` entries of profiles/traffic.json (scripts/train_traffic.sh)"""
+    return _hash_files([os.path.join(CSRC, f) for f in TRAIN_SOURCES], code_only=True)
+
+
 def build_stamp():
     """(extra hipcc flags, stamp) of the build the environment asks for.  TWV_EXTRA_HIPCC_FLAGS (a tuning aid, e.g. -DTWV_TRPROF) is part of
     the stamp, so a variant build never passes for the plain one and the next plain import rebuilds."""

@@ -53,6 +53,17 @@ struct twv_wavenet_trainer {
 //  kernels
 // ---------------------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4t __attribute__((ext_vector_type(4)));
+// 16-byte accesses through a buffer descriptor (out-of-range offset: the load returns zeros, the store is dropped)
+__device__ __forceinline__ f32x4t tr_bld4(rsrc_t r, unsigned off)
+{
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return f32x4t{__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)};
+}
+__device__ __forceinline__ void tr_bst4(rsrc_t r, unsigned off, f32x4t v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, r, (int)off, 0, 0);
+}
 #define GRID_STRIDE(i, n) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
 static inline int tg(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 32768 ? 32768 : g)); }
 
@@ -347,54 +358,87 @@ __global__ __launch_bounds__(256) void tr_tn_partial_kernel(const float* A, int 
         out[(long long)row * Np + col] = (red[0][row][col] + red[1][row][col]) + (red[2][row][col] + red[3][row][col]);
     }
 }
-// C[m][n] = sum over slabs (fixed order: 4 interleaved partial sums, then pairwise); block = 64 outputs x 4 slab groups
-__global__ __launch_bounds__(256) void tr_tn_reduce_kernel(const float* part, int nslab, int Mp, int Np, int M, int N, float* C, int ldc)
+// C[m][n] = sum over slabs (fixed order: blockDim.x / 64 interleaved partial sums, then a pairwise tree); block = 64 outputs x 4 or 16 slab
+// groups (16: the hundreds of 64 KB-strided partial tiles of a single-tile product were 46 us of dependent loads at 4)
+__global__ void tr_tn_reduce_kernel(const float* part, int nslab, int Mp, int Np, int M, int N, float* C, int ldc)
 {
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6, ng = blockDim.x >> 6;
     float s = 0.0f;
     const int m = i / N, n = i % N;
     if (i < M * N)
-        for (int k = grp; k < nslab; k += 4) s += part[((long long)k * Mp + m) * Np + n];
-    __shared__ float sh[256];
+        for (int k = grp; k < nslab; k += ng) s += part[((long long)k * Mp + m) * Np + n];
+    __shared__ float sh[1024];
     sh[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x < 64 && i < M * N) C[(long long)m * ldc + n] = (sh[threadIdx.x] + sh[threadIdx.x + 64]) + (sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+    for (int w = 1; w < ng; w <<= 1) {                  // ng = 4: (s0 + s1) + (s2 + s3)
+        __syncthreads();
+        if ((grp & (2 * w - 1)) == 0 && grp + w < ng) sh[threadIdx.x] += sh[threadIdx.x + 64 * w];
+    }
+    if (threadIdx.x < 64 && i < M * N) C[(long long)m * ldc + n] = sh[threadIdx.x];
 }
-// Skinny output projection on the f32 matrix cores: Y[r][n] = sum_k X[r][k] * W[k][n] (+ bias[n]), N <= 32, K % 16 == 0 (model.py:161-165
+// Skinny output projection on the f32 matrix cores: Y[r][n] = sum_k X[r][k] * W[k][n] (+ bias[n]), N <= 32, K % 64 == 0 (model.py:161-165
 // conv1d_2, 512 -> 30).  rocBLAS spends 0.6 ms on this 9-GFLOP product; it is a single pass over X.  Wave = 32 rows: every lane
-// reads 32 contiguous bytes of its row per 16-wide k step (lanes l and l+32 the two halves of one 64-byte piece) and feeds eight
-// v_mfma_f32_32x32x2_f32 with the k pairs (t, 8 + t); W sits in LDS as [k][32] (zero-padded columns).
-// XRELU: X holds pre-activations, the operand is relu(X[r][k] + xb[k]) (xb nullable, 16-byte aligned): the activation pass over X is never run.
+// reads 64 contiguous bytes of its row per 32-wide k step (lanes l and l+32 the two halves of one 128-byte line) and feeds sixteen
+// v_mfma_f32_32x32x2_f32 with the k pairs (t, 16 + t); W sits in LDS as [k][32] (zero-padded columns).  The next step's four float4
+// are requested before this step's MFMAs, through a buffer descriptor (rows past the end: out-of-range offset, zeros) -- with the loads
+// behind a branch and no prefetch every step waited out a full memory latency (242 us for 616 MB).
+// XRELU: X holds pre-activations, the operand is relu(X[r][k] + xb[k]) (xb nullable): the activation pass over X is never run.
 template <bool XRELU>
 __global__ __launch_bounds__(256) void tr_skinny_nn_kernel(const float* X, int ldx, const float* W, int ldw, const float* bias, long long rows, int K, int N,
                                                            float* Y, int ldy, const float* xb)
 {
-    extern __shared__ float wl[];                       // [K][32]
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [K][32], XRELU: + [K] (the bias, read through LDS: a global load in the
     for (int i = threadIdx.x; i < K * 32; i += 256) { const int k = i >> 5, n = i & 31; wl[i] = n < N ? W[(long long)k * ldw + n] : 0.0f; }
+    if (XRELU)                                          // loop would stand between the prefetch and its s_waitcnt vmcnt)
+        for (int i = threadIdx.x; i < K; i += 256) wl[K * 32 + i] = xb ? xb[i] : 0.0f;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
     const long long ntile = (rows + 31) / 32;
+    const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, (int)(((rows - 1) * ldx + K) * 4), 0x00020000);
+    const int nstep = K >> 5;
     for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntile; tile += (long long)gridDim.x * 4) {
         const long long r = tile * 32 + col;            // A operand row of this lane
-        const bool rok = r < rows;
-        const float* xp = X + (rok ? r : 0) * ldx + half * 8;
+        const unsigned xo = r < rows ? (unsigned)((r * ldx + half * 16) * 4) : 0x80000000u;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-        for (int k0 = 0; k0 < K; k0 += 16) {
-            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-            if (rok) { a0 = *reinterpret_cast<const float4*>(xp + k0); a1 = *reinterpret_cast<const float4*>(xp + k0 + 4); }
-            float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        auto fetch = [&](f32x4t (&d)[4], int st) {       // step st's 64 bytes of the lane's row (past the last step: zeros, never used)
+            const unsigned o = st < nstep ? xo + (unsigned)st * 128u : 0x80000000u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d[q] = tr_bld4(rx, o + q * 16);
+        };
+        auto step = [&](const f32x4t (&d)[4], int st) {
+            const int k0 = st << 5;
+            float av[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) av[t] = d[t >> 2][t & 3];
             if (XRELU) {                                 // (rows past the end: their outputs are not stored)
-                float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-                if (xb) { b0 = *reinterpret_cast<const float4*>(xb + k0 + half * 8); b1 = *reinterpret_cast<const float4*>(xb + k0 + half * 8 + 4); }
-                const float bv8[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-                for (int t = 0; t < 8; ++t) { const float v = av[t] + bv8[t]; av[t] = v > 0.0f ? v : 0.0f; }
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4t bq = *reinterpret_cast<const f32x4t*>(wl + K * 32 + k0 + half * 16 + 4 * q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float v = av[4 * q + j] + bq[j]; av[4 * q + j] = v > 0.0f ? v : 0.0f; }
+                }
             }
+            float bw[16];                                // the step's B operands in one batch of LDS reads (one round trip, not eight)
 #pragma unroll
-            for (int t = 0; t < 8; ++t)                  // lanes < 32 carry k = k0 + t, lanes >= 32 carry k = k0 + 8 + t
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], wl[(k0 + half * 8 + t) * 32 + col], acc, 0, 0, 0);
+            for (int t = 0; t < 16; ++t) bw[t] = wl[(k0 + half * 16 + t) * 32 + col];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 16; ++t)                 // lanes < 32 carry k = k0 + t, lanes >= 32 carry k = k0 + 16 + t
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bw[t], acc, 0, 0, 0);
+        };
+        // two register sets in turn (K % 64 == 0): a copy `a = next` at the end of a trip is a wait for the prefetch it was meant to hide
+        f32x4t a0[4], a1[4];
+        fetch(a0, 0);
+        for (int st = 0; st < nstep; st += 2) {
+            fetch(a1, st + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            step(a0, st);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(a0, st + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            step(a1, st + 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
         const float bv = (bias != nullptr && col < N) ? bias[col] : 0.0f;
 #pragma unroll
@@ -550,7 +594,6 @@ __global__ __launch_bounds__(256) void tr_mol_loss_kernel(const float* y, const 
 //  current tile's MFMAs.  Writes TH, SG (for the backward pass), x_next and the skip input slice ZC -- no pre-activation
 //  or conditioning buffer ever reaches HBM.  Any accumulation order is fine here: training parity is by tolerance.
 // ===================================================================================================================
-typedef float f32x4t __attribute__((ext_vector_type(4)));
 // training-time activations on the transcendental unit (v_exp_f32 / v_rcp_f32, ~1e-6 relative): parity here is by tolerance
 __device__ __forceinline__ float tr_sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tr_tanh_fast(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
@@ -870,15 +913,6 @@ extern "C" int twv_debug_trprof(unsigned long long* out) { return hipMemcpyFromS
 // order, and behind a conditional load or store the compiler has to assume it was not issued -- its wait for an older load then
 // covers the younger ones too (the first version waited for the rows it had just prefetched, and for every store of the last tile).
 struct FwdcBufs { rsrc_t x, th, sg, xn, q, gc; };
-__device__ __forceinline__ f32x4t tr_bld4(rsrc_t r, unsigned off)
-{
-    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
-    return f32x4t{__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)};
-}
-__device__ __forceinline__ void tr_bst4(rsrc_t r, unsigned off, f32x4t v)
-{
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, r, (int)off, 0, 0);
-}
 // everything a tile reads from HBM / L2: the 32 rows of X at t and at t - d (1 KB per instruction), the lc-projection rows Q of the (at most
 // two) frames the tile touches and the gc projection of its batch entry, laid out as the B operands of the five extra k-pairs
 struct FwdcIn { f32x4t g0[4], g1[4]; float qf[4], qg[4], gcf, gcg; };
@@ -1954,6 +1988,7 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
     HIPCHK(hipMemsetAsync(zpage, 0, 4096, st));
     HIPCHK(hipFuncSetAttribute((const void*)tr_layer_bwd1_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BS_FLOATS * 4));
     HIPCHK(hipFuncSetAttribute((const void*)tr_layer_bwd1_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (4 * BS_FLOATS + 2048) * 4));
+    HIPCHK(hipFuncSetAttribute((const void*)tr_skinny_nn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     const long long tsum_ls = (long long)B * ((Tn + 31) / 32) * 96;     // layers back to back: the column sums below treat (layer, batch entry) as segments
     float* tsum = take(tsum_ls * NL);
     float* dGCPall = take((long long)B * 64 * NL);
@@ -1986,7 +2021,7 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         long long rpc = (K + chunks - 1) / chunks; rpc = (rpc + 7) / 8 * 8;
         chunks = (int)((K + rpc - 1) / rpc);
         hipLaunchKernelGGL(tr_tn_partial_kernel, dim3(chunks, mb, nb), dim3(256), 0, st, A, lda, Bm, ldb, K, M, N, rpc, part);
-        hipLaunchKernelGGL(tr_tn_reduce_kernel, dim3((M * N + 63) / 64), dim3(256), 0, st, part, chunks, mb * 32, nb * 32, M, N, C, ldc);
+        hipLaunchKernelGGL(tr_tn_reduce_kernel, dim3((M * N + 63) / 64), dim3(chunks > 64 ? 1024 : 256), 0, st, part, chunks, mb * 32, nb * 32, M, N, C, ldc);
     };
     do {
         // ================= forward =================
@@ -2053,8 +2088,8 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         if ((rc = gemm_rm(bl, false, false, (int)RO, S, S, 1.f, SK, S, P + h->c_w1, S, 0.f, C1, S))) break;
         // conv1d_1's activation: with the skinny output projection (MoL head) the relu(. + b1) pass over the (RO, S) array is never run --
         // its readers (the projection forward; conv1d_2's fused backward: mask of dC1 and operand of dW2) apply it to what they load
-        const bool skinny = O <= 32 && (S & 15) == 0 && S * 32 * 4 <= 64 * 1024;
-        const bool fuse_c2 = skinny && (S & 63) == 0 && 2048 % (S >> 6) == 0 && RO * S * 4 < (1LL << 31) && (h->c_b1 & 3) == 0;   // (`part`: 2048 x 64 floats)
+        const bool skinny = O <= 32 && (S & 63) == 0 && S * 32 * 4 <= 64 * 1024 && RO * S * 4 < (1LL << 31);
+        const bool fuse_c2 = skinny && (S & 63) == 0 && 2048 % (S >> 6) == 0;   // (`part`: 2048 x 64 floats)
         const bool c1_raw = fuse_c2;
         const float* b1p = ub ? P + h->c_b1 : nullptr;
         if (!c1_raw) {
@@ -2062,7 +2097,7 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             else K1(tr_bias_relu_kernel, RO * S, C1, nullptr, 0, 0, ub ? P + h->c_b1 : nullptr, S, RO * S);
         }
         if (skinny) {
-            if (c1_raw) hipLaunchKernelGGL(tr_skinny_nn_kernel<true>, dim3(1024), dim3(256), (size_t)S * 32 * 4, st, C1, S, P + h->c_w2, O, ub ? P + h->c_b2 : nullptr, RO, S, O, Y, O, b1p);
+            if (c1_raw) hipLaunchKernelGGL(tr_skinny_nn_kernel<true>, dim3(1024), dim3(256), (size_t)S * 33 * 4, st, C1, S, P + h->c_w2, O, ub ? P + h->c_b2 : nullptr, RO, S, O, Y, O, b1p);
             else hipLaunchKernelGGL(tr_skinny_nn_kernel<false>, dim3(1024), dim3(256), (size_t)S * 32 * 4, st, C1, S, P + h->c_w2, O, ub ? P + h->c_b2 : nullptr, RO, S, O, Y, O, (const float*)nullptr);
         } else {
             if ((rc = gemm_rm(bl, false, false, (int)RO, O, S, 1.f, C1, S, P + h->c_w2, O, 0.f, Y, O))) break;
@@ -2082,7 +2117,7 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             const int nwg = 512, nchunk = nwg * 4 / (S >> 6);             // two workgroups per CU (171 registers; at three, 168 + spills: 276 vs 263 us)
             hipLaunchKernelGGL(tr_conv2_bwd_kernel, dim3(nwg), dim3(256), 0, st, dY, O, P + h->c_w2, C1, b1p, RO, S, dS, part, wpart);
             if (ub) hipLaunchKernelGGL(tr_colsum_final_kernel, dim3((S + 63) / 64), dim3(256), 0, st, part, nchunk, S, 1, Gd + h->c_b1, S);
-            hipLaunchKernelGGL(tr_tn_reduce_kernel, dim3((S * O + 63) / 64), dim3(256), 0, st, wpart, nchunk, S, 32, S, O, Gd + h->c_w2, O);
+            hipLaunchKernelGGL(tr_tn_reduce_kernel, dim3((S * O + 63) / 64), dim3(1024), 0, st, wpart, nchunk, S, 32, S, O, Gd + h->c_w2, O);
         } else {
             rc |= gemm_rm(bl, false, true, (int)RO, S, O, 1.f, dY, O, P + h->c_w2, O, 0.f, dS, S);               // dH2
             if (ub) relu_bwd_colsum(dS, C1, RO, S, Gd + h->c_b1);                                                // dC1, db1

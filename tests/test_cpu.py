@@ -757,6 +757,12 @@ def test_bench_reports_counter_traffic_only_for_the_measured_sources(monkeypatch
     assert bench.traffic_per_step("wn_xcd_generate_kernel", "B8_NL50") is None
     monkeypatch.setattr(twvk_amd._lib, "generation_hash", lambda: "0" * 16)
     assert bench.traffic_per_step("wn_xcd_generate_kernel", "B8_NL30") is None
+    # the secondary rows the same way: a figure only for the code the counters ran on
+    for fn, name in ((bench.tacotron_traffic, "tacotron_hash"), (bench.train_traffic, "train_hash")):
+        got = fn()
+        assert got is None or 1e8 < got < 3e11, got
+        monkeypatch.setattr(twvk_amd._lib, name, lambda: "0" * 16)
+        assert fn() is None
 
 
 def test_variant_builds_never_pass_for_the_plain_library(monkeypatch):
