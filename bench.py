@@ -306,7 +306,7 @@ def main():
                                                                            "note": "the step's second ruler: the fused layer kernels (39 % of it) run at 3.6-4.2 TB/s, the elementwise "
                                                                                    "passes at 5-6 TB/s; profiles/r05_train_traffic_v1.txt"},
                                       "note": "executed f32 matrix-core FLOPs only (2 x 3 x forward MACs of the dense contractions; per-kernel durations and "
-                                              "SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F32 counters: profiles/r05_rocprofv3_mfma_summary_tacotron_train_v1.txt, r05_rocprofv3_kernel_stats_train_c4_v2.csv)"},
+                                              "SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F32 counters: profiles/r05_rocprofv3_mfma_summary_tacotron_train_v2.txt, r05_rocprofv3_kernel_stats_train_c4_v2.csv)"},
                          "value": world * 64 * TT_ / qdt, "unit": "audio samples/s", "steps_per_s": 1.0 / qdt, "ms_per_step": qdt * 1e3,
                          "n_gpus": world, "scaling": "weak", "dtype": "f32",
                          "collective": "all-reduce(sum) of one flat f32 gradient buffer, %d elements, RCCL" % trn.n_params if world > 1 else "none (1 GPU)",
