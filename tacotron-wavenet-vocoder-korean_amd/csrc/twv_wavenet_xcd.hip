@@ -1954,7 +1954,7 @@ __device__ __forceinline__ void service_many_role(const XArgs& xa, int xcc, int 
                     const float pre = dot32_dpp(t0[i].w, oa, ob);
                     float lcv = 0.0f;
                     if (has_lc) {                                      // frame pushed at step t is used at step t+1 (model.py:79-80)
-                        const int lw = (int)XcdExch::LCR + (((t + 1) % kXcdLcRing) * kXcdLs + l) * 64;
+                        const int lw = (int)XcdExch::LCR + (((t + 1) % kXcdManyLcRing) * kXcdLs + l) * 64;
                         unsigned long long ql;
                         WACC_T0();
                         pl.it = 0;
@@ -2190,7 +2190,7 @@ __device__ __forceinline__ void lc_many_role(const XArgs& xa, int xcc, int ns, i
         (void)t;
         // ---- throttle, every fourth row for the next four: slot (u'+1) % ring is free once the chain has started step u' + 2 - ring
         WACC_T0();
-        if ((u & 3) == 0 && u + 6 - kXcdLcRing > 0) {
+        if ((u & 3) == 0 && u + 6 - kXcdManyLcRing > 0) {
             pl.it = 0;
             for (;;) {
                 bool ok = true;
@@ -2198,7 +2198,7 @@ __device__ __forceinline__ void lc_many_role(const XArgs& xa, int xcc, int ns, i
                 for (int k = 0; k < kManyPerXcd; ++k) {
                     if (k < ns) {
                         const unsigned long long q = xbm_load(exch_rsrc(a, xcc + 8 * k), (int)XcdExch::CTRL, 0);
-                        ok = ok && (int)g_tag(q) >= u + 6 - kXcdLcRing;
+                        ok = ok && (int)g_tag(q) >= u + 6 - kXcdManyLcRing;
                     }
                 }
                 if (ok) break;
@@ -2230,7 +2230,7 @@ __device__ __forceinline__ void lc_many_role(const XArgs& xa, int xcc, int ns, i
             const float t0_ = il == 0 ? k0[0] : (il == 1 ? k0[1] : (il == 2 ? k0[2] : k0[3]));
             const float t1_ = il == 0 ? k1[0] : (il == 1 ? k1[1] : (il == 2 ? k1[2] : k1[3]));
             const int l = lfirst;
-            const int ring = ((int)XcdExch::LCR + (((u + 1) % kXcdLcRing) * kXcdLs + l) * 64);
+            const int ring = ((int)XcdExch::LCR + (((u + 1) % kXcdManyLcRing) * kXcdLs + l) * 64);
 #pragma nounroll
             for (; kdone + 1 < ns; kdone += 2) {
                 WACC_T0();
@@ -2325,11 +2325,11 @@ __device__ __forceinline__ void lc_many_role(const XArgs& xa, int xcc, int ns, i
                         if (idx >= j * NLC && idx < (j + 1) * NLC) r = (idx == j * NLC) ? resx[idx] : r + resx[idx];
                     }
                     const int l = lfirst + j;
-                    if (u + 1 < T) xb_store(rs, (int)XcdExch::LCR + (((u + 1) % kXcdLcRing) * kXcdLs + l) * 64, lane, (unsigned)u + 2u, r);
+                    if (u + 1 < T) xb_store(rs, (int)XcdExch::LCR + (((u + 1) % kXcdManyLcRing) * kXcdLs + l) * 64, lane, (unsigned)u + 2u, r);
                     else {
                         // the frame the NEXT call uses at its step 0; in a short call wait until the service workgroup has read the
                         // previous call's frame from the same slot (its step-0 addend, PG tag 1, carries that frame; see lc_role)
-                        if (T <= kXcdLcRing + 1) {
+                        if (T <= kXcdManyLcRing + 1) {
                             pl.rs = rs;
                             pl.it = 0;
                             for (;;) {

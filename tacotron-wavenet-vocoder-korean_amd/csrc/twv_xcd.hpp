@@ -14,6 +14,11 @@ constexpr int kXcdStreams = 32;        // up to four streams per XCD (stream b r
 constexpr int kXcdManyFrom = 21;       // batch from which the many-streams kernel is the default choice (measured: B = 16 9.25 vs 9.57 us per step, B = 24 9.65 vs 9.54, B = 32 11.0 vs 9.60)
 constexpr int kXcdManyStreams = 96;    // the many-streams kernel (30 layers or fewer): up to twelve per XCD, two per chain workgroup
 constexpr int kXcdLcRing = 16;         // steps of lc projections the lc workgroups may run ahead of the chain
+#ifndef TWV_MANY_LC_RING
+#define TWV_MANY_LC_RING 8
+#endif
+constexpr int kXcdManyLcRing = TWV_MANY_LC_RING;   // the same for the many-streams kernel: the first 8 slots of the same area (>= 8: its lc role is throttled every fourth row).
+                                                   // 16 -> 8: 1.03 -> 0.37 MB written per step at batch 64 (the ring of an XCD's streams no longer spills its L2), step time equal
 constexpr int kXcdXlFloats = 13 * 64 * 4;   // per layer: the chain's register image [13 float4][64 lanes]
 constexpr int kXcdXcFloats = 8 * 64 * 4;    // causal kernel in the chain's lane order
 
