@@ -15,6 +15,8 @@ int main()
         {"conv1 fwd  C[RO,512]  = H1[RO,512] . W1[512,512]", rocblas_operation_none, rocblas_operation_none, 512, RO, 512, 512, 512, 512},
         {"dH1        C[RO,512]  = dC1[RO,512] . W1^T", rocblas_operation_transpose, rocblas_operation_none, 512, RO, 512, 512, 512, 512},
         {"dZC        C[RO,960]  = dSK[RO,512] . WS^T", rocblas_operation_transpose, rocblas_operation_none, 960, RO, 512, 512, 512, 960},
+        // round 5: the forward products with the weight stored transposed ([N][K] row-major), i.e. rocBLAS's (T, N) kernels instead of (N, N)
+        {"skip fwd   C[RO,512]  = ZC[RO,960] . (WSt[512,960])^T", rocblas_operation_transpose, rocblas_operation_none, 512, RO, 960, 960, 960, 512},
     };
     rocblas_handle h; rocblas_create_handle(&h);
     float *A, *B, *C;
