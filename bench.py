@@ -306,7 +306,7 @@ def main():
                                                                            "note": "the step's second ruler: the fused layer kernels (39 % of it) run at 3.6-4.2 TB/s, the elementwise "
                                                                                    "passes at 5-6 TB/s; profiles/r05_train_traffic_v1.txt"},
                                       "note": "executed f32 matrix-core FLOPs only (2 x 3 x forward MACs of the dense contractions; per-kernel durations and "
-                                              "SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F32 counters: profiles/r05_rocprofv3_mfma_summary_tacotron_train_v2.txt, r05_rocprofv3_kernel_stats_train_c4_v2.csv)"},
+                                              "SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F32 counters: profiles/r05_rocprofv3_mfma_summary_tacotron_train_v3.txt, r05_rocprofv3_kernel_stats_train_c4_v2.csv)"},
                          "value": world * 64 * TT_ / qdt, "unit": "audio samples/s", "steps_per_s": 1.0 / qdt, "ms_per_step": qdt * 1e3,
                          "n_gpus": world, "scaling": "weak", "dtype": "f32",
                          "collective": "all-reduce(sum) of one flat f32 gradient buffer, %d elements, RCCL" % trn.n_params if world > 1 else "none (1 GPU)",
@@ -656,7 +656,7 @@ def main():
                                                 "flop_per_pass": gflop, "kernel_ms_per_pass": gms, "traffic": tacotron_traffic(),
                                                 "note": "useful FLOPs (2*rows*K*N, unpadded) of the dense contractions / their summed HIP-event time; "
                                                         "the rest of the pass is the decoder's latency chain (tc_decoder_g_kernel) and the GRU sequences; "
-                                                        "counters: profiles/r05_rocprofv3_mfma_summary_tacotron_train_v1.txt, r05_rocprofv3_kernel_stats_tacotron_c3_v1.csv; HBM bytes (`traffic`): r05_rocprofv3_tacotron_traffic.txt",
+                                                        "counters: profiles/r05_rocprofv3_mfma_summary_tacotron_train_v3.txt, r05_rocprofv3_kernel_stats_tacotron_c3_v2.csv; HBM bytes (`traffic`): r05_rocprofv3_tacotron_traffic.txt",
                                                 "decoder": {"kernel": "tc_decoder_g_kernel (8 workgroups per utterance on one XCD, 11 matvec stages + attention, 13 all-gathers per step through that XCD's L2)",
                                                             "bound": "latency", "us_per_step": dec_us, "ms_per_pass": dec_us * hp.max_iters * 1e-3,
                                                             "latency_floor_us": dec_floor, "frac_of_floor": dec_floor / dec_us,

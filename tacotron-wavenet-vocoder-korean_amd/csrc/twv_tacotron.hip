@@ -144,6 +144,20 @@ __global__ void __launch_bounds__(256) tc_gemm_kernel(GemmArgs a)
 // -----------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kMmRows = 64;
+// a + b as eight v_pk_add_f32 (two IEEE adds each): left to itself the compiler packed a third of the chunk sums and wrote the rest as
+// single adds on register pairs that were just as aligned (88 add instructions per chunk instead of 64)
+__device__ __forceinline__ f32x16 mm_add16(const f32x16 a, const f32x16 b)
+{
+    f32x16 r;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const f32x2p x = {a[2 * p], a[2 * p + 1]}, y = {b[2 * p], b[2 * p + 1]};
+        f32x2p z;
+        asm("v_pk_add_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y));
+        r[2 * p] = z[0]; r[2 * p + 1] = z[1];
+    }
+    return r;
+}
 
 // the lane's four float4 of one 32-term chunk of X': k = 8i + 4*(lane>>5) + {0..3}, i = 0..3 (q[i][j] feeds chain j, pair i)
 struct MmA { f32x4 q[4]; };
@@ -174,7 +188,10 @@ __device__ __forceinline__ void mm_load_a(MmA& A, const GemmArgs& a, rsrc_t rx, 
 // (MODE is a template parameter and `a` travels by value: with a run-time mode test and a reference into the kernel arguments the
 // compiler scheduled the chunk loop with s_waitcnt vmcnt(0) in front of the MFMAs -- the next chunk's prefetch waited for right behind
 // its issue -- and every launch ran 35-50 % longer)
-template <int MODE>
+// WIN: how the lane's four float4 of a chunk are addressed -- 0: plain product (kw == 1), 1: conv window with Cin % 8 == 0 (the window
+// position is the same for every lane: scalar bookkeeping), 2: any other conv window (per-lane bookkeeping, mm_load_a).  A template
+// parameter: a run-time test would put the loads behind a branch (see mm_load_a).
+template <int MODE, int WIN>
 __device__ __forceinline__ void mm_body(const GemmArgs a, const int bx, const int by)
 {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -185,7 +202,10 @@ __device__ __forceinline__ void mm_body(const GemmArgs a, const int bx, const in
     const int nb = by * 2 + wc;
     if (nb >= nblk_total) return;
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    f32x16 tot0 = zero, tot1 = zero;                          // column halves
+    // running totals of the two column halves, from -0: (-0) + x == x for every x, signed zeros included, so "total = first chunk" needs
+    // no select (it was sixteen v_cndmask per chunk)
+    const f32x16 mzero = {-0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f};
+    f32x16 tot0 = mzero, tot1 = mzero;
     MmRow r;
     {
         const int row = row0 + (lane & 31);
@@ -196,27 +216,45 @@ __device__ __forceinline__ void mm_body(const GemmArgs a, const int bx, const in
     const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)((((long long)a.rows - 1) * a.ldx + a.Cin) * 4), 0x00020000);
     const int hh = (lane >> 5) * 4;
     int tap = 0, c = hh;                                      // conv window position of the lane's next float4 (Cin >= 8, multiple of 4)
+    int tap_s = 0, c_s = 0;                                   // the same for half-wave 0, WIN == 1
     const float* wt = a.Wt + (long long)nb * nchunk * kTile;
-    Tile tl;
-    MmA A;
-    load_tile(tl, wt, lane);
-    mm_load_a(A, a, rx, r, hh, tap, c);
-    for (int ch = 0; ch < nchunk; ++ch) {
-        Tile tn;
-        MmA An;
-        {                                                     // next chunk's operands travel while this chunk's 32 MFMAs run (behind the
-            const int chn = ch + 1 < nchunk ? ch + 1 : ch;    // last chunk: its own tile again and k >= K, i.e. zeros -- never used)
-            load_tile(tn, wt + (long long)chn * kTile, lane);
-            mm_load_a(An, a, rx, r, (ch + 1) * 32 + hh, tap, c);
+    // plain product (kw == 1, the lane's row is one contiguous run of K floats): the chunk's four float4 sit at a fixed stride behind one
+    // per-lane offset; only a K that is not a multiple of 32 needs the k < K test (a float4 past K would read the next row)
+    const unsigned xrow = r.ok ? (r.seq + (unsigned)r.t * (unsigned)a.ldx + (unsigned)hh) * 4u : 0x80000000u;
+    const bool ktail = (a.K & 31) != 0;
+    auto fetch = [&](Tile& t_, MmA& A_, int ch) {             // chunk ch's operands (past the last chunk: the last tile again and zeros)
+        const int chc = ch < nchunk ? ch : nchunk - 1;
+        load_tile(t_, wt + (long long)chc * kTile, lane);
+        if constexpr (WIN == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = ch < nchunk && (!ktail || ch * 32 + hh + 8 * i < a.K);
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? xrow + (unsigned)(ch * 32 + 8 * i) * 4u : 0x80000000u), 0, 0);
+                A_.q[i] = f32x4{__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)};
+            }
+        } else if constexpr (WIN == 1) {
+            // k = tap * Cin + c -> X[row + tap - pl][c]: with Cin a multiple of 8 both half-waves (c and c + 4) change taps together, so
+            // (tap, c) live in scalar registers and a lane spends an add, a compare and a select per float4 (per-lane bookkeeping: ~20)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int dt = tap_s - a.pl;
+                const unsigned ts = (unsigned)(r.t + dt);
+                const bool ok = r.ok && ch * 32 + 8 * i < a.K && ts < (unsigned)a.T;
+                const unsigned off = xrow + (unsigned)((dt * a.ldx + c_s) * 4);
+                const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? off : 0x80000000u), 0, 0);
+                A_.q[i] = f32x4{__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)};
+                c_s += 8;
+                if (c_s >= a.Cin) { c_s -= a.Cin; ++tap_s; }
+            }
+        } else {
+            mm_load_a(A_, a, rx, r, ch * 32 + hh, tap, c);
         }
-        // the prefetch stays HERE: left to itself the scheduler may sink the twelve loads down to their first uses in the next trip
-        // (fewer live registers, but then every MFMA group waits for its operand with vmcnt(0): measured 35-50 % longer launches when an
-        // unrelated edit of the epilogue tipped its heuristic that way)
-        __builtin_amdgcn_sched_barrier(0);
-        // The two column halves one after the other, on ONE set of four accumulators (64 registers instead of 128): together with the
-        // waves-per-SIMD bound of the kernels this keeps a wave under 256 registers -- two waves per SIMD, so one wave's chunk sums
-        // and address arithmetic run under the other's MFMAs (inside a wave they do not overlap at all) -- and the accumulators stay
-        // in ordinary VGPRs: the v_pk_add_f32 of the chunk sums read them directly instead of through 128 v_accvgpr_read per chunk.
+    };
+    // one chunk: the two column halves one after the other, on ONE set of four accumulators (64 registers instead of 128): together with
+    // the waves-per-SIMD bound of the kernels this keeps a wave under 256 registers -- two waves per SIMD, so one wave's chunk sums and
+    // address arithmetic run under the other's MFMAs (inside a wave they do not overlap at all) -- and the accumulators stay in ordinary
+    // VGPRs: the v_pk_add_f32 of the chunk sums read them directly instead of through 128 v_accvgpr_read per chunk.
+    auto chunk = [&](const Tile& tl, const MmA& A) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             f32x16 acc[4];
@@ -230,11 +268,25 @@ __device__ __forceinline__ void mm_body(const GemmArgs a, const int bx, const in
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.q[i][j], bh, i == 0 ? zero : acc[j], 0, 0, 0);
                 }
             }
-            const f32x16 cs = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            if (h == 0) tot0 = ch == 0 ? cs : tot0 + cs;
-            else tot1 = ch == 0 ? cs : tot1 + cs;
+            const f32x16 cs = mm_add16(mm_add16(acc[0], acc[1]), mm_add16(acc[2], acc[3]));
+            if (h == 0) tot0 = mm_add16(tot0, cs);
+            else tot1 = mm_add16(tot1, cs);
         }
-        tl = tn; A = An;
+    };
+    // Two operand sets in turn: the next chunk's operands travel while this chunk's 32 MFMAs run, and nothing is copied at the end of a
+    // trip (`tl = tn; A = An` was 24 v_mov_b64 per chunk).  The prefetch stays in FRONT of the MFMAs: left to itself the scheduler may sink
+    // the twelve loads down to their first uses in the next trip (fewer live registers, but then every MFMA group waits for its operand
+    // with vmcnt(0): measured 35-50 % longer launches when an unrelated edit of the epilogue tipped its heuristic that way)
+    Tile t0_, t1_;
+    MmA A0_, A1_;
+    fetch(t0_, A0_, 0);
+    for (int ch = 0; ch < nchunk; ch += 2) {
+        fetch(t1_, A1_, ch + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        chunk(t0_, A0_);
+        fetch(t0_, A0_, ch + 2);                             // (always issued: no memory instruction behind a branch)
+        __builtin_amdgcn_sched_barrier(0);                   // (a barrier behind the chunks as well: 46 registers spilled)
+        if (ch + 1 < nchunk) chunk(t1_, A1_);
     }
     if constexpr (MODE == 1) {                                // highway pair: tot0 = H, tot1 = T of output column n
         const int n = nb * 32 + (lane & 31);
@@ -279,8 +331,17 @@ __device__ __forceinline__ void mm_body(const GemmArgs a, const int bx, const in
     }
 }
 #define TWV_TWO_WAVES __attribute__((amdgpu_waves_per_eu(2, 2)))
-__global__ void __launch_bounds__(256) TWV_TWO_WAVES tc_gemm_mfma_kernel(GemmArgs a) { mm_body<0>(a, blockIdx.x, blockIdx.y); }
-__global__ void __launch_bounds__(256) TWV_TWO_WAVES tc_gemm_mfma_highway_kernel(GemmArgs a) { mm_body<1>(a, blockIdx.x, blockIdx.y); }
+__global__ void __launch_bounds__(256) TWV_TWO_WAVES tc_gemm_mfma_kernel(GemmArgs a)
+{
+    if (a.kw == 1) mm_body<0, 0>(a, blockIdx.x, blockIdx.y);
+    else if ((a.Cin & 7) == 0) mm_body<0, 1>(a, blockIdx.x, blockIdx.y);
+    else mm_body<0, 2>(a, blockIdx.x, blockIdx.y);
+}
+__global__ void __launch_bounds__(256) TWV_TWO_WAVES tc_gemm_mfma_highway_kernel(GemmArgs a)
+{
+    if (a.kw == 1) mm_body<1, 0>(a, blockIdx.x, blockIdx.y);
+    else mm_body<1, 2>(a, blockIdx.x, blockIdx.y);          // (the highway layers are dense: never taken)
+}
 
 // SEVERAL problems in one launch: the conv bank of a CBHG is 16 (encoder) / 8 (post-net) independent GEMMs over the
 // same rows (modules.py:30-35), the four input halves of the biGRU kernels and the five speaker dense layers likewise.  One at a time
@@ -302,7 +363,9 @@ __global__ void __launch_bounds__(256) TWV_TWO_WAVES tc_gemm_mfma_group_kernel(G
     const int local = wg - g.start[p];
     const int by = local % g.nby[p], bx = local / g.nby[p];
     const GemmArgs a = g.a[p];
-    mm_body<0>(a, bx, by);
+    if (a.kw == 1) mm_body<0, 0>(a, bx, by);
+    else if ((a.Cin & 7) == 0) mm_body<0, 1>(a, bx, by);
+    else mm_body<0, 2>(a, bx, by);
 }
 
 // Few rows, deep contraction (encoder CBHG: 3232 rows, K up to 6144): the 64-row kernel would fill ~50 CUs and run 192 chunks
