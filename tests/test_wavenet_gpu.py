@@ -767,9 +767,12 @@ def test_xcd_many_streams_kernel_chunked_calls(torch_cuda, oracle, B):
     m = make_model(B, dil, tensors, xcd_many=1)
     U = m.create_upsample(mel).tensor()
     outs, fi, p = [], seed_in, 0
-    for n in (300, 1, 1, 2, 336):
+    # (launch lengths on both sides of the kernel's lc ring of 8 steps: a launch of at most ring + 1 steps waits for the previous launch's
+    # last frame to be consumed before it overwrites the slot)
+    for n in ((300, 1, 1, 2, 336) if B not in (33, 96) else (290, 1, 1, 2, 8, 9, 10, 16, 17, 286)):
         o = m.generate(U[:, p:p + n].contiguous(), gc, fi, u[:, p:p + n]).cpu().numpy()
         outs.append(o); fi = o[:, -1]; p += n
+    assert p == T
     got = np.concatenate(outs, axis=1)
     assert first_mismatch(got, want) is None, first_mismatch(got, want)
 
