@@ -20,6 +20,8 @@ CASES = [
     ("no-bias", dict(dil=[1, 2, 4], B=1, Tm=2, use_bias=False), False),
     ("hop64", dict(dil=[1, 2, 4, 8], B=2, Tm=21, up=(4, 4, 4)), False),
     ("hop32", dict(dil=[1, 2, 4], B=2, Tm=40, up=(2, 4, 4)), False),
+    ("no-bias-s128", dict(dil=[1, 2, 4], B=2, Tm=5, S=128, use_bias=False), False),
+    ("s256", dict(dil=[1, 2], B=1, Tm=4, S=256), False),
     ("bench-geometry 16 x 3600", dict(dil=[2 ** i for i in range(10)] * 3, B=16, Tm=12, S=512), True),
     ("configs[3] 64 x 7800", dict(dil=[2 ** i for i in range(10)] * 3, B=64, Tm=26, S=512), True),
 ]
