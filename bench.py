@@ -291,11 +291,19 @@ def main():
                 dist.all_reduce(tq, op=dist.ReduceOp.MAX)
                 qdt = float(tq.item())
             # executed matrix-core work of one step (forward + two backward contractions per GEMM; the lc projection is NOT in it: it
-            # runs at frame rate as 8 VALU fmas per row): per layer (2 taps x 32x64 + dense 32x32) MACs on all B*(T-1) rows
-            # and the skip 1x1 (32x512) on the B*out_w output rows; conv1d_1 512x512 and conv1d_2 512x30 on the output rows
-            rows_all = 64 * (TT_ - 1); rows_ow = 64 * trn.output_width
-            mac_fwd = len(dil) * (rows_all * (2 * 32 * 64 + 32 * 32) + rows_ow * 32 * 512) + rows_ow * (512 * 512 + 512 * 30)
-            flop_step = 2.0 * 3.0 * mac_fwd
+            # runs at frame rate as 8 VALU fmas per row): per layer (2 taps x 32x64 + dense 32x32) MACs on the rows the
+            # layer kernels walk and the skip 1x1 (32x512) on the B*out_w output rows; conv1d_1 512x512 and conv1d_2 512x30 on the output rows
+            # Rows per layer: the layer kernels walk a batch entry from the 32-row tile that holds the layer's receptive offset on (forward:
+            # the output's offset off[l+1], the two backward kernels: the input's offset off[l]); the rows in front of it do not exist in the
+            # reference's 'valid' convolutions and are not computed.
+            rows_ow = 64 * trn.output_width
+            off_, mac_layers = hp.initial_filter_width - 1, 0.0
+            for d_ in dil:
+                rows_f = 64 * ((TT_ - 1) - ((off_ + d_) // 32) * 32); rows_b = 64 * ((TT_ - 1) - (off_ // 32) * 32)
+                mac_layers += (rows_f + 2.0 * rows_b) * (2 * 32 * 64 + 32 * 32)
+                off_ += d_
+            mac_post = len(dil) * rows_ow * 32 * 512 + rows_ow * (512 * 512 + 512 * 30)
+            flop_step = 2.0 * (mac_layers + 3.0 * mac_post)
             ttraf_ = train_traffic() if (TT_ == 7800 and len(dil) == 30) else None
             train_res = {"metric": "WaveNet training audio samples/sec (teacher-forced step: MoL loss, backward, all-reduce, Adam, EMA)",
                          "roofline": {"bound": "mfma", "kernel": "whole step: tr_layer_{fwdc,bwd1,bwd2c}_kernel + the wide f32 GEMMs (rocBLAS MI16x16x4)",
@@ -303,10 +311,10 @@ def main():
                                       "flop_per_step": flop_step, "traffic": ttraf_,
                                       "hbm": None if ttraf_ is None else {"bytes_per_step": ttraf_, "achieved": ttraf_ / qdt / 1e9, "peak": 8000.0, "unit": "GB/s",
                                                                            "frac": ttraf_ / qdt / 1e9 / 8000.0,
-                                                                           "note": "the step's second ruler: the fused layer kernels (39 % of it) run at 3.6-4.2 TB/s, the elementwise "
-                                                                                   "passes at 5-6 TB/s; profiles/r05_train_traffic_v1.txt"},
+                                                                           "note": "the step's second ruler: the fused layer kernels (37 % of it) run at 3.8-4.1 TB/s, the elementwise "
+                                                                                   "passes at 5-6 TB/s; profiles/r05_train_traffic_v2.txt"},
                                       "note": "executed f32 matrix-core FLOPs only (2 x 3 x forward MACs of the dense contractions; per-kernel durations and "
-                                              "SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F32 counters: profiles/r05_rocprofv3_mfma_summary_tacotron_train_v3.txt, r05_rocprofv3_kernel_stats_train_c4_v2.csv)"},
+                                              "SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F32 counters: profiles/r05_rocprofv3_mfma_summary_tacotron_train_v4.txt, r05_rocprofv3_kernel_stats_train_c4_v3.csv)"},
                          "value": world * 64 * TT_ / qdt, "unit": "audio samples/s", "steps_per_s": 1.0 / qdt, "ms_per_step": qdt * 1e3,
                          "n_gpus": world, "scaling": "weak", "dtype": "f32",
                          "collective": "all-reduce(sum) of one flat f32 gradient buffer, %d elements, RCCL" % trn.n_params if world > 1 else "none (1 GPU)",

@@ -212,7 +212,9 @@ size_t twv_wavenet_train_param_floats(const twv_wavenet_trainer* h);
 size_t twv_wavenet_train_workspace_bytes(const twv_wavenet_trainer* h);
 int twv_wavenet_train_output_width(const twv_wavenet_trainer* h);          /* n_samples - receptive_field (model.py:135) */
 /* loss (device float[1]) and d loss / d params (device float[param_floats], overwritten).
- * audio (B, n_samples) float in [-1,1]; lc (B, n_samples/hop, lc_channels); gc_ids (B) int32. */
+ * audio (B, n_samples) float in [-1,1]; lc (B, n_samples/hop, lc_channels); gc_ids (B) int32.
+ * workspace: workspace_bytes of device memory that belongs to the trainer between calls (a pointer seen for the first time is
+ * cleared once; parts of it -- activation rows in front of a layer's receptive offset -- are never written afterwards and read as zeros). */
 int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* params, const float* audio, const float* lc,
                                 const int32_t* gc_ids, void* workspace, float* loss, float* grads, void* stream);
 /* model.py:300-312 optional L2 term over the non-bias variables (after loss_grad): loss += strength*sum(w^2)/2, grads += strength*w.

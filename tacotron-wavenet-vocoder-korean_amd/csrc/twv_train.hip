@@ -47,6 +47,7 @@ struct twv_wavenet_trainer {
     TrainLayerOff lo;                     // offsets inside a layer block
     rocblas_handle blas;
     long long ws_floats;
+    const void* ws_clean;                 // the workspace that has been cleared (see twv_wavenet_train_loss_grad)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -595,15 +596,19 @@ __global__ __launch_bounds__(256) void tr_mol_loss_kernel(const float* y, const 
 //  or conditioning buffer ever reaches HBM.  Any accumulation order is fine here: training parity is by tolerance.
 // ===================================================================================================================
 // training-time activations on the transcendental unit (v_exp_f32 / v_rcp_f32, ~1e-6 relative): parity here is by tolerance
-__device__ __forceinline__ float tr_sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tr_tanh_fast(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+// (v_rcp_f32 by name: `__frcp_rn` is the correctly rounded reciprocal -- v_div_scale x 2, v_rcp, four fmas, v_div_fmas, v_div_fixup: ten
+// instructions where one was meant, 320 of the forward kernel's ~750 VALU instructions per tile)
+__device__ __forceinline__ float tr_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tr_tanh_fast(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 struct LayerFwdArgs {
     const float* X; const float* U; const float* gcp;        // (B*Tn,32) (B*T,L=80) (B,64)
     const float* W0; const float* W1; const float* Wlc;      // views (32,64) (32,64) (80,64): columns filter | gate
     const float* Wd;                                         // (32,32)
     const float* bf; const float* bg; const float* bd;       // nullable
     float* TH; float* SG; float* XN; float* ZC;              // ZC already offset to this layer's 32 columns
-    int B, T, Tn, d, o, ow, ldz, tpb;                        // tpb = tiles per batch entry = ceil(Tn / 32)
+    int B, T, Tn, d, o, ow, ldz, tpb;                        // tpb = tiles per batch entry the launch walks (ceil(Tn / 32) - t_lo / 32)
+    int t_lo;                                                // first row the launch walks in every batch entry (a multiple of 32): the rows
+                                                             // below it lie in front of the layer's receptive offset (see the host code)
     // FUSED lc projection (see tr_layer_fwd_kernel): Q[((b*F + frame)*4 + j)*64 + column] = (mel shifted by j bins) . Wlc of this layer,
     // ctab[phase*4 + j] = the 4-tap composition of the three upsampling kernels at that phase of the hop
     const float* Q; const float* ctab; int hop, F;
@@ -707,7 +712,7 @@ struct LayerA { f32x4t x0[4], x1[4], u[kLcSteps]; };
 template <bool FUSED>
 __device__ __forceinline__ void tr_layer_load(LayerA& A, const LayerFwdArgs& a, int tile, int lane)
 {
-    const int b = tile / a.tpb, t = (tile - b * a.tpb) * 32 + (lane & 31), hh = (lane >> 5) * 4;
+    const int b = tile / a.tpb, t = (tile - b * a.tpb) * 32 + a.t_lo + (lane & 31), hh = (lane >> 5) * 4;
     const bool in = tile < a.B * a.tpb && t < a.Tn;
     const float* xr = a.X + ((long long)b * a.Tn + t) * 32 + hh;
     const float* ur = a.U + ((long long)b * a.T + (t - a.o)) * 80 + hh;
@@ -761,7 +766,7 @@ __global__ void __launch_bounds__(512) tr_layer_fwd_kernel(LayerFwdArgs a)
         LayerA A;
         tr_layer_load<FUSED>(A, a, tile, lane);
         // residual operand and gc projection in the output (C) layout: requested now, consumed after the MFMAs
-        const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
+        const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32 + a.t_lo;
         const float gcf = a.gcp ? a.gcp[b * 64 + n] : 0.0f, gcg = a.gcp ? a.gcp[b * 64 + 32 + n] : 0.0f;
         // interior tile: every row is inside the utterance, above the layer's receptive offset and on one side of the skip cut --
         // no per-row predicates, and every access is (per-lane pointer) + (compile-time row offset): the 64 stores and 16 loads
@@ -921,7 +926,7 @@ __device__ __forceinline__ void tr_tile_fetch(FwdcIn& in_, const LayerFwdArgs& a
     f32x4t (&g0)[4] = in_.g0; f32x4t (&g1)[4] = in_.g1;
     const rsrc_t rx = bf.x;
     tile = tile < ntiles ? tile : ntiles - 1;                                   // (past the end: any valid tile, never used)
-    const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32, cr = lane >> 3, cc = (lane & 7) * 4;
+    const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32 + a.t_lo, cr = lane >> 3, cc = (lane & 7) * 4;
     {
         const int n = lane & 31, hh = lane >> 5;
         int u0 = t0 - a.o; u0 = u0 < 0 ? 0 : u0;
@@ -994,7 +999,7 @@ __global__ void __launch_bounds__(kFwdcWaves * 64) tr_layer_fwdc_kernel(LayerFwd
     tr_tile_fetch(in, a, bf, tile, ntiles, lane);
     int tpi = 0;
     for (; tile < ntiles; tile += nwaves, ++tpi) {
-        const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
+        const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32 + a.t_lo;
         TRPROF(0, 0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1127,6 +1132,7 @@ struct LayerBwdArgs {
     float* dX; float* dU;                                    // K2 outputs
     const float* zeros;                                      // >= 1 KB of zeros (masked LDS-DMA lanes read here)
     int B, T, Tn, d, o, ow, ldz, tpb;
+    int t_lo, tpbf;                                          // first row walked per batch entry (see LayerFwdArgs); ceil(Tn / 32) = the tile count tsum / PT are indexed by
     // FUSED lc path (see tr_layer_fwd_kernel): frame-rate projections Q of this layer; D[(b*T + u)*4 + j] accumulates, over the layers,
     // sum_columns dPRE[row of U-row u] * Q_j[frame(u)] -- all the upsampling kernels' gradients need (tr_dctab / tr_up_grad kernels)
     const float* Q; float* D; int hop, F;
@@ -1141,7 +1147,7 @@ enum { BS_TH = 0, BS_SG = 1024, BS_DXN = 2048, BS_DZC = 3072, BS_X1 = 4096, BS_X
 template <bool FUSED>
 __device__ __forceinline__ void tr_bwd1_stage(const LayerBwdArgs& a, int tile, int lane, int base /* float offset of the wave's region in lds[] */)
 {
-    const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
+    const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32 + a.t_lo;
     const long long row0 = (long long)b * a.Tn + t0;
     // four arrays whose 32-row tile is 4 KB contiguous: piece p = 1 KB = 8 rows
 #pragma unroll
@@ -1199,7 +1205,8 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
     if (tile < ntiles) tr_bwd1_stage<FUSED>(a, tile, lane, base);
     int tpi = 0;
     for (; tile < ntiles; tile += nwaves, ++tpi) {
-        const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
+        const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32 + a.t_lo;
+        const int gtile = b * a.tpbf + (t0 >> 5);            // the tile's index in tsum / PT (all ceil(Tn / 32) tiles of every entry)
         TRPROF(1, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this tile's operands are in LDS
         TRPROF(1, 1);
@@ -1281,7 +1288,7 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
         // per-tile column sums (bias and gc gradients): halves combined, lanes 0..31 write
         {
             const float of = tr_xor32(sf), og = tr_xor32(sgs), ox = tr_xor32(sx);
-            if (hh == 0) { a.tsum[(long long)tile * 96 + n] = sf + of; a.tsum[(long long)tile * 96 + 32 + n] = sgs + og; a.tsum[(long long)tile * 96 + 64 + n] = sx + ox; }
+            if (hh == 0) { a.tsum[(long long)gtile * 96 + n] = sf + of; a.tsum[(long long)gtile * 96 + 32 + n] = sgs + og; a.tsum[(long long)gtile * 96 + 64 + n] = sx + ox; }
         }
         if (FUSED) {
             // this tile's share of R_j[frame][column] = sum_rows ctab[phase(row)][j] * dPRE[row][column]; slot 0 = the frame of the tile's
@@ -1321,7 +1328,7 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
                     }
                 }
             }
-            float* pt = a.PT + (long long)tile * 512 + n;
+            float* pt = a.PT + (long long)gtile * 512 + n;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float f0_ = raf[j] + tr_xor32(raf[j]), g0_ = rag[j] + tr_xor32(rag[j]);
@@ -1358,6 +1365,16 @@ __global__ void __launch_bounds__(256) tr_layer_bwd1_kernel(LayerBwdArgs a)
             g[GQ_WD] = __builtin_amdgcn_mfma_f32_32x32x2f32(zc[r], dxc[r], g[GQ_WD], 0, 0, 0);
         }
         TRPROF(1, 6);
+    }
+    // ---- the tiles the launch does not walk (rows in front of the layer's offset): their column sums are zero, and the segment sums
+    // over all tiles of an entry read them
+    {
+        const int nlo = a.t_lo >> 5;
+        for (int s_ = blockIdx.x * 4 + wave; s_ < a.B * nlo; s_ += nwaves) {
+            const int b = s_ / nlo, gt = b * a.tpbf + (s_ - b * nlo);
+            a.tsum[(long long)gt * 96 + lane] = 0.0f;
+            if (lane < 32) a.tsum[(long long)gt * 96 + 64 + lane] = 0.0f;
+        }
     }
     // ---- one slab per workgroup: the four waves' tiles summed through LDS (the staging area is free now) in a fixed order
     float* slab = a.slabs + (long long)blockIdx.x * GQ_N * 1024;
@@ -1472,7 +1489,7 @@ __global__ void __launch_bounds__(512) tr_layer_bwd2_kernel(LayerBwdArgs a)
     const rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(a.dX, 0, FUSED ? (int)((long long)a.B * a.Tn * 32 * 4) : 0, 0x00020000);
     const rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(FUSED ? a.D : a.dX, 0, FUSED ? (int)((long long)a.B * a.T * 4 * 4) : 0, 0x00020000);
     for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += nwaves) {
-        const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
+        const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32 + a.t_lo;
         const int t = t0 + (lane & 31);
         f32x4t qa[8], qb[8];
         if (FUSED) {
@@ -1620,7 +1637,7 @@ __global__ void __launch_bounds__(512) tr_layer_bwd2c_kernel(LayerBwdArgs a)
     float* pa = pt[wave][0]; float* pb = pt[wave][1];
     const int fr = lane >> 4, fq = (lane & 15) * 4;                           // coalesced fetch: row within the 4-row group, first column
     for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += nwaves) {
-        const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32;
+        const int b = tile / a.tpb, t0 = (tile - b * a.tpb) * 32 + a.t_lo;
         const int t = t0 + (lane & 31);
         {
             f32x4t ga[8], gb[8];
@@ -1884,6 +1901,7 @@ extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch,
     for (int i = 0; i < d.n_upsample; ++i) { h->c_up[i] = c; c += (long long)d.upsample_factor[i] * 2; }
     h->nparams = c;
     h->blas = nullptr;
+    h->ws_clean = nullptr;
     // workspace (generous upper bound of what loss_grad carves, each piece rounded up to 64 floats)
     const long long Rr = (long long)batch * h->Tn, RT = (long long)batch * n_samples, RO = (long long)batch * h->ow;
     long long f = 0;
@@ -1938,6 +1956,12 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
     float* Gd = grads;
     HIPCHK(hipMemsetAsync(grads, 0, (size_t)h->nparams * 4, st));
     HIPCHK(hipMemsetAsync(loss, 0, 4, st));
+    // A workspace seen for the first time is cleared once: the layer kernels do not walk the tiles in front of a layer's receptive offset,
+    // and masked rows of the tiles they do walk may read those rows as operands of products with zero (0 x NaN would not be zero)
+    if (h->ws_clean != workspace) {
+        HIPCHK(hipMemsetAsync(workspace, 0, (size_t)h->ws_floats * 4, st));
+        h->ws_clean = workspace;
+    }
     // ---- workspace carve
     float* w = (float*)workspace;
     auto take = [&](long long n) { float* p = w; w += (n + 63) / 64 * 64; return p; };
@@ -2065,6 +2089,12 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             fa.bf = ub ? Lp + h->lo.bf : nullptr; fa.bg = ub ? Lp + h->lo.bg : nullptr; fa.bd = ub ? Lp + h->lo.bd : nullptr;
             fa.TH = TH[l]; fa.SG = SG[l]; fa.XN = X[l + 1]; fa.ZC = ZC + l * 32;
             fa.B = B; fa.T = T; fa.Tn = Tn; fa.d = dl; fa.o = o; fa.ow = ow; fa.ldz = ZW; fa.tpb = (Tn + 31) / 32;
+            // Rows t < o of this layer's output do not exist in the reference ('valid' convolutions, model.py:71-96: every layer is d
+            // samples shorter than its input); in the right-aligned layout they are masked rows -- and whole 32-row tiles of them are
+            // not walked at all (o reaches 3100 of 7800 rows in layer 29: 16 % of the stack's tiles).  Nothing reads them: a reader's
+            // valid rows use t and t - d' with t >= o + d'; its masked rows may see them (zeros: the workspace is cleared once).
+            fa.t_lo = fused_lc ? (o / 32) * 32 : 0;
+            fa.tpb -= fa.t_lo / 32;
             {
                 const int ntiles = B * fa.tpb;
                 int nwg = (ntiles + 7) / 8; nwg = nwg > 256 ? 256 : nwg;      // one workgroup (8 waves, 2 per SIMD) per CU, each wave walks its tiles
@@ -2139,6 +2169,7 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
         if (rc) break;
         float* dXn = dXa; float* dXc = dXb;
         K1(tr_fill_kernel, Rr * 32, dXn, 0.0f, Rr * 32);
+        if (fused_lc) K1(tr_fill_kernel, Rr * 32, dXc, 0.0f, Rr * 32);   // (rows in front of a layer's input offset are not written any more)
         if (fused_lc) K1(tr_fill_kernel, RT * 4, Dbuf, 0.0f, RT * 4);
         else K1(tr_fill_kernel, RT * L, dUa, 0.0f, RT * L);
         K1(tr_fill_kernel, (long long)B * G, demb, 0.0f, (long long)B * G);
@@ -2153,9 +2184,15 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
             ba.W0 = Wv; ba.W1 = Wv + 32 * 64; ba.Wlc = Wv + 64 * 64; ba.Wd = Lp + h->lo.wd;
             ba.dPRE = PRE; ba.slabs = slabs + l * slab_ls; ba.tsum = tsum + l * tsum_ls; ba.dX = dXc; ba.dU = dUa;
             ba.B = B; ba.T = T; ba.Tn = Tn; ba.d = dl; ba.o = o; ba.ow = ow; ba.ldz = ZW; ba.tpb = (Tn + 31) / 32;
-            const int ntiles = B * ba.tpb;
+            // backward: dPRE is zero in front of o, dX in front of o - d (the layer input's offset).  Both kernels walk the tiles from
+            // row o - d on: bwd1 leaves zeros in dPRE rows [o - d, o) for bwd2's second tap, and the rows in front of o - d of the dX
+            // buffer it fills are the zeros of the start of the pass (no layer above writes them: their offsets are larger)
+            ba.tpbf = ba.tpb;
+            ba.t_lo = fused_lc ? ((o - dl > 0 ? o - dl : 0) / 32) * 32 : 0;
+            ba.tpb -= ba.t_lo / 32;
+            const int ntiles = B * ba.tpbf, ntiles_w = B * ba.tpb;     // (bwd1's grid = its slab count stays that of all tiles: one reduction for all layers)
             int nwg = (ntiles + 3) / 4; nwg = nwg > 256 ? 256 : nwg;
-            int nwg2 = (ntiles + 7) / 8; nwg2 = nwg2 > 256 ? 256 : nwg2;
+            int nwg2 = (ntiles_w + 7) / 8; nwg2 = nwg2 > 256 ? 256 : nwg2;
             ba.zeros = zpage;
             ba.Q = Qall + l * (q_ls + 64); ba.D = Dbuf; ba.hop = h->hop; ba.F = F; ba.ctab = ctab; ba.PT = PTall + l * (pt_ls + 64);
             if (fused_lc) hipLaunchKernelGGL(tr_layer_bwd1_kernel<true>, dim3(nwg), dim3(256), (4 * BS_FLOATS + 2048) * 4, st, ba);
