@@ -960,6 +960,7 @@ __global__ void __launch_bounds__(512) tc_decoder_kernel(DecArgs a)
 constexpr int kExN = 1024;          // granules per exchange buffer
 typedef __attribute__((address_space(1))) unsigned long long tgu64;
 typedef unsigned u32x2d __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4d __attribute__((ext_vector_type(4)));
 
 struct DecGArgs {
     DecArgs d;
@@ -1658,6 +1659,7 @@ struct DecXArgs {
     int* tickets;                   // [8], zeroed before the launch
     long long xt_off;               // packed offset (floats) of the row tiles [32][8][kXSlots][2048]
     int upx;                        // utterances per XCD (N <= 8*upx)
+    int* stab;                      // [workgroups][kXStages][16]: every workgroup's copy of the stage table (read with scalar loads)
 };
 // the tasks of slice g, in (stage, chunk group) order: task i belongs to wave i % 8, register slot i / 8
 __host__ __device__ inline int xdec_tasks(const XStageTab& t, int g, int wave, int (&st_of)[kXSlots], int (&grp_of)[kXSlots])
@@ -1703,8 +1705,59 @@ __global__ void tc_xdec_pack_kernel(float* P, XStageTab t, long long xt_off)
 //   CATR+l = [y | state of residual GRU l]                (tacotron.py:167)
 enum { XV_FRAME = 0, XV_VEC, XV_CATA, XV_CATB, XV_PQ, XV_Y, XV_CATR };
 // what the gathering thread does with the value of column `col` (gather kinds)
-enum { XG_PLAIN = 0, XG_GATES, XG_CAND_ATT, XG_CAND_RES, XG_OUT, XG_P, XG_CTX };
+enum { XG_PLAIN = 0, XG_GATES, XG_CAND_ATT, XG_CAND_RES, XG_OUT, XG_P, XG_CTX, XG_PQ };
+// a stage's 64-byte record (one s_load_dwordx16 per stage from the workgroup's copy of the table in global memory)
+enum { XS_K = 0, XS_N, XS_ACT, XS_POST, XS_XO, XS_HASB, XS_KIND, XS_GDST, XS_G0, XS_G1, XS_G2, XS_STRIDE = 16 };
 
+// LDS carve of tc_decoder_x_kernel, shared by the kernel and the host's size check (float offsets)
+struct XCarve {
+    int u_frame, u_vec, u_cata, u_catb, u_catr, u_keep, u_y, u_pq, u_al, u_p, UST;
+    int o_nv, o_ab, o_bias, o_scp, o_keys, o_memo, o_part, o_abort, o_tab, total;
+    int Tp, ntmax, ncol, nch_t, kpitch, mpitch;
+};
+__host__ __device__ inline XCarve xdec_carve(int M, int D1, int ENC, int AS, int layers, int DR, int A, int T, int nu, int nst)
+{
+    XCarve c;
+    c.Tp = ((T + 3) / 4) * 4;
+    int o = 0;
+    c.u_frame = o; o += ((M + 31) / 32) * 32;
+    c.u_vec = o; o += 1024;                                // prenet hidden; gates r | u
+    c.u_cata = o; o += D1 + ENC + AS;
+    c.u_catb = o; o += AS + ENC;
+    c.u_catr = o; o += layers * 2 * DR;
+    c.u_keep = o; o += 512;                                // h before the update
+    c.u_y = o; o += DR;
+    c.u_pq = o; o += A + A / 8;                            // processed query, every 32-word chunk skewed by 4 words (score phase)
+    c.u_al = o; o += c.Tp;
+    c.u_p = o; o += c.Tp;
+    c.UST = o;
+    o = c.UST * nu;
+    c.ntmax = (T + 31) >> 5;                               // time steps of a slice: t = g, g + 32, ...
+    c.ncol = ENC >> 5;                                     // context columns of a slice
+    c.nch_t = (T + 31) >> 5;
+    c.kpitch = A + A / 8 + 16;                             // key rows: chunks skewed by 4 words, consecutive rows 16 banks apart
+    c.mpitch = T * c.ncol + 16 * c.nch_t;                  // memory columns of an utterance: 32-step chunks 16 banks apart
+    c.o_nv = o; o += A + A / 8;
+    c.o_ab = o; o += A + A / 8;
+    c.o_bias = o; o += 16 * nst;                           // this slice's 16 bias values per stage
+    c.o_scp = o; o += nu * c.ntmax * 8 > 64 ? nu * c.ntmax * 8 : 64;   // score chunk values; then the recurrence's block totals [u][8]
+    c.o_keys = o; o += nu * c.ntmax * c.kpitch;
+    c.o_memo = o; o += nu * c.mpitch;
+    c.o_part = o; o += nu * 16 * 24 > nu * c.nch_t * c.ncol ? nu * 16 * 24 : nu * c.nch_t * c.ncol;
+    c.o_abort = o; o += 4;
+    c.o_tab = o; o += kXStages * XS_STRIDE;
+    c.total = o;
+    return c;
+}
+
+// Round 6: the kernel's exchanges and attention block rebuilt with what rounds 4-5 learnt on the split kernel:
+//   * a granule exchange is laid out [element][utterance]: the gathering thread fetches the four utterances' values of ITS element with
+//     two 16-byte loads (four self-tagged 8-byte halves) -- one polling round trip; round 2 polled the utterances one after the other in
+//     branches (a poll is an L2 round trip and polls do not pipeline: 0.9-1.9 us per gather, now ~0.4)
+//   * the stage record comes from ONE s_load_dwordx16 (ten LDS reads + v_readfirstlane per stage before)
+//   * barriers are LDS-only (s_waitcnt lgkmcnt(0) + s_barrier): the mel / alignment stores of slice 0 no longer drain inside them
+//   * the chunk-sum wave requests all chunk values at once; score tables skewed against LDS bank conflicts; the context's four chains
+//     of a chunk on four lanes; the attention recurrence's 64-step blocks side by side on separate waves (AC-6, same adds)
 template <bool PROF>
 __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
 {
@@ -1725,40 +1778,22 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
     nu = nu < 0 ? 0 : (nu > UPX ? UPX : nu);
     if (tid == 0) s_ticket = (xcc < 8u && nu > 0) ? atomicAdd(xa.tickets + xcc, 1) : 1 << 20;
     __syncthreads();
-    const int g = s_ticket;
+    const int g = __builtin_amdgcn_readfirstlane(s_ticket);
     if (g >= 32) return;
     const float* P = a.P;
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xa.exch + (long long)xcc * 2 * kXU * 512, 0, 2 * kXU * 512 * 8, 0x00020000);
-    // ---- LDS carve: per utterance a block of UST floats, then shared areas
-    const int Tp = ((T + 3) / 4) * 4;
-    const int Fp = ((M + 31) / 32) * 32;
-    int o = 0;
-    const int u_frame = o; o += Fp;
-    const int u_vec = o; o += 1024;                        // prenet hidden; gates r | u
-    const int u_cata = o; o += D1 + ENC + AS;
-    const int u_catb = o; o += AS + ENC;
-    const int u_catr = o; o += a.layers * 2 * DR;
-    const int u_keep = o; o += 512;                        // h before the update
-    const int u_y = o; o += DR;
-    const int u_pq = o; o += A;
-    const int u_al = o; o += Tp;
-    const int u_p = o; o += Tp;
-    const int UST = o;
-    o = UST * nu;
+    const int nst = tb.nst;
+    const XCarve cv = xdec_carve(M, D1, ENC, AS, a.layers, DR, A, T, nu, nst);
+    const int Tp = cv.Tp, UST = cv.UST;
+    const int u_frame = cv.u_frame, u_vec = cv.u_vec, u_cata = cv.u_cata, u_catb = cv.u_catb, u_catr = cv.u_catr, u_keep = cv.u_keep;
+    const int u_y = cv.u_y, u_pq = cv.u_pq, u_al = cv.u_al, u_p = cv.u_p;
     const int nAch = A / 32;
-    const int ntmax = (T + 31) >> 5;                       // time steps of this slice: t = g, g+32, ...
+    const int ntmax = cv.ntmax;
     const int nt = T > g ? (T - g + 31) >> 5 : 0;
-    const int ncol = ENC >> 5, c0 = g * ncol;              // context columns of this slice
-    const int nch_t = (T + 31) >> 5;
-    const int o_nv = o; o += A;
-    const int o_ab = o; o += A;
-    const int o_bias = o; o += 16 * tb.nst;                // this slice's 16 bias values per stage
-    const int o_scp = o; o += nu * ntmax * 8;
-    const int o_keys = o; o += nu * ntmax * A;
-    const int o_memo = o; o += nu * T * ncol;
-    const int o_part = o; o += nu * 16 * 24 > nu * nch_t * ncol ? nu * 16 * 24 : nu * nch_t * ncol;
-    const int o_abort = o; o += 4;
-    const int o_tab = o; o += kXStages * 12;              // the stage table (kernel arguments are slow to index per stage)
+    const int ncol = cv.ncol, c0 = g * ncol;              // context columns of this slice
+    const int nch_t = cv.nch_t, kpitch = cv.kpitch, mpitch = cv.mpitch;
+    const int o_nv = cv.o_nv, o_ab = cv.o_ab, o_bias = cv.o_bias, o_scp = cv.o_scp, o_keys = cv.o_keys, o_memo = cv.o_memo;
+    const int o_part = cv.o_part, o_abort = cv.o_abort, o_tab = cv.o_tab;
 
     int len[kXU];
 #pragma unroll
@@ -1774,22 +1809,32 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
         if (tid == 0) lds[ub + u_al] = 1.0f;                // one-hot at 0 [RECALLED-TF initial_alignments]
         const float* keys = a.keys + (long long)(n0 + u) * T * A;
         const float* memo = a.memo + (long long)(n0 + u) * T * ENC;
-        for (int i = tid; i < nt * A; i += 512) { const int tl = i / A, j = i - tl * A; lds[o_keys + (u * ntmax + tl) * A + j] = keys[(long long)((tl << 5) + g) * A + j]; }
-        for (int i = tid; i < T * ncol; i += 512) { const int t = i / ncol, cl = i - t * ncol; lds[o_memo + (u * T + t) * ncol + cl] = memo[(long long)t * ENC + c0 + cl]; }
+        for (int i = tid; i < nt * A; i += 512) { const int tl = i / A, j = i - tl * A; lds[o_keys + (u * ntmax + tl) * kpitch + j + ((j >> 5) << 2)] = keys[(long long)((tl << 5) + g) * A + j]; }
+        for (int i = tid; i < T * ncol; i += 512) { const int t = i / ncol, cl = i - t * ncol; lds[o_memo + u * mpitch + t * ncol + 16 * (t >> 5) + cl] = memo[(long long)t * ENC + c0 + cl]; }
     }
-    for (int i = tid; i < A; i += 512) { lds[o_nv + i] = P[a.w.nv + i]; lds[o_ab + i] = P[a.w.ab + i]; }
-    for (int i = tid; i < 16 * tb.nst; i += 512) {
+    for (int i = tid; i < A; i += 512) { lds[o_nv + i + ((i >> 5) << 2)] = P[a.w.nv + i]; lds[o_ab + i + ((i >> 5) << 2)] = P[a.w.ab + i]; }
+    for (int i = tid; i < 16 * nst; i += 512) {
         const int st = i >> 4, col = 16 * g + (i & 15);
         lds[o_bias + i] = (tb.b[st] >= 0 && col < tb.N[st]) ? P[tb.b[st] + col] : 0.0f;
     }
     if (tid < 4) LDSI(o_abort + tid) = 0;
-    if (tid < tb.nst) {
-        const int q = o_tab + tid * 12;
-        LDSI(q + 0) = tb.K[tid]; LDSI(q + 1) = tb.N[tid]; LDSI(q + 2) = tb.act[tid]; LDSI(q + 3) = tb.post[tid];
-        LDSI(q + 4) = tb.xsel[tid]; LDSI(q + 5) = tb.dsel[tid]; LDSI(q + 6) = tb.p0[tid]; LDSI(q + 7) = tb.p1[tid]; LDSI(q + 8) = tb.p2[tid];
-        LDSI(q + 9) = tb.b[tid] >= 0 ? 1 : 0;
+    if (tid < nst) {
+        auto vsel = [&](int v) { return v == XV_FRAME ? u_frame : v == XV_VEC ? u_vec : v == XV_CATA ? u_cata : v == XV_CATB ? u_catb : v == XV_PQ ? u_pq : v == XV_Y ? u_y : u_catr + (v - XV_CATR) * 2 * DR; };
+        const int q = o_tab + tid * XS_STRIDE;
+        const int post = tb.post[tid], xo = vsel(tb.xsel[tid]), dst = vsel(tb.dsel[tid]), tp0 = tb.p0[tid], tp1 = tb.p1[tid], tp2 = tb.p2[tid];
+        for (int e = 0; e < XS_STRIDE; ++e) LDSI(q + e) = 0;
+        LDSI(q + XS_K) = tb.K[tid]; LDSI(q + XS_N) = tb.N[tid]; LDSI(q + XS_ACT) = tb.act[tid]; LDSI(q + XS_POST) = post;
+        LDSI(q + XS_XO) = xo; LDSI(q + XS_HASB) = tb.b[tid] >= 0 ? 1 : 0;
+        // gather kind and its parameters.  GATES: (cell input, nin, U); CAND: (U, layer, next layer or 0)
+        LDSI(q + XS_KIND) = post == DP_GATES ? XG_GATES : post == DP_CAND ? (tp2 < 0 ? XG_CAND_ATT : XG_CAND_RES) : post == DP_OUT ? XG_OUT : post == DP_QUERY ? XG_PQ : XG_PLAIN;
+        LDSI(q + XS_GDST) = post == DP_GATES ? xo : dst;
+        LDSI(q + XS_G0) = tp0; LDSI(q + XS_G1) = post == DP_GATES ? tp1 : tp1 - 1; LDSI(q + XS_G2) = tp2 - 1;
     }
-    const int nst = tb.nst;
+    __syncthreads();
+    // the stage table once more, where scalar loads can reach it (this workgroup's copy)
+    int* const stab = xa.stab + (long long)blockIdx.x * (kXStages * XS_STRIDE);
+    for (int e = tid; e < kXStages * XS_STRIDE; e += 512) stab[e] = LDSI(o_tab + e);
+    __threadfence();
     const float asb = P[a.w.asb];
     // ---- this wave's tasks and their register-resident row tiles
     int st_of[kXSlots], grp_of[kXSlots];
@@ -1799,76 +1844,76 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
     for (int j = 0; j < kXSlots; ++j)
         load_tile(wt[j], P + xa.xt_off + (((long long)g * 8 + wave) * kXSlots + j) * kTile, lane);
     __syncthreads();
+    __builtin_amdgcn_s_dcache_inv();
 
     unsigned ep = 0;
     bool ok = true;
     int it = 0, st = 0;
-    auto vsel = [&](int v) { return v == XV_FRAME ? u_frame : v == XV_VEC ? u_vec : v == XV_CATA ? u_cata : v == XV_CATB ? u_catb : v == XV_PQ ? u_pq : v == XV_Y ? u_y : u_catr + (v - XV_CATR) * 2 * DR; };
-    // Exchange `ep`: thread i collects element i (< cnt <= 512) of every utterance (granule u*512 + i) and puts it where its readers
-    // want it -- `kind` says what a value means (GRU gates / candidates update the cell state on the spot).
+    const int kAux = (int)(16u | 0x80000000u);
+    // Exchange `ep`, element i (< cnt <= 512) of utterance u = granule i * kXU + u: thread i collects its element of EVERY utterance with
+    // two 16-byte loads (each half carries its own tag) and puts the values where their readers want them -- `kind` says what a value
+    // means (GRU gates / candidates update the cell state on the spot).
     auto gather = [&](int cnt, int kind, int dst, int g0, int g1, int g2) {
-        const int boff = (int)(ep & 1u) * (kXU * 512);
-        bool done[kXU];
-#pragma unroll
-        for (int u = 0; u < kXU; ++u) done[u] = !(u < nu && tid < cnt);
+        const bool need = tid < cnt;
+        const int off = need ? (int)(((ep & 1u) * (kXU * 512) + (unsigned)tid * kXU) * 8u) : (int)0x7ffffff0;   // (out of range: zeros)
+        u32x4d qa = {0u, 0u, 0u, 0u}, qb = {0u, 0u, 0u, 0u};
+        bool fin = false;
         for (int itp = 0; itp < (1 << 20); ++itp) {
-#pragma unroll
-            for (int u = 0; u < kXU; ++u) {
-                if (!done[u]) {
-                    const u32x2d q = __builtin_amdgcn_raw_buffer_load_b64(rs, (boff + u * 512 + tid) * 8, 0, (int)(16u | 0x80000000u));
-                    if (q.y == ep) {
-                        done[u] = true;
-                        const float v = __uint_as_float(q.x);
-                        const int ub = u * UST, col = tid;
-                        if (kind == XG_PLAIN) lds[ub + dst + col] = v;
-                        else if (kind == XG_GATES) {          // tf.contrib.rnn.GRUCell, gate order r | u: keep h, cell input <- [x, r*h]
-                            const int nin = g0, U = g1;        // dst = the cell's concatenated input
-                            if (col < U) { const float h = lds[ub + dst + nin + col]; lds[ub + u_keep + col] = h; lds[ub + dst + nin + col] = v * h; }
-                            else lds[ub + u_vec + col] = v;
-                        } else if (kind == XG_CAND_ATT || kind == XG_CAND_RES) {       // h <- u*h + (1-u)*c
-                            const int U = g0;
-                            const float uu = lds[ub + u_vec + U + col], h = lds[ub + u_keep + col];
-                            const float t1 = uu * h, t2 = 1.0f - uu, t3 = t2 * v;
-                            const float hn = t1 + t3;
-                            if (kind == XG_CAND_ATT) {         // the attention rnn's state: next step's cell input, this step's query / projection input
-                                lds[ub + u_cata + D1 + ENC + col] = hn;
-                                lds[ub + u_catb + col] = hn;
-                            } else {                           // residual layer l = g1: y <- y + h (tacotron.py:167); next layer's input or the output projection's
-                                const int cr = u_catr + g1 * 2 * DR;
-                                lds[ub + cr + DR + col] = hn;
-                                const float yn = lds[ub + cr + col] + hn;
-                                if (g2 > 0) lds[ub + u_catr + g2 * 2 * DR + col] = yn; else lds[ub + u_y + col] = yn;
-                            }
-                        } else if (kind == XG_OUT) {           // tacotron.py:204 reshape; helpers.py:40 last frame fed back
-                            if (g == 0) a.mel[((long long)(n0 + u) * a.iters + it) * M * R + col] = v;
-                            if (col >= M * (R - 1)) lds[ub + u_frame + col - M * (R - 1)] = v;
-                        } else if (kind == XG_P) lds[ub + u_p + col] = v;
-                        else { lds[ub + u_cata + D1 + col] = v; lds[ub + u_catb + AS + col] = v; }       // XG_CTX
-                    }
-                }
-            }
-            if (__all(done[0] && done[1] && done[2] && done[3])) return;
+            asm volatile("" ::: "memory");
+            qa = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, kAux);
+            if (nu > 2) qb = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, kAux);
+            const bool got = !need || (qa.y == ep && (nu < 2 || qa.w == ep) && (nu < 3 || qb.y == ep) && (nu < 4 || qb.w == ep));
+            if (__all(got)) { fin = true; break; }
             if ((itp & 63) == 63 && LDSVI(o_abort)) return;
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
         }
-        LDSVI(o_abort) = 1;
+        if (!fin) { LDSVI(o_abort) = 1; return; }
+        if (!need) return;
+        const int col = tid;
+#pragma unroll
+        for (int u = 0; u < kXU; ++u) {
+            if (u < nu) {
+                const float v = __uint_as_float(u == 0 ? qa.x : u == 1 ? qa.z : u == 2 ? qb.x : qb.z);
+                const int ub = u * UST;
+                if (kind == XG_PLAIN) lds[ub + dst + col] = v;
+                else if (kind == XG_PQ) lds[ub + dst + col + ((col >> 5) << 2)] = v;      // the processed query goes into its skewed table
+                else if (kind == XG_GATES) {          // tf.contrib.rnn.GRUCell, gate order r | u: keep h, cell input <- [x, r*h]
+                    const int nin = g0, U = g1;        // dst = the cell's concatenated input
+                    if (col < U) { const float h = lds[ub + dst + nin + col]; lds[ub + u_keep + col] = h; lds[ub + dst + nin + col] = v * h; }
+                    else lds[ub + u_vec + col] = v;
+                } else if (kind == XG_CAND_ATT || kind == XG_CAND_RES) {       // h <- u*h + (1-u)*c
+                    const int U = g0;
+                    const float uu = lds[ub + u_vec + U + col], h = lds[ub + u_keep + col];
+                    const float t1 = uu * h, t2 = 1.0f - uu, t3 = t2 * v;
+                    const float hn = t1 + t3;
+                    if (kind == XG_CAND_ATT) {         // the attention rnn's state: next step's cell input, this step's query / projection input
+                        lds[ub + u_cata + D1 + ENC + col] = hn;
+                        lds[ub + u_catb + col] = hn;
+                    } else {                           // residual layer l = g1: y <- y + h (tacotron.py:167); next layer's input or the output projection's
+                        const int cr = u_catr + g1 * 2 * DR;
+                        lds[ub + cr + DR + col] = hn;
+                        const float yn = lds[ub + cr + col] + hn;
+                        if (g2 > 0) lds[ub + u_catr + g2 * 2 * DR + col] = yn; else lds[ub + u_y + col] = yn;
+                    }
+                } else if (kind == XG_OUT) {           // tacotron.py:204 reshape; helpers.py:40 last frame fed back
+                    if (g == 0) a.mel[((long long)(n0 + u) * a.iters + it) * M * R + col] = v;
+                    if (col >= M * (R - 1)) lds[ub + u_frame + col - M * (R - 1)] = v;
+                } else if (kind == XG_P) lds[ub + u_p + col] = v;
+                else { lds[ub + u_cata + D1 + col] = v; lds[ub + u_catb + AS + col] = v; }       // XG_CTX
+            }
+        }
     };
     auto publish = [&](int u, int i, float v) {
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2d{__float_as_uint(v), ep}, rs, (int)((ep & 1u) * (kXU * 512) + u * 512 + i) * 8, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2d{__float_as_uint(v), ep}, rs, (int)(((ep & 1u) * (kXU * 512) + (unsigned)i * kXU + (unsigned)u) * 8u), 0, 0);
     };
 
     for (it = 0; it < a.iters && ok; ++it) {
         for (st = 0; st < nst && ok; ++st) {
-            const int q_ = o_tab + st * 12;
-            const int K = __builtin_amdgcn_readfirstlane(LDSI(q_ + 0)), N = __builtin_amdgcn_readfirstlane(LDSI(q_ + 1));
-            const int act = __builtin_amdgcn_readfirstlane(LDSI(q_ + 2)), post = __builtin_amdgcn_readfirstlane(LDSI(q_ + 3));
-            const int xsel = __builtin_amdgcn_readfirstlane(LDSI(q_ + 4)), dsel = __builtin_amdgcn_readfirstlane(LDSI(q_ + 5));
-            const int tp0 = __builtin_amdgcn_readfirstlane(LDSI(q_ + 6)), tp1 = __builtin_amdgcn_readfirstlane(LDSI(q_ + 7));
-            const int tp2 = __builtin_amdgcn_readfirstlane(LDSI(q_ + 8)), has_b = __builtin_amdgcn_readfirstlane(LDSI(q_ + 9));
-            const int xo = vsel(xsel), dst = vsel(dsel);
+            XSTAMPT(0)
+            const i32x16s rec = decg_sload16(stab + st * XS_STRIDE);
+            const int K = rec[XS_K], N = rec[XS_N], act = rec[XS_ACT], post = rec[XS_POST], xo = rec[XS_XO], has_b = rec[XS_HASB];
             const int nchunk = (K + 31) >> 5;
             const bool mine = 16 * g < N;
-            XSTAMPT(0)
             // ---- this wave's task of the stage (at most one): 16 columns x 4 chunks for every utterance, partials to LDS
 #pragma unroll
             for (int j = 0; j < kXSlots; ++j) {
@@ -1894,7 +1939,7 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                 }
             }
             XSTAMPT(1)
-            __syncthreads();
+            lds_barrier();
             XSTAMPT(2)
             // ---- wave 0: chunk values in chunk order (AC-1) + bias + activation -> the slice's 16 values per utterance
             ++ep;
@@ -1903,18 +1948,15 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                 if (u < nu && col < N) {
                     const int b = o_part + u * 24 * 16 + n;
                     float v = lds[b];
-                    int ch = 1;
-                    for (; ch + 7 < nchunk; ch += 8) {      // eight loads in flight, adds in chunk order
-                        const float c0_ = lds[b + ch * 16], c1 = lds[b + (ch + 1) * 16], c2 = lds[b + (ch + 2) * 16], c3 = lds[b + (ch + 3) * 16];
-                        const float c4 = lds[b + (ch + 4) * 16], c5 = lds[b + (ch + 5) * 16], c6 = lds[b + (ch + 6) * 16], c7 = lds[b + (ch + 7) * 16];
+                    // twelve chunk values requested at a time (the rows exist for 24 chunks whatever the stage's depth), adds in chunk order
+                    for (int c0_ = 1; c0_ < nchunk; c0_ += 12) {
+                        float c[12];
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) c[i] = lds[b + (c0_ + i < 24 ? c0_ + i : 23) * 16];
                         __builtin_amdgcn_sched_barrier(0);
-                        v = v + c0_; v = v + c1; v = v + c2; v = v + c3; v = v + c4; v = v + c5; v = v + c6; v = v + c7;
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) if (c0_ + i < nchunk) v = v + c[i];
                     }
-                    for (; ch + 3 < nchunk; ch += 4) {
-                        const float c0_ = lds[b + ch * 16], c1 = lds[b + (ch + 1) * 16], c2 = lds[b + (ch + 2) * 16], c3 = lds[b + (ch + 3) * 16];
-                        v = v + c0_; v = v + c1; v = v + c2; v = v + c3;
-                    }
-                    for (; ch < nchunk; ++ch) v = v + lds[b + ch * 16];
                     if (has_b) v = v + lds[o_bias + st * 16 + n];
                     if (act == DA_SIGMOID) v = sigmoid_e(v);
                     else if (act == DA_TANH) v = tanh_e(v);
@@ -1923,20 +1965,17 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                 }
             }
             XSTAMPT(3)
-            {
-                const int kind = post == DP_GATES ? XG_GATES : post == DP_CAND ? (tp2 < 0 ? XG_CAND_ATT : XG_CAND_RES) : post == DP_OUT ? XG_OUT : XG_PLAIN;
-                // GATES: (cell input, nin, U); CAND: (U, layer, next layer or 0)
-                gather(N, kind, post == DP_GATES ? xo : dst, tp0, post == DP_GATES ? tp1 : tp1 - 1, tp2 - 1);
-            }
+            gather(N, rec[XS_KIND], rec[XS_GDST], rec[XS_G0], rec[XS_G1], rec[XS_G2]);
             XSTAMPT(4)
-            __syncthreads();
+            lds_barrier();
             XSTAMPT(5)
             ok = LDSI(o_abort) == 0;
             if (!ok) break;
             if (post == DP_QUERY) {
                 // [RECALLED-TF BahdanauMonotonicAttention.__call__] score for the time steps t = g, g+32, ... of every utterance:
                 // one thread per (u, t, chunk, chain k): s_k = fma chain over j = k, k+4, ..., k+28; the four chains of a chunk sit in
-                // adjacent lanes and are combined as (s0+s1)+(s2+s3)
+                // adjacent lanes and are combined as (s0+s1)+(s2+s3).  Every 32-word chunk of the tables is skewed by 4 words and
+                // consecutive key rows lie 16 banks apart: the 64 lanes of a wave (8 chunks x 4 chains x 2 rows) read 64 distinct banks / words
                 const int ntask = nu * nt * nAch * 4;
                 for (int task0 = 0; task0 < ntask; task0 += 512) {
                     const int task = task0 + tid;
@@ -1945,16 +1984,16 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                     const int ch = live ? tc % nAch : 0, ut = live ? tc / nAch : 0;
                     const int u = ut / (nt > 0 ? nt : 1), tl = ut - u * nt;
                     float sk = 0.f;
-                    const int jb = ch * 32 + k, kl = o_keys + (u * ntmax + tl) * A + jb, pq = u * UST + u_pq + jb;
+                    const int js = ch * 36 + k, kl = o_keys + (u * ntmax + tl) * kpitch + js, pq = u * UST + u_pq + js;
 #pragma unroll
-                    for (int j = 0; j < 32; j += 4) sk = fma_(lds[o_nv + jb + j], tanh_e((lds[kl + j] + lds[pq + j]) + lds[o_ab + jb + j]), sk);
+                    for (int j = 0; j < 32; j += 4) sk = fma_(lds[o_nv + js + j], tanh_e((lds[kl + j] + lds[pq + j]) + lds[o_ab + js + j]), sk);
                     const float s1 = __shfl_xor(sk, 1);
                     const float pr = (k & 1) ? s1 + sk : sk + s1;       // lanes k=0,1 hold s0+s1 ; k=2,3 hold s2+s3 (operand order as written)
                     const float p2 = __shfl_xor(pr, 2);
                     if (live && k == 0) lds[o_scp + (u * ntmax + tl) * 8 + ch] = pr + p2;
                 }
                 XSTAMPT(6)
-                __syncthreads();
+                lds_barrier();
                 ++ep;
                 for (int i = tid; i < nu * nt; i += 512) {
                     const int u = i / nt, tl = i - u * nt, t = (tl << 5) + g;
@@ -1968,18 +2007,71 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                 }
                 XSTAMPT(7)
                 gather(T, XG_P, 0, 0, 0, 0);
-                __syncthreads();
+                lds_barrier();
                 XSTAMPT(8)
                 ok = LDSI(o_abort) == 0;
                 if (!ok) break;
-                // monotonic attention recurrence (redundant in every workgroup), wave u for utterance u, in registers:
+                // monotonic attention recurrence (redundant in every workgroup), in registers:
                 // cumprod(1 - p) as exp(exclusive cumsum(log(clip(1 - p)))) [RECALLED-TF safe_cumprod], then
                 // alignments = p * cumprod * inclusive cumsum(previous / clip(cumprod, 1e-10, 1))
-                if (wave < nu) {
+                const int nblk = (T + 63) >> 6;
+                if (nu * nblk <= 8) {
+                    // the 64-step blocks of AC-6 side by side: wave (u, b) scans block b of utterance u; a block needs from its predecessors
+                    // only the running total in front of its own scan -- total of block 0, + block 1's own total, ... : the same chain of
+                    // adds whether the blocks are scanned one after the other (the branch below) or their totals are summed afterwards
+                    const int wu = wave / nblk, wb = wave - wu * nblk;
+                    const bool actv = wave < nu * nblk;
+                    const int ub = (actv ? wu : 0) * UST, t = wb * 64 + lane;
+                    const bool live = actv && t < T;
+                    const int o_tot = o_scp + (actv ? wu : 0) * 8;          // block totals (the score chunk values are consumed)
+                    const float pv = live ? lds[ub + u_p + t] : 0.0f;
+                    float om = 1.0f - pv;
+                    const float tiny = 1.17549435e-38f;
+                    om = om < tiny ? tiny : (om > 1.0f ? 1.0f : om);
+                    const float lq = live ? log_e(om) : 0.0f;
+                    const float sc = scan64_f32_wave(lq);
+                    if (actv && lane == 63) lds[o_tot + wb] = sc;             // (the score chunk values were consumed in front of the p gather)
+                    lds_barrier();
+                    float carry = 0.0f, all = 0.0f;
+                    for (int b = 0; b < nblk; ++b) {
+                        const float tb_ = lds[o_tot + b];
+                        const float nx = b == 0 ? tb_ : all + tb_;
+                        if (b < wb) carry = nx;
+                        all = nx;
+                    }
+                    const bool first = wb == 0;
+                    const float incl = first ? sc : carry + sc;
+                    const float up = __shfl_up(incl, 1);
+                    const float ex = lane == 0 ? (first ? 0.0f : carry) : up;
+                    const float cpv = exp_e(ex);
+                    float den = cpv;
+                    den = den < 1e-10f ? 1e-10f : (den > 1.0f ? 1.0f : den);
+                    const float q2 = live ? div_(lds[ub + u_al + t], den) : 0.0f;
+                    const float sc2 = scan64_f32_wave(q2);
+                    lds_barrier();                                         // (the first totals have been read)
+                    if (actv && lane == 63) lds[o_tot + wb] = sc2;
+                    lds_barrier();
+                    float carry2 = 0.0f, all2 = 0.0f;
+                    for (int b = 0; b < nblk; ++b) {
+                        const float tb_ = lds[o_tot + b];
+                        const float nx = b == 0 ? tb_ : all2 + tb_;
+                        if (b < wb) carry2 = nx;
+                        all2 = nx;
+                    }
+                    const float cs = first ? sc2 : carry2 + sc2;
+                    if (live) {
+                        const float pc = pv * cpv;
+                        const float al = pc * cs;
+                        lds[ub + u_al + t] = al;
+                        if (a.align && g == 0) a.align[((long long)(n0 + wu) * T + t) * a.iters + it] = al;      // tacotron.py:223
+                    }
+                    if (actv && wb == nblk - 1) for (int tt = T + lane; tt < Tp; tt += 64) lds[ub + u_al + tt] = 0.0f;
+                } else if (wave < nu) {
+                    // wave u walks the blocks of utterance u
                     const int ub = wave * UST;
                     float run = 0.0f, run2 = 0.0f;
                     for (int base = 0; base < T; base += 64) {
-                        const int t = base + lane, nb_ = T - base < 64 ? T - base : 64;
+                        const int t = base + lane;
                         const bool live = t < T;
                         const float pv = live ? lds[ub + u_p + t] : 0.0f;
                         float om = 1.0f - pv;
@@ -2001,26 +2093,28 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                     }
                     for (int t = T + lane; t < Tp; t += 64) lds[ub + u_al + t] = 0.0f;
                 }
-                __syncthreads();
+                lds_barrier();
                 XSTAMPT(9)
                 // rnn_wrappers.py:390 context = alignments . values: this slice takes ENC/32 columns; one thread per (utterance, column,
-                // 32-step chunk), chunk values added in order
+                // 32-step chunk, CHAIN k): the chunk's four interleaved fma chains (AC-1) sit in four adjacent lanes, eight dependent fmas
+                // each, and meet as (s0+s1)+(s2+s3) through two lane exchanges -- the same adds in the same order; chunk values added in order
                 {
-                    const int ntk = nu * ncol * nch_t;
-                    for (int task = tid; task < ntk; task += 512) {
-                        const int cl = task % ncol, uc = task / ncol, ch = uc % nch_t, u = uc / nch_t;
-                        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                    const int ntk = nu * ncol * nch_t * 4;
+                    for (int task0 = 0; task0 < ntk; task0 += 512) {
+                        const int task = task0 + tid;
+                        const bool live = task < ntk;
+                        const int k = task & 3, tc = live ? task >> 2 : 0;
+                        const int cl = tc % ncol, uc = tc / ncol, ch = uc % nch_t, u = uc / nch_t;
                         const int ta = ch * 32, tbb = T < ta + 32 ? T : ta + 32;
-                        const int mo = o_memo + u * T * ncol + cl, al = u * UST + u_al;
-                        for (int t = ta; t < tbb; t += 4) {
-                            s0 = fma_(lds[mo + t * ncol], lds[al + t], s0);
-                            if (t + 1 < tbb) s1 = fma_(lds[mo + (t + 1) * ncol], lds[al + t + 1], s1);
-                            if (t + 2 < tbb) s2 = fma_(lds[mo + (t + 2) * ncol], lds[al + t + 2], s2);
-                            if (t + 3 < tbb) s3 = fma_(lds[mo + (t + 3) * ncol], lds[al + t + 3], s3);
-                        }
-                        lds[o_part + (u * nch_t + ch) * ncol + cl] = (s0 + s1) + (s2 + s3);
+                        const int mo = o_memo + u * mpitch + 16 * ch + cl, al = u * UST + u_al;
+                        float sk = 0.f;
+                        if (live) for (int t = ta + k; t < tbb; t += 4) sk = fma_(lds[mo + t * ncol], lds[al + t], sk);
+                        const float s1 = __shfl_xor(sk, 1);
+                        const float pr = (k & 1) ? s1 + sk : sk + s1;       // lanes k = 0,1 hold s0+s1 ; k = 2,3 hold s2+s3 (operand order as written)
+                        const float p2 = __shfl_xor(pr, 2);
+                        if (live && k == 0) lds[o_part + (u * nch_t + ch) * ncol + cl] = pr + p2;
                     }
-                    __syncthreads();
+                    lds_barrier();
                     ++ep;
                     if (tid < nu * ncol) {
                         const int u = tid / ncol, cl = tid - u * ncol;
@@ -2030,7 +2124,7 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                     }
                     XSTAMPT(10)
                     gather(ENC, XG_CTX, 0, 0, 0, 0);
-                    __syncthreads();
+                    lds_barrier();
                     ok = LDSI(o_abort) == 0;
                     if (!ok) break;
                 }
@@ -2558,17 +2652,15 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
         taco_xstages(h, xt);
         const int upx = (N + 7) / 8;
         long long xfl = 0;
-        {   // LDS of tc_decoder_x_kernel (mirrors its carve)
-            const int nu = upx < N ? upx : N, ncol = ENC / 32, ntm = (T + 31) / 32;
-            const long long ust = (M + 31) / 32 * 32 + 1024 + (da.D1 + ENC + AS) + (AS + ENC) + d.dec_layer_num * 2 * DR + 512 + DR + A + Tp * 2;
-            const long long p1 = (long long)nu * 16 * 24, p2 = (long long)nu * ntm * ncol;
-            xfl = ust * nu + 2 * A + 16 * xt.nst + (long long)nu * ntm * 8 + (long long)nu * ntm * A + (long long)nu * T * ncol + (p1 > p2 ? p1 : p2) + 4 + kXStages * 12 + 64;
+        {   // LDS of tc_decoder_x_kernel (the kernel's own carve)
+            const int nu = upx < N ? upx : N;
+            xfl = xdec_carve(M, da.D1, ENC, AS, d.dec_layer_num, DR, A, T, nu < 1 ? 1 : nu, xt.nst).total + 64;
         }
         const bool xok = taco_xdec_ok(h, xt) && cus >= 256 && upx <= kXU && T <= 512 && xfl * 4 <= 160 * 1024;
         if (h->dec_groups == 32 && xok) {      // opt-in cross-check: 44.6 us per decoder step against the split kernel's 30.5
             // XCD-local kernel: every XCD's 32 workgroups hold the decoder in registers and serve that XCD's utterances
             DecXArgs xa;
-            xa.d = da; xa.tab = xt; xa.upx = upx; xa.xt_off = h->xt_off;
+            xa.d = da; xa.tab = xt; xa.upx = upx; xa.xt_off = h->xt_off; xa.stab = reinterpret_cast<int*>(stabf);
             xa.exch = reinterpret_cast<unsigned long long*>(xexch);
             xa.tickets = reinterpret_cast<int*>(xexch + 8LL * 2 * kXU * 512 * 2);
             HIPCHK(hipMemsetAsync(xexch, 0, (size_t)(8LL * 2 * kXU * 512 * 2 + 64) * 4, st));
