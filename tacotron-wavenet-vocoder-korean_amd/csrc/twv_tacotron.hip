@@ -1758,7 +1758,10 @@ __host__ __device__ inline XCarve xdec_carve(int M, int D1, int ENC, int AS, int
 //   * barriers are LDS-only (s_waitcnt lgkmcnt(0) + s_barrier): the mel / alignment stores of slice 0 no longer drain inside them
 //   * the chunk-sum wave requests all chunk values at once; score tables skewed against LDS bank conflicts; the context's four chains
 //     of a chunk on four lanes; the attention recurrence's 64-step blocks side by side on separate waves (AC-6, same adds)
-template <bool PROF>
+// DEF: the hparams-default decoder sizes (hparams.py:126-158) as compile-time constants: the LDS carve and most index arithmetic fold
+// (the kernel lives at the scalar-register limit: every run-time size is a spilled SGPR somewhere in the step loop)
+// MM: the tasks run on the matrix core (three or four utterances per XCD); with one or two the row-broadcast fmas are shorter.
+template <bool PROF, bool DEF, bool MM>
 __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
 {
 #define XSTAMPT(k) if (PROF && a.prof && xcc == 0 && g == 0 && tid == 0 && it == 3) a.prof[st * 16 + (k)] = __builtin_amdgcn_s_memtime();
@@ -1766,7 +1769,8 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
     const XStageTab& tb = xa.tab;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int T = a.T, M = a.M, R = a.R, A = a.A, AS = a.AS, ENC = a.ENC, DR = a.DR, D1 = a.D1;
+    const int T = a.T, M = DEF ? 80 : a.M, R = DEF ? 5 : a.R, A = DEF ? 256 : a.A, AS = DEF ? 256 : a.AS, ENC = DEF ? 256 : a.ENC;
+    const int DR = DEF ? 256 : a.DR, D1 = DEF ? 128 : a.D1, NLY = DEF ? 2 : a.layers;
     // ---- which XCD, which slice
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -1782,8 +1786,8 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
     if (g >= 32) return;
     const float* P = a.P;
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xa.exch + (long long)xcc * 2 * kXU * 512, 0, 2 * kXU * 512 * 8, 0x00020000);
-    const int nst = tb.nst;
-    const XCarve cv = xdec_carve(M, D1, ENC, AS, a.layers, DR, A, T, nu, nst);
+    const int nst = DEF ? 11 : tb.nst;
+    const XCarve cv = xdec_carve(M, D1, ENC, AS, NLY, DR, A, T, nu, nst);
     const int Tp = cv.Tp, UST = cv.UST;
     const int u_frame = cv.u_frame, u_vec = cv.u_vec, u_cata = cv.u_cata, u_catb = cv.u_catb, u_catr = cv.u_catr, u_keep = cv.u_keep;
     const int u_y = cv.u_y, u_pq = cv.u_pq, u_al = cv.u_al, u_p = cv.u_p;
@@ -1800,12 +1804,12 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
     for (int u = 0; u < kXU; ++u) len[u] = u < nu ? a.lengths[n0 + u] : 0;
     for (int u = 0; u < nu; ++u) {
         const int ub = u * UST;
-        const float* init = a.init + (long long)(n0 + u) * (AS + a.layers * DR);
+        const float* init = a.init + (long long)(n0 + u) * (AS + NLY * DR);
         for (int i = tid; i < UST; i += 512) lds[ub + i] = 0.0f;
         __syncthreads();
         // initial state (tacotron.py:184-195, AttentionWrapper.zero_state, helpers.py:90-92): go-frame, context and y zero
         for (int i = tid; i < AS; i += 512) { lds[ub + u_cata + D1 + ENC + i] = init[i]; lds[ub + u_catb + i] = init[i]; }
-        for (int i = tid; i < a.layers * DR; i += 512) { const int l = i / DR, k = i - l * DR; lds[ub + u_catr + l * 2 * DR + DR + k] = init[AS + i]; }
+        for (int i = tid; i < NLY * DR; i += 512) { const int l = i / DR, k = i - l * DR; lds[ub + u_catr + l * 2 * DR + DR + k] = init[AS + i]; }
         if (tid == 0) lds[ub + u_al] = 1.0f;                // one-hot at 0 [RECALLED-TF initial_alignments]
         const float* keys = a.keys + (long long)(n0 + u) * T * A;
         const float* memo = a.memo + (long long)(n0 + u) * T * ENC;
@@ -1853,11 +1857,17 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
     // Exchange `ep`, element i (< cnt <= 512) of utterance u = granule i * kXU + u: thread i collects its element of EVERY utterance with
     // two 16-byte loads (each half carries its own tag) and puts the values where their readers want them -- `kind` says what a value
     // means (GRU gates / candidates update the cell state on the spot).
-    auto gather = [&](int cnt, int kind, int dst, int g0, int g1, int g2) {
+    // `owner`: this workgroup published a share of the exchange a moment ago (nothing can arrive before the L2 hop has passed); a
+    // workgroup without columns in the stage arrives a whole dots + chunk-sum phase early and would only load the L2 slices the
+    // publishers' stores have to pass: it sleeps through most of that phase first.
+    auto gather = [&](int cnt, int kind, int dst, int g0, int g1, int g2, bool owner) {
         const bool need = tid < cnt;
         const int off = need ? (int)(((ep & 1u) * (kXU * 512) + (unsigned)tid * kXU) * 8u) : (int)0x7ffffff0;   // (out of range: zeros)
         u32x4d qa = {0u, 0u, 0u, 0u}, qb = {0u, 0u, 0u, 0u};
         bool fin = false;
+        if (!owner) __builtin_amdgcn_s_sleep(32);
+        else if (wave != 0) __builtin_amdgcn_s_sleep(10);
+        else __builtin_amdgcn_s_sleep(3);
         for (int itp = 0; itp < (1 << 20); ++itp) {
             asm volatile("" ::: "memory");
             qa = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, kAux);
@@ -1865,7 +1875,7 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
             const bool got = !need || (qa.y == ep && (nu < 2 || qa.w == ep) && (nu < 3 || qb.y == ep) && (nu < 4 || qb.w == ep));
             if (__all(got)) { fin = true; break; }
             if ((itp & 63) == 63 && LDSVI(o_abort)) return;
-            __builtin_amdgcn_s_sleep(1);
+            if (!owner) __builtin_amdgcn_s_sleep(1);
         }
         if (!fin) { LDSVI(o_abort) = 1; return; }
         if (!need) return;
@@ -1896,8 +1906,7 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                         if (g2 > 0) lds[ub + u_catr + g2 * 2 * DR + col] = yn; else lds[ub + u_y + col] = yn;
                     }
                 } else if (kind == XG_OUT) {           // tacotron.py:204 reshape; helpers.py:40 last frame fed back
-                    if (g == 0) a.mel[((long long)(n0 + u) * a.iters + it) * M * R + col] = v;
-                    if (col >= M * (R - 1)) lds[ub + u_frame + col - M * (R - 1)] = v;
+                    if (col >= M * (R - 1)) lds[ub + u_frame + col - M * (R - 1)] = v;   // (the mel frame itself is written by its publisher)
                 } else if (kind == XG_P) lds[ub + u_p + col] = v;
                 else { lds[ub + u_cata + D1 + col] = v; lds[ub + u_catb + AS + col] = v; }       // XG_CTX
             }
@@ -1914,27 +1923,44 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
             const int K = rec[XS_K], N = rec[XS_N], act = rec[XS_ACT], post = rec[XS_POST], xo = rec[XS_XO], has_b = rec[XS_HASB];
             const int nchunk = (K + 31) >> 5;
             const bool mine = 16 * g < N;
-            // ---- this wave's task of the stage (at most one): 16 columns x 4 chunks for every utterance, partials to LDS
+            const float bias_v = (wave == 0 && has_b) ? lds[o_bias + st * 16 + (lane & 15)] : 0.0f;      // (requested ahead of the chunk sums)
+            // ---- this wave's task of the stage (at most one): 16 columns x 4 chunks for every utterance, partials to LDS.
+            // On the matrix core: v_mfma_f32_4x4x1_16b_f32 is sixteen independent 4 x 4 outer products, D[i][j] += A[i] * B[j] -- one fused
+            // multiply-add per element, like the 32x32x2 form (scripts/ubench/mfma_f32_order.hip).  Block = four of the task's 64 (chunk,
+            // column) lanes, B = the tile register of reduction index k as it stands (lane = (chunk row, column)), A = x_u[k] of the lane's
+            // chunk for utterance u = lane mod 4, D register u = utterance u's partial in the tile's own lane layout: ONE instruction per
+            // k serves all four utterances (four v_fmac_f32_dpp before).  AC-1: chain j accumulates k = j, j + 4, ... from +0.
 #pragma unroll
             for (int j = 0; j < kXSlots; ++j) {
                 if (st_of[j] == st) {
                     const int c = 4 * grp_of[j] + (lane >> 4);
                     const bool live = c < nchunk;
-                    float x0[kXU], x1[kXU];
+                    if (MM) {
+                        const int ua = (lane & 3) < nu ? (lane & 3) : 0;
+                        const int xb_ = ua * UST + xo + 32 * (live ? c : 0);
+                        f32x4 xq[8];
 #pragma unroll
-                    for (int u = 0; u < kXU; ++u) {              // every operand requested before the first dot
-                        const int xb_ = u * UST + xo + 32 * c + (lane & 15);
-                        x0[u] = (live && u < nu) ? lds[xb_] : 0.0f;
-                        x1[u] = (live && u < nu) ? lds[xb_ + 16] : 0.0f;
-                    }
+                        for (int q = 0; q < 8; ++q) xq[q] = LDS4((xb_ >> 2) + q);
+                        f32x4 acc[4];
 #pragma unroll
-                    for (int u = 0; u < kXU; u += 2) {
-                        if (u < nu) {
-                            float r0, r1;
-                            dot32_dpp_x2(wt[j].w, x0[u], x1[u], wt[j].w, x0[u + 1], x1[u + 1], r0, r1);    // two utterances interleaved
-                            if (live) lds[o_part + (u * 24 + c) * 16 + (lane & 15)] = r0;
-                            if (live && u + 1 < nu) lds[o_part + ((u + 1) * 24 + c) * 16 + (lane & 15)] = r1;
+                        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int k = 0; k < 32; ++k)
+                            acc[k & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(xq[k >> 2][k & 3], wt[j].w[k], acc[k & 3], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < kXU; ++u) {
+                            const float r = (acc[0][u] + acc[1][u]) + (acc[2][u] + acc[3][u]);
+                            if (live && u < nu) lds[o_part + (u * 24 + c) * 16 + (lane & 15)] = r;
                         }
+                    } else {
+                        // one or two utterances: the chunk as 32 v_fmac_f32_dpp per utterance, operand fed by row_newbcast, two utterances interleaved
+                        const int xb_ = xo + 32 * c + (lane & 15);
+                        const float x00 = live ? lds[xb_] : 0.0f, x01 = live ? lds[xb_ + 16] : 0.0f;
+                        const float x10 = (live && nu > 1) ? lds[UST + xb_] : 0.0f, x11 = (live && nu > 1) ? lds[UST + xb_ + 16] : 0.0f;
+                        float r0, r1;
+                        dot32_dpp_x2(wt[j].w, x00, x01, wt[j].w, x10, x11, r0, r1);
+                        if (live) lds[o_part + c * 16 + (lane & 15)] = r0;
+                        if (live && nu > 1) lds[o_part + (24 + c) * 16 + (lane & 15)] = r1;
                     }
                 }
             }
@@ -1957,15 +1983,16 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
 #pragma unroll
                         for (int i = 0; i < 12; ++i) if (c0_ + i < nchunk) v = v + c[i];
                     }
-                    if (has_b) v = v + lds[o_bias + st * 16 + n];
+                    if (has_b) v = v + bias_v;
                     if (act == DA_SIGMOID) v = sigmoid_e(v);
                     else if (act == DA_TANH) v = tanh_e(v);
                     else if (act == DA_RELU) v = v > 0.0f ? v : 0.0f;
                     publish(u, col, v);
+                    if (post == DP_OUT) a.mel[((long long)(n0 + u) * a.iters + it) * M * R + col] = v;     // tacotron.py:204 reshape
                 }
             }
             XSTAMPT(3)
-            gather(N, rec[XS_KIND], rec[XS_GDST], rec[XS_G0], rec[XS_G1], rec[XS_G2]);
+            gather(N, rec[XS_KIND], rec[XS_GDST], rec[XS_G0], rec[XS_G1], rec[XS_G2], mine);
             XSTAMPT(4)
             lds_barrier();
             XSTAMPT(5)
@@ -2006,7 +2033,7 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                     publish(u, t, t < lu ? sigmoid_e(sc) : 0.0f);         // _maybe_mask_score(-inf) -> p = 0
                 }
                 XSTAMPT(7)
-                gather(T, XG_P, 0, 0, 0, 0);
+                gather(T, XG_P, 0, 0, 0, 0, true);
                 lds_barrier();
                 XSTAMPT(8)
                 ok = LDSI(o_abort) == 0;
@@ -2048,12 +2075,11 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                     den = den < 1e-10f ? 1e-10f : (den > 1.0f ? 1.0f : den);
                     const float q2 = live ? div_(lds[ub + u_al + t], den) : 0.0f;
                     const float sc2 = scan64_f32_wave(q2);
-                    lds_barrier();                                         // (the first totals have been read)
-                    if (actv && lane == 63) lds[o_tot + wb] = sc2;
+                    if (actv && lane == 63) lds[o_tot + 32 + wb] = sc2;       // (words of their own: the first totals may still be being read)
                     lds_barrier();
                     float carry2 = 0.0f, all2 = 0.0f;
                     for (int b = 0; b < nblk; ++b) {
-                        const float tb_ = lds[o_tot + b];
+                        const float tb_ = lds[o_tot + 32 + b];
                         const float nx = b == 0 ? tb_ : all2 + tb_;
                         if (b < wb) carry2 = nx;
                         all2 = nx;
@@ -2063,7 +2089,7 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                         const float pc = pv * cpv;
                         const float al = pc * cs;
                         lds[ub + u_al + t] = al;
-                        if (a.align && g == 0) a.align[((long long)(n0 + wu) * T + t) * a.iters + it] = al;      // tacotron.py:223
+                        if (a.align && (t & 31) == g) a.align[((long long)(n0 + wu) * T + t) * a.iters + it] = al;      // tacotron.py:223 (every slice holds all of them: slice t mod 32 writes)
                     }
                     if (actv && wb == nblk - 1) for (int tt = T + lane; tt < Tp; tt += 64) lds[ub + u_al + tt] = 0.0f;
                 } else if (wave < nu) {
@@ -2088,7 +2114,7 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                             const float pc = pv * cpv;
                             const float al = pc * cs;
                             lds[ub + u_al + t] = al;
-                            if (a.align && g == 0) a.align[((long long)(n0 + wave) * T + t) * a.iters + it] = al;      // tacotron.py:223
+                            if (a.align && (t & 31) == g) a.align[((long long)(n0 + wave) * T + t) * a.iters + it] = al;      // tacotron.py:223
                         }
                     }
                     for (int t = T + lane; t < Tp; t += 64) lds[ub + u_al + t] = 0.0f;
@@ -2123,7 +2149,7 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                         publish(u, c0 + cl, v);
                     }
                     XSTAMPT(10)
-                    gather(ENC, XG_CTX, 0, 0, 0, 0);
+                    gather(ENC, XG_CTX, 0, 0, 0, 0, true);
                     lds_barrier();
                     ok = LDSI(o_abort) == 0;
                     if (!ok) break;
@@ -2352,6 +2378,8 @@ static bool taco_xdec_ok(const twv_tacotron* h, const XStageTab& t)
 {
     const twv_tacotron_dims& d = h->d;
     if (t.nst > kXStages || d.attention_size % 32 || (2 * d.enc_rnn_size) % 32 || d.attention_size > 256 || d.dec_layer_num > 4) return false;
+    // (the stage inputs are fetched with 16-byte LDS reads: every vector of an utterance's LDS block starts on a multiple of four floats)
+    if (d.dec_prenet_sizes[1] % 4 || d.attention_state_size % 4 || d.dec_rnn_size % 4) return false;
     for (int s = 0; s < t.nst; ++s) if (t.N[s] > 512 || t.K[s] > 24 * 32) return false;
     for (int g = 0; g < 32; ++g) {
         int a[kXSlots], b[kXSlots];
@@ -2657,7 +2685,10 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             xfl = xdec_carve(M, da.D1, ENC, AS, d.dec_layer_num, DR, A, T, nu < 1 ? 1 : nu, xt.nst).total + 64;
         }
         const bool xok = taco_xdec_ok(h, xt) && cus >= 256 && upx <= kXU && T <= 512 && xfl * 4 <= 160 * 1024;
-        if (h->dec_groups == 32 && xok) {      // opt-in cross-check: 44.6 us per decoder step against the split kernel's 30.5
+        // Which kernel (round 6, scripts/tacotron_bench.py --batch 8 / 16 / 32): the XCD-resident kernel runs a pass in 6.7 / 7.4 / 9.2 ms, the
+        // split kernel in 7.6 / 8.0 / 8.8 -- with one or two utterances per XCD the resident kernel's exchanges (32 workgroups, every weight
+        // in registers, no tile stream in front of the polls) are the shorter ones, with four the split kernel's 8-workgroup groups are.
+        if (xok && (h->dec_groups == 32 || (h->dec_groups == 0 && N <= 16))) {
             // XCD-local kernel: every XCD's 32 workgroups hold the decoder in registers and serve that XCD's utterances
             DecXArgs xa;
             xa.d = da; xa.tab = xt; xa.upx = upx; xa.xt_off = h->xt_off; xa.stab = reinterpret_cast<int*>(stabf);
@@ -2665,13 +2696,15 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             xa.tickets = reinterpret_cast<int*>(xexch + 8LL * 2 * kXU * 512 * 2);
             HIPCHK(hipMemsetAsync(xexch, 0, (size_t)(8LL * 2 * kXU * 512 * 2 + 64) * 4, st));
             const size_t shm = (size_t)xfl * 4;
-            if (da.prof) {
-                HIPCHK(hipFuncSetAttribute((const void*)tc_decoder_x_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-                hipLaunchKernelGGL(tc_decoder_x_kernel<true>, dim3(2 * cus), dim3(512), shm, st, xa);
-            } else {
-                HIPCHK(hipFuncSetAttribute((const void*)tc_decoder_x_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-                hipLaunchKernelGGL(tc_decoder_x_kernel<false>, dim3(2 * cus), dim3(512), shm, st, xa);
-            }
+            const bool xdef = M == 80 && R == 5 && A == 256 && AS == 256 && ENC == 256 && DR == 256 && da.D1 == 128 && d.dec_layer_num == 2 && xt.nst == 11;
+            const bool mm = upx > 2;
+            const void* kfn = da.prof ? (xdef ? (mm ? (const void*)tc_decoder_x_kernel<true, true, true> : (const void*)tc_decoder_x_kernel<true, true, false>)
+                                              : (mm ? (const void*)tc_decoder_x_kernel<true, false, true> : (const void*)tc_decoder_x_kernel<true, false, false>))
+                                      : (xdef ? (mm ? (const void*)tc_decoder_x_kernel<false, true, true> : (const void*)tc_decoder_x_kernel<false, true, false>)
+                                              : (mm ? (const void*)tc_decoder_x_kernel<false, false, true> : (const void*)tc_decoder_x_kernel<false, false, false>));
+            HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            void* kargs[] = {&xa};
+            HIPCHK(hipLaunchKernel(kfn, dim3(2 * cus), dim3(512), kargs, shm, st));
         } else if (h->dec_groups == 32) {
             return twv_fail(TWV_E_UNSUPPORTED, "decoder_groups = 32 (XCD-local decoder) needs 256 CUs, batch <= 32, t_in <= 512 and the default decoder sizes");
         } else
