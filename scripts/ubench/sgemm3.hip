@@ -1,0 +1,216 @@
+// Round 6 harness of the training step's own f32-MFMA GEMMs (development copy of csrc/twv_gemm.hpp's kernels):
+//   NT:  C[M][N] = A[M][K] . Bt[N][K]^T      TN:  C[M][N] = sum_r A[r][M] B[r][N]  (split over row slabs)
+// Workgroup = 4 waves on a 256 x 128 tile (wave = 128 x 64 = 4 x 2 blocks of v_mfma_f32_32x32x2_f32), K advances 16 per step through
+// three LDS stages filled by LDS-DMA (global_load_lds b128), fragments of the next half step read while the current one multiplies.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+extern __shared__ __attribute__((aligned(16))) float dyn[];
+#define LDS4(p) (*reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((const __attribute__((address_space(3))) float*)(p)))
+
+#ifndef NSTAGE
+#define NSTAGE 3
+#endif
+constexpr int TM = 256, TN = 128, TK = 16;
+constexpr int SA = TM * TK, SB = TN * TK, SS = SA + SB;          // floats per stage
+
+// LDS image of an operand tile [rows][16]: 64-byte rows, the 16-byte quad q of row r at position q ^ ((r >> 1) & 3) (DMA writes linearly:
+// the swizzle is applied to the global address a lane fetches); a ds_read_b128 of 32 consecutive rows at one quad touches every bank group
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) sgemm_nt3_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bt, int ldb, float* __restrict__ C, int ldc,
+                                                          int M, int N, int K, const float* __restrict__ bias)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 1, wc = wave & 1;
+    const int ntn = (N + TN - 1) / TN, ntm = (M + TM - 1) / TM, ntiles = ntm * ntn;
+    const int hh = lane >> 5, l31 = lane & 31;
+    const int nk = K / TK;
+    // XCD-aware tile order: workgroups go to the 8 XCDs round-robin (blockIdx % 8), each XCD has its own L2.  The ntn column tiles of a
+    // row tile share the A rows: they run on ONE XCD at the same time (slot % ntn), so a row tile crosses the fabric once, not ntn times.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;      // gridDim.x is a multiple of 8 * ntn
+    const int groups = per / ntn;                                                     // row tiles in flight per XCD
+    for (int it = 0;; ++it) {
+        const int tm = ((it * groups + slot / ntn) << 3) + xcd, tn = slot % ntn;
+        if (tm >= ntm) { if (((it * groups) << 3) >= ntm) break; else continue; }
+        if (slot >= groups * ntn) break;
+        const int m0 = tm * TM, n0 = tn * TN;
+        // DMA addresses: A tile = 1024 float4 slots (4 per thread), B tile = 512 (2 per thread); slot s: row s >> 2, position s & 3
+        int va[4], vb[2];                                        // byte offsets from the tile's first row (32-bit: a tile spans < 2 GB)
+        const int mrows = M - m0 < TM ? M - m0 : TM, nrows = N - n0 < TN ? N - n0 : TN;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int sl = (wave * 4 + h) * 64 + lane, row = sl >> 2, q = (sl & 3) ^ ((row >> 1) & 3);
+            va[h] = ((row < mrows ? row : mrows - 1) * lda + 4 * q) * 4;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int sl = (wave * 2 + h) * 64 + lane, row = sl >> 2, q = (sl & 3) ^ ((row >> 1) & 3);
+            vb[h] = ((row < nrows ? row : nrows - 1) * ldb + 4 * q) * 4;
+        }
+        const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (long long)m0 * lda), 0, 0x7fffffff, 0x00020000);
+        const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bt + (long long)n0 * ldb), 0, 0x7fffffff, 0x00020000);
+        auto dma = [&](int step, int buf) {
+#ifdef ABL_NODMA
+            if (step >= 0) return;
+#endif
+            float* as = dyn + buf * SS; float* bs = as + SA;
+            const int so = step * (TK * 4);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(as + (wave * 4 + h) * 256), 16, va[h], so, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(bs + (wave * 2 + h) * 256), 16, vb[h], so, 0, 0);
+        };
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
+        // fragment addresses (floats inside a stage): A row = wr * 128 + 32 x + l31, quad (2 i + hh) at position ^ swz(row)
+        int fa[4][2], fb[2][2];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int row = wr * 128 + 32 * x + l31;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[x][i] = row * 16 + (((2 * i + hh) ^ ((row >> 1) & 3)) << 2);
+        }
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int row = wc * 64 + 32 * y + l31;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fb[y][i] = SA + row * 16 + (((2 * i + hh) ^ ((row >> 1) & 3)) << 2);
+        }
+        dma(0, 0);
+        if (NSTAGE > 2) dma(nk > 1 ? 1 : 0, 1);
+        if (NSTAGE > 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        f32x4 ga[2][4], gb[2][2];                               // fragments of two half steps
+#pragma unroll
+        for (int x = 0; x < 4; ++x) ga[0][x] = LDS4(dyn + fa[x][0]);
+#pragma unroll
+        for (int y = 0; y < 2; ++y) gb[0][y] = LDS4(dyn + fb[y][0]);
+        int cur = 0;
+        for (int s = 0; s < nk; ++s) {
+            int nb2 = cur + (NSTAGE - 1); nb2 = nb2 >= NSTAGE ? nb2 - NSTAGE : nb2;
+            int nb1 = cur + 1; nb1 = nb1 >= NSTAGE ? nb1 - NSTAGE : nb1;
+            dma(s + NSTAGE - 1 < nk ? s + NSTAGE - 1 : s, nb2);          // (past the end: a valid step again, never read)
+            const float* st = dyn + cur * SS;
+            // half step 1 fragments while half step 0 multiplies
+#ifdef ABL_NOLDS
+            if (s < 0) {
+#else
+            {
+#endif
+#pragma unroll
+            for (int x = 0; x < 4; ++x) ga[1][x] = LDS4(st + fa[x][1]);
+#pragma unroll
+            for (int y = 0; y < 2; ++y) gb[1][y] = LDS4(st + fb[y][1]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[0][x][j], gb[0][y][j], acc[x][y], 0, 0, 0);
+#ifndef NO_SGB
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#endif
+            // the next step has landed (this wave's share); everybody's after the barrier
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#ifndef ABL_NOBAR
+            asm volatile("s_barrier" ::: "memory");
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef ABL_NOLDS
+            const float* sn = dyn + nb1 * SS; if (s < 0) {
+#else
+            const float* sn = dyn + nb1 * SS; {
+#endif
+#pragma unroll
+            for (int x = 0; x < 4; ++x) ga[0][x] = LDS4(sn + fa[x][0]);
+#pragma unroll
+            for (int y = 0; y < 2; ++y) gb[0][y] = LDS4(sn + fb[y][0]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[1][x][j], gb[1][y][j], acc[x][y], 0, 0, 0);
+#ifndef NO_SGB
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#endif
+            cur = nb1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        // epilogue: C layout lane = column (l31), register r = row (r & 3) + 8 (r >> 2) + 4 hh
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int n = n0 + wc * 64 + 32 * y + l31;
+            const float bv = (EPI == 1 && bias && n < N) ? bias[n] : 0.0f;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * 128 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    float v = acc[x][y][r];
+                    if (EPI == 1) { v = v + bv; v = v > 0.0f ? v : 0.0f; }
+                    if (m < M && n < N) C[(long long)m * ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
+int main(int argc, char** argv)
+{
+    const int M = argc > 1 ? atoi(argv[1]) : 300736, N = argc > 2 ? atoi(argv[2]) : 512, K = argc > 3 ? atoi(argv[3]) : 960;
+    const int wgs = argc > 4 ? atoi(argv[4]) : 512;
+    float *dA, *dB, *dC;
+    (void)hipMalloc(&dA, (size_t)M * K * 4); (void)hipMalloc(&dB, (size_t)N * K * 4); (void)hipMalloc(&dC, (size_t)M * N * 4);
+    std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+    unsigned s = 12345;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    for (auto& v : hA) v = rnd();
+    for (auto& v : hB) v = rnd();
+    (void)hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice); (void)hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
+    const size_t shm = (size_t)NSTAGE * SS * 4;
+    (void)hipFuncSetAttribute((const void*)sgemm_nt3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    auto launch = [&]() { hipLaunchKernelGGL(sgemm_nt3_kernel<0>, dim3(wgs), dim3(256), shm, 0, dA, K, dB, K, dC, N, M, N, K, (const float*)nullptr); };
+    launch();
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0);
+    const int reps = 5;
+    for (int r = 0; r < reps; ++r) launch();
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    std::vector<float> hC((size_t)300 * N);
+    (void)hipMemcpy(hC.data(), dC + (size_t)(M - 300) * N, hC.size() * 4, hipMemcpyDeviceToHost);
+    double worst = 0;
+    for (int i = 0; i < 300; i += 7)
+        for (int j = 0; j < N; j += 37) {
+            double ref = 0; const size_t m = (size_t)M - 300 + i;
+            for (int k = 0; k < K; ++k) ref += (double)hA[m * K + k] * hB[(size_t)j * K + k];
+            worst = fmax(worst, fabs(ref - hC[(size_t)i * N + j]));
+        }
+    printf("nt3 stages %d wgs %d  M %d N %d K %d: %.3f ms -> %.1f TFLOP/s; worst |err| vs f64 on samples %.3g (hipGetLastError %d)\n", NSTAGE, wgs, M, N, K, ms, 2.0 * M * N * K / ms / 1e9, worst, (int)hipGetLastError());
+    return 0;
+}
