@@ -68,6 +68,14 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 constexpr int kAuxLoad = (int)(16u | 0x80000000u), kAuxStore = 0;
+#ifndef TWV_XCD_KF
+#define TWV_XCD_KF 1
+#endif
+// TWV_XCD_PPOLL = 1: the two polls behind the last layers keep several loads in flight (see skip_role).  Measured, round 6: SLOWER -- 8.59
+// against 8.52 us per step at batch 8 (polling loads do not pipeline: the extra loads lengthen every round trip); off, kept for A/B runs.
+#ifndef TWV_XCD_PPOLL
+#define TWV_XCD_PPOLL 0
+#endif
 __device__ __forceinline__ unsigned long long xb_load(rsrc_t rs, int uword, int lword)
 {
     asm volatile("" ::: "memory");      // a poll must be re-issued on every trip of its loop: see below
@@ -774,13 +782,16 @@ __device__ __forceinline__ void service_role(const XArgs& xa, int b, rsrc_t rs)
 // BIG (more than 32 layers; hparams.py's default has 50): a wave holds FIVE tiles in registers -- the layers NLDS + v + 8i, the late
 // ones, whose values are needed soonest after they appear -- and the tiles of the first NLDS = NL - 40 layers (v, v + 8) sit in LDS
 // and pass through a sixth register tile when their turn comes.
-template <int INSTR, int NS, bool BIG>
+// KF (round 6): the LAST KF layers' skip 1x1 is not computed here but in the conv1 workgroups (conv1_role<..., KF>), which receive z of
+// those layers straight from the chain: the skip -> conv1 hop then only carries the running sum of the layers in front of them -- raw,
+// the relu follows the last add over there -- and leaves the path behind the last layer.
+template <int INSTR, int NS, bool BIG, int KF = 0>
 __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& sx, int g)
 {
     const XcdLaunch& a = xa.p;
     const Layout& L = a.lay;
     const int v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int NL = L.NL, T = a.T;
+    const int NL = L.NL - KF, T = a.T;                       // (the layers this role serves)
     const bool use_bias = L.use_bias != 0;
     Poll pl{sx.rs[0], a.status, 0, false};
     constexpr int kReg = BIG ? 5 : 4, kLds = BIG ? 2 : 0, kSlots = kReg + kLds;
@@ -817,6 +828,9 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
     // kernel (it set the step time at B = 32), so the streams from the third on are summed by a SECOND wave, the owner of layer NL-2,
     // which keeps a copy of the last layer's tile for them.
     constexpr bool SPLIT = NS >= 3 && !BIG;
+    // (Round 6, measured dead end: a DEDICATED summing wave -- every wave only fills the LDS slots, the wave whose own layers end first
+    // spins on them in layer order and publishes -- was 0.75-0.88 us from the last layer's z to the published sum against 0.64 us for the
+    // owner of the last layer summing between its polls: 9.0-9.1 instead of 8.5 us per step at batch 8.)
     const int vA = (NL - 1 - NLDS) & 7, vB = (SPLIT && NL >= 2) ? ((NL - 2) & 7) : -1;
     const bool sumA = v == vA, sumB = v == vB, anysum = sumA || sumB;
     Tile wx;                                                      // wave B: the last layer's tile
@@ -887,6 +901,25 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
                     // 32-63 z[16..31] twice; v_permlane32_swap makes the two dot operands of it
                     unsigned long long qz;
                     pl.it = 0;
+                    if (TWV_XCD_PPOLL && NS == 1 && summer && l == NL - 1) {
+                        // The poll on the sample path, PIPELINED (round 6): a poll is an L2 round trip (0.25 us) whether or not the granule
+                        // has arrived, so a wave that waits for its load before it issues the next one sees a new granule 0.25 - 0.5 us
+                        // after it landed.  Three loads in flight, a new one issued whenever the oldest comes back unsuccessful (loads
+                        // return in order: the wait for the oldest leaves the younger two in flight), sample the L2 every ~0.08 us.
+                        unsigned long long q0 = xb_load(rs, (int)XcdExch::ZX + l * 128, zc_lane * 2);
+                        drain(false);
+                        unsigned long long q1 = xb_load(rs, (int)XcdExch::ZX + l * 128, zc_lane * 2);
+                        drain(false);
+                        unsigned long long q2 = xb_load(rs, (int)XcdExch::ZX + l * 128, zc_lane * 2);
+                        for (;;) {
+                            drain(false);
+                            qz = q0;
+                            if (__all(g_tag(q0) == tag)) break;
+                            if (!poll_tick(pl, 51)) break;
+                            q0 = q1; q1 = q2;
+                            q2 = xb_load(rs, (int)XcdExch::ZX + l * 128, zc_lane * 2);
+                        }
+                    } else
                     for (;;) {
                         qz = xb_load(rs, (int)XcdExch::ZX + l * 128, zc_lane * 2);
                         if (summer) drain(false);                          // while the load is in flight: add what has arrived
@@ -916,7 +949,7 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
                         tot[k] = (l == 0) ? val : tot[k] + val;
                         nextl[k] = l + 1;
                         if (l == NL - 1 && !pl.dead) {                     // this stream's sum is complete: out it goes before the next stream's turn
-                            const float h = tot[k] > 0.0f ? tot[k] : 0.0f;                       // model.py:157
+                            const float h = (KF > 0 || tot[k] > 0.0f) ? tot[k] : 0.0f;           // model.py:157 (KF: the sum is not complete yet)
                             xb_store(rs, (int)XcdExch::H1 + g * 64, lane, tag, h);
                             XSTAMP(g == 0, 21);
                         }
@@ -950,7 +983,12 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
 //  CONV1 workgroup g: model.py:158-160 conv1d_1 + relu for output block g (16 chunk tiles over the 8 waves), then the two
 //  chunks (2g, 2g+1) of model.py:161-165 conv1d_2 that read this block: what travels on is conv1d_2's partial table.
 // =====================================================================================================================
-template <int INSTR, int NS, bool BAR = false, class SX = XStreams<NS>>
+// KF = 1 (round 6): wave v also holds block v of the LAST layer's skip kernel (model.py:94-96).  It polls that layer's z (the granule the
+// skip workgroups poll for their layers) next to the running sum of layers 0 .. NL-2 that skip workgroup v publishes, computes the last
+// skip value while the sum is still on its way, and finishes model.py:154's sum in layer order + relu itself: the last layer's z -> skip
+// workgroup -> dot / sum / publish -> conv1 path (0.31 + 0.33 + 0.25 us behind the last layer) becomes z -> conv1 (0.31 us) in parallel
+// with the second-to-last layer's trip through the skip workgroup.
+template <int INSTR, int NS, bool BAR = false, class SX = XStreams<NS>, int KF = 0>
 __device__ __forceinline__ void conv1_role(const XArgs& xa, const SX& sx, int g, const int ns_rt = NS, const int prof_slot = -1)
 {
     const XcdLaunch& a = xa.p;
@@ -973,6 +1011,14 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const SX& sx, int g,
         if (use_bias) b1v = a.P[L.off_b1 + g * 64 + lane];
         load_tile(t2, a.P + L.off_w2 + (long long)(2 * g + v) * kTile, lane);
     }
+    Tile wl;                                                              // KF: the last layer's skip kernel, output block v
+    float bl = 0.0f;
+    if (KF > 0) {
+        const long long lb = L.off_layer0 + (long long)(L.NL - 1) * L.layer_stride;
+        load_tile(wl, a.P + lb + LayerOff::SK + (long long)v * kTile, lane);
+        if (use_bias) bl = a.P[lb + LayerOff::SK + (long long)L.NSJ * kTile + v * 64 + lane];
+    }
+    const int zc_lane = lane_of_z((lane < 32 ? 0 : 16) + (lane & 15));
     unsigned long long t_arr = 0, period = 0;
     WACC_DECL();
     for (int t = 0; t < T && !pl.dead; ++t) {
@@ -994,11 +1040,46 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const SX& sx, int g,
             unsigned long long q;
             WACC_T0();
             pl.it = 0;
-            for (;;) {
-                q = xb_load_t<BAR>(rs, (int)XcdExch::H1 + v * 64, lane);
-                if (__all(g_tag(q) == tag)) break;
-                if (!poll_tick<BAR>(pl, 61)) break;
-                __builtin_amdgcn_s_sleep(1);
+            if (KF > 0) {
+                // the last layer's z arrives first: its skip value is ready when the running sum comes in
+                unsigned long long qz;
+                float val = 0.0f;
+                bool havez = false;
+                unsigned long long qn = 0, qzn = 0;                                          // the round in flight behind the one being looked at
+                if (TWV_XCD_PPOLL) {
+                    qzn = xb_load_t<BAR>(rs, (int)XcdExch::ZX + (L.NL - 1) * 128, zc_lane * 2);
+                    qn = xb_load_t<BAR>(rs, (int)XcdExch::H1 + v * 64, lane);
+                }
+                for (;;) {
+                    if (TWV_XCD_PPOLL) {                                                     // two rounds in flight (see the skip role's last poll)
+                        qz = qzn; q = qn;
+                        if (!havez) qzn = xb_load_t<BAR>(rs, (int)XcdExch::ZX + (L.NL - 1) * 128, zc_lane * 2);
+                        qn = xb_load_t<BAR>(rs, (int)XcdExch::H1 + v * 64, lane);
+                    } else {
+                    if (!havez) qz = xb_load_t<BAR>(rs, (int)XcdExch::ZX + (L.NL - 1) * 128, zc_lane * 2);
+                    q = xb_load_t<BAR>(rs, (int)XcdExch::H1 + v * 64, lane);
+                    }
+                    if (!havez && __all(g_tag(qz) == tag)) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)qz, (unsigned)qz, false, false);   // [lo, lo], [hi, hi]
+                        val = dot32_dpp(wl.w, __uint_as_float(sw[0]), __uint_as_float(sw[1]));                      // model.py:96
+                        if (use_bias) val = val + bl;
+                        havez = true;
+                        XSTAMP(g == 0 && v == 0, 44);
+                    }
+                    if (havez && __all(g_tag(q) == tag)) break;
+                    if (!poll_tick<BAR>(pl, 61)) break;
+                    if (!havez && !TWV_XCD_PPOLL) __builtin_amdgcn_s_sleep(1);
+                }
+                const float tot = g_val(q) + val;                                            // model.py:154: the last term of the sum
+                const float h = tot > 0.0f ? tot : 0.0f;                                     // model.py:157
+                q = (unsigned long long)__float_as_uint(h);
+            } else {
+                for (;;) {
+                    q = xb_load_t<BAR>(rs, (int)XcdExch::H1 + v * 64, lane);
+                    if (__all(g_tag(q) == tag)) break;
+                    if (!poll_tick<BAR>(pl, 61)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
             }
             WACC_T1(1);
             WTRACE(prof_slot >= 0 && k == 0, 400 + g * 8 + v);
@@ -1473,10 +1554,16 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
         XStreams<NS> sx;
 #pragma unroll
         for (int k = 0; k < NS; ++k) { sx.b[k] = (int)xcc + 8 * k; sx.rs[k] = exch_of(sx.b[k]); }
-        if (role < 8) { if (!forced) skip_role<INSTR, NS, BIGK>(xa, sx, role); }
+        // MoL head, 30 layers or fewer: the last layer's skip 1x1 runs in the conv1 workgroups (KF = 1; needs a layer in front of it)
+        constexpr int KF = (!BIGK && !ONEHOT) ? TWV_XCD_KF : 0;
+        const bool fold = KF > 0 && a.lay.NL > KF;
+        if (role < 8) {
+            if (!forced) { if (fold) skip_role<INSTR, NS, BIGK, KF>(xa, sx, role); else skip_role<INSTR, NS, BIGK, 0>(xa, sx, role); }
+        }
         else if (role < 16) {
             if (!forced) {
                 if constexpr (ONEHOT) conv1_onehot_role<INSTR, NS>(xa, sx, role - 8);
+                else if (fold) conv1_role<INSTR, NS, false, XStreams<NS>, KF>(xa, sx, role - 8);
                 else conv1_role<INSTR, NS>(xa, sx, role - 8);
             }
         }
