@@ -102,7 +102,7 @@ int twv_wavenet_condition_mel(const twv_wavenet* h, const void* packed, const fl
  *                 (generate.py:231).  Injected so that results are reproducible (the reference is unseeded).
  *   temperature : generate.py:219-222 (one-hot only).
  *   out         : (B, n_steps) float32 samples in [-1,1] (scalar_input) or int32 class ids.
- *   status      : device int32[4]; [0] = 0 on success, else an internal watchdog code (checked by twv_wavenet_status).
+ *   status      : device int32[4]; [0] = 0 on success, else an internal code (watchdogs; 31 = NaN class probabilities; checked by twv_wavenet_status).
  * State carries over between calls (n_steps=1 reproduces a single sess.run of generate.py:211).
  * cond must cover the same n_steps as this call (row t = frame pushed at step t). */
 int twv_wavenet_generate(const twv_wavenet* h, const void* packed, void* state, const void* cond,
@@ -149,7 +149,10 @@ int twv_wav_to_int16(const float* wav, int rows, int64_t n, int16_t* out, float*
 /* generate.py:219-231 on rows of logits in device memory: model.py:243 float64 softmax -> float32, the temperature rescale
  * (np.log(p) / T, minus its log-sum-exp, np.exp) and legacy np.random.choice (float64 cumsum / last / searchsorted 'right')
  * with the uniform draw injected.  logits (rows, Q) float, uniforms (rows) double in [0,1), out (rows) int32 class ids,
- * proba (rows, Q) float = generate.py:222's scaled_prediction, or NULL.  The generation kernels draw with the same code. */
+ * proba (rows, Q) float = generate.py:222's scaled_prediction, or NULL.  The generation kernels draw with the same code.
+ * A row whose probabilities are not numbers (a NaN or infinite logit) gets class id -1: np.random.choice raises
+ * "ValueError: probabilities contain NaN" on it.  Inside twv_wavenet_generate the same condition sets status code 31, which
+ * twv_wavenet_status turns into TWV_E_KERNEL with that explanation. */
 int twv_sample_categorical(const float* logits, int64_t rows, int quantization_channels, double temperature, const double* uniforms,
                            int32_t* out, float* proba, void* stream);
 
@@ -210,6 +213,9 @@ int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch, int n_samp
 void twv_wavenet_train_destroy(twv_wavenet_trainer* h);
 size_t twv_wavenet_train_param_floats(const twv_wavenet_trainer* h);
 size_t twv_wavenet_train_workspace_bytes(const twv_wavenet_trainer* h);
+/* forget which workspace has been cleared: the next twv_wavenet_train_loss_grad clears the one it is given.  Call it when a workspace
+ * was freed and re-allocated (a caching allocator may hand out the same address) or written by anything else between two steps. */
+int twv_wavenet_train_reset_workspace(twv_wavenet_trainer* h);
 int twv_wavenet_train_output_width(const twv_wavenet_trainer* h);          /* n_samples - receptive_field (model.py:135) */
 /* loss (device float[1]) and d loss / d params (device float[param_floats], overwritten).
  * audio (B, n_samples) float in [-1,1]; lc (B, n_samples/hop, lc_channels); gc_ids (B) int32.
@@ -218,11 +224,11 @@ int twv_wavenet_train_output_width(const twv_wavenet_trainer* h);          /* n_
 int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* params, const float* audio, const float* lc,
                                 const int32_t* gc_ids, void* workspace, float* loss, float* grads, void* stream);
 /* model.py:300-312 optional L2 term over the non-bias variables (after loss_grad): loss += strength*sum(w^2)/2, grads += strength*w.
- * workspace: the trainer's workspace (reused). */
+ * workspace: the trainer's workspace (the call uses a scratch region of its own at the end of it: nothing loss_grad keeps there is touched). */
 int twv_wavenet_train_l2(twv_wavenet_trainer* h, const float* params, double strength, void* workspace, float* loss, float* grads,
                          void* stream);
 /* model.py:330-331 tf.clip_by_global_norm on the flat gradient buffer: grads <- grads*pre_scale * clip_norm / max(||grads*pre_scale||, clip_norm).
- * scratch: n + 1024 floats. */
+ * scratch: n + 1024 floats of the caller's -- NOT the training workspace (rows of that one must stay as loss_grad left them). */
 int twv_clip_by_global_norm(float* grads, int64_t n, double pre_scale, double clip_norm, void* scratch, void* stream);
 /* tf.train.AdamOptimizer.apply_gradients (t = 1-based update count) on grads*grad_scale, then the EMA shadow update. */
 int twv_adam_ema_step(float* params, const float* grads, float* m, float* v, float* ema, int64_t n, double lr, double beta1,

@@ -69,7 +69,7 @@ def tacotron_hash():
     return _hash_files([os.path.join(CSRC, f) for f in TACOTRON_SOURCES], code_only=True)
 
 
-TRAIN_SOURCES = ("twv_train.hip", "twv_dev.hpp")
+TRAIN_SOURCES = ("twv_train.hip", "twv_dev.hpp", "twv_math.hpp", "twv_layout.hpp")      # twv_dev.hpp includes the other two headers
 
 
 def train_hash():
@@ -84,14 +84,46 @@ def build_stamp():
     return extra, source_hash() + ("+" + " ".join(extra) if extra else "")
 
 
+_toolchain = None
+
+
+def toolchain_id():
+    """what `hipcc --version` prints (part of every object's cache key: a ROCm upgrade must not link objects of the old compiler)"""
+    global _toolchain
+    if _toolchain is None:
+        try:
+            _toolchain = subprocess.check_output(["hipcc", "--version"], stderr=subprocess.STDOUT).decode("utf-8", "replace")
+        except Exception as e:                           # noqa: BLE001 -- no compiler: the build below fails with its own message
+            _toolchain = "hipcc unavailable: %r" % (e,)
+    return _toolchain
+
+
 def build(force=False, verbose=False):
     """hipcc cross-compiles the gfx950 library in-tree (works without a GPU).  The source hash is compiled into the binary and kept
-    in a sidecar file: a library whose stamp differs from the tree's hash is rebuilt (file times say nothing after a checkout)."""
+    in a sidecar file: a library whose stamp differs from the tree's hash is rebuilt (file times say nothing after a checkout).
+    Several processes may call this at once (torchrun ranks, pytest-xdist workers on a stale tree): the whole build runs under an
+    exclusive file lock, and whoever comes second finds the stamp in place."""
     want = source_hash()
     extra, stamp_want = build_stamp()
     stamp = LIB_PATH + ".srchash"
-    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == stamp_want:
+
+    def fresh():
+        return os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == stamp_want
+    if not force and fresh():
         return LIB_PATH
+    import fcntl
+    os.makedirs(os.path.join(_HERE, "_objcache"), exist_ok=True)
+    with open(os.path.join(_HERE, "_objcache", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and fresh():                    # another process built it while this one waited
+                return LIB_PATH
+            return _build_locked(force, verbose, want, extra, stamp_want, stamp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose, want, extra, stamp_want, stamp):
     hip = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
     # one hipcc per source file, side by side (the generation kernels alone take minutes), then one link.  Objects are cached per
     # file under _objcache/ (git- and gpurun-ignored), keyed by the file's text + every header + the flags: an edit of one kernel
@@ -107,17 +139,18 @@ def build(force=False, verbose=False):
         if os.path.basename(src) == "twv_ckpt.hip":
             flags.append('-DTWV_SRC_HASH="%s"' % want)
         import hashlib
-        key = hashlib.sha256((_hash_files([src] + headers) + " ".join(flags)).encode()).hexdigest()[:20]
+        key = hashlib.sha256((_hash_files([src] + headers) + " ".join(flags) + toolchain_id()).encode()).hexdigest()[:20]
         obj = os.path.join(cache, "%s.%s.o" % (os.path.basename(src), key))
         if force or not os.path.exists(obj):
             for old in os.listdir(cache):                       # one object per source file is kept
                 if old.startswith(os.path.basename(src) + "."):
                     os.remove(os.path.join(cache, old))
-            cmd = ["hipcc"] + flags + ["-c", src, "-o", obj + ".tmp.o"]
+            tmp = os.path.join(cache, "tmp.%d.%s.o" % (os.getpid(), os.path.basename(src)))   # (outside the prefix the loop above evicts)
+            cmd = ["hipcc"] + flags + ["-c", src, "-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-            os.replace(obj + ".tmp.o", obj)
+            os.replace(tmp, obj)
         return obj
     with ThreadPoolExecutor(max_workers=min(len(hip), os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_one, hip))
@@ -200,6 +233,7 @@ def lib():
     for n in ("twv_wavenet_train_param_floats", "twv_wavenet_train_workspace_bytes"):
         getattr(L, n).argtypes = [vp]; getattr(L, n).restype = C.c_size_t
     L.twv_wavenet_train_output_width.argtypes = [vp]
+    L.twv_wavenet_train_reset_workspace.argtypes = [vp]
     L.twv_wavenet_train_loss_grad.argtypes = [vp, fp, fp, fp, ip, vp, fp, fp, vp]
     L.twv_wavenet_train_l2.argtypes = [vp, fp, C.c_double, vp, fp, fp, vp]
     L.twv_clip_by_global_norm.argtypes = [fp, C.c_int64, C.c_double, C.c_double, vp, vp]
@@ -218,7 +252,7 @@ EXPORTS = ["twv_last_error", "twv_version", "twv_wavenet_create", "twv_wavenet_d
            "twv_eval_elementwise64", "twv_sample_categorical", "twv_selftest", "twv_debug_occupy", "twv_tacotron_create", "twv_tacotron_destroy", "twv_tacotron_blob_floats",
            "twv_tacotron_packed_bytes", "twv_tacotron_workspace_bytes", "twv_tacotron_pack", "twv_tacotron_infer", "twv_tacotron_set_profile_buffer", "twv_tacotron_set_option", "twv_tacotron_gemm_stats",
            "twv_wavenet_train_create", "twv_wavenet_train_destroy", "twv_wavenet_train_param_floats", "twv_wavenet_train_workspace_bytes",
-           "twv_wavenet_train_output_width", "twv_wavenet_train_loss_grad", "twv_adam_ema_step", "twv_wavenet_train_l2",
+           "twv_wavenet_train_output_width", "twv_wavenet_train_reset_workspace", "twv_wavenet_train_loss_grad", "twv_adam_ema_step", "twv_wavenet_train_l2",
            "twv_clip_by_global_norm", "twv_griffin_lim_create", "twv_griffin_lim_destroy", "twv_griffin_lim_samples",
            "twv_griffin_lim_workspace_bytes", "twv_inv_linear_spectrogram", "twv_crc32c"]
 

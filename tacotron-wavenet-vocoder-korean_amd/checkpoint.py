@@ -522,14 +522,18 @@ def bundle_shapes(prefix, verify=None):
     return out
 
 
-def remap_names(wanted, available):
+def remap_names(wanted, available, strict=False, notes=None):
     """wanted: ordered [(variable name, shape)] the graph expects; available: {variable name: shape} of the checkpoint.
-    Returns {wanted name: checkpoint name}.  Tensors are grouped by (scope path without auto-suffixes, shape).  Only groups with as
-    many members in the checkpoint as in the graph are matched at all.  A group whose
-    wanted names ALL exist in the checkpoint with the right shape is taken by name; otherwise the whole group is matched in
-    creation order (ascending auto-suffix) -- a shifted numbering makes SOME names collide with their neighbours' ("dense_2" of
-    the checkpoint is the graph's "dense_1"), so partial exact matches inside a group would silently load the wrong tensors --
-    and only when the group sizes agree.  Anything else stays unmatched and the caller reports it."""
+    Returns {wanted name: checkpoint name}.  Tensors are grouped by (scope path without auto-suffixes, shape).
+    * A group whose wanted names ALL exist in the checkpoint with the right shape is taken by name -- what tf.train.Saver.restore does
+      (generate.py:157-161, synthesizer.py:69-70: by name only).  When the checkpoint holds a different NUMBER of variables of that
+      scope path and shape than the graph (extra same-shape auto-numbered layers the inference graph does not build -- or one extra
+      layer created first, which shifts the numbering so that the names exist and hold the neighbours' tensors), the match is still
+      made, as TensorFlow would, and a line is appended to `notes`; with strict=True such a group is left unmatched instead.
+    * Otherwise the whole group is matched in creation order (ascending auto-suffix) -- a shifted numbering makes SOME names collide
+      with their neighbours' ("dense_2" of the checkpoint is the graph's "dense_1"), so partial exact matches inside a group would
+      silently load the wrong tensors -- and only when the group sizes agree.
+    Anything else stays unmatched and the caller reports it (`notes` says which groups were ambiguous)."""
     out = {}
     groups_w, groups_a = {}, {}
     for name, shape in wanted:
@@ -540,13 +544,19 @@ def remap_names(wanted, available):
         groups_a.setdefault((st, tuple(shape)), []).append((idx, name))
     for key, ws in groups_w.items():
         cand = groups_a.get(key, [])
+        exact = all(n in available and tuple(available[n]) == key[1] for _, n in ws)
         if len(cand) != len(ws):
-            # the checkpoint holds more (or fewer) variables of this scope path and shape than the graph wants: even if every wanted
-            # NAME exists, one extra auto-numbered layer created first shifts the numbering ("dense" of the checkpoint is then the
-            # extra layer, "dense_1" the graph's "dense") and an exact-name match would load the wrong tensors without a word --
-            # the group stays unmatched and the caller reports it
+            what = "%s %s: the graph wants %d, the checkpoint holds %d" % (key[0], list(key[1]), len(ws), len(cand))
+            if exact and not strict:
+                if notes is not None:
+                    notes.append("matched by name although the group sizes differ (as tf.train.Saver does; an extra layer created first "
+                                 "would have shifted the auto-numbering): " + what)
+                for _, n in ws:
+                    out[n] = n
+            elif notes is not None and cand:
+                notes.append("ambiguous group size, left unmatched: " + what)
             continue
-        if all(n in available and tuple(available[n]) == key[1] for _, n in ws):
+        if exact:
             for _, n in ws:
                 out[n] = n
             continue
@@ -555,20 +565,26 @@ def remap_names(wanted, available):
     return out
 
 
-def restore_variables(prefix, wanted, verify=True, log=None):
+def restore_variables(prefix, wanted, verify=True, log=None, strict=False):
     """{wanted name: ndarray} from the bundle `prefix` (generate.py:157-161 / synthesizer.py:69-70 Saver.restore): by exact variable
-    name where the checkpoint has it, else through remap_names; every remapping is reported through `log` (default: print).
+    name where the checkpoint has it, else through remap_names; every remapping and every by-name match inside a group of a different
+    size is reported through `log` (default: print).  strict=True refuses such groups (remap_names).
     Raises CheckpointError listing what could not be placed."""
     wanted = [(n, tuple(s)) for n, s in wanted]
     shapes = bundle_shapes(prefix, verify=None)
-    mapping = remap_names(wanted, shapes)
+    notes = []
+    mapping = remap_names(wanted, shapes, strict=strict, notes=notes)
+    say = log or print
     missing = [n for n, _ in wanted if n not in mapping]
     if missing:
-        raise CheckpointError("checkpoint lacks %d tensors (no variable of the same scope path and shape either), first: %s"
-                              % (len(missing), ", ".join(missing[:4])))
+        amb = [m for m in notes if m.startswith("ambiguous")]
+        raise CheckpointError("checkpoint lacks %d tensors (no variable of the same scope path and shape%s), first: %s%s"
+                              % (len(missing), " in a group of the same size" if amb else " either", ", ".join(missing[:4]),
+                                 ("; " + "; ".join(amb[:3])) if amb else ""))
+    for m in notes:
+        say("checkpoint: WARNING " + m)
     moved = [(w, a) for w, a in mapping.items() if w != a]
     if moved:
-        say = log or print
         say("checkpoint: %d variables restored under a different auto-generated name:" % len(moved))
         for w, a in sorted(moved):
             say("    %s  <-  %s" % (w, a))

@@ -56,17 +56,21 @@ __device__ __forceinline__ float wave_max_f32(float x)
 // y[k] = logit of class lane + 64 k (k < NB; classes >= Q are ignored).  Returns the drawn class (wave-uniform);
 // sp_out (optional, NB floats per lane) receives the scaled probabilities of generate.py:222.
 // stamps (optional, tuning aid): eight 64-bit slots that receive the chip-wide clock at the phase boundaries marked TWV_CSTAMP
+// nan_out (optional): set to true when the probabilities are not numbers (a NaN or +Inf logit: every class's cdf is NaN and the search
+// below would return class Q - 1) -- np.random.choice (generate.py:231) raises "ValueError: probabilities contain NaN" there, so the
+// callers turn the flag into an error status instead of a sample
 #define TWV_CSTAMP(i_) do { if (stamps != nullptr && lane == 0) stamps[i_] = wall_clock64(); } while (0)
 template <int NB>
 __device__ __forceinline__ int categorical_sample(const float (&y)[NB], const int Q, const int lane, const float temp32, const double u,
-                                                  float* sp_out = nullptr, unsigned long long* stamps = nullptr)
+                                                  float* sp_out = nullptr, unsigned long long* stamps = nullptr, bool* nan_out = nullptr)
 {
     const float ninf = __uint_as_float(0xff800000u);
     // ---- model.py:243 softmax in float64
     float mx = ninf;
+    bool notnum = false;                                           // a NaN or +Inf logit: softmax is NaN in every class (model.py:243)
 #pragma unroll
     for (int k = 0; k < NB; ++k)
-        if (64 * k < Q) { const float v = (lane + 64 * k < Q) ? y[k] : ninf; mx = v > mx ? v : mx; }
+        if (64 * k < Q) { const float v = (lane + 64 * k < Q) ? y[k] : ninf; mx = v > mx ? v : mx; notnum = notnum || !(v <= 3.402823466e38f); }
     mx = wave_max_f32(mx);
     const double m64 = (double)mx;
     double e[NB];
@@ -126,6 +130,9 @@ __device__ __forceinline__ int categorical_sample(const float (&y)[NB], const in
         }
     }
     const double last = base;
+    // (the straight-line float64 exp above maps a NaN argument to a number: the logits themselves are looked at; all logits -Inf is the
+    // third way to no distribution)
+    if (nan_out != nullptr) *nan_out = __any(notnum) != 0 || !(last == last) || mx == ninf;
     TWV_CSTAMP(4);                                                 // scaled probabilities + float64 cdf
     // ---- cdf /= cdf[-1]; searchsorted(u, side='right'): the first class whose normalised cdf exceeds u
     // The quotient is only needed where it decides the comparison: with ul = fl(u * last), c > ul (1 + 2^-50) implies fl(c / last) > u

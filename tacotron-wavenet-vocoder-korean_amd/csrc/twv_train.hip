@@ -47,6 +47,7 @@ struct twv_wavenet_trainer {
     TrainLayerOff lo;                     // offsets inside a layer block
     rocblas_handle blas;
     long long ws_floats;
+    long long l2_off;                     // twv_wavenet_train_l2's scratch inside the workspace (floats)
     const void* ws_clean;                 // the workspace that has been cleared (see twv_wavenet_train_loss_grad)
 };
 
@@ -1926,6 +1927,11 @@ extern "C" int twv_wavenet_train_create(const twv_wavenet_dims* dims, int batch,
     f += 4LL * 512 + 64 + RT / h->hop * 4 * h->L + 64 + (RT / h->hop * 4 * 64 + 64) * h->NL;   // fused lc projection: tap table, shifted mel, per-layer frame projections
     f += 2048LL * 64 * 32 + 64;                 // conv1d_2's fused backward: per-wave shares of dW2
     f += 64 * 64;                               // rounding slack
+    // twv_wavenet_train_l2's scratch (nparams squares + the partial sums) has a region of its OWN behind everything loss_grad carves: at
+    // the start of the workspace it overwrote rows that the fused layer kernels rely on staying zero (the rows in front of a layer's
+    // receptive offset are cleared once and never written again) -- harmless only while every gradient is finite
+    h->l2_off = f;
+    f += (h->nparams + 63) / 64 * 64 + 1024;
     h->ws_floats = f;
     *out = h;
     return TWV_OK;
@@ -1934,6 +1940,12 @@ extern "C" void twv_wavenet_train_destroy(twv_wavenet_trainer* h)
 {
     if (h && h->blas) rocblas_destroy_handle(h->blas);
     delete h;
+}
+extern "C" int twv_wavenet_train_reset_workspace(twv_wavenet_trainer* h)
+{
+    if (!h) return twv_fail(TWV_E_INVALID, "null argument");
+    h->ws_clean = nullptr;                                // the next twv_wavenet_train_loss_grad clears whatever workspace it is given
+    return TWV_OK;
 }
 extern "C" size_t twv_wavenet_train_param_floats(const twv_wavenet_trainer* h) { return (size_t)h->nparams; }
 extern "C" size_t twv_wavenet_train_workspace_bytes(const twv_wavenet_trainer* h) { return (size_t)h->ws_floats * 4; }
@@ -1957,7 +1969,9 @@ extern "C" int twv_wavenet_train_loss_grad(twv_wavenet_trainer* h, const float* 
     HIPCHK(hipMemsetAsync(grads, 0, (size_t)h->nparams * 4, st));
     HIPCHK(hipMemsetAsync(loss, 0, 4, st));
     // A workspace seen for the first time is cleared once: the layer kernels do not walk the tiles in front of a layer's receptive offset,
-    // and masked rows of the tiles they do walk may read those rows as operands of products with zero (0 x NaN would not be zero)
+    // and masked rows of the tiles they do walk may read those rows as operands of products with zero (0 x NaN would not be zero).
+    // "Seen" is the pointer of the last call: a caller that frees the buffer and is handed the same address again, or lets anything else
+    // write into it between two steps, calls twv_wavenet_train_reset_workspace first (the workspace belongs to the trainer between steps).
     if (h->ws_clean != workspace) {
         HIPCHK(hipMemsetAsync(workspace, 0, (size_t)h->ws_floats * 4, st));
         h->ws_clean = workspace;
@@ -2294,7 +2308,7 @@ extern "C" int twv_wavenet_train_l2(twv_wavenet_trainer* h, const float* params,
 {
     if (!h || !params || !workspace || !loss || !grads) return twv_fail(TWV_E_INVALID, "null argument");
     hipStream_t st = (hipStream_t)stream;
-    float* sq = (float*)workspace;                       // nparams floats, then 256 partials + the sum
+    float* sq = (float*)workspace + h->l2_off;           // nparams floats, then 256 partials + the sum: a region of its own (see create)
     float* part = sq + (h->nparams + 63) / 64 * 64;
     L2Layout L{h->c_layer0, h->c_lstride, h->NL, h->lo.bf, h->lo.bg, h->lo.bd, h->lo.bs, 32, 32, h->S, h->c_b1, h->c_b2, h->O, h->d.use_biases};
     hipLaunchKernelGGL(tr_l2_kernel, dim3(tg(h->nparams)), dim3(256), 0, st, params, grads, sq, h->nparams, (float)strength, L);

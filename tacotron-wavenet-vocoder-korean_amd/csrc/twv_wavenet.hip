@@ -938,7 +938,9 @@ __device__ __forceinline__ void worker_main(const GenArgs& a, const Ctx& c, rsrc
                             a.dbg[((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)NL * 64 + lane + 64 * k] = xv[k];
                 }
                 const double uu = reinterpret_cast<const double*>(a.uniforms)[(long long)b * T + t];
-                const int idx = categorical_sample<16>(xv, Q, lane, a.temperature, uu);
+                bool bad = false;
+                const int idx = categorical_sample<16>(xv, Q, lane, a.temperature, uu, nullptr, nullptr, &bad);
+                if (bad && lane == 0) atomicMax(a.status, 31);                     // NaN probabilities: np.random.choice would raise (generate.py:231)
                 if (wprof) wp[63] = __builtin_amdgcn_s_memtime();                  // drawn
                 if (lane == 0) {
                     if (g == 0) reinterpret_cast<int*>(a.out)[(long long)b * T + t] = idx;
@@ -1804,6 +1806,10 @@ extern "C" int twv_wavenet_status(const int32_t* status, void* stream)
     if (hst[0] == 74)
         return fail(TWV_E_INVALID, "the conditioning buffer was not built for the XCD-per-stream kernel (options changed between "
                                    "twv_wavenet_condition and twv_wavenet_generate?); nothing was generated (status code 74)");
+    if (hst[0] == 31)
+        return fail(TWV_E_KERNEL, "the class probabilities of a generation step contain NaN (a NaN or infinite logit): np.random.choice at "
+                                  "generate.py:231 raises 'ValueError: probabilities contain NaN' there; the samples from that step on are "
+                                  "not to be used (status code 31)");
     if (hst[0] != 0) return fail(TWV_E_KERNEL, "generation kernel watchdog code " + std::to_string(hst[0]));
     return TWV_OK;
 }
@@ -1848,8 +1854,9 @@ __global__ void __launch_bounds__(64) wn_categorical_rows_kernel(const float* lo
         float y[16], sp[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) y[k] = (lane + 64 * k < Q) ? logits[r * Q + lane + 64 * k] : 0.0f;
-        const int idx = categorical_sample<16>(y, Q, lane, temperature, u[r], sp);
-        if (lane == 0) out[r] = idx;
+        bool bad = false;
+        const int idx = categorical_sample<16>(y, Q, lane, temperature, u[r], sp, nullptr, &bad);
+        if (lane == 0) out[r] = bad ? -1 : idx;                     // -1: the row's probabilities contain NaN (np.random.choice raises ValueError)
         if (proba != nullptr) {
 #pragma unroll
             for (int k = 0; k < 16; ++k)

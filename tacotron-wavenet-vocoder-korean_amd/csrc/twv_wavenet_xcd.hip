@@ -492,8 +492,10 @@ __device__ __forceinline__ void chain_role(const XArgs& xa, int b, rsrc_t rs)
                     a.dbg[((long long)b * a.dbg_steps + t) * ((long long)NL * 64 + L.Opad) + (long long)NL * 64 + lane + 64 * k] = y[k];
             }
             // model.py:243 + generate.py:219-231 (AC-5, twv_categorical.hpp): the drawn class is the next step's input
+            bool bad_p = false;
             samp_q = categorical_sample<4>(y, L.Q, lane, a.temperature, u_next, nullptr,
-                                           ((INSTR & 1) && a.prof != nullptr && b == a.prof_stream && t < a.prof_steps) ? a.prof + (long long)t * 64 + 38 : nullptr);
+                                           ((INSTR & 1) && a.prof != nullptr && b == a.prof_stream && t < a.prof_steps) ? a.prof + (long long)t * 64 + 38 : nullptr, &bad_p);
+            if (bad_p && lane == 0) atomicMax(a.status, 31);       // NaN probabilities: np.random.choice would raise (generate.py:231)
             XSTAMP(true, 19);
           }
         } else

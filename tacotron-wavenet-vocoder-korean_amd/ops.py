@@ -37,10 +37,12 @@ def mu_law_decode(output, quantization_channels, quantization=True, device="cuda
     return out
 
 
-def sample_categorical(logits, temperature, uniforms, want_proba=False, device="cuda:0"):
+def sample_categorical(logits, temperature, uniforms, want_proba=False, device="cuda:0", check=True):
     """generate.py:219-231 (+ model.py:243's float64 softmax) on rows of logits: (rows, Q) float32 logits, (rows,) float64
     uniforms in [0,1) -> (rows,) int32 class ids [, (rows, Q) scaled probabilities].  The draw np.random.choice makes from its
-    RandomState is an INPUT here, as in the generation kernels."""
+    RandomState is an INPUT here, as in the generation kernels.
+    A row with a NaN / infinite logit has no distribution: np.random.choice (generate.py:231) raises ValueError there, and so does
+    this function (check=True: one host sync); with check=False such a row's class id is -1."""
     y = torch.as_tensor(logits, dtype=torch.float32, device=device).contiguous()
     assert y.dim() == 2
     u = torch.as_tensor(uniforms, dtype=torch.float64, device=device).contiguous()
@@ -50,6 +52,8 @@ def sample_categorical(logits, temperature, uniforms, want_proba=False, device="
         proba = torch.empty_like(y) if want_proba else None
         _lib.check(_lib.lib().twv_sample_categorical(_ptr(y), y.shape[0], y.shape[1], float(temperature), _ptr(u), _ptr(out),
                                                      _ptr(proba) if want_proba else None, _stream()))
+    if check and out.numel() and int(out.min().item()) < 0:
+        raise ValueError("probabilities contain NaN")          # numpy's message (mtrand.RandomState.choice)
     return (out, proba) if want_proba else out
 
 

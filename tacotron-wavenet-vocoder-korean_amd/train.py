@@ -73,6 +73,8 @@ class WaveNetTrainer(object):
             # the gradient buffer carries ONE extra word behind the gradients: a failure flag that rides in the same all-reduce
             # (a rank that cannot produce its batch must not leave the others waiting in the collective, and a separate flag
             # all-reduce + host sync in front of every step would cost a round trip per step)
+            # clip_by_global_norm's scratch (n squares + partial sums): NOT the training workspace -- rows of that one must stay zero
+            self._clip_scratch = None                        # (allocated on the first clipped step)
             self._gbuf = torch.zeros(self.n_params + 1, dtype=torch.float32, device=self.device)
             self.grads = self._gbuf[:self.n_params]
             self._flag = self._gbuf[self.n_params:]
@@ -172,6 +174,11 @@ class WaveNetTrainer(object):
     def gradients(self):
         return self._named(self.grads)
 
+    def reset_workspace(self):
+        """the next step clears the workspace again (twv_wavenet_train_reset_workspace): for a caller that let anything else write into
+        `_ws`, or replaced it by a buffer a caching allocator may have handed out at the same address"""
+        _lib.check(self._L.twv_wavenet_train_reset_workspace(self._h))
+
     # ---- add_loss + compute_gradients ----
     def loss_and_gradients(self, audio, local_condition, gc_ids):
         """audio (B, sample_size) float32, local_condition (B, sample_size/hop, num_mels), gc_ids (B) -> loss (device scalar);
@@ -202,7 +209,9 @@ class WaveNetTrainer(object):
         lr = exponential_decay(self.lr0, self.global_step, self.decay_steps, self.decay_rate)
         with torch.cuda.device(self.device):
             if self.clip_gradients:
-                _lib.check(self._L.twv_clip_by_global_norm(_ptr(self.grads), self.n_params, 1.0 / world, 1.0, _ptr(self._ws), _stream()))
+                if self._clip_scratch is None:
+                    self._clip_scratch = torch.empty(self.n_params + 2048, dtype=torch.float32, device=self.device)
+                _lib.check(self._L.twv_clip_by_global_norm(_ptr(self.grads), self.n_params, 1.0 / world, 1.0, _ptr(self._clip_scratch), _stream()))
                 world = 1
             _lib.check(self._L.twv_adam_ema_step(_ptr(self.params), _ptr(self.grads), _ptr(self.m), _ptr(self.v), _ptr(self.ema),
                                                 self.n_params, lr, self.beta1, self.beta2, self.epsilon, self.global_step + 1,

@@ -315,22 +315,34 @@ def test_restore_tolerates_shifted_auto_generated_names(tmp_path, capsys):
         ck.restore_variables(str(tmp_path / "model.ckpt-5"), ck.tacotron_variable_specs(specs1))
 
 
-def test_restore_refuses_an_exact_name_inside_a_shifted_group(tmp_path):
-    """the checkpoint's graph created ONE MORE unnamed dense layer of the same shape first, so its `dense` is that extra
-    layer and its `dense_1` is the graph's `dense`.  The wanted name exists, with the right shape -- and holds the WRONG tensor: a
-    group is only matched when the checkpoint has as many members of that (scope path, shape) as the graph, so this is refused."""
+def test_restore_by_name_inside_a_group_of_another_size(tmp_path):
+    """The checkpoint's graph created ONE MORE unnamed dense layer of the same shape (its `dense` is that extra layer, its `dense_1` the
+    graph's `dense`).  tf.train.Saver.restore (generate.py:157-161, synthesizer.py:69-70) matches by NAME only and loads `dense` without
+    a word; so does restore_variables -- but it says so -- and strict=True refuses the group with a message that names
+    the ambiguity (ADVICE r04's concern: the name may hold a neighbour's tensor)."""
     from twvk_amd.hparams import hparams as hp
     from twvk_amd.tacotron import tacotron_specs
     specs1 = tacotron_specs(hp, 1)
     rng = np.random.RandomState(3)
     t1 = {n: rng.randn(*s).astype(np.float32) for n, s in specs1}
     v = dict(ck.tacotron_variables(t1))
-    lin_k, lin_b = v.pop("model/inference/dense/kernel"), v.pop("model/inference/dense/bias")
-    v["model/inference/dense/kernel"], v["model/inference/dense/bias"] = lin_k * 0 + 7, lin_b * 0 + 7     # the extra layer
-    v["model/inference/dense_1/kernel"], v["model/inference/dense_1/bias"] = lin_k, lin_b              # the graph's `dense`
+    lin_k, lin_b = v["model/inference/dense/kernel"], v["model/inference/dense/bias"]
+    v["model/inference/dense_1/kernel"], v["model/inference/dense_1/bias"] = lin_k * 0 + 7, lin_b * 0 + 7     # an extra same-shape layer
     ck.write_bundle(str(tmp_path / "model.ckpt-1"), v)
-    with pytest.raises(ck.CheckpointError, match="lacks 2 tensors"):
-        ck.restore_variables(str(tmp_path / "model.ckpt-1"), ck.tacotron_variable_specs(specs1))
+    said = []
+    got = ck.tacotron_tensors(ck.restore_variables(str(tmp_path / "model.ckpt-1"), ck.tacotron_variable_specs(specs1), log=said.append), specs1)
+    assert np.array_equal(got["dense/kernel"], t1["dense/kernel"])                  # by name, as TensorFlow does
+    assert any("WARNING matched by name although the group sizes differ" in m and "the graph wants 1, the checkpoint holds 2" in m for m in said), said
+    with pytest.raises(ck.CheckpointError, match="ambiguous group size"):
+        ck.restore_variables(str(tmp_path / "model.ckpt-1"), ck.tacotron_variable_specs(specs1), strict=True)
+    # a group of another size WITHOUT all the wanted names is refused either way, and the message says why
+    v2 = dict(ck.tacotron_variables(t1))
+    lin = v2.pop("model/inference/dense/kernel")
+    v2["model/inference/dense_1/kernel"] = lin
+    v2["model/inference/dense_2/kernel"] = lin + 1
+    ck.write_bundle(str(tmp_path / "model.ckpt-2"), v2)
+    with pytest.raises(ck.CheckpointError, match="ambiguous group size"):
+        ck.restore_variables(str(tmp_path / "model.ckpt-2"), ck.tacotron_variable_specs(specs1))
 
 
 def test_wavenet_restore_tolerates_shifted_conv1d_names(tmp_path):

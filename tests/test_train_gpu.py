@@ -247,6 +247,48 @@ def test_l2_and_gradient_clipping_options():
     np.testing.assert_allclose(np.sqrt((tr.grads.cpu().numpy().astype(np.float64) ** 2).sum()), 1.0, rtol=1e-5)
 
 
+def test_second_step_with_other_data_and_the_workspace_contract():
+    """the fused layer kernels never write the activation rows in front of a layer's receptive offset again after the
+    workspace's one-time clear and rely on them staying zero, so (1) nothing else may write into the carve: twv_wavenet_train_l2's
+    scratch is a region of its own at the END of the workspace and clip_by_global_norm's is a separate buffer; (2) a second step with
+    OTHER data on the same trainer gives bit for bit what a fresh trainer gives on that data (the step is run-to-run reproducible);
+    (3) a caller that invalidated the workspace says so (reset_workspace) and gets a clean one."""
+    dil = [1, 2, 4, 8, 1, 2]
+    trA, tensors, cfg, audio, lc, gc = _case(dil=dil, B=3, Tm=4, seed=4)
+    rng = np.random.RandomState(99)
+    audio2 = ((rng.rand(*audio.shape) - 0.5) * 1.2).astype(np.float32)
+    lc2 = (rng.randn(*lc.shape) * 0.7).astype(np.float32)
+    gc2 = (1 - gc).astype(np.int32)
+    trA.l2 = 0.01
+    head0 = None
+    trA.loss_and_gradients(audio, lc, gc)                       # first step: the workspace is cleared, L2 runs on it
+    n = trA.n_params
+    head = trA._ws[:n + 1024].clone()
+    import ctypes as C
+    from twvk_amd import _lib
+    from twvk_amd.wavenet import _ptr, _stream
+    with torch.cuda.device(trA.device):
+        _lib.check(trA._L.twv_wavenet_train_l2(trA._h, _ptr(trA.params), 0.01, _ptr(trA._ws), _ptr(trA.loss), _ptr(trA.grads), _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(head, trA._ws[:n + 1024]), "twv_wavenet_train_l2 wrote into the start of the workspace (the carve of loss_grad)"
+    trA.clip_gradients = True
+    trA.apply_gradients()                                       # clipping uses its own scratch
+    assert torch.equal(head, trA._ws[:n + 1024])
+    # (2) second step, other data, same weights as a fresh trainer
+    trB, _, _, _, _, _ = _case(dil=dil, B=3, Tm=4, seed=4)
+    trA.load_weights(tensors); trA.l2 = 0.0
+    lossA = float(trA.loss_and_gradients(audio2, lc2, gc2).item()); gA = trA.grads.clone()
+    lossB = float(trB.loss_and_gradients(audio2, lc2, gc2).item()); gB = trB.grads.clone()
+    assert lossA == lossB and torch.equal(gA, gB)
+    l32, g32 = R.loss_and_grads(tensors, cfg, audio2, lc2, gc2)
+    assert abs(lossA - l32) <= 1e-4 * abs(l32)
+    # (3) a poisoned workspace after reset_workspace: cleared again, same bits
+    trA._ws.fill_(float("nan"))
+    trA.reset_workspace()
+    lossC = float(trA.loss_and_gradients(audio2, lc2, gc2).item())
+    assert lossC == lossB and torch.equal(trA.grads, gB)
+
+
 def test_train_vocoder_cli_trains_checkpoints_and_resumes(tmp_path):
     """train_vocoder.py's loop on synthetic data: steps, a bundle every --checkpoint_every steps, at most hparams.max_checkpoints
     kept, and --logdir alone resumes from the last one (train_vocoder.py:133-152,175-176)"""

@@ -92,6 +92,42 @@ def test_categorical_sampler_rows_bit_exact(torch_cuda, oracle, Q):
         assert got.min() >= 0 and got.max() < Q
 
 
+def test_nan_logits_are_an_error_not_a_sample(torch_cuda, oracle):
+    """np.random.choice (generate.py:231) raises 'ValueError: probabilities contain NaN' when a logit is NaN or infinite; the device
+    sampler marks such a row with class id -1 (twv_sample_categorical), ops.sample_categorical raises like numpy, and inside a
+    generation launch the condition sets status code 31, which generate() turns into a TwvError -- on both generation kernels."""
+    from twvk_amd import ops
+    from twvk_amd._lib import TwvError
+    rng = np.random.RandomState(5)
+    Q, N = 256, 64
+    logits = rng.randn(N, Q).astype(np.float32)
+    u = rng.random_sample(N)
+    clean = ops.sample_categorical(logits, 1.0, u).cpu().numpy()
+    bad = logits.copy(); bad[7, 100] = np.nan; bad[40, 3] = np.inf
+    with pytest.raises(ValueError, match="probabilities contain NaN"):
+        ops.sample_categorical(bad, 1.0, u)
+    got = ops.sample_categorical(bad, 1.0, u, check=False).cpu().numpy()
+    assert got[7] == -1 and got[40] == -1
+    keep = np.ones(N, bool); keep[[7, 40]] = False
+    assert np.array_equal(got[keep], clean[keep])
+    # numpy itself, on the reference's own lines (generate.py:219-231), for the same row
+    with pytest.raises(ValueError, match="probabilities contain NaN"):
+        p = np.exp(bad[7].astype(np.float64) - np.nanmax(bad[7])); p = (p / p.sum()).astype(np.float32)
+        sp = np.log(p); sp = np.exp(sp - np.logaddexp.reduce(sp))
+        np.random.RandomState(0).choice(np.arange(Q), p=sp)
+    dil = [1, 2, 4, 8]
+    d, tensors, blob = make_case(oracle, dil, scalar_input=False, Q=256)
+    tensors = dict(tensors)
+    b2 = tensors["wavenet/conv1d_2/bias"].copy(); b2[17] = np.nan
+    tensors["wavenet/conv1d_2/bias"] = b2
+    for xcd in (1, 0):
+        m = make_model(2, dil, tensors, scalar_input=False, Q=256, xcd=xcd)
+        U = rng.uniform(-4, 4, (2, 40, 80)).astype(np.float32)
+        with pytest.raises(TwvError, match="NaN"):
+            m.generate(U, np.array([0, 1], np.int32), np.array([128, 3], np.int32), rng.random_sample((2, 40)))
+        m.queue_initializer()
+
+
 @pytest.mark.parametrize("name", ["exp64", "log64", "exp64_nonpos"])
 def test_elementwise64_bit_exact(torch_cuda, oracle, name):
     """exp64_nonpos: the float64 softmax's straight-line exp (x = logit - max <= 0) against the contract's exp64 over the whole
