@@ -98,6 +98,27 @@ def train_traffic():
         return None
 
 
+# ---- pieces of the result line that the measured run and `--dry-run` (the N-rank skeleton on CPU, tests/test_cpu.py) share, so that the
+# schema the driver parses at N = 2, 4, 8 is exercised without a GPU
+def headline_fields(value, n_ok, steps, warmup, dt, workload, B, T, kernel_label):
+    return {"metric": "WaveNet autoregressive audio samples/sec at 24 kHz, batch=8",
+            "value": value, "unit": "samples/s", "n_gpus": n_ok, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "batch_per_gpu": B, "samples_per_utterance": T,
+                       "sharding": "utterances, one batch of %d per GPU, no collective" % B, "kernel": kernel_label}}
+
+
+def train_collective(world, n_params):
+    """what the training step exchanges: one all-reduce per step; backend "nccl" of torch.distributed IS RCCL on ROCm"""
+    return "all-reduce(sum) of one flat f32 gradient buffer, %d elements, RCCL" % n_params if world > 1 else "none (1 GPU)"
+
+
+def checked_fields(ncheck, B, n_matched, world):
+    return {"checked_against_oracle": "first %d samples of all %d streams of the last timed pass: bit-identical on %d of %d ranks" % (ncheck, B, n_matched, world),
+            "checked_ranks": n_matched}
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,7 +155,17 @@ def main():
             dist.all_reduce(produced[:1], op=dist.ReduceOp.SUM)
             dist.all_reduce(produced[1:], op=dist.ReduceOp.MAX)
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": int(produced[0].item()), "world": world, "max_seconds": float(produced[1].item())}))
+            # the line of the measured run, same keys through the same helpers, with the skeleton's numbers: every rank "generated" its
+            # batch and "matched" the checker; the timed region is the slowest rank's
+            n_ok, dt = int(produced[0].item()), float(produced[1].item())
+            B, T = args.batch, int(round(args.seconds * 24000))
+            res = headline_fields(n_ok * B * T * args.steps / dt, n_ok, args.steps, args.warmup, dt, "dry run (no GPU work)", B, T, "none (dry run)")
+            res["roofline"] = {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None}
+            res["cpu_baseline"] = None                      # (rank 0 at N = 1 only, and not in a dry run)
+            res.update(checked_fields(0, B, n_ok, world))
+            res["train"] = {"n_gpus": world, "scaling": "weak", "collective": train_collective(world, 1157578)}
+            res.update({"dry_run": True, "world": world, "max_seconds": dt})
+            print(json.dumps(res))
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -317,7 +348,7 @@ def main():
                                               "SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F32 counters: profiles/r05_rocprofv3_mfma_summary_tacotron_train_v4.txt, r05_rocprofv3_kernel_stats_train_c4_v3.csv)"},
                          "value": world * 64 * TT_ / qdt, "unit": "audio samples/s", "steps_per_s": 1.0 / qdt, "ms_per_step": qdt * 1e3,
                          "n_gpus": world, "scaling": "weak", "dtype": "f32",
-                         "collective": "all-reduce(sum) of one flat f32 gradient buffer, %d elements, RCCL" % trn.n_params if world > 1 else "none (1 GPU)",
+                         "collective": train_collective(world, trn.n_params),
                          "config": {"workload": "configs[3]: train_vocoder.py step, 30 layers, per-GPU batch 64 x %d samples, random-init weights" % TT_},
                          "loss_first": l0, "loss_last": float(tl.item())}
             del trn, tnet, taudio, tlc
@@ -334,7 +365,7 @@ def main():
         bytes_per_step = wfloats * 4 + B * (80 + 1 + 1) * 4
         k_ms = float(np.mean(gen_ms))
         achieved = bytes_per_step * T / (k_ms * 1e-3) / 1e9
-        kernel = ("wn_xcd_many_kernel" if B > 20 else "wn_xcd_generate_kernel") if fused else "wn_generate_kernel"
+        kernel = m.kernel_name()                 # the library's own choice for this (model, batch, options): twv_wavenet_kernel_name
         us_step = k_ms * 1e3 / T
         # what binds this kernel is the sample-to-sample dependency chain, not HBM: the floor of that chain from the micro-benchmarks
         # (scripts/ubench/chain_contract_ubench.hip -> profiles/r05_chain_contract_ubench.txt: contract C7 (the product's since round 5), shape R =
@@ -351,16 +382,12 @@ def main():
         macs_stream = NL * (2 * 32 * 64 + 32 * 32 + 32 * 512 + 80 * 64) + 32 * 32 + 512 * 512 + 512 * 30   # executed per stream and step (gc hoisted)
         flop_step = 2.0 * macs_stream * B
         tps = traffic_per_step(kernel, "B%d_NL%d" % (B, NL))
-        res = {
-            "metric": "WaveNet autoregressive audio samples/sec at 24 kHz, batch=8",
-            "value": value, "unit": "samples/s", "n_gpus": n_ok, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: WaveNet autoregressive synth, 30 dilated residual layers (3x[1..512]), R=D=32, S=512, "
-                                   "MoL-30 output, gc+lc conditioning, 24 kHz, batch=%d x %.2f s (%d samples each) per GPU, random-init weights, "
-                                   "injected uniforms" % (B, T / hp.sample_rate, T),
-                       "batch_per_gpu": B, "samples_per_utterance": T, "sharding": "utterances, one batch of %d per GPU, no collective" % B,
-                       "kernel": kernel + (" (stream b on XCD b % 8, weights register-resident, create_upsample + lc projections fused into the launch)" if fused else "")},
+        res = headline_fields(value, n_ok, args.steps, args.warmup, dt,
+                              "configs[1]: WaveNet autoregressive synth, 30 dilated residual layers (3x[1..512]), R=D=32, S=512, "
+                              "MoL-30 output, gc+lc conditioning, 24 kHz, batch=%d x %.2f s (%d samples each) per GPU, random-init weights, "
+                              "injected uniforms" % (B, T / hp.sample_rate, T), B, T,
+                              kernel + (" (stream b on XCD b % 8, weights register-resident, create_upsample + lc projections fused into the launch)" if fused else ""))
+        res.update({
             "target_100x_at_batch_8": {"reachable": False, "target_us_per_step": target_us, "us_per_step": us_step,
                                        "floor_us": floor_us, "floor_us_under_the_contract_of_rounds_1_to_4": floor_r04_contract_us,
                                        "contract": "AC-1b / AC-2 (round 5): the cheapest bit-reproducible contract of the seven priced (C7), adopted in oracle, "
@@ -394,7 +421,7 @@ def main():
                          "fp32_frac": flop_step / (us_step * 1e-6) / 1e12 / 157.3,
                          "note": "weights are register-/L2-resident: the sample loop is a dependent chain (latency), not a bandwidth stream; "
                                  "algorithmic bytes assume the weights were re-read from HBM every step (SURVEY.md 8d)"},
-        }
+        })
         if not args.no_sweep and world == 1:
             # what more streams on the same GPU are worth: 1 s of audio per stream at B = 8 (XCD-per-stream kernel), 16 and 32 (generic kernel)
             sweep = []
@@ -413,7 +440,7 @@ def main():
                                   "realtime_factor_aggregate": Bs * T1 / (kms * 1e-3) / hp.sample_rate,
                                   "realtime_factor_per_stream": T1 / (kms * 1e-3) / hp.sample_rate,
                                   "fp32_frac": 2.0 * macs_stream * Bs / (kms * 1e-3 / T1) / 1e12 / 157.3,
-                                  "kernel": ("wn_xcd_many_kernel" if Bs > 20 else "wn_xcd_generate_kernel") if ms.fused_conditioning() else "wn_generate_kernel"})
+                                  "kernel": ms.kernel_name()})
                     if ms is not m:
                         del ms
                 except Exception as e:
@@ -431,7 +458,7 @@ def main():
                 _lib.check(m50._L.twv_wavenet_status(C.c_void_p(m50._status.data_ptr()), None))
                 res["hparams_default_50_layers"] = {"streams": B, "samples_per_s": B * T1 / (kms * 1e-3), "us_per_generation_step": kms * 1e3 / T1,
                                                     "realtime_factor_per_stream": T1 / (kms * 1e-3) / hp.sample_rate,
-                                                    "kernel": "wn_xcd_generate_kernel" if m50.fused_conditioning() else "wn_generate_kernel"}
+                                                    "kernel": m50.kernel_name()}
                 del m50
             except Exception as e:
                 res["hparams_default_50_layers"] = {"error": repr(e)}
@@ -548,8 +575,7 @@ def main():
             except Exception as e:
                 res["mulaw_256"] = {"error": repr(e)}
         if not args.no_cpu_baseline:
-            res["checked_against_oracle"] = "first %d samples of all %d streams of the last timed pass: bit-identical on %d of %d ranks" % (ncheck, B, n_matched, world)
-            res["checked_ranks"] = n_matched
+            res.update(checked_fields(ncheck, B, n_matched, world))
         if not args.no_cpu_baseline and world == 1:
             d, blob = d_chk, blob_chk
 

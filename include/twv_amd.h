@@ -89,6 +89,9 @@ int twv_wavenet_condition(const twv_wavenet* h, const void* packed, const float*
  *                                    twv_wavenet_generate call may run up to t_mel*hop steps (row t = frame pushed at step t).
  * Results are bit-identical to twv_wavenet_upsample + twv_wavenet_condition. */
 int twv_wavenet_fused_conditioning(const twv_wavenet* h, int batch);
+/* the generation kernel twv_wavenet_generate launches for this (handle, batch, options) on the current device:
+ * "wn_xcd_generate_kernel", "wn_xcd_many_kernel" or "wn_generate_kernel" (static string; measurement label, bench.py) */
+const char* twv_wavenet_kernel_name(const twv_wavenet* h, int batch);
 size_t twv_wavenet_cond_bytes_mel(const twv_wavenet* h, int batch, int t_mel);
 int twv_wavenet_condition_mel(const twv_wavenet* h, const void* packed, const float* mel, const int32_t* gc_ids,
                               int batch, int t_mel, void* cond, void* stream);

@@ -197,6 +197,7 @@ def lib():
     L.twv_wavenet_upsample.argtypes = [vp, vp, fp, C.c_int, C.c_int, fp, fp, vp]
     L.twv_wavenet_condition.argtypes = [vp, vp, fp, ip, C.c_int, C.c_int, vp, vp]
     L.twv_wavenet_fused_conditioning.argtypes = [vp, C.c_int]
+    L.twv_wavenet_kernel_name.argtypes = [vp, C.c_int]; L.twv_wavenet_kernel_name.restype = C.c_char_p
     L.twv_wavenet_cond_bytes_mel.argtypes = [vp, C.c_int, C.c_int]; L.twv_wavenet_cond_bytes_mel.restype = C.c_size_t
     L.twv_wavenet_condition_mel.argtypes = [vp, vp, fp, ip, C.c_int, C.c_int, vp, vp]
     L.twv_wavenet_generate.argtypes = [vp, vp, vp, vp, vp, vp, C.c_double, C.c_int, C.c_int, vp, ip, fp, C.c_int, vp]
@@ -247,7 +248,7 @@ def lib():
 EXPORTS = ["twv_last_error", "twv_version", "twv_wavenet_create", "twv_wavenet_destroy", "twv_wavenet_receptive_field",
            "twv_wavenet_hop_size", "twv_wavenet_blob_floats", "twv_wavenet_packed_bytes", "twv_wavenet_state_bytes",
            "twv_wavenet_cond_bytes", "twv_wavenet_pack", "twv_wavenet_reset_state", "twv_wavenet_upsample",
-           "twv_wavenet_condition", "twv_wavenet_fused_conditioning", "twv_wavenet_cond_bytes_mel", "twv_wavenet_condition_mel", "twv_wavenet_generate", "twv_wavenet_prime", "twv_wavenet_status", "twv_wavenet_set_option", "twv_wavenet_set_profile_buffer",
+           "twv_wavenet_condition", "twv_wavenet_fused_conditioning", "twv_wavenet_kernel_name", "twv_wavenet_cond_bytes_mel", "twv_wavenet_condition_mel", "twv_wavenet_generate", "twv_wavenet_prime", "twv_wavenet_status", "twv_wavenet_set_option", "twv_wavenet_set_profile_buffer",
            "twv_mu_law_encode", "twv_mu_law_decode", "twv_mu_law_expand", "twv_wav_to_int16", "twv_eval_elementwise",
            "twv_eval_elementwise64", "twv_sample_categorical", "twv_selftest", "twv_debug_occupy", "twv_tacotron_create", "twv_tacotron_destroy", "twv_tacotron_blob_floats",
            "twv_tacotron_packed_bytes", "twv_tacotron_workspace_bytes", "twv_tacotron_pack", "twv_tacotron_infer", "twv_tacotron_set_profile_buffer", "twv_tacotron_set_option", "twv_tacotron_gemm_stats",

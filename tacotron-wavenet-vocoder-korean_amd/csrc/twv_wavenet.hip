@@ -1651,6 +1651,12 @@ static int xcd_condition(const twv_wavenet* h, const void* packed, const float* 
     return TWV_OK;
 }
 extern "C" int twv_wavenet_fused_conditioning(const twv_wavenet* h, int batch) { return (h && use_xcd(h, batch) && h->lay.L > 0) ? 1 : 0; }
+extern "C" const char* twv_wavenet_kernel_name(const twv_wavenet* h, int batch)
+{
+    if (!h || batch < 1) return "";
+    if (!use_xcd(h, batch)) return "wn_generate_kernel";
+    return xcd_uses_many(h->lay, batch, h->xcd_many) ? "wn_xcd_many_kernel" : "wn_xcd_generate_kernel";
+}
 extern "C" size_t twv_wavenet_cond_bytes_mel(const twv_wavenet* h, int batch, int t_mel)
 {
     return ((size_t)XH_WORDS + (size_t)batch * h->lay.NL * 64 + (size_t)batch * (size_t)t_mel * h->lay.L) * 4;

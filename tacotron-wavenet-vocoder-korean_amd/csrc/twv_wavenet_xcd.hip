@@ -2557,6 +2557,11 @@ void xcd_pack(float* packed, const float* blob, const Layout& L, hipStream_t st)
 {
     hipLaunchKernelGGL(wn_xcd_pack_kernel, dim3(512), dim3(256), 0, st, packed, blob, L);
 }
+// the choice between the two XCD kernels (also what twv_wavenet_kernel_name reports): `many_opt` = option "xcd_many"
+bool xcd_uses_many(const Layout& L, int batch, int many_opt)
+{
+    return L.scalar && (batch > kXcdStreams || many_opt == 1 || (many_opt == 0 && batch >= kXcdManyFrom)) && L.NL <= kXcdSeg0Layers && xcd_many_lc_fits(L);
+}
 int xcd_launch(const XcdLaunch& p, hipStream_t st)
 {
     XArgs xa;
@@ -2565,7 +2570,7 @@ int xcd_launch(const XcdLaunch& p, hipStream_t st)
     xa.lc_lpw = lc_layers_per_wave(p.lay);
     // chain workgroup: hand-off boxes + the dense kernels of its layers (136 KiB); more than 32 layers: the skip / service workgroups
     // keep the tiles of layers 0 .. NL-41 in LDS next to their value slots (159 KiB of the CU's 160)
-    const bool many = p.lay.scalar && (p.B > kXcdStreams || p.many == 1 || (p.many == 0 && p.B >= kXcdManyFrom)) && p.lay.NL <= kXcdSeg0Layers && xcd_many_lc_fits(p.lay);
+    const bool many = xcd_uses_many(p.lay, p.B, p.many);
     xa.total_roles = 0;
     for (int x = 0; x < 8 && x < p.B; ++x) {
         const int ns = (p.B - x + 7) / 8;

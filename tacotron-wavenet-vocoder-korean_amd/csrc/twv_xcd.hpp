@@ -70,6 +70,7 @@ struct XcdLaunch {
 
 bool xcd_model_ok(const Layout& L);                       // shape the kernel is written for
 int xcd_max_streams(const Layout& L);                     // MoL: 96 (30 layers or fewer), 16 above; one-hot: 32 / 16
+bool xcd_uses_many(const Layout& L, int batch, int many_opt);   // wn_xcd_many_kernel rather than wn_xcd_generate_kernel for this batch
 int xcd_lc_workgroups(const Layout& L);                   // lc workgroups per stream
 int xcd_workgroups_per_stream(const Layout& L);
 size_t xcd_exchange_bytes(int batch);                     // exchange area + role tickets

@@ -187,6 +187,11 @@ class WaveNetModel(object):
         with torch.cuda.device(self.device):             # the answer depends on THIS model's device (its CU count)
             return bool(self._L.twv_wavenet_fused_conditioning(self._h, self.batch_size))
 
+    def kernel_name(self):
+        """the generation kernel `generate` launches for this model, batch and options (twv_wavenet_kernel_name): measurement label"""
+        with torch.cuda.device(self.device):
+            return self._L.twv_wavenet_kernel_name(self._h, self.batch_size).decode()
+
     def create_upsample(self, local_condition_batch, materialize=None):
         """net.create_upsample(mel) (generate.py:200).  With fused conditioning the returned `Upsampled` only holds the mel frames:
         `generate` upsamples row by row inside its launch; `.tensor()` (or materialize=True) builds the (B, T_mel*hop, lc) tensor

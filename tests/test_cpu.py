@@ -669,6 +669,36 @@ def test_bench_starts_its_own_ranks():
     assert out.returncode == 0 and json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
 
 
+def test_bench_line_schema_at_eight_ranks():
+    """the line the driver parses at N = 8, without a GPU -- `bench.py --gpus 8 --dry-run` spawns eight gloo ranks and
+    prints ONE line built by the same helpers as the measured run (headline_fields / checked_fields / train_collective): BASELINE.json's
+    metric, whole-job value, n_gpus = ranks that produced samples, weak scaling, checked_ranks, and a training collective that names RCCL"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--dry-run"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert base["metric"].startswith(res["metric"])                       # "...; mel frames/sec" is the secondary `tacotron` object's metric
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "checked_ranks", "train"):
+        assert k in res, k
+    assert res["n_gpus"] == 8 and res["world"] == 8 and res["checked_ranks"] == 8 and res["steps"] == 3 and res["warmup"] == 1
+    assert res["scaling"] == "weak" and res["higher_is_better"] is True and res["vs_baseline"] is None and res["dtype"] == "f32" and res["data"] == "synthetic"
+    assert set(res["config"]) >= {"workload", "batch_per_gpu", "samples_per_utterance", "sharding", "kernel"} and "model" not in res["config"]
+    assert "no collective" in res["config"]["sharding"]
+    assert set(res["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    # value = the samples ALL ranks produced / the slowest rank's time: 8 ranks x 8 utterances x 192 000 samples x 3 steps
+    assert abs(res["value"] * res["max_seconds"] - 8 * 8 * 192000 * 3) < 1.0 and res["max_seconds"] >= 0.4
+    assert "RCCL" in res["train"]["collective"] and "all-reduce" in res["train"]["collective"] and res["train"]["n_gpus"] == 8
+    import bench
+    assert bench.train_collective(1, 10) == "none (1 GPU)"
+
+
 def test_crop_rule_of_the_wavenet_feeder():
     """datafeeder_wavenet.py:153-156: a random FRAME offset; audio and mel cut in step (hop multiples); global np.random"""
     import twvk_amd
