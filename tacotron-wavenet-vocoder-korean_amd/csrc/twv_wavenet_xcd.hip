@@ -71,11 +71,7 @@ constexpr int kAuxLoad = (int)(16u | 0x80000000u), kAuxStore = 0;
 #ifndef TWV_XCD_KF
 #define TWV_XCD_KF 1
 #endif
-// TWV_XCD_PPOLL = 1: the two polls behind the last layers keep several loads in flight (see skip_role).  Measured, round 6: SLOWER -- 8.59
-// against 8.52 us per step at batch 8 (polling loads do not pipeline: the extra loads lengthen every round trip); off, kept for A/B runs.
-#ifndef TWV_XCD_PPOLL
-#define TWV_XCD_PPOLL 0
-#endif
+
 __device__ __forceinline__ unsigned long long xb_load(rsrc_t rs, int uword, int lword)
 {
     asm volatile("" ::: "memory");      // a poll must be re-issued on every trip of its loop: see below
@@ -903,25 +899,9 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
                     // 32-63 z[16..31] twice; v_permlane32_swap makes the two dot operands of it
                     unsigned long long qz;
                     pl.it = 0;
-                    if (TWV_XCD_PPOLL && NS == 1 && summer && l == NL - 1) {
-                        // The poll on the sample path, PIPELINED (round 6): a poll is an L2 round trip (0.25 us) whether or not the granule
-                        // has arrived, so a wave that waits for its load before it issues the next one sees a new granule 0.25 - 0.5 us
-                        // after it landed.  Three loads in flight, a new one issued whenever the oldest comes back unsuccessful (loads
-                        // return in order: the wait for the oldest leaves the younger two in flight), sample the L2 every ~0.08 us.
-                        unsigned long long q0 = xb_load(rs, (int)XcdExch::ZX + l * 128, zc_lane * 2);
-                        drain(false);
-                        unsigned long long q1 = xb_load(rs, (int)XcdExch::ZX + l * 128, zc_lane * 2);
-                        drain(false);
-                        unsigned long long q2 = xb_load(rs, (int)XcdExch::ZX + l * 128, zc_lane * 2);
-                        for (;;) {
-                            drain(false);
-                            qz = q0;
-                            if (__all(g_tag(q0) == tag)) break;
-                            if (!poll_tick(pl, 51)) break;
-                            q0 = q1; q1 = q2;
-                            q2 = xb_load(rs, (int)XcdExch::ZX + l * 128, zc_lane * 2);
-                        }
-                    } else
+                    // (Round 6, measured dead end: keeping three polls in flight here and two rounds in the conv1 workgroups' poll -- a new load
+                    // issued whenever the oldest comes back unsuccessful -- to sample the L2 more often than once per round trip: 8.59 against
+                    // 8.52 us per step at batch 8.  Polling loads do not pipeline: the extra loads lengthen every round trip.)
                     for (;;) {
                         qz = xb_load(rs, (int)XcdExch::ZX + l * 128, zc_lane * 2);
                         if (summer) drain(false);                          // while the load is in flight: add what has arrived
@@ -985,11 +965,58 @@ __device__ __forceinline__ void skip_role(const XArgs& xa, const XStreams<NS>& s
 //  CONV1 workgroup g: model.py:158-160 conv1d_1 + relu for output block g (16 chunk tiles over the 8 waves), then the two
 //  chunks (2g, 2g+1) of model.py:161-165 conv1d_2 that read this block: what travels on is conv1d_2's partial table.
 // =====================================================================================================================
-// KF = 1 (round 6): wave v also holds block v of the LAST layer's skip kernel (model.py:94-96).  It polls that layer's z (the granule the
-// skip workgroups poll for their layers) next to the running sum of layers 0 .. NL-2 that skip workgroup v publishes, computes the last
-// skip value while the sum is still on its way, and finishes model.py:154's sum in layer order + relu itself: the last layer's z -> skip
-// workgroup -> dot / sum / publish -> conv1 path (0.31 + 0.33 + 0.25 us behind the last layer) becomes z -> conv1 (0.31 us) in parallel
-// with the second-to-last layer's trip through the skip workgroup.
+// conv1 workgroups, wave v: the 64 values h1[64 v ..] of a step (relu of model.py:154's skip sum), as one granule per lane.
+// KF = 0: skip workgroup v publishes them.  KF = 1 (round 6): skip workgroup v publishes the running sum of layers 0 .. NL-2 (raw); the
+// wave holds block v of the LAST layer's skip kernel (wl, bias bl), polls that layer's z (the granule the skip workgroups poll for their
+// layers) next to the sum, has the last skip value ready when the sum comes in, and finishes the sum in layer order + relu itself.
+template <int KF, bool BAR>
+__device__ __forceinline__ unsigned long long conv1_fetch_h1(Poll& pl, const rsrc_t rs, const int v, const int lane, const unsigned tag, const int last_layer,
+                                                             const int zc_lane, const float (&wl)[32], const float bl, const bool use_bias, bool& saw_z)
+{
+    unsigned long long q;
+    pl.it = 0;
+    if (KF > 0) {
+        unsigned long long qz;
+        float val = 0.0f;
+        bool havez = false;
+        for (;;) {
+            if (!havez) qz = xb_load_t<BAR>(rs, (int)XcdExch::ZX + last_layer * 128, zc_lane * 2);
+            q = xb_load_t<BAR>(rs, (int)XcdExch::H1 + v * 64, lane);
+            if (!havez && __all(g_tag(qz) == tag)) {
+                const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)qz, (unsigned)qz, false, false);   // [lo, lo], [hi, hi]
+                val = dot32_dpp(wl, __uint_as_float(sw[0]), __uint_as_float(sw[1]));                        // model.py:96
+                if (use_bias) val = val + bl;
+                havez = true;
+                saw_z = true;
+            }
+            if (havez && __all(g_tag(q) == tag)) break;
+            if (!poll_tick<BAR>(pl, 61)) break;
+            if (!havez) __builtin_amdgcn_s_sleep(1);
+        }
+        const float tot = g_val(q) + val;                                            // model.py:154: the last term of the sum
+        const float h = tot > 0.0f ? tot : 0.0f;                                     // model.py:157
+        q = (unsigned long long)__float_as_uint(h);
+    } else {
+        for (;;) {
+            q = xb_load_t<BAR>(rs, (int)XcdExch::H1 + v * 64, lane);
+            if (__all(g_tag(q) == tag)) break;
+            if (!poll_tick<BAR>(pl, 61)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return q;
+}
+// the last layer's skip tile, output block v, for conv1_fetch_h1<1>
+__device__ __forceinline__ void conv1_load_last_skip(const XcdLaunch& a, const int v, const int lane, Tile& wl, float& bl)
+{
+    const Layout& L = a.lay;
+    const long long lb = L.off_layer0 + (long long)(L.NL - 1) * L.layer_stride;
+    load_tile(wl, a.P + lb + LayerOff::SK + (long long)v * kTile, lane);
+    if (L.use_bias != 0) bl = a.P[lb + LayerOff::SK + (long long)L.NSJ * kTile + v * 64 + lane];
+}
+
+// KF: see conv1_fetch_h1.  The last layer's z -> skip workgroup -> dot / sum / publish -> conv1 path (0.31 + 0.33 + 0.25 us behind the last
+// layer) becomes z -> conv1 (0.31 us) in parallel with the second-to-last layer's trip through the skip workgroup.
 template <int INSTR, int NS, bool BAR = false, class SX = XStreams<NS>, int KF = 0>
 __device__ __forceinline__ void conv1_role(const XArgs& xa, const SX& sx, int g, const int ns_rt = NS, const int prof_slot = -1)
 {
@@ -1015,11 +1042,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const SX& sx, int g,
     }
     Tile wl;                                                              // KF: the last layer's skip kernel, output block v
     float bl = 0.0f;
-    if (KF > 0) {
-        const long long lb = L.off_layer0 + (long long)(L.NL - 1) * L.layer_stride;
-        load_tile(wl, a.P + lb + LayerOff::SK + (long long)v * kTile, lane);
-        if (use_bias) bl = a.P[lb + LayerOff::SK + (long long)L.NSJ * kTile + v * 64 + lane];
-    }
+    if (KF > 0) conv1_load_last_skip(a, v, lane, wl, bl);
     const int zc_lane = lane_of_z((lane < 32 ? 0 : 16) + (lane & 15));
     unsigned long long t_arr = 0, period = 0;
     WACC_DECL();
@@ -1039,50 +1062,10 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const SX& sx, int g,
             pl.rs = rs;
             XMARK(ROLE_CONV0 + g, 1);
             // this wave's two chunks are exactly the 64 values skip workgroup v publishes: ONE granule per lane
-            unsigned long long q;
             WACC_T0();
-            pl.it = 0;
-            if (KF > 0) {
-                // the last layer's z arrives first: its skip value is ready when the running sum comes in
-                unsigned long long qz;
-                float val = 0.0f;
-                bool havez = false;
-                unsigned long long qn = 0, qzn = 0;                                          // the round in flight behind the one being looked at
-                if (TWV_XCD_PPOLL) {
-                    qzn = xb_load_t<BAR>(rs, (int)XcdExch::ZX + (L.NL - 1) * 128, zc_lane * 2);
-                    qn = xb_load_t<BAR>(rs, (int)XcdExch::H1 + v * 64, lane);
-                }
-                for (;;) {
-                    if (TWV_XCD_PPOLL) {                                                     // two rounds in flight (see the skip role's last poll)
-                        qz = qzn; q = qn;
-                        if (!havez) qzn = xb_load_t<BAR>(rs, (int)XcdExch::ZX + (L.NL - 1) * 128, zc_lane * 2);
-                        qn = xb_load_t<BAR>(rs, (int)XcdExch::H1 + v * 64, lane);
-                    } else {
-                    if (!havez) qz = xb_load_t<BAR>(rs, (int)XcdExch::ZX + (L.NL - 1) * 128, zc_lane * 2);
-                    q = xb_load_t<BAR>(rs, (int)XcdExch::H1 + v * 64, lane);
-                    }
-                    if (!havez && __all(g_tag(qz) == tag)) {
-                        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)qz, (unsigned)qz, false, false);   // [lo, lo], [hi, hi]
-                        val = dot32_dpp(wl.w, __uint_as_float(sw[0]), __uint_as_float(sw[1]));                      // model.py:96
-                        if (use_bias) val = val + bl;
-                        havez = true;
-                        XSTAMP(g == 0 && v == 0, 44);
-                    }
-                    if (havez && __all(g_tag(q) == tag)) break;
-                    if (!poll_tick<BAR>(pl, 61)) break;
-                    if (!havez && !TWV_XCD_PPOLL) __builtin_amdgcn_s_sleep(1);
-                }
-                const float tot = g_val(q) + val;                                            // model.py:154: the last term of the sum
-                const float h = tot > 0.0f ? tot : 0.0f;                                     // model.py:157
-                q = (unsigned long long)__float_as_uint(h);
-            } else {
-                for (;;) {
-                    q = xb_load_t<BAR>(rs, (int)XcdExch::H1 + v * 64, lane);
-                    if (__all(g_tag(q) == tag)) break;
-                    if (!poll_tick<BAR>(pl, 61)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
+            bool saw_z = false;
+            const unsigned long long q = conv1_fetch_h1<KF, BAR>(pl, rs, v, lane, tag, L.NL - 1, zc_lane, wl.w, bl, use_bias, saw_z);
+            (void)saw_z;
             WACC_T1(1);
             WTRACE(prof_slot >= 0 && k == 0, 400 + g * 8 + v);
             // (no exit here on a watchdog abort: see the chain role; the loops end at their heads)
@@ -1149,7 +1132,7 @@ __device__ __forceinline__ void conv1_role(const XArgs& xa, const SX& sx, int g,
 //  One more L2 hop than the MoL head (h2), 256 granules instead of 4096 for the sampler to collect.
 // =====================================================================================================================
 constexpr int kConvQLdsFloats = 16 * 64 + 64 + 8 * 64;   // LDS floats per stream: conv1d_1 chunk partials | two arrival counters | conv1d_2 chunk partials
-template <int INSTR, int NS>
+template <int INSTR, int NS, int KF = 0>
 __device__ __forceinline__ void conv1_onehot_role(const XArgs& xa, const XStreams<NS>& sx, int g)
 {
     const XcdLaunch& a = xa.p;
@@ -1177,6 +1160,10 @@ __device__ __forceinline__ void conv1_onehot_role(const XArgs& xa, const XStream
     float b1v = 0.0f, b2v = 0.0f;
     if (use_bias && v == 0) b1v = a.P[L.off_b1 + g * 64 + lane];
     if (use_bias && v == 1 && lane < 32) b2v = a.P[L.off_b2 + g * 32 + lane];
+    Tile wl;                                                              // KF: the last layer's skip kernel, output block v (conv1_fetch_h1)
+    float bl = 0.0f;
+    if (KF > 0) conv1_load_last_skip(a, v, lane, wl, bl);
+    const int zc_lane = lane_of_z((lane < 32 ? 0 : 16) + (lane & 15));
     const int cls = g * 32 + (lane & 31);                                 // the class whose logit lanes 0-31 of wave 1 publish
     const int ql_word = (cls & 63) * 4 + (cls >> 6);
     unsigned long long t_arr = 0, period = 0;
@@ -1193,14 +1180,9 @@ __device__ __forceinline__ void conv1_onehot_role(const XArgs& xa, const XStream
             (void)b;
             pl.rs = rs;
             // ---- model.py:158-160 conv1d_1 + relu for output block g, as in conv1_role
-            unsigned long long q;
-            pl.it = 0;
-            for (;;) {
-                q = xb_load(rs, (int)XcdExch::H1 + v * 64, lane);
-                if (__all(g_tag(q) == tag)) break;
-                if (!poll_tick(pl, 61)) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
+            bool saw_z = false;
+            unsigned long long q = conv1_fetch_h1<KF, false>(pl, rs, v, lane, tag, L.NL - 1, zc_lane, wl.w, bl, use_bias, saw_z);
+            (void)saw_z;
             unsigned long long now_arr = 0;
             if (k == 0) now_arr = __builtin_amdgcn_s_memtime();
             XSTAMP(g == 0 && v == 0, 22);
@@ -1556,15 +1538,15 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
         XStreams<NS> sx;
 #pragma unroll
         for (int k = 0; k < NS; ++k) { sx.b[k] = (int)xcc + 8 * k; sx.rs[k] = exch_of(sx.b[k]); }
-        // MoL head, 30 layers or fewer: the last layer's skip 1x1 runs in the conv1 workgroups (KF = 1; needs a layer in front of it)
-        constexpr int KF = (!BIGK && !ONEHOT) ? TWV_XCD_KF : 0;
+        // the last layer's skip 1x1 runs in the conv1 workgroups (KF = 1; needs a layer in front of it)
+        constexpr int KF = TWV_XCD_KF;
         const bool fold = KF > 0 && a.lay.NL > KF;
         if (role < 8) {
             if (!forced) { if (fold) skip_role<INSTR, NS, BIGK, KF>(xa, sx, role); else skip_role<INSTR, NS, BIGK, 0>(xa, sx, role); }
         }
         else if (role < 16) {
             if (!forced) {
-                if constexpr (ONEHOT) conv1_onehot_role<INSTR, NS>(xa, sx, role - 8);
+                if constexpr (ONEHOT) { if (fold) conv1_onehot_role<INSTR, NS, KF>(xa, sx, role - 8); else conv1_onehot_role<INSTR, NS, 0>(xa, sx, role - 8); }
                 else if (fold) conv1_role<INSTR, NS, false, XStreams<NS>, KF>(xa, sx, role - 8);
                 else conv1_role<INSTR, NS>(xa, sx, role - 8);
             }
