@@ -89,8 +89,9 @@ __global__ void __launch_bounds__(256, 2) sgemm_nt3_kernel(const float* __restri
             for (int i = 0; i < 2; ++i) fb[y][i] = SA + row * 16 + (((2 * i + hh) ^ ((row >> 1) & 3)) << 2);
         }
         dma(0, 0);
-        if (NSTAGE > 2) dma(nk > 1 ? 1 : 0, 1);
-        if (NSTAGE > 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 1; i < NSTAGE - 1; ++i) dma(nk > i ? i : 0, i);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (NSTAGE - 2)) : "memory");
         asm volatile("s_barrier" ::: "memory");
         f32x4 ga[2][4], gb[2][2];                               // fragments of two half steps
 #pragma unroll
@@ -130,7 +131,7 @@ __global__ void __launch_bounds__(256, 2) sgemm_nt3_kernel(const float* __restri
 #endif
             // the next step has landed (this wave's share); everybody's after the barrier
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (NSTAGE - 2)) : "memory");
 #ifndef ABL_NOBAR
             asm volatile("s_barrier" ::: "memory");
 #endif
@@ -161,19 +162,29 @@ __global__ void __launch_bounds__(256, 2) sgemm_nt3_kernel(const float* __restri
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
-        // epilogue: C layout lane = column (l31), register r = row (r & 3) + 8 (r >> 2) + 4 hh
+        // epilogue: C layout lane = column (l31), register r = row (r & 3) + 8 (r >> 2) + 4 hh.  One buffer_store_dword per accumulator
+        // register, the row in a SCALAR offset, the lane's (4 hh rows + column) in one VGPR computed once per tile, rows past M dropped by the
+        // descriptor's size, columns past N by an out-of-range lane offset: no vector arithmetic per element (the first version spent ~25
+        // VALU instructions per store on 64-bit addresses and predicates: 4000 per tile, 8 % of a K = 960 tile's matrix time)
+        {
+            const int mrows_w = M - (m0 + wr * 128);                                            // rows of this wave's 128 that exist
+            const long long cbase = ((long long)(m0 + wr * 128)) * ldc + n0 + wc * 64;
+            const long long cbytes = mrows_w > 0 ? ((long long)(mrows_w < 128 ? mrows_w : 128) * ldc) * 4 : 0;
+            const rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(C + cbase, 0, (int)(cbytes > 0x7fffffffLL ? 0x7fffffff : cbytes), 0x00020000);
 #pragma unroll
-        for (int y = 0; y < 2; ++y) {
-            const int n = n0 + wc * 64 + 32 * y + l31;
-            const float bv = (EPI == 1 && bias && n < N) ? bias[n] : 0.0f;
+            for (int y = 0; y < 2; ++y) {
+                const int n = n0 + wc * 64 + 32 * y + l31;
+                const float bv = (EPI == 1 && bias && n < N) ? bias[n] : 0.0f;
+                const int vo = n < N ? (4 * hh * ldc + 32 * y + l31) * 4 : (int)0x7ffffff0;
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
+                for (int x = 0; x < 4; ++x) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wr * 128 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    float v = acc[x][y][r];
-                    if (EPI == 1) { v = v + bv; v = v > 0.0f ? v : 0.0f; }
-                    if (m < M && n < N) C[(long long)m * ldc + n] = v;
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[x][y][r];
+                        if (EPI == 1) { v = v + bv; v = v > 0.0f ? v : 0.0f; }
+                        const int so = __builtin_amdgcn_readfirstlane((32 * x + (r & 3) + 8 * (r >> 2)) * ldc * 4);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, vo, so, 0);
+                    }
                 }
             }
         }
