@@ -85,6 +85,21 @@ def tacotron_traffic():
         return None
 
 
+def tacotron_decoder_traffic(key="B32_T101"):
+    """fabric bytes of the decoder kernel of one pass (the same committed PMC passes; `key`: B32_T101 = the split decoder at the bench
+    batch, B32_T101_resident = the XCD-resident decoder forced there, B16_T101 = batch 16 where the resident one is the default)"""
+    try:
+        import twvk_amd
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            t = json.load(fh)
+        e = t.get("tacotron:" + twvk_amd._lib.tacotron_hash(), {}).get(key)
+        if e is None or "decoder_fetch_bytes_per_pass" not in e:
+            return None
+        return {"kernel": e.get("decoder_kernel"), "bytes_per_pass": float(e["decoder_fetch_bytes_per_pass"]) + float(e["decoder_write_bytes_per_pass"])}
+    except Exception:
+        return None
+
+
 def train_traffic():
     """HBM bytes of one configs[3] training step (all kernels), from the committed FETCH_SIZE / WRITE_SIZE passes of THIS build of the
     training kernels (profiles/traffic.json, key "train:" + _lib.train_hash(); scripts/train_traffic.sh); None for any other code"""
@@ -681,25 +696,38 @@ def main():
                     for _ in range(2): tm.infer(tokb, tlb, tsb)
                     torch.cuda.synchronize()
                     bdt = (time.perf_counter() - c0) / 2
-                    bsweep.append({"batch": TB, "ms_per_pass": bdt * 1e3, "mel_frames_per_s": TB * hp.max_iters * hp.reduction_factor / bdt})
+                    bsweep.append({"batch": TB, "ms_per_pass": bdt * 1e3, "mel_frames_per_s": TB * hp.max_iters * hp.reduction_factor / bdt,
+                                   "decoder_kernel": "tc_decoder_x_kernel (XCD-resident)" if TB <= 16 else "tc_decoder_g_kernel (split)"})
                 res["tacotron"] = {"metric": "Tacotron mel frames/sec", "value": TN * hp.max_iters * hp.reduction_factor / qdt,
                                    "unit": "mel frames/s", "ms_per_pass": qdt * 1e3, "dtype": "f32", "batch_sweep": bsweep,
-                                   "roofline": {"bound": "mfma", "kernel": "tc_gemm_mfma_{,group_,highway_,ck_}kernel (%d launches per pass: CBHG conv banks as one grouped launch each, projections, "
-                                                                        "fused highway layers, grouped GRU input halves, attention keys, linear)" % gn,
-                                                "achieved": gflop / (gms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": gflop / (gms * 1e-3) / 1e12 / 157.3,
-                                                "flop_per_pass": gflop, "kernel_ms_per_pass": gms, "traffic": tacotron_traffic(),
-                                                "note": "useful FLOPs (2*rows*K*N, unpadded) of the dense contractions / their summed HIP-event time; "
-                                                        "the rest of the pass is the decoder's latency chain (tc_decoder_g_kernel) and the GRU sequences; "
-                                                        "counters: profiles/r05_rocprofv3_mfma_summary_tacotron_train_v3.txt, r05_rocprofv3_kernel_stats_tacotron_c3_v2.csv; HBM bytes (`traffic`): r05_rocprofv3_tacotron_traffic.txt",
-                                                "decoder": {"kernel": "tc_decoder_g_kernel (8 workgroups per utterance on one XCD, 11 matvec stages + attention, 13 all-gathers per step through that XCD's L2)",
-                                                            "bound": "latency", "us_per_step": dec_us, "ms_per_pass": dec_us * hp.max_iters * 1e-3,
-                                                            "latency_floor_us": dec_floor, "frac_of_floor": dec_floor / dec_us,
-                                                            "formula": "per step: tile dots 5.52 + chunk sums / bias / activation / publish 10.35 (of which ~0.4 per stage is the publish store waiting "
-                                                                       "behind the next stage's first weight tiles in the CU's memory pipeline) + barriers and cell updates 2.00 + "
-                                                                       "attention compute 2.66 (score dots 1.02, monotonic recurrence 0.94, context dots 0.59, the rest 0.11) = %.2f us that is "
-                                                                       "not exchange, + %d exchanges x %.2f us (one-way granule hop inside an XCD's L2 measured in isolation; in the kernel an "
-                                                                       "exchange averages 0.64 us incl. the cell update done on arrival: the polls queue behind the next stage's weight tiles); "
-                                                                       "profiles/r05_tacotron_decoder_phase_profile.txt (round 4: r04_..., spread placement r04_..._spread.txt; round 3: 41.4 us)" % (DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US)}},
+                                   # the DOMINANT kernel's ruler first: the decoder is 64 % of the pass and a latency chain
+                                   "roofline": {"bound": "latency", "kernel": "tc_decoder_g_kernel (8 workgroups per utterance on one XCD, 11 matvec stages + attention, 13 all-gathers "
+                                                                             "per step through that XCD's L2)",
+                                                "achieved": dec_us, "peak": dec_floor, "unit": "us per decoder step (lower is better; peak = the floor of the step's decomposition)",
+                                                "frac": dec_floor / dec_us, "us_per_step": dec_us, "ms_per_pass": dec_us * hp.max_iters * 1e-3, "latency_floor_us": dec_floor,
+                                                "traffic": (tacotron_decoder_traffic("B32_T101") or {}).get("bytes_per_pass"),
+                                                "algorithmic_bytes_per_pass": 6.4e6 * 4 + 32 * (2 * 101 * 256 * 4 + 200 * 5 * 80 * 4),
+                                                "formula": "per step: tile dots 5.52 + chunk sums / bias / activation / publish 10.35 (of which ~0.4 per stage is the publish store waiting "
+                                                           "behind the next stage's first weight tiles in the CU's memory pipeline) + barriers and cell updates 2.00 + "
+                                                           "attention compute 2.66 (score dots 1.02, monotonic recurrence 0.94, context dots 0.59, the rest 0.11) = %.2f us that is "
+                                                           "not exchange, + %d exchanges x %.2f us (one-way granule hop inside an XCD's L2 measured in isolation; in the kernel an "
+                                                           "exchange averages 0.64 us incl. the cell update done on arrival: the polls queue behind the next stage's weight tiles); "
+                                                           "profiles/r05_tacotron_decoder_phase_profile.txt" % (DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US),
+                                                "note": "traffic = fabric bytes of the decoder kernel per pass (counters): the split kernel re-streams the 6.4 MB of decoder weights through every "
+                                                        "XCD's 4 MiB L2 once per step.  Round 6 built the alternative -- tc_decoder_x_kernel: every weight in registers for the whole launch, "
+                                                        "32 workgroups per XCD serving its utterances, tasks on v_mfma_f32_4x4x1 -- and measured it (`resident_decoder`): the fabric reads go "
+                                                        "away and the step does not get shorter at four utterances per XCD; the exchanges bound both kernels, not the weight stream",
+                                                "resident_decoder": {"kernel": "tc_decoder_x_kernel",
+                                                                     "default_up_to_batch": 16,
+                                                                     "traffic_at_batch_32": (tacotron_decoder_traffic("B32_T101_resident") or {}).get("bytes_per_pass"),
+                                                                     "traffic_at_batch_16": (tacotron_decoder_traffic("B16_T101") or {}).get("bytes_per_pass"),
+                                                                     "evidence": "profiles/r06_rocprofv3_tacotron_traffic.txt, profiles/r06_tacotron_xdec_phase_profile.txt, batch_sweep of this line"},
+                                                "gemm": {"bound": "mfma", "kernel": "tc_gemm_mfma_{,group_,highway_,ck_}kernel (%d launches per pass: CBHG conv banks as one grouped launch each, projections, "
+                                                                                    "fused highway layers, grouped GRU input halves, attention keys, linear)" % gn,
+                                                         "achieved": gflop / (gms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": gflop / (gms * 1e-3) / 1e12 / 157.3,
+                                                         "flop_per_pass": gflop, "kernel_ms_per_pass": gms, "traffic": tacotron_traffic(),
+                                                         "note": "useful FLOPs (2*rows*K*N, unpadded) of the dense contractions / their summed HIP-event time; 22 % of the pass; "
+                                                                 "counters: profiles/r06_rocprofv3_mfma_summary_tacotron_train.txt, r06_rocprofv3_kernel_stats_tacotron_c3.csv; HBM bytes (`traffic`): r06_rocprofv3_tacotron_traffic.txt"}},
                                    "config": {"workload": "configs[2]: Tacotron text->mel (CBHG encoder, monotonic Bahdanau attention decoder, post-CBHG, "
                                                           "linear), batch=32, 101 tokens, 200 decoder steps = 1000 mel frames/utterance, random-init weights"},
                                    "finite": bool(torch.isfinite(tmel).all().item())}

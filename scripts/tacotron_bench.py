@@ -25,6 +25,8 @@ ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--no-linear", action="store_true"); ap.add_argument("--decoder-groups", type=int, default=0)
 ap.add_argument("--decoder-local", type=int, default=-1, help="1: an utterance's decoder workgroups on one XCD, 0: spread over the XCDs")
 ap.add_argument("--split-all", type=int, default=-1)
+ap.add_argument("--nap-idle", type=int, default=-1); ap.add_argument("--nap-owner", type=int, default=-1)
+ap.add_argument("--nap-round", type=int, default=-1); ap.add_argument("--nap-w0", type=int, default=-1)
 ap.add_argument("--gemm-group", type=int, default=-1, help="0: one launch per GEMM and separate highway kernels (A/B against the grouped launches)"); args = ap.parse_args()
 hp = twvk_amd.default_hparams()
 m = Tacotron(hp, num_speakers=2)
@@ -32,6 +34,10 @@ m.load_weights(random_tensors(m.specs))
 if args.decoder_groups: m.set_option("decoder_groups", args.decoder_groups)
 if args.decoder_local >= 0: m.set_option("decoder_local", args.decoder_local)
 if args.split_all >= 0: m.set_option("decoder_split_all", args.split_all)
+if args.nap_idle >= 0: m.set_option("xdec_nap_idle", args.nap_idle)
+if args.nap_owner >= 0: m.set_option("xdec_nap_owner", args.nap_owner)
+if args.nap_round >= 0: m.set_option("xdec_nap_round", args.nap_round)
+if args.nap_w0 >= 0: m.set_option("xdec_nap_w0", args.nap_w0)
 if args.gemm_group >= 0: m.set_option("gemm_group", args.gemm_group)
 rng = np.random.RandomState(1)
 N, T = args.batch, 101

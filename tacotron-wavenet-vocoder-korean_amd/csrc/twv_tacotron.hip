@@ -1660,6 +1660,8 @@ struct DecXArgs {
     long long xt_off;               // packed offset (floats) of the row tiles [32][8][kXSlots][2048]
     int upx;                        // utterances per XCD (N <= 8*upx)
     int* stab;                      // [workgroups][kXStages][16]: every workgroup's copy of the stage table (read with scalar loads)
+    int nap_idle, nap_owner;        // sleeps in front of a gather's first poll, in units of 64 clocks (options "xdec_nap_idle" / "xdec_nap_owner")
+    int nap_round, nap_w0;          // sleeps between an idle workgroup's polls; wave 0's nap behind its publish
 };
 // the tasks of slice g, in (stage, chunk group) order: task i belongs to wave i % 8, register slot i / 8
 __host__ __device__ inline int xdec_tasks(const XStageTab& t, int g, int wave, int (&st_of)[kXSlots], int (&grp_of)[kXSlots])
@@ -1865,9 +1867,10 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
         const int off = need ? (int)(((ep & 1u) * (kXU * 512) + (unsigned)tid * kXU) * 8u) : (int)0x7ffffff0;   // (out of range: zeros)
         u32x4d qa = {0u, 0u, 0u, 0u}, qb = {0u, 0u, 0u, 0u};
         bool fin = false;
-        if (!owner) __builtin_amdgcn_s_sleep(32);
-        else if (wave != 0) __builtin_amdgcn_s_sleep(10);
-        else __builtin_amdgcn_s_sleep(3);
+        {
+            const int naps = !owner ? xa.nap_idle : (wave != 0 ? xa.nap_owner : xa.nap_w0);
+            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(1);
+        }
         for (int itp = 0; itp < (1 << 20); ++itp) {
             asm volatile("" ::: "memory");
             qa = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, kAux);
@@ -1875,7 +1878,7 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
             const bool got = !need || (qa.y == ep && (nu < 2 || qa.w == ep) && (nu < 3 || qb.y == ep) && (nu < 4 || qb.w == ep));
             if (__all(got)) { fin = true; break; }
             if ((itp & 63) == 63 && LDSVI(o_abort)) return;
-            if (!owner) __builtin_amdgcn_s_sleep(1);
+            if (!owner) for (int i = 0; i < xa.nap_round; ++i) __builtin_amdgcn_s_sleep(1);
         }
         if (!fin) { LDSVI(o_abort) = 1; return; }
         if (!need) return;
@@ -2178,6 +2181,7 @@ struct TCbhg {
 struct twv_tacotron {
     twv_tacotron_dims d;
     unsigned long long* prof = nullptr;
+    int xdec_nap_idle = 8, xdec_nap_owner = 12, xdec_nap_round = 1, xdec_nap_w0 = 3;    // tc_decoder_x_kernel: sleeps in front of a gather's first poll (x 64 clocks)
     int dec_groups = 0;             // 0 auto (16, halved until N*G fits the CUs), -1 single-workgroup kernel
     int dec_split_all = -1;         // prenet + query layer split over the workgroups: -1 = when the exchanges are L2-local, 0 / 1
     int dec_local = 1;              // split kernel: 1 = an utterance's workgroups on one XCD (exchanges through its L2), 0 = spread over the XCDs
@@ -2309,6 +2313,10 @@ extern "C" int twv_tacotron_set_option(twv_tacotron* h, const char* name, int va
     }
     if (!strcmp(name, "decoder_split_all")) { h->dec_split_all = value < 0 ? -1 : (value ? 1 : 0); return TWV_OK; }
     if (!strcmp(name, "decoder_local")) { h->dec_local = value ? 1 : 0; return TWV_OK; }
+    if (!strcmp(name, "xdec_nap_idle")) { h->xdec_nap_idle = value < 0 ? 0 : (value > 200 ? 200 : value); return TWV_OK; }     // tuning aids (round 6)
+    if (!strcmp(name, "xdec_nap_owner")) { h->xdec_nap_owner = value < 0 ? 0 : (value > 200 ? 200 : value); return TWV_OK; }
+    if (!strcmp(name, "xdec_nap_round")) { h->xdec_nap_round = value < 0 ? 0 : (value > 200 ? 200 : value); return TWV_OK; }
+    if (!strcmp(name, "xdec_nap_w0")) { h->xdec_nap_w0 = value < 0 ? 0 : (value > 200 ? 200 : value); return TWV_OK; }
     if (!strcmp(name, "decoder_groups")) {
         if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32)
             return twv_fail(TWV_E_INVALID, "decoder_groups must be -1, 0, 1, 2, 4, 8, 16 or 32 (32 = the XCD-local kernel)");
@@ -2692,6 +2700,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             // XCD-local kernel: every XCD's 32 workgroups hold the decoder in registers and serve that XCD's utterances
             DecXArgs xa;
             xa.d = da; xa.tab = xt; xa.upx = upx; xa.xt_off = h->xt_off; xa.stab = reinterpret_cast<int*>(stabf);
+            xa.nap_idle = h->xdec_nap_idle; xa.nap_owner = h->xdec_nap_owner; xa.nap_round = h->xdec_nap_round; xa.nap_w0 = h->xdec_nap_w0;
             xa.exch = reinterpret_cast<unsigned long long*>(xexch);
             xa.tickets = reinterpret_cast<int*>(xexch + 8LL * 2 * kXU * 512 * 2);
             HIPCHK(hipMemsetAsync(xexch, 0, (size_t)(8LL * 2 * kXU * 512 * 2 + 64) * 4, st));
