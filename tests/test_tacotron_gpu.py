@@ -284,6 +284,26 @@ def test_synthesizer_cli(torch_cuda, oracle, tmp_path):
     assert len(list(out1.glob("*.wav"))) == 1
 
 
+@pytest.mark.parametrize("layers,r,N", [(2, 3, 5), (1, 2, 26), (2, 5, 17)])
+def test_resident_decoder_other_sizes(torch_cuda, oracle, layers, r, N):
+    """tc_decoder_x_kernel outside the folded hparams-default instantiation: other decoder depths / reduction factors (run-time sizes), one
+    utterance per XCD with idle XCDs (N = 5), four and three utterances per XCD with ragged XCD loads (N = 26, 17: the matrix-core task
+    form), ragged lengths; forced (decoder_groups = 32) and, for N <= 16, also the library's own choice.  Bit for bit against the checker."""
+    hp = _hp(max_iters=5, enc_bank_size=3, post_bank_size=2, num_freq=65, dec_layer_num=layers, reduction_factor=r)
+    T = 45
+    rng = np.random.RandomState(layers * 10 + r)
+    lengths = [T] + [int(x) for x in rng.randint(2, T + 1, N - 1)]
+    d, blob, tok, ln, spk, m = _case(oracle, hp, N, T, lengths, seed=41 + layers)
+    mel_o, lin_o, al_o = oracle.taco_infer(d, blob, tok, ln, spk)
+    for groups in ([32, 0] if N <= 16 else [32]):
+        m.set_option("decoder_groups", groups)
+        for _ in range(2):                                              # the second pass reuses the exchange buffers and tickets
+            mel, lin, al = m.infer(tok, ln, spk)
+            assert first_mismatch(al.cpu().numpy(), al_o) is None, (groups, "alignments", first_mismatch(al.cpu().numpy(), al_o))
+            assert first_mismatch(mel.cpu().numpy(), mel_o) is None, (groups, "mel", first_mismatch(mel.cpu().numpy(), mel_o))
+            assert first_mismatch(lin.cpu().numpy(), lin_o) is None
+
+
 def test_xcd_local_decoder_at_bench_geometry(torch_cuda, oracle):
     """decoder_groups = 32: every XCD's 32 workgroups hold the decoder in registers and serve 4 utterances; B = 32, 25 steps, ragged lengths"""
     hp = _hp(max_iters=25)
