@@ -684,6 +684,7 @@ def main():
                 # pieces of one step (us, workgroup 0 of utterance 0, 160 steps averaged): everything that is not an exchange, and the hop
                 DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US = 20.52, 13, 0.27
                 dec_floor = DEC_NONEXCH_US + DEC_EXCHANGES * DEC_HOP_US
+                dec_alg_bytes = hp.max_iters * 1.63e6 * 4 + TN * (2 * TT * 256 * 4 + hp.max_iters * hp.reduction_factor * hp.num_mels * 4)
                 del tm1
                 # other batch sizes on the same GPU (not the metric's configuration: the decoder is a latency chain, so more utterances
                 # per pass cost little; at 64 the 256 CUs hold 4 workgroups per utterance instead of 8)
@@ -701,19 +702,22 @@ def main():
                 res["tacotron"] = {"metric": "Tacotron mel frames/sec", "value": TN * hp.max_iters * hp.reduction_factor / qdt,
                                    "unit": "mel frames/s", "ms_per_pass": qdt * 1e3, "dtype": "f32", "batch_sweep": bsweep,
                                    # the DOMINANT kernel's ruler first: the decoder is 64 % of the pass and a latency chain
-                                   "roofline": {"bound": "latency", "kernel": "tc_decoder_g_kernel (8 workgroups per utterance on one XCD, 11 matvec stages + attention, 13 all-gathers "
-                                                                             "per step through that XCD's L2)",
-                                                "achieved": dec_us, "peak": dec_floor, "unit": "us per decoder step (lower is better; peak = the floor of the step's decomposition)",
-                                                "frac": dec_floor / dec_us, "us_per_step": dec_us, "ms_per_pass": dec_us * hp.max_iters * 1e-3, "latency_floor_us": dec_floor,
+                                   "roofline": {"bound": "hbm", "kernel": "tc_decoder_g_kernel (8 workgroups per utterance on one XCD, 11 matvec stages + attention, 13 all-gathers "
+                                                                         "per step through that XCD's L2)",
+                                                # HBM convention as for the headline: algorithmic bytes = the decoder's weights once per step (every utterance of the pass
+                                                # shares them) + keys / memory in + mel out, over the decoder kernel's time; `traffic` = what the counters saw
+                                                "achieved": dec_alg_bytes / (dec_us * hp.max_iters * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                                "frac": dec_alg_bytes / (dec_us * hp.max_iters * 1e-6) / 1e9 / 8000.0,
                                                 "traffic": (tacotron_decoder_traffic("B32_T101") or {}).get("bytes_per_pass"),
-                                                "algorithmic_bytes_per_pass": 6.4e6 * 4 + 32 * (2 * 101 * 256 * 4 + 200 * 5 * 80 * 4),
+                                                "algorithmic_bytes_per_pass": dec_alg_bytes,
+                                                "us_per_step": dec_us, "ms_per_pass": dec_us * hp.max_iters * 1e-3, "latency_floor_us": dec_floor, "frac_of_floor": dec_floor / dec_us,
                                                 "formula": "per step: tile dots 5.52 + chunk sums / bias / activation / publish 10.35 (of which ~0.4 per stage is the publish store waiting "
                                                            "behind the next stage's first weight tiles in the CU's memory pipeline) + barriers and cell updates 2.00 + "
                                                            "attention compute 2.66 (score dots 1.02, monotonic recurrence 0.94, context dots 0.59, the rest 0.11) = %.2f us that is "
                                                            "not exchange, + %d exchanges x %.2f us (one-way granule hop inside an XCD's L2 measured in isolation; in the kernel an "
                                                            "exchange averages 0.64 us incl. the cell update done on arrival: the polls queue behind the next stage's weight tiles); "
                                                            "profiles/r05_tacotron_decoder_phase_profile.txt" % (DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US),
-                                                "note": "traffic = fabric bytes of the decoder kernel per pass (counters): the split kernel re-streams the 6.4 MB of decoder weights through every "
+                                                "note": "what binds this kernel is its latency chain (latency_floor_us / frac_of_floor), not bandwidth.  traffic = fabric bytes of the decoder kernel per pass (counters): the split kernel re-streams the 6.4 MB of decoder weights through every "
                                                         "XCD's 4 MiB L2 once per step.  Round 6 built the alternative -- tc_decoder_x_kernel: every weight in registers for the whole launch, "
                                                         "32 workgroups per XCD serving its utterances, tasks on v_mfma_f32_4x4x1 -- and measured it (`resident_decoder`): the fabric reads go "
                                                         "away and the step does not get shorter at four utterances per XCD; the exchanges bound both kernels, not the weight stream",
