@@ -54,14 +54,11 @@ for w in range(nw):
         print("wave %d: layers %.2f us%s" % (w, us(done[w] - recv[w]), ("   hand-off to wave %d %.2f" % (w + 1, us(recv[w + 1] - done[w]))) if w + 1 < nw and done[w + 1].any() else ""))
 last = max(w for w in range(nw) if done[w].any())
 print("residual stack total (wave 0 in -> last layer out)  %.2f" % us(done[last] - recv[0]))
-if p[:, 20].any():
-    print("post: z of the last layer -> skip workgroup sees it %.2f" % us(p[:, 20] - done[last]))
-    print("      skip dot + ordered sum + relu -> h1 published %.2f" % us(p[:, 21] - p[:, 20]))
-else:       # round 6, one stream per XCD: a dedicated summing wave publishes (stamp 21); the skip waves only fill LDS slots
-    print("post: last layer out -> running sum published by the skip workgroup's summing wave %.2f" % us(p[:, 21] - done[last]))
-if p[:, 44].any():
-    print("      last layer out -> conv1 workgroup sees its z (KF: the last skip 1x1 runs there) %.2f" % us(p[:, 44] - done[last]))
-print("      h1 / running sum -> conv1 workgroup sees it   %.2f" % us(p[:, 22] - p[:, 21]))
+# round 6 (KF = 1): the skip workgroups serve layers 0 .. NL-2 and publish the RAW running sum; the conv1 workgroups poll the last layer's z
+# themselves, have its skip value ready when the sum arrives, and finish the sum + relu (stamp 22)
+print("post: last layer out -> the skip workgroup's summing wave has seen ITS last z (layer NL-2) %.2f" % us(p[:, 20] - done[last]))
+print("      its dot + ordered sum -> running sum of layers 0..NL-2 published  %.2f" % us(p[:, 21] - p[:, 20]))
+print("      running sum -> conv1 workgroup has it, last skip value added, relu %.2f" % us(p[:, 22] - p[:, 21]))
 print("      two chunk dots -> partials in LDS             %.2f" % us(p[:, 23] - p[:, 22]))
 print("      wait for the other waves                      %.2f" % us(p[:, 24] - p[:, 23]))
 if args.onehot:

@@ -1539,16 +1539,27 @@ __global__ void __launch_bounds__(512) wn_xcd_generate_kernel(XArgs xa)
 #pragma unroll
         for (int k = 0; k < NS; ++k) { sx.b[k] = (int)xcc + 8 * k; sx.rs[k] = exch_of(sx.b[k]); }
         // the last layer's skip 1x1 runs in the conv1 workgroups (KF = 1; needs a layer in front of it)
+        // The unfolded form (a model of KF layers or fewer) is only compiled into the production builds: in the instrumented ones (layer
+        // dumps, phase stamps: every stream count in ONE kernel) the second copy of the skip / conv1 roles pushed the register allocation
+        // of the whole kernel into scratch (720 B per lane: the stamped chain ran 13 % slower than the one it is meant to show);
+        // xcd_launch refuses such a model for those builds.
         constexpr int KF = TWV_XCD_KF;
-        const bool fold = KF > 0 && a.lay.NL > KF;
+        constexpr bool kUnfolded = KF == 0 || INSTR == 0;
+        const bool fold = KF > 0 && (a.lay.NL > KF || !kUnfolded);
         if (role < 8) {
-            if (!forced) { if (fold) skip_role<INSTR, NS, BIGK, KF>(xa, sx, role); else skip_role<INSTR, NS, BIGK, 0>(xa, sx, role); }
+            if (!forced) {
+                if (fold) skip_role<INSTR, NS, BIGK, KF>(xa, sx, role);
+                else if constexpr (kUnfolded) skip_role<INSTR, NS, BIGK, 0>(xa, sx, role);
+            }
         }
         else if (role < 16) {
             if (!forced) {
-                if constexpr (ONEHOT) { if (fold) conv1_onehot_role<INSTR, NS, KF>(xa, sx, role - 8); else conv1_onehot_role<INSTR, NS, 0>(xa, sx, role - 8); }
+                if constexpr (ONEHOT) {
+                    if (fold) conv1_onehot_role<INSTR, NS, KF>(xa, sx, role - 8);
+                    else if constexpr (kUnfolded) conv1_onehot_role<INSTR, NS, 0>(xa, sx, role - 8);
+                }
                 else if (fold) conv1_role<INSTR, NS, false, XStreams<NS>, KF>(xa, sx, role - 8);
-                else conv1_role<INSTR, NS>(xa, sx, role - 8);
+                else if constexpr (kUnfolded) conv1_role<INSTR, NS>(xa, sx, role - 8);
             }
         }
         else lc_role<INSTR, NS, BIGK>(xa, sx, role - 16);
@@ -2575,6 +2586,8 @@ int xcd_launch(const XcdLaunch& p, hipStream_t st)
         (void)hipGetLastError();
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), shm, st, xa);
     };
+    if (!many && instr != 0 && p.lay.NL <= TWV_XCD_KF)
+        return twv_fail(TWV_E_UNSUPPORTED, "layer dumps / phase stamps of the XCD kernel need a model of at least two layers (set option \"xcd\" = 0 for the generic kernel)");
     if (many) {
         if (p.B > kXcdManyStreams) return twv_fail(TWV_E_UNSUPPORTED, "the many-streams XCD kernel takes at most 96 streams");
         // a profile buffer selects the wait-accounting build here (scripts/many_profile.py), not the phase stamps of the batch <= 32 kernel
