@@ -363,7 +363,12 @@ def taco_tensor_specs(d):
     ENC = 2 * RN
     s = [("embedding", (d.n_symbols, E))]
     dn = ([P1, 2 * RN, AS] + [DR] * d.dec_layers) if d.n_speakers > 1 else []      # tacotron.py:62-104
-    if d.n_speakers > 1:
+    if d.n_speakers > 1 and SE == 1:
+        # tacotron.py:69-75: speaker_embedding_size == 1 -> five embedding tables of their own (modules.py:10-12 get_embed), no dense layers
+        names = ["before_highway", "encoder_rnn_init_state", "attention_rnn_init_state"] + ["decoder_rnn_init_states%d" % (i + 1) for i in range(d.dec_layers)]
+        s += [(nm, (d.n_speakers, n)) for nm, n in zip(names, dn)]
+        dn = []
+    elif d.n_speakers > 1:
         s += [("speaker_embedding", (d.n_speakers, SE))]
     for i, n in enumerate(dn):
         nm = "dense" if i == 0 else "dense_%d" % i

@@ -235,12 +235,18 @@ void twvo_taco_infer(const twvo_taco_dims* d, const float* blob, const int32_t* 
     /* tacotron.py:62-104: the speaker tensors exist only when num_speakers > 1; otherwise before_highway and every initial
      * state is None (zero_state) */
     const int multi = d->n_speakers > 1;
-    const float* semb = multi ? take(&c, (size_t)d->n_speakers * SE) : NULL;   /* tacotron.py:67 'speaker_embedding' */
+    /* tacotron.py:69-75: with speaker_embedding_size == 1 the five speaker-dependent vectors are embedding tables of their own
+     * (modules.py:10-12 get_embed), looked up by speaker id; otherwise (:76-82) dense(softsign) layers of ONE speaker embedding */
+    const int tables = multi && SE == 1;
+    const float* semb = (multi && !tables) ? take(&c, (size_t)d->n_speakers * SE) : NULL;   /* tacotron.py:67 'speaker_embedding' */
     /* tacotron.py:76-82 deep_dense (softsign): before_highway, encoder rnn init, attention rnn init, decoder rnn inits */
-    const float *dW[8], *db[8];
+    const float *dW[8], *db[8], *tab[8];
     const int dn[8] = { P1, 2 * RN, AS, DR, DR, DR, DR, DR };
     const int ndense = multi ? 3 + d->dec_layers : 0;
-    for (int i = 0; i < ndense; ++i) { dW[i] = take(&c, (size_t)SE * dn[i]); db[i] = take(&c, dn[i]); }
+    for (int i = 0; i < ndense; ++i) {
+        if (tables) tab[i] = take(&c, (size_t)d->n_speakers * dn[i]);
+        else { dW[i] = take(&c, (size_t)SE * dn[i]); db[i] = take(&c, dn[i]); }
+    }
     const float* pW1 = take(&c, (size_t)E * P0); const float* pb1 = take(&c, P0);      /* prenet, modules.py:15-23 */
     const float* pW2 = take(&c, (size_t)P0 * P1); const float* pb2 = take(&c, P1);
     cbhg_w enc;
@@ -292,7 +298,9 @@ void twvo_taco_infer(const twvo_taco_dims* d, const float* blob, const int32_t* 
         }
         float init[8][512];
         memset(init, 0, sizeof(init));                                      /* single speaker: zero states (tacotron.py:97-104) */
-        if (multi) {
+        if (tables) {
+            for (int i = 0; i < ndense; ++i) memcpy(init[i], tab[i] + (size_t)speaker_ids[n] * dn[i], sizeof(float) * dn[i]);   /* embedding_lookup */
+        } else if (multi) {
             const float* se = semb + (size_t)speaker_ids[n] * SE;
             for (int i = 0; i < ndense; ++i) dense_rows(se, 1, SE, dW[i], db[i], dn[i], ACT_SOFTSIGN, init[i]);
         }
@@ -383,7 +391,9 @@ size_t twvo_taco_blob_floats(const twvo_taco_dims* d)
               AS = d->att_state, DR = d->dec_rnn, M = d->num_mels, R = d->r, ENC = 2 * RN;
     n += (size_t)d->n_symbols * E;
     const int dn[8] = { P1, 2 * RN, AS, DR, DR, DR, DR, DR };
-    if (d->n_speakers > 1) {
+    if (d->n_speakers > 1 && SE == 1) {
+        for (int i = 0; i < 3 + d->dec_layers; ++i) n += (size_t)d->n_speakers * dn[i];
+    } else if (d->n_speakers > 1) {
         n += (size_t)d->n_speakers * SE;
         for (int i = 0; i < 3 + d->dec_layers; ++i) n += (size_t)SE * dn[i] + dn[i];
     }

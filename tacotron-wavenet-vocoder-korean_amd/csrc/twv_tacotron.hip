@@ -2190,6 +2190,7 @@ struct twv_tacotron {
     long long xt_off = 0;           // row tiles of the XCD-local decoder kernel [32 slices][8 waves][kXSlots][2048]
     TMat emb, semb;                 // raw tables (K rows x N)
     TMat dW[8]; TVec db[8]; int ndense, dn[8];
+    TMat stab[8];                   // speaker_embedding_size == 1: the five get_embed tables (tacotron.py:69-75), raw rows
     TMat pW1, pW2; TVec pb1, pb2;
     TCbhg enc, post;
     TMat Wm, Wq; TVec av, ag, ab, asb, nv;
@@ -2248,7 +2249,10 @@ static void taco_build(twv_tacotron* h)
     // has no speaker embedding, no before_highway and zero initial states
     h->ndense = d.num_speakers > 1 ? 3 + d.dec_layer_num : 0;
     const int dn[8] = {P1, 2 * RN, AS, DR, DR, DR, DR, DR};
-    if (d.num_speakers > 1) {
+    if (d.num_speakers > 1 && SE == 1) {
+        // tacotron.py:69-75: speaker_embedding_size == 1 -> five embedding tables (modules.py:10-12 get_embed), one row per speaker
+        for (int i = 0; i < h->ndense; ++i) { h->dn[i] = dn[i]; h->stab[i] = raw(d.num_speakers, dn[i]); }
+    } else if (d.num_speakers > 1) {
         h->semb = raw(d.num_speakers, SE);
         for (int i = 0; i < h->ndense; ++i) { h->dn[i] = dn[i]; h->dW[i] = mat(SE, dn[i]); h->db[i] = vec(dn[i]); }
     }
@@ -2291,8 +2295,7 @@ extern "C" int twv_tacotron_create(const twv_tacotron_dims* dims, twv_tacotron**
         return twv_fail(TWV_E_UNSUPPORTED, "decoder sizes out of range");
     if (d.enc_bank_size > 16 || d.post_bank_size > 16 || d.enc_highway_depth > 8 || d.post_highway_depth > 8) return twv_fail(TWV_E_UNSUPPORTED, "bank / highway depth out of range");
     if (d.num_speakers < 1) return twv_fail(TWV_E_INVALID, "num_speakers must be >= 1");
-    if (d.num_speakers > 1 && d.speaker_embedding_size < 2)
-        return twv_fail(TWV_E_UNSUPPORTED, "multi-speaker: the deepvoice path with speaker_embedding_size > 1 is built (tacotron.py:76-82); the get_embed tables of speaker_embedding_size == 1 are not");
+    if (d.num_speakers > 1 && d.speaker_embedding_size < 1) return twv_fail(TWV_E_INVALID, "speaker_embedding_size must be >= 1");
     twv_tacotron* h = new twv_tacotron();
     h->d = d;
     taco_build(h);
@@ -2629,9 +2632,13 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
     // decoder initial states gathered as [N][AS + layers*DR]
     float* dinit = spk + (long long)N * 2048;
     if (multi) {
-        hipLaunchKernelGGL(tc_gather_rows_kernel, dim3(tgrid((long long)N * SE)), dim3(256), 0, st, P + h->semb.off, speaker_ids, N, SE, spk);
         { float* q = spk + (long long)N * 64; for (int i = 0; i < h->ndense; ++i) { sv[i] = q; q += (long long)N * h->dn[i]; } }
-        {
+        if (SE == 1) {
+            // tacotron.py:69-75 get_embed: tf.nn.embedding_lookup of five tables by speaker id
+            for (int i = 0; i < h->ndense; ++i)
+                hipLaunchKernelGGL(tc_gather_rows_kernel, dim3(tgrid((long long)N * h->dn[i])), dim3(256), 0, st, P + h->stab[i].off, speaker_ids, N, h->dn[i], sv[i]);
+        } else {
+            hipLaunchKernelGGL(tc_gather_rows_kernel, dim3(tgrid((long long)N * SE)), dim3(256), 0, st, P + h->semb.off, speaker_ids, N, SE, spk);
             std::vector<GemmArgs> v;
             for (int i = 0; i < h->ndense; ++i)
                 v.push_back(gemm_args(P, spk, SE, N, 1, SE, 1, h->dW[i], &h->db[i], TACT_SOFTSIGN, nullptr, nullptr, nullptr, 0, nullptr, 0, sv[i], h->dn[i], 0));

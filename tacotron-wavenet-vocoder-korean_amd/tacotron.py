@@ -47,7 +47,13 @@ def tacotron_specs(hp, num_speakers, n_symbols=80):
     # tacotron.py:62-104: speaker embedding + the five deep_dense layers exist for num_speakers > 1 only; tf.layers.dense layers
     # are auto-named dense, dense_1, ... in creation order, so the linear-spectrogram layer is "dense" in a single-speaker graph
     dn = ([P1, 2 * RN, AS] + [DR] * hp.dec_layer_num) if num_speakers > 1 else []
-    if num_speakers > 1:
+    if num_speakers > 1 and SE == 1:
+        # tacotron.py:69-75: speaker_embedding_size == 1 -> the five speaker-dependent vectors are embedding tables of their own
+        # (modules.py:10-12 get_embed, looked up by speaker id); no speaker embedding, no deep_dense layers (the linear layer is "dense")
+        names = ["before_highway", "encoder_rnn_init_state", "attention_rnn_init_state"] + ["decoder_rnn_init_states%d" % (i + 1) for i in range(hp.dec_layer_num)]
+        s += [(nm, (num_speakers, n)) for nm, n in zip(names, dn)]
+        dn = []
+    elif num_speakers > 1:
         s += [("speaker_embedding", (num_speakers, SE))]
     for i, n in enumerate(dn):
         nm = "dense" if i == 0 else "dense_%d" % i
@@ -112,9 +118,10 @@ class Tacotron(object):
 
     def __init__(self, hparams, num_speakers=2, n_symbols=80, device="cuda:0"):
         hp = self._hparams = hparams
-        if hp.attention_type != 'bah_mon_norm' or num_speakers < 1 or (num_speakers > 1 and (hp.model_type != 'deepvoice' or hp.speaker_embedding_size == 1)):
-            raise NotImplementedError("built: attention_type 'bah_mon_norm'; single speaker (tacotron.py:97-104), or model_type 'deepvoice' with "
-                                      "speaker_embedding_size > 1 (tacotron.py:76-82)")
+        if hp.attention_type != 'bah_mon_norm' or num_speakers < 1 or (num_speakers > 1 and hp.model_type != 'deepvoice'):
+            raise NotImplementedError("built: attention_type 'bah_mon_norm'; single speaker (tacotron.py:97-104), or model_type 'deepvoice' "
+                                      "(tacotron.py:68-84: dense(softsign) layers of a speaker embedding, or -- speaker_embedding_size == 1 -- "
+                                      "embedding tables); model_type 'simple' (tacotron.py:85-90) is not")
         self.num_speakers = num_speakers
         self.device = torch.device(device)
         self.specs = tacotron_specs(hp, num_speakers, n_symbols)

@@ -289,15 +289,20 @@ def test_restatement_fixtures_mulaw_and_tacotron(oracle):
     assert t["mel"].shape == (3, 30, 80) and t["linear"].shape == (3, 30, 129) and t["alignments"].shape == (3, 17, 6)
 
 
-@pytest.mark.parametrize("n_speakers", [2, 1])
+@pytest.mark.parametrize("n_speakers", [2, 1, -2])
 def test_torch_tacotron_reference_agrees_with_the_c_restatement(oracle, n_speakers):
     """oracle/tacotron.c gets a second opinion -- tests/torch_tacotron_ref.py, a float64 torch restatement of
     tacotron.py:36-235 + modules.py + rnn_wrappers.py written from the reference source and TensorFlow's published semantics, not from
     the C file.  Default dims (hparams.py:126-165), 25 decoder steps, ragged lengths; multi-speaker (deepvoice) and single speaker.
     1e-5 absolute on mel / linear (values of order 1), 1e-6 on the alignments: float32 chain vs float64."""
     import torch_tacotron_ref as R
-    d = oracle.taco_dims(max_iters=25, n_speakers=n_speakers)
+    tables = n_speakers < 0                                              # -2: two speakers, speaker_embedding_size == 1 (tacotron.py:69-75 get_embed tables)
+    n_speakers = abs(n_speakers)
+    d = oracle.taco_dims(max_iters=25, n_speakers=n_speakers, spk_emb=1 if tables else 16)
     w = oracle.taco_random_tensors(d, seed=3)
+    if tables:
+        assert "speaker_embedding" not in w and w["before_highway"].shape == (2, 128) and w["decoder_rnn_init_states2"].shape == (2, 256)
+        assert w["dense/kernel"].shape == (2 * d.post_rnn, d.num_freq) and "dense_1/kernel" not in w
     blob = oracle.taco_blob(d, w)
     rng = np.random.RandomState(4)
     N, T = 3, 19

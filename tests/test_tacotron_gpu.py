@@ -284,6 +284,41 @@ def test_synthesizer_cli(torch_cuda, oracle, tmp_path):
     assert len(list(out1.glob("*.wav"))) == 1
 
 
+def test_speaker_embedding_size_one_uses_embedding_tables(torch_cuda, oracle):
+    """tacotron.py:69-75: with hparams.speaker_embedding_size == 1 the deepvoice model has no speaker embedding and no deep_dense layers --
+    before_highway, the encoder / attention / decoder initial states are embedding tables of their own (modules.py:10-12 get_embed),
+    looked up by speaker id, and the linear-spectrogram layer is the graph's first tf.layers.dense.  Bit for bit against the checker,
+    on the split and on the resident decoder."""
+    hp = _hp(max_iters=6, enc_bank_size=4, post_bank_size=3, num_freq=129, speaker_embedding_size=1)
+    from twvk_amd.tacotron import Tacotron
+    N, T, lengths = 4, 23, [23, 15, 9, 2]
+    d = oracle.taco_dims(enc_bank=4, post_bank=3, max_iters=6, num_freq=129, n_speakers=3, spk_emb=1)
+    tensors = oracle.taco_random_tensors(d, seed=13)
+    blob = oracle.taco_blob(d, tensors)
+    rng = np.random.RandomState(14)
+    tok = rng.randint(2, 80, (N, T)).astype(np.int32)
+    for n, ln in enumerate(lengths):
+        tok[n, ln - 1] = 1
+        tok[n, ln:] = 0
+    ln_ = np.asarray(lengths, np.int32)
+    spk = np.array([2, 0, 1, 2], np.int32)
+    m = Tacotron(hp, num_speakers=3)
+    names = [n for n, _ in m.specs]
+    assert names == [n for n, _ in oracle.taco_tensor_specs(d)]
+    assert "speaker_embedding" not in names and "before_highway" in names and "decoder_rnn_init_states2" in names and "dense/kernel" in names and "dense_1/kernel" not in names
+    m.load_weights(tensors)
+    mel_o, lin_o, al_o = oracle.taco_infer(d, blob, tok, ln_, spk)
+    for groups in (0, 8):
+        m.set_option("decoder_groups", groups)
+        mel, lin, al = m.infer(tok, ln_, spk)
+        assert first_mismatch(al.cpu().numpy(), al_o) is None, ("alignments", first_mismatch(al.cpu().numpy(), al_o))
+        assert first_mismatch(mel.cpu().numpy(), mel_o) is None, ("mel", first_mismatch(mel.cpu().numpy(), mel_o))
+        assert first_mismatch(lin.cpu().numpy(), lin_o) is None
+    # a different speaker gives a different utterance (the tables are really read)
+    mel2, _, _ = m.infer(tok, ln_, np.array([0, 0, 1, 2], np.int32), want_linear=False, want_alignments=False)
+    assert first_mismatch(mel2.cpu().numpy()[0], mel_o[0]) is not None and first_mismatch(mel2.cpu().numpy()[1:], mel_o[1:]) is None
+
+
 @pytest.mark.parametrize("layers,r,N", [(2, 3, 5), (1, 2, 26), (2, 5, 17)])
 def test_resident_decoder_other_sizes(torch_cuda, oracle, layers, r, N):
     """tc_decoder_x_kernel outside the folded hparams-default instantiation: other decoder depths / reduction factors (run-time sizes), one

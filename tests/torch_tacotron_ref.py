@@ -164,7 +164,15 @@ def infer(w, dims, tokens, lengths, speaker_ids):
     x = table[torch.as_tensor(tokens, dtype=torch.long)]
     before_highway = enc_init = att_init = None
     dec_init = [None] * dims.dec_layers
-    if multi:
+    if multi and "speaker_embedding" not in w:
+        # tacotron.py:69-75, speaker_embedding_size == 1: modules.py:10-12 get_embed -- five tables of their own, embedding_lookup by speaker id
+        ids = torch.as_tensor(np.asarray(speaker_ids), dtype=torch.long)
+        before_highway = w["before_highway"][ids]
+        enc_init = w["encoder_rnn_init_state"][ids]
+        att_init = w["attention_rnn_init_state"][ids]
+        dec_init = [w["decoder_rnn_init_states%d" % (i + 1)][ids] for i in range(dims.dec_layers)]
+        linear_name = "dense"                                        # no deep_dense layers were created before the linear one
+    elif multi:
         # tacotron.py:63-86, model_type 'deepvoice', speaker_embedding_size != 1: softsign(dense(speaker_embed)); tf.layers.dense
         # layers are auto-named dense, dense_1, ... in creation order
         spk = _t(w["speaker_embedding"])[torch.as_tensor(np.asarray(speaker_ids), dtype=torch.long)]
