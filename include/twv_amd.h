@@ -174,6 +174,8 @@ typedef struct {
     int32_t dec_prenet_sizes[2], dec_layer_num, dec_rnn_size;
     int32_t post_bank_size, post_bank_channel_size, post_proj_sizes[2], post_proj_width, post_highway_depth, post_rnn_size;
     int32_t num_mels, reduction_factor, num_freq, max_iters;
+    int32_t model_simple;   /* 0: hparams.model_type 'deepvoice' (hparams.py:123, the default); 1: 'simple' (tacotron.py:85-90: the speaker embedding is
+                             * concatenated inside the decoder, rnn_wrappers.py:425-432 / 455-463); read only when num_speakers > 1 */
 } twv_tacotron_dims;
 typedef struct twv_tacotron twv_tacotron;
 

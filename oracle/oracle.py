@@ -309,15 +309,17 @@ class TacoDims(C.Structure):
                 ("enc_proj_w", C.c_int), ("enc_hw_depth", C.c_int), ("enc_rnn", C.c_int), ("att", C.c_int), ("att_state", C.c_int),
                 ("dec_prenet", C.c_int * 2), ("dec_layers", C.c_int), ("dec_rnn", C.c_int), ("post_bank", C.c_int),
                 ("post_bank_ch", C.c_int), ("post_proj", C.c_int * 2), ("post_proj_w", C.c_int), ("post_hw_depth", C.c_int),
-                ("post_rnn", C.c_int), ("num_mels", C.c_int), ("r", C.c_int), ("num_freq", C.c_int), ("max_iters", C.c_int)]
+                ("post_rnn", C.c_int), ("num_mels", C.c_int), ("r", C.c_int), ("num_freq", C.c_int), ("max_iters", C.c_int),
+                ("model_simple", C.c_int)]
 
 
 def taco_dims(n_symbols=80, emb=256, n_speakers=2, spk_emb=16, enc_prenet=(256, 128), enc_bank=16, enc_bank_ch=128,
               enc_proj=(128, 128), enc_proj_w=3, enc_hw_depth=4, enc_rnn=128, att=256, att_state=256, dec_prenet=(256, 128),
               dec_layers=2, dec_rnn=256, post_bank=8, post_bank_ch=128, post_proj=(256, 80), post_proj_w=3, post_hw_depth=4,
-              post_rnn=128, num_mels=80, r=5, num_freq=1025, max_iters=200):
-    """defaults = hparams.py:126-165"""
+              post_rnn=128, num_mels=80, r=5, num_freq=1025, max_iters=200, model_simple=False):
+    """defaults = hparams.py:126-165; model_simple: hparams.model_type == 'simple' (tacotron.py:85-90), multi-speaker only"""
     d = TacoDims()
+    d.model_simple = 1 if model_simple else 0
     d.n_symbols, d.emb, d.n_speakers, d.spk_emb = n_symbols, emb, n_speakers, spk_emb
     d.enc_prenet[0], d.enc_prenet[1] = enc_prenet
     d.enc_bank, d.enc_bank_ch, d.enc_proj_w, d.enc_hw_depth, d.enc_rnn = enc_bank, enc_bank_ch, enc_proj_w, enc_hw_depth, enc_rnn
@@ -363,7 +365,13 @@ def taco_tensor_specs(d):
     ENC = 2 * RN
     s = [("embedding", (d.n_symbols, E))]
     dn = ([P1, 2 * RN, AS] + [DR] * d.dec_layers) if d.n_speakers > 1 else []      # tacotron.py:62-104
-    if d.n_speakers > 1 and SE == 1:
+    simple = d.n_speakers > 1 and bool(d.model_simple) and SE != 1
+    SEc = SE if simple else 0
+    if simple:
+        # tacotron.py:85-90 model_type 'simple': the speaker embedding only, concatenated inside the decoder (rnn_wrappers.py:425-432, 455-463)
+        s += [("speaker_embedding", (d.n_speakers, SE))]
+        dn = []
+    elif d.n_speakers > 1 and SE == 1:
         # tacotron.py:69-75: speaker_embedding_size == 1 -> five embedding tables of their own (modules.py:10-12 get_embed), no dense layers
         names = ["before_highway", "encoder_rnn_init_state", "attention_rnn_init_state"] + ["decoder_rnn_init_states%d" % (i + 1) for i in range(d.dec_layers)]
         s += [(nm, (d.n_speakers, n)) for nm, n in zip(names, dn)]
@@ -381,10 +389,10 @@ def taco_tensor_specs(d):
     D0, D1 = d.dec_prenet[0], d.dec_prenet[1]
     s += [("decoder/decoder_prenet/dense_1/kernel", (M, D0)), ("decoder/decoder_prenet/dense_1/bias", (D0,)),
           ("decoder/decoder_prenet/dense_2/kernel", (D0, D1)), ("decoder/decoder_prenet/dense_2/bias", (D1,))]
-    ain = D1 + ENC
+    ain = D1 + SEc + ENC                                              # 'simple': [prenet_out, speaker embed, context]
     p = "decoder/attention_wrapper/gru_cell/"
     s += [(p + "gates/kernel", (ain + AS, 2 * AS)), (p + "gates/bias", (2 * AS,)), (p + "candidate/kernel", (ain + AS, AS)), (p + "candidate/bias", (AS,))]
-    s += [("decoder/output_projection_wrapper/multi_rnn_cell/cell_0/output_projection_wrapper/kernel", (AS + ENC, DR)),
+    s += [("decoder/output_projection_wrapper/multi_rnn_cell/cell_0/output_projection_wrapper/kernel", (AS + ENC + SEc, DR)),
           ("decoder/output_projection_wrapper/multi_rnn_cell/cell_0/output_projection_wrapper/bias", (DR,))]
     for i in range(d.dec_layers):
         p = "decoder/output_projection_wrapper/multi_rnn_cell/cell_%d/gru_cell/" % (i + 1)

@@ -237,12 +237,16 @@ void twvo_taco_infer(const twvo_taco_dims* d, const float* blob, const int32_t* 
     const int multi = d->n_speakers > 1;
     /* tacotron.py:69-75: with speaker_embedding_size == 1 the five speaker-dependent vectors are embedding tables of their own
      * (modules.py:10-12 get_embed), looked up by speaker id; otherwise (:76-82) dense(softsign) layers of ONE speaker embedding */
+    /* tacotron.py:85-90 model_type 'simple': no speaker-dependent initial states at all; the speaker embedding itself is concatenated to
+     * the decoder prenet's output (rnn_wrappers.py:425-432) and to [output, attention] in front of the first projection (:455-463) */
+    const int simple = multi && d->model_simple && SE != 1;
     const int tables = multi && SE == 1;
     const float* semb = (multi && !tables) ? take(&c, (size_t)d->n_speakers * SE) : NULL;   /* tacotron.py:67 'speaker_embedding' */
     /* tacotron.py:76-82 deep_dense (softsign): before_highway, encoder rnn init, attention rnn init, decoder rnn inits */
     const float *dW[8], *db[8], *tab[8];
     const int dn[8] = { P1, 2 * RN, AS, DR, DR, DR, DR, DR };
-    const int ndense = multi ? 3 + d->dec_layers : 0;
+    const int ndense = (multi && !simple) ? 3 + d->dec_layers : 0;
+    const int SEc = simple ? SE : 0;                                       /* width of the embedding concatenated inside the decoder */
     for (int i = 0; i < ndense; ++i) {
         if (tables) tab[i] = take(&c, (size_t)d->n_speakers * dn[i]);
         else { dW[i] = take(&c, (size_t)SE * dn[i]); db[i] = take(&c, dn[i]); }
@@ -258,10 +262,10 @@ void twvo_taco_infer(const twvo_taco_dims* d, const float* blob, const int32_t* 
     const float* dpW1 = take(&c, (size_t)M * d->dec_prenet[0]); const float* dpb1 = take(&c, d->dec_prenet[0]);   /* decoder_prenet */
     const float* dpW2 = take(&c, (size_t)d->dec_prenet[0] * d->dec_prenet[1]); const float* dpb2 = take(&c, d->dec_prenet[1]);
     const int DP = d->dec_prenet[1];
-    const int ain = DP + ENC;                                              /* attention GRU input: [prenet_out, context] */
+    const int ain = DP + SEc + ENC;                                        /* attention GRU input: [prenet_out, (speaker embed,) context] */
     const float* aWg = take(&c, (size_t)(ain + AS) * 2 * AS); const float* abg = take(&c, 2 * AS);
     const float* aWc = take(&c, (size_t)(ain + AS) * AS); const float* abc = take(&c, AS);
-    const float* cW = take(&c, (size_t)(AS + ENC) * DR); const float* cb = take(&c, DR);          /* OutputProjectionWrapper -> dec_rnn */
+    const float* cW = take(&c, (size_t)(AS + ENC + SEc) * DR); const float* cb = take(&c, DR);    /* OutputProjectionWrapper -> dec_rnn */
     const float *rWg[4], *rbg[4], *rWc[4], *rbc[4];
     for (int i = 0; i < d->dec_layers; ++i) {
         rWg[i] = take(&c, (size_t)2 * DR * 2 * DR); rbg[i] = take(&c, 2 * DR);
@@ -300,15 +304,17 @@ void twvo_taco_infer(const twvo_taco_dims* d, const float* blob, const int32_t* 
         memset(init, 0, sizeof(init));                                      /* single speaker: zero states (tacotron.py:97-104) */
         if (tables) {
             for (int i = 0; i < ndense; ++i) memcpy(init[i], tab[i] + (size_t)speaker_ids[n] * dn[i], sizeof(float) * dn[i]);   /* embedding_lookup */
-        } else if (multi) {
+        } else if (multi && !simple) {
             const float* se = semb + (size_t)speaker_ids[n] * SE;
             for (int i = 0; i < ndense; ++i) dense_rows(se, 1, SE, dW[i], db[i], dn[i], ACT_SOFTSIGN, init[i]);
         }
+        const int has_init = multi && !simple;                                /* 'simple' and single speaker: None -> zero states, no before_highway */
+        const float* sev = simple ? semb + (size_t)speaker_ids[n] * SE : NULL;
         dense_rows(x0, T, E, pW1, pb1, P0, ACT_RELU, x1);                 /* tacotron.py:108 prenet (dropout rate 0) */
         dense_rows(x1, T, P0, pW2, pb2, P1, ACT_RELU, x2);
         /* tacotron.py:113 encoder cbhg; encoder_rnn_init_state split into fw | bw (modules.py:66) */
         cbhg_one(&enc, x2, T, len, P1, d->enc_bank, d->enc_bank_ch, d->enc_proj, d->enc_proj_w, d->enc_hw_depth, RN,
-                 multi ? init[0] : NULL, multi ? init[1] : NULL, multi ? init[1] + RN : NULL, memo);
+                 has_init ? init[0] : NULL, has_init ? init[1] : NULL, has_init ? init[1] + RN : NULL, memo);
         /* [RECALLED-TF _prepare_memory]: memory zeroed past input_lengths (the biGRU already outputs zeros there) */
         for (int t = len; t < T; ++t) memset(memo + (size_t)t * ENC, 0, sizeof(float) * ENC);
         dense_rows(memo, T, ENC, Wm, NULL, A, ACT_NONE, keys);              /* keys = memory_layer(memory) */
@@ -325,7 +331,9 @@ void twvo_taco_infer(const twvo_taco_dims* d, const float* blob, const int32_t* 
             float q1[512], q2[512], cin[2048], hn[512], pq[1024], outp[2048];
             dense_rows(frame, 1, M, dpW1, dpb1, d->dec_prenet[0], ACT_RELU, q1);       /* rnn_wrappers.py:425 decoder prenet */
             dense_rows(q1, 1, d->dec_prenet[0], dpW2, dpb2, DP, ACT_RELU, q2);
-            memcpy(cin, q2, sizeof(float) * DP); memcpy(cin + DP, ctx, sizeof(float) * ENC);   /* rnn_wrappers.py:310 concat */
+            memcpy(cin, q2, sizeof(float) * DP);
+            if (SEc) memcpy(cin + DP, sev, sizeof(float) * SEc);            /* rnn_wrappers.py:429-430 concat([prenet_out, embed_to_concat]) */
+            memcpy(cin + DP + SEc, ctx, sizeof(float) * ENC);               /* rnn_wrappers.py:310 concat([inputs, state.attention]) */
             gru_step(cin, ain, ah, AS, aWg, abg, aWc, abc, hn);             /* rnn_wrappers.py:312 attention GRU */
             memcpy(ah, hn, sizeof(float) * AS);
             /* rnn_wrappers.py:369-398 + [RECALLED-TF BahdanauMonotonicAttention.__call__] */
@@ -362,8 +370,9 @@ void twvo_taco_infer(const twvo_taco_dims* d, const float* blob, const int32_t* 
             twvo_cdot_rows(memo, ENC, align, T, ctx);                       /* rnn_wrappers.py:390 context = alignments . values */
             /* rnn_wrappers.py:463 concat(output, attention) -> OutputProjectionWrapper(dec_rnn) [RECALLED-TF: linear + bias] */
             memcpy(cin, ah, sizeof(float) * AS); memcpy(cin + AS, ctx, sizeof(float) * ENC);
+            if (SEc) memcpy(cin + AS + ENC, sev, sizeof(float) * SEc);      /* rnn_wrappers.py:458-460 concat([output, attention, embed_to_concat]) */
             float y[512];
-            dense_rows(cin, 1, AS + ENC, cW, cb, DR, ACT_NONE, y);
+            dense_rows(cin, 1, AS + ENC + SEc, cW, cb, DR, ACT_NONE, y);
             for (int i = 0; i < d->dec_layers; ++i) {                       /* tacotron.py:167 ResidualWrapper(GRUCell): y + GRU(y) */
                 gru_step(y, DR, rh[i], DR, rWg[i], rbg[i], rWc[i], rbc[i], hn);
                 memcpy(rh[i], hn, sizeof(float) * DR);
@@ -391,7 +400,11 @@ size_t twvo_taco_blob_floats(const twvo_taco_dims* d)
               AS = d->att_state, DR = d->dec_rnn, M = d->num_mels, R = d->r, ENC = 2 * RN;
     n += (size_t)d->n_symbols * E;
     const int dn[8] = { P1, 2 * RN, AS, DR, DR, DR, DR, DR };
-    if (d->n_speakers > 1 && SE == 1) {
+    const int simple = d->n_speakers > 1 && d->model_simple && SE != 1;
+    const int SEc = simple ? SE : 0;
+    if (simple) {
+        n += (size_t)d->n_speakers * SE;
+    } else if (d->n_speakers > 1 && SE == 1) {
         for (int i = 0; i < 3 + d->dec_layers; ++i) n += (size_t)d->n_speakers * dn[i];
     } else if (d->n_speakers > 1) {
         n += (size_t)d->n_speakers * SE;
@@ -410,9 +423,9 @@ size_t twvo_taco_blob_floats(const twvo_taco_dims* d)
     CBHG_N(P1, d->enc_bank, d->enc_bank_ch, d->enc_proj, d->enc_proj_w, d->enc_hw_depth, RN);
     n += (size_t)ENC * A + (size_t)AS * A + A + 1 + A + 1;
     n += (size_t)M * d->dec_prenet[0] + d->dec_prenet[0] + (size_t)d->dec_prenet[0] * d->dec_prenet[1] + d->dec_prenet[1];
-    const int ain = d->dec_prenet[1] + ENC;
+    const int ain = d->dec_prenet[1] + SEc + ENC;
     n += (size_t)(ain + AS) * 2 * AS + 2 * AS + (size_t)(ain + AS) * AS + AS;
-    n += (size_t)(AS + ENC) * DR + DR;
+    n += (size_t)(AS + ENC + SEc) * DR + DR;
     for (int i = 0; i < d->dec_layers; ++i) n += (size_t)2 * DR * 2 * DR + 2 * DR + (size_t)2 * DR * DR + DR;
     n += (size_t)DR * M * R + M * R;
     CBHG_N(M, d->post_bank, d->post_bank_ch, d->post_proj, d->post_proj_w, d->post_hw_depth, d->post_rnn);

@@ -114,6 +114,7 @@ typedef struct {
     int dec_prenet[2], dec_layers, dec_rnn;         /* [256,128], 2, 256 */
     int post_bank, post_bank_ch, post_proj[2], post_proj_w, post_hw_depth, post_rnn;  /* 8,128,[256,80],3,4,128 */
     int num_mels, r, num_freq, max_iters;           /* 80, 5, 1025, 200 */
+    int model_simple;                               /* 0: hparams.model_type 'deepvoice' (default); 1: 'simple' (tacotron.py:85-90) -- only read when n_speakers > 1 */
 } twvo_taco_dims;
 size_t twvo_taco_blob_floats(const twvo_taco_dims* d);
 void twvo_taco_infer(const twvo_taco_dims* d, const float* blob, const int32_t* tokens, const int32_t* lengths,

@@ -267,7 +267,8 @@ class TacoDims(C.Structure):
                 ("dec_prenet_sizes", C.c_int32 * 2), ("dec_layer_num", C.c_int32), ("dec_rnn_size", C.c_int32),
                 ("post_bank_size", C.c_int32), ("post_bank_channel_size", C.c_int32), ("post_proj_sizes", C.c_int32 * 2),
                 ("post_proj_width", C.c_int32), ("post_highway_depth", C.c_int32), ("post_rnn_size", C.c_int32),
-                ("num_mels", C.c_int32), ("reduction_factor", C.c_int32), ("num_freq", C.c_int32), ("max_iters", C.c_int32)]
+                ("num_mels", C.c_int32), ("reduction_factor", C.c_int32), ("num_freq", C.c_int32), ("max_iters", C.c_int32),
+                ("model_simple", C.c_int32)]
 
 
 TWV_E_BUSY = 5          # include/twv_amd.h: a persistent kernel found the device occupied: nothing was done, retry later

@@ -692,6 +692,8 @@ struct DecArgs {
     const float* init;     // [N][ninit]: attention rnn init (AS) then dec_layers x DR
     const int32_t* lengths;
     int N, T, M, R, D0, D1, A, AS, ENC, DR, layers, iters;
+    int SEc;               // model_type 'simple': width of the speaker embedding concatenated inside the decoder (0 otherwise)
+    const float* semb;     // [N][SEc] the utterances' speaker embeddings (SEc > 0)
     float* mel;            // [N][iters*R][M]
     float* align;          // [N][T][iters] or nullptr
     int32_t* status;
@@ -1193,6 +1195,9 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     }
     const int T = a.T, M = DEF ? 80 : a.M, R = DEF ? 5 : a.R, A = DEF ? 256 : a.A, AS = DEF ? 256 : a.AS, ENC = DEF ? 256 : a.ENC;
     const int DR = DEF ? 256 : a.DR, D0 = DEF ? 256 : a.D0, D1 = DEF ? 128 : a.D1, NL = DEF ? 2 : a.layers;
+    // model_type 'simple' (tacotron.py:85-90): the utterance's speaker embedding (SEc values) sits between the prenet output and the context in
+    // the attention cell's input (rnn_wrappers.py:429-430) and behind [output, attention] in the first projection's input (:458-460)
+    const int SEc = DEF ? 0 : a.SEc, DE = D1 + SEc;
     if (n >= a.N) return;
     const int len = a.lengths[n];
     const float* P = a.P;
@@ -1206,7 +1211,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     // the attention GRU's input [prenet_out | attention | ha] has a buffer of its own: its three parts are written where they are
     // produced (the prenet's epilogue, the context's gather of the PREVIOUS step, the attention cell's update), not copied together
     // behind a barrier at the start of every step
-    const int o_cat2 = o; o += ((D1 + ENC + AS + 63) / 64) * 64;
+    const int o_cat2 = o; o += ((DE + ENC + AS + 63) / 64) * 64;
     const int o_vec = o; o += 1024;                       // gathered gates (r | u), prenet hidden
     const int o_cand = o; o += 512;
     const int o_keep = o; o += 512;                       // h before the update
@@ -1240,8 +1245,9 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
     for (int i = tid; i < AS; i += 512) lds[o_ha + i] = init[i];
     for (int i = tid; i < NL * DR; i += 512) lds[o_hr0 + i] = init[AS + i];
     for (int i = tid; i < ((M + 31) / 32) * 32; i += 512) lds[o_frame + i] = 0.0f;
-    for (int i = tid; i < ENC; i += 512) { lds[o_ctx + i] = 0.0f; lds[o_cat2 + D1 + i] = 0.0f; }
-    for (int i = tid; i < AS; i += 512) lds[o_cat2 + D1 + ENC + i] = init[i];
+    for (int i = tid; i < ENC; i += 512) { lds[o_ctx + i] = 0.0f; lds[o_cat2 + DE + i] = 0.0f; }
+    for (int i = tid; i < AS; i += 512) lds[o_cat2 + DE + ENC + i] = init[i];
+    for (int i = tid; i < SEc; i += 512) { const float e = a.semb[(long long)n * SEc + i]; lds[o_cat2 + D1 + i] = e; lds[o_cat + AS + ENC + i] = e; }
     for (int i = tid; i < Tp; i += 512) lds[o_al + i] = i == 0 ? 1.0f : 0.0f;
     if (tid < 4) LDSI(o_abort + tid) = 0;
     for (int i = tid; i < A; i += 512) { lds[o_nv + i + ((i >> 5) << 2)] = P[a.w.nv + i]; lds[o_ab + i + ((i >> 5) << 2)] = P[a.w.ab + i]; }
@@ -1269,12 +1275,12 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
         put(a.w.dp1, a.w.dp1b, M, D0, o_frame, o_vec, DA_RELU, ga.split_all, DP_NONE, 0, 0, 0);
         put(a.w.dp2, a.w.dp2b, D0, D1, o_vec, o_cat2, DA_RELU, ga.split_all, DP_NONE, 0, 0, 0);
         // rnn_wrappers.py:310-312 attention GRU on [prenet_out | attention | ha]
-        put(a.w.aWg, a.w.abg, D1 + ENC + AS, 2 * AS, o_cat2, o_vec, DA_SIGMOID, 1, DP_GATES, D1 + ENC, AS, 0);
-        put(a.w.aWc, a.w.abc, D1 + ENC + AS, AS, o_cat2, o_cand, DA_TANH, 1, DP_CAND, AS, o_ha, -1);
+        put(a.w.aWg, a.w.abg, DE + ENC + AS, 2 * AS, o_cat2, o_vec, DA_SIGMOID, 1, DP_GATES, DE + ENC, AS, 0);
+        put(a.w.aWc, a.w.abc, DE + ENC + AS, AS, o_cat2, o_cand, DA_TANH, 1, DP_CAND, AS, o_ha, -1);
         // attention query layer (redundant: 32 tiles), then score / recurrence / context
         put(a.w.Wq, -1, AS, A, o_ha, o_pq, DA_NONE, ga.split_all, DP_QUERY, 0, 0, 0);
         // rnn_wrappers.py:463 concat(output, attention) -> OutputProjectionWrapper(dec_rnn)
-        put(a.w.cW, a.w.cb, AS + ENC, DR, o_cat, o_y, DA_NONE, 1, DP_PROJ, 0, 0, 0);
+        put(a.w.cW, a.w.cb, AS + ENC + SEc, DR, o_cat, o_y, DA_NONE, 1, DP_PROJ, 0, 0, 0);
         // tacotron.py:167 ResidualWrapper(GRUCell(dec_rnn)): y <- y + GRU(y, h_l)
         for (int l = 0; l < NL; ++l) {
             put(a.w.rWg[l], a.w.rbg[l], 2 * DR, 2 * DR, o_cat, o_vec, DA_SIGMOID, 1, DP_GATES, DR, DR, 0);
@@ -1408,7 +1414,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                                 lds[o_y + j] = yn;
                                 if (p2 > 0) { lds[o_cat + j] = yn; lds[o_cat + DR + j] = lds[p2 + j]; }
                             } else {                         // the attention cell: its new state is the tail of its own next input and
-                                lds[xo + D1 + ENC + j] = hn; // the head of the concat projection's input (rnn_wrappers.py:463)
+                                lds[xo + DE + ENC + j] = hn; // the head of the concat projection's input (rnn_wrappers.py:463)
                                 lds[o_cat + j] = hn;
                             }
                         } else if (post == DP_PROJ) {
@@ -1452,7 +1458,7 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                         lds[o_y + i] = yn;
                         if (o_next > 0) { lds[o_cat + i] = yn; lds[o_cat + DR + i] = lds[o_next + i]; }
                     } else {
-                        lds[xo + D1 + ENC + i] = hn;
+                        lds[xo + DE + ENC + i] = hn;
                         lds[o_cat + i] = hn;
                     }
                 }
@@ -1613,12 +1619,12 @@ __global__ void __launch_bounds__(512) tc_decoder_g_kernel(DecGArgs ga)
                     if (tid < ncol) {
                         float v = 0.0f;
                         for (int ch = 0; ch < nch; ++ch) { const float c = lds[o_part + ch * ncol + tid]; v = ch == 0 ? c : v + c; }
-                        if (G == 1) { lds[o_ctx + tid] = v; lds[o_cat + AS + tid] = v; lds[o_cat2 + D1 + tid] = v; }
+                        if (G == 1) { lds[o_ctx + tid] = v; lds[o_cat + AS + tid] = v; lds[o_cat2 + DE + tid] = v; }
                         else decg_store(Xb + c0 + tid, ep, v, loc);
                     }
                     if (G > 1)
                         decg_gather_apply(Xb, ENC, ep, tid, o_abort, [&](const int j, const float v) {
-                            lds[o_ctx + j] = v; lds[o_cat + AS + j] = v; lds[o_cat2 + D1 + j] = v;
+                            lds[o_ctx + j] = v; lds[o_cat + AS + j] = v; lds[o_cat2 + DE + j] = v;
                         });
                     __syncthreads();
                     ok = LDSI(o_abort) == 0;
@@ -2247,9 +2253,11 @@ static void taco_build(twv_tacotron* h)
     h->emb = raw(d.n_symbols, E);
     // tacotron.py:63-104: the speaker tensors exist for num_speakers > 1 only; a single-speaker model (synthesizer.py:375's default)
     // has no speaker embedding, no before_highway and zero initial states
-    h->ndense = d.num_speakers > 1 ? 3 + d.dec_layer_num : 0;
+    h->ndense = (d.num_speakers > 1 && !(d.model_simple && SE != 1)) ? 3 + d.dec_layer_num : 0;
     const int dn[8] = {P1, 2 * RN, AS, DR, DR, DR, DR, DR};
-    if (d.num_speakers > 1 && SE == 1) {
+    if (d.num_speakers > 1 && d.model_simple && SE != 1) {
+        h->semb = raw(d.num_speakers, SE);          // 'simple': the embedding table alone
+    } else if (d.num_speakers > 1 && SE == 1) {
         // tacotron.py:69-75: speaker_embedding_size == 1 -> five embedding tables (modules.py:10-12 get_embed), one row per speaker
         for (int i = 0; i < h->ndense; ++i) { h->dn[i] = dn[i]; h->stab[i] = raw(d.num_speakers, dn[i]); }
     } else if (d.num_speakers > 1) {
@@ -2262,9 +2270,12 @@ static void taco_build(twv_tacotron* h)
     h->av = vec(A); h->ag = vec(1); h->ab = vec(A); h->asb = vec(1);
     h->dpW1 = mat(M, d.dec_prenet_sizes[0]); h->dpb1 = vec(d.dec_prenet_sizes[0]);
     h->dpW2 = mat(d.dec_prenet_sizes[0], d.dec_prenet_sizes[1]); h->dpb2 = vec(d.dec_prenet_sizes[1]);
-    const int ain = d.dec_prenet_sizes[1] + ENC;
+    // model_type 'simple' (tacotron.py:85-90): only the speaker embedding, concatenated inside the decoder (rnn_wrappers.py:425-432, 455-463)
+    const bool simple = d.num_speakers > 1 && d.model_simple && SE != 1;
+    const int SEc = simple ? SE : 0;
+    const int ain = d.dec_prenet_sizes[1] + SEc + ENC;
     h->aWgm = mat(ain + AS, 2 * AS); h->abg = vec(2 * AS); h->aWcm = mat(ain + AS, AS); h->abc = vec(AS);
-    h->cW = mat(AS + ENC, DR); h->cb = vec(DR);
+    h->cW = mat(AS + ENC + SEc, DR); h->cb = vec(DR);
     for (int i = 0; i < d.dec_layer_num; ++i) { h->rWg[i] = mat(2 * DR, 2 * DR); h->rbg[i] = vec(2 * DR); h->rWc[i] = mat(2 * DR, DR); h->rbc[i] = vec(DR); }
     h->oW = mat(DR, M * R); h->ob = vec(M * R);
     cbhg(h->post, M, d.post_bank_size, d.post_bank_channel_size, d.post_proj_sizes, d.post_proj_width, d.post_highway_depth, d.post_rnn_size);
@@ -2296,6 +2307,11 @@ extern "C" int twv_tacotron_create(const twv_tacotron_dims* dims, twv_tacotron**
     if (d.enc_bank_size > 16 || d.post_bank_size > 16 || d.enc_highway_depth > 8 || d.post_highway_depth > 8) return twv_fail(TWV_E_UNSUPPORTED, "bank / highway depth out of range");
     if (d.num_speakers < 1) return twv_fail(TWV_E_INVALID, "num_speakers must be >= 1");
     if (d.num_speakers > 1 && d.speaker_embedding_size < 1) return twv_fail(TWV_E_INVALID, "speaker_embedding_size must be >= 1");
+    if (d.num_speakers > 1 && d.model_simple && d.speaker_embedding_size != 1) {
+        // the embedding rides at the tail of the buffer the residual GRU inputs [y | h] share with the first projection's input
+        if (2 * d.dec_rnn_size > d.attention_state_size + 2 * d.enc_rnn_size || d.speaker_embedding_size > 64)
+            return twv_fail(TWV_E_UNSUPPORTED, "model_type 'simple': needs 2 * dec_rnn_size <= attention_state_size + 2 * enc_rnn_size and speaker_embedding_size <= 64");
+    }
     twv_tacotron* h = new twv_tacotron();
     h->d = d;
     taco_build(h);
@@ -2388,6 +2404,7 @@ static void taco_xstages(const twv_tacotron* h, XStageTab& t)
 static bool taco_xdec_ok(const twv_tacotron* h, const XStageTab& t)
 {
     const twv_tacotron_dims& d = h->d;
+    if (d.num_speakers > 1 && d.model_simple && d.speaker_embedding_size != 1) return false;      // 'simple': the split kernel carries the embedding concat
     if (t.nst > kXStages || d.attention_size % 32 || (2 * d.enc_rnn_size) % 32 || d.attention_size > 256 || d.dec_layer_num > 4) return false;
     // (the stage inputs are fetched with 16-byte LDS reads: every vector of an utterance's LDS block starts on a multiple of four floats)
     if (d.dec_prenet_sizes[1] % 4 || d.attention_state_size % 4 || d.dec_rnn_size % 4) return false;
@@ -2627,11 +2644,15 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
     // ---- tacotron.py:51-60 embedding, :67-82 speaker embedding + deep_dense (softsign)
     hipLaunchKernelGGL(tc_embed_kernel, dim3(tgrid((long long)rows * E)), dim3(256), 0, st, P + h->emb.off, tokens, rows, E, ra);
     const bool multi = d.num_speakers > 1;
+    const bool simple = multi && d.model_simple && SE != 1;     // tacotron.py:85-90: no speaker-dependent states, the embedding goes into the decoder
     // spk layout: [N][SE] at 0, then per dense i a [N][dn_i] block
     float* sv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // decoder initial states gathered as [N][AS + layers*DR]
     float* dinit = spk + (long long)N * 2048;
-    if (multi) {
+    if (simple) {
+        hipLaunchKernelGGL(tc_gather_rows_kernel, dim3(tgrid((long long)N * SE)), dim3(256), 0, st, P + h->semb.off, speaker_ids, N, SE, spk);
+        HIPCHK(hipMemsetAsync(dinit, 0, (size_t)N * (AS + d.dec_layer_num * DR) * 4, st));
+    } else if (multi) {
         { float* q = spk + (long long)N * 64; for (int i = 0; i < h->ndense; ++i) { sv[i] = q; q += (long long)N * h->dn[i]; } }
         if (SE == 1) {
             // tacotron.py:69-75 get_embed: tf.nn.embedding_lookup of five tables by speaker id
@@ -2671,12 +2692,13 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
     da.keys = keys; da.memo = memo; da.init = dinit; da.lengths = lengths;
     da.N = N; da.T = T; da.M = M; da.R = R; da.D0 = d.dec_prenet_sizes[0]; da.D1 = d.dec_prenet_sizes[1]; da.A = A; da.AS = AS; da.ENC = ENC;
     da.DR = DR; da.layers = d.dec_layer_num; da.iters = d.max_iters; da.mel = mel; da.align = alignments; da.status = status;
+    da.SEc = simple ? SE : 0; da.semb = simple ? spk : nullptr;
     da.packed_bytes = (long long)h->packed_floats * 4;
     da.prof = h->prof;
     da.nbias = da.D0 + da.D1 + 3 * AS + DR + d.dec_layer_num * 3 * DR + M * R;
     {
         const int Tp = (T + 3) / 4 * 4;
-        const int ain = da.D1 + ENC;
+        const int ain = da.D1 + da.SEc + ENC;
         const int kmax = (ain + AS) > 2 * DR ? (ain + AS) : 2 * DR;
         const long long part = (long long)((kmax + 31) / 32) * ((2 * (AS > DR ? AS : DR) + 63) / 64) * 64;
         const long long part2 = (long long)((DR + 31) / 32) * ((M * R + 63) / 64) * 64;
@@ -2699,7 +2721,9 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             const int nu = upx < N ? upx : N;
             xfl = xdec_carve(M, da.D1, ENC, AS, d.dec_layer_num, DR, A, T, nu < 1 ? 1 : nu, xt.nst).total + 64;
         }
-        const bool xok = taco_xdec_ok(h, xt) && cus >= 256 && upx <= kXU && T <= 512 && xfl * 4 <= 160 * 1024;
+        const bool xok = taco_xdec_ok(h, xt) && cus >= 256 && upx <= kXU && T <= 512 && xfl * 4 <= 160 * 1024 && !simple;
+        if (simple && (h->dec_groups == -1 || h->dec_groups == 32))
+            return twv_fail(TWV_E_UNSUPPORTED, "model_type 'simple' runs on the split decoder kernel only (decoder_groups 0, 1, 2, 4, 8 or 16)");
         // Which kernel (round 6, scripts/tacotron_bench.py --batch 8 / 16 / 32): the XCD-resident kernel runs a pass in 6.7 / 7.4 / 9.2 ms, the
         // split kernel in 7.6 / 8.0 / 8.8 -- with one or two utterances per XCD the resident kernel's exchanges (32 workgroups, every weight
         // in registers, no tile stream in front of the polls) are the shorter ones, with four the split kernel's 8-workgroup groups are.
@@ -2745,7 +2769,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             if (wgs > 512) return twv_fail(TWV_E_UNSUPPORTED, "more than 512 decoder workgroups");
             HIPCHK(hipMemsetAsync(exch, 0, (size_t)N * 2 * kExN * 8 + 64, st));
             ga.tickets = reinterpret_cast<int*>(exch + (long long)N * 2 * kExN * 2);
-            long long fl = 1024 * 2 + (da.D1 + ENC + AS + 63) / 64 * 64 + 512 * 2 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + (M * R + 63) / 64 * 64 + Tp * 4 + A +
+            long long fl = 1024 * 2 + (da.D1 + da.SEc + ENC + AS + 63) / 64 * 64 + 512 * 2 + AS + d.dec_layer_num * DR + (M + 31) / 32 * 32 + ENC + DR + (M * R + 63) / 64 * 64 + Tp * 4 + A +
                            Tp * 8 + 4 + 3 + 16 * 16 + 2 * A + 3 * (A / 8) + da.nbias + pmax;
             const long long kvf = (long long)((T + G - 1) / G) * (A + A / 8) + (long long)T * (ENC / G + 8);
             ga.kv_lds = (fl + kvf) * 4 <= 160 * 1024 ? 1 : 0;
@@ -2755,7 +2779,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
             // plain launch (N * G <= CU count is enforced above); a cooperative launch was measured and dropped, see twv_wavenet.hip
             // the hparams-default sizes have an instantiation of their own (sizes folded: half the scalar-register spills); the
             // instrumented build (phase stamps) likewise
-            const bool def = G == 8 && M == 80 && R == 5 && A == 256 && AS == 256 && ENC == 256 && DR == 256 && da.D0 == 256 && da.D1 == 128 && d.dec_layer_num == 2;
+            const bool def = !simple && G == 8 && M == 80 && R == 5 && A == 256 && AS == 256 && ENC == 256 && DR == 256 && da.D0 == 256 && da.D1 == 128 && d.dec_layer_num == 2;
             const void* kfn = da.prof ? (def ? (const void*)tc_decoder_g_kernel<true, true> : (const void*)tc_decoder_g_kernel<true, false>)
                                       : (def ? (const void*)tc_decoder_g_kernel<false, true> : (const void*)tc_decoder_g_kernel<false, false>);
             HIPCHK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));

@@ -47,7 +47,14 @@ def tacotron_specs(hp, num_speakers, n_symbols=80):
     # tacotron.py:62-104: speaker embedding + the five deep_dense layers exist for num_speakers > 1 only; tf.layers.dense layers
     # are auto-named dense, dense_1, ... in creation order, so the linear-spectrogram layer is "dense" in a single-speaker graph
     dn = ([P1, 2 * RN, AS] + [DR] * hp.dec_layer_num) if num_speakers > 1 else []
-    if num_speakers > 1 and SE == 1:
+    simple = num_speakers > 1 and getattr(hp, "model_type", "deepvoice") == "simple" and SE != 1
+    SEc = SE if simple else 0
+    if simple:
+        # tacotron.py:85-90 model_type 'simple': the speaker embedding only -- it is concatenated to the decoder prenet's output
+        # (rnn_wrappers.py:425-432) and to [output, attention] in front of the first projection (:455-463); no dense layers before "dense"
+        s += [("speaker_embedding", (num_speakers, SE))]
+        dn = []
+    elif num_speakers > 1 and SE == 1:
         # tacotron.py:69-75: speaker_embedding_size == 1 -> the five speaker-dependent vectors are embedding tables of their own
         # (modules.py:10-12 get_embed, looked up by speaker id); no speaker embedding, no deep_dense layers (the linear layer is "dense")
         names = ["before_highway", "encoder_rnn_init_state", "attention_rnn_init_state"] + ["decoder_rnn_init_states%d" % (i + 1) for i in range(hp.dec_layer_num)]
@@ -67,10 +74,10 @@ def tacotron_specs(hp, num_speakers, n_symbols=80):
     D0, D1 = hp.dec_prenet_sizes
     s += [("decoder/decoder_prenet/dense_1/kernel", (M, D0)), ("decoder/decoder_prenet/dense_1/bias", (D0,)),
           ("decoder/decoder_prenet/dense_2/kernel", (D0, D1)), ("decoder/decoder_prenet/dense_2/bias", (D1,))]
-    ain = D1 + ENC
+    ain = D1 + SEc + ENC
     p = "decoder/attention_wrapper/gru_cell/"
     s += [(p + "gates/kernel", (ain + AS, 2 * AS)), (p + "gates/bias", (2 * AS,)), (p + "candidate/kernel", (ain + AS, AS)), (p + "candidate/bias", (AS,))]
-    s += [("decoder/output_projection_wrapper/multi_rnn_cell/cell_0/output_projection_wrapper/kernel", (AS + ENC, DR)),
+    s += [("decoder/output_projection_wrapper/multi_rnn_cell/cell_0/output_projection_wrapper/kernel", (AS + ENC + SEc, DR)),
           ("decoder/output_projection_wrapper/multi_rnn_cell/cell_0/output_projection_wrapper/bias", (DR,))]
     for i in range(hp.dec_layer_num):
         p = "decoder/output_projection_wrapper/multi_rnn_cell/cell_%d/gru_cell/" % (i + 1)
@@ -118,10 +125,10 @@ class Tacotron(object):
 
     def __init__(self, hparams, num_speakers=2, n_symbols=80, device="cuda:0"):
         hp = self._hparams = hparams
-        if hp.attention_type != 'bah_mon_norm' or num_speakers < 1 or (num_speakers > 1 and hp.model_type != 'deepvoice'):
-            raise NotImplementedError("built: attention_type 'bah_mon_norm'; single speaker (tacotron.py:97-104), or model_type 'deepvoice' "
-                                      "(tacotron.py:68-84: dense(softsign) layers of a speaker embedding, or -- speaker_embedding_size == 1 -- "
-                                      "embedding tables); model_type 'simple' (tacotron.py:85-90) is not")
+        if hp.attention_type != 'bah_mon_norm' or num_speakers < 1:
+            raise NotImplementedError("built: attention_type 'bah_mon_norm' (hparams.py:145, the default)")
+        if num_speakers > 1 and hp.model_type not in ('deepvoice', 'simple'):
+            raise Exception(" [!] Unkown multi-speaker model type: {}".format(hp.model_type))       # tacotron.py:92
         self.num_speakers = num_speakers
         self.device = torch.device(device)
         self.specs = tacotron_specs(hp, num_speakers, n_symbols)
@@ -138,6 +145,7 @@ class Tacotron(object):
         d.post_proj_sizes[0], d.post_proj_sizes[1] = hp.post_proj_sizes
         d.post_proj_width, d.post_highway_depth, d.post_rnn_size = hp.post_proj_width, hp.post_highway_depth, hp.post_rnn_size
         d.num_mels, d.reduction_factor, d.num_freq, d.max_iters = hp.num_mels, hp.reduction_factor, hp.num_freq, hp.max_iters
+        d.model_simple = 1 if (num_speakers > 1 and hp.model_type == 'simple') else 0
         self._dims = d
         self._L = _lib.lib()
         h = C.c_void_p()

@@ -289,17 +289,23 @@ def test_restatement_fixtures_mulaw_and_tacotron(oracle):
     assert t["mel"].shape == (3, 30, 80) and t["linear"].shape == (3, 30, 129) and t["alignments"].shape == (3, 17, 6)
 
 
-@pytest.mark.parametrize("n_speakers", [2, 1, -2])
+@pytest.mark.parametrize("n_speakers", [2, 1, -2, "simple"])
 def test_torch_tacotron_reference_agrees_with_the_c_restatement(oracle, n_speakers):
     """oracle/tacotron.c gets a second opinion -- tests/torch_tacotron_ref.py, a float64 torch restatement of
     tacotron.py:36-235 + modules.py + rnn_wrappers.py written from the reference source and TensorFlow's published semantics, not from
     the C file.  Default dims (hparams.py:126-165), 25 decoder steps, ragged lengths; multi-speaker (deepvoice) and single speaker.
     1e-5 absolute on mel / linear (values of order 1), 1e-6 on the alignments: float32 chain vs float64."""
     import torch_tacotron_ref as R
+    simple = n_speakers == "simple"                                      # two speakers, hparams.model_type 'simple' (tacotron.py:85-90)
+    n_speakers = 2 if simple else n_speakers
     tables = n_speakers < 0                                              # -2: two speakers, speaker_embedding_size == 1 (tacotron.py:69-75 get_embed tables)
     n_speakers = abs(n_speakers)
-    d = oracle.taco_dims(max_iters=25, n_speakers=n_speakers, spk_emb=1 if tables else 16)
+    d = oracle.taco_dims(max_iters=25, n_speakers=n_speakers, spk_emb=1 if tables else 16, model_simple=simple)
     w = oracle.taco_random_tensors(d, seed=3)
+    if simple:
+        assert w["speaker_embedding"].shape == (2, 16) and "dense_1/kernel" not in w and w["dense/kernel"].shape == (2 * d.post_rnn, d.num_freq)
+        assert w["decoder/attention_wrapper/gru_cell/gates/kernel"].shape == (128 + 16 + 256 + 256, 512)
+        assert w["decoder/output_projection_wrapper/multi_rnn_cell/cell_0/output_projection_wrapper/kernel"].shape == (256 + 256 + 16, 256)
     if tables:
         assert "speaker_embedding" not in w and w["before_highway"].shape == (2, 128) and w["decoder_rnn_init_states2"].shape == (2, 256)
         assert w["dense/kernel"].shape == (2 * d.post_rnn, d.num_freq) and "dense_1/kernel" not in w

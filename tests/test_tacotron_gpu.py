@@ -319,6 +319,44 @@ def test_speaker_embedding_size_one_uses_embedding_tables(torch_cuda, oracle):
     assert first_mismatch(mel2.cpu().numpy()[0], mel_o[0]) is not None and first_mismatch(mel2.cpu().numpy()[1:], mel_o[1:]) is None
 
 
+@pytest.mark.parametrize("N,groups", [(3, 0), (5, 4), (32, 8)])
+def test_model_type_simple_concatenates_the_speaker_embedding_inside_the_decoder(torch_cuda, oracle, N, groups):
+    """tacotron.py:85-90 (hparams.model_type 'simple'): no speaker-dependent initial states; the speaker embedding is concatenated to the
+    decoder prenet's output (rnn_wrappers.py:425-432: attention-cell input [prenet | embed | context]) and to [output, attention] in
+    front of the first projection (:455-463).  Bit for bit against the checker (which its float64 torch second opinion follows to 1e-5,
+    tests/test_cpu.py), ragged lengths, several split-decoder geometries incl. the bench batch."""
+    hp = _hp(max_iters=5, enc_bank_size=3, post_bank_size=2, num_freq=65, model_type="simple")
+    from twvk_amd.tacotron import Tacotron
+    T = 41
+    rng = np.random.RandomState(50 + N)
+    lengths = [T] + [int(x) for x in rng.randint(2, T + 1, N - 1)]
+    d = oracle.taco_dims(enc_bank=3, post_bank=2, max_iters=5, num_freq=65, n_speakers=4, model_simple=True)
+    tensors = oracle.taco_random_tensors(d, seed=51)
+    blob = oracle.taco_blob(d, tensors)
+    tok = rng.randint(2, 80, (N, T)).astype(np.int32)
+    for n, ln in enumerate(lengths):
+        tok[n, ln - 1] = 1
+        tok[n, ln:] = 0
+    ln_ = np.asarray(lengths, np.int32)
+    spk = (np.arange(N) % 4).astype(np.int32)
+    m = Tacotron(hp, num_speakers=4)
+    assert [n for n, _ in m.specs] == [n for n, _ in oracle.taco_tensor_specs(d)]
+    assert dict(m.specs)["decoder/attention_wrapper/gru_cell/gates/kernel"] == (128 + 16 + 256 + 256, 512)
+    m.load_weights(tensors)
+    m.set_option("decoder_groups", groups)
+    mel_o, lin_o, al_o = oracle.taco_infer(d, blob, tok, ln_, spk)
+    for _ in range(2):
+        mel, lin, al = m.infer(tok, ln_, spk)
+        assert first_mismatch(al.cpu().numpy(), al_o) is None, ("alignments", first_mismatch(al.cpu().numpy(), al_o))
+        assert first_mismatch(mel.cpu().numpy(), mel_o) is None, ("mel", first_mismatch(mel.cpu().numpy(), mel_o))
+        assert first_mismatch(lin.cpu().numpy(), lin_o) is None
+    if N == 3:
+        from twvk_amd._lib import TwvError
+        m.set_option("decoder_groups", 32)
+        with pytest.raises(TwvError, match="split decoder"):
+            m.infer(tok, ln_, spk)
+
+
 @pytest.mark.parametrize("layers,r,N", [(2, 3, 5), (1, 2, 26), (2, 5, 17)])
 def test_resident_decoder_other_sizes(torch_cuda, oracle, layers, r, N):
     """tc_decoder_x_kernel outside the folded hparams-default instantiation: other decoder depths / reduction factors (run-time sizes), one

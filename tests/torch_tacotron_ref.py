@@ -164,7 +164,13 @@ def infer(w, dims, tokens, lengths, speaker_ids):
     x = table[torch.as_tensor(tokens, dtype=torch.long)]
     before_highway = enc_init = att_init = None
     dec_init = [None] * dims.dec_layers
-    if multi and "speaker_embedding" not in w:
+    embed_to_concat = None
+    if multi and getattr(dims, "model_simple", 0) and "speaker_embedding" in w and "dense_1/kernel" not in w:
+        # tacotron.py:85-90 model_type 'simple': before_highway and every initial state None; the speaker embedding itself goes into
+        # DecoderPrenetWrapper (rnn_wrappers.py:425-432) and ConcatOutputAndAttentionWrapper (:455-463) as embed_to_concat
+        embed_to_concat = w["speaker_embedding"][torch.as_tensor(np.asarray(speaker_ids), dtype=torch.long)]
+        linear_name = "dense"
+    elif multi and "speaker_embedding" not in w:
         # tacotron.py:69-75, speaker_embedding_size == 1: modules.py:10-12 get_embed -- five tables of their own, embedding_lookup by speaker id
         ids = torch.as_tensor(np.asarray(speaker_ids), dtype=torch.long)
         before_highway = w["before_highway"][ids]
@@ -211,6 +217,8 @@ def infer(w, dims, tokens, lengths, speaker_ids):
         # DecoderPrenetWrapper -> AttentionWrapper (rnn_wrappers.py:282-398)
         p = _dense(frame, w, "decoder/decoder_prenet/dense_1", torch.relu)
         p = _dense(p, w, "decoder/decoder_prenet/dense_2", torch.relu)
+        if embed_to_concat is not None:
+            p = torch.cat([p, embed_to_concat], dim=-1)              # rnn_wrappers.py:429-430 concat([prenet_out, embed_to_concat])
         att_h = _gru_cell(torch.cat([p, context], dim=-1), att_h, w, "decoder/attention_wrapper/gru_cell")
         q = att_h @ wq
         score = (normed_v * torch.tanh(keys + q[:, None, :] + bvec)).sum(dim=2) + score_bias
@@ -219,7 +227,8 @@ def infer(w, dims, tokens, lengths, speaker_ids):
         context = (align[:, None, :] @ values)[:, 0]
         align_hist.append(align)
         # ConcatOutputAndAttentionWrapper -> OutputProjectionWrapper(dec_rnn) -> ResidualWrapper(GRUCell) x dec_layers
-        y = _dense(torch.cat([att_h, context], dim=-1), w, gp + "cell_0/output_projection_wrapper")
+        cat_out = [att_h, context] if embed_to_concat is None else [att_h, context, embed_to_concat]      # rnn_wrappers.py:458-462
+        y = _dense(torch.cat(cat_out, dim=-1), w, gp + "cell_0/output_projection_wrapper")
         for i in range(dims.dec_layers):
             if dec_h[i] is None:
                 dec_h[i] = torch.zeros(N, y.shape[1], dtype=F64)
