@@ -698,7 +698,7 @@ def main():
                     torch.cuda.synchronize()
                     bdt = (time.perf_counter() - c0) / 2
                     bsweep.append({"batch": TB, "ms_per_pass": bdt * 1e3, "mel_frames_per_s": TB * hp.max_iters * hp.reduction_factor / bdt,
-                                   "decoder_kernel": "tc_decoder_x_kernel (XCD-resident)" if TB <= 16 else "tc_decoder_g_kernel (split)"})
+                                   "decoder_kernel": "tc_decoder_x_kernel (XCD-resident)" if TB <= 24 else "tc_decoder_g_kernel (split)"})
                 res["tacotron"] = {"metric": "Tacotron mel frames/sec", "value": TN * hp.max_iters * hp.reduction_factor / qdt,
                                    "unit": "mel frames/s", "ms_per_pass": qdt * 1e3, "dtype": "f32", "batch_sweep": bsweep,
                                    # the DOMINANT kernel's ruler first: the decoder is 64 % of the pass and a latency chain
@@ -722,7 +722,7 @@ def main():
                                                         "32 workgroups per XCD serving its utterances, tasks on v_mfma_f32_4x4x1 -- and measured it (`resident_decoder`): the fabric reads go "
                                                         "away and the step does not get shorter at four utterances per XCD; the exchanges bound both kernels, not the weight stream",
                                                 "resident_decoder": {"kernel": "tc_decoder_x_kernel",
-                                                                     "default_up_to_batch": 16,
+                                                                     "default_up_to_batch": 24,
                                                                      "traffic_at_batch_32": (tacotron_decoder_traffic("B32_T101_resident") or {}).get("bytes_per_pass"),
                                                                      "traffic_at_batch_16": (tacotron_decoder_traffic("B16_T101") or {}).get("bytes_per_pass"),
                                                                      "evidence": "profiles/r06_rocprofv3_tacotron_traffic.txt, profiles/r06_tacotron_xdec_phase_profile.txt, batch_sweep of this line"},

@@ -2724,10 +2724,11 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
         const bool xok = taco_xdec_ok(h, xt) && cus >= 256 && upx <= kXU && T <= 512 && xfl * 4 <= 160 * 1024 && !simple;
         if (simple && (h->dec_groups == -1 || h->dec_groups == 32))
             return twv_fail(TWV_E_UNSUPPORTED, "model_type 'simple' runs on the split decoder kernel only (decoder_groups 0, 1, 2, 4, 8 or 16)");
-        // Which kernel (round 6, scripts/tacotron_bench.py --batch 8 / 16 / 32): the XCD-resident kernel runs a pass in 6.7 / 7.4 / 9.2 ms, the
-        // split kernel in 7.6 / 8.0 / 8.8 -- with one or two utterances per XCD the resident kernel's exchanges (32 workgroups, every weight
-        // in registers, no tile stream in front of the polls) are the shorter ones, with four the split kernel's 8-workgroup groups are.
-        if (xok && (h->dec_groups == 32 || (h->dec_groups == 0 && N <= 16))) {
+        // Which kernel (round 6, scripts/tacotron_bench.py --batch 8 / 16 / 24 / 28 / 32): the XCD-resident kernel runs a pass in 6.3 / 7.0 / 8.1 /
+        // 8.8 / 8.9 ms, the split kernel in 7.6 / 8.0 / 8.5 / 8.7 / 8.8 -- with up to three utterances per XCD the resident kernel's exchanges (32
+        // workgroups, every weight in registers, no tile stream in front of the polls) are the shorter ones, with four the split kernel's
+        // 8-workgroup groups are.
+        if (xok && (h->dec_groups == 32 || (h->dec_groups == 0 && N <= 24))) {
             // XCD-local kernel: every XCD's 32 workgroups hold the decoder in registers and serve that XCD's utterances
             DecXArgs xa;
             xa.d = da; xa.tab = xt; xa.upx = upx; xa.xt_off = h->xt_off; xa.stab = reinterpret_cast<int*>(stabf);
