@@ -358,9 +358,9 @@ def main():
                                       "hbm": None if ttraf_ is None else {"bytes_per_step": ttraf_, "achieved": ttraf_ / qdt / 1e9, "peak": 8000.0, "unit": "GB/s",
                                                                            "frac": ttraf_ / qdt / 1e9 / 8000.0,
                                                                            "note": "the step's second ruler: the fused layer kernels (37 % of it) run at 3.8-4.1 TB/s, the elementwise "
-                                                                                   "passes at 5-6 TB/s; profiles/r05_train_traffic_v2.txt"},
+                                                                                   "passes at 5-6 TB/s; profiles/r06_train_traffic.txt"},
                                       "note": "executed f32 matrix-core FLOPs only (2 x 3 x forward MACs of the dense contractions; per-kernel durations and "
-                                              "SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F32 counters: profiles/r05_rocprofv3_mfma_summary_tacotron_train_v4.txt, r05_rocprofv3_kernel_stats_train_c4_v3.csv)"},
+                                              "SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F32 counters: profiles/r06_rocprofv3_mfma_summary_tacotron_train.txt, r06_rocprofv3_kernel_stats_train_c4.csv)"},
                          "value": world * 64 * TT_ / qdt, "unit": "audio samples/s", "steps_per_s": 1.0 / qdt, "ms_per_step": qdt * 1e3,
                          "n_gpus": world, "scaling": "weak", "dtype": "f32",
                          "collective": train_collective(world, trn.n_params),
@@ -384,8 +384,11 @@ def main():
         us_step = k_ms * 1e3 / T
         # what binds this kernel is the sample-to-sample dependency chain, not HBM: the floor of that chain from the micro-benchmarks
         # (scripts/ubench/chain_contract_ubench.hip -> profiles/r05_chain_contract_ubench.txt: contract C7 (the product's since round 5), shape R =
-        # 417 core clocks = 0.174 us per layer; hand-offs / post phase: scripts/xcd_phase_profile.py -> profiles/r05_xcd_phase_profile_v2.txt)
-        LAYER_US, HANDOFF_US, CAUSAL_US, POST_US = 0.174, 0.075, 0.15, 3 * 0.26 + 1.08
+        # 417 core clocks = 0.174 us per layer; hand-offs / post phase: scripts/xcd_phase_profile.py -> profiles/r06_xcd_phase_profile.txt).
+        # Round 6 (KF = 1): the last layer's z goes straight to the conv1 workgroups, so the three-hop post path starts at the SECOND-TO-LAST
+        # layer and runs next to the last layer: one layer time comes off the post phase's floor
+        LAYER_US, HANDOFF_US, CAUSAL_US = 0.174, 0.075, 0.15
+        POST_US = 3 * 0.26 + 1.08 - LAYER_US
         floor_us = NL * LAYER_US + 8 * HANDOFF_US + CAUSAL_US + POST_US
         # BASELINE.json north_star: >= 100x real time at batch 8 = 2.4 M samples/s = one generation step every 3.33 us.  Round 5 priced the
         # alternatives (profiles/r05_chain_contract_ubench.txt) and ADOPTED the cheapest one (C7 = AC-1b / AC-2 of DESIGN.md section 2: 562 ->
@@ -393,7 +396,7 @@ def main():
         # chain wave is ISSUE-bound (a layer is ~100 instructions at ~4.5 core clocks each on a lone wave; 48 of them are the fmas of the two
         # dot products, which no arithmetic contract removes), and 30 layers x 0.174 us (the arithmetic alone, registers only) is 5.2 us.
         target_us = 1e6 / (100.0 * hp.sample_rate / B)
-        floor_r04_contract_us = NL * 0.192 + 8 * HANDOFF_US + CAUSAL_US + POST_US
+        floor_r04_contract_us = NL * 0.192 + 8 * HANDOFF_US + CAUSAL_US + POST_US + LAYER_US
         macs_stream = NL * (2 * 32 * 64 + 32 * 32 + 32 * 512 + 80 * 64) + 32 * 32 + 512 * 512 + 512 * 30   # executed per stream and step (gc hoisted)
         flop_step = 2.0 * macs_stream * B
         tps = traffic_per_step(kernel, "B%d_NL%d" % (B, NL))
@@ -430,8 +433,9 @@ def main():
                          "latency_floor_us": floor_us, "frac_of_floor": floor_us / us_step,
                          "latency_floor_formula": "%d layers x 0.174 us (a layer's arithmetic alone on a lone wave, registers only: 32+16 fmas started from the "
                                                   "addends, Estrin rational with a software reciprocal; 417 core clocks) + 8 wave hand-offs x 0.075 + causal layer 0.15 + "
-                                                  "post phase (3 L2 hops x 0.26 + skip 0.22 + chunk dots 0.28 + ordered sum/conv1d_2 0.27 + sampler 0.31); "
-                                                  "measured pieces, profiles/r05_chain_contract_ubench.txt and profiles/r05_xcd_phase_profile_v2.txt" % NL,
+                                                  "post phase (3 L2 hops x 0.26 + skip 0.22 + chunk dots 0.28 + ordered sum/conv1d_2 0.27 + sampler 0.31 - one layer time: since round 6 "
+                                                  "the last layer's skip 1x1 runs in the conv1 workgroups and the three-hop path starts behind the second-to-last layer); "
+                                                  "measured pieces, profiles/r05_chain_contract_ubench.txt and profiles/r06_xcd_phase_profile.txt" % NL,
                          "fp32_flop_per_step": flop_step, "fp32_tflops": flop_step / (us_step * 1e-6) / 1e12,
                          "fp32_frac": flop_step / (us_step * 1e-6) / 1e12 / 157.3,
                          "note": "weights are register-/L2-resident: the sample loop is a dependent chain (latency), not a bandwidth stream; "
@@ -524,7 +528,7 @@ def main():
                 # causal kernel (2 x 256 x 32), conv1d_1, the 512 x 256 conv1d_2; I/O per stream: 80 lc floats, class in, class out, one f64 draw
                 q_wfloats = NL * per_layer + (512 * 512 + 512) + (512 * 256 + 256) + 2 * 256 * 32
                 q_bytes = q_wfloats * 4 + B * (80 * 4 + 4 + 4 + 8)
-                q_floor = NL * 0.174 + 8 * 0.075 + 0.18 + (4 * 0.26 + 0.22 + 0.28 + 0.12 + 0.17 + 0.12 + 1.55)
+                q_floor = NL * 0.174 + 8 * 0.075 + 0.18 + (4 * 0.26 + 0.22 + 0.28 + 0.12 + 0.17 + 0.12 + 1.55) - 0.174   # (- one layer time: KF = 1, see the headline's floor)
                 q_tps = traffic_per_step("wn_xcd_generate_kernel_onehot", "B%d_NL%d" % (B, NL)) if qfused else None
                 q_match = None
                 if not args.no_cpu_baseline:
@@ -548,8 +552,8 @@ def main():
                                                  "kernel_ms": qms, "latency_floor_us": q_floor, "frac_of_floor": q_floor / q_us,
                                                  "latency_floor_formula": "%d layers x 0.174 us + 8 wave hand-offs x 0.075 + causal row load 0.18 + post phase: 4 L2 hops x 0.26 "
                                                                           "(z, h1, h2, logits) + skip 0.22 + conv1d_1 chunk dots 0.28 + ordered sum 0.12 + conv1d_2 chunk dot 0.17 + "
-                                                                          "ordered sum 0.12 + sampler 1.55 (its ~850 VALU instructions at 4 cycles each, one wave, 2.2 GHz; measured 3.18); "
-                                                                          "pieces: profiles/r05_chain_contract_ubench.txt, profiles/r05_xcd_onehot_phase_profile_v1.txt" % NL,
+                                                                          "ordered sum 0.12 + sampler 1.55 (its ~850 VALU instructions at 4 cycles each, one wave, 2.2 GHz; measured 3.18) - one layer time (round 6: the last layer's skip 1x1 in the conv1 workgroups); "
+                                                                          "pieces: profiles/r05_chain_contract_ubench.txt, profiles/r06_xcd_onehot_phase_profile.txt" % NL,
                                                  "note": "as for the headline kernel: weights are register-resident, the step is a dependent chain (latency), "
                                                          "algorithmic bytes assume every weight re-read per step (SURVEY.md 8d)"},
                                     "config": {"workload": "configs[1]'s stack with one-hot mu-law-256 input and a 256-way softmax output (model.py:223-227,243; "
@@ -669,7 +673,7 @@ def main():
                 tm.set_option("gemm_timing", 0)
                 # the decoder (tc_decoder_g_kernel: one persistent launch, 200 steps): per-step time = (200-step pass - 1-step pass) / 199,
                 # both without the post-net; its ruler is a latency floor, from the stamped anatomy of the same kernel
-                # (scripts/tacotron_phase_profile.py -> profiles/r05_tacotron_decoder_phase_profile.txt)
+                # (scripts/tacotron_phase_profile.py -> profiles/r06_tacotron_decoder_phase_profile.txt)
                 import copy
                 hp1 = copy.copy(hp); hp1.max_iters = 1
                 tm1 = Tacotron(hp1, num_speakers=2, device=dev)
@@ -716,7 +720,7 @@ def main():
                                                            "attention compute 2.66 (score dots 1.02, monotonic recurrence 0.94, context dots 0.59, the rest 0.11) = %.2f us that is "
                                                            "not exchange, + %d exchanges x %.2f us (one-way granule hop inside an XCD's L2 measured in isolation; in the kernel an "
                                                            "exchange averages 0.64 us incl. the cell update done on arrival: the polls queue behind the next stage's weight tiles); "
-                                                           "profiles/r05_tacotron_decoder_phase_profile.txt" % (DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US),
+                                                           "profiles/r06_tacotron_decoder_phase_profile.txt" % (DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US),
                                                 "note": "what binds this kernel is its latency chain (latency_floor_us / frac_of_floor), not bandwidth.  traffic = fabric bytes of the decoder kernel per pass (counters): the split kernel re-streams the 6.4 MB of decoder weights through every "
                                                         "XCD's 4 MiB L2 once per step.  Round 6 built the alternative -- tc_decoder_x_kernel: every weight in registers for the whole launch, "
                                                         "32 workgroups per XCD serving its utterances, tasks on v_mfma_f32_4x4x1 -- and measured it (`resident_decoder`): the fabric reads go "
