@@ -1758,6 +1758,23 @@ __host__ __device__ inline XCarve xdec_carve(int M, int D1, int ENC, int AS, int
     return c;
 }
 
+// chunk values 1 .. NCH-1 of one output added to v in chunk order (AC-1), the depth a compile-time constant: no selects between the
+// dependent adds (the run-time form below spends an add AND a select per chunk on the wave every other wave of the stage waits for)
+template <int NCH>
+__device__ __forceinline__ float xdec_chunk_sum(const int b, float v)
+{
+#pragma unroll
+    for (int c0_ = 1; c0_ < NCH; c0_ += 12) {
+        float c[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) if (c0_ + i < NCH) c[i] = lds[b + (c0_ + i) * 16];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) if (c0_ + i < NCH) v = v + c[i];
+    }
+    return v;
+}
+
 // Round 6: the kernel's exchanges and attention block rebuilt with what rounds 4-5 learnt on the split kernel:
 //   * a granule exchange is laid out [element][utterance]: the gathering thread fetches the four utterances' values of ITS element with
 //     two 16-byte loads (four self-tagged 8-byte halves) -- one polling round trip; round 2 polled the utterances one after the other in
@@ -1868,7 +1885,7 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
     // `owner`: this workgroup published a share of the exchange a moment ago (nothing can arrive before the L2 hop has passed); a
     // workgroup without columns in the stage arrives a whole dots + chunk-sum phase early and would only load the L2 slices the
     // publishers' stores have to pass: it sleeps through most of that phase first.
-    auto gather = [&](int cnt, int kind, int dst, int g0, int g1, int g2, bool owner) {
+    auto gather = [&](int tid, int cnt, int kind, int dst, int g0, int g1, int g2, bool owner) {
         const bool need = tid < cnt;
         const int off = need ? (int)(((ep & 1u) * (kXU * 512) + (unsigned)tid * kXU) * 8u) : (int)0x7ffffff0;   // (out of range: zeros)
         u32x4d qa = {0u, 0u, 0u, 0u}, qb = {0u, 0u, 0u, 0u};
@@ -1925,8 +1942,15 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
         __builtin_amdgcn_raw_buffer_store_b64(u32x2d{__float_as_uint(v), ep}, rs, (int)(((ep & 1u) * (kXU * 512) + (unsigned)i * kXU + (unsigned)u) * 8u), 0, 0);
     };
 
+    const int tid_k = tid;
     for (it = 0; it < a.iters && ok; ++it) {
         for (st = 0; st < nst && ok; ++st) {
+            // the thread's index as a value the compiler cannot see through, once per stage: everything derived from it (LDS addresses, task
+            // decompositions) is recomputed where it is used -- hoisted out of the step loop these values outnumber the registers the tiles
+            // leave, and came back from scratch memory (an L2 trip each, 27 of them) in the middle of the stages
+            int tid = tid_k;
+            asm volatile("" : "+v"(tid));
+            const int lane = tid & 63;
             XSTAMPT(0)
             const i32x16s rec = decg_sload16(stab + st * XS_STRIDE);
             const int K = rec[XS_K], N = rec[XS_N], act = rec[XS_ACT], post = rec[XS_POST], xo = rec[XS_XO], has_b = rec[XS_HASB];
@@ -1983,7 +2007,13 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                 if (u < nu && col < N) {
                     const int b = o_part + u * 24 * 16 + n;
                     float v = lds[b];
-                    // twelve chunk values requested at a time (the rows exist for 24 chunks whatever the stage's depth), adds in chunk order
+                    // the depths of the hparams-default stages as straight lines; any other depth: twelve chunk values requested at a time (the
+                    // rows exist for 24 chunks whatever the stage's depth), adds in chunk order
+                    if (nchunk == 20) v = xdec_chunk_sum<20>(b, v);
+                    else if (nchunk == 16) v = xdec_chunk_sum<16>(b, v);
+                    else if (nchunk == 8) v = xdec_chunk_sum<8>(b, v);
+                    else if (nchunk == 3) v = xdec_chunk_sum<3>(b, v);
+                    else
                     for (int c0_ = 1; c0_ < nchunk; c0_ += 12) {
                         float c[12];
 #pragma unroll
@@ -2001,7 +2031,7 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                 }
             }
             XSTAMPT(3)
-            gather(N, rec[XS_KIND], rec[XS_GDST], rec[XS_G0], rec[XS_G1], rec[XS_G2], mine);
+            gather(tid, N, rec[XS_KIND], rec[XS_GDST], rec[XS_G0], rec[XS_G1], rec[XS_G2], mine);
             XSTAMPT(4)
             lds_barrier();
             XSTAMPT(5)
@@ -2042,7 +2072,7 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                     publish(u, t, t < lu ? sigmoid_e(sc) : 0.0f);         // _maybe_mask_score(-inf) -> p = 0
                 }
                 XSTAMPT(7)
-                gather(T, XG_P, 0, 0, 0, 0, true);
+                gather(tid, T, XG_P, 0, 0, 0, 0, true);
                 lds_barrier();
                 XSTAMPT(8)
                 ok = LDSI(o_abort) == 0;
@@ -2142,8 +2172,19 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                         const int cl = tc % ncol, uc = tc / ncol, ch = uc % nch_t, u = uc / nch_t;
                         const int ta = ch * 32, tbb = T < ta + 32 ? T : ta + 32;
                         const int mo = o_memo + u * mpitch + 16 * ch + cl, al = u * UST + u_al;
+                        // eight fmas in a straight line, every operand requested first; a term past the end of the input is 0 x 0 added to a chain
+                        // that is never -0 (it starts at +0, and x + (-x) = +0): fma(0, 0, sk) == sk exactly
+                        float mv[8], av[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int t = ta + k + 4 * i;
+                            const bool in = live && t < tbb;
+                            mv[i] = in ? lds[mo + t * ncol] : 0.0f;
+                            av[i] = in ? lds[al + t] : 0.0f;
+                        }
                         float sk = 0.f;
-                        if (live) for (int t = ta + k; t < tbb; t += 4) sk = fma_(lds[mo + t * ncol], lds[al + t], sk);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) sk = fma_(mv[i], av[i], sk);
                         const float s1 = __shfl_xor(sk, 1);
                         const float pr = (k & 1) ? s1 + sk : sk + s1;       // lanes k = 0,1 hold s0+s1 ; k = 2,3 hold s2+s3 (operand order as written)
                         const float p2 = __shfl_xor(pr, 2);
@@ -2158,7 +2199,7 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                         publish(u, c0 + cl, v);
                     }
                     XSTAMPT(10)
-                    gather(ENC, XG_CTX, 0, 0, 0, 0, true);
+                    gather(tid, ENC, XG_CTX, 0, 0, 0, 0, true);
                     lds_barrier();
                     ok = LDSI(o_abort) == 0;
                     if (!ok) break;
