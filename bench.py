@@ -86,8 +86,8 @@ def tacotron_traffic():
 
 
 def tacotron_decoder_traffic(key="B32_T101"):
-    """fabric bytes of the decoder kernel of one pass (the same committed PMC passes; `key`: B32_T101 = the split decoder at the bench
-    batch, B32_T101_resident = the XCD-resident decoder forced there, B16_T101 = batch 16 where the resident one is the default)"""
+    """fabric bytes of the decoder kernel of one pass (the same committed PMC passes; `key`: B32_T101 = the default (XCD-resident) decoder at
+    the bench batch, B32_T101_split = the split decoder forced there (decoder_groups = 8), B16_T101 = batch 16)"""
     try:
         import twvk_amd
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
@@ -671,9 +671,9 @@ def main():
                 tm.infer(tok, tln, tsp); torch.cuda.synchronize()
                 gflop, gms, gn = tm.gemm_stats()
                 tm.set_option("gemm_timing", 0)
-                # the decoder (tc_decoder_g_kernel: one persistent launch, 200 steps): per-step time = (200-step pass - 1-step pass) / 199,
+                # the decoder (tc_decoder_x_kernel: one persistent launch, 200 steps): per-step time = (200-step pass - 1-step pass) / 199,
                 # both without the post-net; its ruler is a latency floor, from the stamped anatomy of the same kernel
-                # (scripts/tacotron_phase_profile.py -> profiles/r06_tacotron_decoder_phase_profile.txt)
+                # (scripts/tacotron_xdec_profile.py -> profiles/r06_tacotron_xdec_phase_profile.txt)
                 import copy
                 hp1 = copy.copy(hp); hp1.max_iters = 1
                 tm1 = Tacotron(hp1, num_speakers=2, device=dev)
@@ -686,7 +686,7 @@ def main():
                     return (time.perf_counter() - c0) / reps
                 dec_us = (_mel_only(tm) - _mel_only(tm1)) * 1e6 / (hp.max_iters - 1)
                 # pieces of one step (us, workgroup 0 of utterance 0, 160 steps averaged): everything that is not an exchange, and the hop
-                DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US = 20.52, 13, 0.27
+                DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US = 18.48, 13, 0.27
                 dec_floor = DEC_NONEXCH_US + DEC_EXCHANGES * DEC_HOP_US
                 dec_alg_bytes = hp.max_iters * 1.63e6 * 4 + TN * (2 * TT * 256 * 4 + hp.max_iters * hp.reduction_factor * hp.num_mels * 4)
                 del tm1
@@ -702,34 +702,33 @@ def main():
                     torch.cuda.synchronize()
                     bdt = (time.perf_counter() - c0) / 2
                     bsweep.append({"batch": TB, "ms_per_pass": bdt * 1e3, "mel_frames_per_s": TB * hp.max_iters * hp.reduction_factor / bdt,
-                                   "decoder_kernel": "tc_decoder_x_kernel (XCD-resident)" if TB <= 24 else "tc_decoder_g_kernel (split)"})
+                                   "decoder_kernel": "tc_decoder_x_kernel (XCD-resident)" if TB <= 32 else "tc_decoder_g_kernel (split)"})
                 res["tacotron"] = {"metric": "Tacotron mel frames/sec", "value": TN * hp.max_iters * hp.reduction_factor / qdt,
                                    "unit": "mel frames/s", "ms_per_pass": qdt * 1e3, "dtype": "f32", "batch_sweep": bsweep,
                                    # the DOMINANT kernel's ruler first: the decoder is 64 % of the pass and a latency chain
-                                   "roofline": {"bound": "hbm", "kernel": "tc_decoder_g_kernel (8 workgroups per utterance on one XCD, 11 matvec stages + attention, 13 all-gathers "
-                                                                         "per step through that XCD's L2)",
-                                                # HBM convention as for the headline: algorithmic bytes = the decoder's weights once per step (every utterance of the pass
-                                                # shares them) + keys / memory in + mel out, over the decoder kernel's time; `traffic` = what the counters saw
+                                   "roofline": {"bound": "hbm", "kernel": "tc_decoder_x_kernel (XCD-resident: 32 workgroups per XCD hold 16 columns of every decoder matrix in registers "
+                                                                         "for the whole launch and serve that XCD's four utterances; 11 matvec stages on v_mfma_f32_4x4x1 + attention, "
+                                                                         "13 all-gathers per step through that XCD's L2)",
+                                                # HBM convention as for the headline: algorithmic bytes = the decoder's weights once per pass per XCD-resident copy would be
+                                                # 8 x 6.5 MB; kept as in round 5 (weights once per step + keys / memory in + mel out) so the figure stays comparable;
+                                                # `traffic` = what the counters saw
                                                 "achieved": dec_alg_bytes / (dec_us * hp.max_iters * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                                 "frac": dec_alg_bytes / (dec_us * hp.max_iters * 1e-6) / 1e9 / 8000.0,
                                                 "traffic": (tacotron_decoder_traffic("B32_T101") or {}).get("bytes_per_pass"),
                                                 "algorithmic_bytes_per_pass": dec_alg_bytes,
                                                 "us_per_step": dec_us, "ms_per_pass": dec_us * hp.max_iters * 1e-3, "latency_floor_us": dec_floor, "frac_of_floor": dec_floor / dec_us,
-                                                "formula": "per step: tile dots 5.52 + chunk sums / bias / activation / publish 10.35 (of which ~0.4 per stage is the publish store waiting "
-                                                           "behind the next stage's first weight tiles in the CU's memory pipeline) + barriers and cell updates 2.00 + "
-                                                           "attention compute 2.66 (score dots 1.02, monotonic recurrence 0.94, context dots 0.59, the rest 0.11) = %.2f us that is "
-                                                           "not exchange, + %d exchanges x %.2f us (one-way granule hop inside an XCD's L2 measured in isolation; in the kernel an "
-                                                           "exchange averages 0.64 us incl. the cell update done on arrival: the polls queue behind the next stage's weight tiles); "
-                                                           "profiles/r06_tacotron_decoder_phase_profile.txt" % (DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US),
-                                                "note": "what binds this kernel is its latency chain (latency_floor_us / frac_of_floor), not bandwidth.  traffic = fabric bytes of the decoder kernel per pass (counters): the split kernel re-streams the 6.4 MB of decoder weights through every "
-                                                        "XCD's 4 MiB L2 once per step.  Round 6 built the alternative -- tc_decoder_x_kernel: every weight in registers for the whole launch, "
-                                                        "32 workgroups per XCD serving its utterances, tasks on v_mfma_f32_4x4x1 -- and measured it (`resident_decoder`): the fabric reads go "
-                                                        "away and the step does not get shorter at four utterances per XCD; the exchanges bound both kernels, not the weight stream",
-                                                "resident_decoder": {"kernel": "tc_decoder_x_kernel",
-                                                                     "default_up_to_batch": 24,
-                                                                     "traffic_at_batch_32": (tacotron_decoder_traffic("B32_T101_resident") or {}).get("bytes_per_pass"),
-                                                                     "traffic_at_batch_16": (tacotron_decoder_traffic("B16_T101") or {}).get("bytes_per_pass"),
-                                                                     "evidence": "profiles/r06_rocprofv3_tacotron_traffic.txt, profiles/r06_tacotron_xdec_phase_profile.txt, batch_sweep of this line"},
+                                                "formula": "per step (slice 0 of XCD 0, stamped): %.2f us outside the exchanges (tasks on the matrix core ~0.5 per stage, chunk sums / bias / "
+                                                           "activation / publish ~0.3, cell updates 0.2-0.55, barriers; attention: scores 0.8, sum 0.5, monotonic recurrence 1.2, context 0.9) "
+                                                           "+ %d exchanges x %.2f us (one-way granule hop inside an XCD's L2 measured in isolation; in the kernel an exchange averages "
+                                                           "0.57 us from the publish to the last poll); profiles/r06_tacotron_xdec_phase_profile.txt" % (DEC_NONEXCH_US, DEC_EXCHANGES, DEC_HOP_US),
+                                                "note": "what binds this kernel is its latency chain (latency_floor_us / frac_of_floor), not bandwidth: traffic = fabric bytes of the decoder kernel per pass (counters) "
+                                                        "-- the weights cross the fabric once per launch.  The split kernel it replaced as the default at this batch (`split_decoder`: 8 workgroups per "
+                                                        "utterance, the 6.4 MB of decoder weights re-streamed through every XCD's L2 once per step) is still what runs above batch 32 and for "
+                                                        "model_type 'simple'",
+                                                "split_decoder": {"kernel": "tc_decoder_g_kernel", "selected_by": "decoder_groups = 1 / 2 / 4 / 8 / 16, batch > 32, t_in > 512, non-default widths not divisible by 4, model_type 'simple'",
+                                                                  "traffic_at_batch_32": (tacotron_decoder_traffic("B32_T101_split") or {}).get("bytes_per_pass"),
+                                                                  "evidence": "profiles/r06_rocprofv3_tacotron_traffic.txt, profiles/r06_tacotron_decoder_ab.txt (pass times of both kernels at batch 8 / 16 / 24 / 32), "
+                                                                              "profiles/r06_tacotron_decoder_phase_profile.txt"},
                                                 "gemm": {"bound": "mfma", "kernel": "tc_gemm_mfma_{,group_,highway_,ck_}kernel (%d launches per pass: CBHG conv banks as one grouped launch each, projections, "
                                                                                     "fused highway layers, grouped GRU input halves, attention keys, linear)" % gn,
                                                          "achieved": gflop / (gms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": gflop / (gms * 1e-3) / 1e12 / 157.3,

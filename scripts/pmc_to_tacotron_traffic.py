@@ -62,11 +62,11 @@ h = "tacotron:" + twvk_amd._lib.tacotron_hash()
 p = os.path.join(ROOT, "profiles", "traffic.json")
 t = json.load(open(p)) if os.path.exists(p) else {}
 all_lines = []
-# pmc_taco: the default kernels at B = 32 (the split decoder); pmc_tacox32: B = 32 on the XCD-resident decoder (decoder_groups = 32);
-# pmc_taco16: B = 16, the default there = the XCD-resident decoder
+# pmc_taco: the default kernels at B = 32 (the XCD-resident decoder); pmc_tacog32: B = 32 on the split decoder (decoder_groups = 8);
+# pmc_taco16: B = 16
 for prefix, key, title in (("pmc_taco", "B32_T101", "Tacotron configs[2] pass (B = 32, 101 tokens, 200 decoder steps)"),
-                           ("pmc_tacox32", "B32_T101_resident", "the same pass with the XCD-resident decoder forced (decoder_groups = 32)"),
-                           ("pmc_taco16", "B16_T101", "B = 16 (the XCD-resident decoder is the default up to batch 16)")):
+                           ("pmc_tacog32", "B32_T101_split", "the same pass with the split decoder forced (decoder_groups = 8: the default until round 6)"),
+                           ("pmc_taco16", "B16_T101", "B = 16")):
     agg = collect(prefix)
     if not agg:
         continue

@@ -24,7 +24,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 # round 6: the XCD-resident decoder (weights in registers for the whole launch): forced at the bench batch, and at batch 16 where it is the default
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_tacox32_$C -- python $REPO/scripts/tacotron_bench.py --steps 3 --decoder-groups 32 > $OUT/pmc_tacox32_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_tacog32_$C -- python $REPO/scripts/tacotron_bench.py --steps 3 --decoder-groups 8 > $OUT/pmc_tacog32_$C.log 2>&1
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_taco16_$C -- python $REPO/scripts/tacotron_bench.py --steps 3 --batch 16 > $OUT/pmc_taco16_$C.log 2>&1
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_tacotron16 -- python $REPO/scripts/tacotron_bench.py --steps 3 --batch 16 > $OUT/stats_tacotron16.log 2>&1

@@ -14,4 +14,4 @@ cp $P/stats_tacotron16/runc/*_kernel_stats.csv profiles/r06_rocprofv3_kernel_sta
 cp $P/stats_train/runc/*_kernel_stats.csv profiles/r06_rocprofv3_kernel_stats_train_c4.csv
 cp $P/stats_many/runc/*_kernel_stats.csv profiles/r06_rocprofv3_kernel_stats_many_b64_1s.csv
 cp $P/stats_mulaw/runc/*_kernel_stats.csv profiles/r06_rocprofv3_kernel_stats_mulaw_b8_12000.csv
-for f in xcd_phase_profile xcd_onehot_phase_profile tacotron_decoder_phase_profile tacotron_xdec_phase_profile; do grep -v amdgpu.ids gpurun_out/phase_$TAG/$f.txt > profiles/r06_$f.txt; done
+for f in xcd_phase_profile xcd_onehot_phase_profile tacotron_decoder_phase_profile tacotron_xdec_phase_profile tacotron_decoder_ab; do grep -v amdgpu.ids gpurun_out/phase_$TAG/$f.txt > profiles/r06_$f.txt; done

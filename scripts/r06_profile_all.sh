@@ -17,6 +17,8 @@ python scripts/xcd_phase_profile.py > gpurun_out/phase_$TAG/xcd_phase_profile.tx
 python scripts/xcd_phase_profile.py --onehot > gpurun_out/phase_$TAG/xcd_onehot_phase_profile.txt 2>&1
 python scripts/tacotron_phase_profile.py > gpurun_out/phase_$TAG/tacotron_decoder_phase_profile.txt 2>&1
 python scripts/tacotron_xdec_profile.py > gpurun_out/phase_$TAG/tacotron_xdec_phase_profile.txt 2>&1
+bash scripts/r06_decoder_ab.sh > /dev/null 2>&1
+cp gpurun_out/r06_decoder_ab/ab.txt gpurun_out/phase_$TAG/tacotron_decoder_ab.txt
 cp profiles/traffic.json gpurun_out/traffic.json
 # keep the merged-back volume small: the raw counter CSVs of the training / Tacotron MFMA passes are tens of MB
 find gpurun_out/prof_$TAG -name "*.db" -delete 2>/dev/null

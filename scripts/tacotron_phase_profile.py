@@ -17,6 +17,7 @@ exec(src[src.index("def random_tensors"):src.index("ap = argparse")], {"np": np}
 m.load_weights(ns["random_tensors"](m.specs))
 LOCAL = int(sys.argv[1]) if len(sys.argv) > 1 else -1       # optional argument: decoder_local 0 / 1
 if LOCAL >= 0: m.set_option("decoder_local", LOCAL)
+m.set_option("decoder_groups", 8)                            # the split kernel (round 6: the library's own choice at this batch is tc_decoder_x_kernel)
 rng = np.random.RandomState(1)
 N, T = 32, 101
 tok = rng.randint(2, 80, (N, T)).astype(np.int32); tok[:, -1] = 1
@@ -40,6 +41,7 @@ span_ticks = p[-1, 53] - p[0, 0]
 hp1 = twvk_amd.default_hparams(); hp1.max_iters = 1
 m1 = Tacotron(hp1, num_speakers=2); m1.load_weights(ns["random_tensors"](m1.specs))
 if LOCAL >= 0: m1.set_option("decoder_local", LOCAL)
+m1.set_option("decoder_groups", 8)
 m1.infer(tok, ln, spk, want_linear=False); torch.cuda.synchronize()
 e0.record(); m1.infer(tok, ln, spk, want_linear=False); e1.record(); torch.cuda.synchronize()
 front_ms = e0.elapsed_time(e1)

@@ -20,11 +20,12 @@ _lib.check(m._L.twv_tacotron_set_profile_buffer(m._h, C.c_void_p(prof.data_ptr()
 m.infer(tok, ln, spk, want_linear=False); torch.cuda.synchronize()
 p = prof.cpu().numpy().astype(np.int64)[:16 * 16].reshape(16, 16)
 names = ["prenet1", "prenet2", "aGRU gates", "aGRU cand", "query+attention", "proj", "rGRU0 gates", "rGRU0 cand", "rGRU1 gates", "rGRU1 cand", "out"]
-tot = 0
+tot = 0; exch = 0
 for st in range(11):
     r = p[st]; d = lambda a, b: (r[b] - r[a]) / 2.4e3
-    print("%-16s dots %.2f | barrier %.2f | combine+publish %.2f | gather(+update) %.2f | barrier %.2f | stage %.2f us" % (names[st], d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), d(0, 11)))
+    print("%-16s dots %.2f | barrier %.2f | combine+publish %.2f | gather %.2f + update %.2f | barrier %.2f | stage %.2f us" % (names[st], d(0, 1), d(1, 2), d(2, 3), d(3, 12), d(12, 4), d(4, 5), d(0, 11)))
     if st == 4:
         print("   attention: score %.2f | barrier+sum+publish %.2f | gather p %.2f | recurrence %.2f | context+publish %.2f | gather ctx %.2f" % (d(5, 6), d(6, 7), d(7, 8), d(8, 9), d(9, 10), d(10, 11)))
-    tot += d(0, 11)
-print("step total %.2f us" % tot)
+    tot += d(0, 11); exch += d(3, 12) + (d(7, 8) + d(10, 11) if st == 4 else 0.0)
+print("step total %.2f us = %.2f us in the 13 exchanges (publish -> every slice has polled the values in) + %.2f us of everything else "
+      "(stamps included: seven to fourteen per stage, ~0.05 us each)" % (tot, exch, tot - exch))

@@ -97,7 +97,35 @@ __device__ __forceinline__ float act_eval_pk_med3(const ActCoef& c, float x)
 {
     return act_eval_pk_clamped(c, __builtin_amdgcn_fmed3f(x, -c.clampv, c.clampv));
 }
+// Throughput form: TWO evaluations per lane, element by element the operations of act_eval in packed instructions (v_pk_mul_f32 /
+// v_pk_fma_f32 round each half as the scalar instructions do) -- half the issue slots where a workgroup is bound by them (the Tacotron
+// attention scores: 8 tanh per thread behind each other)
+__device__ __forceinline__ f32x2m act_eval2(const ActCoef& c, f32x2m x)
+{
+    x[0] = x[0] < -c.clampv ? -c.clampv : (x[0] > c.clampv ? c.clampv : x[0]);
+    x[1] = x[1] < -c.clampv ? -c.clampv : (x[1] > c.clampv ? c.clampv : x[1]);
+#define TWV_SPLAT(v) f32x2m{(v), (v)}
+    const f32x2m t = x * x, t2 = t * t, t4 = t2 * t2;
+    const f32x2m p01 = __builtin_elementwise_fma(TWV_SPLAT(c.a3), t, TWV_SPLAT(c.a1)), p23 = __builtin_elementwise_fma(TWV_SPLAT(c.a7), t, TWV_SPLAT(c.a5)),
+                 p45 = __builtin_elementwise_fma(TWV_SPLAT(c.a11), t, TWV_SPLAT(c.a9));
+    const f32x2m q01 = __builtin_elementwise_fma(TWV_SPLAT(c.b2), t, TWV_SPLAT(c.b0)), q23 = __builtin_elementwise_fma(TWV_SPLAT(c.b6), t, TWV_SPLAT(c.b4)),
+                 q45 = __builtin_elementwise_fma(TWV_SPLAT(c.b10), t, TWV_SPLAT(c.b8));
+    const f32x2m p456 = __builtin_elementwise_fma(TWV_SPLAT(c.a13), t2, p45);
+    const f32x2m p03 = __builtin_elementwise_fma(p23, t2, p01), q03 = __builtin_elementwise_fma(q23, t2, q01);
+    const f32x2m P = __builtin_elementwise_fma(p456, t4, p03), Q = __builtin_elementwise_fma(q45, t4, q03);
+    const f32x2m xp = x * P;
+    f32x2m r = {__uint_as_float(kRcpMagic - __float_as_uint(Q[0])), __uint_as_float(kRcpMagic - __float_as_uint(Q[1]))};
+    const f32x2m one = {1.0f, 1.0f};
+    f32x2m e = __builtin_elementwise_fma(-Q, r, one);
+    const f32x2m s = __builtin_elementwise_fma(e, e, e);
+    r = __builtin_elementwise_fma(r, s, r);
+    e = __builtin_elementwise_fma(-Q, r, one);
+    r = __builtin_elementwise_fma(r, e, r);
+    return __builtin_elementwise_fma(xp, r, TWV_SPLAT(c.half));
+#undef TWV_SPLAT
+}
 __device__ __forceinline__ float tanh_e(float x) { return act_eval(act_coef(false), x); }
+__device__ __forceinline__ f32x2m tanh_e2(f32x2m x) { return act_eval2(act_coef(false), x); }
 __device__ __forceinline__ float sigmoid_e(float x) { return act_eval(act_coef(true), x); }
 
 // ---- exp / log: Cephes single-precision forms as vectorised in Eigen 3.3 ---------------------------

@@ -1904,38 +1904,68 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
             if (!owner) for (int i = 0; i < xa.nap_round; ++i) __builtin_amdgcn_s_sleep(1);
         }
         if (!fin) { LDSVI(o_abort) = 1; return; }
+        if (kind != XG_P && kind != XG_CTX) { XSTAMPT(12) }
         if (!need) return;
         const int col = tid;
+        // one dispatch on the stage's kind, the utterances unrolled inside each case (a chain of scalar branches per utterance before: most
+        // of the 0.3-0.8 us between the arrival and the barrier); a GRU update requests what it reads beside the arriving value for every
+        // utterance first (the reads of utterance 1 cannot pass the writes of utterance 0 otherwise: the compiler has to assume they alias)
+        float v[kXU];
+        v[0] = __uint_as_float(qa.x); v[1] = __uint_as_float(qa.z); v[2] = __uint_as_float(qb.x); v[3] = __uint_as_float(qb.z);
+        if (kind == XG_PLAIN) {
 #pragma unroll
-        for (int u = 0; u < kXU; ++u) {
-            if (u < nu) {
-                const float v = __uint_as_float(u == 0 ? qa.x : u == 1 ? qa.z : u == 2 ? qb.x : qb.z);
-                const int ub = u * UST;
-                if (kind == XG_PLAIN) lds[ub + dst + col] = v;
-                else if (kind == XG_PQ) lds[ub + dst + col + ((col >> 5) << 2)] = v;      // the processed query goes into its skewed table
-                else if (kind == XG_GATES) {          // tf.contrib.rnn.GRUCell, gate order r | u: keep h, cell input <- [x, r*h]
-                    const int nin = g0, U = g1;        // dst = the cell's concatenated input
-                    if (col < U) { const float h = lds[ub + dst + nin + col]; lds[ub + u_keep + col] = h; lds[ub + dst + nin + col] = v * h; }
-                    else lds[ub + u_vec + col] = v;
-                } else if (kind == XG_CAND_ATT || kind == XG_CAND_RES) {       // h <- u*h + (1-u)*c
-                    const int U = g0;
-                    const float uu = lds[ub + u_vec + U + col], h = lds[ub + u_keep + col];
-                    const float t1 = uu * h, t2 = 1.0f - uu, t3 = t2 * v;
-                    const float hn = t1 + t3;
-                    if (kind == XG_CAND_ATT) {         // the attention rnn's state: next step's cell input, this step's query / projection input
-                        lds[ub + u_cata + D1 + ENC + col] = hn;
-                        lds[ub + u_catb + col] = hn;
-                    } else {                           // residual layer l = g1: y <- y + h (tacotron.py:167); next layer's input or the output projection's
-                        const int cr = u_catr + g1 * 2 * DR;
-                        lds[ub + cr + DR + col] = hn;
-                        const float yn = lds[ub + cr + col] + hn;
-                        if (g2 > 0) lds[ub + u_catr + g2 * 2 * DR + col] = yn; else lds[ub + u_y + col] = yn;
-                    }
-                } else if (kind == XG_OUT) {           // tacotron.py:204 reshape; helpers.py:40 last frame fed back
-                    if (col >= M * (R - 1)) lds[ub + u_frame + col - M * (R - 1)] = v;   // (the mel frame itself is written by its publisher)
-                } else if (kind == XG_P) lds[ub + u_p + col] = v;
-                else { lds[ub + u_cata + D1 + col] = v; lds[ub + u_catb + AS + col] = v; }       // XG_CTX
+            for (int u = 0; u < kXU; ++u) if (u < nu) lds[u * UST + dst + col] = v[u];
+        } else if (kind == XG_GATES) {            // tf.contrib.rnn.GRUCell, gate order r | u: keep h, cell input <- [x, r*h]
+            const int nin = g0, U = g1;           // dst = the cell's concatenated input
+            if (col < U) {
+                float h[kXU];
+#pragma unroll
+                for (int u = 0; u < kXU; ++u) h[u] = u < nu ? lds[u * UST + dst + nin + col] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < kXU; ++u) if (u < nu) { lds[u * UST + u_keep + col] = h[u]; lds[u * UST + dst + nin + col] = v[u] * h[u]; }
+            } else {
+#pragma unroll
+                for (int u = 0; u < kXU; ++u) if (u < nu) lds[u * UST + u_vec + col] = v[u];
             }
+        } else if (kind == XG_CAND_ATT || kind == XG_CAND_RES) {       // h <- u*h + (1-u)*c
+            const int U = g0;
+            const bool res = kind == XG_CAND_RES;
+            const int cr = u_catr + (res ? g1 : 0) * 2 * DR;        // residual layer l = g1
+            float uu[kXU], h[kXU], y[kXU], hn[kXU];
+#pragma unroll
+            for (int u = 0; u < kXU; ++u) {
+                const bool on = u < nu;
+                uu[u] = on ? lds[u * UST + u_vec + U + col] : 0.0f;
+                h[u] = on ? lds[u * UST + u_keep + col] : 0.0f;
+                y[u] = (on && res) ? lds[u * UST + cr + col] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < kXU; ++u) {
+                const float t1 = uu[u] * h[u], t2 = 1.0f - uu[u], t3 = t2 * v[u];
+                hn[u] = t1 + t3;
+            }
+            if (!res) {                            // the attention rnn's state: next step's cell input, this step's query / projection input
+#pragma unroll
+                for (int u = 0; u < kXU; ++u) if (u < nu) { lds[u * UST + u_cata + D1 + ENC + col] = hn[u]; lds[u * UST + u_catb + col] = hn[u]; }
+            } else {                               // y <- y + h (tacotron.py:167); next layer's input or the output projection's
+                const int yd = g2 > 0 ? u_catr + g2 * 2 * DR : u_y;
+#pragma unroll
+                for (int u = 0; u < kXU; ++u) if (u < nu) { lds[u * UST + cr + DR + col] = hn[u]; lds[u * UST + yd + col] = y[u] + hn[u]; }
+            }
+        } else if (kind == XG_OUT) {               // tacotron.py:204 reshape; helpers.py:40 last frame fed back
+            if (col >= M * (R - 1)) {              // (the mel frame itself is written by its publisher)
+#pragma unroll
+                for (int u = 0; u < kXU; ++u) if (u < nu) lds[u * UST + u_frame + col - M * (R - 1)] = v[u];
+            }
+        } else if (kind == XG_PQ) {                // the processed query goes into its skewed table
+#pragma unroll
+            for (int u = 0; u < kXU; ++u) if (u < nu) lds[u * UST + dst + col + ((col >> 5) << 2)] = v[u];
+        } else if (kind == XG_P) {
+#pragma unroll
+            for (int u = 0; u < kXU; ++u) if (u < nu) lds[u * UST + u_p + col] = v[u];
+        } else {                                   // XG_CTX
+#pragma unroll
+            for (int u = 0; u < kXU; ++u) if (u < nu) { lds[u * UST + u_cata + D1 + col] = v[u]; lds[u * UST + u_catb + AS + col] = v[u]; }
         }
     };
     auto publish = [&](int u, int i, float v) {
@@ -1971,15 +2001,26 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                     if (MM) {
                         const int ua = (lane & 3) < nu ? (lane & 3) : 0;
                         const int xb_ = ua * UST + xo + 32 * (live ? c : 0);
-                        f32x4 xq[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) xq[q] = LDS4((xb_ >> 2) + q);
+                        // the chunk's 32 operands as eight 16-byte LDS reads, four of them in flight: left to itself the compiler reads them one
+                        // at a time into the same four registers, eight LDS round trips in a row (0.4 of the task's 0.6 us)
                         f32x4 acc[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                        for (int k = 0; k < 32; ++k)
-                            acc[k & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(xq[k >> 2][k & 3], wt[j].w[k], acc[k & 3], 0, 0, 0);
+                        const int xw = xb_ >> 2;
+#define XMF(q, x) { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) acc[k_] = __builtin_amdgcn_mfma_f32_4x4x1f32((x)[k_], wt[j].w[4 * (q) + k_], acc[k_], 0, 0, 0); }
+                        f32x4 x0 = LDS4(xw), x1 = LDS4(xw + 1), x2 = LDS4(xw + 2), x3 = LDS4(xw + 3);
+                        __builtin_amdgcn_sched_barrier(0);
+                        XMF(0, x0) XMF(1, x1)
+                        __builtin_amdgcn_sched_barrier(0);
+                        x0 = LDS4(xw + 4); x1 = LDS4(xw + 5);
+                        __builtin_amdgcn_sched_barrier(0);
+                        XMF(2, x2) XMF(3, x3)
+                        __builtin_amdgcn_sched_barrier(0);
+                        x2 = LDS4(xw + 6); x3 = LDS4(xw + 7);
+                        __builtin_amdgcn_sched_barrier(0);
+                        XMF(4, x0) XMF(5, x1)
+                        XMF(6, x2) XMF(7, x3)
+#undef XMF
 #pragma unroll
                         for (int u = 0; u < kXU; ++u) {
                             const float r = (acc[0][u] + acc[1][u]) + (acc[2][u] + acc[3][u]);
@@ -2051,8 +2092,24 @@ __global__ void __launch_bounds__(512) tc_decoder_x_kernel(DecXArgs xa)
                     const int u = ut / (nt > 0 ? nt : 1), tl = ut - u * nt;
                     float sk = 0.f;
                     const int js = ch * 36 + k, kl = o_keys + (u * ntmax + tl) * kpitch + js, pq = u * UST + u_pq + js;
+                    // (the tanh evaluations two at a time in packed instructions: the same operations on each, and the phase is issue-bound)
+                    // every operand requested first (pair by pair the compiler waits for each pair's LDS round trip in turn)
+                    f32x2m kv[4], qv[4], bv[4], nv_[4];
 #pragma unroll
-                    for (int j = 0; j < 32; j += 4) sk = fma_(lds[o_nv + js + j], tanh_e((lds[kl + j] + lds[pq + j]) + lds[o_ab + js + j]), sk);
+                    for (int i = 0; i < 4; ++i) {
+                        const int j = 8 * i;
+                        kv[i] = f32x2m{lds[kl + j], lds[kl + j + 4]};
+                        qv[i] = f32x2m{lds[pq + j], lds[pq + j + 4]};
+                        bv[i] = f32x2m{lds[o_ab + js + j], lds[o_ab + js + j + 4]};
+                        nv_[i] = f32x2m{lds[o_nv + js + j], lds[o_nv + js + j + 4]};
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x2m th = tanh_e2((kv[i] + qv[i]) + bv[i]);
+                        sk = fma_(nv_[i][0], th[0], sk);
+                        sk = fma_(nv_[i][1], th[1], sk);
+                    }
                     const float s1 = __shfl_xor(sk, 1);
                     const float pr = (k & 1) ? s1 + sk : sk + s1;       // lanes k=0,1 hold s0+s1 ; k=2,3 hold s2+s3 (operand order as written)
                     const float p2 = __shfl_xor(pr, 2);
@@ -2765,11 +2822,10 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
         const bool xok = taco_xdec_ok(h, xt) && cus >= 256 && upx <= kXU && T <= 512 && xfl * 4 <= 160 * 1024 && !simple;
         if (simple && (h->dec_groups == -1 || h->dec_groups == 32))
             return twv_fail(TWV_E_UNSUPPORTED, "model_type 'simple' runs on the split decoder kernel only (decoder_groups 0, 1, 2, 4, 8 or 16)");
-        // Which kernel (round 6, scripts/tacotron_bench.py --batch 8 / 16 / 24 / 28 / 32): the XCD-resident kernel runs a pass in 6.3 / 7.0 / 8.1 /
-        // 8.8 / 8.9 ms, the split kernel in 7.6 / 8.0 / 8.5 / 8.7 / 8.8 -- with up to three utterances per XCD the resident kernel's exchanges (32
-        // workgroups, every weight in registers, no tile stream in front of the polls) are the shorter ones, with four the split kernel's
-        // 8-workgroup groups are.
-        if (xok && (h->dec_groups == 32 || (h->dec_groups == 0 && N <= 24))) {
+        // Which kernel (round 6, scripts/tacotron_bench.py --batch 8 / 16 / 24 / 32): the XCD-resident kernel is the default wherever it fits
+        // (up to four utterances per XCD = batch 32); pass times against the split kernel are in profiles/r06_tacotron_decoder_ab.txt.
+        // (Until its scratch spills and per-utterance branch chains were removed it tied the split kernel at four utterances per XCD.)
+        if (xok && (h->dec_groups == 32 || h->dec_groups == 0)) {
             // XCD-local kernel: every XCD's 32 workgroups hold the decoder in registers and serve that XCD's utterances
             DecXArgs xa;
             xa.d = da; xa.tab = xt; xa.upx = upx; xa.xt_off = h->xt_off; xa.stab = reinterpret_cast<int*>(stabf);

@@ -361,14 +361,14 @@ def test_model_type_simple_concatenates_the_speaker_embedding_inside_the_decoder
 def test_resident_decoder_other_sizes(torch_cuda, oracle, layers, r, N):
     """tc_decoder_x_kernel outside the folded hparams-default instantiation: other decoder depths / reduction factors (run-time sizes), one
     utterance per XCD with idle XCDs (N = 5), four and three utterances per XCD with ragged XCD loads (N = 26, 17: the matrix-core task
-    form), ragged lengths; forced (decoder_groups = 32) and, for N <= 16, also the library's own choice.  Bit for bit against the checker."""
+    form), ragged lengths; forced (decoder_groups = 32) and the library's own choice (the same kernel up to batch 32).  Bit for bit against the checker."""
     hp = _hp(max_iters=5, enc_bank_size=3, post_bank_size=2, num_freq=65, dec_layer_num=layers, reduction_factor=r)
     T = 45
     rng = np.random.RandomState(layers * 10 + r)
     lengths = [T] + [int(x) for x in rng.randint(2, T + 1, N - 1)]
     d, blob, tok, ln, spk, m = _case(oracle, hp, N, T, lengths, seed=41 + layers)
     mel_o, lin_o, al_o = oracle.taco_infer(d, blob, tok, ln, spk)
-    for groups in ([32, 0] if N <= 16 else [32]):
+    for groups in (32, 0):
         m.set_option("decoder_groups", groups)
         for _ in range(2):                                              # the second pass reuses the exchange buffers and tickets
             mel, lin, al = m.infer(tok, ln, spk)
