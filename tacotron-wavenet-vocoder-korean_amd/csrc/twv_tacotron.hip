@@ -27,6 +27,7 @@
 // options -- one model's A/B toggle must not change another model's launches in the same process)
 static thread_local int g_gemm_valu = 0;            // "gemm_valu" option: 1 = the VALU kernel (cross-check of the MFMA one)
 static thread_local int g_gemm_group = 1;           // "gemm_group" option: 0 = one launch per GEMM, separate highway kernels (A/B runs, cross-check)
+static thread_local int g_hw_stack = 1;             // "highway_stack" option: 0 = one launch per highway layer (the form before round 6: A/B runs, cross-check)
 // "gemm_timing" option (measurement aid, bench.py's `tacotron.roofline`): every GEMM launch is bracketed by a pair of HIP events on
 // its stream and its useful FLOPs (2 * rows * K * N, unpadded) are counted; twv_tacotron_gemm_stats sums both since the option was set.
 // PROCESS-WIDE and single-threaded by design (one bench process, one model): the option set through any handle counts the launches of
@@ -343,6 +344,110 @@ __global__ void __launch_bounds__(256) TWV_TWO_WAVES tc_gemm_mfma_highway_kernel
     else mm_body<1, 2>(a, blockIdx.x, blockIdx.y);          // (the highway layers are dense: never taken)
 }
 
+// The whole HIGHWAY STACK of a CBHG in one launch (round 6; modules.py:40-41, 83-89: four layers of 128 -> 128 | 128): a layer is 2 GFLOP at
+// the post-net and 0.2 at the encoder, so one launch per layer (tc_gemm_mfma_highway_kernel) is mostly launch tail and the layer's rows
+// make a round trip through memory in between.  Here a workgroup owns 64 rows for ALL layers: the rows live in LDS (two buffers of
+// 64 x 132 floats; the pitch keeps sixteen rows' 16-byte reads on distinct banks), wave (wr, wc) computes rows 32 wr .. of the column
+// groups wc and wc + 2 of a layer -- the same tiles, the same MFMA chains, chunk sums and epilogue as mm_body<1, 0>, the A operand read
+// from LDS instead of memory -- writes the layer's output into the other buffer, and a barrier later the next layer starts.
+constexpr int kHwMaxDepth = 8, kHwPitch = 132;
+struct HwStackArgs {
+    const float* X; int ldx;               // [rows][128] the stack's input
+    int rows, depth;
+    const float* Wt[kHwMaxDepth];          // highway pair tiles of layer l: [4 column groups][4 chunks][kTile]
+    const float* bh[kHwMaxDepth]; const float* bt[kHwMaxDepth];
+    float* Y; int ldy;
+};
+// WR = 2: 64 rows per workgroup as described; WR = 1 (few rows: the encoder's 3232 would fill 51 CUs): 32 rows per workgroup, wave w owns
+// column group w alone -- twice the workgroups, half the work in each
+template <int WR>
+__global__ void __launch_bounds__(256) TWV_TWO_WAVES tc_highway_stack_kernel(HwStackArgs a)
+{
+    constexpr int kRows = 32 * WR, kGroups = WR;              // rows per workgroup, column groups per wave
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = WR == 2 ? wave >> 1 : 0, wc = WR == 2 ? wave & 1 : wave;
+    const int row0 = blockIdx.x * kRows;
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const f32x16 mzero = {-0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f, -0.0f};
+    // the rows in: thread -> float4 c4 of row r (rows past the end: zeros)
+    for (int i = tid; i < kRows * 32; i += 256) {
+        const int r = i >> 5, c4 = i & 31;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (row0 + r < a.rows) v = *reinterpret_cast<const f32x4*>(a.X + (long long)(row0 + r) * a.ldx + c4 * 4);
+        LDS4(r * (kHwPitch / 4) + c4) = v;
+    }
+    __syncthreads();
+    int cur = 0, nxt = kRows * kHwPitch;
+    const int arow = (wr * 32 + (lane & 31)) * (kHwPitch / 4) + (lane >> 5);        // float4 index of the lane's first operand of chunk 0
+    for (int l = 0; l < a.depth; ++l) {
+        const bool last = l + 1 == a.depth;
+        const float* wt = a.Wt[l];
+        Tile t0_, t1_;
+        load_tile(t0_, wt + (long long)(wc * 4) * kTile, lane);
+#pragma unroll 1
+        for (int cgi = 0; cgi < kGroups; ++cgi) {
+            const int cg = wc + 2 * cgi;
+            f32x16 tot0 = mzero, tot1 = mzero;
+            auto chunk = [&](const Tile& tl, int ch) {
+                f32x4 q[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[i] = LDS4((cur >> 2) + arow + ch * 8 + 2 * i);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x16 acc[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int ka = j + 8 * i;
+                            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tl.w[ka]), __float_as_uint(tl.w[ka + 4]), false, false);
+                            const float bh_ = __uint_as_float(sw[h]);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(q[i][j], bh_, i == 0 ? zero : acc[j], 0, 0, 0);
+                        }
+                    }
+                    const f32x16 cs = mm_add16(mm_add16(acc[0], acc[1]), mm_add16(acc[2], acc[3]));
+                    if (h == 0) tot0 = mm_add16(tot0, cs);
+                    else tot1 = mm_add16(tot1, cs);
+                }
+            };
+            // four chunks on two tile sets in turn; the tile behind the last chunk of column group wc is chunk 0 of group wc + 2
+            const float* w0 = wt + (long long)(cg * 4) * kTile;
+            const float* wn = wt + (long long)((cgi + 1 < kGroups ? cg + 2 : cg) * 4) * kTile;
+            load_tile(t1_, w0 + 1 * kTile, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            chunk(t0_, 0);
+            load_tile(t0_, w0 + 2 * kTile, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            chunk(t1_, 1);
+            load_tile(t1_, w0 + 3 * kTile, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            chunk(t0_, 2);
+            load_tile(t0_, wn, lane);                          // (the second group loads its own chunk 0 again: no load behind a branch)
+            __builtin_amdgcn_sched_barrier(0);
+            chunk(t1_, 3);
+            // epilogue of mm_body mode 1: relu(H + bias) * sigmoid(T + bias2) + x * (1 - sigmoid(..)), x = the layer's input
+            const int n = cg * 32 + (lane & 31);
+            const float bh = a.bh[l][n], bt = a.bt[l][n];
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int rl = wr * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5);
+                float hv = tot0[rr] + bh;
+                hv = hv > 0.0f ? hv : 0.0f;
+                const float tv = sigmoid_e(tot1[rr] + bt);
+                const float x = lds[cur + rl * kHwPitch + n];
+                const float p0 = hv * tv, p1 = 1.0f - tv;
+                const float p2 = x * p1;
+                const float y = p0 + p2;
+                if (last) { if (row0 + rl < a.rows) a.Y[(long long)(row0 + rl) * a.ldy + n] = y; }
+                else lds[nxt + rl * kHwPitch + n] = y;
+            }
+        }
+        __syncthreads();
+        const int t_ = cur; cur = nxt; nxt = t_;
+    }
+}
+
 // SEVERAL problems in one launch: the conv bank of a CBHG is 16 (encoder) / 8 (post-net) independent GEMMs over the
 // same rows (modules.py:30-35), the four input halves of the biGRU kernels and the five speaker dense layers likewise.  One at a time
 // each fills a fraction of the chip (3232 encoder rows = 51 row tiles) and pays its own launch; here the workgroups of all of them form
@@ -371,14 +476,18 @@ __global__ void __launch_bounds__(256) TWV_TWO_WAVES tc_gemm_mfma_group_kernel(G
 // Few rows, deep contraction (encoder CBHG: 3232 rows, K up to 6144): the 64-row kernel would fill ~50 CUs and run 192 chunks
 // back to back per wave.  Here a workgroup owns ONE 32-row x 64-column tile and its 4 waves take the chunks round-robin; the
 // chunk values meet in LDS and are added to the running total strictly in chunk order (AC-1), each wave keeping a quarter of it.
+// (Round 6 also tried one 32-column half per workgroup -- twice the workgroups, two per CU: the same 121 us for the encoder's K = 6144
+// projection.  Every workgroup streams the whole weight matrix of its columns: 404 workgroups x 1.5 MB + the rows = 0.9 GB through the
+// L2s in 121 us; what bounds this launch is that traffic, which only taller tiles -- fewer workgroups -- would cut.)
 __global__ void __launch_bounds__(256) tc_gemm_mfma_ck_kernel(GemmArgs a)
 {
-    __shared__ float cv[4][2][16][64];                        // [chunk slot][column half][register][lane]
+    constexpr int NH = 2;
+    __shared__ float cv[4][NH][16][64];                       // [chunk slot][column half][register][lane]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.x * 32;
     const int nchunk = (a.K + 31) / 32;
-    const int nb = blockIdx.y;
+    const int nb = blockIdx.y, hsel = 0;
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float tot[2][4];                                          // registers 4*wave .. 4*wave+3 of both halves
     MmRow r;
@@ -391,15 +500,19 @@ __global__ void __launch_bounds__(256) tc_gemm_mfma_ck_kernel(GemmArgs a)
     const rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)((((long long)a.rows - 1) * a.ldx + a.Cin) * 4), 0x00020000);
     const int hh = (lane >> 5) * 4;
     const float* wt = a.Wt + (long long)nb * nchunk * kTile;
-    for (int c0 = 0; c0 < nchunk; c0 += 4) {
+    // Round 6: the next round's operands travel while this round's 32 MFMAs run (two operand sets in turn, as in mm_body; before, every
+    // round started with its own loads: 48 rounds x a memory round trip for the encoder's K = 6144 projection), and the barriers order LDS
+    // only (a __syncthreads() would wait for the prefetch as well)
+    auto fetch = [&](Tile& tl, MmA& A, int ch) {              // (past the last chunk: the last one again, never used)
+        const int chc = ch < nchunk ? ch : nchunk - 1;
+        load_tile(tl, wt + (long long)chc * kTile, lane);
+        int kg = chc * 32 + hh, tap = 0, c = kg;
+        if (a.kw > 1) { tap = kg / a.Cin; c = kg - tap * a.Cin; }
+        mm_load_a(A, a, rx, r, kg, tap, c);
+    };
+    auto round = [&](const Tile& tl, const MmA& A, int c0) {
         const int ch = c0 + wave;
         if (ch < nchunk) {
-            Tile tl;
-            MmA A;
-            load_tile(tl, wt + (long long)ch * kTile, lane);
-            int kg = ch * 32 + hh, tap = 0, c = kg;
-            if (a.kw > 1) { tap = kg / a.Cin; c = kg - tap * a.Cin; }
-            mm_load_a(A, a, rx, r, kg, tap, c);
             f32x16 acc0[4], acc1[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -407,32 +520,47 @@ __global__ void __launch_bounds__(256) tc_gemm_mfma_ck_kernel(GemmArgs a)
                 for (int j = 0; j < 4; ++j) {
                     const int ka = j + 8 * i;
                     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tl.w[ka]), __float_as_uint(tl.w[ka + 4]), false, false);
-                    const float b0 = __uint_as_float(sw[0]), b1 = __uint_as_float(sw[1]);
+                    const float b0 = __uint_as_float(NH == 2 ? sw[0] : (hsel ? sw[1] : sw[0])), b1 = __uint_as_float(sw[1]);
                     const float a0 = A.q[i][j];
                     acc0[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, i == 0 ? zero : acc0[j], 0, 0, 0);
-                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, i == 0 ? zero : acc1[j], 0, 0, 0);
+                    if (NH == 2) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, i == 0 ? zero : acc1[j], 0, 0, 0);
                 }
             }
             const f32x16 v0 = (acc0[0] + acc0[1]) + (acc0[2] + acc0[3]);
-            const f32x16 v1 = (acc1[0] + acc1[1]) + (acc1[2] + acc1[3]);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) { cv[wave][0][q][lane] = v0[q]; cv[wave][1][q][lane] = v1[q]; }
+            for (int q = 0; q < 16; ++q) cv[wave][0][q][lane] = v0[q];
+            if (NH == 2) {
+                const f32x16 v1 = (acc1[0] + acc1[1]) + (acc1[2] + acc1[3]);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) cv[wave][NH - 1][q][lane] = v1[q];
+            }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const int nl = min(4, nchunk - c0);
         for (int s = 0; s < nl; ++s)                           // chunk order
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < NH; ++h)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float v = cv[s][h][4 * wave + q][lane];
                     tot[h][q] = (c0 == 0 && s == 0) ? v : tot[h][q] + v;
                 }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    Tile t0_, t1_;
+    MmA A0_, A1_;
+    fetch(t0_, A0_, wave);
+    for (int c0 = 0; c0 < nchunk; c0 += 8) {
+        fetch(t1_, A1_, c0 + 4 + wave);
+        __builtin_amdgcn_sched_barrier(0);
+        round(t0_, A0_, c0);
+        fetch(t0_, A0_, c0 + 8 + wave);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c0 + 4 < nchunk) round(t1_, A1_, c0 + 4);
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int n = nb * 64 + h * 32 + (lane & 31);
+    for (int h = 0; h < NH; ++h) {
+        const int n = nb * 64 + (NH == 2 ? h : hsel) * 32 + (lane & 31);
         if (n < a.N) {
             const float bv = a.bias ? a.bias[n] : 0.0f;
             const float iv = a.bn_inv ? a.bn_inv[n] : 1.0f, sv = a.bn_inv ? a.bn_shift[n] : 0.0f;
@@ -2290,6 +2418,7 @@ struct twv_tacotron {
     int dec_split_all = -1;         // prenet + query layer split over the workgroups: -1 = when the exchanges are L2-local, 0 / 1
     int dec_local = 1;              // split kernel: 1 = an utterance's workgroups on one XCD (exchanges through its L2), 0 = spread over the XCDs
     int gemm_valu = 0, gemm_group = 1;   // see g_gemm_valu / g_gemm_group
+    int hw_stack = 1;                    // see g_hw_stack
     long long blob_floats, packed_floats;
     long long xt_off = 0;           // row tiles of the XCD-local decoder kernel [32 slices][8 waves][kXSlots][2048]
     TMat emb, semb;                 // raw tables (K rows x N)
@@ -2422,6 +2551,7 @@ extern "C" int twv_tacotron_set_option(twv_tacotron* h, const char* name, int va
 {
     if (!h || !name) return twv_fail(TWV_E_INVALID, "null argument");
     if (!strcmp(name, "gemm_valu")) { h->gemm_valu = value ? 1 : 0; return TWV_OK; }
+    if (!strcmp(name, "highway_stack")) { h->hw_stack = value ? 1 : 0; return TWV_OK; }
     if (!strcmp(name, "gemm_group")) { h->gemm_group = value ? 1 : 0; return TWV_OK; }   // 0: one launch per GEMM, separate highway kernels (A/B runs, cross-check)
     if (!strcmp(name, "gemm_timing")) {   // 1: start counting (resets the sums), 0: stop
         g_gemm_stat.on = value != 0;
@@ -2672,6 +2802,25 @@ static void run_cbhg(hipStream_t st, const twv_tacotron* h, const float* P, cons
     if (c.has_dense) { launch_gemm(st, P, rb, proj[1], rows, T, proj[1], 1, c.dW, &c.db, TACT_NONE, nullptr, nullptr, nullptr, 0, nullptr, 0, rc, rnn, 0); hw = rc; }
     float* hH = ra;
     float* hT = (hw == rc) ? rb : rc;
+    if (!g_gemm_valu && g_gemm_group && g_hw_stack && depth >= 1 && depth <= kHwMaxDepth) {
+        // the whole stack in one launch: rows stay in LDS between the layers
+        HwStackArgs ha;
+        ha.X = hw; ha.ldx = rnn; ha.rows = rows; ha.depth = depth;
+        for (int i = 0; i < depth; ++i) { ha.Wt[i] = P + c.hHT[i].off; ha.bh[i] = P + c.hHb[i].off; ha.bt[i] = P + c.hTb[i].off; }
+        ha.Y = hH; ha.ldy = rnn;
+        {
+            GemmTimed tm(st, 2.0 * (double)rows * (double)rnn * (double)(2 * rnn) * depth, 1);
+            if ((rows + 63) / 64 >= 256) {
+                const size_t shm = (size_t)2 * 64 * kHwPitch * 4;
+                (void)hipFuncSetAttribute((const void*)tc_highway_stack_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+                hipLaunchKernelGGL(tc_highway_stack_kernel<2>, dim3((rows + 63) / 64), dim3(256), shm, st, ha);
+            } else {
+                const size_t shm = (size_t)2 * 32 * kHwPitch * 4;
+                hipLaunchKernelGGL(tc_highway_stack_kernel<1>, dim3((rows + 31) / 32), dim3(256), shm, st, ha);
+            }
+        }
+        hw = hH;
+    } else
     for (int i = 0; i < depth; ++i) {
         if (!g_gemm_valu && g_gemm_group) {
             // the whole highway layer in one launch (mm_body, mode 1): H and T columns interleaved in the tiles, output to the other buffer
@@ -2711,7 +2860,7 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
     if (!h || !packed || !tokens || !lengths || !workspace || !mel || !status) return twv_fail(TWV_E_INVALID, "null argument");
     if (!speaker_ids && h->d.num_speakers > 1) return twv_fail(TWV_E_INVALID, "speaker_ids is required for a multi-speaker model");
     if (batch < 1 || t_in < 1 || t_in > 1024) return twv_fail(TWV_E_INVALID, "batch >= 1 and 1 <= t_in <= 1024 required");
-    g_gemm_valu = h->gemm_valu; g_gemm_group = h->gemm_group;
+    g_gemm_valu = h->gemm_valu; g_gemm_group = h->gemm_group; g_hw_stack = h->hw_stack;
     const twv_tacotron_dims& d = h->d;
     hipStream_t st = (hipStream_t)stream;
     const float* P = (const float*)packed;

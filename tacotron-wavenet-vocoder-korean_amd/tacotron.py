@@ -158,7 +158,7 @@ class Tacotron(object):
         """launch geometry (performance only, results are bit-identical): "decoder_groups" = workgroups per utterance in the decoder
         (0 auto, 1/2/4/8/16, -1 old kernel, 32 XCD-local kernel); "decoder_local" 1/0 = an utterance's workgroups on one XCD (default) or
         spread over the XCDs; "decoder_split_all" -1/0/1 = prenet and query layer split over the workgroups (-1: when local);
-        "gemm_group", "gemm_valu", "gemm_timing" """
+        "gemm_group", "gemm_valu", "gemm_timing", "highway_stack" (0: one launch per highway layer) """
         _lib.check(self._L.twv_tacotron_set_option(self._h, name.encode(), int(value)))
 
     def gemm_stats(self):

@@ -200,6 +200,14 @@ def test_tacotron_gemm_kernels_agree(torch_cuda, oracle):
         m.set_option("gemm_group", 1)
     assert first_mismatch(mel_a.cpu().numpy(), mel_c.cpu().numpy()) is None
     assert first_mismatch(lin_a.cpu().numpy(), lin_c.cpu().numpy()) is None
+    # the highway stack as one launch per layer (the form before round 6) gives the same bits as the fused stack
+    m.set_option("highway_stack", 0)
+    try:
+        mel_d, lin_d, al_d = m.infer(tok, ln, spk)
+    finally:
+        m.set_option("highway_stack", 1)
+    assert first_mismatch(mel_a.cpu().numpy(), mel_d.cpu().numpy()) is None
+    assert first_mismatch(lin_a.cpu().numpy(), lin_d.cpu().numpy()) is None
 
 
 @pytest.mark.parametrize("steps", [25, 200])
