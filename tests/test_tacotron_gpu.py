@@ -365,6 +365,29 @@ def test_model_type_simple_concatenates_the_speaker_embedding_inside_the_decoder
             m.infer(tok, ln_, spk)
 
 
+@pytest.mark.parametrize("N,T", [(26, 200), (9, 330), (32, 140), (32, 330)])
+def test_resident_decoder_long_inputs(torch_cuda, oracle, N, T):
+    """tc_decoder_x_kernel with inputs longer than 128 tokens: the attention block's score / context tasks no longer fit one pass of the
+    workgroup's 512 threads (the branches behind `task0 > 0`), the recurrence walks more than two 64-step blocks (T = 330: the
+    one-wave-per-utterance form), key / memory tables grow towards the LDS limit.  The library's own choice = the forced one where the
+    kernel fits; where it does not (B = 32 x 330 tokens: the LDS carve), decoder_groups = 32 says so and the split kernel serves.  Bit for bit."""
+    from twvk_amd._lib import TwvError
+    hp = _hp(max_iters=3, enc_bank_size=3, post_bank_size=2, num_freq=65)
+    rng = np.random.RandomState(N + T)
+    lengths = [T] + [int(x) for x in rng.randint(T // 3, T + 1, N - 1)]
+    d, blob, tok, ln, spk, m = _case(oracle, hp, N, T, lengths, seed=77)
+    mel_o, lin_o, al_o = oracle.taco_infer(d, blob, tok, ln, spk)
+    for groups in (0, 32):
+        m.set_option("decoder_groups", groups)
+        try:
+            mel, lin, al = m.infer(tok, ln, spk)
+        except TwvError as e:
+            assert groups == 32 and "XCD-local decoder" in str(e), (groups, str(e))
+            continue
+        assert first_mismatch(al.cpu().numpy(), al_o) is None, (groups, "alignments", first_mismatch(al.cpu().numpy(), al_o))
+        assert first_mismatch(mel.cpu().numpy(), mel_o) is None, (groups, "mel", first_mismatch(mel.cpu().numpy(), mel_o))
+
+
 @pytest.mark.parametrize("layers,r,N", [(2, 3, 5), (1, 2, 26), (2, 5, 17)])
 def test_resident_decoder_other_sizes(torch_cuda, oracle, layers, r, N):
     """tc_decoder_x_kernel outside the folded hparams-default instantiation: other decoder depths / reduction factors (run-time sizes), one
