@@ -365,6 +365,26 @@ def test_model_type_simple_concatenates_the_speaker_embedding_inside_the_decoder
             m.infer(tok, ln_, spk)
 
 
+@pytest.mark.parametrize("enc_depth,post_depth,N,iters", [(1, 6, 3, 6), (8, 2, 5, 4), (4, 4, 17, 200)])
+def test_highway_stack_depths_and_ragged_row_tiles(torch_cuda, oracle, enc_depth, post_depth, N, iters):
+    """tc_highway_stack_kernel (a CBHG's highway layers in one launch, modules.py:40-41, 83-89) at other depths than the default four
+    (1 .. 8 layers, the kernel's argument limit) and with row counts that end inside a row tile; the last case has 17 x 1000 = 17 000
+    post-net rows: the 64-row instantiation with a ragged last tile (the small cases run the 32-row one).  Bit for bit against the
+    checker, and against the one-launch-per-layer form."""
+    hp = _hp(max_iters=iters, enc_bank_size=3, post_bank_size=2, num_freq=65, enc_highway_depth=enc_depth, post_highway_depth=post_depth)
+    T = 29
+    rng = np.random.RandomState(enc_depth * 10 + post_depth)
+    lengths = [T] + [int(x) for x in rng.randint(3, T + 1, N - 1)]
+    d, blob, tok, ln, spk, m = _case(oracle, hp, N, T, lengths, seed=90 + enc_depth)
+    mel_o, lin_o, al_o = oracle.taco_infer(d, blob, tok, ln, spk)
+    mel, lin, al = m.infer(tok, ln, spk)
+    assert first_mismatch(mel.cpu().numpy(), mel_o) is None, ("mel", first_mismatch(mel.cpu().numpy(), mel_o))
+    assert first_mismatch(lin.cpu().numpy(), lin_o) is None, ("linear", first_mismatch(lin.cpu().numpy(), lin_o))
+    m.set_option("highway_stack", 0)
+    mel_b, lin_b, _ = m.infer(tok, ln, spk)
+    assert first_mismatch(mel.cpu().numpy(), mel_b.cpu().numpy()) is None and first_mismatch(lin.cpu().numpy(), lin_b.cpu().numpy()) is None
+
+
 @pytest.mark.parametrize("N,T", [(26, 200), (9, 330), (32, 140), (32, 330)])
 def test_resident_decoder_long_inputs(torch_cuda, oracle, N, T):
     """tc_decoder_x_kernel with inputs longer than 128 tokens: the attention block's score / context tasks no longer fit one pass of the
