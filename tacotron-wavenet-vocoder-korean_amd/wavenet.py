@@ -295,7 +295,7 @@ class WaveNetModel(object):
                 u = torch.as_tensor(uniforms, dtype=torch.float32, device=self.device).contiguous()
                 T = u.shape[1]
                 fi = torch.as_tensor(np.asarray(first_input, dtype=np.float32).reshape(B), device=self.device)
-                out = torch.zeros((B, T), dtype=torch.float32, device=self.device)      # zeros: with check=False a launch that found the device busy writes nothing
+                out = torch.zeros((B, T), dtype=torch.float32, device=self.device)      # zeros: with check=False a launch that found the device busy writes nothing (status() tells)
             else:
                 u = torch.as_tensor(uniforms, dtype=torch.float64, device=self.device).contiguous()
                 T = u.shape[1]
@@ -321,6 +321,15 @@ class WaveNetModel(object):
                 _lib.check(rc)
                 break
         return (out, dbg) if debug_steps else out
+
+    def status(self):
+        """The status word of the launches issued so far on this model (generate / prime with check=False return without reading it):
+        waits for the stream, raises TwvError for a watchdog abort, a launch that found the device busy (nothing was written: the
+        zeros of `out` are not samples) or non-finite logits; returns 0 otherwise.  The firm way to end a check=False sequence."""
+        with torch.cuda.device(self.device):
+            rc = self._L.twv_wavenet_status(_ptr(self._status), _stream())
+        _lib.check(rc)
+        return 0
 
     # ---- generate.py:168-180 priming loop: feed the seed samples, discard the predictions ----
     def prime(self, inputs, upsampled_local_condition=None, global_condition=None, check=True):

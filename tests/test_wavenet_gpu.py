@@ -262,6 +262,36 @@ def test_generate_variants(torch_cuda, oracle, kw):
     assert first_mismatch(got.cpu().numpy(), want) is None, kw
 
 
+def test_unchecked_calls_end_with_a_status_read(torch_cuda, oracle):
+    """generate(check=False) returns without a host sync and without reading the status word; status() is the read that ends such a
+    sequence: 0 after clean launches, TwvError after one that saw non-finite logits (the one-hot model with a NaN weight)"""
+    from twvk_amd._lib import TwvError
+    dil = [1, 2, 4, 8] * 2
+    B, T = 2, 24
+    d, tensors, blob = make_case(oracle, dil, S=512, scale=0.1)
+    m = make_model(B, dil, tensors, S=512)
+    rng = np.random.RandomState(5)
+    U = rng.uniform(-1, 1, (B, T, 80)).astype(np.float32)
+    gc = np.array([1, 0], np.int32)
+    seed_in = rng.uniform(-1, 1, B).astype(np.float32)
+    u = mol_uniforms(B, T, 10)
+    want = oracle.generate_mol(d, blob, oracle.State(d, B), U, gc, seed_in, u)
+    a = m.generate(U[:, :10], gc, seed_in, u[:, :10], check=False)
+    b = m.generate(U[:, 10:], gc, a[:, -1].cpu().numpy(), u[:, 10:], check=False)
+    assert m.status() == 0
+    assert first_mismatch(np.concatenate([a.cpu().numpy(), b.cpu().numpy()], axis=1), want) is None
+    d2, t2, _ = make_case(oracle, [1, 2, 4, 8], scalar_input=False, Q=256)
+    t2 = dict(t2)
+    b2 = t2["wavenet/conv1d_2/bias"].copy(); b2[17] = np.nan
+    t2["wavenet/conv1d_2/bias"] = b2
+    m2 = make_model(2, [1, 2, 4, 8], t2, scalar_input=False, Q=256)
+    out = m2.generate(rng.uniform(-4, 4, (2, 40, 80)).astype(np.float32), np.array([0, 1], np.int32), np.array([128, 3], np.int32),
+                      rng.random_sample((2, 40)), check=False)
+    assert out.shape == (2, 40)
+    with pytest.raises(TwvError, match="NaN"):
+        m2.status()
+
+
 @pytest.mark.parametrize("S", [128, 512])
 def test_state_carries_over_between_calls(torch_cuda, oracle, S):
     """generate(T1) then generate(T2) == generate(T1+T2); n_steps=1 calls == one sess.run each (generate.py:211).
