@@ -195,7 +195,8 @@ int twv_tacotron_infer(const twv_tacotron* h, const void* packed, const int32_t*
 /* launch geometry (performance only, results are bit-identical): "decoder_groups" = 0 auto (the XCD-resident decoder kernel wherever it
  * fits -- batch <= 32, t_in <= 512, 256 CUs, decoder widths divisible by 4, not model_type 'simple' -- else the split kernel with 16 / 8 / 4
  * workgroups per utterance), 1/2/4/8/16 = the split kernel with that many workgroups per utterance, 32 = the XCD-resident kernel or an
- * error, -1 = the single-workgroup kernel. */
+ * error, -1 = the single-workgroup kernel.  "gemm_group" / "highway_stack" / "gemm_valu": 0 / 0 / 1 select the older launch forms of the
+ * dense layers (one launch per problem, one per highway layer, the VALU kernel) for A/B runs and cross-checks. */
 int twv_tacotron_set_option(twv_tacotron* h, const char* name, int value);
 /* optional decoder phase timestamps (tuning aid): device uint64[max_iters][16], s_memtime ticks of utterance 0's workgroup at the
  * phase boundaries of every decoder step (prenet, attention GRU, query, score, recurrence, context, projection, residual GRUs,
