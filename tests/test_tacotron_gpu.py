@@ -365,6 +365,45 @@ def test_model_type_simple_concatenates_the_speaker_embedding_inside_the_decoder
             m.infer(tok, ln_, spk)
 
 
+@pytest.mark.parametrize("groups", [0, 8])
+def test_an_utterance_does_not_depend_on_its_place_in_the_batch(torch_cuda, groups):
+    """Size-independent property at BASELINE configs[2]'s full size (B = 32, 101 tokens, 200 decoder steps; no checker involved): an
+    utterance's mel, linear and alignments are the same bits wherever it sits in the batch and whoever sits next to it.  In the
+    XCD-resident decoder (groups = 0) the place decides the XCD and the lane group of the matrix-core tasks (utterance n -> XCD n / 4,
+    slot n mod 4), in the split decoder (8) the XCD its workgroups share; the GEMM rows move between workgroups either way."""
+    import twvk_amd
+    from twvk_amd.tacotron import Tacotron
+    hp = twvk_amd.default_hparams()
+    m = Tacotron(hp, num_speakers=2)
+    rng = np.random.RandomState(3)
+    tt = {}
+    for n_, shp in m.specs:
+        if n_.endswith("batch_normalization"):
+            c_ = shp[1]; tt[n_] = np.stack([np.ones(c_), np.zeros(c_), np.zeros(c_), np.ones(c_)]).astype(np.float32)
+        elif n_.endswith("attention_g"): tt[n_] = np.array([np.sqrt(1.0 / hp.attention_size)], np.float32)
+        elif n_.endswith("attention_score_bias"): tt[n_] = np.zeros(1, np.float32)
+        else:
+            fan = int(np.prod(shp[:-1])) if len(shp) > 1 else 1
+            tt[n_] = (rng.randn(*shp) * (0.05 if len(shp) == 1 else min(0.5, 1.2 / np.sqrt(fan)))).astype(np.float32)
+    m.load_weights(tt)
+    m.set_option("decoder_groups", groups)
+    N, T = 32, 101
+    lengths = np.array([T - (i * 7) % 60 for i in range(N)], np.int32)
+    tok = rng.randint(2, 80, (N, T)).astype(np.int32)
+    for n in range(N):
+        tok[n, lengths[n] - 1] = 1; tok[n, lengths[n]:] = 0
+    spk = (np.arange(N) % 2).astype(np.int32)
+    mel, lin, al = [x.cpu().numpy() for x in m.infer(tok, lengths, spk)]
+    assert np.isfinite(mel).all() and mel.shape == (N, 1000, 80)
+    perm = rng.permutation(N)
+    mel_p, lin_p, al_p = [x.cpu().numpy() for x in m.infer(tok[perm], lengths[perm], spk[perm])]
+    assert first_mismatch(mel_p, mel[perm]) is None and first_mismatch(lin_p, lin[perm]) is None and first_mismatch(al_p, al[perm]) is None
+    # a batch of five of them, in another order: other neighbours, other XCD loads (one or two utterances per XCD: the row-broadcast task form)
+    sub = np.array([17, 3, 30, 8, 21])
+    mel_s, lin_s, al_s = [x.cpu().numpy() for x in m.infer(tok[sub], lengths[sub], spk[sub])]
+    assert first_mismatch(mel_s, mel[sub]) is None and first_mismatch(lin_s, lin[sub]) is None and first_mismatch(al_s, al[sub]) is None
+
+
 @pytest.mark.parametrize("enc_depth,post_depth,N,iters", [(1, 6, 3, 6), (8, 2, 5, 4), (4, 4, 17, 200)])
 def test_highway_stack_depths_and_ragged_row_tiles(torch_cuda, oracle, enc_depth, post_depth, N, iters):
     """tc_highway_stack_kernel (a CBHG's highway layers in one launch, modules.py:40-41, 83-89) at other depths than the default four
