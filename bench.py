@@ -702,11 +702,11 @@ def main():
                     torch.cuda.synchronize()
                     bdt = (time.perf_counter() - c0) / 2
                     bsweep.append({"batch": TB, "ms_per_pass": bdt * 1e3, "mel_frames_per_s": TB * hp.max_iters * hp.reduction_factor / bdt,
-                                   "decoder_kernel": "tc_decoder_x_kernel (XCD-resident)" if TB <= 32 else "tc_decoder_g_kernel (split)"})
+                                   "decoder_kernel": tm.decoder_kernel_name(TB, TT)})
                 res["tacotron"] = {"metric": "Tacotron mel frames/sec", "value": TN * hp.max_iters * hp.reduction_factor / qdt,
                                    "unit": "mel frames/s", "ms_per_pass": qdt * 1e3, "dtype": "f32", "batch_sweep": bsweep,
                                    # the DOMINANT kernel's ruler first: the decoder is 64 % of the pass and a latency chain
-                                   "roofline": {"bound": "hbm", "kernel": "tc_decoder_x_kernel (XCD-resident: 32 workgroups per XCD hold 16 columns of every decoder matrix in registers "
+                                   "roofline": {"bound": "hbm", "kernel": tm.decoder_kernel_name(TN, TT) + " (XCD-resident: 32 workgroups per XCD hold 16 columns of every decoder matrix in registers "
                                                                          "for the whole launch and serve that XCD's four utterances; 11 matvec stages on v_mfma_f32_4x4x1 + attention, "
                                                                          "13 all-gathers per step through that XCD's L2)",
                                                 # HBM convention as for the headline: algorithmic bytes = the decoder's weights once per pass per XCD-resident copy would be

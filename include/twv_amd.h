@@ -207,6 +207,9 @@ int twv_tacotron_set_profile_buffer(twv_tacotron* h, void* dev_u64);
  * linear projection) is bracketed by HIP events on its stream; this returns the useful FLOPs (2*rows*K*N), the summed kernel time
  * and the launch count since then. */
 int twv_tacotron_gemm_stats(twv_tacotron* h, double* flop, double* ms, int64_t* launches);
+/* the decoder kernel twv_tacotron_infer launches for this (handle, batch, t_in, options) on the current device:
+ * "tc_decoder_x_kernel" (XCD-resident), "tc_decoder_g_kernel" (split) or "tc_decoder_kernel" (static string; measurement label, bench.py) */
+const char* twv_tacotron_decoder_kernel_name(const twv_tacotron* h, int batch, int t_in);
 
 /* ======================================= WaveNet teacher-forced training step =======================================
  * Replaces one `sess.run([net.loss, net.optimize])` of train_vocoder.py:155-181 for the scalar-input (MoL) model:

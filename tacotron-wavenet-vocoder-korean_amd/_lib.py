@@ -229,6 +229,7 @@ def lib():
     L.twv_tacotron_set_profile_buffer.argtypes = [vp, vp]
     L.twv_tacotron_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.twv_tacotron_gemm_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.twv_tacotron_decoder_kernel_name.argtypes = [vp, C.c_int, C.c_int]; L.twv_tacotron_decoder_kernel_name.restype = C.c_char_p
     L.twv_wavenet_train_create.argtypes = [C.POINTER(Dims), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.twv_wavenet_train_destroy.argtypes = [vp]; L.twv_wavenet_train_destroy.restype = None
     for n in ("twv_wavenet_train_param_floats", "twv_wavenet_train_workspace_bytes"):
@@ -251,7 +252,7 @@ EXPORTS = ["twv_last_error", "twv_version", "twv_wavenet_create", "twv_wavenet_d
            "twv_wavenet_condition", "twv_wavenet_fused_conditioning", "twv_wavenet_kernel_name", "twv_wavenet_cond_bytes_mel", "twv_wavenet_condition_mel", "twv_wavenet_generate", "twv_wavenet_prime", "twv_wavenet_status", "twv_wavenet_set_option", "twv_wavenet_set_profile_buffer",
            "twv_mu_law_encode", "twv_mu_law_decode", "twv_mu_law_expand", "twv_wav_to_int16", "twv_eval_elementwise",
            "twv_eval_elementwise64", "twv_sample_categorical", "twv_selftest", "twv_debug_occupy", "twv_tacotron_create", "twv_tacotron_destroy", "twv_tacotron_blob_floats",
-           "twv_tacotron_packed_bytes", "twv_tacotron_workspace_bytes", "twv_tacotron_pack", "twv_tacotron_infer", "twv_tacotron_set_profile_buffer", "twv_tacotron_set_option", "twv_tacotron_gemm_stats",
+           "twv_tacotron_packed_bytes", "twv_tacotron_workspace_bytes", "twv_tacotron_pack", "twv_tacotron_infer", "twv_tacotron_set_profile_buffer", "twv_tacotron_set_option", "twv_tacotron_gemm_stats", "twv_tacotron_decoder_kernel_name",
            "twv_wavenet_train_create", "twv_wavenet_train_destroy", "twv_wavenet_train_param_floats", "twv_wavenet_train_workspace_bytes",
            "twv_wavenet_train_output_width", "twv_wavenet_train_reset_workspace", "twv_wavenet_train_loss_grad", "twv_adam_ema_step", "twv_wavenet_train_l2",
            "twv_clip_by_global_norm", "twv_griffin_lim_create", "twv_griffin_lim_destroy", "twv_griffin_lim_samples",

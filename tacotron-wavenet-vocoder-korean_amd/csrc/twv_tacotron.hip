@@ -3043,3 +3043,22 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
     HIPCHK(hipGetLastError());
     return TWV_OK;
 }
+
+// the decoder kernel twv_tacotron_infer launches for this (handle, batch, t_in, options) on the current device -- the rules of the
+// launch code above restated for a measurement label (bench.py's `tacotron.roofline.kernel`, `batch_sweep`); static strings
+extern "C" const char* twv_tacotron_decoder_kernel_name(const twv_tacotron* h, int batch, int t_in)
+{
+    if (!h || batch < 1 || t_in < 1) return "";
+    const twv_tacotron_dims& d = h->d;
+    if (h->dec_groups == -1) return "tc_decoder_kernel";
+    int cus = 0, devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid) != hipSuccess) return "";
+    const bool simple = d.num_speakers > 1 && d.model_simple && d.speaker_embedding_size != 1;
+    XStageTab xt;
+    taco_xstages(h, xt);
+    const int upx = (batch + 7) / 8, nu = upx < batch ? upx : batch;
+    const long long xfl = xdec_carve(d.num_mels, d.dec_prenet_sizes[1], 256, d.attention_state_size, d.dec_layer_num, d.dec_rnn_size, d.attention_size, t_in,
+                                     nu < 1 ? 1 : nu, xt.nst).total + 64;
+    const bool xok = taco_xdec_ok(h, xt) && cus >= 256 && upx <= kXU && t_in <= 512 && xfl * 4 <= 160 * 1024 && !simple;
+    return xok && (h->dec_groups == 32 || h->dec_groups == 0) ? "tc_decoder_x_kernel" : "tc_decoder_g_kernel";
+}

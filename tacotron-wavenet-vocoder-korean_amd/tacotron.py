@@ -161,6 +161,10 @@ class Tacotron(object):
         "gemm_group", "gemm_valu", "gemm_timing", "highway_stack" (0: one launch per highway layer) """
         _lib.check(self._L.twv_tacotron_set_option(self._h, name.encode(), int(value)))
 
+    def decoder_kernel_name(self, batch, t_in):
+        """the decoder kernel infer() launches for this batch and input length with the options set (a measurement label)"""
+        return self._L.twv_tacotron_decoder_kernel_name(self._h, int(batch), int(t_in)).decode()
+
     def gemm_stats(self):
         """after set_option("gemm_timing", 1): (useful FLOPs, summed kernel milliseconds, launches) of the dense contractions since then"""
         f, ms, n = C.c_double(), C.c_double(), C.c_int64()
