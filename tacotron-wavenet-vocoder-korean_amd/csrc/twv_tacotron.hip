@@ -602,7 +602,7 @@ __global__ void tc_gather_rows_kernel(const float* table, const int32_t* ids, in
     }
 }
 // modules.py:38 max_pooling1d(2, stride 1, 'same'): out[t] = max(x[t], x[t+1]) inside each sequence
-__global__ void tc_maxpool2_kernel(const float* x, int rows, int T, int Cn, float* out)
+__global__ void tc_maxpool2_scalar_kernel(const float* x, int rows, int T, int Cn, float* out)      // (a channel count that is not a multiple of 4)
 {
     const long long total = (long long)rows * Cn;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -610,6 +610,23 @@ __global__ void tc_maxpool2_kernel(const float* x, int rows, int T, int Cn, floa
         const float a = x[i];
         const float b = (row % T) + 1 < T ? x[i + Cn] : a;
         out[i] = a > b ? a : b;
+    }
+}
+// four channels per thread: with Cn a multiple of 4 (hparams: bank x 128 channels) a float4 never straddles rows
+__global__ void tc_maxpool2_kernel(const float* x, int rows, int T, int Cn, float* out)
+{
+    const int c4n = Cn >> 2;
+    const long long total = (long long)rows * c4n;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / c4n);
+        const f32x4 a = x4[i];
+        const f32x4 b = (row % T) + 1 < T ? x4[i + c4n] : a;
+        f32x4 r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = a[q] > b[q] ? a[q] : b[q];
+        o4[i] = r;
     }
 }
 // modules.py:89 highway: H*T + x*(1-T)
@@ -2794,7 +2811,8 @@ static void run_cbhg(hipStream_t st, const twv_tacotron* h, const float* P, cons
             v.push_back(gemm_args(P, in, Cin, rows, T, Cin, k, c.W[k], &c.b[k], TACT_RELU, &c.inv[k], &c.shift[k], nullptr, 0, nullptr, 0, bankbuf, CB, (k - 1) * bch));
         launch_gemm_group(st, v);
     }
-    hipLaunchKernelGGL(tc_maxpool2_kernel, dim3(tgrid((long long)rows * CB)), dim3(256), 0, st, bankbuf, rows, T, CB, poolbuf);
+    if (CB % 4 == 0) hipLaunchKernelGGL(tc_maxpool2_kernel, dim3(tgrid((long long)rows * (CB / 4))), dim3(256), 0, st, bankbuf, rows, T, CB, poolbuf);
+    else hipLaunchKernelGGL(tc_maxpool2_scalar_kernel, dim3(tgrid((long long)rows * CB)), dim3(256), 0, st, bankbuf, rows, T, CB, poolbuf);
     launch_gemm(st, P, poolbuf, CB, rows, T, CB, pw, c.pW[0], &c.pb[0], TACT_RELU, &c.pinv[0], &c.pshift[0], nullptr, 0, nullptr, 0, ra, proj[0], 0);
     // second projection + residual: (proj + inputs) + before_highway
     launch_gemm(st, P, ra, proj[0], rows, T, proj[0], pw, c.pW[1], &c.pb[1], TACT_NONE, &c.pinv[1], &c.pshift[1], in, Cin, before_hw, before_hw ? rnn : 0, rb, proj[1], 0);
