@@ -2862,7 +2862,8 @@ static void run_cbhg(hipStream_t st, const twv_tacotron* h, const float* P, cons
         }
         launch_gemm_group(st, v);
     }
-    hipLaunchKernelGGL(tc_zero_kernel, dim3(tgrid((long long)rows * 2 * rnn)), dim3(256), 0, st, out, (long long)rows * 2 * rnn);
+    // (rows past an utterance's length are not written by the recurrent kernel: zeros; without lengths every row is)
+    if (lengths) hipLaunchKernelGGL(tc_zero_kernel, dim3(tgrid((long long)rows * 2 * rnn)), dim3(256), 0, st, out, (long long)rows * 2 * rnn);
     GruSeqArgs g;
     g.Gx = gx; g.Cx = cx; g.gx_dstride = (long long)rows * 2 * rnn; g.cx_dstride = (long long)rows * rnn;
     for (int dr = 0; dr < 2; ++dr) { g.Wgh[dr] = P + c.gWgh[dr].off; g.Wch[dr] = P + c.gWch[dr].off; g.bg[dr] = P + c.gbg[dr].off; g.bc[dr] = P + c.gbc[dr].off; }
@@ -2925,12 +2926,19 @@ extern "C" int twv_tacotron_infer(const twv_tacotron* h, const void* packed, con
                 hipLaunchKernelGGL(tc_gather_rows_kernel, dim3(tgrid((long long)N * h->dn[i])), dim3(256), 0, st, P + h->stab[i].off, speaker_ids, N, h->dn[i], sv[i]);
         } else {
             hipLaunchKernelGGL(tc_gather_rows_kernel, dim3(tgrid((long long)N * SE)), dim3(256), 0, st, P + h->semb.off, speaker_ids, N, SE, spk);
+            // (the decoder's initial states -- dense layers 2 .. -- are written where the decoder reads them: [N][AS + layers * DR])
             std::vector<GemmArgs> v;
-            for (int i = 0; i < h->ndense; ++i)
-                v.push_back(gemm_args(P, spk, SE, N, 1, SE, 1, h->dW[i], &h->db[i], TACT_SOFTSIGN, nullptr, nullptr, nullptr, 0, nullptr, 0, sv[i], h->dn[i], 0));
+            const int dstride = AS + d.dec_layer_num * DR;
+            for (int i = 0; i < h->ndense; ++i) {
+                if (i >= 2 && i < 3 + d.dec_layer_num)
+                    v.push_back(gemm_args(P, spk, SE, N, 1, SE, 1, h->dW[i], &h->db[i], TACT_SOFTSIGN, nullptr, nullptr, nullptr, 0, nullptr, 0, dinit, dstride,
+                                          i == 2 ? 0 : AS + (i - 3) * DR));
+                else
+                    v.push_back(gemm_args(P, spk, SE, N, 1, SE, 1, h->dW[i], &h->db[i], TACT_SOFTSIGN, nullptr, nullptr, nullptr, 0, nullptr, 0, sv[i], h->dn[i], 0));
+            }
             launch_gemm_group(st, v);
         }
-        for (int i = 0; i < 1 + d.dec_layer_num; ++i) {
+        for (int i = 0; SE == 1 && i < 1 + d.dec_layer_num; ++i) {
             const int wdt = i == 0 ? AS : DR;
             HIPCHK(hipMemcpy2DAsync(dinit + (i == 0 ? 0 : AS + (i - 1) * DR), (size_t)(AS + d.dec_layer_num * DR) * 4, sv[2 + i], (size_t)wdt * 4,
                                     (size_t)wdt * 4, N, hipMemcpyDeviceToDevice, st));
